@@ -1,0 +1,105 @@
+/*
+ * sings_hip.h -- C ABI of libsings_hip.so, the MI355X (gfx950) render path for SinGS.
+ *
+ * This library replaces the pybind11 module `diff_gaussian_rasterization._C` that the
+ * reference reaches through
+ *     sings/rec/renderer/gs_renderer_single.py:6-9,69-95   (GaussianRasterizer call)
+ *     sings/rec/renderer/gs_renderer_multiple.py:6-9,95-121
+ * (the package itself is the un-vendored dependency of install_all.sh:22), and adds fused
+ * entry points for the SMPL-LBS deformation block of
+ *     sings/rec/models/sings_hybrid.py:398-428 / sings/rec/utils/body_model/lbs.py:59-74.
+ *
+ * Contract
+ *  - plain C: raw DEVICE pointers (fp32 / int32, contiguous), sizes, a hipStream_t passed
+ *    as void*.  No torch types.  The caller owns every byte (inputs, outputs, workspaces).
+ *  - every entry point returns 0 on success, non-zero on error; sg_last_error() gives the
+ *    message (thread-local).
+ *  - kernels are enqueued on the stream given; nothing synchronises unless stated.
+ *  - re-entrant; no global mutable state besides the thread-local error string.
+ */
+#ifndef SINGS_HIP_H
+#define SINGS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_TILE 16            /* BLOCK_X = BLOCK_Y of the upstream rasterizer */
+#define SG_GRAD_REC_FLOATS 12 /* floats per (tile,Gaussian) gradient record     */
+
+/* Mirrors the 12-field GaussianRasterizationSettings NamedTuple the reference builds at
+ * gs_renderer_single.py:69-82 (bg/viewmatrix/projmatrix/campos are device pointers). */
+typedef struct SgRasterSettings {
+    int32_t image_height;
+    int32_t image_width;
+    float tanfovx;
+    float tanfovy;
+    float scale_modifier;
+    int32_t sh_degree;     /* active degree D (0..3) */
+    int32_t sh_coeffs;     /* M: rows allocated per Gaussian in `shs` ([P,M,3]) */
+    int32_t prefiltered;
+    int32_t debug;         /* 1: synchronise + check after every kernel */
+    int32_t reserved;
+    const float *bg;         /* [3]  */
+    const float *viewmatrix; /* [16] row-major torch tensor = column-major matrix */
+    const float *projmatrix; /* [16] */
+    const float *campos;     /* [3]  */
+} SgRasterSettings;
+
+/* Byte offsets inside the opaque workspaces (exposed for tests / debugging only). */
+typedef struct SgLayout {
+    /* geometry workspace (per Gaussian) */
+    size_t geom_recA, geom_recB, geom_recC, geom_depth, geom_flags, geom_bytes;
+    /* binning workspace */
+    size_t bin_header, bin_tile_count, bin_ranges, bin_cursor, bin_pair_keys, bin_point_list,
+        bin_point_keys, bin_bytes;
+    /* image workspace */
+    size_t img_final_T, img_n_contrib, img_bytes;
+    /* backward workspace */
+    size_t bwd_bytes;
+} SgLayout;
+
+const char *sg_version(void);
+const char *sg_last_error(void);
+
+/* Workspace sizing.  capacity_pairs = upper bound on R = sum of tiles touched. */
+int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out);
+
+/* Forward: replaces _C.rasterize_gaussians.  Exactly one of (shs | colors_precomp) and one
+ * of (scales+rotations | cov3D_precomp) is non-NULL, as GaussianRasterizer.forward enforces.
+ * out_color [3,H,W], radii [P] are fully written.  If num_rendered_host != NULL the call
+ * synchronises the stream and stores R there (R > capacity_pairs => results invalid, retry
+ * with a larger workspace; status stays 0).  point_keys_out: optional [capacity] u64
+ * receiving the upstream-format sorted keys (tile << 32 | depth bits). */
+int sg_rasterize_forward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                         const float *colors_precomp, const float *opacities, const float *scales,
+                         const float *rotations, const float *cov3D_precomp, void *geom_ws,
+                         void *binning_ws, size_t capacity_pairs, void *image_ws, float *out_color,
+                         int32_t *radii, int write_point_keys, int64_t *num_rendered_host,
+                         void *stream);
+
+/* Backward: replaces _C.rasterize_gaussians_backward.  All gradient outputs are fully
+ * written (no pre-zeroing needed).  Pointers for absent inputs may be NULL. */
+int sg_rasterize_backward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                          const float *colors_precomp, const float *opacities, const float *scales,
+                          const float *rotations, const float *cov3D_precomp, const int32_t *radii,
+                          const void *geom_ws, const void *binning_ws, size_t capacity_pairs,
+                          const void *image_ws, void *bwd_ws, const float *dL_dout_color,
+                          float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors,
+                          float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                          float *dL_dcov3D, void *stream);
+
+/* markVisible of the upstream module: present[i] = view-space z > 0.2 */
+int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                    uint8_t *present, void *stream);
+
+/* Reads R written by the last forward into this binning workspace (synchronises). */
+int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,71 @@
+"""ctypes binding of libsings_hip.so (the C ABI declared in include/sings_hip.h).
+
+The product path has no CPU fallback: if the HIP library is missing or cannot be loaded this
+module raises, loudly.  Build it with ``python -c "import __graft_entry__ as g; g.build()"`` or
+``make -C sings_amd/csrc``.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsings_hip.so")
+_lib = None
+
+
+class SgRasterSettings(C.Structure):
+    _fields_ = [
+        ("image_height", C.c_int32), ("image_width", C.c_int32),
+        ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
+        ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("reserved", C.c_int32),
+        ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+    ]
+
+
+class SgLayout(C.Structure):
+    _fields_ = [(n, C.c_size_t) for n in (
+        "geom_recA", "geom_recB", "geom_recC", "geom_depth", "geom_flags", "geom_bytes",
+        "bin_header", "bin_tile_count", "bin_ranges", "bin_cursor", "bin_pair_keys", "bin_point_list",
+        "bin_point_keys", "bin_bytes", "img_final_T", "img_n_contrib", "img_bytes", "bwd_bytes")]
+
+
+# every symbol include/sings_hip.h declares
+EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
+           "sg_mark_visible", "sg_read_num_rendered")
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"sings_amd: HIP library not built ({LIB_PATH} missing). There is no CPU fallback; "
+            "run `make -C sings_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    lib.sg_version.restype = C.c_char_p
+    lib.sg_last_error.restype = C.c_char_p
+    lib.sg_layout.argtypes = [i32, i32, i32, sz, C.POINTER(SgLayout)]
+    lib.sg_rasterize_forward.argtypes = ([C.POINTER(SgRasterSettings), i32] + [vp] * 7 +
+                                         [vp, vp, sz, vp, vp, vp, i32, C.POINTER(C.c_int64), vp])
+    lib.sg_rasterize_backward.argtypes = ([C.POINTER(SgRasterSettings), i32] + [vp] * 7 +
+                                          [vp, vp, vp, sz, vp, vp, vp] + [vp] * 8 + [vp])
+    lib.sg_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
+    lib.sg_read_num_rendered.argtypes = [vp, C.POINTER(C.c_int64), vp]
+    for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",
+              "sg_read_num_rendered"):
+        getattr(lib, f).restype = C.c_int
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError(f"sings_hip {what} failed: {load().sg_last_error().decode()}")
+
+
+def layout(P, W, H, cap):
+    L = SgLayout()
+    check(load().sg_layout(P, W, H, cap, C.byref(L)), "sg_layout")
+    return L

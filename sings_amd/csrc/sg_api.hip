@@ -1,0 +1,168 @@
+// extern "C" boundary of libsings_hip.so (see include/sings_hip.h for the contract and the
+// reference interfaces each entry point replaces).
+#include "sg_common.h"
+
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+static int sg_fail(const char *what, hipError_t e)
+{
+    snprintf(g_err, sizeof g_err, "%s: %s", what, e == hipSuccess ? "invalid argument" : hipGetErrorString(e));
+    return 1;
+}
+
+#define SG_CHECK_LAST(what, s, st)                                           \
+    do {                                                                     \
+        hipError_t e_ = hipGetLastError();                                   \
+        if (e_ != hipSuccess) return sg_fail(what, e_);                      \
+        if ((s)->debug) {                                                    \
+            e_ = hipStreamSynchronize(st);                                   \
+            if (e_ != hipSuccess) return sg_fail(what, e_);                  \
+        }                                                                    \
+    } while (0)
+
+extern "C" const char *sg_version(void) { return "sings_hip 0.1 (gfx950)"; }
+extern "C" const char *sg_last_error(void) { return g_err; }
+
+extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
+{
+    if (!L || P < 0 || width <= 0 || height <= 0) return sg_fail("sg_layout", hipSuccess);
+    const size_t gx = (width + SG_TILE - 1) / SG_TILE, gy = (height + SG_TILE - 1) / SG_TILE, T = gx * gy;
+    const size_t Pn = P > 0 ? P : 1, hw = (size_t)width * height;
+    size_t o = 0;
+    L->geom_recA = o; o = sg_align(o + Pn * 16);
+    L->geom_recB = o; o = sg_align(o + Pn * 16);
+    L->geom_recC = o; o = sg_align(o + Pn * 16);
+    L->geom_depth = o; o = sg_align(o + Pn * 4);
+    L->geom_flags = o; o = sg_align(o + Pn * 4);
+    L->geom_bytes = o;
+    o = 0;
+    L->bin_header = o; o = sg_align(o + 256);
+    L->bin_tile_count = o; o = sg_align(o + T * 4);
+    L->bin_ranges = o; o = sg_align(o + T * 8);
+    L->bin_cursor = o; o = sg_align(o + T * 4);
+    L->bin_pair_keys = o; o = sg_align(o + (cap + 1) * 8);
+    L->bin_point_list = o; o = sg_align(o + (cap + 1) * 4);
+    L->bin_point_keys = o; o = sg_align(o + (cap + 1) * 8);
+    L->bin_bytes = o;
+    o = 0;
+    L->img_final_T = o; o = sg_align(o + hw * 4);
+    L->img_n_contrib = o; o = sg_align(o + hw * 4);
+    L->img_bytes = o;
+    L->bwd_bytes = sg_align((cap + 1) * SG_GRAD_REC_FLOATS * 4);
+    return 0;
+}
+
+static int sg_make_cam(const SgRasterSettings *s, SgCam *c)
+{
+    if (!s || s->image_width <= 0 || s->image_height <= 0 || !s->viewmatrix || !s->projmatrix || !s->campos || !s->bg)
+        return 1;
+    if (s->sh_degree < 0 || s->sh_degree > 3) return 1;
+    c->W = s->image_width; c->H = s->image_height;
+    c->gx = (c->W + SG_TILE - 1) / SG_TILE; c->gy = (c->H + SG_TILE - 1) / SG_TILE;
+    c->tanfovx = s->tanfovx; c->tanfovy = s->tanfovy;
+    c->fx = (float)c->W / (2.0f * s->tanfovx); c->fy = (float)c->H / (2.0f * s->tanfovy);
+    c->mod = s->scale_modifier; c->D = s->sh_degree; c->M = s->sh_coeffs;
+    c->view = s->viewmatrix; c->proj = s->projmatrix; c->campos = s->campos; c->bg = s->bg;
+    return 0;
+}
+
+extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                                    const float *colors_precomp, const float *opacities, const float *scales,
+                                    const float *rotations, const float *cov3D_precomp, void *geom_ws,
+                                    void *binning_ws, size_t cap, void *image_ws, float *out_color,
+                                    int32_t *radii, int write_point_keys, int64_t *num_rendered_host, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_forward: bad settings", hipSuccess);
+    if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!means3D || !opacities || !radii)))
+        return sg_fail("sg_rasterize_forward: null pointer", hipSuccess);
+    if (P > 0 && ((shs != nullptr) == (colors_precomp != nullptr)))
+        return sg_fail("sg_rasterize_forward: provide exactly one of shs / colors_precomp", hipSuccess);
+    if (P > 0 && (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr)))
+        return sg_fail("sg_rasterize_forward: provide exactly one of (scales,rotations) / cov3D_precomp", hipSuccess);
+    if (shs && (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)))
+        return sg_fail("sg_rasterize_forward: sh_coeffs smaller than (sh_degree+1)^2", hipSuccess);
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgGeom g = sg_geom_view(geom_ws, L);
+    SgBin b = sg_bin_view(binning_ws, L);
+    SgImg im = sg_img_view(image_ws, L);
+    // header + tile counters zeroed every call (stream-ordered)
+    hipError_t e = hipMemsetAsync(b.header, 0, L.bin_ranges - L.bin_header, st);
+    if (e != hipSuccess) return sg_fail("memset", e);
+    sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, radii, st);
+    SG_CHECK_LAST("preprocess_fwd", s, st);
+    sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
+    SG_CHECK_LAST("binning", s, st);
+    sg_launch_render_fwd(c, g, b, cap, im, out_color, st);
+    SG_CHECK_LAST("render_fwd", s, st);
+    if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
+    return 0;
+}
+
+extern "C" int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream)
+{
+    uint32_t r = 0;
+    hipError_t e = hipMemcpyAsync(&r, binning_ws, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return sg_fail("sg_read_num_rendered", e);
+    *num_rendered_host = (int64_t)r;
+    return 0;
+}
+
+extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                                     const float *colors_precomp, const float *opacities, const float *scales,
+                                     const float *rotations, const float *cov3D_precomp, const int32_t *radii,
+                                     const void *geom_ws, const void *binning_ws, size_t cap, const void *image_ws,
+                                     void *bwd_ws, const float *dL_dout_color, float *dL_dmeans3D,
+                                     float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors, float *dL_dopacity,
+                                     float *dL_dscales, float *dL_drotations, float *dL_dcov3D, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_backward: bad settings", hipSuccess);
+    if (P <= 0) return 0;
+    if (!means3D || !radii || !geom_ws || !binning_ws || !image_ws || !bwd_ws || !dL_dout_color || !dL_dmeans3D ||
+        !dL_dmeans2D || !dL_dopacity)
+        return sg_fail("sg_rasterize_backward: null pointer", hipSuccess);
+    if (shs && !dL_dsh) return sg_fail("sg_rasterize_backward: dL_dsh missing", hipSuccess);
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgGeom g = sg_geom_view((void *)geom_ws, L);
+    SgBin b = sg_bin_view((void *)binning_ws, L);
+    SgImg im = sg_img_view((void *)image_ws, L);
+    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
+    SG_CHECK_LAST("render_bwd", s, st);
+    sg_launch_preprocess_bwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
+                             (const float *)bwd_ws, cap, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
+                             dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
+                             cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, st);
+    SG_CHECK_LAST("preprocess_bwd", s, st);
+    return 0;
+}
+
+__global__ void sg_mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ view,
+                                       uint8_t *__restrict__ present)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P) return;
+    float x = means3D[3 * i], y = means3D[3 * i + 1], z = means3D[3 * i + 2];
+    float vz = view[2] * x + view[6] * y + view[10] * z + view[14];
+    present[i] = vz > 0.2f ? 1 : 0;
+}
+
+extern "C" int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
+                               uint8_t *present, void *stream)
+{
+    (void)projmatrix;
+    if (P <= 0) return 0;
+    if (!means3D || !viewmatrix || !present) return sg_fail("sg_mark_visible: null pointer", hipSuccess);
+    hipLaunchKernelGGL(sg_mark_visible_kernel, dim3((P + 255) / 256), dim3(256), 0, (hipStream_t)stream, P, means3D,
+                       viewmatrix, present);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_mark_visible", e);
+}

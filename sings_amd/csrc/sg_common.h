@@ -1,0 +1,88 @@
+// Shared device/host helpers for libsings_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/sings_hip.h"
+
+#define SG_WAVE 64
+
+struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
+    float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
+    float4 *recB;          // (conic.z, opacity, r, g)
+    float4 *recC;          // (b, bits(goff), bits(minx | miny<<16), bits(w | h<<16))
+    float *depth;          // view-space z
+    uint32_t *flags;       // bits 0..2: SH colour channel clamped at 0
+};
+
+struct SgBin {
+    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles
+    uint32_t *tile_count;  // [T]
+    uint2 *ranges;         // [T] (start,end) into point_list
+    uint32_t *cursor;      // [T]
+    uint64_t *pair_keys;   // [cap] (depth_bits << 32 | gid), grouped by tile, sorted in place
+    uint32_t *point_list;  // [cap] sorted Gaussian ids
+    uint64_t *point_keys;  // [cap] optional upstream-format keys
+};
+
+struct SgImg {
+    float *final_T;        // [H*W]
+    uint32_t *n_contrib;   // [H*W]
+};
+
+static inline size_t sg_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline SgGeom sg_geom_view(void *ws, const SgLayout &L)
+{
+    char *b = (char *)ws;
+    SgGeom g;
+    g.recA = (float4 *)(b + L.geom_recA); g.recB = (float4 *)(b + L.geom_recB);
+    g.recC = (float4 *)(b + L.geom_recC); g.depth = (float *)(b + L.geom_depth);
+    g.flags = (uint32_t *)(b + L.geom_flags);
+    return g;
+}
+static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
+{
+    char *b = (char *)ws;
+    SgBin g;
+    g.header = (uint32_t *)(b + L.bin_header); g.tile_count = (uint32_t *)(b + L.bin_tile_count);
+    g.ranges = (uint2 *)(b + L.bin_ranges); g.cursor = (uint32_t *)(b + L.bin_cursor);
+    g.pair_keys = (uint64_t *)(b + L.bin_pair_keys); g.point_list = (uint32_t *)(b + L.bin_point_list);
+    g.point_keys = (uint64_t *)(b + L.bin_point_keys);
+    return g;
+}
+static inline SgImg sg_img_view(void *ws, const SgLayout &L)
+{
+    char *b = (char *)ws;
+    SgImg g;
+    g.final_T = (float *)(b + L.img_final_T); g.n_contrib = (uint32_t *)(b + L.img_n_contrib);
+    return g;
+}
+
+// Kernel parameter block for per-Gaussian kernels
+struct SgCam {
+    int W, H, gx, gy;
+    float tanfovx, tanfovy, fx, fy, mod;
+    int D, M;
+    const float *view, *proj, *campos, *bg;
+};
+
+// launchers (defined in the .hip files)
+void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
+                              const float *colors_precomp, const float *opacities, const float *scales,
+                              const float *rotations, const float *cov3D_precomp, SgGeom g, SgBin b,
+                              int32_t *radii, hipStream_t st);
+void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
+                       int write_keys, hipStream_t st);
+void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
+                          hipStream_t st);
+void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
+                          const float *dL_dpix, float *grec, hipStream_t st);
+void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
+                              const float *colors_precomp, const float *opacities, const float *scales,
+                              const float *rotations, const float *cov3D_precomp,
+                              const int32_t *radii, SgGeom g, const float *grec, size_t cap,
+                              float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
+                              float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
+                              float *dL_drots, float *dL_dcov3D, hipStream_t st);

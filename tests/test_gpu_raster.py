@@ -1,0 +1,226 @@
+"""GPU parity: HIP rasterizer (through the C ABI) vs the CPU oracle on identical seeded inputs.
+
+Bars (BASELINE.json north_star): bit-exact tile/key indices (radii, tile rectangles, depth key
+bits, sorted point list, tile ranges, upstream-format keys); per-pixel RGB within 1e-5 of the
+oracle; gradients within a relative tolerance (fp32 summation order differs by design).
+
+The oracle evaluates exp() with libm, the kernel with v_exp_f32 (1 ulp).  A pixel whose
+alpha / transmittance lands within 2e-5 (relative) of one of the hard thresholds of the algorithm
+(alpha < 1/255, T < 1e-4, power > 0) can therefore legitimately flip; the oracle reports that
+margin per pixel and such pixels (a few per 10^5 pixels) are compared with a loose bound
+and counted.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from sings_amd.scene import synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+RGB_TOL = 1e-5
+BORDER = 2e-5          # relative threshold margin below which a pixel is "borderline" (exp noise ~2e-7)
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _settings(s, dev, debug=False, scale_modifier=1.0):
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return GaussianRasterizationSettings(
+        image_height=s["H"], image_width=s["W"], tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+        scale_modifier=scale_modifier, viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]),
+        sh_degree=s["sh_degree"], campos=t(s["campos"]), prefiltered=False, debug=debug)
+
+
+def _oracle(s, scale_modifier=1.0, colors=None):
+    return ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"],
+                      s["tanfovx"], s["tanfovy"], s["bg"], scales=s["scales"], rotations=s["rotations"],
+                      shs=None if colors is not None else s["shs"], sh_degree=s["sh_degree"],
+                      colors_precomp=colors, scale_modifier=scale_modifier)
+
+
+def _check_forward_state(s, st, o):
+    vis = o["radii"] > 0
+    np.testing.assert_array_equal(st["radii"].cpu().numpy(), o["radii"])
+    # depth key bits, pixel centres, conics, colours: same fp32 operation order -> bit exact
+    for name, a, b in (("depths", st["depths"], o["depths"]), ("xy", st["xy"], o["xy"]),
+                       ("conic_opacity", st["conic_opacity"], o["conic_opacity"]), ("rgb", st["rgb"], o["rgb"])):
+        a = a.cpu().numpy()[vis]; b = b[vis]
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), \
+            f"{name}: {np.sum(a.view(np.uint32) != b.view(np.uint32))} of {a.size} words differ, max abs {np.abs(a-b).max()}"
+    rmin = st["rect_min"].cpu().numpy(); rwh = st["rect_wh"].cpu().numpy()
+    rect = np.stack([rmin & 0xffff, rmin >> 16, (rmin & 0xffff) + (rwh & 0xffff), (rmin >> 16) + (rwh >> 16)], 1)
+    np.testing.assert_array_equal(rect[vis], o["rect"][vis])
+    clamp = st["clamp_bits"].cpu().numpy()
+    exp_bits = o["clamped"][:, 0] | (o["clamped"][:, 1] << 1) | (o["clamped"][:, 2] << 2)
+    np.testing.assert_array_equal(clamp[vis], exp_bits[vis])
+    assert st["R"] == o["R"]
+    np.testing.assert_array_equal(st["ranges"].cpu().numpy().astype(np.uint32), o["ranges"])
+    np.testing.assert_array_equal(st["point_list"].cpu().numpy().astype(np.uint32), o["point_list"])
+    np.testing.assert_array_equal(st["point_keys"].cpu().numpy().astype(np.uint64), o["keys"])
+
+
+def _check_image(color, final_T, n_contrib, o):
+    diff = np.abs(color - o["color"]).max(0)
+    border = o["margin"] < BORDER
+    nb = int(border.sum())
+    assert nb <= max(16, 1e-3 * border.size), f"{nb} borderline pixels"
+    strict = ~border
+    assert diff[strict].max() <= RGB_TOL, f"RGB L_inf {diff[strict].max()} at {np.argwhere(diff == diff[strict].max())[:3]}"
+    assert diff.max() <= 5e-2
+    assert np.abs(final_T - o["final_T"])[strict].max() <= 1e-5
+    assert np.array_equal(n_contrib[strict].astype(np.uint32), o["n_contrib"][strict])
+    return nb
+
+
+def _grad_close(name, a, b, rtol=2e-4):
+    a = a.astype(np.float64); b = b.astype(np.float64)
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b)
+    bound = rtol * np.abs(b) + 2e-6 * scale
+    bad = err > bound
+    assert not bad.any(), f"{name}: {bad.sum()} of {bad.size} off; worst abs {err.max():.3e} (scale {scale:.3e})"
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(2000, 128, 128, 3, 1), (3000, 200, 136, 1, 11), (500, 64, 48, 0, 5)])
+def test_forward_state_and_image(N, W, H, deg, seed):
+    from sings_amd.inspect_ws import forward_with_state
+    dev = _dev()
+    s = synthetic_scene(N, W, H, deg, seed)
+    o = _oracle(s)
+    rs = _settings(s, dev, debug=True)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]),
+                            rotations=t(s["rotations"]))
+    _check_forward_state(s, st, o)
+    _check_image(st["color"].cpu().numpy(), st["final_T"].cpu().numpy(), st["n_contrib"].cpu().numpy(), o)
+
+
+def test_forward_backward_autograd_api():
+    """GaussianRasterizer (the reference-facing API) forward + backward vs oracle, scale_modifier != 1."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(4000, 160, 128, 3, 21)
+    mod = 1.0
+    o = _oracle(s, scale_modifier=mod)
+    g = ro.backward(o, s["dL_dimage"])
+    rs = _settings(s, dev, scale_modifier=mod)
+    t = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    means3D, opac, shs, scales, rots = t(s["means3D"]), t(s["opacities"]), t(s["shs"]), t(s["scales"]), t(s["rotations"])
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    color, radii = GaussianRasterizer(rs)(means3D=means3D, means2D=means2D, opacities=opac, shs=shs,
+                                          scales=scales, rotations=rots)
+    assert radii.dtype == torch.int32 and not radii.requires_grad
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    border = o["margin"] < BORDER
+    diff = np.abs(color.detach().cpu().numpy() - o["color"]).max(0)
+    assert diff[~border].max() <= RGB_TOL
+    dL = torch.from_numpy(s["dL_dimage"]).to(dev)
+    # pixels whose threshold decisions are borderline are excluded from the loss on both sides
+    if border.any():
+        dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+        g = ro.backward(o, dLn); dL = torch.from_numpy(dLn).to(dev)
+    color.backward(dL)
+    _grad_close("means3D", means3D.grad.cpu().numpy(), g["dL_dmeans3D"])
+    _grad_close("means2D", means2D.grad.cpu().numpy(), g["dL_dmean2D"])
+    _grad_close("opacity", opac.grad.cpu().numpy(), g["dL_dopacity"])
+    _grad_close("sh", shs.grad.cpu().numpy(), g["dL_dsh"])
+    _grad_close("scales", scales.grad.cpu().numpy(), g["dL_dscales"])
+    _grad_close("rotations", rots.grad.cpu().numpy(), g["dL_drots"])
+
+
+def test_backward_deterministic():
+    """No float atomics: two backward runs give bitwise identical gradients."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(3000, 128, 96, 2, 4)
+    rs = _settings(s, dev)
+    outs = []
+    for _ in range(2):
+        t = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+        m, op, sh, sc, ro_ = t(s["means3D"]), t(s["opacities"]), t(s["shs"]), t(s["scales"]), t(s["rotations"])
+        m2 = torch.zeros_like(m, requires_grad=True)
+        color, _ = GaussianRasterizer(rs)(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=ro_)
+        color.backward(torch.from_numpy(s["dL_dimage"]).to(dev))
+        outs.append([x.grad.clone() for x in (m, m2, op, sh, sc, ro_)] + [color.detach().clone()])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_colors_precomp_and_cov3d_precomp():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(1500, 96, 96, 0, 8)
+    rs_np = np.random.RandomState(0)
+    colors = rs_np.uniform(0, 1, (1500, 3)).astype(np.float32)
+    o = _oracle(s, colors=colors)
+    g = ro.backward(o, s["dL_dimage"])
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    m, op, col, sc, rt = t(s["means3D"]), t(s["opacities"]), t(colors), t(s["scales"]), t(s["rotations"])
+    m2 = torch.zeros_like(m, requires_grad=True)
+    color, radii = GaussianRasterizer(rs)(means3D=m, means2D=m2, opacities=op, colors_precomp=col, scales=sc, rotations=rt)
+    border = o["margin"] < BORDER
+    assert np.abs(color.detach().cpu().numpy() - o["color"]).max(0)[~border].max() <= RGB_TOL
+    dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+    g = ro.backward(o, dLn)
+    color.backward(torch.from_numpy(dLn).to(dev))
+    _grad_close("colors", col.grad.cpu().numpy(), g["dL_dcolor"])
+    _grad_close("means3D", m.grad.cpu().numpy(), g["dL_dmeans3D"])
+    # cov3D_precomp path: feed the oracle's covariances
+    cov = torch.from_numpy(o["cov3D"]).to(dev).requires_grad_(True)
+    o2 = ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"],
+                    s["tanfovx"], s["tanfovy"], s["bg"], colors_precomp=colors, cov3D_precomp=o["cov3D"])
+    g2 = ro.backward(o2, dLn)
+    m_, op_, col_ = t(s["means3D"]), t(s["opacities"]), t(colors)
+    color2, radii2 = GaussianRasterizer(rs)(means3D=m_, means2D=torch.zeros_like(m_, requires_grad=True), opacities=op_,
+                                            colors_precomp=col_, cov3D_precomp=cov)
+    np.testing.assert_array_equal(radii2.cpu().numpy(), o2["radii"])
+    color2.backward(torch.from_numpy(dLn).to(dev))
+    _grad_close("cov3D", cov.grad.cpu().numpy(), g2["dL_dcov3D"])
+
+
+def test_api_validation_and_edge_cases():
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(64, 40, 24, 1, 2)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    r = GaussianRasterizer(rs)
+    m = t(s["means3D"])
+    with pytest.raises(Exception):
+        r(means3D=m, means2D=m, opacities=t(s["opacities"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+    with pytest.raises(Exception):
+        r(means3D=m, means2D=m, opacities=t(s["opacities"]), shs=t(s["shs"]))
+    # all Gaussians behind the camera -> background image, radii 0
+    behind = s["means3D"].copy(); behind[:, 2] = -1
+    color, radii = r(means3D=t(behind), means2D=m, opacities=t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]),
+                     rotations=t(s["rotations"]))
+    assert int(radii.abs().sum()) == 0
+    assert torch.allclose(color, t(s["bg"])[:, None, None].expand_as(color))
+    vis = r.markVisible(t(s["means3D"]))
+    assert vis.dtype == torch.bool and vis.shape == (64,)
+    assert torch.equal(vis.cpu(), torch.from_numpy(s["means3D"][:, 2] > 0.2))
+    # CPU tensors are refused loudly (no fallback)
+    with pytest.raises(RuntimeError):
+        r(means3D=torch.from_numpy(s["means3D"]), means2D=m, opacities=t(s["opacities"]), shs=t(s["shs"]),
+          scales=t(s["scales"]), rotations=t(s["rotations"]))
+
+
+def test_config2_50k_512_forward():
+    """BASELINE config 2: 50k Gaussians, 512x512, SH deg 0, forward; bit-exact binning."""
+    from sings_amd.inspect_ws import forward_with_state
+    dev = _dev()
+    s = synthetic_scene(50000, 512, 512, 0, 2)
+    o = _oracle(s)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]),
+                            rotations=t(s["rotations"]))
+    _check_forward_state(s, st, o)
+    _check_image(st["color"].cpu().numpy(), st["final_T"].cpu().numpy(), st["n_contrib"].cpu().numpy(), o)
