@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: rendered views/s, forward+backward, 200k Gaussians @ 1080p (BASELINE.json
+configs[2]; SURVEY.md 8(d) scene S(200000,1920,1080,3,seed=3)), 1..8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one view per rank: rasterizer forward (preprocess ->
+tile binning -> alpha composite) + backward (composite bwd -> per-Gaussian bwd) through the C ABI,
+inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside the timed region.
+With N > 1 the ranks render DIFFERENT cameras of the same Gaussians (frame-parallel) and sum the
+canonical-Gaussian gradients with one RCCL all-reduce per step ("scaling": "weak").
+
+Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
+  roofline     - dominant kernel: algorithmic bytes / its mean launch duration,
+                 measured live with HIP events on the launch stream, vs the 8 TB/s HBM peak
+  cpu_baseline - the CPU oracle (scalar C port, 1 core) timed on one full view of the same workload
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0
+
+
+def algorithmic_bytes(N, H, W, R, deg):
+    """SURVEY.md 8(d) per-unit figures, split per kernel."""
+    inb = 44 + 12 * (deg + 1) ** 2
+    rec, gout, hw = 75, 248, H * W
+    per = {
+        "sg_preprocess_fwd_kernel": N * (inb + 4 + rec),
+        "binning": R * 12,
+        "sg_render_fwd_kernel": N * rec + hw * (12 + 8) + R * 4,
+        "sg_render_bwd_kernel": hw * (12 + 8) + R * 4,
+        "sg_preprocess_bwd_kernel": N * (inb + gout),
+    }
+    total = N * (2 * inb + gout + 4 + 2 * rec) + hw * 40 + R * 20
+    return per, total
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--gaussians", type=int, default=200000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from sings_amd import _lib
+    from sings_amd.engine import RasterEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+
+    N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
+    s = synthetic_scene(N, W, H, deg, 3)
+    # frame-parallel: rank r looks at the same Gaussians from a camera shifted along x
+    view = s["viewmatrix"].copy()
+    view[3, 0] = 0.05 * rank
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    proj = (view @ P_T).astype(np.float32)
+    campos = np.linalg.inv(view)[3, :3].astype(np.float32)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]), scale_modifier=1.0,
+        viewmatrix=t(view), projmatrix=t(proj), sh_degree=deg, campos=t(campos), prefiltered=False, debug=False)
+    means3D, shs, opac, scales, rots = t(s["means3D"]), t(s["shs"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"])
+    dL = t(s["dL_dimage"])
+
+    # sizing pass (untimed): find R, then fix the pair capacity for the whole run
+    eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=8 * N + 65536)
+    eng.set_camera(rs)
+    R = eng.forward(means3D, shs, opac, scales, rots, sync_num_rendered=True)
+    if R > eng.cap:
+        raise SystemExit(f"pair capacity too small: R={R}")
+    del eng
+    torch.cuda.empty_cache()
+    eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096)
+    eng.set_camera(rs)
+
+    def step():
+        eng.forward(means3D, shs, opac, scales, rots)
+        eng.backward(means3D, shs, opac, scales, rots, dL)
+        if dist is not None:
+            dist.all_reduce(eng.grad_flat)
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert eng.num_rendered() <= eng.cap
+
+    # per-kernel durations: HIP events around every launch, on the launch stream (separate pass)
+    lib = _lib.load()
+    lib.sg_profile_enable(1)
+    for _ in range(a.steps):
+        eng.forward(means3D, shs, opac, scales, rots)
+        eng.backward(means3D, shs, opac, scales, rots, dL)
+    ms = (C.c_double * _lib.NUM_KERNELS)()
+    cnt = (C.c_int64 * _lib.NUM_KERNELS)()
+    _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
+    lib.sg_profile_enable(0)
+    kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    per, total_bytes = algorithmic_bytes(N, H, W, R, deg)
+    dom = max(("sg_preprocess_fwd_kernel", "sg_render_fwd_kernel", "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel"),
+              key=lambda k: kern[k])
+    achieved = per[dom] / (kern[dom] * 1e-3) / 1e9
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived bytes per launch, if collected
+    if os.path.exists(tj):
+        try:
+            traffic = json.load(open(tj)).get(dom)
+        except Exception:
+            traffic = None
+    ms_per_step = el / a.steps * 1e3
+    views_s = world * a.steps / el
+    out = {
+        "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p",
+        "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, fwd+bwd, "
+                               f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
+                   "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R,
+                   "parallelism": f"dp{world}"},
+        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]},
+        "roofline_whole_pass": {"algorithmic_bytes_per_view": total_bytes,
+                                "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
+                                "frac_of_8TBs": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "frac_of_measured_copy_6.29TBs": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS},
+        "kernel_ms": kern,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        from oracle import raster_oracle as ro
+        t0 = time.perf_counter()
+        o = ro.forward(s["means3D"], s["opacities"], view, proj, campos, W, H, s["tanfovx"], s["tanfovy"], s["bg"],
+                       scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=deg, want_margin=False)
+        ro.backward(o, s["dL_dimage"])
+        tc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": 1.0 / tc, "unit": "views/s", "cores": 1, "kind": "port",
+                               "sample": f"1 full view fwd+bwd of the same scene with the scalar C oracle ({tc:.1f} s)",
+                               "host_cpus": os.cpu_count()}
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,6 +99,19 @@ int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const 
 /* Reads R written by the last forward into this binning workspace (synchronises). */
 int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream);
 
+/* ---- optional per-kernel timing (bench / profiling only; process-global, not thread-safe).
+ * When enabled, every kernel launch of forward/backward is bracketed by hipEvents on the
+ * caller's stream.  sg_profile_collect synchronises, adds the elapsed milliseconds and launch
+ * counts per kernel id into the caller's arrays (length >= SG_NUM_KERNELS) and drops the events. */
+#define SG_NUM_KERNELS 8
+enum SgKernelId {
+    SG_K_PREPROCESS_FWD = 0, SG_K_TILE_COUNT = 1, SG_K_TILE_SCAN = 2, SG_K_TILE_SCATTER = 3,
+    SG_K_TILE_SORT = 4, SG_K_RENDER_FWD = 5, SG_K_RENDER_BWD = 6, SG_K_PREPROCESS_BWD = 7
+};
+int sg_profile_enable(int on);
+int sg_profile_collect(double *total_ms, int64_t *launches, int n);
+const char *sg_kernel_name(int id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,7 +31,9 @@ class SgLayout(C.Structure):
 
 # every symbol include/sings_hip.h declares
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
-           "sg_mark_visible", "sg_read_num_rendered")
+           "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
+           "sg_kernel_name")
+NUM_KERNELS = 8
 
 
 def load():
@@ -42,6 +44,9 @@ def load():
         raise RuntimeError(
             f"sings_amd: HIP library not built ({LIB_PATH} missing). There is no CPU fallback; "
             "run `make -C sings_amd/csrc` (needs hipcc, --offload-arch=gfx950).")
+    # The process must hold ONE HIP runtime: import torch first so that libamdhip64.so.7 resolves to the
+    # copy PyTorch-ROCm already loaded (loading ours first makes the two runtimes disagree about devices).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.sg_version.restype = C.c_char_p
@@ -53,6 +58,10 @@ def load():
                                           [vp, vp, vp, sz, vp, vp, vp] + [vp] * 8 + [vp])
     lib.sg_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.sg_read_num_rendered.argtypes = [vp, C.POINTER(C.c_int64), vp]
+    lib.sg_profile_enable.argtypes = [i32]
+    lib.sg_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    lib.sg_kernel_name.argtypes = [i32]
+    lib.sg_kernel_name.restype = C.c_char_p
     for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",
               "sg_read_num_rendered"):
         getattr(lib, f).restype = C.c_int

@@ -4,6 +4,8 @@
 
 #include <stdio.h>
 #include <string.h>
+#include <utility>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -165,4 +167,50 @@ extern "C" int sg_mark_visible(int P, const float *means3D, const float *viewmat
                        viewmatrix, present);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_mark_visible", e);
+}
+
+// ---- per-kernel event timing ------------------------------------------------------------
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[SG_NUM_KERNELS];
+static hipEvent_t g_prof_open[SG_NUM_KERNELS];
+
+void sg_prof_begin(int id, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, st);
+    g_prof_open[id] = e;
+}
+void sg_prof_end(int id, hipStream_t st)
+{
+    if (!g_prof_on) return;
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    (void)hipEventRecord(e, st);
+    g_prof_ev[id].push_back(std::make_pair(g_prof_open[id], e));
+}
+extern "C" int sg_profile_enable(int on) { g_prof_on = on != 0; return 0; }
+extern "C" int sg_profile_collect(double *total_ms, int64_t *launches, int n)
+{
+    if (!total_ms || !launches || n < SG_NUM_KERNELS) return sg_fail("sg_profile_collect", hipSuccess);
+    hipError_t e = hipDeviceSynchronize();
+    if (e != hipSuccess) return sg_fail("sg_profile_collect", e);
+    for (int k = 0; k < SG_NUM_KERNELS; k++) {
+        for (auto &p : g_prof_ev[k]) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, p.first, p.second);
+            total_ms[k] += ms; launches[k] += 1;
+            (void)hipEventDestroy(p.first); (void)hipEventDestroy(p.second);
+        }
+        g_prof_ev[k].clear();
+    }
+    return 0;
+}
+extern "C" const char *sg_kernel_name(int id)
+{
+    static const char *names[SG_NUM_KERNELS] = { "sg_preprocess_fwd_kernel", "sg_tile_count_kernel", "sg_tile_scan_kernel",
+                                                 "sg_tile_scatter_kernel", "sg_tile_sort_kernel", "sg_render_fwd_kernel",
+                                                 "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel" };
+    return id >= 0 && id < SG_NUM_KERNELS ? names[id] : "?";
 }

@@ -162,12 +162,20 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
 {
     const int T = c.gx * c.gy;
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
+    sg_prof_begin(SG_K_TILE_COUNT, st);
     if (P > 0)
         hipLaunchKernelGGL(sg_tile_count_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, g.recC, c.gx, b.tile_count);
+    sg_prof_end(SG_K_TILE_COUNT, st);
+    sg_prof_begin(SG_K_TILE_SCAN, st);
     hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.ranges, b.cursor, b.header, cap32);
+    sg_prof_end(SG_K_TILE_SCAN, st);
+    sg_prof_begin(SG_K_TILE_SCATTER, st);
     if (P > 0)
         hipLaunchKernelGGL(sg_tile_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, g.recC, g.depth,
                            c.gx, b.cursor, b.pair_keys, cap32);
+    sg_prof_end(SG_K_TILE_SCATTER, st);
+    sg_prof_begin(SG_K_TILE_SORT, st);
     hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T), dim3(SG_SORT_THREADS), 0, st, b.ranges, b.pair_keys,
                        b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr);
+    sg_prof_end(SG_K_TILE_SORT, st);
 }

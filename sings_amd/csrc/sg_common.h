@@ -86,3 +86,7 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, hipStream_t st);
+
+// per-kernel event timing (sg_api.hip)
+void sg_prof_begin(int id, hipStream_t st);
+void sg_prof_end(int id, hipStream_t st);

@@ -126,7 +126,9 @@ void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const
 #define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b.header, radii)
     int D = colors_precomp ? 0 : c.D;
+    sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (D) { case 0: SG_PP(0); break; case 1: SG_PP(1); break; case 2: SG_PP(2); break; default: SG_PP(3); break; }
+    sg_prof_end(SG_K_PREPROCESS_FWD, st);
 #undef SG_PP
 }
 
@@ -325,6 +327,8 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
                                      (const float4 *)grec, cap, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     int D = shs ? c.D : 0;
+    sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (D) { case 0: SG_PB(0); break; case 1: SG_PB(1); break; case 2: SG_PB(2); break; default: SG_PB(3); break; }
+    sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_PB
 }

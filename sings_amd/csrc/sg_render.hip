@@ -90,8 +90,10 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     (void)cap;
     const int T = c.gx * c.gy;
     const int grid = ((T + 7) / 8) * 8;
+    sg_prof_begin(SG_K_RENDER_FWD, st);
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib);
+    sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -243,7 +245,9 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const int T = c.gx * c.gy;
     const int grid = ((T + 7) / 8) * 8;
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
+    sg_prof_begin(SG_K_RENDER_BWD, st);
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                        (float4 *)grec, cap32);
+    sg_prof_end(SG_K_RENDER_BWD, st);
 }

@@ -1,0 +1,75 @@
+"""Pre-allocated forward/backward driver over the C ABI (no autograd, no per-call allocation).
+
+This is what a training loop that owns its buffers (and bench.py) calls: workspaces and the
+flat gradient buffer are sized once for 288 GB-class HBM and reused every step, the capacity
+for (tile, Gaussian) pairs is a fixed upper bound, and nothing synchronises inside a step.  The
+gradient tensors are views into ONE flat fp32 buffer so that frame-parallel training can
+all-reduce them with a single RCCL call (see sings_amd/dp.py).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rasterizer import _settings_struct, _ptr
+
+
+class RasterEngine:
+    # flat gradient layout (floats per Gaussian): means3D 3, scales 3, rotations 4, opacity 1, sh 3*M
+    def __init__(self, P, W, H, sh_coeffs, device, capacity_pairs):
+        self.lib = _lib.load()
+        self.P, self.W, self.H, self.M = int(P), int(W), int(H), int(sh_coeffs)
+        self.dev = torch.device(device)
+        self.cap = int(capacity_pairs)
+        L = _lib.layout(self.P, self.W, self.H, self.cap)
+        self.L = L
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        self.geom = torch.empty(L.geom_bytes, **u8)
+        self.binning = torch.empty(L.bin_bytes, **u8)
+        self.img = torch.empty(L.img_bytes, **u8)
+        self.bwd_ws = torch.empty(L.bwd_bytes, **u8)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.color = torch.empty((3, self.H, self.W), **f32)
+        self.radii = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
+        per = 3 + 3 + 4 + 1 + 3 * self.M
+        self.grad_flat = torch.empty(self.P * per, **f32)
+        o = 0
+        def carve(n, *shape):
+            nonlocal o
+            v = self.grad_flat[o:o + n].view(*shape); o += n
+            return v
+        self.d_means3D = carve(self.P * 3, self.P, 3)
+        self.d_scales = carve(self.P * 3, self.P, 3)
+        self.d_rots = carve(self.P * 4, self.P, 4)
+        self.d_opacity = carve(self.P, self.P, 1)
+        self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3) if self.M else None
+        self.d_means2D = torch.empty((self.P, 3), **f32)      # densification statistic, not reduced as a weight grad
+        self._keep = []
+        self._s = None
+
+    def set_camera(self, raster_settings):
+        self._keep = []
+        self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def forward(self, means3D, shs, opacities, scales, rotations, sync_num_rendered=False):
+        nr = C.c_int64(-1)
+        _lib.check(self.lib.sg_rasterize_forward(
+            C.byref(self._s), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales), _ptr(rotations),
+            None, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii),
+            0, C.byref(nr) if sync_num_rendered else None, self._stream()), "forward")
+        return int(nr.value)
+
+    def backward(self, means3D, shs, opacities, scales, rotations, dL_dcolor):
+        _lib.check(self.lib.sg_rasterize_backward(
+            C.byref(self._s), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales), _ptr(rotations),
+            None, _ptr(self.radii), _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
+            _ptr(dL_dcolor), _ptr(self.d_means3D), _ptr(self.d_means2D), _ptr(self.d_sh), None, _ptr(self.d_opacity),
+            _ptr(self.d_scales), _ptr(self.d_rots), None, self._stream()), "backward")
+
+    def num_rendered(self):
+        nr = C.c_int64(0)
+        _lib.check(self.lib.sg_read_num_rendered(_ptr(self.binning), C.byref(nr), self._stream()), "read R")
+        return int(nr.value)
