@@ -1,0 +1,151 @@
+"""CPU tests of the rasterizer oracle (parity UNPINNED upstream -> self-validation):
+analytic cases, invariants of the binning, fp64 finite differences of the explicit backward."""
+import numpy as np
+import pytest
+
+from oracle import raster_oracle as ro
+from sings_amd.camera import get_projection_matrix, focal2fov
+from sings_amd.scene import synthetic_scene
+
+
+def _cam(W, H, f):
+    fovx, fovy = focal2fov(f, W), focal2fov(f, H)
+    view = np.eye(4, dtype=np.float32)
+    proj = (view @ get_projection_matrix(0.01, 100.0, fovx, fovy).T).astype(np.float32)
+    return view, proj, W / (2 * f), H / (2 * f)
+
+
+def _run(s, dtype=np.float32, **kw):
+    return ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"],
+                      s["tanfovx"], s["tanfovy"], s["bg"], scales=s["scales"], rotations=s["rotations"], shs=s["shs"],
+                      sh_degree=s["sh_degree"], dtype=dtype, **kw)
+
+
+def test_higher_msb_values():
+    # 1 024 -> 11, 8 160 -> 13, 16 384 -> 15
+    assert ro.higher_msb(1024) == 11 and ro.higher_msb(8160) == 13 and ro.higher_msb(16384) == 15
+
+
+def test_single_gaussian_analytic():
+    W = H = 64; f = 80.0
+    view, proj, tx, ty = _cam(W, H, f)
+    z, sc, o = 4.0, 0.12, 0.8
+    col = np.array([[0.9, 0.3, 0.1]], np.float32); bg = np.array([0.05, 0.1, 0.2], np.float32)
+    out = ro.forward(np.array([[0, 0, z]], np.float32), np.array([[o]], np.float32), view, proj, np.zeros(3, np.float32),
+                     W, H, tx, ty, bg, scales=np.full((1, 3), sc, np.float32),
+                     rotations=np.array([[1, 0, 0, 0]], np.float32), colors_precomp=col, dtype=np.float64)
+    # isotropic: cov2D = (f*s/z)^2 + 0.3 on the diagonal; pixel centre of the mean = (W-1)/2
+    var = (f * sc / z) ** 2 + 0.3
+    ys, xs = np.mgrid[0:H, 0:W]
+    d2 = (xs - (W - 1) / 2) ** 2 + (ys - (H - 1) / 2) ** 2
+    alpha = np.minimum(0.99, o * np.exp(-0.5 * d2 / var))
+    radius = int(np.ceil(3 * np.sqrt(var)))
+    assert out["radii"][0] == radius
+    alpha = np.where(alpha < 1 / 255, 0, alpha)
+    # contributions exist only inside the tiles of the 3-sigma rectangle
+    x0 = int(((W - 1) / 2 - radius) / 16); x1 = int(((W - 1) / 2 + radius + 15) / 16)
+    inside = (xs // 16 >= x0) & (xs // 16 < x1) & (ys // 16 >= x0) & (ys // 16 < x1)
+    alpha = np.where(inside, alpha, 0)
+    exp = col[0][:, None, None] * alpha + bg[:, None, None] * (1 - alpha)
+    assert np.abs(out["color"] - exp).max() < 1e-6
+    assert np.abs(out["final_T"] - (1 - alpha)).max() < 1e-6
+
+
+def test_two_gaussians_front_to_back():
+    W = H = 32; f = 40.0
+    view, proj, tx, ty = _cam(W, H, f)
+    means = np.array([[0, 0, 6.0], [0.05, 0, 3.0]], np.float32)      # second one is nearer
+    o = np.array([[0.7], [0.5]], np.float32)
+    cols = np.array([[1, 0, 0], [0, 1, 0]], np.float32); bg = np.array([0, 0, 1], np.float32)
+    out = ro.forward(means, o, view, proj, np.zeros(3, np.float32), W, H, tx, ty, bg, scales=np.full((2, 3), 0.3, np.float32),
+                     rotations=np.tile(np.array([[1, 0, 0, 0]], np.float32), (2, 1)), colors_precomp=cols, dtype=np.float64)
+    assert list(out["point_list"][:2]) == [1, 0]                     # depth order: id 1 first
+    py, px = 16, 16
+    a = []
+    for g in (1, 0):
+        d = out["xy"][g] - np.array([px, py]); c = out["conic_opacity"][g]
+        a.append(min(0.99, c[3] * np.exp(-0.5 * (c[0] * d[0] ** 2 + c[2] * d[1] ** 2) - c[1] * d[0] * d[1])))
+    exp = cols[1] * a[0] + cols[0] * a[1] * (1 - a[0]) + bg * (1 - a[0]) * (1 - a[1])
+    assert np.abs(out["color"][:, py, px] - exp).max() < 1e-12
+
+
+@pytest.mark.parametrize("N,W,H,deg,seed", [(3000, 200, 120, 3, 1), (800, 50, 70, 0, 9)])
+def test_binning_invariants(N, W, H, deg, seed):
+    s = synthetic_scene(N, W, H, deg, seed)
+    o = _run(s)
+    assert int(o["tiles_touched"].sum()) == o["R"] == len(o["keys"])
+    k = o["keys"]
+    assert (k[1:] >= k[:-1]).all()
+    # stable: equal keys keep ascending Gaussian order
+    eq = k[1:] == k[:-1]
+    assert (o["point_list"][1:][eq] > o["point_list"][:-1][eq]).all()
+    r = o["ranges"].astype(np.int64)
+    touched = r[:, 1] > r[:, 0]
+    assert (r[~touched] == 0).all()
+    assert (r[touched][1:, 0] == r[touched][:-1, 1]).all() and r[touched][0, 0] == 0 and r[touched][-1, 1] == o["R"]
+    tiles = (k >> np.uint64(32)).astype(np.int64)
+    for t in np.nonzero(touched)[0][:50]:
+        assert (tiles[r[t, 0]:r[t, 1]] == t).all()
+    # depth bits in the key are the fp32 view-space z
+    g = o["point_list"]
+    assert np.array_equal((k & np.uint64(0xffffffff)).astype(np.uint32), o["depths"].astype(np.float32).view(np.uint32)[g])
+    # near-culled / invisible Gaussians have radius 0 and no tiles
+    assert (o["tiles_touched"][o["radii"] == 0] == 0).all()
+    assert (o["radii"][s["means3D"][:, 2] <= 0.2] == 0).all()
+
+
+def test_f32_matches_f64():
+    s = synthetic_scene(1500, 96, 80, 3, 3)
+    a = _run(s, np.float32); b = _run(s, np.float64)
+    same = (a["radii"] == b["radii"])
+    assert same.mean() > 0.995
+    strict = (b["margin"] > 1e-4) & (a["margin"] > 1e-4)
+    assert np.abs(a["color"] - b["color"]).max(0)[strict].max() < 2e-5
+
+
+def test_explicit_backward_matches_fp64_finite_differences():
+    s = synthetic_scene(60, 48, 32, 3, 7)
+    s["opacities"] = np.minimum(s["opacities"], 0.95)          # the 0.99 alpha clamp is gradient-transparent by design
+    campos = np.array([0.3, -0.2, -1.0])
+    names = ["means3D", "opacities", "scales", "rotations", "shs"]
+    p = {k: s[k].astype(np.float64) for k in names}
+
+    def fwd():
+        return ro.forward(p["means3D"], p["opacities"], s["viewmatrix"], s["projmatrix"], campos, 48, 32, s["tanfovx"],
+                          s["tanfovy"], s["bg"], scales=p["scales"], rotations=p["rotations"], shs=p["shs"], sh_degree=3,
+                          dtype=np.float64, scale_modifier=1.3, want_margin=False)
+    dL = np.random.RandomState(0).normal(size=(3, 32, 48))
+    o = fwd(); g = ro.backward(o, dL)
+    gm = dict(means3D=g["dL_dmeans3D"], opacities=g["dL_dopacity"], scales=g["dL_dscales"], rotations=g["dL_drots"],
+              shs=g["dL_dsh"])
+    rs = np.random.RandomState(1)
+    vis = np.nonzero(o["radii"] > 0)[0]
+    for k in names:
+        errs = []
+        for _ in range(12):
+            i = rs.choice(vis); flat = p[k].reshape(len(p[k]), -1); j = rs.randint(flat.shape[1])
+            old = flat[i, j]; eps = 1e-6
+            flat[i, j] = old + eps; lp = (fwd()["color"] * dL).sum()
+            flat[i, j] = old - eps; lm = (fwd()["color"] * dL).sum()
+            flat[i, j] = old
+            fd = (lp - lm) / (2 * eps); an = gm[k].reshape(len(p[k]), -1)[i, j]
+            errs.append(abs(fd - an) / (abs(fd) + abs(an) + 1e-7))
+        assert np.median(errs) < 1e-6 and max(errs) < 1e-3, (k, errs)
+
+
+def test_mean2d_gradient_is_ndc_scaled():
+    """means2D.grad[:, :2] is dL/d(pixel mean) * (0.5 W, 0.5 H) and z = 0 (consumer: sings_hybrid.py:1013-1015)."""
+    s = synthetic_scene(300, 64, 48, 1, 12)
+    o = _run(s); g = ro.backward(o, s["dL_dimage"][:, :48, :64])
+    assert (g["dL_dmean2D"][:, 2] == 0).all()
+    assert np.abs(g["dL_dmean2D"][o["radii"] == 0]).max() == 0
+
+
+def test_empty_and_all_culled():
+    s = synthetic_scene(50, 40, 24, 0, 2)
+    s["means3D"][:, 2] = -1.0
+    o = _run(s)
+    assert o["R"] == 0 and (o["radii"] == 0).all()
+    assert np.allclose(o["color"], s["bg"][:, None, None])
+    g = ro.backward(o, np.ones((3, 24, 40), np.float32))
+    assert np.abs(g["dL_dmeans3D"]).max() == 0
