@@ -99,6 +99,50 @@ int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const 
 /* Reads R written by the last forward into this binning workspace (synchronises). */
 int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream);
 
+/* ---- LBS-fused path: canonical Gaussians + joint transforms in, image out ------------------
+ * Replaces the LBS block of SinGS.forward (sings/rec/models/sings_hybrid.py:398-428; lbs_extra at
+ * sings/rec/utils/body_model/lbs.py:59-74; matrix_to_quaternion at
+ * sings/rec/utils/geometry/rotations.py:98-149) AND the rasterizer call that follows it
+ * (gs_renderer_single.py:87-95): posed means / quaternions / T[N,4,4] stay in registers. */
+typedef struct SgSkinInputs {
+    int32_t J;                /* joints: 24 (SMPL) or 52 (SMPL-H); <= 64 */
+    int32_t reserved;
+    const float *xyz_canon;   /* [P,3] canonical means */
+    const float *rot_canon;   /* [P,9] row-major canonical rotation matrices, NULL = identity (isotropic) */
+    const float *lbs_weights; /* [P,J] skinning weights */
+    const float *A;           /* [J,16] row-major cano->pose joint transforms (A_t2pose @ inv_A_t2cano) */
+    const float *smpl_scale;  /* [1] or NULL */
+    const float *transl;      /* [3] or NULL */
+    const float *ext_trans;   /* [3]  \                                                    */
+    const float *ext_rot;     /* [9]   > ext_tfs of sings_hybrid.py:421-428, all or none;   */
+    const float *ext_scale;   /* [1]  /  forward only (the reference uses them under no_grad) */
+} SgSkinInputs;
+
+/* floats the caller must provide as `skin_ws` to sg_skinned_backward */
+size_t sg_skin_ws_floats(int P);
+
+/* Forward.  `scales` are the CANONICAL scales [P,3]; optional outputs posed_xyz [P,3],
+ * posed_rotq [P,4] (real first, not normalised), posed_scales [P,3] may be NULL. */
+int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                       const float *opacities, const float *scales, void *geom_ws, void *binning_ws,
+                       size_t capacity_pairs, void *image_ws, float *out_color, int32_t *radii,
+                       float *posed_xyz, float *posed_rotq, float *posed_scales,
+                       int64_t *num_rendered_host, void *stream);
+
+/* Backward (LBS^T).  dL_dposed_xyz_in / dL_dposed_rotq_in: optional upstream gradients on the posed
+ * outputs.  Outputs fully written: dL_dxyz_canon [P,3], dL_drot_canon [P,9] (may be NULL),
+ * dL_dscales [P,3], dL_dopacity [P], dL_dsh [P,M,3], dL_dmeans2D [P,3], dL_dA [J,16],
+ * dL_dtransl [3] (may be NULL).  smpl_scale, lbs_weights and ext_tfs receive no gradient (they are
+ * data / buffers in the reference: sings_hybrid.py:724, gs_trainer.py:230). */
+int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                        const float *opacities, const float *scales, const int32_t *radii,
+                        const void *geom_ws, const void *binning_ws, size_t capacity_pairs,
+                        const void *image_ws, void *bwd_ws, float *skin_ws, const float *dL_dout_color,
+                        const float *dL_dposed_xyz_in, const float *dL_dposed_rotq_in,
+                        float *dL_dxyz_canon, float *dL_drot_canon, float *dL_dscales,
+                        float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
+                        float *dL_dtransl, void *stream);
+
 /* ---- optional per-kernel timing (bench / profiling only; process-global, not thread-safe).
  * When enabled, every kernel launch of forward/backward is bracketed by hipEvents on the
  * caller's stream.  sg_profile_collect synchronises, adds the elapsed milliseconds and launch

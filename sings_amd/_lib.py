@@ -29,10 +29,15 @@ class SgLayout(C.Structure):
         "bin_point_keys", "bin_bytes", "img_final_T", "img_n_contrib", "img_bytes", "bwd_bytes")]
 
 
+class SgSkinInputs(C.Structure):
+    _fields_ = [("J", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in (
+        "xyz_canon", "rot_canon", "lbs_weights", "A", "smpl_scale", "transl", "ext_trans", "ext_rot", "ext_scale")]
+
+
 # every symbol include/sings_hip.h declares
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
            "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
-           "sg_kernel_name")
+           "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward")
 NUM_KERNELS = 8
 
 
@@ -62,8 +67,14 @@ def load():
     lib.sg_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.sg_kernel_name.argtypes = [i32]
     lib.sg_kernel_name.restype = C.c_char_p
+    lib.sg_skin_ws_floats.argtypes = [i32]
+    lib.sg_skin_ws_floats.restype = sz
+    lib.sg_skinned_forward.argtypes = ([C.POINTER(SgRasterSettings), i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
+                                       [vp, vp, sz, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int64), vp])
+    lib.sg_skinned_backward.argtypes = ([C.POINTER(SgRasterSettings), i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
+                                        [vp, vp, vp, sz, vp, vp, vp] + [vp] * 3 + [vp] * 8 + [vp])
     for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",
-              "sg_read_num_rendered"):
+              "sg_read_num_rendered", "sg_skinned_forward", "sg_skinned_backward"):
         getattr(lib, f).restype = C.c_int
     _lib = lib
     return lib

@@ -147,6 +147,79 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
     return 0;
 }
 
+static int sg_check_skin(const SgSkinInputs *k, int P, bool fwd)
+{
+    if (!k || k->J <= 0 || k->J > 64) return 1;
+    if (P > 0 && (!k->xyz_canon || !k->lbs_weights || !k->A)) return 1;
+    int e = (k->ext_trans != nullptr) + (k->ext_rot != nullptr) + (k->ext_scale != nullptr);
+    if (e != 0 && e != 3) return 1;
+    if (!fwd && e) return 1;
+    return 0;
+}
+
+extern "C" size_t sg_skin_ws_floats(int P) { return sg_skin_slab_floats(P > 0 ? P : 1); }
+
+extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                                  const float *opacities, const float *scales, void *geom_ws, void *binning_ws,
+                                  size_t cap, void *image_ws, float *out_color, int32_t *radii, float *posed_xyz,
+                                  float *posed_rotq, float *posed_scales, int64_t *num_rendered_host, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_skinned_forward: bad settings", hipSuccess);
+    if (sg_check_skin(skin, P, true)) return sg_fail("sg_skinned_forward: bad skin inputs (J in 1..64, ext_tfs all or none)", hipSuccess);
+    if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!shs || !opacities || !scales || !radii)))
+        return sg_fail("sg_skinned_forward: null pointer", hipSuccess);
+    if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1))
+        return sg_fail("sg_skinned_forward: sh_coeffs smaller than (sh_degree+1)^2", hipSuccess);
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgGeom g = sg_geom_view(geom_ws, L);
+    SgBin b = sg_bin_view(binning_ws, L);
+    SgImg im = sg_img_view(image_ws, L);
+    hipError_t e = hipMemsetAsync(b.header, 0, L.bin_ranges - L.bin_header, st);
+    if (e != hipSuccess) return sg_fail("memset", e);
+    sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, radii, posed_xyz, posed_rotq, posed_scales, st);
+    SG_CHECK_LAST("skin_fwd", s, st);
+    sg_launch_binning(c, P, radii, g, b, cap, 0, st);
+    SG_CHECK_LAST("binning", s, st);
+    sg_launch_render_fwd(c, g, b, cap, im, out_color, st);
+    SG_CHECK_LAST("render_fwd", s, st);
+    if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
+    return 0;
+}
+
+extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                                   const float *opacities, const float *scales, const int32_t *radii,
+                                   const void *geom_ws, const void *binning_ws, size_t cap, const void *image_ws,
+                                   void *bwd_ws, float *skin_ws, const float *dL_dout_color,
+                                   const float *dL_dposed_xyz_in, const float *dL_dposed_rotq_in, float *dL_dxyz_canon,
+                                   float *dL_drot_canon, float *dL_dscales, float *dL_dopacity, float *dL_dsh,
+                                   float *dL_dmeans2D, float *dL_dA, float *dL_dtransl, void *stream)
+{
+    (void)opacities;
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_skinned_backward: bad settings", hipSuccess);
+    if (sg_check_skin(skin, P, false)) return sg_fail("sg_skinned_backward: bad skin inputs (ext_tfs are forward-only)", hipSuccess);
+    if (P <= 0) return 0;
+    if (!shs || !scales || !radii || !geom_ws || !binning_ws || !image_ws || !bwd_ws || !skin_ws || !dL_dout_color ||
+        !dL_dxyz_canon || !dL_dscales || !dL_dopacity || !dL_dsh || !dL_dmeans2D || !dL_dA)
+        return sg_fail("sg_skinned_backward: null pointer", hipSuccess);
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgGeom g = sg_geom_view((void *)geom_ws, L);
+    SgBin b = sg_bin_view((void *)binning_ws, L);
+    SgImg im = sg_img_view((void *)image_ws, L);
+    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
+    SG_CHECK_LAST("render_bwd", s, st);
+    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, (const float *)bwd_ws, cap, dL_dposed_xyz_in, dL_dposed_rotq_in,
+                       skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
+                       dL_dtransl, st);
+    SG_CHECK_LAST("skin_bwd", s, st);
+    return 0;
+}
+
 __global__ void sg_mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ view,
                                        uint8_t *__restrict__ present)
 {

@@ -90,3 +90,14 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
 // per-kernel event timing (sg_api.hip)
 void sg_prof_begin(int id, hipStream_t st);
 void sg_prof_end(int id, hipStream_t st);
+
+// LBS-fused per-Gaussian kernels (sg_skin.hip)
+void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
+                        const float *scales, SgGeom g, SgBin b, int32_t *radii, float *posed_xyz, float *posed_rotq,
+                        float *posed_scales, hipStream_t st);
+size_t sg_skin_slab_floats(int P);
+void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
+                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
+                        const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
+                        float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
+                        float *dL_dtransl, hipStream_t st);

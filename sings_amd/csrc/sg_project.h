@@ -1,0 +1,273 @@
+// Per-Gaussian projection math shared by the plain and the LBS-fused kernels.
+// Forward: SURVEY.md App. A.1; backward: App. A.5 (reference call site
+// sings/rec/renderer/gs_renderer_single.py:87-95).  Exact operation order -- see sg_math.h.
+#pragma once
+#include "sg_math.h"
+
+template <int D>
+__device__ __forceinline__ void sg_eval_sh(const float *__restrict__ sh, const float dir[3],
+                                           float rgb[3], uint32_t &clampbits)
+{
+    float b[16];
+    sg_sh_basis<D>(dir, b);
+    constexpr int nc = (D + 1) * (D + 1);
+    clampbits = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float acc = b[0] * sh[c];
+#pragma unroll
+        for (int k = 1; k < nc; k++) acc = acc + b[k] * sh[3 * k + c];
+        acc = acc + 0.5f;
+        if (acc < 0.0f) { clampbits |= 1u << c; acc = 0.0f; }
+        rgb[c] = acc;
+    }
+}
+
+
+struct SgProj {
+    int mr;                      // radius in pixels (0: culled / invisible)
+    uint32_t tt, clampbits;      // tiles touched, SH clamp mask
+    int x0, y0, x1, y1;          // tile rectangle
+    float pix[2], conic[3], rgb[3], depth;
+};
+
+// p: world-space mean, s3: scales, q: (r,x,y,z) un-normalised quaternion; c6pre / colpre: optional
+// precomputed covariance (6) / colour (3) of THIS Gaussian; sh: this Gaussian's [M,3] SH rows.
+template <int D>
+__device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3], const float s3[3], const float q[4],
+                                               const float *__restrict__ c6pre, const float *__restrict__ colpre,
+                                               const float *__restrict__ sh, SgProj &o)
+{
+    o.mr = 0; o.tt = 0; o.clampbits = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
+    o.pix[0] = o.pix[1] = 0; o.conic[0] = o.conic[1] = o.conic[2] = 0; o.rgb[0] = o.rgb[1] = o.rgb[2] = 0; o.depth = 0;
+    float pv[3];
+    sg_xf4x3(p, c.view, pv);
+    if (!(pv[2] > 0.2f)) return;
+    float ph[4];
+    sg_xf4x4(p, c.proj, ph);
+    float pw = 1.0f / (ph[3] + 0.0000001f);
+    float ppx = ph[0] * pw, ppy = ph[1] * pw;
+    float c6[6];
+    if (c6pre) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = c6pre[k];
+    } else {
+        sg_cov3d(s3, c.mod, q, c6);
+    }
+    float Mm[6], tc[3], abc[3]; bool xin, yin;
+    sg_proj_jac(pv, c.fx, c.fy, c.tanfovx, c.tanfovy, c.view, Mm, tc, xin, yin);
+    sg_cov2d(Mm, c6, abc);
+    float det = abc[0] * abc[2] - abc[1] * abc[1];
+    if (det == 0.0f) return;
+    float det_inv = 1.0f / det;
+    float conic[3] = { abc[2] * det_inv, -abc[1] * det_inv, abc[0] * det_inv };
+    float mid = 0.5f * (abc[0] + abc[2]);
+    float dd = mid * mid - det; dd = dd < 0.1f ? 0.1f : dd;
+    float sq = sqrtf(dd);
+    float l1 = mid + sq, l2 = mid - sq;
+    float lm = l1 > l2 ? l1 : l2;
+    float my_radius = ceilf(3.0f * sqrtf(lm));
+    float pix0 = ((ppx + 1.0f) * (float)c.W - 1.0f) * 0.5f;
+    float pix1 = ((ppy + 1.0f) * (float)c.H - 1.0f) * 0.5f;
+    int r = (int)my_radius, x0, y0, x1, y1;
+    sg_rect(pix0, pix1, r, c.gx, c.gy, x0, y0, x1, y1);
+    uint32_t area = (uint32_t)((x1 - x0) * (y1 - y0));
+    if (area == 0) return;
+    o.mr = r; o.tt = area; o.depth = pv[2];
+    o.x0 = x0; o.y0 = y0; o.x1 = x1; o.y1 = y1;
+    o.pix[0] = pix0; o.pix[1] = pix1; o.conic[0] = conic[0]; o.conic[1] = conic[1]; o.conic[2] = conic[2];
+    if (colpre) {
+        o.rgb[0] = colpre[0]; o.rgb[1] = colpre[1]; o.rgb[2] = colpre[2];
+    } else {
+        float dir[3] = { p[0] - c.campos[0], p[1] - c.campos[1], p[2] - c.campos[2] };
+        float len = sqrtf(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        dir[0] = dir[0] / len; dir[1] = dir[1] / len; dir[2] = dir[2] / len;
+        sg_eval_sh<D>(sh, dir, o.rgb, o.clampbits);
+    }
+}
+
+// Stores the projected record.  MUST be reached by every lane of the wave (live or not): the
+// Gaussian-major slots of the backward gradient records are allocated with one atomic per wave.
+__device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g,
+                                              uint32_t *__restrict__ header, int32_t *__restrict__ radii)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = o.tt;
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) {
+        uint32_t v = __shfl_up(incl, s, 64);
+        if (lane >= s) incl += v;
+    }
+    uint32_t total = __shfl(incl, 63, 64);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = atomicAdd(&header[2], total);
+    base = __shfl(base, 63, 64);
+    if (live) {
+        uint32_t goff = base + incl - o.tt;
+        radii[idx] = o.mr;
+        g.recA[idx] = make_float4(o.pix[0], o.pix[1], o.conic[0], o.conic[1]);
+        g.recB[idx] = make_float4(o.conic[2], o.mr ? opac : 0.0f, o.rgb[0], o.rgb[1]);
+        g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(goff),
+                                  __uint_as_float((uint32_t)o.x0 | ((uint32_t)o.y0 << 16)),
+                                  __uint_as_float((uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16)));
+        g.depth[idx] = o.depth;
+        g.flags[idx] = o.clampbits;
+    }
+}
+
+struct SgGaussGrad {
+    float dmean[3], g2[2], dop, dcol[3], dsc[3], drot[4], g6[6];
+};
+
+// Sum of this Gaussian's (tile,Gaussian) gradient records, fixed order -> deterministic.
+__device__ __forceinline__ void sg_sum_records(const float4 *__restrict__ grec, size_t cap, float4 recC, float a9[9])
+{
+    uint32_t goff = __float_as_uint(recC.y), wh = __float_as_uint(recC.w);
+    uint32_t tt = (wh & 0xffffu) * (wh >> 16);
+#pragma unroll
+    for (int i = 0; i < 9; i++) a9[i] = 0.0f;
+    for (uint32_t k = 0; k < tt; k++) {
+        size_t r = (size_t)goff + k;
+        if (r >= cap) break;
+        float4 r0 = grec[3 * r], r1 = grec[3 * r + 1], r2 = grec[3 * r + 2];
+        a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
+        a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r2.x;
+    }
+}
+
+// Backward of sg_project_fwd for one VISIBLE Gaussian.  a9 = summed record
+// (mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, colour r,g,b).
+// dsh_out: this Gaussian's [M,3] gradient rows (rows < (D+1)^2 written here) or NULL.
+template <int D>
+__device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3], const float s3[3], const float q[4],
+                                               const float *__restrict__ c6pre, const float *__restrict__ sh,
+                                               uint32_t clampbits, const float a9[9], float *__restrict__ dsh_out,
+                                               SgGaussGrad &G)
+{
+    float *dmean = G.dmean, *g2 = G.g2, *dcol = G.dcol, *dsc = G.dsc, *drot = G.drot, *g6 = G.g6;
+    g2[0] = a9[0]; g2[1] = a9[1];
+    float dLx = a9[2], dLy = a9[3], dLz = a9[4];
+    G.dop = a9[5]; dcol[0] = a9[6]; dcol[1] = a9[7]; dcol[2] = a9[8];
+#pragma unroll
+    for (int k = 0; k < 3; k++) dsc[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; k++) drot[k] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) g6[k] = 0.0f;
+    float c6[6];
+    if (c6pre) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = c6pre[k];
+    } else {
+        sg_cov3d(s3, c.mod, q, c6);
+    }
+    // ---- cov2D backward
+    float pv[3], Mm[6], tc[3], abc[3]; bool xin, yin;
+    sg_xf4x3(p, c.view, pv);
+    sg_proj_jac(pv, c.fx, c.fy, c.tanfovx, c.tanfovy, c.view, Mm, tc, xin, yin);
+    sg_cov2d(Mm, c6, abc);
+    float a = abc[0], b = abc[1], cc = abc[2];
+    float denom = a * cc - b * b;
+    float denom2inv = 1.0f / (denom * denom + 0.0000001f);
+    float dL_da = 0, dL_db = 0, dL_dc = 0;
+    if (denom2inv != 0.0f) {
+        dL_da = denom2inv * (-cc * cc * dLx + 2.0f * b * cc * dLy + (denom - a * cc) * dLz);
+        dL_dc = denom2inv * (-a * a * dLz + 2.0f * a * b * dLy + (denom - a * cc) * dLx);
+        dL_db = denom2inv * 2.0f * (b * cc * dLx - (denom + 2.0f * b * b) * dLy + a * b * dLz);
+        const float *m0 = Mm, *m1 = Mm + 3;
+        g6[0] = m0[0] * m0[0] * dL_da + m0[0] * m1[0] * dL_db + m1[0] * m1[0] * dL_dc;
+        g6[3] = m0[1] * m0[1] * dL_da + m0[1] * m1[1] * dL_db + m1[1] * m1[1] * dL_dc;
+        g6[5] = m0[2] * m0[2] * dL_da + m0[2] * m1[2] * dL_db + m1[2] * m1[2] * dL_dc;
+        g6[1] = 2.0f * m0[0] * m0[1] * dL_da + (m0[0] * m1[1] + m0[1] * m1[0]) * dL_db + 2.0f * m1[0] * m1[1] * dL_dc;
+        g6[2] = 2.0f * m0[0] * m0[2] * dL_da + (m0[0] * m1[2] + m0[2] * m1[0]) * dL_db + 2.0f * m1[0] * m1[2] * dL_dc;
+        g6[4] = 2.0f * m0[2] * m0[1] * dL_da + (m0[1] * m1[2] + m0[2] * m1[1]) * dL_db + 2.0f * m1[1] * m1[2] * dL_dc;
+    }
+    float gM[6];
+    {
+        float V[9] = { c6[0], c6[1], c6[2], c6[1], c6[3], c6[4], c6[2], c6[4], c6[5] };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float v0 = Mm[0] * V[3 * k] + Mm[1] * V[3 * k + 1] + Mm[2] * V[3 * k + 2];
+            float v1 = Mm[3] * V[3 * k] + Mm[4] * V[3 * k + 1] + Mm[5] * V[3 * k + 2];
+            gM[k] = 2.0f * v0 * dL_da + v1 * dL_db;
+            gM[3 + k] = 2.0f * v1 * dL_dc + v0 * dL_db;
+        }
+    }
+    const float *view = c.view, *proj = c.proj;
+    float dJ00 = gM[0] * view[0] + gM[1] * view[4] + gM[2] * view[8];
+    float dJ02 = gM[0] * view[2] + gM[1] * view[6] + gM[2] * view[10];
+    float dJ11 = gM[3] * view[1] + gM[4] * view[5] + gM[5] * view[9];
+    float dJ12 = gM[3] * view[2] + gM[4] * view[6] + gM[5] * view[10];
+    float tz = 1.0f / tc[2], tz2 = tz * tz, tz3 = tz2 * tz;
+    float dtx = (xin ? 1.0f : 0.0f) * -c.fx * tz2 * dJ02;
+    float dty = (yin ? 1.0f : 0.0f) * -c.fy * tz2 * dJ12;
+    float dtz = -c.fx * tz2 * dJ00 - c.fy * tz2 * dJ11 + (2.0f * c.fx * tc[0]) * tz3 * dJ02 + (2.0f * c.fy * tc[1]) * tz3 * dJ12;
+    dmean[0] = view[0] * dtx + view[1] * dty + view[2] * dtz;
+    dmean[1] = view[4] * dtx + view[5] * dty + view[6] * dtz;
+    dmean[2] = view[8] * dtx + view[9] * dty + view[10] * dtz;
+    // ---- projection backward
+    float mh[4];
+    sg_xf4x4(p, proj, mh);
+    float mw = 1.0f / (mh[3] + 0.0000001f);
+    float mul1 = (proj[0] * p[0] + proj[4] * p[1] + proj[8] * p[2] + proj[12]) * mw * mw;
+    float mul2 = (proj[1] * p[0] + proj[5] * p[1] + proj[9] * p[2] + proj[13]) * mw * mw;
+    dmean[0] += (proj[0] * mw - proj[3] * mul1) * g2[0] + (proj[1] * mw - proj[3] * mul2) * g2[1];
+    dmean[1] += (proj[4] * mw - proj[7] * mul1) * g2[0] + (proj[5] * mw - proj[7] * mul2) * g2[1];
+    dmean[2] += (proj[8] * mw - proj[11] * mul1) * g2[0] + (proj[9] * mw - proj[11] * mul2) * g2[1];
+    // ---- cov3D backward
+    if (!c6pre) {
+        float Gs[9] = { g6[0], 0.5f * g6[1], 0.5f * g6[2], 0.5f * g6[1], g6[3], 0.5f * g6[4],
+                        0.5f * g6[2], 0.5f * g6[4], g6[5] };
+        float R[9];
+        sg_quat_to_R(q, R);
+        float s[3] = { c.mod * s3[0], c.mod * s3[1], c.mod * s3[2] };
+        float GR[9], dR[9];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; a2++)
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                GR[3 * a2 + k] = Gs[3 * a2] * R[k] + Gs[3 * a2 + 1] * R[3 + k] + Gs[3 * a2 + 2] * R[6 + k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            float rgr = R[k] * GR[k] + R[3 + k] * GR[3 + k] + R[6 + k] * GR[6 + k];
+            dsc[k] = c.mod * 2.0f * s[k] * rgr;
+#pragma unroll
+            for (int a2 = 0; a2 < 3; a2++) dR[3 * a2 + k] = 2.0f * GR[3 * a2 + k] * s[k] * s[k];
+        }
+        float r = q[0], x = q[1], y = q[2], z = q[3];
+        drot[0] = 2.0f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        drot[1] = 2.0f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.0f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.0f * x * dR[8]);
+        drot[2] = 2.0f * (-2.0f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.0f * y * dR[8]);
+        drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+    }
+    // ---- SH backward (and its contribution to dL/dmean through the view direction)
+    if (dsh_out) {
+        constexpr int nc = (D + 1) * (D + 1);
+        float dorig[3] = { p[0] - c.campos[0], p[1] - c.campos[1], p[2] - c.campos[2] };
+        float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];
+        float len = sqrtf(sum2);
+        float dir[3] = { dorig[0] / len, dorig[1] / len, dorig[2] / len };
+        float bas[16], db[48];
+        sg_sh_basis<D>(dir, bas);
+        sg_sh_basis_grad<D>(dir, db);
+        float dRGB[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ch++) dRGB[ch] = (clampbits >> ch) & 1u ? 0.0f : dcol[ch];
+        float ddir[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < nc; k++)
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+                dsh_out[3 * k + ch] = bas[k] * dRGB[ch];
+                if (k > 0) {
+                    float sv = sh[3 * k + ch] * dRGB[ch];
+                    ddir[0] += db[3 * k] * sv; ddir[1] += db[3 * k + 1] * sv; ddir[2] += db[3 * k + 2] * sv;
+                }
+            }
+        float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+        float vx = dorig[0], vy = dorig[1], vz = dorig[2];
+        dmean[0] += ((sum2 - vx * vx) * ddir[0] - vy * vx * ddir[1] - vz * vx * ddir[2]) * inv32;
+        dmean[1] += (-vx * vy * ddir[0] + (sum2 - vy * vy) * ddir[1] - vz * vy * ddir[2]) * inv32;
+        dmean[2] += (-vx * vz * ddir[0] - vy * vz * ddir[1] + (sum2 - vz * vz) * ddir[2]) * inv32;
+    }
+}

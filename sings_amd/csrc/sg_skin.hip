@@ -1,0 +1,436 @@
+// SMPL linear-blend-skinning fused with the projection preprocess (forward and backward).
+//
+// Replaces the LBS block of SinGS.forward -- sings/rec/models/sings_hybrid.py:398-428 with
+// sings/rec/utils/body_model/lbs.py:59-74 (T = W . A, v' = T [v;1]) and
+// sings/rec/utils/geometry/rotations.py:98-149 (matrix_to_quaternion) -- and feeds the posed
+// mean / rotation / scale straight into the projection of sg_project.h, so the posed means and
+// quaternions, T[N,4,4] and the ~15 eager kernels of the reference never touch HBM.
+//
+// The only dense contraction on the path, T[64 x 16] = W[64 x J] . A[J x 16] per wave, runs on the
+// matrix cores with v_mfma_f32_16x16x4_f32 (exact fp32, bitwise a k-ordered fmaf chain); its
+// transpose dA[J x 16] = W^T . dT in backward likewise.  W is streamed once per pass in 64-B row
+// segments through LDS (HBM-bound: 4J bytes per Gaussian dominate).
+#include "sg_project.h"
+
+#define SG_SKIN_THREADS 256
+#define SG_SKIN_WAVES 4
+#define SG_JMAX 64
+#define SG_WSTRIDE 17
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct SgSkin {
+    int J;
+    const float *xyz_canon, *rot_canon, *lbs_w, *A, *smpl_scale, *transl, *ext_trans, *ext_rot, *ext_scale;
+};
+
+// ---- rotations.py:98-149 ----------------------------------------------------------------
+__device__ __forceinline__ void sg_m2q(const float m[9], float q[4], int &best, float &qab)
+{
+    float x0 = 1.0f + m[0] + m[4] + m[8], x1 = 1.0f + m[0] - m[4] - m[8];
+    float x2 = 1.0f - m[0] + m[4] - m[8], x3 = 1.0f - m[0] - m[4] + m[8];
+    float a0 = x0 > 0.0f ? sqrtf(x0) : 0.0f, a1 = x1 > 0.0f ? sqrtf(x1) : 0.0f;
+    float a2 = x2 > 0.0f ? sqrtf(x2) : 0.0f, a3 = x3 > 0.0f ? sqrtf(x3) : 0.0f;
+    best = 0; qab = a0;
+    if (a1 > qab) { best = 1; qab = a1; }
+    if (a2 > qab) { best = 2; qab = a2; }
+    if (a3 > qab) { best = 3; qab = a3; }
+    float n0, n1, n2, n3;
+    if (best == 0)      { n0 = a0 * a0;      n1 = m[7] - m[5]; n2 = m[2] - m[6]; n3 = m[3] - m[1]; }
+    else if (best == 1) { n0 = m[7] - m[5];  n1 = a1 * a1;     n2 = m[3] + m[1]; n3 = m[2] + m[6]; }
+    else if (best == 2) { n0 = m[2] - m[6];  n1 = m[3] + m[1]; n2 = a2 * a2;     n3 = m[5] + m[7]; }
+    else                { n0 = m[3] - m[1];  n1 = m[6] + m[2]; n2 = m[7] + m[5]; n3 = a3 * a3; }
+    float den = 2.0f * (qab > 0.1f ? qab : 0.1f);
+    q[0] = n0 / den; q[1] = n1 / den; q[2] = n2 / den; q[3] = n3 / den;
+}
+
+// gradient of sg_m2q: dq[4] -> dm[9] (autograd of the reference expression: zero sub-gradient of
+// sqrt at <= 0, of the 0.1 floor below it, and only the selected candidate receives gradient)
+__device__ __forceinline__ void sg_m2q_bwd(const float q[4], int best, float qab, const float dq[4], float dm[9])
+{
+#pragma unroll
+    for (int i = 0; i < 9; i++) dm[i] = 0.0f;
+    float den = 2.0f * (qab > 0.1f ? qab : 0.1f);
+    float dn0 = dq[0] / den, dn1 = dq[1] / den, dn2 = dq[2] / den, dn3 = dq[3] / den;
+    float dden = -(dq[0] * q[0] + dq[1] * q[1] + dq[2] * q[2] + dq[3] * q[3]) / den;
+    // d(num_best)/dx = 1 (x>0), d(den)/dx = 2 * [qab > 0.1] * 0.5 / qab
+    float dx = 0.0f;
+    if (qab > 0.0f) {
+        float dnb = best == 0 ? dn0 : (best == 1 ? dn1 : (best == 2 ? dn2 : dn3));
+        dx = dnb + (qab > 0.1f ? dden / qab : 0.0f);
+    }
+    if (best == 0) {
+        dm[0] += dx; dm[4] += dx; dm[8] += dx;
+        dm[7] += dn1; dm[5] -= dn1; dm[2] += dn2; dm[6] -= dn2; dm[3] += dn3; dm[1] -= dn3;
+    } else if (best == 1) {
+        dm[0] += dx; dm[4] -= dx; dm[8] -= dx;
+        dm[7] += dn0; dm[5] -= dn0; dm[3] += dn2; dm[1] += dn2; dm[2] += dn3; dm[6] += dn3;
+    } else if (best == 2) {
+        dm[0] -= dx; dm[4] += dx; dm[8] -= dx;
+        dm[2] += dn0; dm[6] -= dn0; dm[3] += dn1; dm[1] += dn1; dm[5] += dn3; dm[7] += dn3;
+    } else {
+        dm[0] -= dx; dm[4] -= dx; dm[8] += dx;
+        dm[3] += dn0; dm[1] -= dn0; dm[6] += dn1; dm[2] += dn1; dm[7] += dn2; dm[5] += dn2;
+    }
+}
+
+// rotations.py:372-407: Hamilton product, real part made non-negative
+__device__ __forceinline__ void sg_qmul_std(const float a[4], const float b[4], float o[4])
+{
+    o[0] = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+    o[1] = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+    o[2] = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+    o[3] = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+    if (o[0] < 0.0f) { o[0] = -o[0]; o[1] = -o[1]; o[2] = -o[2]; o[3] = -o[3]; }
+}
+
+// ---- W . A on the matrix cores -----------------------------------------------------------
+// Stages joints [16c, 16c+16) of the wave's 64 skinning-weight rows into sW[64][17] (zero padded).
+__device__ __forceinline__ void sg_stage_w_chunk(const float *__restrict__ W, int J, int P, int g0, int c, int lane,
+                                                 float *__restrict__ sW)
+{
+    if ((J & 3) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int row = i * 16 + (lane >> 2), col = c * 16 + 4 * (lane & 3);
+            float4 v = make_float4(0, 0, 0, 0);
+            if (g0 + row < P && col < J) v = *(const float4 *)(W + (size_t)(g0 + row) * J + col);
+            float *d = sW + row * SG_WSTRIDE + 4 * (lane & 3);
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            int row = i * 4 + (lane >> 4), col = c * 16 + (lane & 15);
+            float v = 0.0f;
+            if (g0 + row < P && col < J) v = W[(size_t)(g0 + row) * J + col];
+            sW[row * SG_WSTRIDE + (lane & 15)] = v;
+        }
+    }
+}
+
+// T rows 0..2 (12 floats, row-major 3x4) of this lane's Gaussian g0 + lane.
+// sA: [Jp][16] joint transforms (zero padded to a multiple of 16 rows), sW / sT: this wave's scratch.
+__device__ __forceinline__ void sg_skin_T(const float *__restrict__ W, int J, int P, int g0, int lane,
+                                          const float *__restrict__ sA, float *__restrict__ sW,
+                                          float *__restrict__ sT, float T[12])
+{
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[b] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    const int nchunk = (J + 15) >> 4;
+    for (int c = 0; c < nchunk; c++) {
+        sg_stage_w_chunk(W, J, P, g0, c, lane, sW);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            float bv = sA[(c * 16 + 4 * kk + (lane >> 4)) * 16 + (lane & 15)];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                float av = sW[(16 * b + (lane & 15)) * SG_WSTRIDE + 4 * kk + (lane >> 4)];
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // acc[b][r] = T[gaussian 16b + 4(lane>>4) + r][entry lane&15]  ->  transpose through LDS
+    if ((lane & 15) < 12) {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sT[(16 * b + 4 * (lane >> 4) + r) * 13 + (lane & 15)] = acc[b][r];
+    }
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sT[lane * 13 + i];
+    __builtin_amdgcn_wave_barrier();
+}
+
+struct SgPosed { float p[3], q[4], s3[3], Rdef[9], x[3], Rc[9], sc; int best; float qab; };
+
+// sings_hybrid.py:400-428 for one Gaussian, given its blended transform T (3x4)
+__device__ __forceinline__ void sg_pose_gaussian(const SgSkin &k, int idx, const float T[12],
+                                                 const float *__restrict__ scales, SgPosed &o)
+{
+    o.x[0] = k.xyz_canon[3 * idx]; o.x[1] = k.xyz_canon[3 * idx + 1]; o.x[2] = k.xyz_canon[3 * idx + 2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) o.p[i] = T[4 * i] * o.x[0] + T[4 * i + 1] * o.x[1] + T[4 * i + 2] * o.x[2] + T[4 * i + 3];
+    o.s3[0] = scales[3 * idx]; o.s3[1] = scales[3 * idx + 1]; o.s3[2] = scales[3 * idx + 2];
+    o.sc = k.smpl_scale ? k.smpl_scale[0] : 1.0f;
+    if (k.smpl_scale) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { o.p[i] = o.p[i] * o.sc; o.s3[i] = o.s3[i] * o.sc; }
+    }
+    if (k.transl) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) o.p[i] = o.p[i] + k.transl[i];
+    }
+    if (k.rot_canon) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.Rc[i] = k.rot_canon[9 * (size_t)idx + i];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+                o.Rdef[3 * i + j] = T[4 * i] * o.Rc[j] + T[4 * i + 1] * o.Rc[3 + j] + T[4 * i + 2] * o.Rc[6 + j];
+    } else {                    // isotropic: R_canon = I (sings_hybrid.py:358-361)
+#pragma unroll
+        for (int i = 0; i < 9; i++) o.Rc[i] = (i % 4 == 0) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) o.Rdef[3 * i + j] = T[4 * i + j];
+    }
+    sg_m2q(o.Rdef, o.q, o.best, o.qab);
+    if (k.ext_rot) {            // sings_hybrid.py:421-428 (animation only; forward)
+        float e = k.ext_scale[0], pr[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+            pr[i] = k.ext_rot[3 * i] * o.p[0] + k.ext_rot[3 * i + 1] * o.p[1] + k.ext_rot[3 * i + 2] * o.p[2];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { o.p[i] = k.ext_trans[i] + e * pr[i]; o.s3[i] = e * o.s3[i]; }
+        float er[9], qe[4], qo[4]; int bb; float qq;
+#pragma unroll
+        for (int i = 0; i < 9; i++) er[i] = k.ext_rot[i];
+        sg_m2q(er, qe, bb, qq);
+        sg_qmul_std(qe, o.q, qo);
+        o.q[0] = qo[0]; o.q[1] = qo[1]; o.q[2] = qo[2]; o.q[3] = qo[3];
+    }
+}
+
+__device__ __forceinline__ void sg_load_A(const SgSkin &k, float *__restrict__ sA)
+{
+    const int Jp = ((k.J + 15) >> 4) << 4;
+    for (int i = threadIdx.x; i < Jp * 16; i += blockDim.x) sA[i] = i < k.J * 16 ? k.A[i] : 0.0f;
+}
+
+template <int D>
+__global__ void __launch_bounds__(SG_SKIN_THREADS)
+sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ opacities,
+                   const float *__restrict__ scales, SgGeom g, uint32_t *__restrict__ header,
+                   int32_t *__restrict__ radii, float *__restrict__ posed_xyz, float *__restrict__ posed_rotq,
+                   float *__restrict__ posed_scales)
+{
+    __shared__ float sA[SG_JMAX * 16];
+    __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
+    __shared__ float sT[SG_SKIN_WAVES][64 * 13];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
+    const int idx = g0 + lane;
+    sg_load_A(k, sA);
+    __syncthreads();
+    float T[12];
+    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sW[wave], sT[wave], T);
+    const bool live = idx < P;
+    SgProj o;
+    o.mr = 0; o.tt = 0; o.clampbits = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
+    o.pix[0] = o.pix[1] = 0; o.conic[0] = o.conic[1] = o.conic[2] = 0; o.rgb[0] = o.rgb[1] = o.rgb[2] = 0; o.depth = 0;
+    float opac = 0.0f;
+    if (live) {
+        SgPosed ps;
+        sg_pose_gaussian(k, idx, T, scales, ps);
+        sg_project_fwd<D>(c, ps.p, ps.s3, ps.q, nullptr, nullptr, shs + (size_t)idx * c.M * 3, o);
+        opac = opacities[idx];
+        if (posed_xyz) { posed_xyz[3 * idx] = ps.p[0]; posed_xyz[3 * idx + 1] = ps.p[1]; posed_xyz[3 * idx + 2] = ps.p[2]; }
+        if (posed_rotq) { posed_rotq[4 * idx] = ps.q[0]; posed_rotq[4 * idx + 1] = ps.q[1]; posed_rotq[4 * idx + 2] = ps.q[2]; posed_rotq[4 * idx + 3] = ps.q[3]; }
+        if (posed_scales) { posed_scales[3 * idx] = ps.s3[0]; posed_scales[3 * idx + 1] = ps.s3[1]; posed_scales[3 * idx + 2] = ps.s3[2]; }
+    }
+    sg_store_proj(live, idx, o, opac, g, header, radii);
+}
+
+// Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
+// per workgroup: partial dL/dA [Jp x 16] (matrix cores) and dL/dtransl [3] written to a slab
+// (reduced by sg_skin_reduce_kernel -- no atomics, deterministic).
+template <int D>
+__global__ void __launch_bounds__(SG_SKIN_THREADS)
+sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
+                   const int32_t *__restrict__ radii, SgGeom g, const float4 *__restrict__ grec, size_t cap,
+                   const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+                   float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
+                   float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
+                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
+{
+    __shared__ float sA[SG_JMAX * 16];
+    __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
+    __shared__ float sT[SG_SKIN_WAVES][64 * SG_WSTRIDE];     // T transpose scratch, then the dT tile
+    __shared__ float sRed[SG_SKIN_WAVES][SG_JMAX * 16 + 4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
+    const int idx = g0 + lane;
+    sg_load_A(k, sA);
+    __syncthreads();
+    float T[12];
+    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sW[wave], sT[wave], T);
+    const bool live = idx < P;
+    float dT[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) dT[i] = 0.0f;
+    float dtr[3] = { 0, 0, 0 };
+    if (live) {
+        const int Mrows = c.M;
+        constexpr int nc = (D + 1) * (D + 1);
+        float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+        float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0, g2[2] = { 0, 0 };
+        const bool vis = radii[idx] > 0;
+        const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
+        if (vis || have_in) {
+            SgPosed ps;
+            sg_pose_gaussian(k, idx, T, scales, ps);
+            SgGaussGrad G;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) G.drot[i] = 0;
+            G.g2[0] = G.g2[1] = 0; G.dop = 0;
+            if (vis) {
+                float a9[9];
+                sg_sum_records(grec, cap, g.recC[idx], a9);
+                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, dsh_row, G);
+                for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+            } else {
+                for (int i = 0; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+            }
+            if (dposed_xyz_in) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * idx + i];
+            }
+            if (dposed_rotq_in) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * idx + i];
+            }
+            g2[0] = G.g2[0]; g2[1] = G.g2[1]; dop = G.dop;
+            // scales_posed = scales * s ; p = (T33 x + t) * s + transl
+#pragma unroll
+            for (int i = 0; i < 3; i++) { dsc[i] = G.dsc[i] * ps.sc; dtr[i] = G.dmean[i]; }
+            float dps[3] = { G.dmean[0] * ps.sc, G.dmean[1] * ps.sc, G.dmean[2] * ps.sc };
+            float dRd[9];
+            sg_m2q_bwd(ps.q, ps.best, ps.qab, G.drot, dRd);
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    // dT33 = dp x^T + dRdef Rc^T
+                    dT[4 * i + kx] = dps[i] * ps.x[kx] + dRd[3 * i] * ps.Rc[3 * kx] + dRd[3 * i + 1] * ps.Rc[3 * kx + 1] + dRd[3 * i + 2] * ps.Rc[3 * kx + 2];
+                }
+                dT[4 * i + 3] = dps[i];
+            }
+#pragma unroll
+            for (int kx = 0; kx < 3; kx++) {
+                dxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
+#pragma unroll
+                for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
+                    dRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
+            }
+        } else {
+            for (int i = 0; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+        }
+        dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
+        if (dL_drot_canon) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i];
+        }
+        dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
+        dL_dopacity[idx] = dop;
+        dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
+    }
+    // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
+    float *sdT = sT[wave];
+#pragma unroll
+    for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
+#pragma unroll
+    for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
+    const int nchunk = (k.J + 15) >> 4;
+    float *red = sRed[wave];
+    for (int cch = 0; cch < nchunk; cch++) {
+        sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sW[wave]);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            float av = sW[wave][(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
+            float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
+#pragma unroll
+        for (int r = 0; r < 4; r++) red[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // dtransl: wave sum
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float v = dtr[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) red[SG_JMAX * 16 + i] = v;
+    }
+    __syncthreads();
+    // cross-wave sum (fixed order) -> this workgroup's slab row
+    float *out = slab + (size_t)blockIdx.x * slab_stride;
+    const int nA = nchunk * 256;
+    for (int i = threadIdx.x; i < nA; i += SG_SKIN_THREADS)
+        out[i] = sRed[0][i] + sRed[1][i] + sRed[2][i] + sRed[3][i];
+    if (threadIdx.x < 3) {
+        int i = SG_JMAX * 16 + threadIdx.x;
+        out[SG_JMAX * 16 + threadIdx.x] = sRed[0][i] + sRed[1][i] + sRed[2][i] + sRed[3][i];
+    }
+}
+
+// sums the per-workgroup slabs: dL_dA [J,16] and dL_dtransl [3]
+__global__ void __launch_bounds__(256)
+sg_skin_reduce_kernel(const float *__restrict__ slab, int nblocks, int slab_stride, int J,
+                      float *__restrict__ dL_dA, float *__restrict__ dL_dtransl)
+{
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int nA = J * 16;
+    if (i >= nA + 3) return;
+    int col = i < nA ? i : SG_JMAX * 16 + (i - nA);
+    float s = 0.0f;
+    for (int b = 0; b < nblocks; b++) s += slab[(size_t)b * slab_stride + col];
+    if (i < nA) dL_dA[i] = s;
+    else if (dL_dtransl) dL_dtransl[i - nA] = s;
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
+                        const float *scales, SgGeom g, SgBin b, int32_t *radii, float *posed_xyz, float *posed_rotq,
+                        float *posed_scales, hipStream_t st)
+{
+    if (P <= 0) return;
+    SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
+                 in->ext_trans, in->ext_rot, in->ext_scale };
+    dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
+#define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
+                                     b.header, radii, posed_xyz, posed_rotq, posed_scales)
+    sg_prof_begin(SG_K_PREPROCESS_FWD, st);
+    switch (c.D) { case 0: SG_SF(0); break; case 1: SG_SF(1); break; case 2: SG_SF(2); break; default: SG_SF(3); break; }
+    sg_prof_end(SG_K_PREPROCESS_FWD, st);
+#undef SG_SF
+}
+
+size_t sg_skin_slab_floats(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * (SG_JMAX * 16 + 4); }
+
+void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
+                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
+                        const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
+                        float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
+                        float *dL_dtransl, hipStream_t st)
+{
+    if (P <= 0) return;
+    SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
+                 nullptr, nullptr, nullptr };
+    const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
+    dim3 grid(nblocks), block(SG_SKIN_THREADS);
+#define SG_SB(DD) hipLaunchKernelGGL(sg_skin_bwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
+                                     (const float4 *)grec, cap, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,          \
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
+    sg_prof_begin(SG_K_PREPROCESS_BWD, st);
+    switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
+    hipLaunchKernelGGL(sg_skin_reduce_kernel, dim3((in->J * 16 + 3 + 255) / 256), dim3(256), 0, st, slab, nblocks, stride,
+                       in->J, dL_dA, dL_dtransl);
+    sg_prof_end(SG_K_PREPROCESS_BWD, st);
+#undef SG_SB
+}

@@ -1,0 +1,142 @@
+"""Fused "posed-frame" operator: SMPL-LBS deformation of canonical Gaussians + rasterization.
+
+Opt-in replacement of the LBS block of ``SinGS.forward`` (sings/rec/models/sings_hybrid.py:398-428)
+followed by ``get_render_pkg`` (sings/rec/renderer/gs_renderer_single.py:12-42): the caller hands over
+canonical means / rotations / scales, the skinning weights and the cano->pose joint transforms
+``A_cano2pose = A_t2pose @ inv_A_t2cano`` (:398-399); posed means, rotation quaternions and the
+blended T[N,4,4] never reach HBM.  Gradients flow to xyz_canon, rotmat_canon, scales, opacity, shs,
+``A`` (hence body_pose / global_orient through the SMPL chain in torch) and ``transl``.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rasterizer import _capacity_hint, _f32, _ptr, _settings_struct
+
+
+def _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs, keep):
+    k = _lib.SgSkinInputs()
+    A = _f32(A, "A", dev).reshape(-1, 16)
+    k.J = int(A.shape[0]); k.reserved = 0
+    lbs_weights = _f32(lbs_weights, "lbs_weights", dev)
+    if lbs_weights.shape != (xyz_canon.shape[0], k.J):
+        raise RuntimeError(f"lbs_weights must be [N,{k.J}], got {tuple(lbs_weights.shape)}")
+    ts = [xyz_canon, rotmat_canon, lbs_weights, A,
+          None if smpl_scale is None else _f32(smpl_scale, "smpl_scale", dev).reshape(-1),
+          None if transl is None else _f32(transl, "transl", dev).reshape(-1)]
+    if ext_tfs is not None:
+        tr, rm, sc = ext_tfs
+        ts += [_f32(tr, "ext trans", dev).reshape(-1), _f32(rm, "ext rotmat", dev).reshape(-1),
+               _f32(sc, "ext scale", dev).reshape(-1)]
+    else:
+        ts += [None, None, None]
+    keep.extend(ts)
+    for name, t in zip(("xyz_canon", "rot_canon", "lbs_weights", "A", "smpl_scale", "transl", "ext_trans", "ext_rot",
+                        "ext_scale"), ts):
+        setattr(k, name, None if t is None else t.data_ptr())
+    return k
+
+
+class _RasterizeSkinnedGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xyz_canon, rotmat_canon, scales, opacities, shs, A, transl, lbs_weights, smpl_scale, ext_tfs,
+                raster_settings, return_posed):
+        lib = _lib.load()
+        dev = xyz_canon.device
+        if dev.type != "cuda":
+            raise RuntimeError("sings_amd fused LBS+raster runs on the MI355X only; there is no CPU fallback")
+        rs = raster_settings
+        xyz_canon = _f32(xyz_canon, "xyz_canon", dev)
+        rotmat_canon = None if rotmat_canon is None else _f32(rotmat_canon, "rotmat_canon", dev).reshape(-1, 9)
+        scales = _f32(scales, "scales", dev); opacities = _f32(opacities, "opacities", dev); shs = _f32(shs, "shs", dev)
+        P = int(xyz_canon.shape[0]); H, W = int(rs.image_height), int(rs.image_width); M = int(shs.shape[1])
+        keep = []
+        s = _settings_struct(rs, dev, M, keep)
+        k = _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs, keep)
+        color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((P,), dtype=torch.int32, device=dev)
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        pxyz, pq, psc = (e(P, 3), e(P, 4), e(P, 3)) if return_posed else (None, None, None)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        cap = max(_capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            while True:
+                L = _lib.layout(P, W, H, cap)
+                geom = torch.empty(L.geom_bytes, dtype=torch.uint8, device=dev)
+                binning = torch.empty(L.bin_bytes, dtype=torch.uint8, device=dev)
+                img = torch.empty(L.img_bytes, dtype=torch.uint8, device=dev)
+                nr = C.c_int64(0)
+                _lib.check(lib.sg_skinned_forward(C.byref(s), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales),
+                                                  _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii),
+                                                  _ptr(pxyz), _ptr(pq), _ptr(psc), C.byref(nr), stream), "skinned forward")
+                R = int(nr.value)
+                if R <= cap:
+                    break
+                cap = int(R * 1.25) + 1024
+        _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
+        ctx.rs, ctx.cap, ctx.M, ctx.num_rendered = rs, cap, M, R
+        ctx.has_rot = rotmat_canon is not None
+        ctx.has_ext = ext_tfs is not None
+        ctx.return_posed = return_posed
+        ctx.aux = (lbs_weights, smpl_scale, A.shape, None if transl is None else transl.shape)
+        z = torch.empty(0, device=dev)
+        ctx.save_for_backward(xyz_canon, rotmat_canon if ctx.has_rot else z, scales, opacities, shs,
+                              _f32(A, "A", dev), transl if transl is not None else z, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        if return_posed:
+            ctx.mark_non_differentiable(psc)
+            return color, radii, pxyz, pq, psc
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii=None, g_pxyz=None, g_pq=None, _g_psc=None):
+        lib = _lib.load()
+        if ctx.has_ext:
+            raise RuntimeError("ext_tfs are forward-only (the reference applies them under no_grad: anim_avatar.py:27)")
+        xyz_canon, rotmat_canon, scales, opacities, shs, A, transl, radii, geom, binning, img = ctx.saved_tensors
+        lbs_weights, smpl_scale, A_shape, transl_shape = ctx.aux
+        dev = xyz_canon.device
+        rs = ctx.rs
+        P = int(xyz_canon.shape[0]); H, W = int(rs.image_height), int(rs.image_width)
+        keep = []
+        s = _settings_struct(rs, dev, ctx.M, keep)
+        k = _skin_struct(dev, xyz_canon, rotmat_canon if ctx.has_rot else None, lbs_weights, A, smpl_scale,
+                         transl if transl_shape is not None else None, None, keep)
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        d_xyz, d_scales, d_op, d_sh, d_m2d = e(P, 3), e(P, 3), e(P, 1), e(P, ctx.M, 3), e(P, 3)
+        d_rot = e(P, 9) if ctx.has_rot else None
+        d_A = e(k.J, 16); d_tr = e(3)
+        g_color = _f32(g_color, "grad_out_color", dev)
+        g_pxyz = None if g_pxyz is None else _f32(g_pxyz, "grad posed xyz", dev)
+        g_pq = None if g_pq is None else _f32(g_pq, "grad posed rotq", dev)
+        with torch.cuda.device(dev):
+            L = _lib.layout(P, W, H, ctx.cap)
+            bwd_ws = torch.empty(L.bwd_bytes, dtype=torch.uint8, device=dev)
+            skin_ws = e(int(lib.sg_skin_ws_floats(P)))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_skinned_backward(
+                C.byref(s), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(radii), _ptr(geom),
+                _ptr(binning), ctx.cap, _ptr(img), _ptr(bwd_ws), _ptr(skin_ws), _ptr(g_color), _ptr(g_pxyz), _ptr(g_pq),
+                _ptr(d_xyz), _ptr(d_rot), _ptr(d_scales), _ptr(d_op), _ptr(d_sh), _ptr(d_m2d), _ptr(d_A), _ptr(d_tr),
+                stream), "skinned backward")
+        ctx.viewspace_grad = d_m2d
+        _RasterizeSkinnedGaussians.last_viewspace_grad = d_m2d
+        return (d_xyz, None if d_rot is None else d_rot.view(P, 3, 3), d_scales, d_op.view_as(opacities), d_sh,
+                d_A.view(A_shape), None if transl_shape is None else d_tr.view(transl_shape), None, None, None, None, None)
+
+
+_RasterizeSkinnedGaussians.last_viewspace_grad = None
+
+
+def rasterize_skinned_gaussians(xyz_canon, rotmat_canon, scales, opacities, shs, lbs_weights, A_cano2pose,
+                                raster_settings, smpl_scale=None, transl=None, ext_tfs=None, return_posed=False):
+    """color, radii[, posed_xyz, posed_rotq, posed_scales] = fused LBS + rasterization of one posed frame.
+
+    ``rotmat_canon=None`` means isotropic Gaussians (identity canonical rotation, sings_hybrid.py:358-361).
+    After ``backward`` the screen-space gradient the densifier reads (``viewspace_points.grad`` in the
+    reference, sings_hybrid.py:1013-1015) is at ``_RasterizeSkinnedGaussians.last_viewspace_grad``.
+    """
+    return _RasterizeSkinnedGaussians.apply(xyz_canon, rotmat_canon, scales, opacities, shs, A_cano2pose, transl,
+                                            lbs_weights, smpl_scale, ext_tfs, raster_settings, return_posed)
