@@ -104,11 +104,16 @@ def main():
     eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096)
     eng.set_camera(rs)
 
+    fp = None
+    if dist is not None:
+        from sings_amd.dp import FrameParallel
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"))
+
     def step():
         eng.forward(means3D, shs, opac, scales, rots)
         eng.backward(means3D, shs, opac, scales, rots, dL)
-        if dist is not None:
-            dist.all_reduce(eng.grad_flat)
+        if fp is not None:
+            fp.all_reduce_grads(eng.grad_flat)
 
     for _ in range(a.warmup):
         step()

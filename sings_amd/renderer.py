@@ -1,0 +1,86 @@
+"""Host-side mirror of the reference's render glue (sings/rec/renderer/gs_renderer_single.py:12-107,
+twin gs_renderer_multiple.py:12-132): same function names, argument meaning, returned keys and dtypes,
+so that the reference trainer's call sites (gs_trainer.py:240-244, :561-575, :695-714) work unchanged.
+
+Two entry points beyond the mirror:
+ * ``get_render_pkgs`` concatenates several avatars before ONE raster call (gs_renderer_multiple.py:12-68);
+ * ``get_render_pkg_fused`` takes CANONICAL Gaussians + joint transforms and runs the LBS-fused kernels.
+"""
+import math
+
+import torch
+
+from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
+from .skinned import rasterize_skinned_gaussians, _RasterizeSkinnedGaussians
+
+
+def get_render_pkg(data, human_gs_out, bg_color, scaling_modifier=1.0):
+    render_pkg = render(means3D=human_gs_out['xyz'], feats=human_gs_out['shs'], opacity=human_gs_out['opacity'],
+                        scales=human_gs_out['scales'], rotations=human_gs_out['rotq'], data=data,
+                        scaling_modifier=scaling_modifier, bg_color=bg_color,
+                        active_sh_degree=human_gs_out['active_sh_degree'])
+    render_pkg['human_visibility_filter'] = render_pkg['visibility_filter']
+    render_pkg['human_radii'] = render_pkg['radii']
+    return render_pkg
+
+
+def get_render_pkgs(data, human_gs_outs, bg_color, scaling_modifier=1.0):
+    """Several avatars in one frame: concatenate then rasterize once (gs_renderer_multiple.py:12-68)."""
+    cat = lambda k: torch.cat([h[k] for h in human_gs_outs], dim=0)
+    render_pkg = render(means3D=cat('xyz'), feats=cat('shs'), opacity=cat('opacity'), scales=cat('scales'),
+                        rotations=cat('rotq'), data=data, scaling_modifier=scaling_modifier, bg_color=bg_color,
+                        active_sh_degree=human_gs_outs[0]['active_sh_degree'])
+    render_pkg['human_visibility_filter'] = render_pkg['visibility_filter']
+    render_pkg['human_radii'] = render_pkg['radii']
+    return render_pkg
+
+
+def _settings(data, bg_color, scaling_modifier, active_sh_degree):
+    return GaussianRasterizationSettings(
+        image_height=int(data['image_height']), image_width=int(data['image_width']),
+        tanfovx=math.tan(data['fovx'] * 0.5), tanfovy=math.tan(data['fovy'] * 0.5), bg=bg_color,
+        scale_modifier=scaling_modifier, viewmatrix=data['world_view_transform'],
+        projmatrix=data['full_proj_transform'], sh_degree=active_sh_degree, campos=data['camera_center'],
+        prefiltered=False, debug=False)
+
+
+def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.0, bg_color=None, active_sh_degree=0):
+    dev = means3D.device
+    if bg_color is None:
+        bg_color = torch.zeros(3, dtype=torch.float32, device=dev)
+    screenspace_points = torch.zeros_like(means3D, dtype=means3D.dtype, requires_grad=True, device=dev) + 0
+    try:
+        screenspace_points.retain_grad()
+    except Exception:
+        pass
+    shs, rgb = (None, feats) if feats.dim() == 2 else (feats, None)
+    rasterizer = GaussianRasterizer(raster_settings=_settings(data, bg_color, scaling_modifier, active_sh_degree))
+    rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, opacities=opacity,
+                                       scales=scales, rotations=rotations, colors_precomp=rgb)
+    rendered_image = torch.clamp(rendered_image, 0.0, 1.0)
+    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
+            "radii": radii}
+
+
+class _ViewspaceGrad:
+    """Stand-in for ``viewspace_points`` of the fused path: ``.grad`` is filled by backward
+    (consumer: SinGS.add_densification_stats, sings_hybrid.py:1013-1015)."""
+
+    @property
+    def grad(self):
+        return _RasterizeSkinnedGaussians.last_viewspace_grad
+
+
+def get_render_pkg_fused(data, canon, A_cano2pose, bg_color, smpl_scale=None, transl=None, ext_tfs=None,
+                         scaling_modifier=1.0, return_posed=False):
+    """canon: dict(xyz_canon, rotmat_canon|None, scales, opacity, shs, lbs_weights, active_sh_degree)."""
+    rs = _settings(data, bg_color, scaling_modifier, canon['active_sh_degree'])
+    out = rasterize_skinned_gaussians(canon['xyz_canon'], canon.get('rotmat_canon'), canon['scales'], canon['opacity'],
+                                      canon['shs'], canon['lbs_weights'], A_cano2pose, rs, smpl_scale=smpl_scale,
+                                      transl=transl, ext_tfs=ext_tfs, return_posed=return_posed)
+    radii = out[1]
+    pkg = {"render": torch.clamp(out[0], 0.0, 1.0), "viewspace_points": _ViewspaceGrad(), "visibility_filter": radii > 0,
+           "radii": radii, "human_visibility_filter": radii > 0, "human_radii": radii}
+    if return_posed:
+        pkg.update(xyz=out[2], rotq=out[3], scales=out[4])
+    return pkg

@@ -1,0 +1,82 @@
+"""Frame-parallel host logic on CPU: world_size-2 gloo processes."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sings_amd.dp import FrameParallel, FrameSharder
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, algorithm, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fp = FrameParallel(algorithm=algorithm)
+        n = 1003                                       # not a multiple of world: exercises padding
+        g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+        fp.all_reduce_grads(g)
+        acc = torch.full((50,), float(rank + 1)); den = torch.ones(50); rad = torch.arange(50, dtype=torch.int32) * (rank + 1)
+        fp.reduce_densification_stats(acc, den, rad)
+        p = torch.full((7,), float(rank))
+        fp.broadcast_([p])
+        loss = fp.reduce_scalar(float(rank), "mean")
+        sh = FrameSharder(71, world, rank, seed=5)
+        out.put((rank, g.numpy(), acc.numpy(), den.numpy(), rad.numpy(), p.numpy(), loss,
+                 [sh.frame(t) for t in range(80)], sh.eval_frames()))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(algorithm):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, algorithm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def _check(res):
+    exp = np.arange(1003, dtype=np.float32) * 3
+    for r in res:
+        assert np.array_equal(r[1], exp)
+        assert (r[2] == 3).all() and (r[3] == 2).all()
+        assert np.array_equal(r[4], np.arange(50) * 2)
+        assert (r[5] == 0).all()
+        assert abs(r[6] - 0.5) < 1e-12
+    # per step the two ranks render different frames; over one epoch every frame is rendered once
+    f0, f1 = res[0][7], res[1][7]
+    assert all(a != b for a, b in zip(f0, f1))
+    epoch = [x for pair in zip(f0, f1) for x in pair][:71]
+    assert sorted(epoch) == list(range(71))
+    assert sorted(res[0][8] + res[1][8]) == list(range(71))
+
+
+def test_all_reduce_world2():
+    _check(_run("all_reduce"))
+
+
+def test_reduce_scatter_all_gather_world2():
+    _check(_run("rs_ag"))
+
+
+def test_sharder_is_deterministic_and_rank_consistent():
+    a = FrameSharder(120, 8, 3, seed=1)
+    assert [a.frame(t) for t in range(40)] == [FrameSharder(120, 8, 3, seed=1).frame(t) for t in range(40)]
+    for t in range(30):
+        fr = a.frames_of_step(t)
+        assert len(set(fr)) == 8 and fr[3] == a.frame(t)
