@@ -48,6 +48,9 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_pair_keys = o; o = sg_align(o + (cap + 1) * 8);
     L->bin_point_list = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_point_keys = o; o = sg_align(o + (cap + 1) * 8);
+    L->bin_pair_gid = o; o = sg_align(o + (cap + 1) * 4);
+    L->bin_pair_tile = o; o = sg_align(o + (cap + 1) * 4);
+    L->bin_pair_local = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);
@@ -96,7 +99,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     // header + tile counters zeroed every call (stream-ordered)
     hipError_t e = hipMemsetAsync(b.header, 0, L.bin_ranges - L.bin_header, st);
     if (e != hipSuccess) return sg_fail("memset", e);
-    sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, radii, st);
+    sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
     SG_CHECK_LAST("binning", s, st);
@@ -179,7 +182,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SgImg im = sg_img_view(image_ws, L);
     hipError_t e = hipMemsetAsync(b.header, 0, L.bin_ranges - L.bin_header, st);
     if (e != hipSuccess) return sg_fail("memset", e);
-    sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, radii, posed_xyz, posed_rotq, posed_scales, st);
+    sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, 0, st);
     SG_CHECK_LAST("binning", s, st);

@@ -6,28 +6,17 @@
 // tile with equal depth bits come from different Gaussians and a stable sort keeps them in
 // ascending Gaussian id, so the order is exactly the lexicographic order of
 // (tile, depth_bits, gaussian_id).  MI355X-first formulation (integer, HBM-light):
-//   1. count  : one lane per Gaussian adds 1 to tile_count[t] for every tile of its rectangle
+//   1. count  : fused into the preprocess kernel (sg_project.h::sg_store_proj): every
+//               (tile,Gaussian) pair takes a RETURNING atomic on its tile counter and records
+//               (Gaussian, tile, arrival rank) in Gaussian-major order, load-balanced per wave
 //   2. scan   : one 1024-thread workgroup turns counts into [start,end) ranges, R = total
-//   3. scatter: one lane per Gaussian writes (depth_bits<<32 | id) into its tiles' segments
-//   4. sort   : one workgroup per tile sorts its segment in LDS (bitonic, u64 keys) and
-//               writes point_list (and, on request, the upstream-format keys)
-// Traffic: 8 B written + 8 B read + 4 B written per pair, instead of six 24-B/pair radix passes.
+//   3. scatter: one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id
+//   4. sort   : one wave per tile sorts its segment in LDS (bitonic, u64 keys; one workgroup per
+//               tile for lists longer than 256) and writes point_list (+ upstream-format keys)
+// Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
 #include "sg_common.h"
 
-__global__ void __launch_bounds__(256)
-sg_tile_count_kernel(int P, const int32_t *__restrict__ radii, const float4 *__restrict__ recC, int gx,
-                     uint32_t *__restrict__ tile_count)
-{
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
-    float4 rc = recC[idx];
-    uint32_t mn = __float_as_uint(rc.z), wh = __float_as_uint(rc.w);
-    int x0 = mn & 0xffff, y0 = mn >> 16, w = wh & 0xffff, h = wh >> 16;
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) atomicAdd(&tile_count[(y0 + y) * gx + x0 + x], 1u);
-}
-
-// single workgroup, 1024 threads: exclusive scan over T tile counts
+// single workgroup, 1024 threads x 8 consecutive tiles each: exclusive scan over T tile counts
 __global__ void __launch_bounds__(1024)
 sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap)
@@ -37,10 +26,12 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__res
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     if (tid == 0) carry_s = 0;
     __syncthreads();
-    for (int base = 0; base < T; base += 1024) {
-        int i = base + tid;
-        uint32_t v = i < T ? tile_count[i] : 0u;
-        uint32_t incl = v;
+    for (int base = 0; base < T; base += 8192) {
+        const int i0 = base + tid * 8;
+        uint32_t v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { v[k] = i0 + k < T ? tile_count[i0 + k] : 0u; sum += v[k]; }
+        uint32_t incl = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t u = __shfl_up(incl, o, 64);
@@ -50,15 +41,18 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__res
         __syncthreads();
         uint32_t woff = 0;
         for (int w = 0; w < wid; w++) woff += wsum[w];
-        uint32_t carry = carry_s;
-        uint32_t start = carry + woff + incl - v;
-        if (i < T) {
-            uint32_t s = start < cap ? start : cap, e = start + v < cap ? start + v : cap;
-            ranges[i] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
-            cursor[i] = start;
+        uint32_t start = carry_s + woff + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k < T) {
+                uint32_t s = start < cap ? start : cap, e = start + v[k] < cap ? start + v[k] : cap;
+                ranges[i0 + k] = v[k] ? make_uint2(s, e) : make_uint2(0u, 0u);
+                cursor[i0 + k] = start;
+            }
+            start += v[k];
         }
         __syncthreads();
-        if (tid == 1023) carry_s = start + v;
+        if (tid == 1023) carry_s = start;
         __syncthreads();
     }
     if (tid == 0) {
@@ -68,22 +62,19 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__res
     }
 }
 
+// one lane per pair (Gaussian-major list written by the preprocess); no atomics
 __global__ void __launch_bounds__(256)
-sg_tile_scatter_kernel(int P, const int32_t *__restrict__ radii, const float4 *__restrict__ recC,
-                       const float *__restrict__ depth, int gx, uint32_t *__restrict__ cursor,
+sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ pair_gid,
+                       const uint32_t *__restrict__ pair_tile, const uint32_t *__restrict__ pair_local,
+                       const float *__restrict__ depth, const uint32_t *__restrict__ start,
                        uint64_t *__restrict__ pair_keys, uint32_t cap)
 {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P || !(radii[idx] > 0)) return;
-    float4 rc = recC[idx];
-    uint32_t mn = __float_as_uint(rc.z), wh = __float_as_uint(rc.w);
-    int x0 = mn & 0xffff, y0 = mn >> 16, w = wh & 0xffff, h = wh >> 16;
-    uint64_t key = ((uint64_t)__float_as_uint(depth[idx]) << 32) | (uint32_t)idx;
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
-            uint32_t slot = atomicAdd(&cursor[(y0 + y) * gx + x0 + x], 1u);
-            if (slot < cap) pair_keys[slot] = key;
-        }
+    const uint32_t R = header[0] < cap ? header[0] : cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+        uint32_t gid = pair_gid[i];
+        uint32_t slot = start[pair_tile[i]] + pair_local[i];
+        if (slot < cap) pair_keys[slot] = ((uint64_t)__float_as_uint(depth[gid]) << 32) | gid;
+    }
 }
 
 // ---- per-tile sort ---------------------------------------------------------------------
@@ -106,6 +97,44 @@ __device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid, int
     }
 }
 
+#define SG_WSORT_MAX 256   // longest list sorted by a single wave
+
+// one wave per tile, 4 tiles per workgroup, no workgroup barriers
+__global__ void __launch_bounds__(256)
+sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t *__restrict__ pair_keys,
+                         uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+{
+    __shared__ uint64_t sall[4][SG_WSORT_MAX];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = blockIdx.x * 4 + wave;
+    if (tile >= T) return;
+    const uint2 r = ranges[tile];
+    const int n = (int)(r.y - r.x);
+    if (n == 0 || n > SG_WSORT_MAX) return;
+    uint64_t *s = sall[wave];
+    int n2 = 1; while (n2 < n) n2 <<= 1;
+    for (int i = lane; i < n2; i += 64) s[i] = i < n ? pair_keys[r.x + i] : ~0ull;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (n2 >> 1); t += 64) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+                bool up = (i & k) == 0;
+                uint64_t a = s[i], b = s[ixj];
+                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    for (int i = lane; i < n; i += 64) {
+        uint64_t kx = s[i];
+        point_list[r.x + i] = (uint32_t)kx;
+        if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (kx >> 32);
+    }
+}
+
+// long lists: one workgroup per tile
 __global__ void __launch_bounds__(SG_SORT_THREADS)
 sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
                     uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
@@ -114,7 +143,7 @@ sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pai
     const int tile = blockIdx.x, tid = threadIdx.x;
     uint2 r = ranges[tile];
     uint32_t n = r.y - r.x;
-    if (n == 0) return;
+    if (n <= SG_WSORT_MAX) return;
     uint64_t *seg = pair_keys + r.x;
     if (n <= SG_SORT_LDS) {
         int n2 = 1; while (n2 < (int)n) n2 <<= 1;
@@ -160,22 +189,25 @@ sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pai
 void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st)
 {
+    (void)radii;
     const int T = c.gx * c.gy;
-    uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
-    sg_prof_begin(SG_K_TILE_COUNT, st);
-    if (P > 0)
-        hipLaunchKernelGGL(sg_tile_count_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, g.recC, c.gx, b.tile_count);
-    sg_prof_end(SG_K_TILE_COUNT, st);
+    const uint32_t cap32 = sg_cap32(cap);
+    uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
     hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.ranges, b.cursor, b.header, cap32);
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
-    if (P > 0)
-        hipLaunchKernelGGL(sg_tile_scatter_kernel, dim3((P + 255) / 256), dim3(256), 0, st, P, radii, g.recC, g.depth,
-                           c.gx, b.cursor, b.pair_keys, cap32);
+    if (P > 0) {
+        size_t want = (cap + 255) / 256;
+        int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
+        hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
+                           b.pair_local, g.depth, b.cursor, b.pair_keys, cap32);
+    }
     sg_prof_end(SG_K_TILE_SCATTER, st);
     sg_prof_begin(SG_K_TILE_SORT, st);
+    hipLaunchKernelGGL(sg_tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, st, T, b.ranges, b.pair_keys,
+                       b.point_list, pk);
     hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T), dim3(SG_SORT_THREADS), 0, st, b.ranges, b.pair_keys,
-                       b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr);
+                       b.point_list, pk);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

@@ -24,6 +24,9 @@ struct SgBin {
     uint64_t *pair_keys;   // [cap] (depth_bits << 32 | gid), grouped by tile, sorted in place
     uint32_t *point_list;  // [cap] sorted Gaussian ids
     uint64_t *point_keys;  // [cap] optional upstream-format keys
+    uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
+    uint32_t *pair_tile;   //       tile id,
+    uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
 };
 
 struct SgImg {
@@ -50,6 +53,8 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.ranges = (uint2 *)(b + L.bin_ranges); g.cursor = (uint32_t *)(b + L.bin_cursor);
     g.pair_keys = (uint64_t *)(b + L.bin_pair_keys); g.point_list = (uint32_t *)(b + L.bin_point_list);
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);
+    g.pair_gid = (uint32_t *)(b + L.bin_pair_gid); g.pair_tile = (uint32_t *)(b + L.bin_pair_tile);
+    g.pair_local = (uint32_t *)(b + L.bin_pair_local);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
@@ -72,9 +77,10 @@ struct SgCam {
 void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, SgGeom g, SgBin b,
-                              int32_t *radii, hipStream_t st);
+                              size_t cap, int32_t *radii, hipStream_t st);
 void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st);
+static inline uint32_t sg_cap32(size_t cap) { return cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap; }
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           hipStream_t st);
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
@@ -93,8 +99,8 @@ void sg_prof_end(int id, hipStream_t st);
 
 // LBS-fused per-Gaussian kernels (sg_skin.hip)
 void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
-                        const float *scales, SgGeom g, SgBin b, int32_t *radii, float *posed_xyz, float *posed_rotq,
-                        float *posed_scales, hipStream_t st);
+                        const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
+                        float *posed_rotq, float *posed_scales, hipStream_t st);
 size_t sg_skin_slab_floats(int P);
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,

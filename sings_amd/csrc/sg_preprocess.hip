@@ -13,7 +13,7 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
                          const float *__restrict__ shs, const float *__restrict__ colors_precomp,
                          const float *__restrict__ opacities, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         SgGeom g, uint32_t *__restrict__ header, int32_t *__restrict__ radii)
+                         SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii)
 {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = idx < P;
@@ -33,18 +33,18 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
                           shs ? shs + (size_t)idx * c.M * 3 : nullptr, o);
         opac = opacities[idx];
     }
-    sg_store_proj(live, idx, o, opac, g, header, radii);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii);
 }
 
 void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, SgGeom g, SgBin b,
-                              int32_t *radii, hipStream_t st)
+                              size_t cap, int32_t *radii, hipStream_t st)
 {
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
 #define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
-                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b.header, radii)
+                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii)
     int D = colors_precomp ? 0 : c.D;
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (D) { case 0: SG_PP(0); break; case 1: SG_PP(1); break; case 2: SG_PP(2); break; default: SG_PP(3); break; }

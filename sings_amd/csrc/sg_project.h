@@ -86,33 +86,63 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
     }
 }
 
-// Stores the projected record.  MUST be reached by every lane of the wave (live or not): the
-// Gaussian-major slots of the backward gradient records are allocated with one atomic per wave.
-__device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g,
-                                              uint32_t *__restrict__ header, int32_t *__restrict__ radii)
+// Stores the projected record and bins the Gaussian.  MUST be reached by every lane of the wave
+// (live or not) of a 256-thread workgroup.
+//  * the Gaussian-major slots [base, base+total) of this wave's (tile,Gaussian) pairs are reserved
+//    with ONE atomic per wave (prefix sum over tiles_touched);
+//  * the pairs are then expanded load-balanced: lane l of pass c handles pair 64c + l of the wave
+//    (binary search of the owner in the wave's prefix sums held in LDS), adds 1 to its tile's
+//    counter with a RETURNING atomic and records (Gaussian, tile, arrival rank) -- the scatter that
+//    follows the tile scan then needs no atomics at all.
+__device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
+                                              int gx, uint32_t cap, int32_t *__restrict__ radii)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ uint32_t sIncl[4][64], sMin[4][64], sWid[4][64];
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
     uint32_t incl = o.tt;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
         uint32_t v = __shfl_up(incl, s, 64);
         if (lane >= s) incl += v;
     }
-    uint32_t total = __shfl(incl, 63, 64);
+    const uint32_t total = __shfl(incl, 63, 64);
     uint32_t base = 0;
-    if (lane == 63 && total) base = atomicAdd(&header[2], total);
+    if (lane == 63 && total) base = atomicAdd(&bn.header[2], total);
     base = __shfl(base, 63, 64);
+    const uint32_t rmin = (uint32_t)o.x0 | ((uint32_t)o.y0 << 16);
+    const uint32_t rwh = (uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16);
     if (live) {
         uint32_t goff = base + incl - o.tt;
         radii[idx] = o.mr;
         g.recA[idx] = make_float4(o.pix[0], o.pix[1], o.conic[0], o.conic[1]);
         g.recB[idx] = make_float4(o.conic[2], o.mr ? opac : 0.0f, o.rgb[0], o.rgb[1]);
-        g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(goff),
-                                  __uint_as_float((uint32_t)o.x0 | ((uint32_t)o.y0 << 16)),
-                                  __uint_as_float((uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16)));
+        g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(goff), __uint_as_float(rmin), __uint_as_float(rwh));
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
+    if (total == 0) return;                       // wave-uniform
+    sIncl[wave][lane] = incl; sMin[wave][lane] = rmin; sWid[wave][lane] = rwh & 0xffffu;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    const int g0 = idx - lane;
+    for (uint32_t p = lane; p < total; p += 64) {
+        int lo = 0, hi = 63;                      // smallest j with incl[j] > p
+#pragma unroll
+        for (int it = 0; it < 6; it++) {
+            int mid = (lo + hi) >> 1;
+            if (sIncl[wave][mid] > p) hi = mid; else lo = mid + 1;
+        }
+        const int j = lo;
+        const uint32_t excl = j ? sIncl[wave][j - 1] : 0u;
+        const uint32_t t = p - excl, w = sWid[wave][j], mn = sMin[wave][j];
+        const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)w);      // exact floor: t, w < 2^16
+        const uint32_t tx = t - ty * w;
+        const uint32_t tile = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
+        const uint32_t local = atomicAdd(&bn.tile_count[tile], 1u);
+        const uint32_t slot = base + p;
+        if (slot < cap) { bn.pair_gid[slot] = (uint32_t)(g0 + j); bn.pair_tile[slot] = tile; bn.pair_local[slot] = local; }
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 
 struct SgGaussGrad {

@@ -209,7 +209,7 @@ __device__ __forceinline__ void sg_load_A(const SgSkin &k, float *__restrict__ s
 template <int D>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ opacities,
-                   const float *__restrict__ scales, SgGeom g, uint32_t *__restrict__ header,
+                   const float *__restrict__ scales, SgGeom g, SgBin bn, uint32_t cap,
                    int32_t *__restrict__ radii, float *__restrict__ posed_xyz, float *__restrict__ posed_rotq,
                    float *__restrict__ posed_scales)
 {
@@ -237,7 +237,7 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         if (posed_rotq) { posed_rotq[4 * idx] = ps.q[0]; posed_rotq[4 * idx + 1] = ps.q[1]; posed_rotq[4 * idx + 2] = ps.q[2]; posed_rotq[4 * idx + 3] = ps.q[3]; }
         if (posed_scales) { posed_scales[3 * idx] = ps.s3[0]; posed_scales[3 * idx + 1] = ps.s3[1]; posed_scales[3 * idx + 2] = ps.s3[2]; }
     }
-    sg_store_proj(live, idx, o, opac, g, header, radii);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii);
 }
 
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
@@ -396,15 +396,15 @@ sg_skin_reduce_kernel(const float *__restrict__ slab, int nblocks, int slab_stri
 
 // ---- launchers ---------------------------------------------------------------------------
 void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
-                        const float *scales, SgGeom g, SgBin b, int32_t *radii, float *posed_xyz, float *posed_rotq,
-                        float *posed_scales, hipStream_t st)
+                        const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
+                        float *posed_rotq, float *posed_scales, hipStream_t st)
 {
     if (P <= 0) return;
     SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
                  in->ext_trans, in->ext_rot, in->ext_scale };
     dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
 #define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
-                                     b.header, radii, posed_xyz, posed_rotq, posed_scales)
+                                     b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales)
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (c.D) { case 0: SG_SF(0); break; case 1: SG_SF(1); break; case 2: SG_SF(2); break; default: SG_SF(3); break; }
     sg_prof_end(SG_K_PREPROCESS_FWD, st);
