@@ -237,7 +237,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     if (n == 0) return;
     const size_t hw = (size_t)H * W;
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    float Tr[4], Tfin[4], ar0[4], ar1[4], ar2[4], lc0[4], lc1[4], lc2[4], la[4], d0[4], d1[4], d2[4], bgd[4];
+    // per-pixel state (x4 quadrants): running T, colour accumulated BEHIND the current entry (S), dL/dpixel,
+    // T_final * <bg, dL/dpixel>, n_contrib
+    float Tr[4], S0[4], S1[4], S2[4], d0[4], d1[4], d2[4], tb[4];
     uint32_t ncq[4];
     uint32_t maxc[4];
     int max_contrib = 0;
@@ -246,11 +248,11 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         const int px = X0 + 8 * (q & 1) + lx, py = Y0 + 8 * (q >> 1) + ly;
         const bool inside = px < W && py < H;
         const size_t pid = (size_t)py * W + px;
-        Tfin[q] = inside ? final_T[pid] : 0.0f;
+        const float Tfin = inside ? final_T[pid] : 0.0f;
         ncq[q] = inside ? n_contrib[pid] : 0u;
         d0[q] = inside ? dL_dpix[pid] : 0.0f; d1[q] = inside ? dL_dpix[hw + pid] : 0.0f; d2[q] = inside ? dL_dpix[2 * hw + pid] : 0.0f;
-        bgd[q] = bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q];
-        Tr[q] = Tfin[q]; ar0[q] = ar1[q] = ar2[q] = 0.0f; lc0[q] = lc1[q] = lc2[q] = 0.0f; la[q] = 0.0f;
+        tb[q] = Tfin * (bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q]);
+        Tr[q] = Tfin; S0[q] = S1[q] = S2[q] = 0.0f;
         uint32_t m = ncq[q];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
@@ -297,41 +299,35 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             const float4 ga = L.sA[k], gb = L.sB[k];
             const float gc = L.sC[k];
             const uint32_t ee = mm >> 4;
+            // v[0..4]: sums of w*m with w = G dL/dalpha; the per-Gaussian factors (-o W/2, -o H/2, -o/2)
+            // are applied once per record when it is flushed (the reduction is linear).
             float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
             bool hit = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!(mm & (1u << q))) continue;                 // wave-uniform
                 if (!(ee < ncq[q])) continue;
-                float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
-                float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
+                const float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
+                const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
                 if (power > 0.0f) continue;
-                float G = sg_exp(power);
-                float alpha = fminf(0.99f, gb.y * G);
+                const float G = sg_exp(power);
+                const float alpha = fminf(0.99f, gb.y * G);
                 if (alpha < 1.0f / 255.0f) continue;
                 hit = true;
-                float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
-                Tr[q] = Tr[q] * rinv;
-                float dchan = alpha * Tr[q];
-                ar0[q] = fmaf(la[q], lc0[q], (1.0f - la[q]) * ar0[q]);
-                ar1[q] = fmaf(la[q], lc1[q], (1.0f - la[q]) * ar1[q]);
-                ar2[q] = fmaf(la[q], lc2[q], (1.0f - la[q]) * ar2[q]);
-                lc0[q] = gb.z; lc1[q] = gb.w; lc2[q] = gc;
-                float dL_dalpha = (gb.z - ar0[q]) * d0[q] + (gb.w - ar1[q]) * d1[q] + (gc - ar2[q]) * d2[q];
-                v[6] += dchan * d0[q]; v[7] += dchan * d1[q]; v[8] += dchan * d2[q];
-                dL_dalpha *= Tr[q];
-                la[q] = alpha;
-                dL_dalpha += (-Tfin[q] * rinv) * bgd[q];
-                float dL_dG = gb.y * dL_dalpha;
-                float gdx = G * dx, gdy = G * dy;
-                float dG_ddelx = -gdx * ga.z - gdy * ga.w;
-                float dG_ddely = -gdy * gb.x - gdx * ga.w;
-                v[0] += dL_dG * dG_ddelx * ddelx_dx;
-                v[1] += dL_dG * dG_ddely * ddely_dy;
-                v[2] += -0.5f * gdx * dx * dL_dG;
-                v[3] += -0.5f * gdx * dy * dL_dG;
-                v[4] += -0.5f * gdy * dy * dL_dG;
-                v[5] += G * dL_dalpha;
+                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                Tr[q] = Tr[q] * rinv;                            // T in front of this entry
+                const float dchan = alpha * Tr[q];
+                const float e0 = gb.z - S0[q], e1 = gb.w - S1[q], e2 = gc - S2[q];
+                float dLa = fmaf(e2, d2[q], fmaf(e1, d1[q], e0 * d0[q]));
+                S0[q] = fmaf(alpha, e0, S0[q]); S1[q] = fmaf(alpha, e1, S1[q]); S2[q] = fmaf(alpha, e2, S2[q]);
+                v[6] = fmaf(dchan, d0[q], v[6]); v[7] = fmaf(dchan, d1[q], v[7]); v[8] = fmaf(dchan, d2[q], v[8]);
+                dLa = fmaf(-tb[q], rinv, dLa * Tr[q]);          // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
+                const float w = G * dLa;                         // = dL/dopacity contribution; dL/dG = o * dLa
+                v[5] += w;
+                v[0] = fmaf(w, fmaf(dy, ga.w, dx * ga.z), v[0]);
+                v[1] = fmaf(w, fmaf(dx, ga.w, dy * gb.x), v[1]);
+                const float wx = w * dx;
+                v[2] = fmaf(wx, dx, v[2]); v[3] = fmaf(wx, dy, v[3]); v[4] = fmaf(w * dy, dy, v[4]);
             }
             if (__ballot(hit) == 0ull) {                         // wave-uniform
                 if (lane < 9) L.sG[k][lane] = 0.0f;
@@ -348,8 +344,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             uint32_t r = L.sR[lane];
             if (r < cap) {
                 const float *s = L.sG[lane];
-                grec[3 * (size_t)r] = make_float4(s[0], s[1], s[2], s[3]);
-                grec[3 * (size_t)r + 1] = make_float4(s[4], s[5], s[6], s[7]);
+                const float no = -L.sB[lane].y, nh = 0.5f * no;          // -opacity, -opacity / 2
+                grec[3 * (size_t)r] = make_float4(no * ddelx_dx * s[0], no * ddely_dy * s[1], nh * s[2], nh * s[3]);
+                grec[3 * (size_t)r + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
                 grec[3 * (size_t)r + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
             }
         }
