@@ -33,26 +33,46 @@ __device__ __forceinline__ int sg_tile_of_wave(int block, int wave, int nblocks)
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
-// alpha = min(.99, o exp(power)) >= 1/255  =>  power >= -tau, tau = ln(255 o): the pixel lies in the
-// ellipse d^T conic d <= 2 tau, whose bounding box has half extents sqrt(2 tau Sigma_xx|yy).
-// Inflated (tau, extents) so that fp32 rounding of power / exp can never make it exclude a pixel the
-// blend loop would accept; ill-conditioned conics fall back to "all quadrants".
+// alpha = min(.99, o exp(power)) >= 1/255  =>  power >= -tau, tau = ln(255 o), i.e. the pixel lies in the
+// ellipse q(d) = A dx^2 + 2 B dx dy + C dy^2 <= 2 tau (d = pixel - mean).  A quadrant is kept iff the
+// minimum of q over its pixel rectangle (0 if the mean is inside, else the minimum over the four edges,
+// each a clamped 1-D parabola) is within the bound.  tau and the comparison carry safety margins far
+// above the fp32 rounding of power / exp / this test, so a pixel the blend loop would accept is never
+// dropped; ill-conditioned conics keep all quadrants.
+__device__ __forceinline__ float sg_min_q_rect(float A, float B, float C, float mx, float my, float x0, float x1,
+                                               float y0, float y1)
+{
+    if (mx >= x0 && mx <= x1 && my >= y0 && my <= y1) return 0.0f;
+    const float rA = __builtin_amdgcn_rcpf(A), rC = __builtin_amdgcn_rcpf(C);
+    float best = 3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        float dx = (e ? x1 : x0) - mx;
+        float dy = fminf(fmaxf(-B * dx * rC, y0 - my), y1 - my);
+        best = fminf(best, fmaf(A * dx, dx, fmaf(2.0f * B * dx, dy, C * dy * dy)));
+        float dy2 = (e ? y1 : y0) - my;
+        float dx2 = fminf(fmaxf(-B * dy2 * rA, x0 - mx), x1 - mx);
+        best = fminf(best, fmaf(A * dx2, dx2, fmaf(2.0f * B * dx2, dy2, C * dy2 * dy2)));
+    }
+    return best;
+}
+
 __device__ __forceinline__ uint32_t sg_quad_mask(float4 a, float4 b, float X0, float Y0)
 {
-    float o255 = 255.0f * b.y;
+    const float o255 = 255.0f * b.y;
     if (!(o255 >= 0.999f)) return 0u;
-    float tau = __logf(o255) * 1.002f + 0.004f;
-    float A = a.z, B = a.w, C = b.x;
-    float det = A * C - B * B;
+    const float bound = 2.0f * (__logf(o255) * 1.002f + 0.004f) + 0.01f;
+    const float A = a.z, B = a.w, C = b.x;
+    const float det = A * C - B * B;
     if (!(det > 1e-3f * A * C) || !(A > 0.0f) || !(C > 0.0f)) return 0xFu;
-    float k = 2.06f * tau / det;
-    float hx = sqrtf(k * C) + 0.05f, hy = sqrtf(k * A) + 0.05f;
-    float xl = a.x - hx - X0, xh = a.x + hx - X0, yl = a.y - hy - Y0, yh = a.y + hy - Y0;
-    uint32_t mx = (xl <= 7.0f && xh >= 0.0f ? 1u : 0u) | (xl <= 15.0f && xh >= 8.0f ? 2u : 0u);
-    uint32_t my = (yl <= 7.0f && yh >= 0.0f ? 1u : 0u) | (yl <= 15.0f && yh >= 8.0f ? 2u : 0u);
+    const float mx = a.x - X0, my = a.y - Y0;
     uint32_t m = 0;
-    if (my & 1u) m |= mx;
-    if (my & 2u) m |= mx << 2;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const float x0 = 8.0f * (q & 1), y0 = 8.0f * (q >> 1);
+        float mq = sg_min_q_rect(A, B, C, mx, my, x0, x0 + 7.0f, y0, y0 + 7.0f);
+        if (mq * 0.999f <= bound) m |= 1u << q;
+    }
     return m;
 }
 
