@@ -142,19 +142,20 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             const uint32_t contributor = (mm >> 4) + 1u;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (!(mm & (1u << q))) continue;                 // wave-uniform
-                if ((dmask >> q) & 1u) continue;
-                float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
-                float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
-                if (power > 0.0f) continue;
-                float alpha = fminf(0.99f, gb.y * sg_exp(power));
-                if (alpha < 1.0f / 255.0f) continue;
-                float test_T = Tq[q] * (1.0f - alpha);
-                if (test_T < 0.0001f) { dmask |= 1u << q; continue; }
-                float w = alpha * Tq[q];
+                if (!(mm & (1u << q))) continue;                 // wave-uniform (scalar branch)
+                // straight-line, predicated: no exec-mask branches inside a quadrant pass
+                const float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
+                const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
+                const float alpha = fminf(0.99f, gb.y * sg_exp(power));
+                const float test_T = Tq[q] * (1.0f - alpha);
+                const bool valid = !((dmask >> q) & 1u) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                const bool term = valid & (test_T < 0.0001f);
+                const bool blend = valid & !term;
+                const float w = blend ? alpha * Tq[q] : 0.0f;
                 C0[q] = fmaf(gb.z, w, C0[q]); C1[q] = fmaf(gb.w, w, C1[q]); C2[q] = fmaf(gc, w, C2[q]);
-                Tq[q] = test_T;
-                lastq[q] = contributor;
+                Tq[q] = blend ? test_T : Tq[q];
+                lastq[q] = blend ? contributor : lastq[q];
+                dmask |= term ? (1u << q) : 0u;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -325,24 +326,24 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             bool hit = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                if (!(mm & (1u << q))) continue;                 // wave-uniform
-                if (!(ee < ncq[q])) continue;
+                if (!(mm & (1u << q))) continue;                 // wave-uniform (scalar branch)
+                // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
                 const float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
                 const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
-                if (power > 0.0f) continue;
                 const float G = sg_exp(power);
                 const float alpha = fminf(0.99f, gb.y * G);
-                if (alpha < 1.0f / 255.0f) continue;
-                hit = true;
-                const float rinv = __builtin_amdgcn_rcpf(1.0f - alpha);
+                const bool valid = (ee < ncq[q]) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                hit |= valid;
+                const float ae = valid ? alpha : 0.0f;
+                const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
                 Tr[q] = Tr[q] * rinv;                            // T in front of this entry
-                const float dchan = alpha * Tr[q];
+                const float dchan = ae * Tr[q];
                 const float e0 = gb.z - S0[q], e1 = gb.w - S1[q], e2 = gc - S2[q];
                 float dLa = fmaf(e2, d2[q], fmaf(e1, d1[q], e0 * d0[q]));
-                S0[q] = fmaf(alpha, e0, S0[q]); S1[q] = fmaf(alpha, e1, S1[q]); S2[q] = fmaf(alpha, e2, S2[q]);
+                S0[q] = fmaf(ae, e0, S0[q]); S1[q] = fmaf(ae, e1, S1[q]); S2[q] = fmaf(ae, e2, S2[q]);
                 v[6] = fmaf(dchan, d0[q], v[6]); v[7] = fmaf(dchan, d1[q], v[7]); v[8] = fmaf(dchan, d2[q], v[8]);
                 dLa = fmaf(-tb[q], rinv, dLa * Tr[q]);          // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
-                const float w = G * dLa;                         // = dL/dopacity contribution; dL/dG = o * dLa
+                const float w = valid ? G * dLa : 0.0f;          // = dL/dopacity contribution; dL/dG = o * dLa
                 v[5] += w;
                 v[0] = fmaf(w, fmaf(dy, ga.w, dx * ga.z), v[0]);
                 v[1] = fmaf(w, fmaf(dx, ga.w, dy * gb.x), v[1]);
