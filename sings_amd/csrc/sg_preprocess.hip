@@ -15,8 +15,17 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                          SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii)
 {
+    __shared__ uint32_t scratch_all[4][192];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int wave = threadIdx.x >> 6;
     const bool live = idx < P;
+    constexpr int nc = (D + 1) * (D + 1);
+    float sh[nc * 3];
+    if (shs && live) {
+        const float *src = shs + (size_t)idx * c.M * 3;
+#pragma unroll
+        for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+    }
     SgProj o;
     o.mr = 0; o.tt = 0; o.clampbits = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
     o.pix[0] = o.pix[1] = 0; o.conic[0] = o.conic[1] = o.conic[2] = 0; o.rgb[0] = o.rgb[1] = o.rgb[2] = 0; o.depth = 0;
@@ -29,11 +38,10 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
             q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
         }
         sg_project_fwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr,
-                          colors_precomp ? colors_precomp + 3 * (size_t)idx : nullptr,
-                          shs ? shs + (size_t)idx * c.M * 3 : nullptr, o);
+                          colors_precomp ? colors_precomp + 3 * (size_t)idx : nullptr, sh, o);
         opac = opacities[idx];
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave]);
 }
 
 void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
@@ -64,8 +72,13 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
 {
+    __shared__ float lds_all[4][64 * SG_ROW_LDS];         // 13 KiB per wave: records, then SH rows in / out
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= P) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = idx - lane;
+    if (g0 >= P) return;                                    // whole wave out of range
+    float *L = lds_all[wave];
+    const bool live = idx < P;
     SgGaussGrad G;
 #pragma unroll
     for (int k = 0; k < 3; k++) { G.dmean[k] = 0; G.dcol[k] = 0; G.dsc[k] = 0; }
@@ -74,25 +87,64 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 #pragma unroll
     for (int k = 0; k < 6; k++) G.g6[k] = 0;
     G.g2[0] = G.g2[1] = 0; G.dop = 0;
-    const bool vis = radii[idx] > 0;
+    const bool vis = live && radii[idx] > 0;
     const int Mrows = c.M;
     constexpr int nc = (D + 1) * (D + 1);
-    float *dsh_row = dL_dsh ? dL_dsh + (size_t)idx * Mrows * 3 : nullptr;
+    // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
+    float a9[9];
+    float4 rc = make_float4(0, 0, 0, 0);
+    if (vis) rc = g.recC[idx];
+    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+    // 2. SH rows in (coalesced when they are full 48-float rows)
+    const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
+    float sh[nc * 3], dsh[nc * 3];
+#pragma unroll
+    for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
+    if (staged) {
+        sg_rows48_load(shs, g0, P, lane, L);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        if (vis) {
+#pragma unroll
+            for (int k = 0; k < nc * 3 / 4; k++) {
+                float4 v = *(const float4 *)(L + lane * SG_ROW_LDS + 4 * k);
+                sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    } else if (shs && vis) {
+        const float *src = shs + (size_t)idx * Mrows * 3;
+#pragma unroll
+        for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+    }
+    // 3. the chain rule
     if (vis) {
-        float a9[9];
-        sg_sum_records(grec, cap, g.recC[idx], a9);
         float p[3] = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
         float s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 };
         if (!cov3D_precomp) {
             s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
             q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
         }
-        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr,
-                          shs ? shs + (size_t)idx * Mrows * 3 : nullptr, g.flags[idx], a9, dsh_row, G);
-        if (dsh_row) for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
-    } else if (dsh_row) {
-        for (int k = 0; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
+        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, g.flags[idx], a9,
+                          dL_dsh ? dsh : nullptr, G);
     }
+    // 4. dL/dsh rows out (every one of the M rows is written; coalesced through LDS when staged)
+    if (dL_dsh) {
+        if (staged) {
+#pragma unroll
+            for (int k = 0; k < 12; k++)
+                *(float4 *)(L + lane * SG_ROW_LDS + 4 * k) = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            sg_rows48_store(dL_dsh, g0, P, lane, L);
+        } else if (live) {
+            float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+#pragma unroll
+            for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
+            for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
+        }
+    }
+    if (!live) return;
     dL_dmeans3D[3 * idx] = G.dmean[0]; dL_dmeans3D[3 * idx + 1] = G.dmean[1]; dL_dmeans3D[3 * idx + 2] = G.dmean[2];
     dL_dmeans2D[3 * idx] = G.g2[0]; dL_dmeans2D[3 * idx + 1] = G.g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     dL_dopacity[idx] = G.dop;

@@ -86,19 +86,22 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
     }
 }
 
-// Stores the projected record and bins the Gaussian.  MUST be reached by every lane of the wave
-// (live or not) of a 256-thread workgroup.
-//  * the Gaussian-major slots [base, base+total) of this wave's (tile,Gaussian) pairs are reserved
-//    with ONE atomic per wave (prefix sum over tiles_touched);
+// Stores the projected record and bins the Gaussian.  MUST be reached by EVERY thread (live or not) of a
+// 256-thread workgroup (it contains workgroup barriers).
+//  * the Gaussian-major slots of the workgroup's (tile,Gaussian) pairs are reserved with ONE atomic per
+//    workgroup (prefix sums over tiles_touched); a wave's slots [base, base+total) are contiguous and in
+//    lane order, which the backward relies on to stream a wave's gradient records coalesced;
 //  * the pairs are then expanded load-balanced: lane l of pass c handles pair 64c + l of the wave
 //    (binary search of the owner in the wave's prefix sums held in LDS), adds 1 to its tile's
 //    counter with a RETURNING atomic and records (Gaussian, tile, arrival rank) -- the scatter that
 //    follows the tile scan then needs no atomics at all.
+// `scratch`: >= 192 words of LDS private to this wave.
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
-                                              int gx, uint32_t cap, int32_t *__restrict__ radii)
+                                              int gx, uint32_t cap, int32_t *__restrict__ radii,
+                                              uint32_t *__restrict__ scratch)
 {
-    __shared__ uint32_t sIncl[4][64], sMin[4][64], sWid[4][64];
-    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;
+    uint32_t *sIncl = scratch, *sMin = scratch + 64, *sWid = scratch + 128;
+    const int lane = threadIdx.x & 63;
     uint32_t incl = o.tt;
 #pragma unroll
     for (int s = 1; s < 64; s <<= 1) {
@@ -106,9 +109,20 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         if (lane >= s) incl += v;
     }
     const uint32_t total = __shfl(incl, 63, 64);
-    uint32_t base = 0;
-    if (lane == 63 && total) base = atomicAdd(&bn.header[2], total);
-    base = __shfl(base, 63, 64);
+    // ONE allocator atomic per 256-thread workgroup: a single counter word sustains only ~88 returning
+    // atomics per microsecond (MI355X_MICROARCH.md "dequeue"), one per wave would cost ~35 us at 2e5 Gaussians
+    __shared__ uint32_t sWaveTot[4];
+    __shared__ uint32_t sBlockBase;
+    const int wave_ = (threadIdx.x >> 6) & 3;
+    if (lane == 63) sWaveTot[wave_] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
+        sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
+    }
+    __syncthreads();
+    uint32_t base = sBlockBase;
+    for (int w = 0; w < wave_; w++) base += sWaveTot[w];
     const uint32_t rmin = (uint32_t)o.x0 | ((uint32_t)o.y0 << 16);
     const uint32_t rwh = (uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16);
     if (live) {
@@ -121,28 +135,76 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         g.flags[idx] = o.clampbits;
     }
     if (total == 0) return;                       // wave-uniform
-    sIncl[wave][lane] = incl; sMin[wave][lane] = rmin; sWid[wave][lane] = rwh & 0xffffu;
+    sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
-    for (uint32_t p = lane; p < total; p += 64) {
-        int lo = 0, hi = 63;                      // smallest j with incl[j] > p
+    // four pairs per lane per round: the four returning atomics are in flight together
+    for (uint32_t p0 = 0; p0 < total; p0 += 256) {
+        uint32_t tile[4], local[4], gj[4];
 #pragma unroll
-        for (int it = 0; it < 6; it++) {
-            int mid = (lo + hi) >> 1;
-            if (sIncl[wave][mid] > p) hi = mid; else lo = mid + 1;
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            tile[u] = 0; local[u] = 0; gj[u] = 0;
+            if (p < total) {
+                int lo = 0, hi = 63;                  // smallest j with incl[j] > p
+#pragma unroll
+                for (int it = 0; it < 6; it++) {
+                    int mid = (lo + hi) >> 1;
+                    if (sIncl[mid] > p) hi = mid; else lo = mid + 1;
+                }
+                const int j = lo;
+                const uint32_t excl = j ? sIncl[j - 1] : 0u;
+                const uint32_t t = p - excl, w = sWid[j], mn = sMin[j];
+                const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)w);      // exact floor: t, w < 2^16
+                const uint32_t tx = t - ty * w;
+                tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
+                gj[u] = (uint32_t)(g0 + j);
+                local[u] = atomicAdd(&bn.tile_count[tile[u]], 1u);
+            }
         }
-        const int j = lo;
-        const uint32_t excl = j ? sIncl[wave][j - 1] : 0u;
-        const uint32_t t = p - excl, w = sWid[wave][j], mn = sMin[wave][j];
-        const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)w);      // exact floor: t, w < 2^16
-        const uint32_t tx = t - ty * w;
-        const uint32_t tile = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
-        const uint32_t local = atomicAdd(&bn.tile_count[tile], 1u);
-        const uint32_t slot = base + p;
-        if (slot < cap) { bn.pair_gid[slot] = (uint32_t)(g0 + j); bn.pair_tile[slot] = tile; bn.pair_local[slot] = local; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = p0 + 64 * u + lane;
+            const uint32_t slot = base + p;
+            if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
+        }
     }
     __builtin_amdgcn_wave_barrier();
+}
+
+// ---- coalesced staging of 48-float rows ([P,16,3] SH coefficients / their gradients) through LDS:
+// the wave's 64 rows are one contiguous 12-KiB block, moved with 16-B-per-lane accesses; LDS rows are
+// 52 floats apart so that both the row-major fill and the one-row-per-lane ds_read_b128 are conflict-free.
+#define SG_ROW_LDS 52
+__device__ __forceinline__ void sg_rows48_load(const float *__restrict__ base, int g0, int P, int lane,
+                                               float *__restrict__ l)
+{
+    const float4 *src = (const float4 *)(base + (size_t)g0 * 48);
+    const int nf4 = (P - g0 < 64 ? P - g0 : 64) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int f = i * 64 + lane;
+        if (f < nf4) {
+            const float4 v = src[f];
+            const int row = f / 12, c4 = f - row * 12;
+            *(float4 *)(l + row * SG_ROW_LDS + 4 * c4) = v;
+        }
+    }
+}
+__device__ __forceinline__ void sg_rows48_store(float *__restrict__ base, int g0, int P, int lane,
+                                                const float *__restrict__ l)
+{
+    float4 *dst = (float4 *)(base + (size_t)g0 * 48);
+    const int nf4 = (P - g0 < 64 ? P - g0 : 64) * 12;
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+        const int f = i * 64 + lane;
+        if (f < nf4) {
+            const int row = f / 12, c4 = f - row * 12;
+            dst[f] = *(const float4 *)(l + row * SG_ROW_LDS + 4 * c4);
+        }
+    }
 }
 
 struct SgGaussGrad {
@@ -162,6 +224,43 @@ __device__ __forceinline__ void sg_sum_records(const float4 *__restrict__ grec, 
         float4 r0 = grec[3 * r], r1 = grec[3 * r + 1], r2 = grec[3 * r + 2];
         a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
         a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r2.x;
+    }
+}
+
+// Cooperative variant: the wave's records are ONE contiguous range (slots are reserved per wave in lane
+// order), so the wave streams them with 16-B-per-lane loads into LDS (chunks of SG_REC_CHUNK records)
+// and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*12 floats.
+#define SG_REC_CHUNK 256
+__device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ grec, size_t cap, bool vis, float4 recC,
+                                                    int lane, float *__restrict__ l, float a9[9])
+{
+    const uint32_t goff = __float_as_uint(recC.y), wh = __float_as_uint(recC.w);
+    const uint32_t tt = vis ? (wh & 0xffffu) * (wh >> 16) : 0u;
+    const uint32_t lo = vis ? goff : 0xffffffffu, hi = vis ? goff + tt : 0u;
+    uint32_t wlo = lo, whi = hi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t a = __shfl_xor(wlo, o, 64), b = __shfl_xor(whi, o, 64);
+        wlo = a < wlo ? a : wlo; whi = b > whi ? b : whi;
+    }
+#pragma unroll
+    for (int i = 0; i < 9; i++) a9[i] = 0.0f;
+    if (whi <= wlo) return;                               // wave-uniform: nothing visible
+    if ((size_t)whi > cap) whi = (uint32_t)cap;
+    for (uint32_t c0 = wlo; c0 < whi; c0 += SG_REC_CHUNK) {
+        const uint32_t n = whi - c0 < SG_REC_CHUNK ? whi - c0 : SG_REC_CHUNK;
+        const float4 *src = grec + 3 * (size_t)c0;
+        for (uint32_t f = lane; f < 3 * n; f += 64) ((float4 *)l)[f] = src[f];
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t k0 = lo > c0 ? lo : c0, k1 = hi < c0 + n ? hi : c0 + n;
+        for (uint32_t k = k0; k < k1; k++) {
+            const float4 *r = (const float4 *)l + 3 * (k - c0);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
+            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r2.x;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 

@@ -237,7 +237,7 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         if (posed_rotq) { posed_rotq[4 * idx] = ps.q[0]; posed_rotq[4 * idx + 1] = ps.q[1]; posed_rotq[4 * idx + 2] = ps.q[2]; posed_rotq[4 * idx + 3] = ps.q[3]; }
         if (posed_scales) { posed_scales[3 * idx] = ps.s3[0]; posed_scales[3 * idx + 1] = ps.s3[1]; posed_scales[3 * idx + 2] = ps.s3[2]; }
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, (uint32_t *)sT[wave]);
 }
 
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
