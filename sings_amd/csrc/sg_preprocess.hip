@@ -72,7 +72,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
 {
-    __shared__ float lds_all[4][64 * SG_ROW_LDS];         // 13 KiB per wave: records, then SH rows in / out
+    __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g0 = idx - lane;
@@ -90,53 +90,58 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
     const bool vis = live && radii[idx] > 0;
     const int Mrows = c.M;
     constexpr int nc = (D + 1) * (D + 1);
-    // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
-    float a9[9];
-    float4 rc = make_float4(0, 0, 0, 0);
-    if (vis) rc = g.recC[idx];
-    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
-    // 2. SH rows in (coalesced when they are full 48-float rows)
     const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
-    float sh[nc * 3], dsh[nc * 3];
+    // 0. issue every load that does not depend on another one up front (one memory round trip, not four)
+    float4 rc = make_float4(0, 0, 0, 0);
+    float p[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 }, sh[nc * 3], dsh[nc * 3];
+    uint32_t flags = 0;
 #pragma unroll
     for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
-    if (staged) {
-        sg_rows48_load(shs, g0, P, lane, L);
-        __builtin_amdgcn_s_waitcnt(0);
-        __builtin_amdgcn_wave_barrier();
-        if (vis) {
-#pragma unroll
-            for (int k = 0; k < nc * 3 / 4; k++) {
-                float4 v = *(const float4 *)(L + lane * SG_ROW_LDS + 4 * k);
-                sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    } else if (shs && vis) {
-        const float *src = shs + (size_t)idx * Mrows * 3;
-#pragma unroll
-        for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
-    }
-    // 3. the chain rule
     if (vis) {
-        float p[3] = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
-        float s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 };
+        rc = g.recC[idx];
+        flags = g.flags[idx];
+        p[0] = means3D[3 * idx]; p[1] = means3D[3 * idx + 1]; p[2] = means3D[3 * idx + 2];
         if (!cov3D_precomp) {
             s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
             q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
         }
-        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, g.flags[idx], a9,
-                          dL_dsh ? dsh : nullptr, G);
+        if (shs) {
+            const float *src = shs + (size_t)idx * Mrows * 3;
+            if (staged) {
+#pragma unroll
+                for (int k = 0; k < nc * 3 / 4; k++) {
+                    float4 v = ((const float4 *)src)[k];
+                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+            }
+        }
     }
-    // 4. dL/dsh rows out (every one of the M rows is written; coalesced through LDS when staged)
+    // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
+    float a9[9];
+    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+    // 2. the chain rule
+    if (vis)
+        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
+                          dL_dsh != nullptr, dsh, G);
+    // 3. dL/dsh rows out (every one of the M rows is written; coalesced through LDS when staged)
     if (dL_dsh) {
         if (staged) {
 #pragma unroll
-            for (int k = 0; k < 12; k++)
-                *(float4 *)(L + lane * SG_ROW_LDS + 4 * k) = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-            sg_rows48_store(dL_dsh, g0, P, lane, L);
+            for (int h = 0; h < 2; h++) {                    // 32 rows at a time (keeps LDS at 6.5 KiB per wave)
+                if ((lane >> 5) == h) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++)
+                        *(float4 *)(L + (lane & 31) * SG_ROW_LDS + 4 * k) = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+            }
         } else if (live) {
             float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
 #pragma unroll

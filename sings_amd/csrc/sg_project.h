@@ -192,11 +192,12 @@ __device__ __forceinline__ void sg_rows48_load(const float *__restrict__ base, i
         }
     }
 }
+// stores `rows` (<= 64) rows starting at Gaussian g0
 __device__ __forceinline__ void sg_rows48_store(float *__restrict__ base, int g0, int P, int lane,
-                                                const float *__restrict__ l)
+                                                const float *__restrict__ l, int rows = 64)
 {
     float4 *dst = (float4 *)(base + (size_t)g0 * 48);
-    const int nf4 = (P - g0 < 64 ? P - g0 : 64) * 12;
+    const int nf4 = (P - g0 < rows ? (P - g0 > 0 ? P - g0 : 0) : rows) * 12;
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         const int f = i * 64 + lane;
@@ -230,7 +231,7 @@ __device__ __forceinline__ void sg_sum_records(const float4 *__restrict__ grec, 
 // Cooperative variant: the wave's records are ONE contiguous range (slots are reserved per wave in lane
 // order), so the wave streams them with 16-B-per-lane loads into LDS (chunks of SG_REC_CHUNK records)
 // and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*12 floats.
-#define SG_REC_CHUNK 256
+#define SG_REC_CHUNK 128
 __device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ grec, size_t cap, bool vis, float4 recC,
                                                     int lane, float *__restrict__ l, float a9[9])
 {
@@ -266,12 +267,12 @@ __device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ g
 
 // Backward of sg_project_fwd for one VISIBLE Gaussian.  a9 = summed record
 // (mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, colour r,g,b).
-// dsh_out: this Gaussian's [M,3] gradient rows (rows < (D+1)^2 written here) or NULL.
+// dsh_out: (D+1)^2 x 3 gradient rows of this Gaussian (written iff want_sh; pass a local array).
 template <int D>
 __device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3], const float s3[3], const float q[4],
                                                const float *__restrict__ c6pre, const float *__restrict__ sh,
-                                               uint32_t clampbits, const float a9[9], float *__restrict__ dsh_out,
-                                               SgGaussGrad &G)
+                                               uint32_t clampbits, const float a9[9], bool want_sh,
+                                               float *__restrict__ dsh_out, SgGaussGrad &G)
 {
     float *dmean = G.dmean, *g2 = G.g2, *dcol = G.dcol, *dsc = G.dsc, *drot = G.drot, *g6 = G.g6;
     g2[0] = a9[0]; g2[1] = a9[1];
@@ -370,7 +371,7 @@ __device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3],
         drot[3] = 2.0f * (-2.0f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.0f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
     }
     // ---- SH backward (and its contribution to dL/dmean through the view direction)
-    if (dsh_out) {
+    if (want_sh) {
         constexpr int nc = (D + 1) * (D + 1);
         float dorig[3] = { p[0] - c.campos[0], p[1] - c.campos[1], p[2] - c.campos[2] };
         float sum2 = dorig[0] * dorig[0] + dorig[1] * dorig[1] + dorig[2] * dorig[2];

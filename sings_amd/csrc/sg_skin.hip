@@ -287,7 +287,7 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
             if (vis) {
                 float a9[9];
                 sg_sum_records(grec, cap, g.recC[idx], a9);
-                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, dsh_row, G);
+                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh_row, G);
                 for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
             } else {
                 for (int i = 0; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
