@@ -323,7 +323,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             // v[0..4]: sums of w*m with w = G dL/dalpha; the per-Gaussian factors (-o W/2, -o H/2, -o/2)
             // are applied once per record when it is flushed (the reduction is linear).
             float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            bool hit = false;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 if (!(mm & (1u << q))) continue;                 // wave-uniform (scalar branch)
@@ -333,7 +332,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float G = sg_exp(power);
                 const float alpha = fminf(0.99f, gb.y * G);
                 const bool valid = (ee < ncq[q]) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                hit |= valid;
                 const float ae = valid ? alpha : 0.0f;
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
                 Tr[q] = Tr[q] * rinv;                            // T in front of this entry
@@ -350,10 +348,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float wx = w * dx;
                 v[2] = fmaf(wx, dx, v[2]); v[3] = fmaf(wx, dy, v[3]); v[4] = fmaf(w * dy, dy, v[4]);
             }
-            if (__ballot(hit) == 0ull) {                         // wave-uniform
-                if (lane < 9) L.sG[k][lane] = 0.0f;
-                continue;
-            }
+            // (entries that pass the quadrant test but touch no pixel are < 1 %: always reduce)
             float v8;
             float z = sg_reduce9(v, lane, &v8);
             if ((lane & 7) == 0) L.sG[k][ridx] = z;
