@@ -66,3 +66,18 @@ def test_g5_camera_of_shipped_kit():
     close(cam["full_proj_transform"], G["g5_full"], 1e-6)
     close(cam["camera_center"], G["g5_center"], 1e-7)
     assert cam["image_width"] == 512 and cam["image_height"] == 896
+
+
+def test_body_joint_transforms_match_reference_chain():
+    """sings_amd/body.py (the product-side producer of A) vs the reference's batch_rigid_transform (golden G2)."""
+    from sings_amd.body import joint_transforms
+    bm = lo.synthetic_body_model(seed=0)
+    v_shaped = T(bm["v_template"]) + torch.einsum("l,mkl->mk", T(G["g2_betas"][0]), T(bm["shapedirs"]))
+    J_rest = torch.einsum("ik,ji->jk", v_shaped, T(bm["J_regressor"]))
+    for i in range(3):
+        A = joint_transforms(T(G["g2_poses"][i]), J_rest, tuple(bm["parents"].tolist()))
+        close(A, G[f"g2_A_{i}"][0], 3e-6)
+    # differentiable w.r.t. the pose
+    pose = T(G["g2_poses"][2]).clone().requires_grad_(True)
+    joint_transforms(pose, J_rest).square().sum().backward()
+    assert torch.isfinite(pose.grad).all() and pose.grad.abs().max() > 0

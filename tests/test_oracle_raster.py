@@ -149,3 +149,23 @@ def test_empty_and_all_culled():
     assert np.allclose(o["color"], s["bg"][:, None, None])
     g = ro.backward(o, np.ones((3, 24, 40), np.float32))
     assert np.abs(g["dL_dmeans3D"]).max() == 0
+
+
+def test_vectorised_torch_twin_matches_scalar_oracle():
+    """the vectorised torch preprocess (the `cpu_lbs_project` baseline of BASELINE.md) agrees
+    with the scalar C restatement: integers exactly, floats to summation-order rounding."""
+    import torch
+    from oracle import lbs_project_torch as lp
+    s = synthetic_scene(6000, 320, 200, 3, 13)
+    o = _run(s)
+    T = torch.from_numpy
+    r = lp.project(T(s["means3D"]), T(s["scales"]), T(s["rotations"]), T(s["opacities"]), T(s["shs"]), 3, T(s["viewmatrix"]),
+                   T(s["projmatrix"]), T(s["campos"]), 320, 200, s["tanfovx"], s["tanfovy"])
+    assert np.array_equal(r["radii"].numpy(), o["radii"])
+    assert np.array_equal(r["tiles_touched"].numpy().astype(np.uint32), o["tiles_touched"])
+    vis = o["radii"] > 0
+    assert np.array_equal(r["rect"].numpy()[vis], o["rect"][vis])
+    assert np.array_equal(r["depths"].numpy()[vis], o["depths"][vis])
+    for k in ("xy", "conic_opacity", "rgb"):
+        a, b = r[k].numpy()[vis], o[k][vis]
+        assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(b).max()), k
