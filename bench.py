@@ -57,7 +57,12 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=("raster", "avatar"), default="raster",
+                    help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
+                         "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
     a = ap.parse_args()
+    if a.workload == "avatar":
+        return main_avatar(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -194,6 +199,127 @@ def main():
                                "sample": f"1 full view fwd+bwd of the same scene with the scalar C oracle ({tc:.1f} s)",
                                "host_cpus": os.cpu_count()}
     print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def _dist_setup():
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    return rank, world, dev, dist
+
+
+def main_avatar(a):
+    """BASELINE configs[3]: frame-parallel training step of an avatar through the LBS-fused kernels."""
+    import math
+    rank, world, dev, dist = _dist_setup()
+    from sings_amd import _lib
+    from sings_amd.body import joint_transforms
+    from sings_amd.dp import FrameParallel, FrameSharder
+    from sings_amd.engine import SkinnedEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import avatar_scene
+    N = a.gaussians if a.gaussians != 200000 else 150000
+    s = avatar_scene(N=N, J=52)
+    W, H, J = s["W"], s["H"], s["J"]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    cam = s["cam"]
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)          # human.sh_degree: 0 (human_complex.yaml:34)
+    poses72 = np.load(os.path.join(ROOT, "tests", "golden", "lbs_golden.npz"))["amass_poses_72"]      # [120,72] AMASS frames
+    F = poses72.shape[0]
+    poses = np.zeros((F, J * 3), np.float32); poses[:, :72] = poses72
+    poses[:, :3] = 0                                                             # global orient: face the camera
+    jr = t(s["joints_rest"])
+    A_all = torch.stack([joint_transforms(t(poses[f]), jr, tuple(s["parents"])) for f in range(F)]).reshape(F, J, 16).contiguous()
+    xyz, w, sc, op, sh = t(s["xyz_canon"]), t(s["lbs_weights"]), t(s["scales"]), t(s["opacities"]), t(s["shs"])
+    smpl_scale, transl, dL = t(s["smpl_scale"]), t(s["transl"]), t(s["dL_dimage"])
+    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=16 * N + 65536)
+    eng.set_camera(rs)
+    Rmax = 0
+    for f in range(0, F, 8):
+        eng.set_frame(xyz, None, w, A_all[f], smpl_scale, transl)
+        Rmax = max(Rmax, eng.forward(sh, op, sc, sync_num_rendered=True))
+    del eng
+    torch.cuda.empty_cache()
+    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096)
+    eng.set_camera(rs)
+    shard = FrameSharder(F, world, rank, seed=0)
+    fp = FrameParallel() if dist is not None else None
+
+    def step(i):
+        eng.set_frame(xyz, None, w, A_all[shard.frame(i)], smpl_scale, transl)
+        eng.forward(sh, op, sc)
+        eng.backward(sh, op, sc, dL)
+        if fp is not None:
+            fp.all_reduce_grads(eng.grad_flat)
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(a.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    assert eng.num_rendered() <= eng.cap
+    lib = _lib.load()
+    lib.sg_profile_enable(1)
+    for i in range(a.steps):
+        eng.set_frame(xyz, None, w, A_all[shard.frame(i)], smpl_scale, transl)
+        eng.forward(sh, op, sc); eng.backward(sh, op, sc, dL)
+    ms = (C.c_double * _lib.NUM_KERNELS)(); cnt = (C.c_int64 * _lib.NUM_KERNELS)()
+    _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
+    lib.sg_profile_enable(0)
+    kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
+    if rank == 0:
+        out = {"metric": "rendered views/sec fwd+bwd, avatar ~150k posed Gaussians x 120 AMASS frames (LBS-fused)",
+               "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H} fx=fy=5000, {F} AMASS frames, SH deg 0, fused LBS+raster "
+                                      f"fwd+bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
+                          "width": W, "height": H, "max_num_rendered": Rmax, "parallelism": f"dp{world}"},
+               "kernel_ms": kern}
+        if world == 1 and not a.no_cpu_baseline:
+            from oracle import lbs_project_torch as lp
+            T = torch.from_numpy
+            nthr = min(os.cpu_count(), 16)          # tiny batched matmuls: more threads only add OpenMP overhead
+            torch.set_num_threads(nthr)
+            args = (T(s["xyz_canon"]), torch.eye(3)[None].repeat(N, 1, 1), T(s["scales"]), T(s["opacities"]), T(s["shs"]), 0,
+                    T(s["lbs_weights"]), A_all[0].cpu().view(J, 4, 4), T(s["smpl_scale"]), T(s["transl"]),
+                    T(cam["world_view_transform"]), T(cam["full_proj_transform"]), T(cam["camera_center"]), W, H,
+                    math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5))
+            ts = []
+            for _ in range(3):
+                t1 = time.perf_counter(); lp.lbs_project(*args); ts.append(time.perf_counter() - t1)
+            tm = sorted(ts)[len(ts) // 2]
+            out["cpu_baseline"] = {"value": 1.0 / tm, "unit": "frames/s (LBS + project only, no raster)", "cores": nthr,
+                                   "kind": "port", "sample": f"PyTorch-CPU LBS+project (BASELINE.md section 3), N={N}, J={J}, "
+                                   f"median of 3 ({tm * 1e3:.1f} ms), torch {torch.__version__}"}
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -18,7 +18,7 @@
 
 // single workgroup, 1024 threads x 8 consecutive tiles each: exclusive scan over T tile counts
 __global__ void __launch_bounds__(1024)
-sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
+sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_stride, uint2 *__restrict__ ranges,
                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap)
 {
     __shared__ uint32_t wsum[16];
@@ -30,7 +30,7 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__res
         const int i0 = base + tid * 8;
         uint32_t v[8], sum = 0;
 #pragma unroll
-        for (int k = 0; k < 8; k++) { v[k] = i0 + k < T ? tile_count[i0 + k] : 0u; sum += v[k]; }
+        for (int k = 0; k < 8; k++) { v[k] = i0 + k < T ? tile_count[(size_t)(i0 + k) * tc_stride] : 0u; sum += v[k]; }
         uint32_t incl = sum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
@@ -137,7 +137,7 @@ sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t
 // long lists: one workgroup per tile
 __global__ void __launch_bounds__(SG_SORT_THREADS)
 sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
-                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys, uint32_t *__restrict__ rank)
 {
     __shared__ uint64_t s[SG_SORT_LDS];
     const int tile = blockIdx.x, tid = threadIdx.x;
@@ -156,9 +156,11 @@ sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pai
             if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
         }
     } else {
-        // Rare long tile: sort LDS-sized chunks in place, then place every element by rank.
-        // Keys are unique (Gaussian id in the low word), so the final position of a key is
-        // the number of smaller keys summed over all sorted chunks (binary searches).
+        // Long tile (> SG_SORT_LDS entries): sort LDS-sized chunks in place, then place every element by rank.
+        // Keys are unique (Gaussian id in the low word), so the final position of a key is the number of
+        // smaller keys summed over all sorted chunks.  Each sorted chunk is brought back into LDS once and all
+        // threads binary-search it there; the running ranks live in `rank` (the pair_local array, dead after
+        // the scatter), indexed like the segment.
         const uint32_t nchunks = (n + SG_SORT_LDS - 1) / SG_SORT_LDS;
         for (uint32_t c = 0; c < nchunks; c++) {
             uint32_t off = c * SG_SORT_LDS, m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
@@ -169,17 +171,25 @@ sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pai
             for (int i = tid; i < (int)m; i += SG_SORT_THREADS) seg[off + i] = s[i];
             __syncthreads();
         }
+        uint32_t *rk = rank + r.x;
+        for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) rk[i] = 0;
         __threadfence();   // chunk stores must be visible to every wave of this workgroup
         __syncthreads();
+        for (uint32_t c = 0; c < nchunks; c++) {
+            uint32_t off = c * SG_SORT_LDS, m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
+            for (uint32_t i = tid; i < m; i += SG_SORT_THREADS) s[i] = seg[off + i];
+            __syncthreads();
+            for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) {
+                uint64_t k = seg[i];
+                uint32_t lo = 0, hi = m;
+                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s[mid] < k) lo = mid + 1; else hi = mid; }
+                rk[i] += lo;
+            }
+            __syncthreads();
+        }
         for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) {
             uint64_t k = seg[i];
-            uint32_t pos = 0;
-            for (uint32_t c = 0; c < nchunks; c++) {
-                uint32_t off = c * SG_SORT_LDS, m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
-                uint32_t lo = 0, hi = m;
-                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (seg[off + mid] < k) lo = mid + 1; else hi = mid; }
-                pos += lo;
-            }
+            uint32_t pos = rk[i];
             point_list[r.x + pos] = (uint32_t)k;
             if (point_keys) point_keys[r.x + pos] = ((uint64_t)tile << 32) | (k >> 32);
         }
@@ -194,7 +204,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
-    hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.ranges, b.cursor, b.header, cap32);
+    hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.tc_stride, b.ranges, b.cursor, b.header, cap32);
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
     if (P > 0) {
@@ -208,6 +218,6 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     hipLaunchKernelGGL(sg_tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, st, T, b.ranges, b.pair_keys,
                        b.point_list, pk);
     hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T), dim3(SG_SORT_THREADS), 0, st, b.ranges, b.pair_keys,
-                       b.point_list, pk);
+                       b.point_list, pk, b.pair_local);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

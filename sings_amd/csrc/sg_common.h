@@ -7,6 +7,13 @@
 #include "../../include/sings_hip.h"
 
 #define SG_WAVE 64
+// Words between two tile counters.  Packed counters (stride 1) let one 64-lane atomic instruction touch few
+// lines (a Gaussian's tiles are neighbours) -- best when the image has many tiles and ~100 pairs per tile
+// (cfg3: 39 us vs 55 us padded).  With few tiles and thousands of pairs per tile (avatar close-ups: a row of 32
+// tiles shares one 128-B line) the returning atomics serialise in that line's L2 channel -- there one counter
+// per line wins (141 us vs 415 us).  The pair density is unknown before the pass, so the tile count decides.
+#define SG_TC_STRIDE_MAX 32
+static inline uint32_t sg_tc_stride(size_t T) { return T <= 4096 ? SG_TC_STRIDE_MAX : 1; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
@@ -18,7 +25,8 @@ struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vec
 
 struct SgBin {
     uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles
-    uint32_t *tile_count;  // [T]
+    uint32_t *tile_count;  // [T * tc_stride], counter of tile t at t * tc_stride
+    uint32_t tc_stride;
     uint2 *ranges;         // [T] (start,end) into point_list
     uint32_t *cursor;      // [T]
     uint64_t *pair_keys;   // [cap] (depth_bits << 32 | gid), grouped by tile, sorted in place
@@ -50,6 +58,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     char *b = (char *)ws;
     SgBin g;
     g.header = (uint32_t *)(b + L.bin_header); g.tile_count = (uint32_t *)(b + L.bin_tile_count);
+    g.tc_stride = SG_TC_STRIDE_MAX;           // callers that know the tile count set sg_tc_stride(T)
     g.ranges = (uint2 *)(b + L.bin_ranges); g.cursor = (uint32_t *)(b + L.bin_cursor);
     g.pair_keys = (uint64_t *)(b + L.bin_pair_keys); g.point_list = (uint32_t *)(b + L.bin_point_list);
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);

@@ -160,7 +160,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t tx = t - ty * w;
                 tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
                 gj[u] = (uint32_t)(g0 + j);
-                local[u] = atomicAdd(&bn.tile_count[tile[u]], 1u);
+                local[u] = atomicAdd(&bn.tile_count[(size_t)tile[u] * bn.tc_stride], 1u);
             }
         }
 #pragma unroll

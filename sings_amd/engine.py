@@ -73,3 +73,69 @@ class RasterEngine:
         nr = C.c_int64(0)
         _lib.check(self.lib.sg_read_num_rendered(_ptr(self.binning), C.byref(nr), self._stream()), "read R")
         return int(nr.value)
+
+
+class SkinnedEngine:
+    """Same idea for the LBS-fused path (sg_skinned_forward / backward): canonical Gaussians + per-frame joint
+    transforms in, image + flat canonical-Gaussian gradient buffer out.  Flat layout (floats): xyz_canon 3P,
+    scales 3P, opacity P, sh 3MP, [rot_canon 9P].  dL/dA [J,16] and dL/dtransl [3] are per-frame (not all-reduced)."""
+
+    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False):
+        self.lib = _lib.load()
+        self.P, self.J, self.W, self.H, self.M = int(P), int(J), int(W), int(H), int(sh_coeffs)
+        self.dev = torch.device(device)
+        self.cap = int(capacity_pairs)
+        L = _lib.layout(self.P, self.W, self.H, self.cap)
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.geom = torch.empty(L.geom_bytes, **u8); self.binning = torch.empty(L.bin_bytes, **u8)
+        self.img = torch.empty(L.img_bytes, **u8); self.bwd_ws = torch.empty(L.bwd_bytes, **u8)
+        self.skin_ws = torch.empty(int(self.lib.sg_skin_ws_floats(self.P)), **f32)
+        self.color = torch.empty((3, self.H, self.W), **f32)
+        self.radii = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
+        per = 3 + 3 + 1 + 3 * self.M + (9 if with_rot else 0)
+        self.grad_flat = torch.empty(self.P * per, **f32)
+        o = 0
+
+        def carve(n, *shape):
+            nonlocal o
+            v = self.grad_flat[o:o + n].view(*shape); o += n
+            return v
+        self.d_xyz = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
+        self.d_opacity = carve(self.P, self.P, 1); self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
+        self.d_rot = carve(self.P * 9, self.P, 9) if with_rot else None
+        self.d_means2D = torch.empty((self.P, 3), **f32)
+        self.d_A = torch.empty((self.J, 16), **f32); self.d_transl = torch.empty(3, **f32)
+        self._keep = []; self._s = None; self._k = None
+
+    def set_camera(self, raster_settings):
+        self._keep = []
+        self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+
+    def set_frame(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl):
+        from .skinned import _skin_struct
+        self._kkeep = []
+        self._k = _skin_struct(self.dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, None, self._kkeep)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def forward(self, shs, opacities, scales, sync_num_rendered=False):
+        nr = C.c_int64(-1)
+        _lib.check(self.lib.sg_skinned_forward(
+            C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.geom),
+            _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
+            C.byref(nr) if sync_num_rendered else None, self._stream()), "skinned forward")
+        return int(nr.value)
+
+    def backward(self, shs, opacities, scales, dL_dcolor):
+        _lib.check(self.lib.sg_skinned_backward(
+            C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.radii),
+            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws), _ptr(self.skin_ws),
+            _ptr(dL_dcolor), None, None, _ptr(self.d_xyz), _ptr(self.d_rot), _ptr(self.d_scales), _ptr(self.d_opacity),
+            _ptr(self.d_sh), _ptr(self.d_means2D), _ptr(self.d_A), _ptr(self.d_transl), self._stream()), "skinned backward")
+
+    def num_rendered(self):
+        nr = C.c_int64(0)
+        _lib.check(self.lib.sg_read_num_rendered(_ptr(self.binning), C.byref(nr), self._stream()), "read R")
+        return int(nr.value)
