@@ -5,31 +5,33 @@
 //
 // Both kernels are VALU-issue bound (not HBM): ~2e8 pixel x Gaussian evaluations per direction at
 // cfg3.  wave64 design:
-//  * ONE wave per 16x16 tile (4 independent tiles per 256-thread workgroup, no workgroup barriers);
-//    each lane owns 4 pixels, one in each 8x8 quadrant of the tile.
-//  * The tile's depth-sorted list is staged through LDS 64 entries at a time (three aligned 16-B
-//    gathers per entry).  While staging, each lane computes for ITS entry which quadrants the
-//    alpha >= 1/255 ellipse can reach (conservative bounding box from conic + opacity); entries that
-//    reach nothing are dropped by a ballot compaction, and a quadrant pass runs only where the bit is
-//    set -> ~2.5x fewer wave-level evaluations than the upstream 16x16 block, identical results.
-//  * Backward: the 9 per-pixel partials are first summed over the lane's quadrant passes in
-//    registers, then across the 64 lanes with a multi-value butterfly (v_permlane32_swap /
-//    v_permlane16_swap / DPP: 24 ops for 9 values instead of 54), and stored ONCE per
-//    (tile,Gaussian) as a 48-byte record at the Gaussian-major slot reserved in the forward pass.
-//    No float atomics (memory-side atomics cap at ~1.3 TB/s on MI355X and scattered single-row adds
-//    are 17x slower); gradients are bitwise reproducible.
+//  * One 256-thread workgroup per 16x16 tile; wave w owns the 8x8 pixel QUADRANT w (lane = pixel).
+//  * The tile's depth-sorted list is staged cooperatively through LDS (three aligned 16-B gathers per
+//    entry, one entry per thread).  While staging, each thread computes for ITS entry which quadrants the
+//    alpha >= 1/255 ellipse can reach (exact ellipse-vs-rectangle test with safety margins); every wave
+//    then compacts (ballot) the entries that reach its quadrant and loops over those only: ~2.4x fewer
+//    wave-level evaluations than the upstream 16x16 block, identical results, and 4 independent waves
+//    per tile keep avatar close-ups (few, very long tile lists) busy.
+//  * The per-entry body is straight-line predicated code (no exec-mask branches).
+//  * Backward: the 9 per-pixel partials of an entry are summed across the wave's 64 lanes with a
+//    multi-value butterfly (v_permlane32_swap / v_permlane16_swap / DPP: 24 ops for 9 values instead of
+//    54), the <= 4 quadrant sums are combined in LDS in a fixed order and stored ONCE per (tile,Gaussian)
+//    as a 48-byte record at the Gaussian-major slot reserved in the forward pass.  No float atomics
+//    (memory-side atomics cap at ~1.3 TB/s on MI355X and scattered single-row adds are 17x slower);
+//    gradients are bitwise reproducible.
 #include "sg_common.h"
 
-#define SG_WB 64          // list entries staged per batch (one per lane)
+#define SG_FB 256         // forward: list entries staged per batch (one per thread)
+#define SG_BB 128         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
 // XCD-aware map: workgroup b runs on XCD b % 8 (round-robin dispatch); give each XCD a contiguous
 // range of tiles so that neighbouring tiles (which share Gaussians) hit the same L2.
-__device__ __forceinline__ int sg_tile_of_wave(int block, int wave, int nblocks)
+__device__ __forceinline__ int sg_tile_of_block(int block, int nblocks)
 {
     int chunk = nblocks >> 3;                     // nblocks is a multiple of 8
-    return (((block & 7) * chunk + (block >> 3)) << 2) + wave;
+    return (block & 7) * chunk + (block >> 3);
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
@@ -76,14 +78,23 @@ __device__ __forceinline__ uint32_t sg_quad_mask(float4 a, float4 b, float X0, f
     return m;
 }
 
-struct SgWaveLds {
-    float4 sA[SG_WB];
-    float4 sB[SG_WB];
-    float sC[SG_WB];
-    uint32_t sM[SG_WB];     // (entry index << 4) | quadrant mask
-    uint32_t sR[SG_WB];     // backward: gradient-record slot
-    float sG[SG_WB][9];     // backward: reduced partials
-};
+
+// entries of the staged batch whose mask has bit `w`, compacted in list order (wave-local)
+__device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ sM, int cnt, int w, int lane,
+                                                   unsigned long long lt, uint16_t *__restrict__ list, int batch)
+{
+    int nl = 0;
+    for (int c = 0; c < batch; c += 64) {
+        const int idx = c + lane;
+        const bool bit = idx < cnt && ((sM[idx] >> w) & 1u);
+        const unsigned long long bal = __ballot(bit);
+        if (bit) list[nl + __popcll(bal & lt)] = (uint16_t)idx;
+        nl += __popcll(bal);
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    return nl;
+}
 
 __global__ void __launch_bounds__(256)
 sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
@@ -92,89 +103,68 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib)
 {
-    __shared__ SgWaveLds lds_all[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = sg_tile_of_wave(blockIdx.x, wave, nblocks);
+    __shared__ float4 sA[SG_FB];
+    __shared__ float4 sB[SG_FB];
+    __shared__ float sC[SG_FB];
+    __shared__ uint32_t sM[SG_FB];
+    __shared__ uint16_t sList[4][SG_FB];
+    const int tile = sg_tile_of_block(blockIdx.x, nblocks);
     if (tile >= T) return;
-    SgWaveLds &L = lds_all[wave];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
-    const int lx = lane & 7, ly = lane >> 3;
-    const float pxf[2] = { (float)(X0 + lx), (float)(X0 + 8 + lx) };
-    const float pyf[2] = { (float)(Y0 + ly), (float)(Y0 + 8 + ly) };
+    const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    float Tq[4], C0[4], C1[4], C2[4];
-    uint32_t lastq[4];
-    uint32_t dmask = 0;                       // bit q: this lane's pixel in quadrant q is finished
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        Tq[q] = 1.0f; C0[q] = C1[q] = C2[q] = 0.0f; lastq[q] = 0;
-        if (!(X0 + 8 * (q & 1) + lx < W && Y0 + 8 * (q >> 1) + ly < H)) dmask |= 1u << q;
-    }
-    const uint32_t outside = dmask;
+    float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
+    uint32_t last = 0;
+    bool done = !inside;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    for (int base = 0; base < n; base += SG_WB) {
-        uint32_t qdone = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (__ballot((dmask >> q) & 1u) == ~0ull) qdone |= 1u << q;
-        if (qdone == 0xFu) break;
-        const int e = base + lane;
-        uint32_t m = 0;
-        float4 a, b; float cb = 0;
+    for (int base = 0; base < n; base += SG_FB) {
+        if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
+        const int e = base + tid;
         if (e < n) {
-            uint32_t gid = point_list[range.x + e];
-            a = recA[gid]; b = recB[gid]; cb = recC[gid].x;
-            m = sg_quad_mask(a, b, (float)X0, (float)Y0) & ~qdone;
+            const uint32_t gid = point_list[range.x + e];
+            const float4 a = recA[gid], b = recB[gid];
+            sA[tid] = a; sB[tid] = b; sC[tid] = recC[gid].x;
+            sM[tid] = sg_quad_mask(a, b, (float)X0, (float)Y0);
         }
-        const unsigned long long bal = __ballot(m != 0u);
-        const int cnt = __popcll(bal);
-        if (m) {
-            int pos = __popcll(bal & lt);
-            L.sA[pos] = a; L.sB[pos] = b; L.sC[pos] = cb; L.sM[pos] = ((uint32_t)e << 4) | m;
+        __syncthreads();
+        if (__ballot(done) == ~0ull) continue;             // this quadrant is finished (wave-uniform)
+        const int cnt = n - base < SG_FB ? n - base : SG_FB;
+        uint16_t *list = sList[wave];
+        const int nl = sg_compact_quadrant(sM, cnt, wave, lane, lt, list, SG_FB);
+        for (int i = 0; i < nl; i++) {
+            const int k = list[i];
+            const float4 ga = sA[k], gb = sB[k];
+            const float gc = sC[k];
+            // straight-line, predicated: no exec-mask branches
+            const float dx = ga.x - pxf, dy = ga.y - pyf;
+            const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
+            const float alpha = fminf(0.99f, gb.y * sg_exp(power));
+            const float test_T = Tr * (1.0f - alpha);
+            const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+            const bool term = valid & (test_T < 0.0001f);
+            const bool blend = valid & !term;
+            const float w = blend ? alpha * Tr : 0.0f;
+            C0 = fmaf(gb.z, w, C0); C1 = fmaf(gb.w, w, C1); C2 = fmaf(gc, w, C2);
+            Tr = blend ? test_T : Tr;
+            last = blend ? (uint32_t)(base + k + 1) : last;
+            done = done | term;
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
-        for (int k = 0; k < cnt; k++) {
-            const uint32_t mm = __builtin_amdgcn_readfirstlane(L.sM[k]);
-            const float4 ga = L.sA[k], gb = L.sB[k];
-            const float gc = L.sC[k];
-            const uint32_t contributor = (mm >> 4) + 1u;
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!(mm & (1u << q))) continue;                 // wave-uniform (scalar branch)
-                // straight-line, predicated: no exec-mask branches inside a quadrant pass
-                const float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
-                const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
-                const float alpha = fminf(0.99f, gb.y * sg_exp(power));
-                const float test_T = Tq[q] * (1.0f - alpha);
-                const bool valid = !((dmask >> q) & 1u) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                const bool term = valid & (test_T < 0.0001f);
-                const bool blend = valid & !term;
-                const float w = blend ? alpha * Tq[q] : 0.0f;
-                C0[q] = fmaf(gb.z, w, C0[q]); C1[q] = fmaf(gb.w, w, C1[q]); C2[q] = fmaf(gc, w, C2[q]);
-                Tq[q] = blend ? test_T : Tq[q];
-                lastq[q] = blend ? contributor : lastq[q];
-                dmask |= term ? (1u << q) : 0u;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
     }
-    const size_t hw = (size_t)H * W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        if ((outside >> q) & 1u) continue;
-        size_t pid = (size_t)(Y0 + 8 * (q >> 1) + ly) * W + (X0 + 8 * (q & 1) + lx);
-        final_T[pid] = Tq[q];
-        n_contrib[pid] = lastq[q];
-        out_color[pid] = fmaf(Tq[q], bg0, C0[q]);
-        out_color[hw + pid] = fmaf(Tq[q], bg1, C1[q]);
-        out_color[2 * hw + pid] = fmaf(Tq[q], bg2, C2[q]);
+    if (inside) {
+        const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
+        final_T[pid] = Tr;
+        n_contrib[pid] = last;
+        out_color[pid] = fmaf(Tr, bg[0], C0);
+        out_color[hw + pid] = fmaf(Tr, bg[1], C1);
+        out_color[2 * hw + pid] = fmaf(Tr, bg[2], C2);
     }
 }
 
-static inline int sg_render_blocks(int T) { return (((T + 3) / 4 + 7) / 8) * 8; }
+static inline int sg_render_blocks(int T) { return ((T + 7) / 8) * 8; }
 
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           hipStream_t st)
@@ -191,29 +181,21 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
 // ------------------------------------------------------------------------------------------
 #define SG_DPP(v, ctrl) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, 0xF, 0xF, false))
 
-// lanes i and i+32 : returns (x_lo + x_hi | y_lo + y_hi)
-__device__ __forceinline__ float sg_fold32(float x, float y)
-{
-    // inline asm: hipcc (ROCm 7.2) folds "r[0] + r[1]" of __builtin_amdgcn_permlane32_swap into r[0] + r[0]
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-// lanes i and i+16 inside each half: rows become (x_r0+x_r1, y_r0+y_r1, x_r2+x_r3, y_r2+y_r3)
-__device__ __forceinline__ float sg_fold16(float x, float y)
-{
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
-    return x + y;
-}
-
-// Sums v[0..8] over the 64 lanes (fixed order).  Afterwards every lane of the 8-lane group
-// g = lane >> 3 holds the total of value SG_RED_IDX(g); lane 63 additionally returns the total of v[8]
-// in *v8tot.
+// Sums v[0..8] over the 64 lanes (fixed order).  Afterwards every lane of the 8-lane group g = lane >> 3 holds the
+// total of value sg_red_idx(lane); lane 63 additionally gets the total of v[8] in *v8tot.
+// v_permlane{32,16}_swap are issued from inline asm: hipcc (ROCm 7.2) folds "r[0] + r[1]" of the builtins' result
+// into r[0] + r[0]; the swaps of one level are independent, so one pair of wait states serves all of them.
 __device__ __forceinline__ float sg_reduce9(const float v[9], int lane, float *v8tot)
 {
-    float s01 = sg_fold32(v[0], v[1]), s23 = sg_fold32(v[2], v[3]);
-    float s45 = sg_fold32(v[4], v[5]), s67 = sg_fold32(v[6], v[7]);
-    float t0 = sg_fold16(s01, s23);          // rows: v0, v2, v1, v3
-    float t1 = sg_fold16(s45, s67);          // rows: v4, v6, v5, v7
+    float a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3], a4 = v[4], a5 = v[5], a6 = v[6], a7 = v[7];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    float s01 = a0 + a1, s23 = a2 + a3, s45 = a4 + a5, s67 = a6 + a7;   // (x_lo + x_hi | y_lo + y_hi)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(s01), "+v"(s23), "+v"(s45), "+v"(s67));
+    float t0 = s01 + s23;                    // rows: v0, v2, v1, v3
+    float t1 = s45 + s67;                    // rows: v4, v6, v5, v7
     float u = t0 + SG_DPP(t0, 0x128);        // row_ror:8 -> lanes i, i^8 summed
     float w = t1 + SG_DPP(t1, 0x128);
     float z = (lane & 8) ? w : u;            // per row: lanes 0-7 <- first value, 8-15 <- second
@@ -243,130 +225,123 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
                      float4 *__restrict__ grec, uint32_t cap)
 {
-    __shared__ SgWaveLds lds_all[4];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = sg_tile_of_wave(blockIdx.x, wave, nblocks);
+    __shared__ float4 sA[SG_BB];
+    __shared__ float4 sB[SG_BB];
+    __shared__ float sC[SG_BB];
+    __shared__ uint32_t sM[SG_BB];
+    __shared__ uint16_t sList[4][SG_BB];
+    __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
+    __shared__ uint32_t sFlag[SG_BB];          // byte w != 0: quadrant w wrote sG[w][k]
+    __shared__ uint32_t smax[4];
+    const int tile = sg_tile_of_block(blockIdx.x, nblocks);
     if (tile >= T) return;
-    SgWaveLds &L = lds_all[wave];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int X0 = tx * 16, Y0 = ty * 16;
-    const int lx = lane & 7, ly = lane >> 3;
-    const float pxf[2] = { (float)(X0 + lx), (float)(X0 + 8 + lx) };
-    const float pyf[2] = { (float)(Y0 + ly), (float)(Y0 + 8 + ly) };
+    const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
     if (n == 0) return;
-    const size_t hw = (size_t)H * W;
-    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
-    // per-pixel state (x4 quadrants): running T, colour accumulated BEHIND the current entry (S), dL/dpixel,
-    // T_final * <bg, dL/dpixel>, n_contrib
-    float Tr[4], S0[4], S1[4], S2[4], d0[4], d1[4], d2[4], tb[4];
-    uint32_t ncq[4];
-    uint32_t maxc[4];
-    int max_contrib = 0;
+    const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
+    // per-pixel state: running T, colour accumulated BEHIND the current entry, dL/dpixel, T_final <bg, dL/dpixel>
+    const float Tfin = inside ? final_T[pid] : 0.0f;
+    const uint32_t ncq = inside ? n_contrib[pid] : 0u;
+    const float d0 = inside ? dL_dpix[pid] : 0.0f, d1 = inside ? dL_dpix[hw + pid] : 0.0f, d2 = inside ? dL_dpix[2 * hw + pid] : 0.0f;
+    const float tb = Tfin * (bg[0] * d0 + bg[1] * d1 + bg[2] * d2);
+    float Tr = Tfin, S0 = 0.0f, S1 = 0.0f, S2 = 0.0f;
+    uint32_t m = ncq;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const int px = X0 + 8 * (q & 1) + lx, py = Y0 + 8 * (q >> 1) + ly;
-        const bool inside = px < W && py < H;
-        const size_t pid = (size_t)py * W + px;
-        const float Tfin = inside ? final_T[pid] : 0.0f;
-        ncq[q] = inside ? n_contrib[pid] : 0u;
-        d0[q] = inside ? dL_dpix[pid] : 0.0f; d1[q] = inside ? dL_dpix[hw + pid] : 0.0f; d2[q] = inside ? dL_dpix[2 * hw + pid] : 0.0f;
-        tb[q] = Tfin * (bg0 * d0[q] + bg1 * d1[q] + bg2 * d2[q]);
-        Tr[q] = Tfin; S0[q] = S1[q] = S2[q] = 0.0f;
-        uint32_t m = ncq[q];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
-        maxc[q] = __builtin_amdgcn_readfirstlane(m);
-        max_contrib = max_contrib > (int)maxc[q] ? max_contrib : (int)maxc[q];
-    }
+    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+    const int maxq = (int)__builtin_amdgcn_readfirstlane(m);          // this quadrant's deepest contributor
+    if (lane == 0) smax[wave] = m;
+    __syncthreads();
+    const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int nbatches = (n + SG_WB - 1) / SG_WB;
     const int ridx = sg_red_idx(lane);
+    const int nbatches = (n + SG_BB - 1) / SG_BB;
     for (int kb = nbatches - 1; kb >= 0; kb--) {
-        const int e = kb * SG_WB + lane;
-        uint32_t m = 0, rslot = 0xffffffffu;
-        float4 a, b, c4;
-        if (e < n) {
-            uint32_t gid = point_list[range.x + e];
-            c4 = recC[gid];
-            uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
-            int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
+        const int base = kb * SG_BB;
+        const int cnt = n - base < SG_BB ? n - base : SG_BB;
+        // ---- stage (threads 0..127): records, quadrant mask, gradient-record slot
+        uint32_t rslot = 0xffffffffu;
+        float opac = 0.0f;
+        if (tid < cnt) {
+            const int e = base + tid;
+            const uint32_t gid = point_list[range.x + e];
+            const float4 c4 = recC[gid];
+            const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
+            const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
+            uint32_t mk = 0;
             if (e < max_contrib) {
-                a = recA[gid]; b = recB[gid];
-                m = sg_quad_mask(a, b, (float)X0, (float)Y0);
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    if (!((uint32_t)e < maxc[q])) m &= ~(1u << q);
+                const float4 a = recA[gid], b = recB[gid];
+                opac = b.y;
+                sA[tid] = a; sB[tid] = b; sC[tid] = c4.x;
+                mk = sg_quad_mask(a, b, (float)X0, (float)Y0);
             }
-            if (m == 0u && rslot < cap) {          // reaches no pixel of this tile: zero record
-                float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                grec[3 * (size_t)rslot] = z4; grec[3 * (size_t)rslot + 1] = z4; grec[3 * (size_t)rslot + 2] = z4;
-            }
+            sM[tid] = mk;
         }
-        const unsigned long long bal = __ballot(m != 0u);
-        const int cnt = __popcll(bal);
-        if (cnt == 0) continue;
-        if (m) {
-            int pos = __popcll(bal & lt);
-            L.sA[pos] = a; L.sB[pos] = b; L.sC[pos] = c4.x; L.sM[pos] = ((uint32_t)e << 4) | m; L.sR[pos] = rslot;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        for (int k = cnt - 1; k >= 0; k--) {
-            const uint32_t mm = __builtin_amdgcn_readfirstlane(L.sM[k]);
-            const float4 ga = L.sA[k], gb = L.sB[k];
-            const float gc = L.sC[k];
-            const uint32_t ee = mm >> 4;
-            // v[0..4]: sums of w*m with w = G dL/dalpha; the per-Gaussian factors (-o W/2, -o H/2, -o/2)
-            // are applied once per record when it is flushed (the reduction is linear).
-            float v[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!(mm & (1u << q))) continue;                 // wave-uniform (scalar branch)
+        if (tid < SG_BB) sFlag[tid] = 0;
+        __syncthreads();
+        // ---- each wave: the entries that can reach its quadrant, back to front
+        if (base < maxq) {
+            uint16_t *list = sList[wave];
+            const int lim = maxq - base < cnt ? maxq - base : cnt;         // entries >= maxq touch no pixel here
+            const int nl = sg_compact_quadrant(sM, lim, wave, lane, lt, list, SG_BB);
+            for (int i = nl - 1; i >= 0; i--) {
+                const int k = list[i];
+                const uint32_t ee = (uint32_t)(base + k);
+                const float4 ga = sA[k], gb = sB[k];
+                const float gc = sC[k];
                 // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
-                const float dx = ga.x - pxf[q & 1], dy = ga.y - pyf[q >> 1];
+                const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
                 const float G = sg_exp(power);
                 const float alpha = fminf(0.99f, gb.y * G);
-                const bool valid = (ee < ncq[q]) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                const bool valid = (ee < ncq) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
                 const float ae = valid ? alpha : 0.0f;
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
-                Tr[q] = Tr[q] * rinv;                            // T in front of this entry
-                const float dchan = ae * Tr[q];
-                const float e0 = gb.z - S0[q], e1 = gb.w - S1[q], e2 = gc - S2[q];
-                float dLa = fmaf(e2, d2[q], fmaf(e1, d1[q], e0 * d0[q]));
-                S0[q] = fmaf(ae, e0, S0[q]); S1[q] = fmaf(ae, e1, S1[q]); S2[q] = fmaf(ae, e2, S2[q]);
-                v[6] = fmaf(dchan, d0[q], v[6]); v[7] = fmaf(dchan, d1[q], v[7]); v[8] = fmaf(dchan, d2[q], v[8]);
-                dLa = fmaf(-tb[q], rinv, dLa * Tr[q]);          // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
+                Tr = Tr * rinv;                                  // T in front of this entry
+                const float dchan = ae * Tr;
+                const float e0 = gb.z - S0, e1 = gb.w - S1, e2 = gc - S2;
+                float dLa = fmaf(e2, d2, fmaf(e1, d1, e0 * d0));
+                S0 = fmaf(ae, e0, S0); S1 = fmaf(ae, e1, S1); S2 = fmaf(ae, e2, S2);
+                dLa = fmaf(-tb, rinv, dLa * Tr);                // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
                 const float w = valid ? G * dLa : 0.0f;          // = dL/dopacity contribution; dL/dG = o * dLa
-                v[5] += w;
-                v[0] = fmaf(w, fmaf(dy, ga.w, dx * ga.z), v[0]);
-                v[1] = fmaf(w, fmaf(dx, ga.w, dy * gb.x), v[1]);
+                // v[0..4]: sums of w*m; the per-Gaussian factors (-o W/2, -o H/2, -o/2) are applied once per record
+                float v[9];
+                v[0] = w * fmaf(dy, ga.w, dx * ga.z);
+                v[1] = w * fmaf(dx, ga.w, dy * gb.x);
                 const float wx = w * dx;
-                v[2] = fmaf(wx, dx, v[2]); v[3] = fmaf(wx, dy, v[3]); v[4] = fmaf(w * dy, dy, v[4]);
-            }
-            // (entries that pass the quadrant test but touch no pixel are < 1 %: always reduce)
-            float v8;
-            float z = sg_reduce9(v, lane, &v8);
-            if ((lane & 7) == 0) L.sG[k][ridx] = z;
-            if (lane == 63) L.sG[k][8] = v8;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        if (lane < cnt) {
-            uint32_t r = L.sR[lane];
-            if (r < cap) {
-                const float *s = L.sG[lane];
-                const float no = -L.sB[lane].y, nh = 0.5f * no;          // -opacity, -opacity / 2
-                grec[3 * (size_t)r] = make_float4(no * ddelx_dx * s[0], no * ddely_dy * s[1], nh * s[2], nh * s[3]);
-                grec[3 * (size_t)r + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
-                grec[3 * (size_t)r + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
+                v[2] = wx * dx; v[3] = wx * dy; v[4] = w * dy * dy;
+                v[5] = w;
+                v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;
+                float v8;
+                const float z = sg_reduce9(v, lane, &v8);
+                if ((lane & 7) == 0) sG[wave][k][ridx] = z;
+                if (lane == 63) { sG[wave][k][8] = v8; ((volatile uint8_t *)&sFlag[k])[wave] = 1; }
             }
         }
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        // ---- combine the quadrants in a fixed order and store the record
+        if (tid < cnt && rslot < cap) {
+            float s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+            const uint32_t f = sFlag[tid];
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if ((f >> (8 * w)) & 0xffu) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) s[q] += sG[w][tid][q];
+                }
+            const float no = -opac, nh = 0.5f * no;              // -opacity, -opacity / 2
+            grec[3 * (size_t)rslot] = make_float4(no * ddelx_dx * s[0], no * ddely_dy * s[1], nh * s[2], nh * s[3]);
+            grec[3 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
+            grec[3 * (size_t)rslot + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
+        }
+        __syncthreads();
     }
 }
 
