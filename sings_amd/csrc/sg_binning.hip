@@ -78,7 +78,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
 }
 
 // ---- per-tile sort ---------------------------------------------------------------------
-#define SG_SORT_THREADS 256
+#define SG_SORT_THREADS 1024   // long lists are a tail of a few workgroups: give each the whole CU
 #define SG_SORT_LDS 4096   // u64 entries sorted in LDS (32 KiB)
 
 __device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid, int nthreads)

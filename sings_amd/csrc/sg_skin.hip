@@ -255,7 +255,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     __shared__ float sA[SG_JMAX * 16];
     __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
     __shared__ float sT[SG_SKIN_WAVES][64 * SG_WSTRIDE];     // T transpose scratch, then the dT tile
-    __shared__ float sRed[SG_SKIN_WAVES][SG_JMAX * 16 + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
     const int idx = g0 + lane;
@@ -342,7 +341,8 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 #pragma unroll
     for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
     const int nchunk = (k.J + 15) >> 4;
-    float *red = sRed[wave];
+    // every wave owns one slab row (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
+    float *out = slab + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
     for (int cch = 0; cch < nchunk; cch++) {
         sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sW[wave]);
         __builtin_amdgcn_s_waitcnt(0);
@@ -356,7 +356,7 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         }
         // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
 #pragma unroll
-        for (int r = 0; r < 4; r++) red[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
         __builtin_amdgcn_wave_barrier();
     }
     // dtransl: wave sum
@@ -365,33 +365,34 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         float v = dtr[i];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) red[SG_JMAX * 16 + i] = v;
-    }
-    __syncthreads();
-    // cross-wave sum (fixed order) -> this workgroup's slab row
-    float *out = slab + (size_t)blockIdx.x * slab_stride;
-    const int nA = nchunk * 256;
-    for (int i = threadIdx.x; i < nA; i += SG_SKIN_THREADS)
-        out[i] = sRed[0][i] + sRed[1][i] + sRed[2][i] + sRed[3][i];
-    if (threadIdx.x < 3) {
-        int i = SG_JMAX * 16 + threadIdx.x;
-        out[SG_JMAX * 16 + threadIdx.x] = sRed[0][i] + sRed[1][i] + sRed[2][i] + sRed[3][i];
+        if (lane == 0) out[SG_JMAX * 16 + i] = v;
     }
 }
 
-// sums the per-workgroup slabs: dL_dA [J,16] and dL_dtransl [3]
+// sums the per-wave slab rows in a fixed order: dL_dA [J,16] and dL_dtransl [3].
+// One workgroup per 16 output columns; 16 row groups per column, combined through LDS.
 __global__ void __launch_bounds__(256)
-sg_skin_reduce_kernel(const float *__restrict__ slab, int nblocks, int slab_stride, int J,
+sg_skin_reduce_kernel(const float *__restrict__ slab, int nrows, int slab_stride, int J,
                       float *__restrict__ dL_dA, float *__restrict__ dL_dtransl)
 {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    int nA = J * 16;
-    if (i >= nA + 3) return;
-    int col = i < nA ? i : SG_JMAX * 16 + (i - nA);
+    __shared__ float part[16][17];
+    const int o = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + o;
+    const int nA = J * 16;
+    const bool ok = i < nA + 3;
+    const int col = i < nA ? i : SG_JMAX * 16 + (i - nA);
     float s = 0.0f;
-    for (int b = 0; b < nblocks; b++) s += slab[(size_t)b * slab_stride + col];
-    if (i < nA) dL_dA[i] = s;
-    else if (dL_dtransl) dL_dtransl[i - nA] = s;
+    if (ok)
+        for (int b = rg; b < nrows; b += 16) s += slab[(size_t)b * slab_stride + col];
+    part[rg][o] = s;
+    __syncthreads();
+    if (rg == 0 && ok) {
+        float t = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += part[r][o];
+        if (i < nA) dL_dA[i] = t;
+        else if (dL_dtransl) dL_dtransl[i - nA] = t;
+    }
 }
 
 // ---- launchers ---------------------------------------------------------------------------
@@ -411,7 +412,7 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
 #undef SG_SF
 }
 
-size_t sg_skin_slab_floats(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * (SG_JMAX * 16 + 4); }
+size_t sg_skin_slab_floats(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES * (SG_JMAX * 16 + 4); }
 
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
@@ -429,8 +430,8 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                                      dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
-    hipLaunchKernelGGL(sg_skin_reduce_kernel, dim3((in->J * 16 + 3 + 255) / 256), dim3(256), 0, st, slab, nblocks, stride,
-                       in->J, dL_dA, dL_dtransl);
+    hipLaunchKernelGGL(sg_skin_reduce_kernel, dim3((in->J * 16 + 3 + 15) / 16), dim3(256), 0, st, slab,
+                       nblocks * SG_SKIN_WAVES, stride, in->J, dL_dA, dL_dtransl);
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
 }
