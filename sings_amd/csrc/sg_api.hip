@@ -51,6 +51,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_pair_gid = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_pair_tile = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_pair_local = o; o = sg_align(o + (cap + 1) * 4);
+    L->bin_long_tiles = o; o = sg_align(o + T * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);

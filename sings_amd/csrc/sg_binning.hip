@@ -19,7 +19,8 @@
 // single workgroup, 1024 threads x 8 consecutive tiles each: exclusive scan over T tile counts
 __global__ void __launch_bounds__(1024)
 sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_stride, uint2 *__restrict__ ranges,
-                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap)
+                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap,
+                    uint32_t *__restrict__ long_tiles, uint32_t long_threshold)
 {
     __shared__ uint32_t wsum[16];
     __shared__ uint32_t carry_s;
@@ -48,6 +49,7 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_
                 uint32_t s = start < cap ? start : cap, e = start + v[k] < cap ? start + v[k] : cap;
                 ranges[i0 + k] = v[k] ? make_uint2(s, e) : make_uint2(0u, 0u);
                 cursor[i0 + k] = start;
+                if (e - s > long_threshold) long_tiles[atomicAdd(&header[4], 1u)] = (uint32_t)(i0 + k);
             }
             start += v[k];
         }
@@ -136,14 +138,18 @@ sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t
 
 // long lists: one workgroup per tile
 __global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
+sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ long_tiles,
+                    const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
                     uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys, uint32_t *__restrict__ rank)
 {
     __shared__ uint64_t s[SG_SORT_LDS];
-    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t nlong = header[4];
+    for (uint32_t li = blockIdx.x; li < nlong; li += gridDim.x) {      // work list written by the scan kernel
+    const int tile = (int)long_tiles[li];
     uint2 r = ranges[tile];
     uint32_t n = r.y - r.x;
-    if (n <= SG_WSORT_MAX) return;
+    __syncthreads();
     uint64_t *seg = pair_keys + r.x;
     if (n <= SG_SORT_LDS) {
         int n2 = 1; while (n2 < (int)n) n2 <<= 1;
@@ -194,6 +200,7 @@ sg_tile_sort_kernel(const uint2 *__restrict__ ranges, uint64_t *__restrict__ pai
             if (point_keys) point_keys[r.x + pos] = ((uint64_t)tile << 32) | (k >> 32);
         }
     }
+    }
 }
 
 void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
@@ -204,7 +211,8 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
-    hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.tc_stride, b.ranges, b.cursor, b.header, cap32);
+    hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.tc_stride, b.ranges, b.cursor, b.header, cap32,
+                       b.long_tiles, (uint32_t)SG_WSORT_MAX);
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
     if (P > 0) {
@@ -217,7 +225,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     sg_prof_begin(SG_K_TILE_SORT, st);
     hipLaunchKernelGGL(sg_tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, st, T, b.ranges, b.pair_keys,
                        b.point_list, pk);
-    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T), dim3(SG_SORT_THREADS), 0, st, b.ranges, b.pair_keys,
-                       b.point_list, pk, b.pair_local);
+    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T < 2048 ? T : 2048), dim3(SG_SORT_THREADS), 0, st, b.header, b.long_tiles,
+                       b.ranges, b.pair_keys, b.point_list, pk, b.pair_local);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

@@ -24,7 +24,7 @@ struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vec
 };
 
 struct SgBin {
-    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles
+    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] number of long tiles
     uint32_t *tile_count;  // [T * tc_stride], counter of tile t at t * tc_stride
     uint32_t tc_stride;
     uint2 *ranges;         // [T] (start,end) into point_list
@@ -35,6 +35,7 @@ struct SgBin {
     uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
     uint32_t *pair_tile;   //       tile id,
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
+    uint32_t *long_tiles;  // [T] ids of tiles whose list is too long for the one-wave sort; count in header[4]
 };
 
 struct SgImg {
@@ -64,6 +65,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);
     g.pair_gid = (uint32_t *)(b + L.bin_pair_gid); g.pair_tile = (uint32_t *)(b + L.bin_pair_tile);
     g.pair_local = (uint32_t *)(b + L.bin_pair_local);
+    g.long_tiles = (uint32_t *)(b + L.bin_long_tiles);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
