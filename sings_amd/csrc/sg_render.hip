@@ -231,7 +231,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ uint32_t sM[SG_BB];
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
-    __shared__ uint32_t sFlag[SG_BB];          // byte w != 0: quadrant w wrote sG[w][k]
+    __shared__ uint8_t sFlag[4][SG_BB];        // [w][k] != 0: quadrant w wrote sG[w][k]
     __shared__ uint32_t smax[4];
     const int tile = sg_tile_of_block(blockIdx.x, nblocks);
     if (tile >= T) return;
@@ -284,7 +284,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             }
             sM[tid] = mk;
         }
-        if (tid < SG_BB) sFlag[tid] = 0;
+        if (tid < SG_BB) { sFlag[0][tid] = 0; sFlag[1][tid] = 0; sFlag[2][tid] = 0; sFlag[3][tid] = 0; }
         __syncthreads();
         // ---- each wave: the entries that can reach its quadrant, back to front
         if (base < maxq) {
@@ -322,17 +322,16 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 float v8;
                 const float z = sg_reduce9(v, lane, &v8);
                 if ((lane & 7) == 0) sG[wave][k][ridx] = z;
-                if (lane == 63) { sG[wave][k][8] = v8; ((volatile uint8_t *)&sFlag[k])[wave] = 1; }
+                if (lane == 63) { sG[wave][k][8] = v8; sFlag[wave][k] = 1; }
             }
         }
         __syncthreads();
         // ---- combine the quadrants in a fixed order and store the record
         if (tid < cnt && rslot < cap) {
             float s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-            const uint32_t f = sFlag[tid];
 #pragma unroll
             for (int w = 0; w < 4; w++)
-                if ((f >> (8 * w)) & 0xffu) {
+                if (sFlag[w][tid]) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) s[q] += sG[w][tid][q];
                 }
