@@ -1,0 +1,93 @@
+"""GPU test of the host-side mirror of the reference's render glue:
+same keys, dtypes and side outputs as sings/rec/renderer/gs_renderer_single.py:12-107."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import raster_oracle as ro
+from sings_amd.camera import make_camera
+from sings_amd.scene import synthetic_scene
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(dev, W, H):
+    cam = make_camera(np.eye(4, dtype=np.float32), 1.2 * W, 1.2 * W, W / 2, H / 2, W, H)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return cam, dict(fovx=cam["fovx"], fovy=cam["fovy"], image_height=H, image_width=W,
+                     world_view_transform=t(cam["world_view_transform"]), full_proj_transform=t(cam["full_proj_transform"]),
+                     camera_center=t(cam["camera_center"]))
+
+
+def test_get_render_pkg_keys_dtypes_and_densification_outputs():
+    from sings_amd.renderer import get_render_pkg, get_render_pkgs
+    dev = torch.device("cuda:0")
+    W, H = 160, 96
+    s = synthetic_scene(2500, W, H, 2, 6)
+    cam, data = _data(dev, W, H)
+    req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    gs = dict(xyz=req(s["means3D"]), shs=req(s["shs"]), opacity=req(s["opacities"]), scales=req(s["scales"]),
+              rotq=req(s["rotations"]), active_sh_degree=2)
+    bg = torch.rand(3, device=dev)                                 # gs_trainer.py:238
+    pkg = get_render_pkg(data, gs, bg)
+    assert set(pkg) >= {"render", "viewspace_points", "visibility_filter", "radii", "human_visibility_filter", "human_radii"}
+    assert pkg["render"].shape == (3, H, W) and pkg["render"].dtype == torch.float32
+    assert float(pkg["render"].detach().min()) >= 0.0 and float(pkg["render"].detach().max()) <= 1.0      # clamp(0,1), :96
+    assert pkg["radii"].dtype == torch.int32 and pkg["visibility_filter"].dtype == torch.bool
+    assert torch.equal(pkg["visibility_filter"], pkg["radii"] > 0)
+    o = ro.forward(s["means3D"], s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
+                   W, H, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), bg.cpu().numpy(), scales=s["scales"],
+                   rotations=s["rotations"], shs=s["shs"], sh_degree=2)
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), o["radii"])
+    strict = o["margin"] >= 2e-5
+    assert np.abs(pkg["render"].detach().cpu().numpy() - np.clip(o["color"], 0, 1)).max(0)[strict].max() <= 1e-5
+    # the clamp zeroes dL/dimage on saturated pixels before the op's backward (SURVEY App. A.5 last bullet)
+    sat = (o["color"] <= 0) | (o["color"] >= 1)
+    dLn = s["dL_dimage"][:, :H, :W].copy(); dLn[:, ~strict] = 0
+    (pkg["render"] * torch.from_numpy(dLn).to(dev)).sum().backward()      # clamp's own autograd zeroes saturated pixels
+    dLn[sat] = 0
+    g = ro.backward(o, dLn)
+    vg = pkg["viewspace_points"].grad                                # consumer: sings_hybrid.py:1013-1015
+    assert vg.shape == (2500, 3) and float(vg[:, 2].abs().max()) == 0.0
+    ok = np.abs(vg.cpu().numpy() - g["dL_dmean2D"]) <= 5e-4 * np.abs(g["dL_dmean2D"]) + 1e-4 * np.abs(g["dL_dmean2D"]).max()
+    assert ok.mean() > 0.9995         # pixels within rounding of the 0 / 1 clamp may saturate on one side only
+    # several avatars in one frame: concatenation then one raster call (gs_renderer_multiple.py:12-68)
+    half = lambda d, a, b: {k: (v[a:b] if torch.is_tensor(v) else v) for k, v in d.items()}
+    with torch.no_grad():
+        p2 = get_render_pkgs(data, [half(gs, 0, 1000), half(gs, 1000, 2500)], bg)
+        p1 = get_render_pkg(data, gs, bg)
+    assert torch.equal(p1["render"], p2["render"]) and torch.equal(p1["radii"], p2["radii"])
+
+
+def test_get_render_pkg_fused_matches_unfused():
+    from oracle import lbs_oracle as lo
+    from sings_amd.renderer import get_render_pkg, get_render_pkg_fused
+    from sings_amd.scene import avatar_scene
+    from sings_amd.body import joint_transforms
+    dev = torch.device("cuda:0")
+    s = avatar_scene(N=20000, J=52, W=256, H=448, seed=3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = make_camera(np.eye(4, dtype=np.float32), 2500.0, 2500.0, 128, 224, 256, 448)
+    data = dict(fovx=cam["fovx"], fovy=cam["fovy"], image_height=448, image_width=256,
+                world_view_transform=t(cam["world_view_transform"]), full_proj_transform=t(cam["full_proj_transform"]),
+                camera_center=t(cam["camera_center"]))
+    pose = np.zeros(156, np.float32); pose[3:72] = np.random.RandomState(1).normal(0, 0.25, 69)
+    A = joint_transforms(t(pose), t(s["joints_rest"]), tuple(s["parents"]))
+    canon = dict(xyz_canon=t(s["xyz_canon"]), rotmat_canon=None, scales=t(s["scales"]), opacity=t(s["opacities"]),
+                 shs=t(s["shs"]), lbs_weights=t(s["lbs_weights"]), active_sh_degree=0)
+    bg = torch.ones(3, device=dev)
+    with torch.no_grad():
+        fused = get_render_pkg_fused(data, canon, A, bg, smpl_scale=t(s["smpl_scale"]), transl=t(s["transl"]), return_posed=True)
+        gs = dict(xyz=fused["xyz"], shs=canon["shs"], opacity=canon["opacity"], scales=fused["scales"], rotq=fused["rotq"],
+                  active_sh_degree=0)
+        plain = get_render_pkg(data, gs, bg)
+    assert torch.equal(fused["render"], plain["render"]) and torch.equal(fused["radii"], plain["radii"])
+    assert int(fused["visibility_filter"].sum()) > 15000
+    # isotropic canonical rotation = identity -> posed quaternion of the blended joint rotation (non-unit is expected)
+    xyz_o, q_o, sc_o, _ = lo.deform_gaussians(torch.from_numpy(s["xyz_canon"]), torch.eye(3)[None].repeat(20000, 1, 1),
+                                              torch.from_numpy(s["scales"]), torch.from_numpy(s["lbs_weights"]), A.cpu(),
+                                              smpl_scale=torch.from_numpy(s["smpl_scale"]), transl=torch.from_numpy(s["transl"]))
+    assert np.abs(fused["xyz"].cpu().numpy() - xyz_o.numpy()).max() < 5e-5
+    assert np.abs(fused["rotq"].cpu().numpy() - q_o.numpy()).max() < 5e-5
