@@ -91,3 +91,33 @@ def test_get_render_pkg_fused_matches_unfused():
                                               smpl_scale=torch.from_numpy(s["smpl_scale"]), transl=torch.from_numpy(s["transl"]))
     assert np.abs(fused["xyz"].cpu().numpy() - xyz_o.numpy()).max() < 5e-5
     assert np.abs(fused["rotq"].cpu().numpy() - q_o.numpy()).max() < 5e-5
+
+
+def test_animate_chunk_matches_per_frame_fused_calls():
+    from sings_amd.body import joint_transforms
+    from sings_amd.posed import animate_chunk
+    from sings_amd.renderer import get_render_pkg_fused
+    from sings_amd.scene import avatar_scene
+    dev = torch.device("cuda:0")
+    s = avatar_scene(N=8000, J=24, W=128, H=224, seed=5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = make_camera(np.eye(4, dtype=np.float32), 1250.0, 1250.0, 64, 112, 128, 224)
+    data = dict(fovx=cam["fovx"], fovy=cam["fovy"], image_height=224, image_width=128,
+                world_view_transform=t(cam["world_view_transform"]), full_proj_transform=t(cam["full_proj_transform"]),
+                camera_center=t(cam["camera_center"]))
+    rs = np.random.RandomState(2)
+    poses = t(rs.normal(0, 0.2, (5, 72)).astype(np.float32))
+    transl = t(np.tile(s["transl"], (5, 1)) + rs.normal(0, 0.02, (5, 3)).astype(np.float32))
+    jr = t(s["joints_rest"])
+    canon = dict(xyz_canon=t(s["xyz_canon"]), rotmat_canon=None, scales=t(s["scales"]), opacity=t(s["opacities"]),
+                 shs=t(s["shs"]), lbs_weights=t(s["lbs_weights"]), active_sh_degree=0)
+    A_cano = joint_transforms(torch.zeros(72, device=dev), jr, tuple(s["parents"]))          # canonical = rest pose
+    bg = torch.ones(3, device=dev)
+    imgs = dict(animate_chunk(canon, poses, jr, A_cano, data, bg, transl=transl, parents=tuple(s["parents"]), chunk_size=2))
+    assert sorted(imgs) == [0, 1, 2, 3, 4]
+    for f in range(5):
+        A = joint_transforms(poses[f], jr, tuple(s["parents"])) @ torch.inverse(A_cano)
+        with torch.no_grad():
+            ref = get_render_pkg_fused(data, canon, A, bg, transl=transl[f])["render"]
+        assert torch.allclose(imgs[f], ref, atol=2e-6)
+        assert float((imgs[f] < 0.999).float().mean()) > 0.02          # the avatar is in view

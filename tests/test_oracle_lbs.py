@@ -81,3 +81,18 @@ def test_body_joint_transforms_match_reference_chain():
     pose = T(G["g2_poses"][2]).clone().requires_grad_(True)
     joint_transforms(pose, J_rest).square().sum().backward()
     assert torch.isfinite(pose.grad).all() and pose.grad.abs().max() > 0
+
+
+def test_posed_driver_batch_chain_and_amass_mapping():
+    """sings_amd/posed.py: chunked A production equals the per-frame chain (hence golden G2); AMASS joint map."""
+    from sings_amd.body import joint_transforms
+    from sings_amd.posed import AMASS_SMPLH_TO_SMPL_JOINTS, amass_to_smpl_pose, joint_transforms_batch
+    bm = lo.synthetic_body_model(seed=0)
+    J_rest = torch.einsum("ik,ji->jk", T(bm["v_template"]), T(bm["J_regressor"]))
+    poses = T(G["amass_poses_72"][:6])
+    A = joint_transforms_batch(poses, J_rest, tuple(bm["parents"].tolist()))
+    for f in range(6):
+        close(A[f], joint_transforms(poses[f], J_rest, tuple(bm["parents"].tolist())).numpy(), 1e-6)
+    assert AMASS_SMPLH_TO_SMPL_JOINTS.shape == (72,) and list(AMASS_SMPLH_TO_SMPL_JOINTS[-3:]) == [111, 112, 113]
+    p156 = np.arange(2 * 156, dtype=np.float32).reshape(2, 156)
+    assert np.array_equal(amass_to_smpl_pose(p156)[:, :69], p156[:, :69]) and np.array_equal(amass_to_smpl_pose(p156)[:, 69:], p156[:, 111:114])
