@@ -52,10 +52,13 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_pair_tile = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_pair_local = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_long_tiles = o; o = sg_align(o + T * 4);
+    L->bin_items = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
+    L->bin_ck_start = o; o = sg_align(o + T * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);
     L->img_n_contrib = o; o = sg_align(o + hw * 4);
+    L->img_ckpt = o; o = sg_align(o + (size_t)sg_ckpt_cap(cap) * (256 * 16));
     L->img_bytes = o;
     L->bwd_bytes = sg_align((cap + 1) * SG_GRAD_REC_FLOATS * 4);
     return 0;

@@ -20,29 +20,38 @@
 __global__ void __launch_bounds__(1024)
 sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_stride, uint2 *__restrict__ ranges,
                     uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap,
-                    uint32_t *__restrict__ long_tiles, uint32_t long_threshold)
+                    uint32_t *__restrict__ long_tiles, uint32_t long_threshold, uint32_t *__restrict__ items,
+                    uint32_t *__restrict__ ck_start, uint32_t items_cap)
 {
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry_s;
+    __shared__ uint32_t wsum[16], wsum_i[16], wsum_c[16];
+    __shared__ uint32_t carry_s, carry_i, carry_c;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) { carry_s = 0; carry_i = 0; carry_c = 0; }
     __syncthreads();
     for (int base = 0; base < T; base += 8192) {
         const int i0 = base + tid * 8;
         uint32_t v[8], sum = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) { v[k] = i0 + k < T ? tile_count[(size_t)(i0 + k) * tc_stride] : 0u; sum += v[k]; }
-        uint32_t incl = sum;
+        // backward work items (1 per tile, one per SG_SEG entries for longer lists) and checkpoint slots
+        uint32_t isum = 0, csum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t seg = sg_nseg(v[k]);
+            if (i0 + k < T) { isum += seg ? seg : 1u; csum += seg; }
+        }
+        uint32_t incl = sum, incl_i = isum, incl_c = csum;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(incl, o, 64);
-            if (lane >= o) incl += u;
+            uint32_t u = __shfl_up(incl, o, 64), ui = __shfl_up(incl_i, o, 64), uc = __shfl_up(incl_c, o, 64);
+            if (lane >= o) { incl += u; incl_i += ui; incl_c += uc; }
         }
-        if (lane == 63) wsum[wid] = incl;
+        if (lane == 63) { wsum[wid] = incl; wsum_i[wid] = incl_i; wsum_c[wid] = incl_c; }
         __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wid; w++) woff += wsum[w];
+        uint32_t woff = 0, woff_i = 0, woff_c = 0;
+        for (int w = 0; w < wid; w++) { woff += wsum[w]; woff_i += wsum_i[w]; woff_c += wsum_c[w]; }
         uint32_t start = carry_s + woff + incl - sum;
+        uint32_t istart = carry_i + woff_i + incl_i - isum, cstart = carry_c + woff_c + incl_c - csum;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
             if (i0 + k < T) {
@@ -50,14 +59,20 @@ sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_
                 ranges[i0 + k] = v[k] ? make_uint2(s, e) : make_uint2(0u, 0u);
                 cursor[i0 + k] = start;
                 if (e - s > long_threshold) long_tiles[atomicAdd(&header[4], 1u)] = (uint32_t)(i0 + k);
+                const uint32_t nseg = sg_nseg(v[k]), nit = nseg ? nseg : 1u;
+                for (uint32_t sg = 0; sg < nit; sg++)
+                    if (istart + sg < items_cap) items[istart + sg] = (uint32_t)(i0 + k) | (sg << 20);
+                ck_start[i0 + k] = nseg ? cstart : 0xffffffffu;
+                istart += nit; cstart += nseg;
             }
             start += v[k];
         }
         __syncthreads();
-        if (tid == 1023) carry_s = start;
+        if (tid == 1023) { carry_s = start; carry_i = istart; carry_c = cstart; }
         __syncthreads();
     }
     if (tid == 0) {
+        header[5] = carry_i < items_cap ? carry_i : items_cap;
         header[0] = carry_s;
         header[1] = carry_s > cap ? 1u : 0u;
         header[3] = (uint32_t)T;
@@ -212,7 +227,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
     hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.tc_stride, b.ranges, b.cursor, b.header, cap32,
-                       b.long_tiles, (uint32_t)SG_WSORT_MAX);
+                       b.long_tiles, (uint32_t)SG_WSORT_MAX, b.items, b.ck_start, sg_items_cap(T, cap));
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
     if (P > 0) {

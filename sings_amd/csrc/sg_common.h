@@ -7,6 +7,14 @@
 #include "../../include/sings_hip.h"
 
 #define SG_WAVE 64
+// Tile lists longer than SG_SEG entries are cut into depth segments of SG_SEG entries: the forward checkpoints the
+// per-pixel (T, colour) at every segment boundary, the backward runs one workgroup per (tile, segment).
+#define SG_SEG 256
+// number of segments (= checkpoint slots) of a tile list of n entries; 0: not segmented (segment id has 12 bits)
+__host__ __device__ inline uint32_t sg_nseg(uint32_t n) { return n > SG_SEG && n <= SG_SEG * 4095u ? (n + SG_SEG - 1) / SG_SEG : 0u; }
+// capacities of the work-item list and of the checkpoint buffer (slots of 256 float4) for T tiles / cap pairs
+__host__ __device__ inline uint32_t sg_items_cap(size_t T, size_t cap) { size_t v = T + cap / SG_SEG + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
+__host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (cap / SG_SEG) + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 // Words between two tile counters.  Packed counters (stride 1) let one 64-lane atomic instruction touch few
 // lines (a Gaussian's tiles are neighbours) -- best when the image has many tiles and ~100 pairs per tile
 // (cfg3: 39 us vs 55 us padded).  With few tiles and thousands of pairs per tile (avatar close-ups: a row of 32
@@ -24,7 +32,7 @@ struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vec
 };
 
 struct SgBin {
-    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] number of long tiles
+    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] number of long tiles  [5] number of backward work items
     uint32_t *tile_count;  // [T * tc_stride], counter of tile t at t * tc_stride
     uint32_t tc_stride;
     uint2 *ranges;         // [T] (start,end) into point_list
@@ -36,11 +44,14 @@ struct SgBin {
     uint32_t *pair_tile;   //       tile id,
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
     uint32_t *long_tiles;  // [T] ids of tiles whose list is too long for the one-wave sort; count in header[4]
+    uint32_t *items;       // backward work items: tile | segment << 20; count in header[5]
+    uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
 };
 
 struct SgImg {
     float *final_T;        // [H*W]
     uint32_t *n_contrib;   // [H*W]
+    float4 *ckpt;          // [slots][256 pixels] (T, C.r, C.g, C.b); slot 0 of a tile = final state
 };
 
 static inline size_t sg_align(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -66,6 +77,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.pair_gid = (uint32_t *)(b + L.bin_pair_gid); g.pair_tile = (uint32_t *)(b + L.bin_pair_tile);
     g.pair_local = (uint32_t *)(b + L.bin_pair_local);
     g.long_tiles = (uint32_t *)(b + L.bin_long_tiles);
+    g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
@@ -73,6 +85,7 @@ static inline SgImg sg_img_view(void *ws, const SgLayout &L)
     char *b = (char *)ws;
     SgImg g;
     g.final_T = (float *)(b + L.img_final_T); g.n_contrib = (uint32_t *)(b + L.img_n_contrib);
+    g.ckpt = (float4 *)(b + L.img_ckpt);
     return g;
 }
 

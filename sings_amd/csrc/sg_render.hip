@@ -101,7 +101,8 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, float *__restrict__ out_color,
-                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib)
+                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
+                     const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap)
 {
     __shared__ float4 sA[SG_FB];
     __shared__ float4 sB[SG_FB];
@@ -117,6 +118,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
+    const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
     bool done = !inside;
@@ -132,6 +134,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         }
         __syncthreads();
         if (__ballot(done) == ~0ull) continue;             // this quadrant is finished (wave-uniform)
+        // state in front of entry `base`, for the backward pass of the segments behind it (SG_FB == SG_SEG)
+        if (base > 0 && cks != 0xffffffffu && cks + (uint32_t)(base / SG_SEG) < ck_cap)
+            ckpt[(size_t)(cks + (uint32_t)(base / SG_SEG)) * 256 + tid] = make_float4(Tr, C0, C1, C2);
         const int cnt = n - base < SG_FB ? n - base : SG_FB;
         uint16_t *list = sList[wave];
         const int nl = sg_compact_quadrant(sM, cnt, wave, lane, lt, list, SG_FB);
@@ -154,6 +159,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             done = done | term;
         }
     }
+    if (cks < ck_cap) ckpt[(size_t)cks * 256 + tid] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
     if (inside) {
         const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
         final_T[pid] = Tr;
@@ -169,12 +175,13 @@ static inline int sg_render_blocks(int T) { return ((T + 7) / 8) * 8; }
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           hipStream_t st)
 {
-    (void)cap;
+    static_assert(SG_FB == SG_SEG, "forward batches are the checkpoint granularity");
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
-                       b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib);
+                       b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib,
+                       b.ck_start, im.ckpt, sg_ckpt_cap(cap));
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -223,7 +230,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, const float *__restrict__ final_T,
                      const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
-                     float4 *__restrict__ grec, uint32_t cap)
+                     float4 *__restrict__ grec, uint32_t cap, const uint32_t *__restrict__ header,
+                     const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
+                     const float4 *__restrict__ ckpt, uint32_t ck_cap)
 {
     __shared__ float4 sA[SG_BB];
     __shared__ float4 sB[SG_BB];
@@ -233,8 +242,16 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
     __shared__ uint8_t sFlag[4][SG_BB];        // [w][k] != 0: quadrant w wrote sG[w][k]
     __shared__ uint32_t smax[4];
-    const int tile = sg_tile_of_block(blockIdx.x, nblocks);
-    if (tile >= T) return;
+    // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
+    // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
+    (void)T; (void)nblocks;
+    const int nitems = (int)header[5];
+    const int chunk = (nitems + 7) >> 3;
+    if ((int)(blockIdx.x >> 3) >= chunk) return;
+    const int it = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if (it >= nitems) return;
+    const uint32_t item = items[it];
+    const int tile = (int)(item & 0xfffffu), seg = (int)(item >> 20);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
     const int X0 = tx * 16, Y0 = ty * 16;
@@ -243,7 +260,10 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = (int)(range.y - range.x);
-    if (n == 0) return;
+    const uint32_t cks = ck_start[tile];
+    const int lo = seg * SG_SEG;                                   // this item: entries [lo, hi)
+    const int hi = cks != 0xffffffffu && lo + SG_SEG < n ? lo + SG_SEG : n;
+    if (lo >= n) return;
     const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
     // per-pixel state: running T, colour accumulated BEHIND the current entry, dL/dpixel, T_final <bg, dL/dpixel>
     const float Tfin = inside ? final_T[pid] : 0.0f;
@@ -251,6 +271,16 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const float d0 = inside ? dL_dpix[pid] : 0.0f, d1 = inside ? dL_dpix[hw + pid] : 0.0f, d2 = inside ? dL_dpix[2 * hw + pid] : 0.0f;
     const float tb = Tfin * (bg[0] * d0 + bg[1] * d1 + bg[2] * d2);
     float Tr = Tfin, S0 = 0.0f, S1 = 0.0f, S2 = 0.0f;
+    // Not the last segment, and this pixel has contributors behind it: start from the forward checkpoint at `hi`.
+    // T in front of entry hi; S = colour composited behind it, normalised by that T.  (A pixel with ncq <= hi has
+    // nothing behind: final state.  ncq > hi implies the forward reached that boundary with this pixel live.)
+    if (hi < n && ncq > (uint32_t)hi && cks + (uint32_t)(hi / SG_SEG) < ck_cap) {
+        const float4 cb = ckpt[(size_t)(cks + (uint32_t)(hi / SG_SEG)) * 256 + tid];
+        const float4 cf = ckpt[(size_t)cks * 256 + tid];
+        const float rT = 1.0f / cb.x;
+        Tr = cb.x;
+        S0 = (cf.y - cb.y) * rT; S1 = (cf.z - cb.z) * rT; S2 = (cf.w - cb.w) * rT;
+    }
     uint32_t m = ncq;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
@@ -261,10 +291,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int ridx = sg_red_idx(lane);
-    const int nbatches = (n + SG_BB - 1) / SG_BB;
-    for (int kb = nbatches - 1; kb >= 0; kb--) {
+    for (int kb = (hi - 1) / SG_BB; kb >= lo / SG_BB; kb--) {
         const int base = kb * SG_BB;
-        const int cnt = n - base < SG_BB ? n - base : SG_BB;
+        const int cnt = hi - base < SG_BB ? hi - base : SG_BB;
         // ---- stage (threads 0..127): records, quadrant mask, gradient-record slot
         uint32_t rslot = 0xffffffffu;
         float opac = 0.0f;
@@ -347,12 +376,13 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, float *grec, hipStream_t st)
 {
+    static_assert(SG_SEG % SG_BB == 0, "segments are whole backward batches");
     const int T = c.gx * c.gy;
-    const int grid = sg_render_blocks(T);
+    const int grid = sg_render_blocks((int)sg_items_cap((size_t)T, cap));
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     sg_prof_begin(SG_K_RENDER_BWD, st);
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
-                       (float4 *)grec, cap32);
+                       (float4 *)grec, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap));
     sg_prof_end(SG_K_RENDER_BWD, st);
 }

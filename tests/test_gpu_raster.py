@@ -78,11 +78,11 @@ def _check_image(color, final_T, n_contrib, o):
     return nb
 
 
-def _grad_close(name, a, b, rtol=2e-4):
+def _grad_close(name, a, b, rtol=2e-4, atol=2e-6):
     a = a.astype(np.float64); b = b.astype(np.float64)
     scale = np.abs(b).max() + 1e-30
     err = np.abs(a - b)
-    bound = rtol * np.abs(b) + 2e-6 * scale
+    bound = rtol * np.abs(b) + atol * scale
     bad = err > bound
     assert not bad.any(), f"{name}: {bad.sum()} of {bad.size} off; worst abs {err.max():.3e} (scale {scale:.3e})"
 
@@ -253,8 +253,11 @@ def test_long_tile_lists_sort_paths(N, W, H):
     color, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh,
                                       scales=sc, rotations=rt)
     color.backward(torch.from_numpy(dLn).to(dev))
-    _grad_close("means3D", m.grad.cpu().numpy(), g["dL_dmeans3D"], rtol=1e-3)
-    _grad_close("opacity", op.grad.cpu().numpy(), g["dL_dopacity"], rtol=1e-3)
+    # Lists longer than 256 entries are composited backward per depth segment, each segment starting from the forward
+    # checkpoint: the colour behind the segment is (C_total - C_front) / T_front instead of the oracle's back-to-front
+    # recursion -- the same quantity with a different fp32 rounding (~1e-6 per pixel term, summed over the tile).
+    _grad_close("means3D", m.grad.cpu().numpy(), g["dL_dmeans3D"], rtol=1e-3, atol=6e-6)
+    _grad_close("opacity", op.grad.cpu().numpy(), g["dL_dopacity"], rtol=1e-3, atol=6e-6)
 
 
 def test_capacity_growth_and_empty_input():
