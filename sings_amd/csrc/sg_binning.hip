@@ -16,78 +16,152 @@
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
 #include "sg_common.h"
 
-// single workgroup, 1024 threads x 8 consecutive tiles each: exclusive scan over T tile counts
+#define SG_WSORT_MAX 256       // longest list sorted by a single wave
+#define SG_SORT_THREADS 1024   // longer lists: one 1024-thread workgroup per chunk of
+#define SG_SORT_LDS 4096       // u64 entries sorted in LDS (32 KiB)
+
+// Exclusive scans over the T tile counts of
+//   q0 pairs (-> ranges, per-counter cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
+// Workgroup b owns tiles [b * 1024 * tpt, (b + 1) * 1024 * tpt), one tile per thread and round.  Instead of a second
+// kernel (or a look-back chain) every workgroup first REDUCES the counts of all tiles in front of its range itself:
+// at most T words per workgroup, coalesced and L2-resident.  The kernel is a handful of waves that start with a cold
+// instruction cache, so its loops are deliberately NOT unrolled: the fully unrolled version (1200 instructions of
+// straight-line code) took 22 us at 8160 tiles and 49 us with 8 sub-counters, this one 12 us / 23 us.
+// The work lists themselves are written by the (chip-wide) scatter kernel from the per-tile
+// `plan` = (first backward item, first sort item, first rank item, pair count).  K = sub-counters per tile.
+#define SG_SCAN_NQ 5
+__device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ])
+{
+    const uint32_t seg = sg_nseg(v);
+    const uint32_t nch = v > SG_WSORT_MAX ? (v + SG_SORT_LDS - 1) / SG_SORT_LDS : 0u;
+    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = nch; q[4] = nch > 1 ? nch : 0u;
+}
+
+template <int K>
 __global__ void __launch_bounds__(1024)
-sg_tile_scan_kernel(int T, const uint32_t *__restrict__ tile_count, uint32_t tc_stride, uint2 *__restrict__ ranges,
-                    uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap,
-                    uint32_t *__restrict__ long_tiles, uint32_t long_threshold, uint32_t *__restrict__ items,
+sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uint32_t tc_stride,
+                    uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
+                    uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
                     uint32_t *__restrict__ ck_start, uint32_t items_cap)
 {
-    __shared__ uint32_t wsum[16], wsum_i[16], wsum_c[16];
-    __shared__ uint32_t carry_s, carry_i, carry_c;
+    constexpr int NQ = SG_SCAN_NQ;
+    __shared__ uint32_t wsum[NQ][16];
+    __shared__ uint32_t carry[NQ];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    if (tid == 0) { carry_s = 0; carry_i = 0; carry_c = 0; }
+    const int first = blockIdx.x * 1024 * tpt;
+    // ---- 1. totals of everything in front of this workgroup's range
+    uint32_t acc[NQ] = { 0, 0, 0, 0, 0 };
+    for (int t = tid; t < first; t += 1024) {
+        uint32_t v = 0, q[NQ];
+#pragma unroll
+        for (int sb = 0; sb < K; sb++) v += tile_count[((size_t)t * K + sb) * tc_stride];
+        sg_scan_derive(v, q);
+#pragma unroll
+        for (int a = 0; a < NQ; a++) acc[a] += q[a];
+    }
+#pragma unroll 1
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int a = 0; a < NQ; a++) acc[a] += __shfl_xor(acc[a], o, 64);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int a = 0; a < NQ; a++) wsum[a][wid] = acc[a];
+    }
     __syncthreads();
-    for (int base = 0; base < T; base += 8192) {
-        const int i0 = base + tid * 8;
-        uint32_t v[8], sum = 0;
+    if (tid < NQ) {
+        uint32_t t = 0;
+#pragma unroll 1
+        for (int w = 0; w < 16; w++) t += wsum[tid][w];
+        carry[tid] = t;
+    }
+    __syncthreads();
+    // ---- 2. scan of the own range, 1024 tiles per round
+    for (int r = 0; r < tpt; r++) {
+        const int tile = first + r * 1024 + tid;
+        const bool ok = tile < T;
+        uint32_t cnt[K], v = 0, q[NQ] = { 0, 0, 0, 0, 0 };
 #pragma unroll
-        for (int k = 0; k < 8; k++) { v[k] = i0 + k < T ? tile_count[(size_t)(i0 + k) * tc_stride] : 0u; sum += v[k]; }
-        // backward work items (1 per tile, one per SG_SEG entries for longer lists) and checkpoint slots
-        uint32_t isum = 0, csum = 0;
+        for (int sb = 0; sb < K; sb++) { cnt[sb] = ok ? tile_count[((size_t)tile * K + sb) * tc_stride] : 0u; v += cnt[sb]; }
+        if (ok) sg_scan_derive(v, q);
+        uint32_t incl[NQ];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t seg = sg_nseg(v[k]);
-            if (i0 + k < T) { isum += seg ? seg : 1u; csum += seg; }
-        }
-        uint32_t incl = sum, incl_i = isum, incl_c = csum;
-#pragma unroll
+        for (int a = 0; a < NQ; a++) incl[a] = q[a];
+#pragma unroll 1
         for (int o = 1; o < 64; o <<= 1) {
-            uint32_t u = __shfl_up(incl, o, 64), ui = __shfl_up(incl_i, o, 64), uc = __shfl_up(incl_c, o, 64);
-            if (lane >= o) { incl += u; incl_i += ui; incl_c += uc; }
-        }
-        if (lane == 63) { wsum[wid] = incl; wsum_i[wid] = incl_i; wsum_c[wid] = incl_c; }
-        __syncthreads();
-        uint32_t woff = 0, woff_i = 0, woff_c = 0;
-        for (int w = 0; w < wid; w++) { woff += wsum[w]; woff_i += wsum_i[w]; woff_c += wsum_c[w]; }
-        uint32_t start = carry_s + woff + incl - sum;
-        uint32_t istart = carry_i + woff_i + incl_i - isum, cstart = carry_c + woff_c + incl_c - csum;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            if (i0 + k < T) {
-                uint32_t s = start < cap ? start : cap, e = start + v[k] < cap ? start + v[k] : cap;
-                ranges[i0 + k] = v[k] ? make_uint2(s, e) : make_uint2(0u, 0u);
-                cursor[i0 + k] = start;
-                if (e - s > long_threshold) long_tiles[atomicAdd(&header[4], 1u)] = (uint32_t)(i0 + k);
-                const uint32_t nseg = sg_nseg(v[k]), nit = nseg ? nseg : 1u;
-                for (uint32_t sg = 0; sg < nit; sg++)
-                    if (istart + sg < items_cap) items[istart + sg] = (uint32_t)(i0 + k) | (sg << 20);
-                ck_start[i0 + k] = nseg ? cstart : 0xffffffffu;
-                istart += nit; cstart += nseg;
+            for (int a = 0; a < NQ; a++) {
+                const uint32_t u = __shfl_up(incl[a], o, 64);
+                if (lane >= o) incl[a] += u;
             }
-            start += v[k];
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int a = 0; a < NQ; a++) wsum[a][wid] = incl[a];
         }
         __syncthreads();
-        if (tid == 1023) { carry_s = start; carry_i = istart; carry_c = cstart; }
+        uint32_t st[NQ], tot[NQ];
+#pragma unroll
+        for (int a = 0; a < NQ; a++) {
+            uint32_t woff = 0, all = 0;
+#pragma unroll 1
+            for (int w = 0; w < 16; w++) { const uint32_t x = wsum[a][w]; woff += w < wid ? x : 0u; all += x; }
+            st[a] = carry[a] + woff + incl[a] - q[a];
+            tot[a] = carry[a] + all;
+        }
+        if (ok) {
+            const uint32_t s = st[0] < cap ? st[0] : cap, e = st[0] + v < cap ? st[0] + v : cap;
+            ranges[tile] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
+            uint32_t cs = st[0];                          // sub-ranges of the tile, back to back
+#pragma unroll
+            for (int sb = 0; sb < K; sb++) { cursor[(size_t)tile * K + sb] = cs; cs += cnt[sb]; }
+            ck_start[tile] = q[2] ? st[2] : 0xffffffffu;
+            plan[tile] = make_uint4(st[1], st[3], st[4], v);
+        }
+        __syncthreads();
+        if (tid < NQ) {
+            // (every thread computed the same tot[]; thread a publishes quantity a)
+            uint32_t t = 0;
+#pragma unroll
+            for (int a = 0; a < NQ; a++) t = tid == a ? tot[a] : t;
+            carry[tid] = t;
+        }
         __syncthreads();
     }
-    if (tid == 0) {
-        header[5] = carry_i < items_cap ? carry_i : items_cap;
-        header[0] = carry_s;
-        header[1] = carry_s > cap ? 1u : 0u;
+    if (blockIdx.x == gridDim.x - 1 && tid == 0) {
+        header[0] = carry[0];
+        header[1] = carry[0] > cap ? 1u : 0u;
         header[3] = (uint32_t)T;
+        header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
+        header[5] = carry[1] < items_cap ? carry[1] : items_cap;
+        header[6] = carry[4] < rank_cap ? carry[4] : rank_cap;
     }
 }
 
-// one lane per pair (Gaussian-major list written by the preprocess); no atomics
+// One lane per pair (Gaussian-major list written by the preprocess): key -> its slot, no atomics.
+// The first T threads also expand their tile's plan into the work lists of the sort / merge / backward kernels.
 __global__ void __launch_bounds__(256)
 sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ pair_gid,
                        const uint32_t *__restrict__ pair_tile, const uint32_t *__restrict__ pair_local,
                        const float *__restrict__ depth, const uint32_t *__restrict__ start,
-                       uint64_t *__restrict__ pair_keys, uint32_t cap)
+                       uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
+                       uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
+                       uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap)
 {
+    const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
+    for (uint32_t tile = gtid; tile < (uint32_t)T; tile += nthreads) {
+        const uint4 pl = plan[tile];
+        const uint32_t nseg = sg_nseg(pl.w), nit = nseg ? nseg : 1u;
+        for (uint32_t sg = 0; sg < nit; sg++)
+            if (pl.x + sg < items_cap) items[pl.x + sg] = tile | (sg << 20);
+        const uint32_t nch = pl.w > SG_WSORT_MAX ? (pl.w + SG_SORT_LDS - 1) / SG_SORT_LDS : 0u;
+        for (uint32_t c = 0; c < nch; c++) {
+            if (pl.y + c < sort_cap) sort_items[pl.y + c] = make_uint2(tile, c);
+            if (nch > 1 && pl.z + c < rank_cap) rank_items[pl.z + c] = make_uint2(tile, c);
+        }
+    }
     const uint32_t R = header[0] < cap ? header[0] : cap;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < R; i += gridDim.x * blockDim.x) {
+    for (uint32_t i = gtid; i < R; i += nthreads) {
         uint32_t gid = pair_gid[i];
         uint32_t slot = start[pair_tile[i]] + pair_local[i];
         if (slot < cap) pair_keys[slot] = ((uint64_t)__float_as_uint(depth[gid]) << 32) | gid;
@@ -95,26 +169,36 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
 }
 
 // ---- per-tile sort ---------------------------------------------------------------------
-#define SG_SORT_THREADS 1024   // long lists are a tail of a few workgroups: give each the whole CU
-#define SG_SORT_LDS 4096   // u64 entries sorted in LDS (32 KiB)
 
-__device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid, int nthreads)
+// Bitonic sort of s[0, n2) (n2 a power of two <= SG_SORT_LDS) by the whole SG_SORT_THREADS workgroup.
+// Wave w owns the comparators of a contiguous block of B = 128 * cpt elements: every stage with 2j <= B touches only
+// the wave's own block and needs no workgroup barrier (LDS operations of one wave complete in order), which leaves
+// 14 workgroup barriers instead of 78 at n2 = 4096.
+__device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid)
 {
+    const int cpt = n2 > 2048 ? n2 / 2048 : 1;          // comparators per thread
+    const int wave = tid >> 6, lane = tid & 63;
+    const int B = 128 * cpt;
+    const bool active = wave * B < n2;
     for (int k = 2; k <= n2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += nthreads) {
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
-                int ixj = i | j;
-                bool up = (i & k) == 0;
-                uint64_t a = s[i], b = s[ixj];
-                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+            if (active) {
+                for (int c = 0; c < cpt; c++) {
+                    const int t = (wave * cpt + c) * 64 + lane;
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+                    const bool up = (i & k) == 0;
+                    const uint64_t a = s[i], b = s[ixj];
+                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+                }
             }
-            __syncthreads();
+            if (2 * j <= B) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
+            else __syncthreads();
         }
+        if (2 * k > B) __syncthreads();                  // the next k starts with a cross-wave stage (or we are done)
     }
+    __syncthreads();
 }
 
-#define SG_WSORT_MAX 256   // longest list sorted by a single wave
 
 // one wave per tile, 4 tiles per workgroup, no workgroup barriers
 __global__ void __launch_bounds__(256)
@@ -151,70 +235,93 @@ sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t
     }
 }
 
-// long lists: one workgroup per tile
+// Long lists: one workgroup per work item (tile, chunk of SG_SORT_LDS entries), items written by the scan kernel.
+// A list of one chunk is sorted and written out; the chunks of a longer list are sorted in place and merged by
+// sg_tile_rank_kernel.
 __global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint32_t *__restrict__ long_tiles,
+sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
                     const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
-                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys, uint32_t *__restrict__ rank)
+                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
 {
     __shared__ uint64_t s[SG_SORT_LDS];
     const int tid = threadIdx.x;
-    const uint32_t nlong = header[4];
-    for (uint32_t li = blockIdx.x; li < nlong; li += gridDim.x) {      // work list written by the scan kernel
-    const int tile = (int)long_tiles[li];
-    uint2 r = ranges[tile];
-    uint32_t n = r.y - r.x;
-    __syncthreads();
-    uint64_t *seg = pair_keys + r.x;
-    if (n <= SG_SORT_LDS) {
-        int n2 = 1; while (n2 < (int)n) n2 <<= 1;
-        for (int i = tid; i < n2; i += SG_SORT_THREADS) s[i] = i < (int)n ? seg[i] : ~0ull;
+    const uint32_t nitems = header[4];
+    for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
+        const uint2 it = sort_items[li];
+        const int tile = (int)it.x;
+        const uint2 r = ranges[tile];
+        const uint32_t n = r.y - r.x, off = it.y * SG_SORT_LDS;
+        if (off >= n) continue;
+        const int m = (int)(n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS);
+        uint64_t *seg = pair_keys + r.x + off;
+        int n2 = 1; while (n2 < m) n2 <<= 1;
         __syncthreads();
-        if (n > 1) sg_bitonic_lds(s, n2, tid, SG_SORT_THREADS);
-        for (int i = tid; i < (int)n; i += SG_SORT_THREADS) {
-            uint64_t k = s[i];
-            point_list[r.x + i] = (uint32_t)k;
-            if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
-        }
-    } else {
-        // Long tile (> SG_SORT_LDS entries): sort LDS-sized chunks in place, then place every element by rank.
-        // Keys are unique (Gaussian id in the low word), so the final position of a key is the number of
-        // smaller keys summed over all sorted chunks.  Each sorted chunk is brought back into LDS once and all
-        // threads binary-search it there; the running ranks live in `rank` (the pair_local array, dead after
-        // the scatter), indexed like the segment.
-        const uint32_t nchunks = (n + SG_SORT_LDS - 1) / SG_SORT_LDS;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            uint32_t off = c * SG_SORT_LDS, m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
-            int n2 = 1; while (n2 < (int)m) n2 <<= 1;
-            for (int i = tid; i < n2; i += SG_SORT_THREADS) s[i] = i < (int)m ? seg[off + i] : ~0ull;
-            __syncthreads();
-            sg_bitonic_lds(s, n2, tid, SG_SORT_THREADS);
-            for (int i = tid; i < (int)m; i += SG_SORT_THREADS) seg[off + i] = s[i];
-            __syncthreads();
-        }
-        uint32_t *rk = rank + r.x;
-        for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) rk[i] = 0;
-        __threadfence();   // chunk stores must be visible to every wave of this workgroup
+        for (int i = tid; i < n2; i += SG_SORT_THREADS) s[i] = i < m ? seg[i] : ~0ull;
         __syncthreads();
-        for (uint32_t c = 0; c < nchunks; c++) {
-            uint32_t off = c * SG_SORT_LDS, m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
-            for (uint32_t i = tid; i < m; i += SG_SORT_THREADS) s[i] = seg[off + i];
-            __syncthreads();
-            for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) {
-                uint64_t k = seg[i];
-                uint32_t lo = 0, hi = m;
-                while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (s[mid] < k) lo = mid + 1; else hi = mid; }
-                rk[i] += lo;
+        if (m > 1) sg_bitonic_lds(s, n2, tid);
+        if (n <= SG_SORT_LDS) {
+            for (int i = tid; i < m; i += SG_SORT_THREADS) {
+                const uint64_t k = s[i];
+                point_list[r.x + i] = (uint32_t)k;
+                if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
             }
-            __syncthreads();
-        }
-        for (uint32_t i = tid; i < n; i += SG_SORT_THREADS) {
-            uint64_t k = seg[i];
-            uint32_t pos = rk[i];
-            point_list[r.x + pos] = (uint32_t)k;
-            if (point_keys) point_keys[r.x + pos] = ((uint64_t)tile << 32) | (k >> 32);
+        } else {
+            for (int i = tid; i < m; i += SG_SORT_THREADS) seg[i] = s[i];
         }
     }
+}
+
+// Lists longer than SG_SORT_LDS: one workgroup per (tile, chunk).  Keys are unique (Gaussian id in the low word), so
+// the final position of a key is its index in its own sorted chunk plus the number of smaller keys in every other
+// chunk; each other chunk is brought into LDS once and binary-searched there.
+__global__ void __launch_bounds__(SG_SORT_THREADS)
+sg_tile_rank_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ rank_items,
+                    const uint2 *__restrict__ ranges, const uint64_t *__restrict__ pair_keys,
+                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+{
+    __shared__ uint64_t s[SG_SORT_LDS];
+    constexpr int KPT = SG_SORT_LDS / SG_SORT_THREADS;
+    const int tid = threadIdx.x;
+    const uint32_t nitems = header[6];
+    for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
+        const uint2 it = rank_items[li];
+        const int tile = (int)it.x;
+        const uint2 r = ranges[tile];
+        const uint32_t n = r.y - r.x, off = it.y * SG_SORT_LDS;
+        if (off >= n) continue;
+        const uint32_t m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
+        const uint64_t *seg = pair_keys + r.x;
+        uint64_t key[KPT];
+        uint32_t rk[KPT];
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+            const uint32_t i = tid + q * SG_SORT_THREADS;
+            key[q] = i < m ? seg[off + i] : ~0ull;
+            rk[q] = i;
+        }
+        const uint32_t nchunks = (n + SG_SORT_LDS - 1) / SG_SORT_LDS;
+        for (uint32_t c = 0; c < nchunks; c++) {
+            if (c == it.y) continue;
+            const uint32_t co = c * SG_SORT_LDS, cm = n - co < SG_SORT_LDS ? n - co : SG_SORT_LDS;
+            __syncthreads();
+            for (uint32_t i = tid; i < cm; i += SG_SORT_THREADS) s[i] = seg[co + i];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < KPT; q++) {
+                uint32_t lo = 0, hi = cm;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s[mid] < key[q]) lo = mid + 1; else hi = mid; }
+                rk[q] += lo;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < KPT; q++) {
+            const uint32_t i = tid + q * SG_SORT_THREADS;
+            if (i < m) {
+                point_list[r.x + rk[q]] = (uint32_t)key[q];
+                if (point_keys) point_keys[r.x + rk[q]] = ((uint64_t)tile << 32) | (key[q] >> 32);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -226,21 +333,31 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
-    hipLaunchKernelGGL(sg_tile_scan_kernel, dim3(1), dim3(1024), 0, st, T, b.tile_count, b.tc_stride, b.ranges, b.cursor, b.header, cap32,
-                       b.long_tiles, (uint32_t)SG_WSORT_MAX, b.items, b.ck_start, sg_items_cap(T, cap));
+    const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;       // at most 64 workgroups
+    const int sgrid0 = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
+#define SG_SCAN(KK) hipLaunchKernelGGL(sg_tile_scan_kernel<KK>, dim3(sgrid0), dim3(1024), 0, st, T, tpt, b.tile_count, b.tc_stride, \
+                                       b.ranges, b.cursor, b.header, cap32, sg_sort_items_cap(T, cap),                 \
+                                       sg_rank_items_cap(cap), b.plan, b.ck_start, sg_items_cap(T, cap))
+    if (b.tc_sub == SG_TC_SUB_MAX) SG_SCAN(SG_TC_SUB_MAX); else SG_SCAN(1);
+#undef SG_SCAN
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
-    if (P > 0) {
-        size_t want = (cap + 255) / 256;
+    {
+        size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
         hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
-                           b.pair_local, g.depth, b.cursor, b.pair_keys, cap32);
+                           b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
+                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap));
     }
     sg_prof_end(SG_K_TILE_SCATTER, st);
     sg_prof_begin(SG_K_TILE_SORT, st);
     hipLaunchKernelGGL(sg_tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, st, T, b.ranges, b.pair_keys,
                        b.point_list, pk);
-    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(T < 2048 ? T : 2048), dim3(SG_SORT_THREADS), 0, st, b.header, b.long_tiles,
-                       b.ranges, b.pair_keys, b.point_list, pk, b.pair_local);
+    const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
+    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items,
+                       b.ranges, b.pair_keys, b.point_list, pk);
+    const uint32_t rgrid = sg_rank_items_cap(cap) < 128 ? sg_rank_items_cap(cap) : 128;
+    hipLaunchKernelGGL(sg_tile_rank_kernel, dim3(rgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.rank_items,
+                       b.ranges, b.pair_keys, b.point_list, pk);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

@@ -14,6 +14,10 @@
 __host__ __device__ inline uint32_t sg_nseg(uint32_t n) { return n > SG_SEG && n <= SG_SEG * 4095u ? (n + SG_SEG - 1) / SG_SEG : 0u; }
 // capacities of the work-item list and of the checkpoint buffer (slots of 256 float4) for T tiles / cap pairs
 __host__ __device__ inline uint32_t sg_items_cap(size_t T, size_t cap) { size_t v = T + cap / SG_SEG + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
+// work items of the long-list sort (one per tile with > 256 entries + one per further 4096-entry chunk) and of the
+// chunk merge (lists of more than one chunk)
+__host__ __device__ inline uint32_t sg_sort_items_cap(size_t T, size_t cap) { size_t v = T + cap / 4096 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
+__host__ __device__ inline uint32_t sg_rank_items_cap(size_t cap) { size_t v = cap / 2048 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (cap / SG_SEG) + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 // Words between two tile counters.  Packed counters (stride 1) let one 64-lane atomic instruction touch few
 // lines (a Gaussian's tiles are neighbours) -- best when the image has many tiles and ~100 pairs per tile
@@ -22,6 +26,13 @@ __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (ca
 // per line wins (141 us vs 415 us).  The pair density is unknown before the pass, so the tile count decides.
 #define SG_TC_STRIDE_MAX 32
 static inline uint32_t sg_tc_stride(size_t T) { return T <= 4096 ? SG_TC_STRIDE_MAX : 1; }
+// In the few-tiles regime one tile can collect ~1e4 pairs, and a single counter word sustains only ~88 returning
+// atomics per microsecond (113 us for the heaviest avatar tile).  Each tile therefore gets SG_TC_SUB sub-counters
+// (own 128-B line each); workgroup b counts into sub-counter b % SG_TC_SUB.  The scan lays the sub-ranges of a tile
+// out back to back, so everything downstream sees one contiguous range per tile.
+#define SG_TC_SUB_MAX 8
+static inline uint32_t sg_tc_sub(size_t T) { return T <= 4096 ? SG_TC_SUB_MAX : 1; }
+static inline size_t sg_tc_words(size_t T) { return T * sg_tc_sub(T) * sg_tc_stride(T); }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
@@ -32,20 +43,22 @@ struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vec
 };
 
 struct SgBin {
-    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] number of long tiles  [5] number of backward work items
-    uint32_t *tile_count;  // [T * tc_stride], counter of tile t at t * tc_stride
-    uint32_t tc_stride;
+    uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] sort items  [5] backward work items  [6] rank items
+    uint32_t *tile_count;  // counter c = tile * tc_sub + sub at word c * tc_stride
+    uint32_t tc_stride, tc_sub;
     uint2 *ranges;         // [T] (start,end) into point_list
-    uint32_t *cursor;      // [T]
+    uint32_t *cursor;      // [T * tc_sub] first slot of every counter's sub-range
     uint64_t *pair_keys;   // [cap] (depth_bits << 32 | gid), grouped by tile, sorted in place
     uint32_t *point_list;  // [cap] sorted Gaussian ids
     uint64_t *point_keys;  // [cap] optional upstream-format keys
     uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
-    uint32_t *pair_tile;   //       tile id,
+    uint32_t *pair_tile;   //       counter id (tile * tc_sub + sub),
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
-    uint32_t *long_tiles;  // [T] ids of tiles whose list is too long for the one-wave sort; count in header[4]
+    uint2 *sort_items;     // (tile, chunk) of lists too long for the one-wave sort; count in header[4]
+    uint2 *rank_items;     // (tile, chunk) of lists of more than one chunk; count in header[6]
     uint32_t *items;       // backward work items: tile | segment << 20; count in header[5]
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
+    uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)
 };
 
 struct SgImg {
@@ -70,14 +83,15 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     char *b = (char *)ws;
     SgBin g;
     g.header = (uint32_t *)(b + L.bin_header); g.tile_count = (uint32_t *)(b + L.bin_tile_count);
-    g.tc_stride = SG_TC_STRIDE_MAX;           // callers that know the tile count set sg_tc_stride(T)
+    g.tc_stride = SG_TC_STRIDE_MAX; g.tc_sub = 1;   // callers that know the tile count set sg_tc_stride/sub(T)
     g.ranges = (uint2 *)(b + L.bin_ranges); g.cursor = (uint32_t *)(b + L.bin_cursor);
     g.pair_keys = (uint64_t *)(b + L.bin_pair_keys); g.point_list = (uint32_t *)(b + L.bin_point_list);
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);
     g.pair_gid = (uint32_t *)(b + L.bin_pair_gid); g.pair_tile = (uint32_t *)(b + L.bin_pair_tile);
     g.pair_local = (uint32_t *)(b + L.bin_pair_local);
-    g.long_tiles = (uint32_t *)(b + L.bin_long_tiles);
+    g.sort_items = (uint2 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
+    g.plan = (uint4 *)(b + L.bin_plan);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)

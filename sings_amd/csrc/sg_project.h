@@ -139,6 +139,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
+    const uint32_t sub = blockIdx.x & (bn.tc_sub - 1);          // this workgroup's sub-counter (tc_sub is 1 or 8)
     // four pairs per lane per round: the four returning atomics are in flight together
     for (uint32_t p0 = 0; p0 < total; p0 += 256) {
         uint32_t tile[4], local[4], gj[4];
@@ -158,7 +159,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t t = p - excl, w = sWid[j], mn = sMin[j];
                 const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)w);      // exact floor: t, w < 2^16
                 const uint32_t tx = t - ty * w;
-                tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
+                tile[u] = (((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx) * bn.tc_sub + sub;   // counter id
                 gj[u] = (uint32_t)(g0 + j);
                 local[u] = atomicAdd(&bn.tile_count[(size_t)tile[u] * bn.tc_stride], 1u);
             }

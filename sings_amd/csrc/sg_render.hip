@@ -123,14 +123,24 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     uint32_t last = 0;
     bool done = !inside;
     const unsigned long long lt = (1ull << lane) - 1ull;
+    // software pipeline over batches: the gathers of batch k+1 are in flight while batch k is composited (a tile
+    // whose list is thousands of entries long runs alone on its CU -- nothing else hides the two dependent loads)
+    float4 pa = make_float4(0, 0, 0, 0), pb = pa;
+    float pc = 0.0f;
+    if (tid < n) {
+        const uint32_t gid = point_list[range.x + tid];
+        pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
+    }
     for (int base = 0; base < n; base += SG_FB) {
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
         const int e = base + tid;
         if (e < n) {
-            const uint32_t gid = point_list[range.x + e];
-            const float4 a = recA[gid], b = recB[gid];
-            sA[tid] = a; sB[tid] = b; sC[tid] = recC[gid].x;
-            sM[tid] = sg_quad_mask(a, b, (float)X0, (float)Y0);
+            sA[tid] = pa; sB[tid] = pb; sC[tid] = pc;
+            sM[tid] = sg_quad_mask(pa, pb, (float)X0, (float)Y0);
+        }
+        if (e + SG_FB < n) {
+            const uint32_t gid = point_list[range.x + e + SG_FB];
+            pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
         }
         __syncthreads();
         if (__ballot(done) == ~0ull) continue;             // this quadrant is finished (wave-uniform)

@@ -369,30 +369,42 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     }
 }
 
-// sums the per-wave slab rows in a fixed order: dL_dA [J,16] and dL_dtransl [3].
-// One workgroup per 16 output columns; 16 row groups per column, combined through LDS.
+// sums the per-wave slab rows in a fixed order: dL_dA [J,16] and dL_dtransl [3].  Two passes so that the
+// ~10 MB of slabs are read by thousands of waves with 256-B coalesced rows (a single 53-block pass took 44 us):
+//  pass 1: grid (column blocks of 64, SG_RED_GROUPS/4); wave = row group rg sums rows rg, rg + G, ... into part[rg]
+//  pass 2: one thread per column sums the G partial rows.
+#define SG_RED_GROUPS 128
 __global__ void __launch_bounds__(256)
-sg_skin_reduce_kernel(const float *__restrict__ slab, int nrows, int slab_stride, int J,
-                      float *__restrict__ dL_dA, float *__restrict__ dL_dtransl)
+sg_skin_reduce1_kernel(const float *__restrict__ slab, int nrows, int slab_stride, float *__restrict__ part)
 {
-    __shared__ float part[16][17];
-    const int o = threadIdx.x & 15, rg = threadIdx.x >> 4;
-    const int i = blockIdx.x * 16 + o;
-    const int nA = J * 16;
-    const bool ok = i < nA + 3;
-    const int col = i < nA ? i : SG_JMAX * 16 + (i - nA);
-    float s = 0.0f;
-    if (ok)
-        for (int b = rg; b < nrows; b += 16) s += slab[(size_t)b * slab_stride + col];
-    part[rg][o] = s;
-    __syncthreads();
-    if (rg == 0 && ok) {
-        float t = 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; r++) t += part[r][o];
-        if (i < nA) dL_dA[i] = t;
-        else if (dL_dtransl) dL_dtransl[i - nA] = t;
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (col >= slab_stride) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = rg;
+    for (; b + 3 * SG_RED_GROUPS < nrows; b += 4 * SG_RED_GROUPS) {
+        s0 += slab[(size_t)b * slab_stride + col];
+        s1 += slab[(size_t)(b + SG_RED_GROUPS) * slab_stride + col];
+        s2 += slab[(size_t)(b + 2 * SG_RED_GROUPS) * slab_stride + col];
+        s3 += slab[(size_t)(b + 3 * SG_RED_GROUPS) * slab_stride + col];
     }
+    for (; b < nrows; b += SG_RED_GROUPS) s0 += slab[(size_t)b * slab_stride + col];
+    part[(size_t)rg * slab_stride + col] = (s0 + s1) + (s2 + s3);
+}
+
+__global__ void __launch_bounds__(64)
+sg_skin_reduce2_kernel(const float *__restrict__ part, int slab_stride, int J, float *__restrict__ dL_dA,
+                       float *__restrict__ dL_dtransl)
+{
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const int nA = J * 16;
+    if (i >= nA + 3) return;
+    const int col = i < nA ? i : SG_JMAX * 16 + (i - nA);
+    float t = 0.0f;
+#pragma unroll 8
+    for (int r = 0; r < SG_RED_GROUPS; r++) t += part[(size_t)r * slab_stride + col];
+    if (i < nA) dL_dA[i] = t;
+    else if (dL_dtransl) dL_dtransl[i - nA] = t;
 }
 
 // ---- launchers ---------------------------------------------------------------------------
@@ -412,7 +424,8 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
 #undef SG_SF
 }
 
-size_t sg_skin_slab_floats(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES * (SG_JMAX * 16 + 4); }
+// per-wave slabs followed by the SG_RED_GROUPS partial rows of the reduction
+size_t sg_skin_slab_floats(int P) { return ((size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES + SG_RED_GROUPS) * (SG_JMAX * 16 + 4); }
 
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
@@ -430,8 +443,11 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                                      dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
-    hipLaunchKernelGGL(sg_skin_reduce_kernel, dim3((in->J * 16 + 3 + 15) / 16), dim3(256), 0, st, slab,
-                       nblocks * SG_SKIN_WAVES, stride, in->J, dL_dA, dL_dtransl);
+    float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;
+    hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4), dim3(256), 0, st, slab,
+                       nblocks * SG_SKIN_WAVES, stride, part);
+    hipLaunchKernelGGL(sg_skin_reduce2_kernel, dim3((in->J * 16 + 3 + 63) / 64), dim3(64), 0, st, part, stride, in->J,
+                       dL_dA, dL_dtransl);
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
 }

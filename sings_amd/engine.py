@@ -86,6 +86,7 @@ class SkinnedEngine:
         self.dev = torch.device(device)
         self.cap = int(capacity_pairs)
         L = _lib.layout(self.P, self.W, self.H, self.cap)
+        self.L = L
         u8 = dict(dtype=torch.uint8, device=self.dev)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.geom = torch.empty(L.geom_bytes, **u8); self.binning = torch.empty(L.bin_bytes, **u8)

@@ -284,3 +284,119 @@ def test_capacity_growth_and_empty_input():
                                           rotations=torch.zeros((0, 4), device=dev))
     assert radii.numel() == 0
     assert torch.allclose(color, t(s["bg"])[:, None, None].expand_as(color))
+
+
+def test_many_tiles_packed_counters_vs_oracle():
+    """> 4096 tiles: the binning switches to packed single counters per tile (the cfg3 regime).  Same bars as the small
+    scenes: bit-exact binning, RGB <= 1e-5, gradients within tolerance."""
+    from sings_amd.inspect_ws import forward_with_state
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(40000, 1600, 1056, 1, 41)
+    assert ((s["W"] + 15) // 16) * ((s["H"] + 15) // 16) > 4096
+    o = _oracle(s)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]),
+                            rotations=t(s["rotations"]))
+    _check_forward_state(s, st, o)
+    _check_image(st["color"].cpu().numpy(), st["final_T"].cpu().numpy(), st["n_contrib"].cpu().numpy(), o)
+    border = o["margin"] < BORDER
+    dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+    g = ro.backward(o, dLn)
+    req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+    color, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh,
+                                      scales=sc, rotations=rt)
+    color.backward(torch.from_numpy(dLn).to(dev))
+    for name, a, b in (("means3D", m.grad, g["dL_dmeans3D"]), ("opacity", op.grad, g["dL_dopacity"]),
+                       ("scales", sc.grad, g["dL_dscales"]), ("rotations", rt.grad, g["dL_drots"]),
+                       ("shs", sh.grad, g["dL_dsh"])):
+        _grad_close(name, a.cpu().numpy().reshape(b.shape), b)
+
+
+@pytest.mark.parametrize("opacity_scale", [0.25, 1.0])
+def test_segmented_backward_with_early_termination(opacity_scale):
+    """Tile lists of several 256-entry depth segments where pixels saturate INSIDE the list: segments behind the deepest
+    contributor only write zero records, segments in front start from the forward checkpoints; every gradient is
+    checked against the oracle's single back-to-front pass."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(24000, 96, 80, 2, 43)
+    s["opacities"] = (s["opacities"] * opacity_scale).astype(np.float32)
+    o = _oracle(s)
+    tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
+    nc = o["n_contrib"]
+    assert tl.max() > 3 * 256 and np.median(tl) > 256          # most tiles are segmented
+    assert nc.max() < tl.max()                                  # and some pixels stop before the end of their list
+    rs = _settings(s, dev)
+    border = o["margin"] < BORDER
+    dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+    g = ro.backward(o, dLn)
+    req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+    m2 = torch.zeros_like(m, requires_grad=True)
+    color, _ = GaussianRasterizer(rs)(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rt)
+    diff = np.abs(color.detach().cpu().numpy() - o["color"]).max(0)
+    assert diff[~border].max() <= 2e-5
+    color.backward(torch.from_numpy(dLn).to(dev))
+    for name, a, b in (("means3D", m.grad, g["dL_dmeans3D"]), ("means2D", m2.grad, g["dL_dmean2D"]),
+                       ("opacity", op.grad, g["dL_dopacity"]), ("scales", sc.grad, g["dL_dscales"]),
+                       ("rotations", rt.grad, g["dL_drots"]), ("shs", sh.grad, g["dL_dsh"])):
+        _grad_close(name, a.cpu().numpy().reshape(b.shape), b, rtol=1e-3, atol=6e-6)
+
+
+def test_cfg3_full_size_properties():
+    """BASELINE configs[1] at full size (200 k Gaussians, 1920x1080, SH degree 3) -- too big for the CPU oracle in a
+    test, so size-independent properties: every tile range is strictly sorted by (depth bits, Gaussian id), every
+    Gaussian appears exactly once in each tile of its rectangle and nowhere else, R = sum of tiles touched, two runs are
+    bitwise identical, and the backward pass is linear in dL/dimage."""
+    from sings_amd.inspect_ws import forward_with_state
+    from sings_amd.engine import RasterEngine
+    dev = _dev()
+    s = synthetic_scene(200000, 1920, 1080, 3, 3)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    st = forward_with_state(rs, ins[0], ins[2], shs=ins[1], scales=ins[3], rotations=ins[4], capacity=4 * 200000)
+    R, W, H = st["R"], s["W"], s["H"]
+    gx = (W + 15) // 16
+    radii = st["radii"].cpu().numpy(); rwh = st["rect_wh"].cpu().numpy(); rmin = st["rect_min"].cpu().numpy()
+    tt = np.where(radii > 0, (rwh & 0xffff) * (rwh >> 16), 0).astype(np.int64)
+    assert R == int(tt.sum())
+    ranges = st["ranges"].cpu().numpy().astype(np.int64)
+    n = ranges[:, 1] - ranges[:, 0]
+    assert int(n.sum()) == R and (ranges[n > 0, 0] == np.concatenate([[0], np.cumsum(n[n > 0])[:-1]])).all()
+    keys = st["point_keys"].cpu().numpy().astype(np.uint64); pl = st["point_list"].cpu().numpy().astype(np.int64)
+    tile_of = (keys >> np.uint64(32)).astype(np.int64)
+    assert (tile_of == np.repeat(np.arange(len(n)), n)).all()                    # ranges and keys agree
+    depth_bits = st["depths"].cpu().numpy().view(np.uint32).astype(np.uint64)
+    assert ((keys & np.uint64(0xffffffff)) == depth_bits[pl]).all()
+    # strictly increasing (tile, depth bits, gid): compare neighbours inside each range
+    same = tile_of[1:] == tile_of[:-1]
+    k0, k1 = keys[:-1][same], keys[1:][same]
+    g0, g1 = pl[:-1][same], pl[1:][same]
+    assert ((k0 < k1) | ((k0 == k1) & (g0 < g1))).all()
+    # membership: each pair's tile lies in the Gaussian's rectangle, and each Gaussian occurs tiles_touched times
+    tx, ty = tile_of % gx, tile_of // gx
+    x0, y0 = (rmin & 0xffff)[pl], (rmin >> 16)[pl]
+    assert ((tx >= x0) & (tx < x0 + (rwh & 0xffff)[pl]) & (ty >= y0) & (ty < y0 + (rwh >> 16)[pl])).all()
+    assert (np.bincount(pl, minlength=len(tt)) == tt).all()
+    assert len(np.unique(tile_of * (1 << 20) + pl)) == R                          # no duplicate (tile, Gaussian)
+    # determinism + linearity of the backward through the pre-allocated engine
+    eng = RasterEngine(200000, W, H, 16, dev, capacity_pairs=R + 4096)
+    eng.set_camera(rs)
+    rng = np.random.RandomState(0)
+    d1 = t(s["dL_dimage"]); d2 = t(rng.standard_normal(s["dL_dimage"].shape).astype(np.float32))
+    def grads(d):
+        eng.forward(*ins); eng.backward(*ins, d)
+        torch.cuda.synchronize()
+        return eng.grad_flat.clone(), eng.color.clone()
+    ga, ca = grads(d1); gb, cb = grads(d1)
+    assert torch.equal(ga, gb) and torch.equal(ca, cb)
+    assert torch.equal(ca, st["color"])
+    g2, _ = grads(d2)
+    g12, _ = grads(0.5 * d1 - 2.0 * d2)
+    ref = 0.5 * ga.double() - 2.0 * g2.double()
+    err = (g12.double() - ref).abs().max().item(); scale = ref.abs().max().item()
+    assert err <= 2e-5 * scale, (err, scale)
