@@ -59,20 +59,42 @@ __device__ __forceinline__ float sg_min_q_rect(float A, float B, float C, float 
     return best;
 }
 
-__device__ __forceinline__ uint32_t sg_quad_mask(float4 a, float4 b, float X0, float Y0)
+// Bounding box (tile-relative pixel coordinates) of the lanes of an 8x8 quadrant whose bit is set in `live`
+// (lane = 8 * row + column); an empty set gives an empty box (x0 > x1).  Wave-uniform scalar arithmetic.
+__device__ __forceinline__ float4 sg_live_box(unsigned long long live, int wave)
+{
+    if (live == 0ull) return make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    unsigned long long m = live;
+    m |= m >> 32; m |= m >> 16; m |= m >> 8;
+    const uint32_t cols = (uint32_t)m & 0xffu;
+    unsigned long long t = live;
+    t |= t >> 4; t |= t >> 2; t |= t >> 1;
+    const uint32_t rows = (uint32_t)(((t & 0x0101010101010101ull) * 0x0102040810204080ull) >> 56);
+    const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), r0 = __builtin_ctz(rows), r1 = 31 - __builtin_clz(rows);
+    const int qx = 8 * (wave & 1), qy = 8 * (wave >> 1);
+    return make_float4((float)(qx + c0), (float)(qx + c1), (float)(qy + r0), (float)(qy + r1));
+}
+
+// box[q] = (x0, x1, y0, y1): the part of quadrant q that still matters (sg_live_box) -- the whole quadrant at first;
+// once pixels saturate (forward) / for the pixels an entry can still have contributed to (backward) only the
+// bounding box of the live pixels.  Entries that cannot reach it are dropped from that quadrant's list: this is what
+// keeps silhouette tiles of an opaque body cheap (thousands of entries hidden behind saturated pixels, a few
+// background pixels that never saturate).
+__device__ __forceinline__ uint32_t sg_quad_mask(float4 a, float4 b, float X0, float Y0, const float4 *__restrict__ box)
 {
     const float o255 = 255.0f * b.y;
     if (!(o255 >= 0.999f)) return 0u;
     const float bound = 2.0f * (__logf(o255) * 1.002f + 0.004f) + 0.01f;
     const float A = a.z, B = a.w, C = b.x;
     const float det = A * C - B * B;
-    if (!(det > 1e-3f * A * C) || !(A > 0.0f) || !(C > 0.0f)) return 0xFu;
+    const bool illc = !(det > 1e-3f * A * C) || !(A > 0.0f) || !(C > 0.0f);     // ill-conditioned: keep everything live
     const float mx = a.x - X0, my = a.y - Y0;
     uint32_t m = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-        const float x0 = 8.0f * (q & 1), y0 = 8.0f * (q >> 1);
-        float mq = sg_min_q_rect(A, B, C, mx, my, x0, x0 + 7.0f, y0, y0 + 7.0f);
+        const float4 bx = box[q];
+        if (!(bx.x <= bx.y)) continue;
+        float mq = illc ? 0.0f : sg_min_q_rect(A, B, C, mx, my, bx.x, bx.y, bx.z, bx.w);
         if (mq * 0.999f <= bound) m |= 1u << q;
     }
     return m;
@@ -109,6 +131,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ float sC[SG_FB];
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];
+    __shared__ float4 sBox[4];
     const int tile = sg_tile_of_block(blockIdx.x, nblocks);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -132,11 +155,15 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
     }
     for (int base = 0; base < n; base += SG_FB) {
+        {   // this quadrant's pixels that are still being composited
+            const float4 bx = sg_live_box(__ballot(!done), wave);
+            if (lane == 0) sBox[wave] = bx;
+        }
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
         const int e = base + tid;
         if (e < n) {
             sA[tid] = pa; sB[tid] = pb; sC[tid] = pc;
-            sM[tid] = sg_quad_mask(pa, pb, (float)X0, (float)Y0);
+            sM[tid] = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
         }
         if (e + SG_FB < n) {
             const uint32_t gid = point_list[range.x + e + SG_FB];
@@ -252,6 +279,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
     __shared__ uint8_t sFlag[4][SG_BB];        // [w][k] != 0: quadrant w wrote sG[w][k]
     __shared__ uint32_t smax[4];
+    __shared__ float4 sBox[4];                 // per quadrant: box of the pixels with contributors in the current batch
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
     (void)T; (void)nblocks;
@@ -296,6 +324,10 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
     const int maxq = (int)__builtin_amdgcn_readfirstlane(m);          // this quadrant's deepest contributor
     if (lane == 0) smax[wave] = m;
+    {   // entries of batch [base, ...) can only have contributed to pixels with n_contrib > base
+        const float4 bx = sg_live_box(__ballot(ncq > (uint32_t)(((hi - 1) / SG_BB) * SG_BB)), wave);
+        if (lane == 0) sBox[wave] = bx;
+    }
     __syncthreads();
     const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
@@ -319,7 +351,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float4 a = recA[gid], b = recB[gid];
                 opac = b.y;
                 sA[tid] = a; sB[tid] = b; sC[tid] = c4.x;
-                mk = sg_quad_mask(a, b, (float)X0, (float)Y0);
+                mk = sg_quad_mask(a, b, (float)X0, (float)Y0, sBox);
             }
             sM[tid] = mk;
         }
@@ -378,6 +410,10 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             grec[3 * (size_t)rslot] = make_float4(no * ddelx_dx * s[0], no * ddely_dy * s[1], nh * s[2], nh * s[3]);
             grec[3 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
             grec[3 * (size_t)rslot + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
+        }
+        if (kb > 0) {                                            // box for the next (shallower) batch
+            const float4 bx = sg_live_box(__ballot(ncq > (uint32_t)(base - SG_BB)), wave);
+            if (lane == 0) sBox[wave] = bx;
         }
         __syncthreads();
     }
