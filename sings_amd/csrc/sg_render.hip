@@ -26,12 +26,15 @@
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
-// XCD-aware map: workgroup b runs on XCD b % 8 (round-robin dispatch); give each XCD a contiguous
-// range of tiles so that neighbouring tiles (which share Gaussians) hit the same L2.
-__device__ __forceinline__ int sg_tile_of_block(int block, int nblocks)
+// XCD-aware map: workgroup b runs on XCD b % 8 (round-robin dispatch).  Each XCD takes runs of SG_XCD_RUN consecutive
+// tiles (neighbouring tiles share Gaussians -> same L2), and the runs are dealt round-robin to the XCDs so that
+// every XCD sees every part of the image: with one contiguous band of tiles per XCD an avatar (all the work in the
+// middle rows) kept two of the eight XCDs almost idle.
+#define SG_XCD_RUN 16
+__device__ __forceinline__ int sg_tile_of_block(int block)
 {
-    int chunk = nblocks >> 3;                     // nblocks is a multiple of 8
-    return (block & 7) * chunk + (block >> 3);
+    const int xcd = block & 7, slot = block >> 3;
+    return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + slot % SG_XCD_RUN;
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
@@ -132,7 +135,8 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];
     __shared__ float4 sBox[4];
-    const int tile = sg_tile_of_block(blockIdx.x, nblocks);
+    (void)nblocks;
+    const int tile = sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
@@ -207,7 +211,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     }
 }
 
-static inline int sg_render_blocks(int T) { return ((T + 7) / 8) * 8; }
+static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
 
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           hipStream_t st)
@@ -284,9 +288,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
     (void)T; (void)nblocks;
     const int nitems = (int)header[5];
-    const int chunk = (nitems + 7) >> 3;
-    if ((int)(blockIdx.x >> 3) >= chunk) return;
-    const int it = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    const int it = sg_tile_of_block(blockIdx.x);
     if (it >= nitems) return;
     const uint32_t item = items[it];
     const int tile = (int)(item & 0xfffffu), seg = (int)(item >> 20);
