@@ -258,11 +258,20 @@ def main_avatar(a):
     eng.set_camera(rs)
     shard = FrameSharder(F, world, rank, seed=0)
     fp = FrameParallel() if dist is not None else None
+    # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
+    # mask, forward and gradient -> backward (SURVEY.md 8d "Timing"); weights human.loss.l1_w / ssim_w
+    from sings_amd.photo_loss import PhotoLossEngine
+    loss = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2)
+    gt_rgb = torch.rand((3, H, W), device=dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    mask = ((((xx - W / 2) / (W / 4)) ** 2 + ((yy - H / 2) / (H / 2.2)) ** 2) < 1).float().contiguous()
+    bg_t = t(s["bg"])
 
     def step(i):
         eng.set_frame(xyz, None, w, A_all[shard.frame(i)], smpl_scale, transl)
         eng.forward(sh, op, sc)
-        eng.backward(sh, op, sc, dL)
+        dLi = loss(eng.color, gt_rgb, mask, bg_t)
+        eng.backward(sh, op, sc, dLi)
         if fp is not None:
             fp.all_reduce_grads(eng.grad_flat)
 
@@ -288,19 +297,18 @@ def main_avatar(a):
     lib = _lib.load()
     lib.sg_profile_enable(1)
     for i in range(a.steps):
-        eng.set_frame(xyz, None, w, A_all[shard.frame(i)], smpl_scale, transl)
-        eng.forward(sh, op, sc); eng.backward(sh, op, sc, dL)
+        step(i)
     ms = (C.c_double * _lib.NUM_KERNELS)(); cnt = (C.c_int64 * _lib.NUM_KERNELS)()
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
     lib.sg_profile_enable(0)
     kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
     if rank == 0:
-        out = {"metric": "rendered views/sec fwd+bwd, avatar ~150k posed Gaussians x 120 AMASS frames (LBS-fused)",
+        out = {"metric": "train-step views/sec (LBS-fused fwd + L1/SSIM loss + bwd), avatar ~150k Gaussians x 120 AMASS frames",
                "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
                "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H} fx=fy=5000, {F} AMASS frames, SH deg 0, fused LBS+raster "
-                                      f"fwd+bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
+                                      f"fwd + L1/SSIM loss + bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
                           "width": W, "height": H, "max_num_rendered": Rmax, "parallelism": f"dp{world}"},
                "kernel_ms": kern}
         if world == 1 and not a.no_cpu_baseline:

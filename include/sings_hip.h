@@ -143,13 +143,30 @@ int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *sk
                         float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, void *stream);
 
+/* ---- photometric loss of one view, forward + gradient -------------------------------------------
+ * Replaces, for the L1 and SSIM terms of HumanSceneLoss.forward (sings/rec/losses/loss.py:55-69):
+ *   pred = clamp(raw, 0, 1)                         gs_renderer_single.py:96
+ *   gt   = gt_rgb * mask + bg * (1 - mask)          loss.py:58
+ *   losses[0] = l1_w   * |pred - gt|.sum() / mask.sum()                 losses/utils.py:16-20, loss.py:61-63
+ *   losses[1] = ssim_w * (1 - ssim(pred, gt)) * mask.sum() / (H * W)    losses/utils.py:28-70, loss.py:65-69
+ *   losses[2] = the unweighted L1, losses[3] = mean SSIM
+ * and the autograd backward of losses[0] * upstream[0] + losses[1] * upstream[1] down to the rasterizer
+ * output: dL_draw [3,H,W] (upstream NULL = (1, 1); dL_draw NULL = forward only).  All pointers are device
+ * memory; raw / gt_rgb [3,H,W], mask [H,W], bg [3], losses [4]; pred_out / gt_out [3,H,W] optional (the
+ * reference's extras_dict 'pred_img' / 'gt_img').  `ws`: sg_photo_loss_ws_bytes(W, H) bytes of scratch.
+ * The LPIPS term of the reference is a VGG forward pass and is not part of this library. */
+size_t sg_photo_loss_ws_bytes(int width, int height);
+int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                  const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out, float *losses,
+                  const float *upstream, float *dL_draw, void *stream);
+
 /* ---- optional per-kernel timing (bench / profiling only; process-global, not thread-safe).
  * When enabled, every kernel launch of forward/backward is bracketed by hipEvents on the
  * caller's stream.  sg_profile_collect synchronises, adds the elapsed milliseconds and launch
  * counts per kernel id into the caller's arrays (length >= SG_NUM_KERNELS) and drops the events. */
 #define SG_NUM_KERNELS 8
 enum SgKernelId {
-    SG_K_PREPROCESS_FWD = 0, SG_K_TILE_COUNT = 1, SG_K_TILE_SCAN = 2, SG_K_TILE_SCATTER = 3,
+    SG_K_PREPROCESS_FWD = 0, SG_K_PHOTO_LOSS = 1, SG_K_TILE_SCAN = 2, SG_K_TILE_SCATTER = 3,
     SG_K_TILE_SORT = 4, SG_K_RENDER_FWD = 5, SG_K_RENDER_BWD = 6, SG_K_PREPROCESS_BWD = 7
 };
 int sg_profile_enable(int on);

@@ -37,7 +37,8 @@ class SgSkinInputs(C.Structure):
 # every symbol include/sings_hip.h declares
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
            "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
-           "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward")
+           "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
+           "sg_photo_loss_ws_bytes", "sg_photo_loss")
 NUM_KERNELS = 8
 
 
@@ -73,6 +74,10 @@ def load():
                                        [vp, vp, sz, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int64), vp])
     lib.sg_skinned_backward.argtypes = ([C.POINTER(SgRasterSettings), i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
                                         [vp, vp, vp, sz, vp, vp, vp] + [vp] * 3 + [vp] * 8 + [vp])
+    lib.sg_photo_loss_ws_bytes.argtypes = [i32, i32]
+    lib.sg_photo_loss_ws_bytes.restype = sz
+    lib.sg_photo_loss.argtypes = [i32, i32, C.c_float, C.c_float] + [vp] * 11
+    lib.sg_photo_loss.restype = C.c_int
     for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",
               "sg_read_num_rendered", "sg_skinned_forward", "sg_skinned_backward"):
         getattr(lib, f).restype = C.c_int

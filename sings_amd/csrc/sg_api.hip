@@ -253,6 +253,25 @@ extern "C" int sg_mark_visible(int P, const float *means3D, const float *viewmat
     return e == hipSuccess ? 0 : sg_fail("sg_mark_visible", e);
 }
 
+extern "C" size_t sg_photo_loss_ws_bytes(int width, int height)
+{
+    return width > 0 && height > 0 ? sg_photo_loss_ws_bytes_impl(width, height) : 0;
+}
+
+extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                             const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
+                             float *losses, const float *upstream, float *dL_draw, void *stream)
+{
+    if (width <= 0 || height <= 0) return sg_fail("sg_photo_loss: bad image size", hipSuccess);
+    if (!raw || !gt_rgb || !mask || !bg || !ws || (!losses && !dL_draw))
+        return sg_fail("sg_photo_loss: null pointer", hipSuccess);
+    sg_launch_photo_loss(width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, pred_out, gt_out, losses, upstream,
+                         dL_draw, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sg_fail("sg_photo_loss", e);
+    return 0;
+}
+
 // ---- per-kernel event timing ------------------------------------------------------------
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[SG_NUM_KERNELS];
@@ -293,7 +312,7 @@ extern "C" int sg_profile_collect(double *total_ms, int64_t *launches, int n)
 }
 extern "C" const char *sg_kernel_name(int id)
 {
-    static const char *names[SG_NUM_KERNELS] = { "sg_preprocess_fwd_kernel", "sg_tile_count_kernel", "sg_tile_scan_kernel",
+    static const char *names[SG_NUM_KERNELS] = { "sg_preprocess_fwd_kernel", "sg_photo_loss_kernels", "sg_tile_scan_kernel",
                                                  "sg_tile_scatter_kernel", "sg_tile_sort_kernel", "sg_render_fwd_kernel",
                                                  "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel" };
     return id >= 0 && id < SG_NUM_KERNELS ? names[id] : "?";

@@ -140,6 +140,10 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
                         float *posed_rotq, float *posed_scales, hipStream_t st);
 size_t sg_skin_slab_floats(int P);
+size_t sg_photo_loss_ws_bytes_impl(int W, int H);
+void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                          const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
+                          float *losses, const float *upstream, float *dL_draw, hipStream_t st);
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
                         const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,

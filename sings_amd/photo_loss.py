@@ -1,0 +1,108 @@
+"""L1 + SSIM photometric loss of one rendered view through the C ABI (sg_photo_loss).
+
+Mirrors the L1 / SSIM part of ``HumanSceneLoss.forward`` (sings/rec/losses/loss.py:46-69) together with the
+renderer's final clamp (gs_renderer_single.py:96):
+
+    pred = clamp(raw, 0, 1);  gt = rgb * mask + bg * (1 - mask)
+    loss_dict['l1']   = l1_w   * |pred - gt|.sum() / mask.sum()
+    loss_dict['ssim'] = ssim_w * (1 - ssim(pred, gt)) * mask.sum() / (H * W)
+
+``photometric_loss`` takes the UNCLAMPED rasterizer output (the clamp is fused) and returns the reference's
+``loss_dict`` / ``extras_dict`` entries; both loss tensors carry autograd back to ``raw``.  The forward call computes
+the gradient in the same pass over the image, so backward only scales it.  LPIPS (a VGG network) is not provided.
+No CPU fallback: the HIP library must be present.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .rasterizer import _ptr
+
+
+class _PhotoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, raw, gt_rgb, mask, bg, l1_w, ssim_w, want_images):
+        if not raw.is_cuda:
+            raise RuntimeError("sings_amd.photo_loss: tensors must live on the GPU (no CPU fallback)")
+        lib = _lib.load()
+        raw = raw.contiguous().float(); gt_rgb = gt_rgb.contiguous().float()
+        mask = mask.contiguous().float(); bg = bg.contiguous().float()
+        if raw.dim() != 3 or raw.shape[0] != 3 or gt_rgb.shape != raw.shape or mask.numel() != raw.shape[1] * raw.shape[2]:
+            raise ValueError("photometric_loss: raw / gt_rgb must be [3,H,W] and mask [H,W] or [1,H,W]")
+        H, W = int(raw.shape[1]), int(raw.shape[2])
+        dev = raw.device
+        ws = torch.empty(int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
+        losses = torch.empty(4, dtype=torch.float32, device=dev)
+        grad = torch.empty_like(raw)
+        pred = torch.empty_like(raw) if want_images else None
+        gt = torch.empty_like(raw) if want_images else None
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_photo_loss(W, H, float(l1_w), float(ssim_w), _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg),
+                                         _ptr(ws), _ptr(pred), _ptr(gt), _ptr(losses), None, _ptr(grad), stream),
+                       "photo loss")
+        # grad = d(l1 term + ssim term)/d raw; the two terms are separated again in backward only if their upstream
+        # gradients differ (they never do in the reference: loss = sum(loss_dict.values()))
+        ctx.save_for_backward(grad)
+        ctx.args = (raw, gt_rgb, mask, bg, float(l1_w), float(ssim_w), W, H)
+        outs = (losses[0], losses[1], losses[2], losses[3])
+        if want_images:
+            ctx.mark_non_differentiable(pred, gt)
+            return outs + (pred, gt)
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim, g_raw_l1=None, g_ssim_mean=None, *unused):
+        (grad,) = ctx.saved_tensors
+        same = bool(torch.equal(g_l1, g_ssim)) if (g_l1 is not None and g_ssim is not None) else False
+        if same:
+            return grad * g_l1, None, None, None, None, None, None
+        # general case: one more call with explicit upstream weights
+        raw, gt_rgb, mask, bg, l1_w, ssim_w, W, H = ctx.args
+        lib = _lib.load()
+        dev = raw.device
+        up = torch.stack([g_l1 if g_l1 is not None else torch.zeros((), device=dev),
+                          g_ssim if g_ssim is not None else torch.zeros((), device=dev)]).float().contiguous()
+        ws = torch.empty(int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(raw)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_photo_loss(W, H, l1_w, ssim_w, _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg), _ptr(ws),
+                                         None, None, None, _ptr(up), _ptr(out), stream), "photo loss backward")
+        return out, None, None, None, None, None, None
+
+
+def photometric_loss(raw_image, gt_rgb, mask, bg_color, l1_w=0.8, ssim_w=0.2, return_images=False):
+    """-> (loss_dict, extras_dict) with the reference's keys 'l1', 'ssim' (weighted, differentiable w.r.t. raw_image)
+    and, when ``return_images``, 'pred_img' / 'gt_img'.  Default weights: human.loss.l1_w / ssim_w (defaults/config.py:89-90).
+    The unweighted L1 and the mean SSIM are returned under 'l1_raw' / 'ssim_mean' in extras_dict (detached)."""
+    out = _PhotoLoss.apply(raw_image, gt_rgb, mask, bg_color, l1_w, ssim_w, bool(return_images))
+    loss_dict = {}
+    if l1_w > 0.0:
+        loss_dict["l1"] = out[0]
+    if ssim_w > 0.0:
+        loss_dict["ssim"] = out[1]
+    extras = {"l1_raw": out[2].detach(), "ssim_mean": out[3].detach()}
+    if return_images:
+        extras["pred_img"], extras["gt_img"] = out[4], out[5]
+    return loss_dict, extras
+
+
+class PhotoLossEngine:
+    """Pre-allocated variant for training loops / bench.py: no allocation, no synchronisation per call."""
+
+    def __init__(self, W, H, device, l1_w=0.8, ssim_w=0.2):
+        self.lib = _lib.load()
+        self.W, self.H, self.l1_w, self.ssim_w = int(W), int(H), float(l1_w), float(ssim_w)
+        self.dev = torch.device(device)
+        self.ws = torch.empty(int(self.lib.sg_photo_loss_ws_bytes(self.W, self.H)), dtype=torch.uint8, device=self.dev)
+        self.losses = torch.zeros(4, dtype=torch.float32, device=self.dev)
+        self.grad = torch.empty((3, self.H, self.W), dtype=torch.float32, device=self.dev)
+
+    def __call__(self, raw, gt_rgb, mask, bg):
+        stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+        _lib.check(self.lib.sg_photo_loss(self.W, self.H, self.l1_w, self.ssim_w, _ptr(raw), _ptr(gt_rgb), _ptr(mask),
+                                          _ptr(bg), _ptr(self.ws), None, None, _ptr(self.losses), None, _ptr(self.grad),
+                                          stream), "photo loss")
+        return self.grad
