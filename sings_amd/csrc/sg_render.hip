@@ -127,7 +127,8 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                     const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap)
+                     const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
+                     const uint32_t *__restrict__ header)
 {
     __shared__ float4 sA[SG_FB];
     __shared__ float4 sB[SG_FB];
@@ -144,7 +145,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const bool inside = px < W && py < H;
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
-    const int n = (int)(range.y - range.x);
+    // R > capacity: part of the sorted list was never written (the caller re-runs with a larger workspace) --
+    // render the background instead of gathering through stale ids
+    const int n = header[1] ? 0 : (int)(range.y - range.x);
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -222,7 +225,7 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     sg_prof_begin(SG_K_RENDER_FWD, st);
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib,
-                       b.ck_start, im.ckpt, sg_ckpt_cap(cap));
+                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -287,7 +290,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
     (void)T; (void)nblocks;
-    const int nitems = (int)header[5];
+    const int nitems = header[1] ? 0 : (int)header[5];             // nothing to do after a capacity overflow
     const int it = sg_tile_of_block(blockIdx.x);
     if (it >= nitems) return;
     const uint32_t item = items[it];

@@ -400,3 +400,33 @@ def test_cfg3_full_size_properties():
     ref = 0.5 * ga.double() - 2.0 * g2.double()
     err = (g12.double() - ref).abs().max().item(); scale = ref.abs().max().item()
     assert err <= 2e-5 * scale, (err, scale)
+
+
+def test_capacity_overflow_is_reported_and_harmless():
+    """R > capacity_pairs: the call reports R (so the caller can grow the workspace), never follows unwritten list
+    entries (workspaces poisoned with 0xFF here) and renders the background."""
+    import ctypes as C
+    from sings_amd import _lib
+    from sings_amd.rasterizer import _settings_struct, _ptr
+    dev = _dev()
+    s = synthetic_scene(3000, 160, 128, 0, 9)
+    s["scales"] = (s["scales"] * 30).astype(np.float32)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    P, W, H, cap = 3000, s["W"], s["H"], 20000
+    keep = []
+    st = _settings_struct(rs, dev, 16, keep)
+    L = _lib.layout(P, W, H, cap)
+    poison = lambda n: torch.full((n,), 0xFF, dtype=torch.uint8, device=dev)
+    geom, binning, img = poison(L.geom_bytes), poison(L.bin_bytes), poison(L.img_bytes)
+    color = torch.empty((3, H, W), device=dev); radii = torch.empty(P, dtype=torch.int32, device=dev)
+    nr = C.c_int64(0)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(_lib.load().sg_rasterize_forward(
+        C.byref(st), P, _ptr(ins[0]), _ptr(ins[1]), None, _ptr(ins[2]), _ptr(ins[3]), _ptr(ins[4]), None, _ptr(geom),
+        _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii), 0, C.byref(nr), stream), "forward")
+    torch.cuda.synchronize()
+    assert nr.value > cap
+    bgv = torch.from_numpy(s["bg"]).to(dev)[:, None, None].expand(3, H, W)
+    assert torch.equal(color, bgv)
