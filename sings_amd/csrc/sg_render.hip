@@ -378,6 +378,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float G = sg_exp(power);
                 const float alpha = fminf(0.99f, gb.y * G);
                 const bool valid = (ee < ncq) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: record stays zero
                 const float ae = valid ? alpha : 0.0f;
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
                 Tr = Tr * rinv;                                  // T in front of this entry
