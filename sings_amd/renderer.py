@@ -57,9 +57,11 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
     rasterizer = GaussianRasterizer(raster_settings=_settings(data, bg_color, scaling_modifier, active_sh_degree))
     rendered_image, radii = rasterizer(means3D=means3D, means2D=screenspace_points, shs=shs, opacities=opacity,
                                        scales=scales, rotations=rotations, colors_precomp=rgb)
+    raw = rendered_image
     rendered_image = torch.clamp(rendered_image, 0.0, 1.0)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii}
+    # 'render_raw' (not in the reference's dict): the unclamped image, input of the fused loss (photo_loss.py)
+    return {"render": rendered_image, "render_raw": raw, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii}
 
 
 class _ViewspaceGrad:
@@ -79,7 +81,8 @@ def get_render_pkg_fused(data, canon, A_cano2pose, bg_color, smpl_scale=None, tr
                                       canon['shs'], canon['lbs_weights'], A_cano2pose, rs, smpl_scale=smpl_scale,
                                       transl=transl, ext_tfs=ext_tfs, return_posed=return_posed)
     radii = out[1]
-    pkg = {"render": torch.clamp(out[0], 0.0, 1.0), "viewspace_points": _ViewspaceGrad(), "visibility_filter": radii > 0,
+    pkg = {"render": torch.clamp(out[0], 0.0, 1.0), "render_raw": out[0], "viewspace_points": _ViewspaceGrad(),
+           "visibility_filter": radii > 0,
            "radii": radii, "human_visibility_filter": radii > 0, "human_radii": radii}
     if return_posed:
         pkg.update(xyz=out[2], rotq=out[3], scales=out[4])

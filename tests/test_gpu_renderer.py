@@ -121,3 +121,37 @@ def test_animate_chunk_matches_per_frame_fused_calls():
             ref = get_render_pkg_fused(data, canon, A, bg, transl=transl[f])["render"]
         assert torch.allclose(imgs[f], ref, atol=2e-6)
         assert float((imgs[f] < 0.999).float().mean()) > 0.02          # the avatar is in view
+
+
+def test_render_then_fused_photometric_loss_matches_torch_chain():
+    """render_pkg['render_raw'] -> sg_photo_loss -> rasterizer backward  ==  the reference's chain
+    clamp -> l1_loss + ssim (torch ops, here the oracle's restatement on the GPU tensors) -> rasterizer backward."""
+    from oracle import photo_loss_oracle as plo
+    from sings_amd.photo_loss import photometric_loss
+    from sings_amd.renderer import get_render_pkg
+    dev = torch.device("cuda:0")
+    W, H = 160, 96
+    s = synthetic_scene(2500, W, H, 2, 6)
+    cam, data = _data(dev, W, H)
+    rs = np.random.RandomState(3)
+    gt = torch.from_numpy(rs.uniform(0, 1, (3, H, W)).astype(np.float32)).to(dev)
+    mask = torch.from_numpy((rs.uniform(size=(H, W)) < 0.7).astype(np.float32)).to(dev)
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+    grads = []
+    for fused in (True, False):
+        req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+        gs = dict(xyz=req(s["means3D"]), shs=req(s["shs"]), opacity=req(s["opacities"]), scales=req(s["scales"]),
+                  rotq=req(s["rotations"]), active_sh_degree=2)
+        pkg = get_render_pkg(data, gs, bg)
+        if fused:
+            ld, _ = photometric_loss(pkg["render_raw"], gt, mask, bg, 0.8, 0.2)
+            loss = ld["l1"] + ld["ssim"]
+        else:
+            o = plo.photometric_loss(pkg["render_raw"], gt, mask, bg, 0.8, 0.2)
+            loss = o["l1"] + o["ssim"]
+        loss.backward()
+        grads.append([loss.item()] + [gs[k].grad.cpu().numpy() for k in ("xyz", "shs", "opacity", "scales", "rotq")])
+    assert abs(grads[0][0] - grads[1][0]) <= 2e-6 * abs(grads[1][0])
+    for a, b in zip(grads[0][1:], grads[1][1:]):
+        scale = np.abs(b).max()
+        assert (np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5 * scale).all()
