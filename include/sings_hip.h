@@ -160,6 +160,36 @@ int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *
                   const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out, float *losses,
                   const float *upstream, float *dL_draw, void *stream);
 
+/* ---- geometry-preserving regularisers, value + gradient ---------------------------------
+ * Replace sings/rec/losses/loss_items.py (called from gs_trainer.py:355-399).  All pointers device memory;
+ * `loss` [1]; `upstream` [1] = d(total)/d(this loss), NULL = 1; gradient outputs may be NULL (value only).
+ * `ws`: sg_reg_ws_bytes(rows) bytes (sg_knn_ws_bytes(N) for the edge loss).  Deterministic (no float atomics). */
+size_t sg_reg_ws_bytes(int rows);
+/* RegionLaplacianLoss_v2.forward / forward_hands (:93-192) on the static graph: CSR (row_ptr [V+1], col [nnz], both
+ * directions of every edge whose endpoints share a label), deg_inv [V] = 1/deg (0 if isolated),
+ * vscale [V] = weight(region) / (V_region * C) (0 outside the summed regions); x [V,C]; g_ws [V,C] scratch.
+ *   loss = sum_i vscale_i * |(D^-1 A x - x)_i|^2 */
+int sg_region_laplacian(int V, int C, const float *x, const int *row_ptr, const int *col, const float *deg_inv,
+                        const float *vscale, void *ws, float *g_ws, float *loss, const float *upstream,
+                        float *dL_dx, void *stream);
+/* pytorch3d.loss.mesh_edge_loss(mesh, target_length=0) (gs_trainer.py:366): (1/E) sum_e |v0 - v1|^2; CSR with both
+ * directions of the E unique edges */
+int sg_mesh_edge_loss(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws, float *loss,
+                      const float *upstream, float *dL_dx, void *stream);
+/* L2Norm.forward (:15-54): lambdas = (lambda_xyz_offsets, lambda_scales_diff, lambda_max_scale, max_scale_threshold,
+ * lambda_min_opacity, min_opacity_threshold); xyz_offsets [N,3], scales [N,3] (column 0 is used), opacity [N,1];
+ * any of the three inputs may be NULL (= not in norm_list) */
+int sg_l2norm_reg(int N, const float *xyz_offsets, const float *scales, const float *opacity, const float *lambdas6,
+                  void *ws, float *loss, const float *upstream, float *d_offsets, float *d_scales, float *d_opacity,
+                  void *stream);
+/* GaussiansEdgeLoss.forward (:57-90): mean_edge_i = mean Euclidean distance to the K-1 nearest other points
+ * (K = 9 in the reference, K in {5, 9, 17} supported, N >= K), exact, uniform-grid search instead of the brute-force
+ * pytorch3d.ops.knn_points; loss = mean((scales[:,0] - mean_edge)^2), gradient to scales only (edge lengths are
+ * detached in the reference).  mean_edge_out [N] optional; scales NULL = neighbour search only. */
+size_t sg_knn_ws_bytes(int N);
+int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out,
+                          float *loss, const float *upstream, float *d_scales, void *stream);
+
 /* ---- optional per-kernel timing (bench / profiling only; process-global, not thread-safe).
  * When enabled, every kernel launch of forward/backward is bracketed by hipEvents on the
  * caller's stream.  sg_profile_collect synchronises, adds the elapsed milliseconds and launch

@@ -38,7 +38,8 @@ class SgSkinInputs(C.Structure):
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
            "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
-           "sg_photo_loss_ws_bytes", "sg_photo_loss")
+           "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
+           "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss")
 NUM_KERNELS = 8
 
 
@@ -78,6 +79,14 @@ def load():
     lib.sg_photo_loss_ws_bytes.restype = sz
     lib.sg_photo_loss.argtypes = [i32, i32, C.c_float, C.c_float] + [vp] * 11
     lib.sg_photo_loss.restype = C.c_int
+    lib.sg_reg_ws_bytes.argtypes = [i32]; lib.sg_reg_ws_bytes.restype = sz
+    lib.sg_knn_ws_bytes.argtypes = [i32]; lib.sg_knn_ws_bytes.restype = sz
+    lib.sg_region_laplacian.argtypes = [i32, i32] + [vp] * 11
+    lib.sg_mesh_edge_loss.argtypes = [i32, i32] + [vp] * 8
+    lib.sg_l2norm_reg.argtypes = [i32] + [vp] * 11
+    lib.sg_gaussian_edge_loss.argtypes = [i32, i32] + [vp] * 8
+    for f in ("sg_region_laplacian", "sg_mesh_edge_loss", "sg_l2norm_reg", "sg_gaussian_edge_loss"):
+        getattr(lib, f).restype = C.c_int
     for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",
               "sg_read_num_rendered", "sg_skinned_forward", "sg_skinned_backward"):
         getattr(lib, f).restype = C.c_int

@@ -272,6 +272,57 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
     return 0;
 }
 
+// ---- regularisers (f1)
+extern "C" size_t sg_reg_ws_bytes(int rows) { return sg_reg_ws_bytes_impl(rows > 0 ? rows : 1); }
+extern "C" size_t sg_knn_ws_bytes(int N) { return sg_knn_ws_bytes_impl(N > 0 ? N : 1); }
+
+#define SG_RET_LAST(what)                                     \
+    do {                                                      \
+        hipError_t e_ = hipGetLastError();                    \
+        if (e_ != hipSuccess) return sg_fail(what, e_);       \
+        return 0;                                             \
+    } while (0)
+
+extern "C" int sg_region_laplacian(int V, int C, const float *x, const int *row_ptr, const int *col,
+                                   const float *deg_inv, const float *vscale, void *ws, float *g_ws, float *loss,
+                                   const float *upstream, float *dL_dx, void *stream)
+{
+    if (V <= 0 || C <= 0 || !x || !row_ptr || !col || !deg_inv || !vscale || !ws || !g_ws || (!loss && !dL_dx))
+        return sg_fail("sg_region_laplacian: bad argument", hipSuccess);
+    sg_launch_region_laplacian(V, C, x, row_ptr, col, deg_inv, vscale, ws, g_ws, loss, upstream, dL_dx, (hipStream_t)stream);
+    SG_RET_LAST("sg_region_laplacian");
+}
+
+extern "C" int sg_mesh_edge_loss(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws,
+                                 float *loss, const float *upstream, float *dL_dx, void *stream)
+{
+    if (V <= 0 || E <= 0 || !x || !row_ptr || !col || !ws || (!loss && !dL_dx))
+        return sg_fail("sg_mesh_edge_loss: bad argument", hipSuccess);
+    sg_launch_mesh_edge(V, E, x, row_ptr, col, ws, loss, upstream, dL_dx, (hipStream_t)stream);
+    SG_RET_LAST("sg_mesh_edge_loss");
+}
+
+extern "C" int sg_l2norm_reg(int N, const float *xyz_offsets, const float *scales, const float *opacity,
+                             const float *lambdas6, void *ws, float *loss, const float *upstream, float *d_offsets,
+                             float *d_scales, float *d_opacity, void *stream)
+{
+    if (N <= 0 || !lambdas6 || !ws || (!xyz_offsets && !scales && !opacity))
+        return sg_fail("sg_l2norm_reg: bad argument", hipSuccess);
+    sg_launch_l2norm(N, xyz_offsets, scales, opacity, lambdas6, ws, loss, upstream, d_offsets, d_scales, d_opacity,
+                     (hipStream_t)stream);
+    SG_RET_LAST("sg_l2norm_reg");
+}
+
+extern "C" int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float *scales, void *ws,
+                                     float *mean_edge_out, float *loss, const float *upstream, float *d_scales,
+                                     void *stream)
+{
+    if (N < K || !xyz || !ws) return sg_fail("sg_gaussian_edge_loss: bad argument (need N >= K)", hipSuccess);
+    if (sg_launch_knn_edge(N, K, xyz, scales, ws, mean_edge_out, loss, upstream, d_scales, (hipStream_t)stream))
+        return sg_fail("sg_gaussian_edge_loss: K must be 5, 9 or 17", hipSuccess);
+    SG_RET_LAST("sg_gaussian_edge_loss");
+}
+
 // ---- per-kernel event timing ------------------------------------------------------------
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[SG_NUM_KERNELS];

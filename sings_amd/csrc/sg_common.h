@@ -141,6 +141,17 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                         float *posed_rotq, float *posed_scales, hipStream_t st);
 size_t sg_skin_slab_floats(int P);
 size_t sg_photo_loss_ws_bytes_impl(int W, int H);
+size_t sg_reg_ws_bytes_impl(int n);
+size_t sg_knn_ws_bytes_impl(int N);
+void sg_launch_region_laplacian(int V, int C, const float *x, const int *row_ptr, const int *col, const float *deg_inv,
+                                const float *vscale, void *ws, float *g_ws, float *loss, const float *upstream,
+                                float *dL_dx, hipStream_t st);
+void sg_launch_mesh_edge(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws, float *loss,
+                         const float *upstream, float *dL_dx, hipStream_t st);
+void sg_launch_l2norm(int N, const float *off, const float *scales, const float *opacity, const float *lambdas6, void *ws,
+                      float *loss, const float *upstream, float *d_off, float *d_scales, float *d_opacity, hipStream_t st);
+int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
+                       const float *upstream, float *d_scales, hipStream_t st);
 void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                           const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
                           float *losses, const float *upstream, float *dL_draw, hipStream_t st);

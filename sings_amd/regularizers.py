@@ -1,0 +1,232 @@
+"""Geometry-preserving regularisers of the SinGS trainer through the C ABI.
+
+Same class / function names, constructor arguments and forward signatures as the reference
+(sings/rec/losses/loss_items.py; pytorch3d.loss.mesh_edge_loss for the mesh term), so
+``gs_trainer.py:168-194, 355-399`` can use them unchanged:
+
+    L2Norm(**lambdas)(human_gs_out)                                   loss_items.py:15-54
+    GaussiansEdgeLoss(K=9)(human_gs_out)                              :57-90
+    RegionLaplacianLoss_v2(verts, edges, vertex_labels, region_weights=...)(x), .forward_hands(x)   :93-192
+    mesh_edge_loss(verts, edges)                                      pytorch3d.loss.mesh_edge_loss(mesh, 0)
+
+Each returns a 0-dim loss tensor with autograd; the gradient is computed in the same kernel pass as the value and only
+scaled in backward.  Static graph structure (CSR of same-label edges, degrees, per-vertex region scale) is built once on
+the host with numpy, like ``reset_laplacians`` does with torch.  No CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from .rasterizer import _ptr
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _need_gpu(t, what):
+    if not t.is_cuda:
+        raise RuntimeError(f"sings_amd.regularizers.{what}: tensors must live on the GPU (no CPU fallback)")
+
+
+def _csr(num_verts, edges):
+    """edges [E,2] unique undirected -> (row_ptr int32 [V+1], col int32 [2E]) with both directions."""
+    e = np.asarray(edges, dtype=np.int64).reshape(-1, 2)
+    src = np.concatenate([e[:, 0], e[:, 1]]); dst = np.concatenate([e[:, 1], e[:, 0]])
+    order = np.lexsort((dst, src))
+    src, dst = src[order], dst[order]
+    row_ptr = np.zeros(num_verts + 1, np.int64)
+    np.add.at(row_ptr, src + 1, 1)
+    return np.cumsum(row_ptr).astype(np.int32), dst.astype(np.int32)
+
+
+class _ScaledGrad(torch.autograd.Function):
+    """loss (0-dim) whose gradients w.r.t. the listed inputs were already computed by the kernel."""
+
+    @staticmethod
+    def forward(ctx, loss, n_inputs, *tensors):
+        inputs, grads = tensors[:n_inputs], tensors[n_inputs:]
+        ctx.save_for_backward(*grads)
+        ctx.n = n_inputs
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None, None) + tuple(g * d if d is not None else None for d in ctx.saved_tensors) + (None,) * ctx.n
+
+
+def _attach(loss, inputs, grads):
+    keep_i, keep_g = [], []
+    for t, d in zip(inputs, grads):
+        if t is not None and d is not None and t.requires_grad:
+            keep_i.append(t); keep_g.append(d)
+    if not keep_i:
+        return loss.clone()
+    return _ScaledGrad.apply(loss, len(keep_i), *keep_i, *keep_g)
+
+
+class L2Norm(torch.nn.Module):
+    def __init__(self, lambda_xyz_offsets=0.005, lambda_scales_diff=0.005, lambda_max_scale=0.001,
+                 max_scale_threshold=0.008, lambda_min_opacity=0.0001, min_opacity_threshold=0.2):
+        super().__init__()
+        self._l = (lambda_xyz_offsets, lambda_scales_diff, lambda_max_scale, max_scale_threshold, lambda_min_opacity,
+                   min_opacity_threshold)
+
+    def forward(self, human_gs_out):
+        lib = _lib.load()
+        off = human_gs_out['xyz_offsets'].contiguous().float()
+        sc = human_gs_out['scales'].contiguous().float()
+        op = human_gs_out['opacity'].contiguous().float() if 'opacity' in human_gs_out else None
+        _need_gpu(off, "L2Norm")
+        dev, N = off.device, int(off.shape[0])
+        lam = torch.tensor(self._l, dtype=torch.float32, device=dev)
+        ws = torch.empty(int(lib.sg_reg_ws_bytes(N)), dtype=torch.uint8, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        d_off, d_sc = torch.empty_like(off), torch.empty_like(sc)
+        d_op = torch.empty_like(op) if op is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_l2norm_reg(N, _ptr(off), _ptr(sc), _ptr(op), _ptr(lam), _ptr(ws), _ptr(loss), None,
+                                         _ptr(d_off), _ptr(d_sc), _ptr(d_op), _stream(dev)), "l2norm")
+        return _attach(loss[0], [human_gs_out['xyz_offsets'], human_gs_out['scales'], human_gs_out.get('opacity')],
+                       [d_off, d_sc, d_op])
+
+
+class GaussiansEdgeLoss(torch.nn.Module):
+    def __init__(self, K=9, eps=1e-12):
+        super().__init__()
+        self._K, self._eps = K, eps
+
+    def forward(self, human_gs_out):
+        lib = _lib.load()
+        verts = human_gs_out['xyz_canon'].detach().contiguous().float()      # edge lengths are detached (:75)
+        sc = human_gs_out['scales'].contiguous().float()
+        _need_gpu(verts, "GaussiansEdgeLoss")
+        dev, N = verts.device, int(verts.shape[0])
+        ws = torch.empty(int(lib.sg_knn_ws_bytes(N)), dtype=torch.uint8, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        d_sc = torch.empty_like(sc)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_gaussian_edge_loss(N, self._K, _ptr(verts), _ptr(sc), _ptr(ws), None, _ptr(loss), None,
+                                                 _ptr(d_sc), _stream(dev)), "gaussian edge loss")
+        return _attach(loss[0], [human_gs_out['scales']], [d_sc])
+
+
+def knn_mean_edge(xyz, K=9):
+    """[N] mean distance to the K-1 nearest other points (exact)."""
+    lib = _lib.load()
+    xyz = xyz.detach().contiguous().float()
+    _need_gpu(xyz, "knn_mean_edge")
+    dev, N = xyz.device, int(xyz.shape[0])
+    ws = torch.empty(int(lib.sg_knn_ws_bytes(N)), dtype=torch.uint8, device=dev)
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(lib.sg_gaussian_edge_loss(N, K, _ptr(xyz), None, _ptr(ws), _ptr(out), None, None, None, _stream(dev)),
+                   "knn")
+    return out
+
+
+class RegionLaplacianLoss_v2(torch.nn.Module):
+    def __init__(self, verts, edges, vertex_labels, faces=None, region_weights=None, laplacian_type="standard"):
+        """only for unique edges.  ``region_weights``: sequence indexed by label (what the reference's ``parse_weights``
+        returns) or a dict label -> weight."""
+        super().__init__()
+        if laplacian_type != "standard":
+            raise NotImplementedError("only the standard (uniform) Laplacian of the reference's default is provided")
+        self.dev = verts.device
+        self.reset_laplacians(verts, edges, vertex_labels, faces)
+        n_lab = int(self.unique_labels.max()) + 1
+        if region_weights is None:
+            w = np.ones(n_lab)
+        elif isinstance(region_weights, dict):
+            w = np.ones(n_lab)
+            for k, v in region_weights.items():
+                w[int(k)] = v
+        else:
+            w = np.asarray(region_weights, dtype=np.float64)
+        self.weights = w
+
+    def reset_laplacians(self, verts, edges, vertex_labels, faces=None):
+        lab = vertex_labels.detach().cpu().numpy() if torch.is_tensor(vertex_labels) else np.asarray(vertex_labels)
+        lab = lab.astype(np.int64)
+        if (lab < 0).any():
+            raise ValueError("vertex labels must be >= 0")
+        e = edges.detach().cpu().numpy() if torch.is_tensor(edges) else np.asarray(edges)
+        e = e.astype(np.int64).reshape(-1, 2)
+        V = int(lab.shape[0])
+        same = lab[e[:, 0]] == lab[e[:, 1]]                     # loss_items.py:139: edges whose endpoints share the label
+        row_ptr, col = _csr(V, e[same])
+        deg = np.diff(row_ptr).astype(np.float64)
+        self.V = V
+        self.labels = lab
+        self.unique_labels = np.unique(lab)
+        self.counts = np.bincount(lab, minlength=int(lab.max()) + 1)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(self.dev)
+        self.row_ptr, self.col = t(row_ptr, np.int32), t(col, np.int32)
+        self.deg_inv = t(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0), np.float32)
+        self._vscale_cache = {}
+
+    def _vscale(self, C, per_label):
+        key = (C, tuple(np.round(per_label, 12)))
+        if key not in self._vscale_cache:
+            vs = per_label[self.labels] / (self.counts[self.labels] * float(C))
+            self._vscale_cache[key] = torch.from_numpy(vs.astype(np.float32)).to(self.dev)
+        return self._vscale_cache[key]
+
+    def _run(self, x, per_label):
+        lib = _lib.load()
+        xin = x
+        x = x.contiguous().float()
+        _need_gpu(x, "RegionLaplacianLoss_v2")
+        if x.shape[0] != self.V:
+            raise ValueError(f"expected {self.V} rows, got {x.shape[0]}")
+        C_ = int(x.numel() // self.V)
+        vs = self._vscale(C_, per_label)
+        dev = x.device
+        ws = torch.empty(int(lib.sg_reg_ws_bytes(self.V)), dtype=torch.uint8, device=dev)
+        g = torch.empty_like(x); dx = torch.empty_like(x)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_region_laplacian(self.V, C_, _ptr(x), _ptr(self.row_ptr), _ptr(self.col), _ptr(self.deg_inv),
+                                               _ptr(vs), _ptr(ws), _ptr(g), _ptr(loss), None, _ptr(dx), _stream(dev)),
+                       "region laplacian")
+        return _attach(loss[0], [xin], [dx.view_as(xin)])
+
+    def forward(self, x):
+        per = np.zeros(len(self.counts))
+        per[self.unique_labels] = self.weights[self.unique_labels]
+        return self._run(x, per)
+
+    def forward_hands(self, x, hand_strength=1000):
+        per = np.zeros(len(self.counts))
+        per[[6, 7]] = hand_strength                              # loss_items.py:172-180
+        return self._run(x[:self.V] if x.shape[0] != self.V else x, per)
+
+
+class _MeshEdges:
+    def __init__(self, num_verts, edges, dev):
+        row_ptr, col = _csr(num_verts, edges)
+        self.V, self.E = int(num_verts), int(np.asarray(edges).reshape(-1, 2).shape[0])
+        self.row_ptr = torch.from_numpy(row_ptr).to(dev); self.col = torch.from_numpy(col).to(dev)
+
+
+def mesh_edge_loss(verts, edges, _cache={}):
+    """pytorch3d.loss.mesh_edge_loss(Meshes([verts], [faces]), target_length=0.0) for ONE mesh whose unique edges are
+    ``edges`` [E,2] (``mesh.edges_packed()``): mean_e |v0 - v1|^2."""
+    lib = _lib.load()
+    x = verts.contiguous().float()
+    _need_gpu(x, "mesh_edge_loss")
+    dev = x.device
+    e = edges.detach().cpu().numpy() if torch.is_tensor(edges) else np.asarray(edges)
+    key = (id(edges), int(x.shape[0]), str(dev))
+    if key not in _cache:
+        _cache.clear()
+        _cache[key] = _MeshEdges(int(x.shape[0]), e, dev)
+    m = _cache[key]
+    ws = torch.empty(int(lib.sg_reg_ws_bytes(m.V)), dtype=torch.uint8, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev); dx = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        _lib.check(lib.sg_mesh_edge_loss(m.V, m.E, _ptr(x), _ptr(m.row_ptr), _ptr(m.col), _ptr(ws), _ptr(loss), None,
+                                         _ptr(dx), _stream(dev)), "mesh edge loss")
+    return _attach(loss[0], [verts], [dx])
