@@ -190,6 +190,42 @@ size_t sg_knn_ws_bytes(int N);
 int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out,
                           float *loss, const float *upstream, float *d_scales, void *stream);
 
+/* ---- attribute decode ---------------------------------------------------------------------
+ * Multi-resolution tri-plane features: HexPlaneField.forward (sings/rec/models/modules/hexplane.py:46-105,163-190):
+ * per scale s the product over the planes (x,y), (x,z), (y,z) of F.grid_sample(bilinear, border, align_corners=True),
+ * concatenated over scales.  planes[s][c]: the reference parameter grids[s][c] of shape [1, feat, res[s][b], res[s][a]]
+ * for the coordinate pair (a, b) of plane c; feat must be 32; aabb = HexPlaneField.aabb (row 0, row 1).
+ * forward: feats [N, n_scales * feat].  backward: dplanes[s][c] in the same layout (fully written; NULL = skip),
+ * dxyz [N,3] optional.  `ws`: sg_triplane_ws_bytes() bytes, may be reused between the two calls (both re-transpose
+ * the current parameters).  Plane gradients are accumulated with float atomics (reproducible to rounding only). */
+typedef struct {
+    int n_scales, feat;
+    int res[4][3];
+    const float *planes[4][3];
+    float aabb[2][3];
+} SgTriplane;
+size_t sg_triplane_ws_bytes(const SgTriplane *tp);
+int sg_triplane_forward(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, void *stream);
+int sg_triplane_backward(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                         float *const dplanes[4][3], float *dxyz, void *stream);
+/* Bias + activation around the decoders' library GEMMs (modules/decoders.py:16-110).  act: 0 identity, 1 GELU (erf),
+ * 2 sigmoid(z + row_offset[n]) (AppearanceDecoder.opacity_offset; row_offset may be NULL), 3 log(exp(z) + 1).
+ * forward: z = y + bias (stored if z_out != NULL), h = act(z); y, z_out, h_out [N,C] (h_out may alias y).
+ * backward: dz = dh * act'(z), dbias [C] = column sums of dz (fixed order, deterministic); C <= 128;
+ * `ws`: sg_bias_act_ws_bytes(N, C). */
+size_t sg_bias_act_ws_bytes(int N, int C);
+int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
+                        float *z_out, float *h_out, void *stream);
+int sg_bias_act_backward(int N, int C, int act, const float *z, const float *row_offset, const float *dh, void *ws,
+                         float *dz, float *dbias, void *stream);
+
+/* Weight / bias gradient of one decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz (db may be NULL);
+ * dz [N,Cout], x [N,Cin]; Cin in {32, 64, 96, 128}, Cout <= 128.  fp32 on the matrix cores, deterministic.
+ * `ws`: sg_weight_grad_ws_bytes(N, Cout, Cin). */
+size_t sg_weight_grad_ws_bytes(int N, int Cout, int Cin);
+int sg_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
+                   void *stream);
+
 /* ---- optional per-kernel timing (bench / profiling only; process-global, not thread-safe).
  * When enabled, every kernel launch of forward/backward is bracketed by hipEvents on the
  * caller's stream.  sg_profile_collect synchronises, adds the elapsed milliseconds and launch

@@ -272,6 +272,59 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
     return 0;
 }
 
+// ---- attribute decode (f3)
+extern "C" size_t sg_triplane_ws_bytes(const SgTriplane *tp) { return sg_tp_check(tp) ? 0 : sg_triplane_ws_bytes_impl(tp); }
+extern "C" int sg_triplane_forward(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, void *stream)
+{
+    if (sg_tp_check(tp)) return sg_fail("sg_triplane_forward: bad plane description (feat must be 32, 1..4 scales)", hipSuccess);
+    if (N <= 0 || !xyz || !ws || !feats) return sg_fail("sg_triplane_forward: bad argument", hipSuccess);
+    sg_launch_triplane_fwd(tp, N, xyz, ws, feats, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_triplane_forward", e);
+}
+extern "C" int sg_triplane_backward(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                                    float *const dplanes[4][3], float *dxyz, void *stream)
+{
+    if (sg_tp_check(tp)) return sg_fail("sg_triplane_backward: bad plane description", hipSuccess);
+    if (N <= 0 || !xyz || !ws || !dfeats || !dplanes) return sg_fail("sg_triplane_backward: bad argument", hipSuccess);
+    if (sg_launch_triplane_bwd(tp, N, xyz, ws, dfeats, dplanes, dxyz, (hipStream_t)stream))
+        return sg_fail("sg_triplane_backward: memset", hipGetLastError());
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_triplane_backward", e);
+}
+extern "C" size_t sg_bias_act_ws_bytes(int N, int C) { return sg_bias_act_ws_bytes_impl(N > 0 ? N : 1, C > 0 ? C : 1); }
+extern "C" int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
+                                   float *z_out, float *h_out, void *stream)
+{
+    if (N <= 0 || C <= 0 || act < 0 || act > 3 || !y || !h_out) return sg_fail("sg_bias_act_forward: bad argument", hipSuccess);
+    sg_launch_bias_act_fwd(N, C, act, y, bias, row_offset, z_out, h_out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_bias_act_forward", e);
+}
+extern "C" int sg_bias_act_backward(int N, int C, int act, const float *z, const float *row_offset, const float *dh,
+                                    void *ws, float *dz, float *dbias, void *stream)
+{
+    if (N <= 0 || C <= 0 || C > 128 || act < 0 || act > 3 || !z || !dh || !ws || !dz)
+        return sg_fail("sg_bias_act_backward: bad argument (C <= 128)", hipSuccess);
+    sg_launch_bias_act_bwd(N, C, act, z, row_offset, dh, ws, dz, dbias, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_bias_act_backward", e);
+}
+
+extern "C" size_t sg_weight_grad_ws_bytes(int N, int Cout, int Cin)
+{
+    return N > 0 && Cout > 0 && Cin > 0 ? sg_weight_grad_ws_bytes_impl(N, Cout, Cin) : 0;
+}
+extern "C" int sg_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
+                              void *stream)
+{
+    if (N <= 0 || !dz || !x || !ws || !dW) return sg_fail("sg_weight_grad: bad argument", hipSuccess);
+    if (sg_launch_weight_grad(N, Cout, Cin, dz, x, ws, dW, db, (hipStream_t)stream))
+        return sg_fail("sg_weight_grad: Cin must be 32/64/96/128 and Cout <= 128", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_weight_grad", e);
+}
+
 // ---- regularisers (f1)
 extern "C" size_t sg_reg_ws_bytes(int rows) { return sg_reg_ws_bytes_impl(rows > 0 ? rows : 1); }
 extern "C" size_t sg_knn_ws_bytes(int N) { return sg_knn_ws_bytes_impl(N > 0 ? N : 1); }

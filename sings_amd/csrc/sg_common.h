@@ -141,6 +141,19 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                         float *posed_rotq, float *posed_scales, hipStream_t st);
 size_t sg_skin_slab_floats(int P);
 size_t sg_photo_loss_ws_bytes_impl(int W, int H);
+int sg_tp_check(const SgTriplane *tp);
+size_t sg_triplane_ws_bytes_impl(const SgTriplane *tp);
+void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st);
+int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                           float *const dplanes[4][3], float *dxyz, hipStream_t st);
+size_t sg_bias_act_ws_bytes_impl(int N, int C);
+void sg_launch_bias_act_fwd(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
+                            float *z_out, float *h_out, hipStream_t st);
+void sg_launch_bias_act_bwd(int N, int C, int act, const float *z, const float *row_offset, const float *dh, void *ws,
+                            float *dz, float *dbias, hipStream_t st);
+size_t sg_weight_grad_ws_bytes_impl(int N, int Cout, int Cin);
+int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
+                          hipStream_t st);
 size_t sg_reg_ws_bytes_impl(int n);
 size_t sg_knn_ws_bytes_impl(int N);
 void sg_launch_region_laplacian(int V, int C, const float *x, const int *row_ptr, const int *col, const float *deg_inv,

@@ -1,0 +1,439 @@
+// Attribute decode upstream of the render path: multi-resolution tri-plane features and the
+// element-wise parts of the two decoder MLPs, forward and backward.
+//
+// Replaces
+//   HexPlaneField.forward / interpolate_ms_features / grid_sample_wrapper   sings/rec/models/modules/hexplane.py:46-105,163-190
+//     (per scale: three F.grid_sample(bilinear, border, align_corners=True) calls, product over planes, concat over scales)
+//   bias + activation of every nn.Linear of GeometryDecoder / AppearanceDecoder   modules/decoders.py:16-110
+//     (GELU(erf), Sigmoid(x + opacity_offset), log(exp(x) + 1))
+// The GEMMs themselves (N x {96,128,64} by <= 128) stay library GEMMs (rocBLAS through the host).
+//
+// Tri-plane kernels are gather / scatter bound.  The reference keeps a plane as [feat][H][W]: the 32 features of a
+// texel are H*W floats apart, 1152 scattered 4-B loads per point.  Here every plane is first transposed to
+// texel-major [H][W][feat] (one 128-B line per texel, 33 MB for the shipped 64/128/256 config -> L2/MALL resident) and
+// 32 lanes = 32 features handle one point: 36 coalesced 128-B reads per point forward.  Backward recomputes the
+// interpolation, scatters w * dL/dinterp rows into a texel-major gradient buffer (one coalesced 128-B float-atomic
+// row per texel corner -- the only float atomics in this library; the reference's grid_sample backward uses them too,
+// so plane gradients are reproducible to rounding, not bitwise) and transposes it back to the reference layout.
+#include "sg_common.h"
+
+#define SG_TP_FEAT 32
+#define SG_TP_MAXS 4
+
+struct SgTpDev {                       // device-side view
+    int n_scales;
+    int res[SG_TP_MAXS][3];
+    size_t fm_off[SG_TP_MAXS][3];      // float offset of the texel-major copy of plane (s, c) in the workspace
+    float a0[3], ascale[3];            // normalised = (p - a0) * ascale - 1
+};
+__constant__ int sg_comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };   // itertools.combinations(range(3), 2)
+
+// [feat][H][W] -> [H][W][feat]   (and the reverse for gradients)
+__global__ void __launch_bounds__(256)
+sg_plane_to_fm_kernel(const float *__restrict__ src, float *__restrict__ dst, int HW)
+{
+    __shared__ float t[32][33];
+    const int x0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 texels x 32 features per block
+    for (int f = ty; f < 32; f += 8) t[f][tx] = x0 + tx < HW ? src[(size_t)f * HW + x0 + tx] : 0.0f;
+    __syncthreads();
+    for (int p = ty; p < 32; p += 8)
+        if (x0 + p < HW) dst[(size_t)(x0 + p) * 32 + tx] = t[tx][p];
+}
+__global__ void __launch_bounds__(256)
+sg_plane_from_fm_kernel(const float *__restrict__ src, float *__restrict__ dst, int HW)
+{
+    __shared__ float t[32][33];
+    const int x0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int p = ty; p < 32; p += 8) t[p][tx] = x0 + p < HW ? src[(size_t)(x0 + p) * 32 + tx] : 0.0f;
+    __syncthreads();
+    for (int f = ty; f < 32; f += 8)
+        if (x0 + tx < HW) dst[(size_t)f * HW + x0 + tx] = t[tx][f];
+}
+
+struct SgTexel {
+    int x0, x1, y0, y1;
+    float wx, wy;          // weight of x1 / y1
+    float gx, gy;          // d(ix)/du, d(iy)/dv incl. the border-clip mask
+};
+// F.grid_sample coordinate rule: align_corners=True, padding_mode='border'
+__device__ __forceinline__ void sg_texel(float u, float v, int W, int H, SgTexel &t)
+{
+    float ix = (u + 1.0f) * 0.5f * (float)(W - 1), iy = (v + 1.0f) * 0.5f * (float)(H - 1);
+    // clip_coordinates_set_grad: the coordinate gradient is zero AT and beyond the border
+    t.gx = (ix > 0.0f && ix < (float)(W - 1)) ? 0.5f * (float)(W - 1) : 0.0f;
+    t.gy = (iy > 0.0f && iy < (float)(H - 1)) ? 0.5f * (float)(H - 1) : 0.0f;
+    ix = fminf(fmaxf(ix, 0.0f), (float)(W - 1)); iy = fminf(fmaxf(iy, 0.0f), (float)(H - 1));
+    const float fx = floorf(ix), fy = floorf(iy);
+    t.x0 = (int)fx; t.y0 = (int)fy;
+    t.x1 = min(t.x0 + 1, W - 1); t.y1 = min(t.y0 + 1, H - 1);
+    t.wx = ix - fx; t.wy = iy - fy;
+}
+
+// 32 lanes per point (lane = feature), 8 points per 256-thread workgroup
+__global__ void __launch_bounds__(256)
+sg_triplane_fwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const float *__restrict__ fm,
+                       float *__restrict__ feats)
+{
+    const int n = blockIdx.x * 8 + (threadIdx.x >> 5), f = threadIdx.x & 31;
+    if (n >= N) return;
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) p[a] = (xyz[3 * (size_t)n + a] - d.a0[a]) * d.ascale[a] - 1.0f;
+    const int F = d.n_scales * SG_TP_FEAT;
+    for (int s = 0; s < d.n_scales; s++) {
+        float prod = 1.0f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int a = sg_comb[c][0], b = sg_comb[c][1];
+            const int W = d.res[s][a], H = d.res[s][b];
+            SgTexel t;
+            sg_texel(p[a], p[b], W, H, t);
+            const float *pl = fm + d.fm_off[s][c];
+            const float v00 = pl[((size_t)t.y0 * W + t.x0) * 32 + f], v01 = pl[((size_t)t.y0 * W + t.x1) * 32 + f];
+            const float v10 = pl[((size_t)t.y1 * W + t.x0) * 32 + f], v11 = pl[((size_t)t.y1 * W + t.x1) * 32 + f];
+            // same weights as grid_sample: nw = (1-wx)(1-wy), ne = wx (1-wy), sw = (1-wx) wy, se = wx wy
+            const float interp = v00 * ((1.0f - t.wx) * (1.0f - t.wy)) + v01 * (t.wx * (1.0f - t.wy)) +
+                                 v10 * ((1.0f - t.wx) * t.wy) + v11 * (t.wx * t.wy);
+            prod = prod * interp;
+        }
+        feats[(size_t)n * F + s * SG_TP_FEAT + f] = prod;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+sg_triplane_bwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const float *__restrict__ fm,
+                       const float *__restrict__ dfeats, float *__restrict__ gfm, float *__restrict__ dxyz)
+{
+    const int n = blockIdx.x * 8 + (threadIdx.x >> 5), f = threadIdx.x & 31;
+    if (n >= N) return;
+    float p[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) p[a] = (xyz[3 * (size_t)n + a] - d.a0[a]) * d.ascale[a] - 1.0f;
+    const int F = d.n_scales * SG_TP_FEAT;
+    float dp[3] = { 0.0f, 0.0f, 0.0f };                    // this lane's share of dL/d(normalised coordinate)
+    for (int s = 0; s < d.n_scales; s++) {
+        SgTexel t[3];
+        float v[3][4], interp[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int a = sg_comb[c][0], b = sg_comb[c][1];
+            const int W = d.res[s][a], H = d.res[s][b];
+            sg_texel(p[a], p[b], W, H, t[c]);
+            const float *pl = fm + d.fm_off[s][c];
+            v[c][0] = pl[((size_t)t[c].y0 * W + t[c].x0) * 32 + f]; v[c][1] = pl[((size_t)t[c].y0 * W + t[c].x1) * 32 + f];
+            v[c][2] = pl[((size_t)t[c].y1 * W + t[c].x0) * 32 + f]; v[c][3] = pl[((size_t)t[c].y1 * W + t[c].x1) * 32 + f];
+            interp[c] = v[c][0] * ((1.0f - t[c].wx) * (1.0f - t[c].wy)) + v[c][1] * (t[c].wx * (1.0f - t[c].wy)) +
+                        v[c][2] * ((1.0f - t[c].wx) * t[c].wy) + v[c][3] * (t[c].wx * t[c].wy);
+        }
+        const float g = dfeats[(size_t)n * F + s * SG_TP_FEAT + f];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int a = sg_comb[c][0], b = sg_comb[c][1];
+            const int W = d.res[s][a];
+            const float gi = g * interp[(c + 1) % 3] * interp[(c + 2) % 3];      // dL/d interp_c
+            float *gp = gfm + d.fm_off[s][c];
+            const float wx = t[c].wx, wy = t[c].wy;
+            unsafeAtomicAdd(&gp[((size_t)t[c].y0 * W + t[c].x0) * 32 + f], gi * ((1.0f - wx) * (1.0f - wy)));
+            unsafeAtomicAdd(&gp[((size_t)t[c].y0 * W + t[c].x1) * 32 + f], gi * (wx * (1.0f - wy)));
+            unsafeAtomicAdd(&gp[((size_t)t[c].y1 * W + t[c].x0) * 32 + f], gi * ((1.0f - wx) * wy));
+            unsafeAtomicAdd(&gp[((size_t)t[c].y1 * W + t[c].x1) * 32 + f], gi * (wx * wy));
+            // d interp / d ix = (v01 - v00)(1 - wy) + (v11 - v10) wy ;  d / d iy = (v10 - v00)(1 - wx) + (v11 - v01) wx
+            dp[a] += gi * ((v[c][1] - v[c][0]) * (1.0f - wy) + (v[c][3] - v[c][2]) * wy) * t[c].gx;
+            dp[b] += gi * ((v[c][2] - v[c][0]) * (1.0f - wx) + (v[c][3] - v[c][1]) * wx) * t[c].gy;
+        }
+    }
+    if (dxyz) {
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            float r = dp[a];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);       // over the 32 features of this point
+            if (f == 0) dxyz[3 * (size_t)n + a] = r * d.ascale[a];
+        }
+    }
+}
+
+// ---- bias + activation ------------------------------------------------------------------------------------
+// act: 0 identity, 1 GELU (erf), 2 sigmoid(z + row_offset), 3 log(exp(z) + 1)
+__device__ __forceinline__ float sg_gelu(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sg_gelu_grad(float z)
+{
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+__global__ void __launch_bounds__(256)
+sg_bias_act_fwd_kernel(size_t total, int C, int act, const float *__restrict__ y, const float *__restrict__ bias,
+                       const float *__restrict__ row_offset, float *__restrict__ z_out, float *__restrict__ h_out)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % (size_t)C);
+    float z = y[i] + (bias ? bias[c] : 0.0f);
+    if (z_out) z_out[i] = z;
+    float h = z;
+    if (act == 1) h = sg_gelu(z);
+    else if (act == 2) { const float t = z + (row_offset ? row_offset[i / (size_t)C] : 0.0f); h = 1.0f / (1.0f + expf(-t)); }
+    else if (act == 3) h = logf(expf(z) + 1.0f);
+    h_out[i] = h;
+}
+// dz = dh * act'(z); column sums of dz (bias gradient) as per-block partials [gridDim.x][C] (C <= 128)
+__global__ void __launch_bounds__(256)
+sg_bias_act_bwd_kernel(int N, int C, int act, int rows_per_block, const float *__restrict__ z,
+                       const float *__restrict__ row_offset, const float *__restrict__ dh, float *__restrict__ dz,
+                       float *__restrict__ partial)
+{
+    __shared__ float sAcc[256];
+    // thread t handles column t % Cp and row phase t / Cp, Cp = C rounded up to a divisor-friendly width
+    const int Cp = C <= 1 ? 1 : (C <= 4 ? 4 : (C <= 64 ? 64 : 128));
+    const int col = threadIdx.x % Cp, ph = threadIdx.x / Cp, nph = 256 / Cp;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(r0 + rows_per_block, N);
+    float acc = 0.0f;
+    if (col < C)
+        for (int r = r0 + ph; r < r1; r += nph) {
+            const size_t i = (size_t)r * C + col;
+            const float zz = z[i], g = dh[i];
+            float d = g;
+            if (act == 1) d = g * sg_gelu_grad(zz);
+            else if (act == 2) { const float s = 1.0f / (1.0f + expf(-(zz + (row_offset ? row_offset[r] : 0.0f)))); d = g * s * (1.0f - s); }
+            else if (act == 3) { const float e = expf(zz); d = g * e / (e + 1.0f); }
+            dz[i] = d;
+            acc += d;
+        }
+    sAcc[threadIdx.x] = acc;
+    __syncthreads();
+    if (ph == 0 && col < C) {
+        float t = 0.0f;
+        for (int q = 0; q < nph; q++) t += sAcc[q * Cp + col];
+        partial[(size_t)blockIdx.x * C + col] = t;
+    }
+}
+// dz = dh * act'(z) only (the bias gradient comes out of sg_weight_grad): plain streaming kernel
+__global__ void __launch_bounds__(256)
+sg_act_bwd_kernel(size_t total, int C, int act, const float *__restrict__ z, const float *__restrict__ row_offset,
+                  const float *__restrict__ dh, float *__restrict__ dz)
+{
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float zz = z[i], g = dh[i];
+    float d = g;
+    if (act == 1) d = g * sg_gelu_grad(zz);
+    else if (act == 2) { const float s = 1.0f / (1.0f + expf(-(zz + (row_offset ? row_offset[i / (size_t)C] : 0.0f)))); d = g * s * (1.0f - s); }
+    else if (act == 3) { const float e = expf(zz); d = g * e / (e + 1.0f); }
+    dz[i] = d;
+}
+__global__ void __launch_bounds__(128)
+sg_colsum_reduce_kernel(const float *__restrict__ partial, int nblocks, int C, float *__restrict__ out)
+{
+    const int c = blockIdx.x * 128 + threadIdx.x;
+    if (c >= C) return;
+    double t = 0.0;
+    for (int b = 0; b < nblocks; b++) t += (double)partial[(size_t)b * C + c];
+    out[c] = (float)t;
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+static size_t sg_tp_layout(const SgTriplane *tp, SgTpDev *d)
+{
+    size_t o = 0;
+    d->n_scales = tp->n_scales;
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int c = 0; c < 3; c++) {
+            const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+            d->fm_off[s][c] = o;
+            o += (size_t)tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]] * SG_TP_FEAT;
+            o = (o + 63) & ~(size_t)63;
+        }
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int a = 0; a < 3; a++) d->res[s][a] = tp->res[s][a];
+    for (int a = 0; a < 3; a++) {
+        d->a0[a] = tp->aabb[0][a];
+        d->ascale[a] = 2.0f / (tp->aabb[1][a] - tp->aabb[0][a]);          // hexplane.py:161 normalize_aabb
+    }
+    return o;
+}
+int sg_tp_check(const SgTriplane *tp)
+{
+    if (!tp || tp->n_scales < 1 || tp->n_scales > SG_TP_MAXS || tp->feat != SG_TP_FEAT) return 1;
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int a = 0; a < 3; a++)
+            if (tp->res[s][a] < 2) return 1;
+    return 0;
+}
+size_t sg_triplane_ws_bytes_impl(const SgTriplane *tp)
+{
+    SgTpDev d;
+    return 2 * sg_align(sg_tp_layout(tp, &d) * 4);           // texel-major planes + texel-major gradients
+}
+static void sg_tp_upload(const SgTriplane *tp, const SgTpDev &d, float *fm, hipStream_t st)
+{
+    const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int c = 0; c < 3; c++) {
+            const int HW = tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]];
+            hipLaunchKernelGGL(sg_plane_to_fm_kernel, dim3((HW + 31) / 32), dim3(256), 0, st, tp->planes[s][c],
+                               fm + d.fm_off[s][c], HW);
+        }
+}
+void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st)
+{
+    SgTpDev d;
+    sg_tp_layout(tp, &d);
+    float *fm = (float *)ws;
+    sg_tp_upload(tp, d, fm, st);
+    hipLaunchKernelGGL(sg_triplane_fwd_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, feats);
+}
+int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                           float *const dplanes[SG_TP_MAXS][3], float *dxyz, hipStream_t st)
+{
+    SgTpDev d;
+    const size_t floats = sg_tp_layout(tp, &d);
+    float *fm = (float *)ws, *gfm = (float *)((char *)ws + sg_align(floats * 4));
+    sg_tp_upload(tp, d, fm, st);                              // (parameters may have changed since the forward call)
+    if (hipMemsetAsync(gfm, 0, floats * 4, st) != hipSuccess) return 1;
+    hipLaunchKernelGGL(sg_triplane_bwd_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, dfeats, gfm, dxyz);
+    const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int c = 0; c < 3; c++) {
+            if (!dplanes[s][c]) continue;
+            const int HW = tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]];
+            hipLaunchKernelGGL(sg_plane_from_fm_kernel, dim3((HW + 31) / 32), dim3(256), 0, st, gfm + d.fm_off[s][c],
+                               dplanes[s][c], HW);
+        }
+    return 0;
+}
+
+void sg_launch_bias_act_fwd(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
+                            float *z_out, float *h_out, hipStream_t st)
+{
+    const size_t total = (size_t)N * C;
+    hipLaunchKernelGGL(sg_bias_act_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, act, y,
+                       bias, row_offset, z_out, h_out);
+}
+static inline int sg_ba_blocks(int N) { int b = (N + 511) / 512; return b < 1 ? 1 : (b > 1024 ? 1024 : b); }
+size_t sg_bias_act_ws_bytes_impl(int N, int C) { return sg_align((size_t)sg_ba_blocks(N) * C * 4); }
+void sg_launch_bias_act_bwd(int N, int C, int act, const float *z, const float *row_offset, const float *dh, void *ws,
+                            float *dz, float *dbias, hipStream_t st)
+{
+    if (!dbias) {
+        const size_t total = (size_t)N * C;
+        hipLaunchKernelGGL(sg_act_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, total, C, act, z,
+                           row_offset, dh, dz);
+        return;
+    }
+    const int nb = sg_ba_blocks(N), rpb = (N + nb - 1) / nb;
+    float *partial = (float *)ws;
+    hipLaunchKernelGGL(sg_bias_act_bwd_kernel, dim3(nb), dim3(256), 0, st, N, C, act, rpb, z, row_offset, dh, dz, partial);
+    if (dbias) hipLaunchKernelGGL(sg_colsum_reduce_kernel, dim3((C + 127) / 128), dim3(128), 0, st, partial, nb, C, dbias);
+}
+
+// ---- weight / bias gradient of a decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz ---------------
+// A GEMM whose reduction dimension is the N ~ 10^5 points and whose output is at most 128 x 128: the library kernels
+// chosen for this shape ran at 330-430 us per layer (150 k points).  Here a workgroup owns a slice of rows and the whole
+// output: wave w accumulates the 32 output rows [32w, 32w+32) x all Cin columns on the matrix cores
+// (v_mfma_f32_32x32x2_f32, exact fp32 products, k-ordered accumulation).  The MFMA operand layout IS the memory layout
+// of two consecutive rows (lane l: A = dz[n + l/32][32w + l%32], B = x[n + l/32][32t + l%32]), so operands are loaded
+// straight from global memory with 128-B coalesced half-wave reads -- no LDS, 1 + Cin/32 loads per Cin/32 MFMAs.
+// Per-workgroup partials are summed in a fixed order by sg_wgrad_reduce_kernel (deterministic).
+typedef float sg_v16f __attribute__((ext_vector_type(16)));
+#define SG_WG_ROWS 256
+
+template <int TI>
+__global__ void __launch_bounds__(256)
+sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
+                float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad)
+{
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (32 * wave >= cout_pad) return;
+    const int o = 32 * wave + (lane & 31), half = lane >> 5;
+    const bool ok_o = o < Cout;
+    sg_v16f acc[TI];
+#pragma unroll
+    for (int t = 0; t < TI; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+    float bsum = 0.0f;
+    // workgroup b takes the row slices b, b + gridDim.x, ... ; 8 k-steps (16 rows) per round: all 8 * (1 + TI) loads
+    // are issued before the first MFMA needs one of them
+    for (int r0 = blockIdx.x * SG_WG_ROWS; r0 < N; r0 += gridDim.x * SG_WG_ROWS) {
+    const int r1 = min(r0 + SG_WG_ROWS, N);
+    for (int n = r0; n < r1; n += 16) {
+        float a[8], b[8][TI];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int row = n + 2 * u + half;
+            const bool ok = row < r1;
+            a[u] = ok && ok_o ? dz[(size_t)row * Cout + o] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < TI; t++) b[u][t] = ok ? x[(size_t)row * Cin + 32 * t + (lane & 31)] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            bsum += a[u];
+#pragma unroll
+            for (int t = 0; t < TI; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+        }
+    }
+    }
+    // D layout of the 32x32 tile: lane l, register r -> row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32
+    float *pw = partial + (size_t)blockIdx.x * cout_pad * Cin;
+#pragma unroll
+    for (int t = 0; t < TI; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int i = 32 * wave + 8 * (r >> 2) + 4 * half + (r & 3);
+            pw[(size_t)i * Cin + 32 * t + (lane & 31)] = acc[t][r];
+        }
+    bsum += __shfl_xor(bsum, 32, 64);
+    if (half == 0) bpartial[(size_t)blockIdx.x * cout_pad + o] = bsum;
+}
+
+// 64 output elements per workgroup, the per-workgroup partials split over 4 waves (fixed slices, fixed order)
+__global__ void __launch_bounds__(256)
+sg_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial, int nwg, int Cout, int Cin,
+                       int cout_pad, float *__restrict__ dW, float *__restrict__ db)
+{
+    __shared__ float sS[4][64];
+    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    const int total = Cout * Cin;
+    const int per = (nwg + 3) / 4, w0 = sl * per, w1 = min(w0 + per, nwg);
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    if (e < total) {
+        const int o = e / Cin, c = e - o * Cin;
+        const float *p = partial + (size_t)o * Cin + c;
+        const size_t st = (size_t)cout_pad * Cin;
+        int w = w0;
+        for (; w + 3 < w1; w += 4) { s0 += p[w * st]; s1 += p[(w + 1) * st]; s2 += p[(w + 2) * st]; s3 += p[(w + 3) * st]; }
+        for (; w < w1; w++) s0 += p[w * st];
+    } else if (db && e < total + Cout) {
+        const int o = e - total;
+        for (int w = w0; w < w1; w++) s0 += bpartial[(size_t)w * cout_pad + o];
+    }
+    sS[sl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0) {
+        const float t = (sS[0][threadIdx.x] + sS[1][threadIdx.x]) + (sS[2][threadIdx.x] + sS[3][threadIdx.x]);
+        if (e < total) dW[e] = t;
+        else if (db && e < total + Cout) db[e - total] = t;
+    }
+}
+
+static inline int sg_wg_count(int N) { const int n = (N + SG_WG_ROWS - 1) / SG_WG_ROWS; return n < 512 ? n : 512; }
+size_t sg_weight_grad_ws_bytes_impl(int N, int Cout, int Cin)
+{
+    const size_t cp = (size_t)((Cout + 31) / 32) * 32;
+    return sg_align((size_t)sg_wg_count(N) * cp * Cin * 4) + sg_align((size_t)sg_wg_count(N) * cp * 4);
+}
+int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
+                          hipStream_t st)
+{
+    if (Cin % 32 != 0 || Cin > 128 || Cout > 128 || Cout < 1) return 1;
+    const int cp = ((Cout + 31) / 32) * 32, nwg = sg_wg_count(N), ti = Cin / 32;
+    float *partial = (float *)ws;
+    float *bpartial = (float *)((char *)ws + sg_align((size_t)nwg * cp * Cin * 4));
+#define SG_WGK(T) hipLaunchKernelGGL(sg_wgrad_kernel<T>, dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
+    switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
+#undef SG_WGK
+    hipLaunchKernelGGL(sg_wgrad_reduce_kernel, dim3((Cout * Cin + Cout + 63) / 64), dim3(256), 0, st, partial, bpartial, nwg,
+                       Cout, Cin, cp, dW, db);
+    return 0;
+}

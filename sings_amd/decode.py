@@ -1,0 +1,283 @@
+"""Attribute decode upstream of the render path: tri-plane features + the two decoder MLPs.
+
+Module and parameter names mirror the reference so that its checkpoints load unchanged
+(``SinGS.state_dict()['triplane']``, ``['geometry_dec_i']``, ``['appearance_dec_i']``):
+
+    HexPlaneField(planeconfig, bounds)        sings/rec/models/modules/hexplane.py:107-190   (grids.{s}.{c}, aabb)
+    GeometryDecoder(n_features, isotropic)    modules/decoders.py:57-110   (net.0, net.2, xyz_offsets, scales.0, scales.2, rotations.0)
+    AppearanceDecoder(n_features, ...)        modules/decoders.py:16-54    (net.0, net.2, opacity, shs)
+    decode_attributes(...)                    SinGS.get_gs_attrs, sings_hybrid.py:249-313 (single level)
+
+Tri-plane sampling (forward, plane / coordinate gradients) and every bias + activation (forward, backward, bias
+gradient) are HIP kernels behind the C ABI (sg_triplane_*, sg_bias_act_*); the GEMMs are library GEMMs (torch.mm ->
+rocBLAS / hipBLASLt).  No CPU fallback.
+"""
+import ctypes as C
+import itertools
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .rasterizer import _ptr
+
+ACT_NONE, ACT_GELU, ACT_SIGMOID, ACT_SOFTPLUS_REF = 0, 1, 2, 3
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _tp_struct(grids, aabb, keep):
+    tp = _lib.SgTriplane()
+    tp.n_scales, tp.feat = len(grids), int(grids[0][0].shape[1])
+    for s, planes in enumerate(grids):
+        # plane (0,1) is [1, F, Ry, Rx], (0,2) is [1, F, Rz, Rx], (1,2) is [1, F, Rz, Ry]
+        rx, ry, rz = int(planes[0].shape[3]), int(planes[0].shape[2]), int(planes[1].shape[2])
+        tp.res[s][0], tp.res[s][1], tp.res[s][2] = rx, ry, rz
+        for c in range(3):
+            t = planes[c].detach().contiguous().float()
+            keep.append(t)
+            tp.planes[s][c] = t.data_ptr()
+    a = aabb.detach().float().cpu()
+    for r in range(2):
+        for k in range(3):
+            tp.aabb[r][k] = float(a[r, k])
+    return tp
+
+
+class _Triplane(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pts, aabb, n_scales, *planes):
+        if not pts.is_cuda:
+            raise RuntimeError("sings_amd.decode: tensors must live on the GPU (no CPU fallback)")
+        lib = _lib.load()
+        grids = [planes[3 * s:3 * s + 3] for s in range(n_scales)]
+        keep = []
+        tp = _tp_struct(grids, aabb, keep)
+        x = pts.detach().contiguous().float()
+        dev, N = x.device, int(x.shape[0])
+        ws = torch.empty(int(lib.sg_triplane_ws_bytes(C.byref(tp))), dtype=torch.uint8, device=dev)
+        feats = torch.empty((N, tp.n_scales * tp.feat), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_triplane_forward(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(feats), _stream(dev)), "triplane forward")
+        ctx.save_for_backward(x, aabb, *planes)
+        ctx.n_scales = n_scales
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeats):
+        lib = _lib.load()
+        x, aabb, *planes = ctx.saved_tensors
+        n_scales = ctx.n_scales
+        grids = [planes[3 * s:3 * s + 3] for s in range(n_scales)]
+        keep = []
+        tp = _tp_struct(grids, aabb, keep)
+        dev, N = x.device, int(x.shape[0])
+        ws = torch.empty(int(lib.sg_triplane_ws_bytes(C.byref(tp))), dtype=torch.uint8, device=dev)
+        dplanes = [torch.empty_like(p, dtype=torch.float32) for p in planes]
+        arr = ((C.c_void_p * 3) * 4)()
+        for s in range(n_scales):
+            for c in range(3):
+                arr[s][c] = dplanes[3 * s + c].data_ptr()
+        dxyz = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        df = dfeats.contiguous().float()
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_triplane_backward(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(df), C.byref(arr), _ptr(dxyz),
+                                                _stream(dev)), "triplane backward")
+        return (dxyz, None, None) + tuple(dplanes)
+
+
+def init_grid_param(grid_nd, in_dim, out_dim, reso, a=0.1, b=0.5, device='cuda'):
+    """hexplane.py:18-43 (3-D inputs only)."""
+    assert in_dim == len(reso) == 3 and grid_nd == 2
+    grid_coefs = nn.ParameterList()
+    for coo_comb in itertools.combinations(range(in_dim), grid_nd):
+        p = nn.Parameter(torch.empty([1, out_dim] + [reso[cc] for cc in coo_comb[::-1]], device=device))
+        nn.init.uniform_(p, a=a, b=b)
+        grid_coefs.append(p)
+    return grid_coefs
+
+
+class HexPlaneField(nn.Module):
+    def __init__(self, planeconfig, bounds=1., device='cuda'):
+        super().__init__()
+        aabb = torch.tensor([[bounds, bounds, bounds], [-bounds, -bounds, -bounds]], dtype=torch.float32)
+        self.aabb = nn.Parameter(aabb, requires_grad=False).to(device)
+        self.grid_config = [planeconfig]
+        self.multiscale_res_multipliers = planeconfig["multires"]
+        self.concat_features = True
+        self.grids = nn.ModuleList()
+        self.feat_dim = 0
+        for res in self.multiscale_res_multipliers:
+            config = dict(self.grid_config[0])
+            config["resolution"] = [r * res for r in config["resolution"][:3]]
+            gp = init_grid_param(config["grid_dimensions"], config["input_coordinate_dim"], config["output_coordinate_dim"],
+                                 config["resolution"], device=device)
+            self.feat_dim += gp[-1].shape[1]
+            self.grids.append(gp)
+
+    @property
+    def get_aabb(self):
+        return self.aabb[0], self.aabb[1]
+
+    def set_aabb(self, xyz_max, xyz_min):
+        self.aabb = nn.Parameter(torch.tensor([xyz_max, xyz_min], dtype=torch.float32, device=self.aabb.device), requires_grad=False)
+
+    def forward(self, pts, timestamps=None):
+        assert timestamps is None, "spatial planes only (the reference's human model never passes timestamps)"
+        planes = [p for gp in self.grids for p in gp]
+        return _Triplane.apply(pts.reshape(-1, 3), self.aabb, len(self.grids), *planes)
+
+    get_density = forward
+
+
+class _LinearAct(torch.autograd.Function):
+    """h = act(x @ W^T + b): library GEMM + fused HIP bias/activation; backward likewise."""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, row_offset):
+        lib = _lib.load()
+        x = x.contiguous().float()
+        dev, N, Cout = x.device, int(x.shape[0]), int(W.shape[0])
+        y = torch.mm(x, W.t())
+        z = torch.empty_like(y) if act != ACT_NONE else None
+        h = y                                                    # in place: y is not needed afterwards
+        ro = row_offset.contiguous().float().reshape(-1) if row_offset is not None else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_bias_act_forward(N, Cout, act, _ptr(y), _ptr(b), _ptr(ro), _ptr(z), _ptr(h), _stream(dev)),
+                       "bias/act forward")
+        ctx.save_for_backward(x, W, z if z is not None else h, ro if ro is not None else torch.empty(0, device=dev))
+        ctx.act, ctx.has_ro, ctx.has_b = act, ro is not None, b is not None
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        x, W, z, ro = ctx.saved_tensors
+        dev, N, Cout = x.device, int(x.shape[0]), int(W.shape[0])
+        dh = dh.contiguous().float()
+        Cin = int(W.shape[1])
+        if ctx.act != ACT_NONE:
+            dz = torch.empty_like(dh)
+            ws = torch.empty(int(lib.sg_bias_act_ws_bytes(N, Cout)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sg_bias_act_backward(N, Cout, ctx.act, _ptr(z), _ptr(ro) if ctx.has_ro else None, _ptr(dh),
+                                                    _ptr(ws), _ptr(dz), None, _stream(dev)), "bias/act backward")
+        else:
+            dz = dh
+        dx = torch.mm(dz, W) if ctx.needs_input_grad[0] else None
+        dW = db = None
+        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
+            # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
+            dW = torch.empty_like(W, dtype=torch.float32)
+            db = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b else None
+            ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
+                           "weight gradient")
+        return dx, dW, db, None, None
+
+
+def linear_act(x, lin, act=ACT_NONE, row_offset=None):
+    return _LinearAct.apply(x, lin.weight, lin.bias, act, row_offset)
+
+
+class AppearanceDecoder(nn.Module):
+    def __init__(self, n_features, hidden_dim=64, act='gelu', fixed_opacity=False):
+        super().__init__()
+        assert act == 'gelu', "the reference's default (and only configured) activation"
+        self.hidden_dim = hidden_dim
+        self.net = nn.Sequential(nn.Linear(n_features, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU())
+        if not fixed_opacity:
+            self.opacity = nn.Linear(hidden_dim, 1)
+            self.opacity_act = nn.Sigmoid()
+            self.opacity_offset = 0
+        self.fixed_opacity = fixed_opacity
+        self.shs = nn.Linear(hidden_dim, 16 * 3)
+
+    def _trunk(self, x):
+        return linear_act(linear_act(x, self.net[0], ACT_GELU), self.net[2], ACT_GELU)
+
+    def reset_opacity(self, x):
+        with torch.no_grad():
+            o = linear_act(self._trunk(x), self.opacity)
+            self.opacity_offset = torch.where(o > 0, torch.zeros_like(o), -o)
+
+    def forward(self, x):
+        x = self._trunk(x)
+        shs = linear_act(x, self.shs).reshape(-1, 16, 3)
+        if not self.fixed_opacity:
+            off = self.opacity_offset if torch.is_tensor(self.opacity_offset) else None
+            opacity = linear_act(x, self.opacity, ACT_SIGMOID, off)
+        else:
+            opacity = torch.ones((x.shape[0], 1), device=x.device)
+        return {'shs': shs, 'opacity': opacity}
+
+
+class GeometryDecoder(nn.Module):
+    def __init__(self, n_features, isotropic=True, hidden_dim=128, act='gelu'):
+        super().__init__()
+        assert act == 'gelu'
+        self.hidden_dim, self.isotropic = hidden_dim, isotropic
+        self.net = nn.Sequential(nn.Linear(n_features, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, hidden_dim), nn.GELU())
+        self.xyz_offsets = nn.Linear(hidden_dim, 3)
+        if not isotropic:
+            self.rotations = nn.Sequential(nn.Linear(hidden_dim, 6))
+        self.scales = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, 1 if isotropic else 3))
+
+    def forward(self, x):
+        x = linear_act(linear_act(x, self.net[0], ACT_GELU), self.net[2], ACT_GELU)
+        xyz_offsets = linear_act(x, self.xyz_offsets)
+        rotations = linear_act(x, self.rotations[0]) if not self.isotropic else None
+        s1 = linear_act(x, self.scales[0], ACT_GELU)
+        scales_aux = linear_act(s1, self.scales[2])
+        # scales = log(exp(scales_aux) + 1): the activation kernel on the bias-added value (identity GEMM avoided)
+        scales = _Act.apply(scales_aux, ACT_SOFTPLUS_REF)
+        if scales_aux.shape[-1] == 1:
+            scales_aux = scales_aux.repeat(1, 3)
+            scales = scales.repeat(1, 3)
+        return {'xyz_offsets': xyz_offsets, 'rotations': rotations, 'scales': scales, 'scales_aux': scales_aux}
+
+
+class _Act(torch.autograd.Function):
+    """element-wise activation through the same kernels (no bias)."""
+
+    @staticmethod
+    def forward(ctx, z, act):
+        lib = _lib.load()
+        z = z.contiguous().float()
+        dev, N, Cc = z.device, int(z.shape[0]), int(z.shape[1])
+        h = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_bias_act_forward(N, Cc, act, _ptr(z), None, None, None, _ptr(h), _stream(dev)), "act forward")
+        ctx.save_for_backward(z)
+        ctx.act = act
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        dev, N, Cc = z.device, int(z.shape[0]), int(z.shape[1])
+        dh = dh.contiguous().float()
+        dz = torch.empty_like(dh)
+        ws = torch.empty(int(lib.sg_bias_act_ws_bytes(N, Cc)), dtype=torch.uint8, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_bias_act_backward(N, Cc, ctx.act, _ptr(z), None, _ptr(dh), _ptr(ws), _ptr(dz), None, _stream(dev)),
+                       "act backward")
+        return dz, None
+
+
+def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_factor=1.0, scaling_multiplier=None):
+    """SinGS.get_gs_attrs for one level (sings_hybrid.py:249-313): the dict the LBS/render path consumes."""
+    tri_feats = triplane(xyz)
+    g = geometry_dec(tri_feats)
+    a = appearance_dec(tri_feats)
+    scales = g['scales']
+    if thickness_factor != 1.0:
+        scales = torch.cat([scales[:, :-1], scales[:, -1:] * thickness_factor], dim=1)
+    if scaling_multiplier is not None:
+        scales = scales * scaling_multiplier
+    return {"xyz_canon": xyz + g['xyz_offsets'], "xyz_offsets": g['xyz_offsets'], "rot6d_canon": g['rotations'],
+            "scales_aux": g['scales_aux'], "scales": scales, "opacity": a['opacity'], "shs": a['shs']}

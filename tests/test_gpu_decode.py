@@ -1,0 +1,121 @@
+"""GPU parity of the attribute decode (tri-plane kernels + bias/activation kernels through the C ABI, library GEMMs)
+with golden vectors produced by the reference's modules and with the CPU oracle at the shipped plane configuration.
+Tolerances: fp32 with a different summation order (GEMM blocking, atomics) -> 2e-5 relative + 2e-6 of the scale."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_oracle as do
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "decode_golden.npz"))
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, b, rtol=2e-5, atol_scale=2e-6, atol=0.0, what=""):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    scale = np.abs(b).max() + 1e-30
+    err = np.abs(a - b)
+    assert (err <= rtol * np.abs(b) + atol_scale * scale + atol).all(), (what, err.max(), scale)
+
+
+def _field(dev):
+    from sings_amd.decode import HexPlaneField
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32,
+           'resolution': [int(r) for r in G["tp_res"]], 'multires': [int(m) for m in G["tp_multires"]]}
+    f = HexPlaneField(cfg, device=dev)
+    sd = {f"grids.{s}.{c}": torch.from_numpy(G[f"tp_plane_{s}_{c}"]) for s in range(len(cfg['multires'])) for c in range(3)}
+    f.set_aabb(G["tp_aabb"][0].tolist(), G["tp_aabb"][1].tolist())      # (makes aabb a state_dict entry, as in the reference)
+    sd["aabb"] = torch.from_numpy(G["tp_aabb"])
+    f.load_state_dict(sd)                                     # the reference's parameter names
+    return f.to(dev)
+
+
+def test_triplane_golden_forward_backward():
+    dev = _dev()
+    f = _field(dev)
+    pts = torch.from_numpy(G["tp_pts"]).to(dev).requires_grad_(True)
+    feats = f(pts)
+    _close(feats.detach().cpu().numpy(), G["tp_feats"])
+    (feats * torch.from_numpy(G["tp_w"]).to(dev)).sum().backward()
+    _close(pts.grad.cpu().numpy(), G["tp_dpts"])
+    for s, gp in enumerate(f.grids):
+        for c, p in enumerate(gp):
+            _close(p.grad.cpu().numpy(), G[f"tp_dplane_{s}_{c}"])
+
+
+def test_decoders_golden_forward_backward():
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder
+    dev = _dev()
+    N = G["geo_iso_x"].shape[0]
+    for tag, iso in (("iso", True), ("aniso", False)):
+        g = GeometryDecoder(n_features=64, isotropic=iso)
+        g.load_state_dict({k[len(f"geo_{tag}_p_"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith(f"geo_{tag}_p_")})
+        g = g.to(dev)
+        x = torch.from_numpy(G[f"geo_{tag}_x"]).to(dev).requires_grad_(True)
+        o = g(x)
+        for k in ('xyz_offsets', 'scales', 'scales_aux') + (() if iso else ('rotations',)):
+            _close(o[k].detach().cpu().numpy(), G[f"geo_{tag}_o_{k}"])
+        loss = (o['xyz_offsets'] * 1.3).sum() + (o['scales'] ** 2).sum() + o['scales_aux'].sum() * 0.1
+        if not iso:
+            loss = loss + (o['rotations'] * 0.7).sum()
+        loss.backward()
+        _close(x.grad.cpu().numpy(), G[f"geo_{tag}_dx"], what=f"geo {tag} dx")
+        for k, p in g.named_parameters():
+            _close(p.grad.cpu().numpy(), G[f"geo_{tag}_g_{k}"], atol_scale=2e-5, atol=2e-5, what=f"geo {tag} {k}")
+            # (parameter gradients are cancelling sums over the N = 700 points of terms of magnitude <= ~1: fp32 sum noise
+            #  ~1e-5 absolute in the reference's own result as well)
+    a = AppearanceDecoder(n_features=64)
+    a.load_state_dict({k[len("app_p_"):]: torch.from_numpy(G[k]) for k in G.files if k.startswith("app_p_")})
+    a = a.to(dev)
+    x = torch.from_numpy(G["geo_aniso_x"]).to(dev).requires_grad_(True)
+    a.reset_opacity(x.detach())
+    _close(a.opacity_offset.cpu().numpy(), G["app_offset"], atol_scale=5e-6)
+    a.opacity_offset = torch.from_numpy(G["app_offset"]).to(dev)        # identical offsets for the comparison below
+    o = a(x)
+    _close(o['shs'].detach().cpu().numpy(), G["app_o_shs"])
+    _close(o['opacity'].detach().cpu().numpy(), G["app_o_opacity"])
+    ((o['shs'] ** 2).sum() * 0.5 + (o['opacity'] * torch.linspace(-1, 1, N, device=dev)[:, None]).sum()).backward()
+    _close(x.grad.cpu().numpy(), G["app_dx"])
+    for k, p in a.named_parameters():
+        _close(p.grad.cpu().numpy(), G[f"app_g_{k}"], atol_scale=2e-5, atol=2e-5, what=f"app {k}")
+
+
+def test_shipped_config_vs_oracle_and_decode_attributes():
+    """kplanes of human_complex.yaml (32 features, 64^3, multires 1/2/4), 20 k points: features and all gradients vs the
+    CPU oracle; decode_attributes returns the keys of SinGS.get_gs_attrs."""
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField, decode_attributes
+    dev = _dev()
+    torch.manual_seed(0)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [64, 64, 64], 'multires': [1, 2, 4]}
+    f = HexPlaneField(cfg, device=dev)
+    N = 20000
+    pts_c = (torch.rand(N, 3) * 1.9 - 0.95)
+    w_c = torch.randn(N, 96)
+    pts = pts_c.to(dev).requires_grad_(True)
+    feats = f(pts)
+    (feats * w_c.to(dev)).sum().backward()
+    grids_c = [[p.detach().cpu().clone().requires_grad_(True) for p in gp] for gp in f.grids]
+    pc = pts_c.clone().requires_grad_(True)
+    fo = do.triplane_features(pc, grids_c, f.aabb.detach().cpu())
+    (fo * w_c).sum().backward()
+    _close(feats.detach().cpu().numpy(), fo.detach().numpy())
+    _close(pts.grad.cpu().numpy(), pc.grad.numpy(), rtol=1e-4, atol_scale=1e-5)
+    for gp, gc in zip(f.grids, grids_c):
+        for p, q in zip(gp, gc):
+            _close(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-4, atol_scale=1e-5)
+    g = GeometryDecoder(96).to(dev); a = AppearanceDecoder(96).to(dev)
+    out = decode_attributes(pts.detach(), f, g, a, thickness_factor=0.5, scaling_multiplier=torch.full((N, 1), 2.0, device=dev))
+    assert set(out) == {"xyz_canon", "xyz_offsets", "rot6d_canon", "scales_aux", "scales", "opacity", "shs"}
+    assert out["shs"].shape == (N, 16, 3) and out["opacity"].shape == (N, 1) and out["scales"].shape == (N, 3)
+    sd_g = {k: v.detach().cpu() for k, v in g.state_dict().items()}
+    og = do.geometry_decoder(fo.detach(), sd_g)
+    ref_scales = og['scales'].clone(); ref_scales[:, -1] *= 0.5; ref_scales = ref_scales * 2.0
+    _close(out["scales"].detach().cpu().numpy(), ref_scales.numpy(), rtol=1e-4, atol_scale=1e-5)
+    _close(out["xyz_canon"].detach().cpu().numpy(), (pts_c + og['xyz_offsets']).numpy(), rtol=1e-4, atol_scale=1e-5)
