@@ -57,12 +57,14 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=("raster", "avatar"), default="raster",
+    ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
     a = ap.parse_args()
     if a.workload == "avatar":
         return main_avatar(a)
+    if a.workload == "train":
+        return main_train(a)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -219,6 +221,92 @@ def _dist_setup():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     return rank, world, dev, dist
+
+
+def main_train(a):
+    """Extra workload: ONE COMPLETE training step of an avatar through autograd -- tri-plane + decoder decode of all
+    Gaussians, fused LBS + raster forward, clamp + L1 + SSIM, L2Norm + Gaussian edge regularisers, backward through all
+    of it to the planes / decoder weights / anchors (SURVEY.md 3.1 without optimiser and densification)."""
+    import math
+    rank, world, dev, dist = _dist_setup()
+    from sings_amd.body import joint_transforms
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.dp import FrameSharder
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm
+    from sings_amd.scene import avatar_scene
+    from sings_amd.train_step import AvatarStep
+    N = a.gaussians if a.gaussians != 200000 else 150000
+    s = avatar_scene(N=N, J=52)
+    W, H, J = s["W"], s["H"], s["J"]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    cam = s["cam"]
+    rs = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    poses72 = np.load(os.path.join(ROOT, "tests", "golden", "lbs_golden.npz"))["amass_poses_72"]
+    F = poses72.shape[0]
+    poses = np.zeros((F, J * 3), np.float32); poses[:, :72] = poses72; poses[:, :3] = 0
+    jr = t(s["joints_rest"])
+    A_all = torch.stack([joint_transforms(t(poses[f]), jr, tuple(s["parents"])) for f in range(F)]).reshape(F, J, 4, 4).contiguous()
+    torch.manual_seed(0)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [64, 64, 64],
+           'multires': [1, 2, 4]}                                              # human_complex.yaml:38-43
+    tri = HexPlaneField(cfg, bounds=1.2, device=dev); geo = GeometryDecoder(96).to(dev); app = AppearanceDecoder(96).to(dev)
+    with torch.no_grad():                                                      # millimetre-sized splats, tiny offsets
+        geo.scales[2].bias.fill_(-5.3); geo.scales[2].weight.mul_(0.1)
+        geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()
+    step_mod = AvatarStep(t(s["xyz_canon"]), t(s["lbs_weights"]), tri, geo, app, l2_norm=L2Norm(),
+                          gaussian_connect=GaussiansEdgeLoss(), gaussian_connect_w=1.0).to(dev)
+    params = [p for p in step_mod.parameters() if p.requires_grad]
+    gt_rgb = torch.rand((3, H, W), device=dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
+    mask = ((((xx - W / 2) / (W / 4)) ** 2 + ((yy - H / 2) / (H / 2.2)) ** 2) < 1).float().contiguous()
+    bg_t, smpl_scale, transl = t(s["bg"]), t(s["smpl_scale"]), t(s["transl"])
+    shard = FrameSharder(F, world, rank, seed=0)
+
+    def step(i):
+        for p in params:
+            p.grad = None
+        loss, ld, ex = step_mod(A_all[shard.frame(i)], rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
+        loss.backward()
+        if dist is not None:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+        return ld
+
+    for i in range(a.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        ld = step(a.warmup + i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    if rank == 0:
+        nparam = sum(p.numel() for p in params)
+        print(json.dumps({
+            "metric": "full train-step views/sec (decode + LBS-fused raster + L1/SSIM + regularisers, fwd+bwd), avatar ~150k Gaussians",
+            "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H}, tri-plane 32 x (64,128,256)^2 x 3, decoders 96-128-128 / "
+                                   f"96-64-64, SH deg 0, {F} AMASS frames, no optimiser step, frame-parallel dp{world}",
+                       "gaussians": N, "trainable_parameters": nparam, "parallelism": f"dp{world}"},
+            "losses": {k: float(v.detach()) for k, v in ld.items()}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
 
 
 def main_avatar(a):

@@ -46,3 +46,13 @@ def joint_transforms(pose, joints_rest, parents=SMPL_PARENTS):
 def cano_to_pose(A_t2pose, A_t2cano):
     """A_cano2pose = A_t2pose @ inverse(A_t2cano)  (sings_hybrid.py:398-399, get_canonical_verts :578-596)."""
     return A_t2pose @ torch.inverse(A_t2cano)
+
+
+def rotation_6d_to_matrix(d6):
+    """sings/rec/utils/geometry/rotations.py:545-566 (Zhou et al. 6-D rotation): Gram-Schmidt of the two 3-vectors."""
+    a1, a2 = d6[..., :3], d6[..., 3:]
+    b1 = torch.nn.functional.normalize(a1, dim=-1)
+    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
+    b2 = torch.nn.functional.normalize(b2, dim=-1)
+    b3 = torch.cross(b1, b2, dim=-1)
+    return torch.stack((b1, b2, b3), dim=-2)

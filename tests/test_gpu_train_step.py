@@ -1,0 +1,101 @@
+"""End to end on the GPU: parameters -> tri-plane decode -> fused LBS + raster -> clamp + L1 + SSIM -> backward, against
+the same chain assembled from the CPU oracles (decode_oracle -> lbs_oracle.deform_gaussians -> raster oracle (C) ->
+photo_loss_oracle, gradients carried back by torch autograd and the oracle's explicit rasterizer backward).
+
+Every oracle is pinned separately; this test checks that the pieces compose -- data layouts between the stages, the
+unclamped image feeding the loss, gradient hand-over from the composite to LBS^T to the decoders and planes."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decode_oracle as do
+from oracle import lbs_oracle as lo
+from oracle import photo_loss_oracle as plo
+from oracle import raster_oracle as ro
+from sings_amd.camera import make_camera
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_step_matches_oracle_chain():
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.train_step import AvatarStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    rs = np.random.RandomState(3)
+    N, J, W, H = 1500, 24, 160, 144
+    xyz = (rs.normal(0, 0.3, (N, 3)) * np.array([0.5, 1.0, 0.3])).astype(np.float32)
+    A = np.tile(np.eye(4, dtype=np.float32), (J, 1, 1))
+    for j in range(J):
+        A[j, :3, :3] = lo.batch_rodrigues(torch.from_numpy(rs.normal(0, 0.25, (1, 3)).astype(np.float32))).numpy()[0]
+        A[j, :3, 3] = rs.normal(0, 0.04, 3)
+    w = rs.rand(N, J).astype(np.float32) ** 6
+    w[np.arange(N), rs.randint(0, J, N)] += 0.3
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    cam = make_camera(np.eye(4, dtype=np.float32), 900.0, 900.0, W / 2, H / 2, W, H)
+    transl = np.array([0.02, -0.05, 4.0], np.float32); smpl_scale = np.array([1.05], np.float32)
+    bg = np.array([0.3, 0.5, 0.2], np.float32)
+    gt = rs.uniform(0, 1, (3, H, W)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    mask = ((((xx - W / 2) / (W / 3)) ** 2 + ((yy - H / 2) / (H / 2.4)) ** 2) < 1).astype(np.float32)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [16, 16, 16], 'multires': [1, 2]}
+    tri = HexPlaneField(cfg, device=dev); geo = GeometryDecoder(64).to(dev); app = AppearanceDecoder(64).to(dev)
+    with torch.no_grad():                                       # visible splats: larger scales, moderate opacity, small offsets
+        geo.scales[2].bias.fill_(-3.6); geo.xyz_offsets.weight.mul_(0.05); geo.xyz_offsets.bias.mul_(0.05)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    step = AvatarStep(t(xyz), t(w), tri, geo, app).to(dev)
+    rset = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(bg),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    A_g = t(A).requires_grad_(True)
+    loss, ld, ex = step(A_g, rset, t(gt), t(mask), t(bg), smpl_scale=t(smpl_scale), transl=t(transl))
+    loss.backward()
+
+    # ---- the same chain from the oracles (CPU)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+    xyz_c = T(xyz).requires_grad_(True); A_c = T(A).requires_grad_(True)
+    grids = [[p.detach().cpu().clone().requires_grad_(True) for p in gp] for gp in tri.grids]
+    sdg = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in geo.named_parameters()}
+    sda = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in app.named_parameters()}
+    feats = do.triplane_features(xyz_c, grids, tri.aabb.detach().cpu())
+    og = do.geometry_decoder(feats, sdg); oa = do.appearance_decoder(feats, sda)
+    xyz_canon = xyz_c + og['xyz_offsets']
+    posed = lo.deform_gaussians(xyz_canon, torch.eye(3)[None].repeat(N, 1, 1), og['scales'], T(w), A_c, smpl_scale=T(smpl_scale),
+                                transl=T(transl))
+    pxyz, prot, psc, _ = posed
+    o = ro.forward(pxyz.detach().numpy(), oa['opacity'].detach().numpy(), cam["world_view_transform"], cam["full_proj_transform"],
+                   cam["camera_center"], W, H, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), bg,
+                   scales=psc.detach().numpy(), rotations=prot.detach().numpy(), shs=oa['shs'].detach().numpy(), sh_degree=0)
+    assert o["R"] > 3000 and (o["radii"] > 0).mean() > 0.8            # the scene actually renders
+    img = T(o["color"]).requires_grad_(True)
+    pl = plo.photometric_loss(img, T(gt), T(mask), T(bg), 0.8, 0.2)
+    loss_c = pl["l1"] + pl["ssim"]
+    loss_c.backward()
+    g = ro.backward(o, img.grad.numpy())
+    torch.autograd.backward([pxyz, psc, prot, oa['opacity'], oa['shs']],
+                            [T(g["dL_dmeans3D"]), T(g["dL_dscales"]), T(g["dL_drots"]), T(g["dL_dopacity"]).reshape(N, 1),
+                             T(g["dL_dsh"]).reshape(N, 16, 3)])
+    # ---- compare
+    strict = o["margin"] >= 2e-5
+    assert np.abs(ex["render_raw"].detach().cpu().numpy() - o["color"]).max(0)[strict].max() <= 2e-5
+    assert abs(loss.item() - loss_c.item()) <= 2e-5 * abs(loss_c.item())
+
+    def close(name, a, b, frac=0.999):
+        a = a.detach().cpu().numpy().astype(np.float64).ravel(); b = b.detach().numpy().astype(np.float64).ravel()
+        scale = np.abs(b).max() + 1e-30
+        ok = np.abs(a - b) <= 2e-3 * np.abs(b) + 2e-4 * scale
+        assert ok.mean() >= frac, (name, ok.mean(), np.abs(a - b).max(), scale)
+
+    close("xyz anchors", step.xyz.grad, xyz_c.grad)
+    close("A", A_g.grad, A_c.grad)
+    for (k, p) in geo.named_parameters():
+        close("geo " + k, p.grad, sdg[k].grad)
+    for (k, p) in app.named_parameters():
+        close("app " + k, p.grad, sda[k].grad)
+    for gp, gc in zip(tri.grids, grids):
+        for p, q in zip(gp, gc):
+            close("plane", p.grad, q.grad)
