@@ -387,15 +387,17 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     if (half == 0) bpartial[(size_t)blockIdx.x * cout_pad + o] = bsum;
 }
 
-// 64 output elements per workgroup, the per-workgroup partials split over 4 waves (fixed slices, fixed order)
+// 16 output elements x 16 slices of the per-workgroup partials per 256-thread workgroup (fixed slices, fixed order):
+// the sum over <= 256 partials is latency-bound, so it is spread over many short chains
 __global__ void __launch_bounds__(256)
 sg_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bpartial, int nwg, int Cout, int Cin,
                        int cout_pad, float *__restrict__ dW, float *__restrict__ db)
 {
-    __shared__ float sS[4][64];
-    const int e = blockIdx.x * 64 + (threadIdx.x & 63), sl = threadIdx.x >> 6;
+    __shared__ float sS[16][17];
+    const int el = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
     const int total = Cout * Cin;
-    const int per = (nwg + 3) / 4, w0 = sl * per, w1 = min(w0 + per, nwg);
+    const int per = (nwg + 15) / 16, w0 = sl * per, w1 = min(w0 + per, nwg);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     if (e < total) {
         const int o = e / Cin, c = e - o * Cin;
@@ -408,10 +410,12 @@ sg_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restric
         const int o = e - total;
         for (int w = w0; w < w1; w++) s0 += bpartial[(size_t)w * cout_pad + o];
     }
-    sS[sl][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+    sS[sl][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (sl == 0) {
-        const float t = (sS[0][threadIdx.x] + sS[1][threadIdx.x]) + (sS[2][threadIdx.x] + sS[3][threadIdx.x]);
+        float t = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 16; q++) t += sS[q][el];
         if (e < total) dW[e] = t;
         else if (db && e < total + Cout) db[e - total] = t;
     }
@@ -433,7 +437,7 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
 #define SG_WGK(T) hipLaunchKernelGGL(sg_wgrad_kernel<T>, dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
     switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
 #undef SG_WGK
-    hipLaunchKernelGGL(sg_wgrad_reduce_kernel, dim3((Cout * Cin + Cout + 63) / 64), dim3(256), 0, st, partial, bpartial, nwg,
+    hipLaunchKernelGGL(sg_wgrad_reduce_kernel, dim3((Cout * Cin + Cout + 15) / 16), dim3(256), 0, st, partial, bpartial, nwg,
                        Cout, Cin, cp, dW, db);
     return 0;
 }
