@@ -34,7 +34,13 @@ __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f
 __device__ __forceinline__ int sg_tile_of_block(int block)
 {
     const int xcd = block & 7, slot = block >> 3;
-    return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + slot % SG_XCD_RUN;
+    // Workgroups of one XCD go round its 32 CUs (measured with s_getreg HW_ID: a CU receives blocks b, b + 256, ...), so
+    // without the skew a CU always gets the same position of the run -- the same image column when the image is 32
+    // tiles wide -- and the CUs that own an avatar's body columns carry 2.6x the mean load.  (slot / 32) * 7 walks the
+    // position through the run from one visit of a CU to the next (max/mean load 1.6).  The avatar forward itself is
+    // bound by its longest tile (39 serial batches), not by this; see DESIGN.md.
+    const int within = (slot + 7 * (slot >> 5)) & (SG_XCD_RUN - 1);
+    return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + within;
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
