@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: collects the rocprofv3 summaries that profiles/ keeps.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01b'
+#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01c'
 # rocprofv3 gets `python3 <script>` directly after `--` (no wrappers), counters in their own passes.
 set -u
-TAG=${1:-r01b}
+TAG=${1:-r01c}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
