@@ -342,38 +342,73 @@ __global__ void __launch_bounds__(256)
 sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
                 float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad)
 {
+    // the four waves need the same 16 rows of x per round: they go through LDS once (double-buffered, one barrier per
+    // round) instead of being read from L2/HBM by every wave (4x the traffic made the direct version bandwidth-bound)
+    __shared__ float sX[2][16][TI * 32 + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    if (32 * wave >= cout_pad) return;
+    const bool active = 32 * wave < cout_pad;
     const int o = 32 * wave + (lane & 31), half = lane >> 5;
-    const bool ok_o = o < Cout;
+    const bool ok_o = active && o < Cout;
+    constexpr int CIN = TI * 32;
+    constexpr int F4 = 16 * CIN / 4;                 // float4 elements of one 16-row slab
+    constexpr int PER = (F4 + 255) / 256;            // per thread
     sg_v16f acc[TI];
 #pragma unroll
     for (int t = 0; t < TI; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
     float bsum = 0.0f;
-    // workgroup b takes the row slices b, b + gridDim.x, ... ; 8 k-steps (16 rows) per round: all 8 * (1 + TI) loads
-    // are issued before the first MFMA needs one of them
+    (void)Cin;
     for (int r0 = blockIdx.x * SG_WG_ROWS; r0 < N; r0 += gridDim.x * SG_WG_ROWS) {
-    const int r1 = min(r0 + SG_WG_ROWS, N);
-    for (int n = r0; n < r1; n += 16) {
-        float a[8], b[8][TI];
+        const int r1 = min(r0 + SG_WG_ROWS, N);
+        float4 xr[PER];
+        auto fetch = [&](int n) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            const int row = n + 2 * u + half;
-            const bool ok = row < r1;
-            a[u] = ok && ok_o ? dz[(size_t)row * Cout + o] : 0.0f;
+            for (int q = 0; q < PER; q++) {
+                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
+                xr[q] = (f < F4 && n + row < r1) ? *(const float4 *)(x + (size_t)(n + row) * CIN + 4 * c4) : make_float4(0, 0, 0, 0);
+            }
+        };
+        auto stash = [&](int buf) {
 #pragma unroll
-            for (int t = 0; t < TI; t++) b[u][t] = ok ? x[(size_t)row * Cin + 32 * t + (lane & 31)] : 0.0f;
-        }
+            for (int q = 0; q < PER; q++) {
+                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
+                if (f < F4) *(float4 *)&sX[buf][row][4 * c4] = xr[q];
+            }
+        };
+        float an[8];
+        auto fetch_a = [&](int n) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
-            bsum += a[u];
+            for (int u = 0; u < 8; u++) {
+                const int row = n + 2 * u + half;
+                an[u] = (ok_o && row < r1) ? dz[(size_t)row * Cout + o] : 0.0f;
+            }
+        };
+        fetch(r0);
+        fetch_a(r0);
+        __syncthreads();                             // previous slice's last round is consumed
+        stash(0);
+        __syncthreads();
+        int buf = 0;
+        for (int n = r0; n < r1; n += 16, buf ^= 1) {
+            float a[8];
 #pragma unroll
-            for (int t = 0; t < TI; t++) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+            for (int u = 0; u < 8; u++) a[u] = an[u];
+            if (n + 16 < r1) { fetch(n + 16); fetch_a(n + 16); }      // next round's operands are in flight during the MFMAs
+            if (active) {
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    bsum += a[u];
+#pragma unroll
+                    for (int t = 0; t < TI; t++)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
+                }
+            }
+            if (n + 16 < r1) stash(buf ^ 1);
+            __syncthreads();
         }
     }
-    }
+    if (!active) return;
     // D layout of the 32x32 tile: lane l, register r -> row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32
     float *pw = partial + (size_t)blockIdx.x * cout_pad * Cin;
 #pragma unroll
