@@ -57,6 +57,8 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
+    ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=1,
                     help="raster workload: views each rank renders (gradients accumulated locally) per all-reduce; 1 = the "
                          "reference's one frame per rank and step (default).  k > 1 amortises the 47 MB all-reduce")
@@ -123,10 +125,16 @@ def main():
     k_views = max(1, a.views_per_step)
     acc = torch.zeros_like(eng.grad_flat) if k_views > 1 else None
 
+    graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
+
     def step():
         for v in range(k_views):
-            eng.forward(means3D, shs, opac, scales, rots)
-            eng.backward(means3D, shs, opac, scales, rots, dL)
+            if graph is not None:
+                graph.replay()
+            else:
+                eng.forward(means3D, shs, opac, scales, rots)
+                if not a.forward_only:
+                    eng.backward(means3D, shs, opac, scales, rots, dL)
             if acc is not None:
                 if v == 0:
                     acc.copy_(eng.grad_flat)
@@ -160,7 +168,8 @@ def main():
     lib.sg_profile_enable(1)
     for _ in range(a.steps):
         eng.forward(means3D, shs, opac, scales, rots)
-        eng.backward(means3D, shs, opac, scales, rots, dL)
+        if not a.forward_only:
+            eng.backward(means3D, shs, opac, scales, rots, dL)
     ms = (C.c_double * _lib.NUM_KERNELS)()
     cnt = (C.c_int64 * _lib.NUM_KERNELS)()
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
@@ -173,6 +182,8 @@ def main():
         return
 
     per, total_bytes = algorithmic_bytes(N, H, W, R, deg)
+    if a.forward_only:                                          # B_f = N (in + 4 + 2 rec) + HW 12 + R 16
+        total_bytes = N * (44 + 12 * (deg + 1) ** 2 + 4 + 2 * 75) + H * W * 12 + R * 16
     dom = max(("sg_preprocess_fwd_kernel", "sg_render_fwd_kernel", "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel"),
               key=lambda k: kern[k])
     achieved = per[dom] / (kern[dom] * 1e-3) / 1e9
@@ -186,13 +197,15 @@ def main():
     ms_per_step = el / a.steps * 1e3
     views_s = world * a.steps * k_views / el
     out = {
-        "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p",
+        "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
+                  else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
         "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, fwd+bwd, "
                                f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "views_per_step": k_views,
+                   "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

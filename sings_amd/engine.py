@@ -74,6 +74,27 @@ class RasterEngine:
         _lib.check(self.lib.sg_read_num_rendered(_ptr(self.binning), C.byref(nr), self._stream()), "read R")
         return int(nr.value)
 
+    def capture(self, means3D, shs, opacities, scales, rotations, dL_dcolor=None):
+        """Record one step (forward, + backward when dL_dcolor is given) into a HIP graph and return it; ``graph.replay()``
+        re-runs the whole launch sequence with one host call.  Possible because nothing in a step synchronises or
+        allocates: every buffer (inputs included -- update them IN PLACE between replays) is fixed, the camera is read
+        from device memory.  Pays off when the step is launch-bound (small scenes, forward-only animation)."""
+        torch.cuda.synchronize(self.dev)
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):                            # warm-up on the capture stream
+            self.forward(means3D, shs, opacities, scales, rotations)
+            if dL_dcolor is not None:
+                self.backward(means3D, shs, opacities, scales, rotations, dL_dcolor)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.forward(means3D, shs, opacities, scales, rotations)
+            if dL_dcolor is not None:
+                self.backward(means3D, shs, opacities, scales, rotations, dL_dcolor)
+        return g
+
 
 class SkinnedEngine:
     """Same idea for the LBS-fused path (sg_skinned_forward / backward): canonical Gaussians + per-frame joint
