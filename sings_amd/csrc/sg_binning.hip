@@ -22,7 +22,7 @@
 
 // Exclusive scans over the T tile counts of
 //   q0 pairs (-> ranges, per-counter cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
-// Workgroup b owns tiles [b * 1024 * tpt, (b + 1) * 1024 * tpt), one tile per thread and round.  Instead of a second
+// Workgroup b owns tiles [b * SG_SCAN_BS * tpt, (b + 1) * SG_SCAN_BS * tpt), one tile per thread and round.  Instead of a second
 // kernel (or a look-back chain) every workgroup first REDUCES the counts of all tiles in front of its range itself:
 // at most T words per workgroup, coalesced and L2-resident.  The kernel is a handful of waves that start with a cold
 // instruction cache, so its loops are deliberately NOT unrolled: the fully unrolled version (1200 instructions of
@@ -30,6 +30,8 @@
 // The work lists themselves are written by the (chip-wide) scatter kernel from the per-tile
 // `plan` = (first backward item, first sort item, first rank item, pair count).  K = sub-counters per tile.
 #define SG_SCAN_NQ 5
+// BS = threads (= tiles per round) of a scan workgroup: 256 for images of few tiles (several CUs even at 1000 tiles),
+// 1024 for many tiles (fewer workgroups re-reducing the counts in front of them)
 __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ])
 {
     const uint32_t seg = sg_nseg(v);
@@ -37,21 +39,21 @@ __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ
     q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = nch; q[4] = nch > 1 ? nch : 0u;
 }
 
-template <int K>
-__global__ void __launch_bounds__(1024)
+template <int K, int SG_SCAN_BS>
+__global__ void __launch_bounds__(SG_SCAN_BS)
 sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uint32_t tc_stride,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
                     uint32_t *__restrict__ ck_start, uint32_t items_cap)
 {
     constexpr int NQ = SG_SCAN_NQ;
-    __shared__ uint32_t wsum[NQ][16];
+    __shared__ uint32_t wsum[NQ][SG_SCAN_BS / 64];
     __shared__ uint32_t carry[NQ];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    const int first = blockIdx.x * 1024 * tpt;
+    const int first = blockIdx.x * SG_SCAN_BS * tpt;
     // ---- 1. totals of everything in front of this workgroup's range
     uint32_t acc[NQ] = { 0, 0, 0, 0, 0 };
-    for (int t = tid; t < first; t += 1024) {
+    for (int t = tid; t < first; t += SG_SCAN_BS) {
         uint32_t v = 0, q[NQ];
 #pragma unroll
         for (int sb = 0; sb < K; sb++) v += tile_count[((size_t)t * K + sb) * tc_stride];
@@ -72,13 +74,13 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uin
     if (tid < NQ) {
         uint32_t t = 0;
 #pragma unroll 1
-        for (int w = 0; w < 16; w++) t += wsum[tid][w];
+        for (int w = 0; w < SG_SCAN_BS / 64; w++) t += wsum[tid][w];
         carry[tid] = t;
     }
     __syncthreads();
-    // ---- 2. scan of the own range, 1024 tiles per round
+    // ---- 2. scan of the own range, SG_SCAN_BS tiles per round
     for (int r = 0; r < tpt; r++) {
-        const int tile = first + r * 1024 + tid;
+        const int tile = first + r * SG_SCAN_BS + tid;
         const bool ok = tile < T;
         uint32_t cnt[K], v = 0, q[NQ] = { 0, 0, 0, 0, 0 };
 #pragma unroll
@@ -105,7 +107,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uin
         for (int a = 0; a < NQ; a++) {
             uint32_t woff = 0, all = 0;
 #pragma unroll 1
-            for (int w = 0; w < 16; w++) { const uint32_t x = wsum[a][w]; woff += w < wid ? x : 0u; all += x; }
+            for (int w = 0; w < SG_SCAN_BS / 64; w++) { const uint32_t x = wsum[a][w]; woff += w < wid ? x : 0u; all += x; }
             st[a] = carry[a] + woff + incl[a] - q[a];
             tot[a] = carry[a] + all;
         }
@@ -333,13 +335,14 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     sg_prof_begin(SG_K_TILE_SCAN, st);
-    const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;       // at most 64 workgroups
-    const int sgrid0 = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
-#define SG_SCAN(KK) hipLaunchKernelGGL(sg_tile_scan_kernel<KK>, dim3(sgrid0), dim3(1024), 0, st, T, tpt, b.tile_count, b.tc_stride, \
+    const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;       // at most 64 (1024-thread) / 256 (256-thread) workgroups
+#define SG_SCAN_GRID(BS) ((T + (BS) * tpt - 1) / ((BS) * tpt) > 0 ? (T + (BS) * tpt - 1) / ((BS) * tpt) : 1)
+#define SG_SCAN(KK, BS) hipLaunchKernelGGL((sg_tile_scan_kernel<KK, BS>), dim3(SG_SCAN_GRID(BS)), dim3(BS), 0, st, T, tpt, b.tile_count, b.tc_stride, \
                                        b.ranges, b.cursor, b.header, cap32, sg_sort_items_cap(T, cap),                 \
                                        sg_rank_items_cap(cap), b.plan, b.ck_start, sg_items_cap(T, cap))
-    if (b.tc_sub == SG_TC_SUB_MAX) SG_SCAN(SG_TC_SUB_MAX); else SG_SCAN(1);
+    if (b.tc_sub == SG_TC_SUB_MAX) SG_SCAN(SG_TC_SUB_MAX, 256); else SG_SCAN(1, 1024);
 #undef SG_SCAN
+#undef SG_SCAN_GRID
     sg_prof_end(SG_K_TILE_SCAN, st);
     sg_prof_begin(SG_K_TILE_SCATTER, st);
     {
