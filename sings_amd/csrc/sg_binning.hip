@@ -202,19 +202,14 @@ __device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid)
 }
 
 
-// one wave per tile, 4 tiles per workgroup, no workgroup barriers
-__global__ void __launch_bounds__(256)
-sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t *__restrict__ pair_keys,
-                         uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+// lists of at most SG_WSORT_MAX entries: one wave per tile, bitonic in the wave's slice of LDS, no workgroup barriers
+__device__ __forceinline__ void sg_tile_sort_wave(int tile, uint64_t *__restrict__ s, int lane, const uint2 *__restrict__ ranges,
+                                                  const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
+                                                  uint64_t *__restrict__ point_keys)
 {
-    __shared__ uint64_t sall[4][SG_WSORT_MAX];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int tile = blockIdx.x * 4 + wave;
-    if (tile >= T) return;
     const uint2 r = ranges[tile];
     const int n = (int)(r.y - r.x);
     if (n == 0 || n > SG_WSORT_MAX) return;
-    uint64_t *s = sall[wave];
     int n2 = 1; while (n2 < n) n2 <<= 1;
     for (int i = lane; i < n2; i += 64) s[i] = i < n ? pair_keys[r.x + i] : ~0ull;
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -237,18 +232,24 @@ sg_tile_sort_wave_kernel(int T, const uint2 *__restrict__ ranges, const uint64_t
     }
 }
 
-// Long lists: one workgroup per work item (tile, chunk of SG_SORT_LDS entries), items written by the scan kernel.
-// A list of one chunk is sorted and written out; the chunks of a longer list are sorted in place and merged by
-// sg_tile_rank_kernel.
+// One launch for both kinds of list.  Workgroups [0, wave_blocks): 16 short lists each, one per wave (above).  The
+// others: one workgroup per work item (tile, chunk of SG_SORT_LDS entries) of the lists longer than SG_WSORT_MAX,
+// items written by the scatter kernel; a list of one chunk is sorted and written out, the chunks of a longer list are
+// sorted in place and merged by sg_tile_rank_kernel.
 __global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
+sg_tile_sort_kernel(int T, int wave_blocks, const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
                     const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
                     uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
 {
     __shared__ uint64_t s[SG_SORT_LDS];
     const int tid = threadIdx.x;
+    if ((int)blockIdx.x < wave_blocks) {
+        const int tile = blockIdx.x * (SG_SORT_THREADS / 64) + (tid >> 6);
+        if (tile < T) sg_tile_sort_wave(tile, s + (tid >> 6) * SG_WSORT_MAX, tid & 63, ranges, pair_keys, point_list, point_keys);
+        return;
+    }
     const uint32_t nitems = header[4];
-    for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
+    for (uint32_t li = blockIdx.x - wave_blocks; li < nitems; li += gridDim.x - wave_blocks) {
         const uint2 it = sort_items[li];
         const int tile = (int)it.x;
         const uint2 r = ranges[tile];
@@ -354,11 +355,11 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     }
     sg_prof_end(SG_K_TILE_SCATTER, st);
     sg_prof_begin(SG_K_TILE_SORT, st);
-    hipLaunchKernelGGL(sg_tile_sort_wave_kernel, dim3((T + 3) / 4), dim3(256), 0, st, T, b.ranges, b.pair_keys,
-                       b.point_list, pk);
+    static_assert(SG_WSORT_MAX * (SG_SORT_THREADS / 64) <= SG_SORT_LDS, "16 wave slices fit the sort buffer");
+    const int wave_blocks = (T + SG_SORT_THREADS / 64 - 1) / (SG_SORT_THREADS / 64);
     const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
-    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items,
-                       b.ranges, b.pair_keys, b.point_list, pk);
+    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(wave_blocks + sgrid), dim3(SG_SORT_THREADS), 0, st, T, wave_blocks, b.header,
+                       b.sort_items, b.ranges, b.pair_keys, b.point_list, pk);
     const uint32_t rgrid = sg_rank_items_cap(cap) < 128 ? sg_rank_items_cap(cap) : 128;
     hipLaunchKernelGGL(sg_tile_rank_kernel, dim3(rgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.rank_items,
                        b.ranges, b.pair_keys, b.point_list, pk);
