@@ -42,9 +42,9 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->geom_bytes = o;
     o = 0;
     L->bin_header = o; o = sg_align(o + 256);
-    L->bin_tile_count = o; o = sg_align(o + sg_tc_words(T) * 4);
+    L->bin_tile_count = o; o = sg_align(o + T * 4);
     L->bin_ranges = o; o = sg_align(o + T * 8);
-    L->bin_cursor = o; o = sg_align(o + T * 4 * SG_TC_SUB_MAX);
+    L->bin_cursor = o; o = sg_align(o + T * 4);
     L->bin_pair_keys = o; o = sg_align(o + (cap + 1) * 8);
     L->bin_point_list = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_point_keys = o; o = sg_align(o + (cap + 1) * 8);
@@ -101,10 +101,9 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     sg_layout(P, c.W, c.H, cap, &L);
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
-    b.tc_stride = sg_tc_stride((size_t)c.gx * c.gy); b.tc_sub = sg_tc_sub((size_t)c.gx * c.gy);
     SgImg im = sg_img_view(image_ws, L);
     // header + tile counters zeroed every call (stream-ordered)
-    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + sg_tc_words((size_t)c.gx * c.gy) * 4, st);
+    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     if (e != hipSuccess) return sg_fail("memset", e);
     sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
@@ -186,9 +185,8 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     sg_layout(P, c.W, c.H, cap, &L);
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
-    b.tc_stride = sg_tc_stride((size_t)c.gx * c.gy); b.tc_sub = sg_tc_sub((size_t)c.gx * c.gy);
     SgImg im = sg_img_view(image_ws, L);
-    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + sg_tc_words((size_t)c.gx * c.gy) * 4, st);
+    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     if (e != hipSuccess) return sg_fail("memset", e);
     sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);

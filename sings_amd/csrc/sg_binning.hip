@@ -26,9 +26,9 @@
 // kernel (or a look-back chain) every workgroup first REDUCES the counts of all tiles in front of its range itself:
 // at most T words per workgroup, coalesced and L2-resident.  The kernel is a handful of waves that start with a cold
 // instruction cache, so its loops are deliberately NOT unrolled: the fully unrolled version (1200 instructions of
-// straight-line code) took 22 us at 8160 tiles and 49 us with 8 sub-counters, this one 12 us / 23 us.
+// straight-line code) took 22 us at 8160 tiles, this one 12 us.
 // The work lists themselves are written by the (chip-wide) scatter kernel from the per-tile
-// `plan` = (first backward item, first sort item, first rank item, pair count).  K = sub-counters per tile.
+// `plan` = (first backward item, first sort item, first rank item, pair count).
 #define SG_SCAN_NQ 5
 // BS = threads (= tiles per round) of a scan workgroup: 256 for images of few tiles (several CUs even at 1000 tiles),
 // 1024 for many tiles (fewer workgroups re-reducing the counts in front of them)
@@ -39,9 +39,9 @@ __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ
     q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = nch; q[4] = nch > 1 ? nch : 0u;
 }
 
-template <int K, int SG_SCAN_BS>
+template <int SG_SCAN_BS>
 __global__ void __launch_bounds__(SG_SCAN_BS)
-sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uint32_t tc_stride,
+sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
                     uint32_t *__restrict__ ck_start, uint32_t items_cap)
@@ -54,9 +54,8 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uin
     // ---- 1. totals of everything in front of this workgroup's range
     uint32_t acc[NQ] = { 0, 0, 0, 0, 0 };
     for (int t = tid; t < first; t += SG_SCAN_BS) {
-        uint32_t v = 0, q[NQ];
-#pragma unroll
-        for (int sb = 0; sb < K; sb++) v += tile_count[((size_t)t * K + sb) * tc_stride];
+        uint32_t q[NQ];
+        const uint32_t v = tile_count[t];
         sg_scan_derive(v, q);
 #pragma unroll
         for (int a = 0; a < NQ; a++) acc[a] += q[a];
@@ -82,9 +81,8 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uin
     for (int r = 0; r < tpt; r++) {
         const int tile = first + r * SG_SCAN_BS + tid;
         const bool ok = tile < T;
-        uint32_t cnt[K], v = 0, q[NQ] = { 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int sb = 0; sb < K; sb++) { cnt[sb] = ok ? tile_count[((size_t)tile * K + sb) * tc_stride] : 0u; v += cnt[sb]; }
+        uint32_t q[NQ] = { 0, 0, 0, 0, 0 };
+        const uint32_t v = ok ? tile_count[tile] : 0u;
         if (ok) sg_scan_derive(v, q);
         uint32_t incl[NQ];
 #pragma unroll
@@ -114,9 +112,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count, uin
         if (ok) {
             const uint32_t s = st[0] < cap ? st[0] : cap, e = st[0] + v < cap ? st[0] + v : cap;
             ranges[tile] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
-            uint32_t cs = st[0];                          // sub-ranges of the tile, back to back
-#pragma unroll
-            for (int sb = 0; sb < K; sb++) { cursor[(size_t)tile * K + sb] = cs; cs += cnt[sb]; }
+            cursor[tile] = st[0];
             ck_start[tile] = q[2] ? st[2] : 0xffffffffu;
             plan[tile] = make_uint4(st[1], st[3], st[4], v);
         }
@@ -338,10 +334,10 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     sg_prof_begin(SG_K_TILE_SCAN, st);
     const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;       // at most 64 (1024-thread) / 256 (256-thread) workgroups
 #define SG_SCAN_GRID(BS) ((T + (BS) * tpt - 1) / ((BS) * tpt) > 0 ? (T + (BS) * tpt - 1) / ((BS) * tpt) : 1)
-#define SG_SCAN(KK, BS) hipLaunchKernelGGL((sg_tile_scan_kernel<KK, BS>), dim3(SG_SCAN_GRID(BS)), dim3(BS), 0, st, T, tpt, b.tile_count, b.tc_stride, \
+#define SG_SCAN(BS) hipLaunchKernelGGL((sg_tile_scan_kernel<BS>), dim3(SG_SCAN_GRID(BS)), dim3(BS), 0, st, T, tpt, b.tile_count, \
                                        b.ranges, b.cursor, b.header, cap32, sg_sort_items_cap(T, cap),                 \
                                        sg_rank_items_cap(cap), b.plan, b.ck_start, sg_items_cap(T, cap))
-    if (b.tc_sub == SG_TC_SUB_MAX) SG_SCAN(SG_TC_SUB_MAX, 256); else SG_SCAN(1, 1024);
+    if (T <= SG_HIST_TILES_MAX) SG_SCAN(256); else SG_SCAN(1024);
 #undef SG_SCAN
 #undef SG_SCAN_GRID
     sg_prof_end(SG_K_TILE_SCAN, st);

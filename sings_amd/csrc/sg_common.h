@@ -19,20 +19,14 @@ __host__ __device__ inline uint32_t sg_items_cap(size_t T, size_t cap) { size_t 
 __host__ __device__ inline uint32_t sg_sort_items_cap(size_t T, size_t cap) { size_t v = T + cap / 4096 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 __host__ __device__ inline uint32_t sg_rank_items_cap(size_t cap) { size_t v = cap / 2048 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (cap / SG_SEG) + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
-// Words between two tile counters.  Packed counters (stride 1) let one 64-lane atomic instruction touch few
-// lines (a Gaussian's tiles are neighbours) -- best when the image has many tiles and ~100 pairs per tile
-// (cfg3: 39 us vs 55 us padded).  With few tiles and thousands of pairs per tile (avatar close-ups: a row of 32
-// tiles shares one 128-B line) the returning atomics serialise in that line's L2 channel -- there one counter
-// per line wins (141 us vs 415 us).  The pair density is unknown before the pass, so the tile count decides.
-#define SG_TC_STRIDE_MAX 32
-static inline uint32_t sg_tc_stride(size_t T) { return T <= 4096 ? SG_TC_STRIDE_MAX : 1; }
-// In the few-tiles regime one tile can collect ~1e4 pairs, and a single counter word sustains only ~88 returning
-// atomics per microsecond (113 us for the heaviest avatar tile).  Each tile therefore gets SG_TC_SUB sub-counters
-// (own 128-B line each); workgroup b counts into sub-counter b % SG_TC_SUB.  The scan lays the sub-ranges of a tile
-// out back to back, so everything downstream sees one contiguous range per tile.
-#define SG_TC_SUB_MAX 8
-static inline uint32_t sg_tc_sub(size_t T) { return T <= 4096 ? SG_TC_SUB_MAX : 1; }
-static inline size_t sg_tc_words(size_t T) { return T * sg_tc_sub(T) * sg_tc_stride(T); }
+// Tile counters: one packed word per tile (a Gaussian's tiles are neighbours, so one 64-lane atomic instruction
+// touches few lines).  When the image has few tiles (<= SG_HIST_TILES_MAX) a single tile can collect ~1e4 pairs and a
+// counter word sustains only ~88 returning atomics per microsecond; there the preprocess kernels count a workgroup's
+// pairs per tile in an LDS histogram first and issue ONE global atomic per (workgroup, touched tile).  (Earlier
+// schemes for that regime -- one counter per 128-B line, then 8 sub-counters per tile -- took 141 / 80 us of
+// preprocess + 22 us of scan on the avatar frame; the histogram: 43 + 7 us.)
+#define SG_HIST_TILES_MAX 4096
+static inline bool sg_lds_hist(size_t T) { return T <= SG_HIST_TILES_MAX; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
@@ -44,15 +38,14 @@ struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vec
 
 struct SgBin {
     uint32_t *header;      // [0] R  [1] overflow  [2] pair allocator  [3] ntiles  [4] sort items  [5] backward work items  [6] rank items
-    uint32_t *tile_count;  // counter c = tile * tc_sub + sub at word c * tc_stride
-    uint32_t tc_stride, tc_sub;
+    uint32_t *tile_count;  // [T]
     uint2 *ranges;         // [T] (start,end) into point_list
-    uint32_t *cursor;      // [T * tc_sub] first slot of every counter's sub-range
+    uint32_t *cursor;      // [T] unclipped first slot of every tile
     uint64_t *pair_keys;   // [cap] (depth_bits << 32 | gid), grouped by tile, sorted in place
     uint32_t *point_list;  // [cap] sorted Gaussian ids
     uint64_t *point_keys;  // [cap] optional upstream-format keys
     uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
-    uint32_t *pair_tile;   //       counter id (tile * tc_sub + sub),
+    uint32_t *pair_tile;   //       tile id,
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
     uint2 *sort_items;     // (tile, chunk) of lists too long for the one-wave sort; count in header[4]
     uint2 *rank_items;     // (tile, chunk) of lists of more than one chunk; count in header[6]
@@ -83,7 +76,6 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     char *b = (char *)ws;
     SgBin g;
     g.header = (uint32_t *)(b + L.bin_header); g.tile_count = (uint32_t *)(b + L.bin_tile_count);
-    g.tc_stride = SG_TC_STRIDE_MAX; g.tc_sub = 1;   // callers that know the tile count set sg_tc_stride/sub(T)
     g.ranges = (uint2 *)(b + L.bin_ranges); g.cursor = (uint32_t *)(b + L.bin_cursor);
     g.pair_keys = (uint64_t *)(b + L.bin_pair_keys); g.point_list = (uint32_t *)(b + L.bin_point_list);
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);

@@ -13,8 +13,9 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
                          const float *__restrict__ shs, const float *__restrict__ colors_precomp,
                          const float *__restrict__ opacities, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii)
+                         SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii, int hist_tiles)
 {
+    extern __shared__ uint32_t sg_hist_lds[];               // hist_tiles words (0: per-pair global atomics)
     __shared__ uint32_t scratch_all[4][192];
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int wave = threadIdx.x >> 6;
@@ -41,7 +42,7 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
                           colors_precomp ? colors_precomp + 3 * (size_t)idx : nullptr, sh, o);
         opac = opacities[idx];
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave]);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave], hist_tiles ? sg_hist_lds : nullptr, hist_tiles);
 }
 
 void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
@@ -51,8 +52,9 @@ void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const
 {
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
-#define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
-                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii)
+    const int T = c.gx * c.gy, ht = sg_lds_hist((size_t)T) ? T : 0;
+#define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, (size_t)ht * 4, st, c, P, means3D, shs, \
+                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii, ht)
     int D = colors_precomp ? 0 : c.D;
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (D) { case 0: SG_PP(0); break; case 1: SG_PP(1); break; case 2: SG_PP(2); break; default: SG_PP(3); break; }

@@ -98,7 +98,7 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
 // `scratch`: >= 192 words of LDS private to this wave.
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
                                               int gx, uint32_t cap, int32_t *__restrict__ radii,
-                                              uint32_t *__restrict__ scratch)
+                                              uint32_t *__restrict__ scratch, uint32_t *__restrict__ hist, int T)
 {
     uint32_t *sIncl = scratch, *sMin = scratch + 64, *sWid = scratch + 128;
     const int lane = threadIdx.x & 63;
@@ -115,6 +115,8 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     __shared__ uint32_t sBlockBase;
     const int wave_ = (threadIdx.x >> 6) & 3;
     if (lane == 63) sWaveTot[wave_] = total;
+    if (hist)                                     // few-tiles regime: this workgroup's per-tile pair counts live in LDS
+        for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0u;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
@@ -134,12 +136,11 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
-    if (total == 0) return;                       // wave-uniform
+    if (total == 0 && !hist) return;              // wave-uniform (with the LDS histogram the workgroup barriers follow)
     sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
-    const uint32_t sub = blockIdx.x & (bn.tc_sub - 1);          // this workgroup's sub-counter (tc_sub is 1 or 8)
     // four pairs per lane per round: the four returning atomics are in flight together
     for (uint32_t p0 = 0; p0 < total; p0 += 256) {
         uint32_t tile[4], local[4], gj[4];
@@ -159,9 +160,11 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t t = p - excl, w = sWid[j], mn = sMin[j];
                 const uint32_t ty = (uint32_t)(((float)t + 0.5f) / (float)w);      // exact floor: t, w < 2^16
                 const uint32_t tx = t - ty * w;
-                tile[u] = (((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx) * bn.tc_sub + sub;   // counter id
+                tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
                 gj[u] = (uint32_t)(g0 + j);
-                local[u] = atomicAdd(&bn.tile_count[(size_t)tile[u] * bn.tc_stride], 1u);
+                // rank inside this workgroup's share of the tile (LDS) / inside the tile (global)
+                local[u] = hist ? atomicAdd(&hist[tile[u]], 1u)
+                                : atomicAdd(&bn.tile_count[tile[u]], 1u);
             }
         }
 #pragma unroll
@@ -169,6 +172,20 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             const uint32_t p = p0 + 64 * u + lane;
             const uint32_t slot = base + p;
             if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
+        }
+    }
+    if (hist) {
+        // one global returning atomic per (workgroup, touched tile) instead of one per pair -- on an avatar frame the
+        // per-pair atomics were 55 of the 80 us of this kernel -- then the workgroup-local ranks are rebased
+        __syncthreads();
+        for (int t = threadIdx.x; t < T; t += blockDim.x) {
+            const uint32_t c = hist[t];
+            if (c) hist[t] = atomicAdd(&bn.tile_count[t], c);
+        }
+        __syncthreads();
+        for (uint32_t p = lane; p < total; p += 64) {           // a lane re-reads exactly the slots it wrote above
+            const uint32_t slot = base + p;
+            if (slot < cap) bn.pair_local[slot] += hist[bn.pair_tile[slot]];
         }
     }
     __builtin_amdgcn_wave_barrier();

@@ -211,11 +211,12 @@ __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ opacities,
                    const float *__restrict__ scales, SgGeom g, SgBin bn, uint32_t cap,
                    int32_t *__restrict__ radii, float *__restrict__ posed_xyz, float *__restrict__ posed_rotq,
-                   float *__restrict__ posed_scales)
+                   float *__restrict__ posed_scales, int hist_tiles)
 {
     __shared__ float sA[SG_JMAX * 16];
     __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
     __shared__ float sT[SG_SKIN_WAVES][64 * 13];
+    static_assert(SG_SKIN_WAVES * 64 * SG_WSTRIDE >= SG_HIST_TILES_MAX, "the weight tiles double as the per-tile histogram");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
     const int idx = g0 + lane;
@@ -237,7 +238,12 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         if (posed_rotq) { posed_rotq[4 * idx] = ps.q[0]; posed_rotq[4 * idx + 1] = ps.q[1]; posed_rotq[4 * idx + 2] = ps.q[2]; posed_rotq[4 * idx + 3] = ps.q[3]; }
         if (posed_scales) { posed_scales[3 * idx] = ps.s3[0]; posed_scales[3 * idx + 1] = ps.s3[1]; posed_scales[3 * idx + 2] = ps.s3[2]; }
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, (uint32_t *)sT[wave]);
+    uint32_t *hist = nullptr;
+    if (hist_tiles) {                                         // the skinning-weight tiles are dead: reuse them as histogram
+        __syncthreads();
+        hist = (uint32_t *)&sW[0][0];
+    }
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, (uint32_t *)sT[wave], hist, hist_tiles);
 }
 
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
@@ -416,8 +422,9 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
     SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
                  in->ext_trans, in->ext_rot, in->ext_scale };
     dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
+    const int T = c.gx * c.gy, ht = sg_lds_hist((size_t)T) ? T : 0;
 #define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
-                                     b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales)
+                                     b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales, ht)
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (c.D) { case 0: SG_SF(0); break; case 1: SG_SF(1); break; case 2: SG_SF(2); break; default: SG_SF(3); break; }
     sg_prof_end(SG_K_PREPROCESS_FWD, st);
