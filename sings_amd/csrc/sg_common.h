@@ -52,6 +52,7 @@ struct SgBin {
     uint32_t *items;       // backward work items: tile | segment << 20; count in header[5]
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
     uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)
+    uint8_t *pair_mask;    // [cap] per sorted list entry: quadrants the forward composited it in (0 if it never staged it)
 };
 
 struct SgImg {
@@ -83,7 +84,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.pair_local = (uint32_t *)(b + L.bin_pair_local);
     g.sort_items = (uint2 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
-    g.plan = (uint4 *)(b + L.bin_plan);
+    g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)

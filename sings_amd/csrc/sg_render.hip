@@ -134,7 +134,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                     const uint32_t *__restrict__ header)
+                     const uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask)
 {
     __shared__ float4 sA[SG_FB];
     __shared__ float4 sB[SG_FB];
@@ -176,7 +176,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         const int e = base + tid;
         if (e < n) {
             sA[tid] = pa; sB[tid] = pb; sC[tid] = pc;
-            sM[tid] = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
+            const uint32_t mk = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
+            sM[tid] = mk;
+            pair_mask[range.x + e] = (uint8_t)mk;          // the backward composites exactly these (entry, quadrant) pairs
         }
         if (e + SG_FB < n) {
             const uint32_t gid = point_list[range.x + e + SG_FB];
@@ -231,7 +233,7 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     sg_prof_begin(SG_K_RENDER_FWD, st);
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib,
-                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header);
+                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -282,7 +284,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
                      float4 *__restrict__ grec, uint32_t cap, const uint32_t *__restrict__ header,
                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
-                     const float4 *__restrict__ ckpt, uint32_t ck_cap)
+                     const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask)
 {
     __shared__ float4 sA[SG_BB];
     __shared__ float4 sB[SG_BB];
@@ -292,7 +294,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
     __shared__ uint8_t sFlag[4][SG_BB];        // [w][k] != 0: quadrant w wrote sG[w][k]
     __shared__ uint32_t smax[4];
-    __shared__ float4 sBox[4];                 // per quadrant: box of the pixels with contributors in the current batch
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
     (void)T; (void)nblocks;
@@ -335,10 +336,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
     const int maxq = (int)__builtin_amdgcn_readfirstlane(m);          // this quadrant's deepest contributor
     if (lane == 0) smax[wave] = m;
-    {   // entries of batch [base, ...) can only have contributed to pixels with n_contrib > base
-        const float4 bx = sg_live_box(__ballot(ncq > (uint32_t)(((hi - 1) / SG_BB) * SG_BB)), wave);
-        if (lane == 0) sBox[wave] = bx;
-    }
     __syncthreads();
     const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
@@ -357,12 +354,13 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
             const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
-            uint32_t mk = 0;
-            if (e < max_contrib) {
+            // quadrants the forward composited this entry in: nothing else can carry a gradient, so neither the
+            // rectangle tests nor the two record gathers are repeated for the rest
+            const uint32_t mk = e < max_contrib ? (uint32_t)pair_mask[range.x + e] : 0u;
+            if (mk) {
                 const float4 a = recA[gid], b = recB[gid];
                 opac = b.y;
                 sA[tid] = a; sB[tid] = b; sC[tid] = c4.x;
-                mk = sg_quad_mask(a, b, (float)X0, (float)Y0, sBox);
             }
             sM[tid] = mk;
         }
@@ -423,10 +421,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             grec[3 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
             grec[3 * (size_t)rslot + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
         }
-        if (kb > 0) {                                            // box for the next (shallower) batch
-            const float4 bx = sg_live_box(__ballot(ncq > (uint32_t)(base - SG_BB)), wave);
-            if (lane == 0) sBox[wave] = bx;
-        }
         __syncthreads();
     }
 }
@@ -441,6 +435,6 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     sg_prof_begin(SG_K_RENDER_BWD, st);
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
-                       (float4 *)grec, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap));
+                       (float4 *)grec, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask);
     sg_prof_end(SG_K_RENDER_BWD, st);
 }
