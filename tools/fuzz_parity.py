@@ -1,0 +1,91 @@
+"""Randomised HIP-vs-oracle parity sweep (GPU box): python tools/fuzz_parity.py [n_cases]
+Random scene sizes / SH degrees / densities / opacity scales, plus crafted tiles whose list length sits exactly on the
+internal boundaries (256 = wave sort / depth segment, 4096 = sort chunk).  Checks per case: binning bit-exact, RGB <= 2e-5
+off borderline pixels, gradients within tolerance.  Exit code 1 on the first failure (prints the case)."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import raster_oracle as ro
+from sings_amd.scene import synthetic_scene
+from sings_amd.inspect_ws import forward_with_state
+from diff_gaussian_rasterization import GaussianRasterizer
+from sings_amd.rasterizer import GaussianRasterizationSettings
+
+dev = torch.device("cuda:0")
+BORDER = 2e-5
+
+
+def settings(s):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    return GaussianRasterizationSettings(image_height=s["H"], image_width=s["W"], tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                         scale_modifier=1.0, viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]),
+                                         sh_degree=s["sh_degree"], campos=t(s["campos"]), prefiltered=False, debug=False)
+
+
+def check(s, tag):
+    o = ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], s["W"], s["H"], s["tanfovx"], s["tanfovy"],
+                   s["bg"], scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=s["sh_degree"])
+    rs = settings(s)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+    assert st["R"] == o["R"], (tag, "R", st["R"], o["R"])
+    assert np.array_equal(st["ranges"].cpu().numpy().astype(np.uint32), o["ranges"]), (tag, "ranges")
+    assert np.array_equal(st["point_list"].cpu().numpy().astype(np.uint32), o["point_list"]), (tag, "point_list")
+    assert np.array_equal(st["radii"].cpu().numpy(), o["radii"]), (tag, "radii")
+    border = o["margin"] < BORDER
+    diff = np.abs(st["color"].cpu().numpy() - o["color"]).max(0)
+    assert diff[~border].max() <= 2e-5, (tag, "rgb", diff[~border].max())
+    dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+    g = ro.backward(o, dLn)
+    req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+    color, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh, scales=sc, rotations=rt)
+    color.backward(torch.from_numpy(dLn).to(dev))
+    for name, a, b in (("means3D", m.grad, g["dL_dmeans3D"]), ("opacity", op.grad, g["dL_dopacity"]), ("scales", sc.grad, g["dL_dscales"]),
+                       ("rots", rt.grad, g["dL_drots"]), ("sh", sh.grad, g["dL_dsh"])):
+        a = a.cpu().numpy().reshape(b.shape).astype(np.float64); b = b.astype(np.float64)
+        scale = np.abs(b).max() + 1e-30
+        bad = np.abs(a - b) > 1e-3 * np.abs(b) + 1e-5 * scale
+        assert bad.mean() <= 1e-4, (tag, name, bad.sum(), np.abs(a - b).max(), scale)
+    tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
+    return int(o["R"]), int(tl.max())
+
+
+def crafted(n_in_tile, seed):
+    """n small Gaussians whose 3-sigma squares all lie inside ONE 16x16 tile of a 64x48 image -> that tile's list has
+    exactly n entries (plus a sprinkle elsewhere)."""
+    s = synthetic_scene(200, 64, 48, 1, seed)
+    rs = np.random.RandomState(seed)
+    N = n_in_tile + 200
+    fx = 1.2 * 64
+    z = rs.uniform(2, 10, n_in_tile).astype(np.float32)
+    px = rs.uniform(22, 26, n_in_tile); py = rs.uniform(22, 26, n_in_tile)           # tile (1,1) spans 16..31
+    x = ((px - 32) / fx * z).astype(np.float32); y = ((py - 24) / fx * z).astype(np.float32)
+    means = np.concatenate([np.stack([x, y, z], 1), s["means3D"]]).astype(np.float32)
+    sig = (0.35 * z / fx).astype(np.float32)                                          # sigma 0.35 px -> radius ceil(3 sqrt(.35^2+.3)) = 3
+    scales = np.concatenate([np.stack([sig, sig, sig], 1), s["scales"]]).astype(np.float32)
+    rot = np.concatenate([np.tile(np.array([[1, 0, 0, 0]], np.float32), (n_in_tile, 1)), s["rotations"]])
+    op = np.concatenate([rs.uniform(0.01, 0.2, (n_in_tile, 1)).astype(np.float32), s["opacities"]])
+    shs = np.concatenate([rs.normal(0, 0.5, (n_in_tile, 16, 3)).astype(np.float32), s["shs"]])
+    out = dict(s); out.update(means3D=means, scales=scales, rotations=rot.astype(np.float32), opacities=op, shs=shs)
+    return out
+
+
+if __name__ == "__main__":
+    ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    for n in (255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8192, 8193):
+        s = crafted(n, n)
+        R, mx = check(s, f"crafted {n}")
+        print(f"crafted list length {n}: R={R} max list {mx}  ok", flush=True)
+        assert mx >= n
+    rs = np.random.RandomState(1234)
+    for c in range(ncase):
+        W, H = int(rs.choice([33, 64, 100, 160, 257, 400])), int(rs.choice([17, 48, 96, 144, 230]))
+        N = int(rs.choice([1, 7, 300, 2000, 9000, 30000]))
+        deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
+        s = synthetic_scene(N, W, H, deg, seed)
+        s["opacities"] = (s["opacities"] * rs.choice([0.05, 0.3, 1.0])).astype(np.float32)
+        s["scales"] = (s["scales"] * rs.choice([0.3, 1.0, 4.0])).astype(np.float32)
+        R, mx = check(s, f"case {c}: N={N} {W}x{H} deg={deg} seed={seed}")
+        print(f"case {c}: N={N} {W}x{H} deg={deg} R={R} max list {mx}  ok", flush=True)
+    print("all cases passed")
