@@ -36,15 +36,15 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
                      float *__restrict__ pred_out, float *__restrict__ gt_out, float4 *__restrict__ partial)
 {
     __shared__ float sX[SG_LH][SG_LP], sY[SG_LH][SG_LP];
-    __shared__ float sHq[5][SG_LH][SG_LT + 1];
+    __shared__ float sH[SG_LH][SG_LT + 1];
     __shared__ float sRed[4][3];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
     float acc_l1 = 0.0f, acc_ssim = 0.0f, acc_mask = 0.0f;
-    for (int ch = 0; ch < 3; ch++) {
+    {   // one (tile, channel) per workgroup: a 512x896 frame is only 448 tiles, fewer than two per CU
+        const int ch = blockIdx.z;
         const float bgc = bg[ch];
-        __syncthreads();
         for (int i = tid; i < SG_LH * SG_LH; i += 256) {
             const int r = i / SG_LH, c = i - r * SG_LH;
             const int x = X0 - 5 + c, y = Y0 - 5 + r;
@@ -58,15 +58,22 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
             sX[r][c] = xv; sY[r][c] = yv;
         }
         __syncthreads();
-        // horizontal pass: one item = 8 consecutive output columns of one halo row (18 samples of x and y in
-        // registers instead of 11 LDS reads per output and quantity)
-        if (tid < SG_LH * 4) {
-            const int r = tid >> 2, c0 = (tid & 3) * 8;
-            float xs[18], ys[18];
+        // Separable window, one quantity at a time through ONE LDS plane (20 KB per workgroup instead of 42 KB: the
+        // kernel is latency-bound, resident workgroups are what hides it).  Horizontal pass: an item = 8 consecutive
+        // output columns of one halo row, its 18 samples of x and y stay in registers for all five quantities;
+        // vertical pass: 4 consecutive rows of one column per thread (14 LDS reads for 4 outputs).
+        const bool hthread = tid < SG_LH * 4;
+        const int hr = tid >> 2, hc0 = (tid & 3) * 8;
+        float xs[18], ys[18];
+        if (hthread) {
 #pragma unroll
-            for (int k = 0; k < 18; k++) { xs[k] = sX[r][c0 + k]; ys[k] = sY[r][c0 + k]; }
+            for (int k = 0; k < 18; k++) { xs[k] = sX[hr][hc0 + k]; ys[k] = sY[hr][hc0 + k]; }
+        }
+        const int c = tid & 31, r0 = (tid >> 5) * 4;
+        float vq[5][4];
 #pragma unroll
-            for (int q = 0; q < 5; q++) {
+        for (int q = 0; q < 5; q++) {
+            if (hthread) {
                 float v[18];
 #pragma unroll
                 for (int k = 0; k < 18; k++)
@@ -76,19 +83,13 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
                     float h = 0.0f;
 #pragma unroll
                     for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v[o + k], h);
-                    sHq[q][r][c0 + o] = h;
+                    sH[hr][hc0 + o] = h;
                 }
             }
-        }
-        __syncthreads();
-        // vertical pass + SSIM: 4 consecutive rows of one column per thread (14 LDS reads per quantity for 4 outputs)
-        const int c = tid & 31, r0 = (tid >> 5) * 4;
-        float vq[5][4];
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
+            __syncthreads();
             float col[14];
 #pragma unroll
-            for (int k = 0; k < 14; k++) col[k] = sHq[q][r0 + k][c];
+            for (int k = 0; k < 14; k++) col[k] = sH[r0 + k][c];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float h = 0.0f;
@@ -96,6 +97,7 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
                 for (int k = 0; k < 11; k++) h = fmaf(a.w[k], col[j + k], h);
                 vq[q][j] = h;
             }
+            __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -137,7 +139,7 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
     if (tid == 0) {
         float t0 = 0, t1 = 0, t2 = 0;
         for (int w = 0; w < 4; w++) { t0 += sRed[w][0]; t1 += sRed[w][1]; t2 += sRed[w][2]; }
-        partial[blockIdx.y * gridDim.x + blockIdx.x] = make_float4(t0, t1, t2, 0.0f);
+        partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float4(t0, t1, t2, 0.0f);
     }
 }
 
@@ -175,15 +177,15 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
                     const float *__restrict__ scalars, const float *__restrict__ upstream, float *__restrict__ dL_draw)
 {
     __shared__ float sM[3][SG_LH][SG_LP];
-    __shared__ float sHq[3][SG_LH][SG_LT + 1];
+    __shared__ float sH[SG_LH][SG_LT + 1];
     const int tid = threadIdx.x;
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
     // upstream = (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL
     const float u_l1 = upstream ? upstream[0] : 1.0f, u_ss = upstream ? upstream[1] : 1.0f;
     const float c_l1 = scalars[4] * u_l1, c_ss = scalars[5] * u_ss;
-    for (int ch = 0; ch < 3; ch++) {
-        __syncthreads();
+    {
+        const int ch = blockIdx.z;
         for (int i = tid; i < SG_LH * SG_LH; i += 256) {
             const int r = i / SG_LH, c = i - r * SG_LH;
             const int x = X0 - 5 + c, y = Y0 - 5 + r;
@@ -196,31 +198,29 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
             sM[0][r][c] = m0; sM[1][r][c] = m1; sM[2][r][c] = m2;
         }
         __syncthreads();
-        if (tid < SG_LH * 4) {
-            const int r = tid >> 2, c0 = (tid & 3) * 8;
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                float v[18];
-#pragma unroll
-                for (int k = 0; k < 18; k++) v[k] = sM[q][r][c0 + k];
-#pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    float h = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v[o + k], h);
-                    sHq[q][r][c0 + o] = h;
-                }
-            }
-        }
-        __syncthreads();
+        const bool hthread = tid < SG_LH * 4;
+        const int hr = tid >> 2, hc0 = (tid & 3) * 8;
         const int c = tid & 31, r0 = (tid >> 5) * 4;
         const float bgc = bg[ch];
         float gq[3][4];
 #pragma unroll
         for (int q = 0; q < 3; q++) {
+            if (hthread) {
+                float v[18];
+#pragma unroll
+                for (int k = 0; k < 18; k++) v[k] = sM[q][hr][hc0 + k];
+#pragma unroll
+                for (int o = 0; o < 8; o++) {
+                    float h = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v[o + k], h);
+                    sH[hr][hc0 + o] = h;
+                }
+            }
+            __syncthreads();
             float col[14];
 #pragma unroll
-            for (int k = 0; k < 14; k++) col[k] = sHq[q][r0 + k][c];
+            for (int k = 0; k < 14; k++) col[k] = sH[r0 + k][c];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float h = 0.0f;
@@ -228,6 +228,7 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
                 for (int k = 0; k < 11; k++) h = fmaf(a.w[k], col[j + k], h);
                 gq[q][j] = h;
             }
+            __syncthreads();
         }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -251,7 +252,7 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
 size_t sg_photo_loss_ws_bytes_impl(int W, int H)
 {
     const size_t hw = (size_t)W * H;
-    const size_t nb = (size_t)((W + SG_LT - 1) / SG_LT) * ((H + SG_LT - 1) / SG_LT);
+    const size_t nb = (size_t)((W + SG_LT - 1) / SG_LT) * ((H + SG_LT - 1) / SG_LT) * 3;
     return sg_align(9 * hw * 4) + sg_align(nb * 16) + 256;
 }
 
@@ -268,8 +269,8 @@ void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *r
         for (int x = 0; x < 11; x++) a.w[x] = g[x] / s;
     }
     const size_t hw = (size_t)W * H;
-    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT), block(256);
-    const int nb = (int)(grid.x * grid.y);
+    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3), block(256);
+    const int nb = (int)(grid.x * grid.y * grid.z);
     char *b = (char *)ws;
     float *maps = (float *)b;
     float4 *partial = (float4 *)(b + sg_align(9 * hw * 4));
