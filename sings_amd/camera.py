@@ -70,3 +70,44 @@ def make_camera(extrinsic, fx, fy, cx, cy, width, height, znear=0.01, zfar=100.0
     center = np.linalg.inv(wvt)[3, :3].astype(np.float32)
     return dict(fovx=fovx, fovy=fovy, image_height=int(height), image_width=int(width),
                 world_view_transform=wvt, full_proj_transform=full, camera_center=center)
+
+
+def _camera_datum(world_view_transform, img_hw, fov, znear=0.01, zfar=100.0):
+    import torch
+    h, w = img_hw
+    fx = fov2focal(fov, h)
+    cam_int = torch.eye(3)
+    cam_int[0, 0] = fx; cam_int[1, 1] = fx; cam_int[0, 2] = w / 2; cam_int[1, 2] = h / 2
+    P = torch.from_numpy(get_projection_matrix(znear, zfar, fov, fov)).float().transpose(0, 1)
+    return {"fovx": fov, "fovy": fov, "image_height": h, "image_width": w, "world_view_transform": world_view_transform,
+            "full_proj_transform": world_view_transform @ P, "camera_center": world_view_transform.inverse()[3, :3],
+            "cam_int": cam_int, "cam_ext": world_view_transform, "near": znear, "far": zfar}
+
+
+def get_static_camera(img_size=512, fov=0.4, device="cuda"):
+    """sings/rec/datasets/utils.py:19-57: identity view, square image."""
+    import torch
+    d = _camera_datum(torch.eye(4), (img_size, img_size), fov)
+    return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}
+
+
+def get_rotating_camera(img_size=512, fov=0.4, dist=5.0, device="cuda", nframes=40, angle_limit=None):
+    """sings/rec/datasets/utils.py:60-120: nframes cameras orbiting the origin at height -0.25, distance `dist` (the
+    reference's ``rot_z`` is a rotation about the y axis; y and z of the camera frame are flipped)."""
+    import math
+    import torch
+    if angle_limit is None:
+        angle_limit = 2 * math.pi
+    hw = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+    out = []
+    for azim in torch.linspace(0, angle_limit, nframes):
+        rot = lambda a: torch.tensor([[torch.cos(a), 0, torch.sin(a)], [0, 1, 0], [-torch.sin(a), 0, torch.cos(a)]])
+        t = (rot(-azim) @ torch.tensor([[0., -0.25, dist]]).T).T
+        R = rot(azim)[None]
+        R[:, 1:3] *= -1
+        Rt = torch.eye(4)
+        Rt[:3, :3] = R[0].T
+        Rt[:3, 3] = t[0].squeeze()
+        d = _camera_datum(Rt.inverse().T, hw, fov)
+        out.append({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()})
+    return out
