@@ -109,6 +109,26 @@ __device__ __forceinline__ void sg_stage_w_chunk(const float *__restrict__ W, in
     }
 }
 
+// the same in two halves (J % 4 == 0): issue the loads of a chunk / put them into LDS -- the chunk loops below keep the
+// next chunk's loads in flight while the matrix cores work on the current one
+__device__ __forceinline__ void sg_w_fetch(const float *__restrict__ W, int J, int P, int g0, int c, int lane, float4 v[4])
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int row = i * 16 + (lane >> 2), col = c * 16 + 4 * (lane & 3);
+        v[i] = make_float4(0, 0, 0, 0);
+        if (g0 + row < P && col < J) v[i] = *(const float4 *)(W + (size_t)(g0 + row) * J + col);
+    }
+}
+__device__ __forceinline__ void sg_w_stash(const float4 v[4], int lane, float *__restrict__ sW)
+{
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float *d = sW + (i * 16 + (lane >> 2)) * SG_WSTRIDE + 4 * (lane & 3);
+        d[0] = v[i].x; d[1] = v[i].y; d[2] = v[i].z; d[3] = v[i].w;
+    }
+}
+
 // T rows 0..2 (12 floats, row-major 3x4) of this lane's Gaussian g0 + lane.
 // sA: [Jp][16] joint transforms (zero padded to a multiple of 16 rows), sW / sT: this wave's scratch.
 __device__ __forceinline__ void sg_skin_T(const float *__restrict__ W, int J, int P, int g0, int lane,
@@ -119,9 +139,18 @@ __device__ __forceinline__ void sg_skin_T(const float *__restrict__ W, int J, in
 #pragma unroll
     for (int b = 0; b < 4; b++) acc[b] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
     const int nchunk = (J + 15) >> 4;
+    const bool vec = (J & 3) == 0;
+    float4 wv[4];
+    if (vec) sg_w_fetch(W, J, P, g0, 0, lane, wv);
     for (int c = 0; c < nchunk; c++) {
-        sg_stage_w_chunk(W, J, P, g0, c, lane, sW);
-        __builtin_amdgcn_s_waitcnt(0);
+        if (vec) {
+            sg_w_stash(wv, lane, sW);
+            if (c + 1 < nchunk) sg_w_fetch(W, J, P, g0, c + 1, lane, wv);
+            __builtin_amdgcn_s_waitcnt(0xC07F);             // LDS only: the next chunk's global loads stay in flight
+        } else {
+            sg_stage_w_chunk(W, J, P, g0, c, lane, sW);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) {
@@ -259,26 +288,37 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
                    float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
 {
     __shared__ float sA[SG_JMAX * 16];
-    __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
-    __shared__ float sT[SG_SKIN_WAVES][64 * SG_WSTRIDE];     // T transpose scratch, then the dT tile
+    // per wave: [weights tile | T transpose scratch, later the dT tile]; between the two uses the whole 2 x 4.3 KB is
+    // the staging buffer of the record sums and of the dL/dsh rows
+    __shared__ float sWT[SG_SKIN_WAVES][2 * 64 * SG_WSTRIDE];
+    static_assert(2 * 64 * SG_WSTRIDE >= SG_REC_CHUNK * 12 && 2 * 64 * SG_WSTRIDE >= 32 * SG_ROW_LDS, "staging buffer size");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *const sWw = sWT[wave], *const sTw = sWT[wave] + 64 * SG_WSTRIDE;
     const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
     const int idx = g0 + lane;
     sg_load_A(k, sA);
     __syncthreads();
     float T[12];
-    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sW[wave], sT[wave], T);
+    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sWw, sTw, T);
     const bool live = idx < P;
     float dT[12];
 #pragma unroll
     for (int i = 0; i < 12; i++) dT[i] = 0.0f;
     float dtr[3] = { 0, 0, 0 };
+    const int Mrows = c.M;
+    constexpr int nc = (D + 1) * (D + 1);
+    // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
+    const bool vis = live && radii[idx] > 0;
+    const float4 rc = vis ? g.recC[idx] : make_float4(0, 0, 0, 0);
+    float a9[9];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
+    float dsh[nc * 3];
+#pragma unroll
+    for (int i = 0; i < nc * 3; i++) dsh[i] = 0.0f;
     if (live) {
-        const int Mrows = c.M;
-        constexpr int nc = (D + 1) * (D + 1);
-        float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
         float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0, g2[2] = { 0, 0 };
-        const bool vis = radii[idx] > 0;
         const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
         if (vis || have_in) {
             SgPosed ps;
@@ -289,14 +329,8 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 #pragma unroll
             for (int i = 0; i < 4; i++) G.drot[i] = 0;
             G.g2[0] = G.g2[1] = 0; G.dop = 0;
-            if (vis) {
-                float a9[9];
-                sg_sum_records(grec, cap, g.recC[idx], a9);
-                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh_row, G);
-                for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
-            } else {
-                for (int i = 0; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
-            }
+            if (vis)
+                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh, G);
             if (dposed_xyz_in) {
 #pragma unroll
                 for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * idx + i];
@@ -328,8 +362,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
                 for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
                     dRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
             }
-        } else {
-            for (int i = 0; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
         }
         dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
         if (dL_drot_canon) {
@@ -340,8 +372,29 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         dL_dopacity[idx] = dop;
         dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     }
+    // dL/dsh rows (every one of the M rows is written): through LDS as 16-B-per-lane coalesced stores when M == 16
+    if (Mrows == 16) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((lane >> 5) == h) {
+                float *row = sWw + (lane & 31) * SG_ROW_LDS;
+#pragma unroll
+                for (int i = 0; i < 48; i++) row[i] = i < nc * 3 ? dsh[i < nc * 3 ? i : 0] : 0.0f;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, sWw, 32);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (live) {
+        float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+#pragma unroll
+        for (int i = 0; i < nc * 3; i++) dsh_row[i] = dsh[i];
+        for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+    }
     // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
-    float *sdT = sT[wave];
+    float *sdT = sTw;
 #pragma unroll
     for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
 #pragma unroll
@@ -349,14 +402,23 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     const int nchunk = (k.J + 15) >> 4;
     // every wave owns one slab row (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
     float *out = slab + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
+    const bool vec = (k.J & 3) == 0;
+    float4 wv[4];
+    if (vec) sg_w_fetch(k.lbs_w, k.J, P, g0, 0, lane, wv);
     for (int cch = 0; cch < nchunk; cch++) {
-        sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sW[wave]);
-        __builtin_amdgcn_s_waitcnt(0);
+        if (vec) {
+            sg_w_stash(wv, lane, sWw);
+            if (cch + 1 < nchunk) sg_w_fetch(k.lbs_w, k.J, P, g0, cch + 1, lane, wv);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        } else {
+            sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sWw);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
         __builtin_amdgcn_wave_barrier();
         f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
 #pragma unroll
         for (int kk = 0; kk < 16; kk++) {
-            float av = sW[wave][(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
+            float av = sWw[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
             float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
             acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
         }
