@@ -68,3 +68,16 @@ def test_argument_validation_and_no_cpu_fallback():
     # CPU tensors: the product path refuses instead of silently falling back
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         r(m, m, o, shs=sh, scales=sc, rotations=q)
+
+
+def test_bench_algorithmic_bytes_follow_the_survey_formula():
+    """bench.py's roofline numerators are SURVEY.md 8(d): B = N (2 in + gout + 4 + 2 rec) + HW 40 + R 20, in = 44 + 12 (deg+1)^2,
+    rec = 75, gout = 248; cfg3 with R = 8.4e5 is the survey's 0.27 GB/view."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(os.path.dirname(os.path.dirname(__file__)), "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    per, total = bench.algorithmic_bytes(200000, 1080, 1920, 840000, 3)
+    assert total == 200000 * (2 * 236 + 248 + 4 + 150) + 2073600 * 40 + 840000 * 20
+    assert abs(total / 1e9 - 0.2745) < 1e-3
+    assert per["sg_render_bwd_kernel"] == 2073600 * 20 + 840000 * 4
+    assert sum(per.values()) <= total + 840000 * 12       # the split never exceeds the whole-pass figure (+ binning keys)
