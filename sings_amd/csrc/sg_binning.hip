@@ -6,13 +6,14 @@
 // tile with equal depth bits come from different Gaussians and a stable sort keeps them in
 // ascending Gaussian id, so the order is exactly the lexicographic order of
 // (tile, depth_bits, gaussian_id).  MI355X-first formulation (integer, HBM-light):
-//   1. count  : fused into the preprocess kernel (sg_project.h::sg_store_proj): every
-//               (tile,Gaussian) pair takes a RETURNING atomic on its tile counter and records
-//               (Gaussian, tile, arrival rank) in Gaussian-major order, load-balanced per wave
-//   2. scan   : one 1024-thread workgroup turns counts into [start,end) ranges, R = total
-//   3. scatter: one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id
-//   4. sort   : one wave per tile sorts its segment in LDS (bitonic, u64 keys; one workgroup per
-//               tile for lists longer than 256) and writes point_list (+ upstream-format keys)
+//   1. count  : fused into the preprocess kernels (sg_project.h::sg_store_proj): every (tile,Gaussian) pair gets its
+//               arrival rank in the tile -- a RETURNING atomic on the tile counter, or (few tiles) an LDS histogram per
+//               workgroup + one global atomic per touched tile -- and is recorded as (Gaussian, tile, rank) in
+//               Gaussian-major order, load-balanced per wave
+//   2. scan   : a few workgroups turn counts into [start,end) ranges, R, and the per-tile plans of the work lists
+//   3. scatter: one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id; + work lists
+//   4. sort   : one wave per tile sorts its segment in LDS (bitonic, u64 keys); lists longer than 256: one workgroup
+//               per 4096-entry chunk, longer still: chunks merged by rank; writes point_list (+ upstream-format keys)
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
 #include "sg_common.h"
 
@@ -21,7 +22,7 @@
 #define SG_SORT_LDS 4096       // u64 entries sorted in LDS (32 KiB)
 
 // Exclusive scans over the T tile counts of
-//   q0 pairs (-> ranges, per-counter cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
+//   q0 pairs (-> ranges, cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
 // Workgroup b owns tiles [b * SG_SCAN_BS * tpt, (b + 1) * SG_SCAN_BS * tpt), one tile per thread and round.  Instead of a second
 // kernel (or a look-back chain) every workgroup first REDUCES the counts of all tiles in front of its range itself:
 // at most T words per workgroup, coalesced and L2-resident.  The kernel is a handful of waves that start with a cold
