@@ -94,7 +94,9 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
 //  * the pairs are then expanded load-balanced: lane l of pass c handles pair 64c + l of the wave
 //    (binary search of the owner in the wave's prefix sums held in LDS), adds 1 to its tile's
 //    counter with a RETURNING atomic and records (Gaussian, tile, arrival rank) -- the scatter that
-//    follows the tile scan then needs no atomics at all.
+//    follows the tile scan then needs no atomics at all.  With `hist` (T words of workgroup LDS, images of few
+//    tiles) the ranks are first taken from an LDS histogram of the workgroup and rebased with one global atomic per
+//    touched tile.
 // `scratch`: >= 192 words of LDS private to this wave.
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
                                               int gx, uint32_t cap, int32_t *__restrict__ radii,

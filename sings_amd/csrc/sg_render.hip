@@ -12,7 +12,11 @@
 //    then compacts (ballot) the entries that reach its quadrant and loops over those only: ~2.4x fewer
 //    wave-level evaluations than the upstream 16x16 block, identical results, and 4 independent waves
 //    per tile keep avatar close-ups (few, very long tile lists) busy.
+//    The rectangle is the bounding box of the quadrant's LIVE pixels (unsaturated ones), so entries hidden behind
+//    saturated pixels drop out; the forward stores the mask byte per sorted entry and the backward reuses it.
 //  * The per-entry body is straight-line predicated code (no exec-mask branches).
+//  * Lists longer than 256 entries: the forward checkpoints (T, colour) every 256 entries and the backward runs one
+//    workgroup per (tile, 256-entry depth segment) instead of one serial walk per tile.
 //  * Backward: the 9 per-pixel partials of an entry are summed across the wave's 64 lanes with a
 //    multi-value butterfly (v_permlane32_swap / v_permlane16_swap / DPP: 24 ops for 9 values instead of
 //    54), the <= 4 quadrant sums are combined in LDS in a fixed order and stored ONCE per (tile,Gaussian)
