@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--morton", action="store_true", help="avatar / train workloads: store the canonical Gaussians in Morton order")
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=1,
@@ -359,6 +360,11 @@ def main_avatar(a):
     from sings_amd.scene import avatar_scene
     N = a.gaussians if a.gaussians != 200000 else 150000
     s = avatar_scene(N=N, J=52)
+    if a.morton:
+        from sings_amd.scene import morton_order
+        perm = morton_order(s["xyz_canon"])
+        for key in ("xyz_canon", "lbs_weights", "scales", "opacities", "shs"):
+            s[key] = np.ascontiguousarray(s[key][perm])
     W, H, J = s["W"], s["H"], s["J"]
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     cam = s["cam"]

@@ -98,3 +98,21 @@ def avatar_scene(N=150000, J=52, W=512, H=896, seed=4, M=16, isotropic=True):
                 rotmat_canon=None, joints_rest=rest, parents=parents, cam=cam, smpl_scale=np.array([1.0], np.float32),
                 transl=np.array([-0.04, 0.09, 10.06], np.float32), bg=np.array([1, 1, 1], np.float32),
                 dL_dimage=rs.normal(0, 1, (3, H, W)).astype(np.float32))
+
+
+def morton_order(xyz, bits=10):
+    """Permutation that sorts points along a 3-D Morton (Z-order) curve over their bounding box.  Canonical Gaussians
+    stored in this order make consecutive Gaussians neighbours in space -- the reference gets that for free from mesh
+    subdivision; a randomly ordered cloud (e.g. after densification appends) loses it.  Spatial order is what the
+    per-workgroup tile histogram of the preprocess, the tri-plane gathers and the record sums profit from."""
+    x = np.asarray(xyz, dtype=np.float64)
+    lo, hi = x.min(0), x.max(0)
+    q = np.clip(((x - lo) / np.maximum(hi - lo, 1e-12) * ((1 << bits) - 1)).astype(np.uint64), 0, (1 << bits) - 1)
+
+    def spread(v):
+        out = np.zeros_like(v)
+        for b in range(bits):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+    code = spread(q[:, 0]) | (spread(q[:, 1]) << np.uint64(1)) | (spread(q[:, 2]) << np.uint64(2))
+    return np.argsort(code, kind="stable")

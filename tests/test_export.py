@@ -66,3 +66,14 @@ def test_binary_ply_reader_and_checkpoint_keys(tmp_path):
     assert np.array_equal(w["x"], v["x"]) and np.array_equal(w["red"], v["red"])
     k = export.checkpoint_keys(num_gs_level=2)
     assert k[:3] == ["active_sh_degree", "xyz", "triplane"] and k[-4:] == ["appearance_dec_0", "geometry_dec_0", "appearance_dec_1", "geometry_dec_1"]
+
+
+def test_morton_order_is_a_spatially_coherent_permutation():
+    from sings_amd.scene import morton_order
+    rs = np.random.RandomState(0)
+    x = rs.uniform(-1, 1, (20000, 3)).astype(np.float32)
+    p = morton_order(x)
+    assert sorted(p.tolist()) == list(range(20000))
+    step_sorted = np.linalg.norm(np.diff(x[p], axis=0), axis=1).mean()
+    step_random = np.linalg.norm(np.diff(x, axis=0), axis=1).mean()
+    assert step_sorted < 0.15 * step_random                  # neighbours in the order are neighbours in space
