@@ -4,11 +4,15 @@ configs[2]; SURVEY.md 8(d) scene S(200000,1920,1080,3,seed=3)), 1..8 MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one view per rank: rasterizer forward (preprocess ->
-tile binning -> alpha composite) + backward (composite bwd -> per-Gaussian bwd) through the C ABI,
-inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside the timed region.
-With N > 1 the ranks render DIFFERENT cameras of the same Gaussians (frame-parallel) and sum the
-canonical-Gaussian gradients with one RCCL all-reduce per step ("scaling": "weak").
+One "step" = one pass of the hot path over one BATCH of views per rank (default 4 views, `--views-per-step`): for
+every view the rasterizer forward (preprocess -> tile binning -> alpha composite) + backward (composite bwd ->
+per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside
+the timed region; the views of a batch are spread over `--streams` HIP streams (default 2: the latency-bound binning
+kernels and the tile-imbalance tails of one view overlap the other's composite; +15 % views/s on one GPU) and their
+gradients are summed in one pass.  `--views-per-step 1` is the reference's one frame per step
+(gs_trainer.py:207-215); "ms_per_view" = ms_per_step / views.  With N > 1 every (rank, view) pair renders a
+DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the canonical-Gaussian gradients of the
+batch with ONE RCCL all-reduce per step ("scaling": "weak": the batch per rank is fixed).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline     - dominant kernel: algorithmic bytes / its mean launch duration,
@@ -60,9 +64,12 @@ def main():
     ap.add_argument("--morton", action="store_true", help="avatar / train workloads: store the canonical Gaussians in Morton order")
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
-    ap.add_argument("--views-per-step", type=int, default=1,
-                    help="raster workload: views each rank renders (gradients accumulated locally) per all-reduce; 1 = the "
-                         "reference's one frame per rank and step (default).  k > 1 amortises the 47 MB all-reduce")
+    ap.add_argument("--views-per-step", type=int, default=4,
+                    help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
+                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
+                         "workspaces; the per-view gradients are summed in one pass at the end of the step)")
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
@@ -94,16 +101,22 @@ def main():
 
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
     s = synthetic_scene(N, W, H, deg, 3)
-    # frame-parallel: rank r looks at the same Gaussians from a camera shifted along x
-    view = s["viewmatrix"].copy()
-    view[3, 0] = 0.05 * rank
-    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
-    proj = (view @ P_T).astype(np.float32)
-    campos = np.linalg.inv(view)[3, :3].astype(np.float32)
+    # frame-parallel: every (rank, view-of-the-step) pair looks at the same Gaussians from its own camera, shifted along x
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    rs = GaussianRasterizationSettings(
-        image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]), scale_modifier=1.0,
-        viewmatrix=t(view), projmatrix=t(proj), sh_degree=deg, campos=t(campos), prefiltered=False, debug=False)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    bg_t = t(s["bg"])
+
+    def camera(index):
+        view = s["viewmatrix"].copy()
+        view[3, 0] = 0.05 * index
+        proj = (view @ P_T).astype(np.float32)
+        campos = np.linalg.inv(view)[3, :3].astype(np.float32)
+        return view, proj, campos, GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=bg_t, scale_modifier=1.0,
+            viewmatrix=t(view), projmatrix=t(proj), sh_degree=deg, campos=t(campos), prefiltered=False, debug=False)
+
+    k_views = 1 if a.graph else max(1, a.views_per_step)       # a captured graph replays one view on one stream
+    view, proj, campos, rs = camera(rank * k_views)
     means3D, shs, opac, scales, rots = t(s["means3D"]), t(s["shs"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"])
     dL = t(s["dL_dimage"])
 
@@ -123,24 +136,51 @@ def main():
         from sings_amd.dp import FrameParallel
         fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"))
 
-    k_views = max(1, a.views_per_step)
-    acc = torch.zeros_like(eng.grad_flat) if k_views > 1 else None
+    n_streams = max(1, min(a.streams, k_views))
+    per_view = eng.grad_flat.numel()
+    engs, streams, grads = [eng], [None], None
+    if k_views > 1:
+        # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on
+        # different streams share no state) writing its gradients into its own row of `grads`; ONE pass sums the rows
+        grads = torch.empty((k_views, per_view), dtype=torch.float32, device=dev)
+        acc = torch.empty(per_view, dtype=torch.float32, device=dev)
+        engs = []
+        for v in range(k_views):
+            e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=eng.cap, grad_flat=grads[v])
+            e.set_camera(camera(rank * k_views + v)[3])
+            engs.append(e)
+        eng = engs[0]
+        streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    else:
+        acc = None
 
     graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
 
+    def one_view(e):
+        e.forward(means3D, shs, opac, scales, rots)
+        if not a.forward_only:
+            e.backward(means3D, shs, opac, scales, rots, dL)
+
     def step():
-        for v in range(k_views):
+        if k_views == 1:
             if graph is not None:
                 graph.replay()
             else:
-                eng.forward(means3D, shs, opac, scales, rots)
-                if not a.forward_only:
-                    eng.backward(means3D, shs, opac, scales, rots, dL)
-            if acc is not None:
-                if v == 0:
-                    acc.copy_(eng.grad_flat)
-                else:
-                    acc.add_(eng.grad_flat)
+                one_view(eng)
+        elif n_streams == 1:
+            for v in range(k_views):
+                one_view(engs[v])
+            torch.sum(grads, dim=0, out=acc)
+        else:
+            cur = torch.cuda.current_stream(dev)
+            for st in streams:
+                st.wait_stream(cur)
+            for v in range(k_views):
+                with torch.cuda.stream(streams[v % n_streams]):
+                    one_view(engs[v])
+            for st in streams:
+                cur.wait_stream(st)
+            torch.sum(grads, dim=0, out=acc)
         if fp is not None:
             fp.all_reduce_grads(eng.grad_flat if acc is None else acc)
 
@@ -162,7 +202,7 @@ def main():
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    assert eng.num_rendered() <= eng.cap
+    assert all(e.num_rendered() <= e.cap for e in engs)
 
     # per-kernel durations: HIP events around every launch, on the launch stream (separate pass)
     lib = _lib.load()
@@ -201,20 +241,20 @@ def main():
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
         "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "ms_per_step": ms_per_step, "ms_per_view": ms_per_step / k_views, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, fwd+bwd, "
                                f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
-                   "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "views_per_step": k_views,
+                   "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "views_per_step": k_views, "streams": n_streams,
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]},
         "roofline_whole_pass": {"algorithmic_bytes_per_view": total_bytes,
-                                "achieved_GBs": total_bytes / (ms_per_step * 1e-3) / 1e9,
-                                "frac_of_8TBs": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                "frac_of_measured_copy_6.29TBs": total_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_COPY_GBS},
+                                "achieved_GBs": total_bytes * views_s / world / 1e9,
+                                "frac_of_8TBs": total_bytes * views_s / world / 1e9 / HBM_PEAK_GBS,
+                                "frac_of_measured_copy_6.29TBs": total_bytes * views_s / world / 1e9 / HBM_COPY_GBS},
         "kernel_ms": kern,
     }
     if world == 1 and not a.no_cpu_baseline:

@@ -16,7 +16,7 @@ from .rasterizer import _settings_struct, _ptr
 
 class RasterEngine:
     # flat gradient layout (floats per Gaussian): means3D 3, scales 3, rotations 4, opacity 1, sh 3*M
-    def __init__(self, P, W, H, sh_coeffs, device, capacity_pairs):
+    def __init__(self, P, W, H, sh_coeffs, device, capacity_pairs, grad_flat=None):
         self.lib = _lib.load()
         self.P, self.W, self.H, self.M = int(P), int(W), int(H), int(sh_coeffs)
         self.dev = torch.device(device)
@@ -32,7 +32,12 @@ class RasterEngine:
         self.color = torch.empty((3, self.H, self.W), **f32)
         self.radii = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
         per = 3 + 3 + 4 + 1 + 3 * self.M
-        self.grad_flat = torch.empty(self.P * per, **f32)
+        # grad_flat: optional caller-owned storage (one row of a [views, P*per] buffer when several engines render the
+        # views of one step concurrently and their gradients are summed in one pass)
+        if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
+                                      or not grad_flat.is_contiguous() or grad_flat.device != self.dev):
+            raise ValueError(f"grad_flat must be a contiguous fp32 tensor of {self.P * per} elements on {self.dev}")
+        self.grad_flat = torch.empty(self.P * per, **f32) if grad_flat is None else grad_flat.view(-1)
         o = 0
         def carve(n, *shape):
             nonlocal o
