@@ -198,8 +198,10 @@ int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float *scales, v
  * concatenated over scales.  planes[s][c]: the reference parameter grids[s][c] of shape [1, feat, res[s][b], res[s][a]]
  * for the coordinate pair (a, b) of plane c; feat must be 32; aabb = HexPlaneField.aabb (row 0, row 1).
  * forward: feats [N, n_scales * feat].  backward: dplanes[s][c] in the same layout (fully written; NULL = skip),
- * dxyz [N,3] optional.  `ws`: sg_triplane_ws_bytes() bytes, may be reused between the two calls (both re-transpose
- * the current parameters).  Plane gradients are accumulated with float atomics (reproducible to rounding only). */
+ * dxyz [N,3] optional.  `ws`: sg_triplane_ws_bytes() bytes for the forward, sg_triplane_bwd_ws_bytes(tp, N) for the
+ * backward (both calls re-transpose the current parameters).  The backward is a gather: the points are counting-sorted
+ * by texel cell once per projection and every texel block sums its points' rows in LDS -- no global float atomics;
+ * the order of the additions inside a texel is not fixed (reproducible to rounding, like grid_sample's backward). */
 typedef struct {
     int n_scales, feat;
     int res[4][3];
@@ -207,6 +209,7 @@ typedef struct {
     float aabb[2][3];
 } SgTriplane;
 size_t sg_triplane_ws_bytes(const SgTriplane *tp);
+size_t sg_triplane_bwd_ws_bytes(const SgTriplane *tp, int N);
 int sg_triplane_forward(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, void *stream);
 int sg_triplane_backward(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
                          float *const dplanes[4][3], float *dxyz, void *stream);

@@ -273,6 +273,10 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
 
 // ---- attribute decode (f3)
 extern "C" size_t sg_triplane_ws_bytes(const SgTriplane *tp) { return sg_tp_check(tp) ? 0 : sg_triplane_ws_bytes_impl(tp); }
+extern "C" size_t sg_triplane_bwd_ws_bytes(const SgTriplane *tp, int N)
+{
+    return sg_tp_check(tp) || N <= 0 ? 0 : sg_triplane_bwd_ws_bytes_impl(tp, N);
+}
 extern "C" int sg_triplane_forward(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, void *stream)
 {
     if (sg_tp_check(tp)) return sg_fail("sg_triplane_forward: bad plane description (feat must be 32, 1..4 scales)", hipSuccess);

@@ -136,6 +136,7 @@ size_t sg_skin_slab_floats(int P);
 size_t sg_photo_loss_ws_bytes_impl(int W, int H);
 int sg_tp_check(const SgTriplane *tp);
 size_t sg_triplane_ws_bytes_impl(const SgTriplane *tp);
+size_t sg_triplane_bwd_ws_bytes_impl(const SgTriplane *tp, int N);
 void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st);
 int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
                            float *const dplanes[4][3], float *dxyz, hipStream_t st);

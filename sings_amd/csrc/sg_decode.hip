@@ -12,9 +12,10 @@
 // texel are H*W floats apart, 1152 scattered 4-B loads per point.  Here every plane is first transposed to
 // texel-major [H][W][feat] (one 128-B line per texel, 33 MB for the shipped 64/128/256 config -> L2/MALL resident) and
 // 32 lanes = 32 features handle one point: 36 coalesced 128-B reads per point forward.  Backward recomputes the
-// interpolation, scatters w * dL/dinterp rows into a texel-major gradient buffer (one coalesced 128-B float-atomic
-// row per texel corner -- the only float atomics in this library; the reference's grid_sample backward uses them too,
-// so plane gradients are reproducible to rounding, not bitwise) and transposes it back to the reference layout.
+// interpolation per point, counting-sorts the points by texel cell (once per projection) and adds the w * dL/dinterp
+// rows into a texel-major gradient buffer in SORTED order, one 128-B float-atomic row per corner and cell CHANGE (the
+// only float atomics in this library; the reference's grid_sample backward uses one per corner and point, so plane
+// gradients are reproducible to rounding, not bitwise, in both) and transposes it back to the reference layout.
 #include "sg_common.h"
 
 #define SG_TP_FEAT 32
@@ -28,22 +29,35 @@ struct SgTpDev {                       // device-side view
 };
 __constant__ int sg_comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };   // itertools.combinations(range(3), 2)
 
-// [feat][H][W] -> [H][W][feat]   (and the reverse for gradients)
+// [feat][H][W] -> [H][W][feat]   (and the reverse for gradients); blockIdx.y = plane, ONE launch for all planes
+struct SgTpPlanes {
+    const float *src[SG_TP_MAXS * 3];
+    float *dst[SG_TP_MAXS * 3];
+    int HW[SG_TP_MAXS * 3];
+};
 __global__ void __launch_bounds__(256)
-sg_plane_to_fm_kernel(const float *__restrict__ src, float *__restrict__ dst, int HW)
+sg_plane_to_fm_kernel(SgTpPlanes P)
 {
     __shared__ float t[32][33];
+    const int HW = P.HW[blockIdx.y];
+    const float *__restrict__ src = P.src[blockIdx.y];
+    float *__restrict__ dst = P.dst[blockIdx.y];
     const int x0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;     // 32 texels x 32 features per block
+    if (x0 >= HW || !src || !dst) return;
     for (int f = ty; f < 32; f += 8) t[f][tx] = x0 + tx < HW ? src[(size_t)f * HW + x0 + tx] : 0.0f;
     __syncthreads();
     for (int p = ty; p < 32; p += 8)
         if (x0 + p < HW) dst[(size_t)(x0 + p) * 32 + tx] = t[tx][p];
 }
 __global__ void __launch_bounds__(256)
-sg_plane_from_fm_kernel(const float *__restrict__ src, float *__restrict__ dst, int HW)
+sg_plane_from_fm_kernel(SgTpPlanes P)
 {
     __shared__ float t[32][33];
+    const int HW = P.HW[blockIdx.y];
+    const float *__restrict__ src = P.src[blockIdx.y];
+    float *__restrict__ dst = P.dst[blockIdx.y];
     const int x0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    if (x0 >= HW || !src || !dst) return;
     for (int p = ty; p < 32; p += 8) t[p][tx] = x0 + p < HW ? src[(size_t)(x0 + p) * 32 + tx] : 0.0f;
     __syncthreads();
     for (int f = ty; f < 32; f += 8)
@@ -100,9 +114,132 @@ sg_triplane_fwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
     }
 }
 
+// ---- plane gradient: sort, then segmented scatter ---------------------------------------------------------
+// A plain scatter (one float atomic per texel corner and feature: 1.7e8 memory-side adds for 150k points) was the
+// slowest kernel of a training step (1.2 ms; an avatar's points pile up on the same texels).  Instead:
+//   1. sg_tp_cell_count / bsum / scan / pos   counting sort of the points by the texel cell of the FINEST level they
+//                               fall in (+ parity sub-keys, see sg_tp_sort_key), once per projection (xy, xz, yz): 3 sorts
+//                               serve all 9 planes;
+//   2. sg_tp_bwd_point_kernel   per point: recompute the interpolation, dL/dxyz, and ONE 128-B row per plane
+//                               dL/dfeat * (product of the other two planes) plus a 16-B (cell, weights) record, both
+//                               stored at the point's SORTED slot of that plane (random 128-B writes are fire-and-forget);
+//   3. sg_tp_sorted_scatter_kernel   a half-wave streams 32 consecutive slots (rows and records are sequential in memory)
+//                               and keeps the corner sums of the current texel cell in registers; a row of float atomics
+//                               leaves only when the cell changes: ~2.5e7 atomics instead of 1.7e8 on the avatar, which is
+//                               what is left of the kernel's time (46 us of streaming + ~120 us at the ~0.8 TB/s the
+//                               memory-side float atomics sustain).  Tried and dropped: a texel-owner gather (one
+//                               workgroup per 8x8 texel block, LDS accumulators, no global atomics at all) -- an avatar
+//                               fills ~2 % of the texels, so ~100 workgroups did all the work (19 ms); rows left in point
+//                               order and gathered through the permutation (152 us of dependent random reads).
+//   Avatar cloud, 150k points: 1 180 us (plain scatter) -> 533 us.
+// Sum order inside a texel is not fixed: reproducible to rounding, like the scatter and the reference.
+struct SgTpSort {                      // per projection c: fine grid = max over the scales of the resolutions
+    int Wf[3], Hf[3];
+    int nsub[3], sub_scale[3][SG_TP_MAXS];   // coarser scales of the projection: 2 key bits each (cell parity in x, y)
+    int nkeys[3];                      // Wf * Hf << (2 * nsub)
+    size_t start_off[3];               // uint32 offset of start[c][0 .. nkeys] in the cell workspace
+    size_t bsum_off[3];                // uint32 offset of the 1024-key block sums
+};
+// Sort key of a point for projection c: its cell on the finest grid, then -- because align_corners cells of different
+// levels are NOT nested (63 / 127 / 255 cells across) -- the parity of its cell on every coarser level: a fine cell
+// overlaps at most two coarser cells per axis, so inside one fine cell the points come out grouped by the cell of every
+// level.  (Without the parity bits the points of a fine cell that a coarse boundary crosses alternate between the two
+// coarse cells in arrival order: 60 000 cell changes per plane instead of 12 000 on the avatar.)
+__device__ __forceinline__ uint32_t sg_tp_sort_key(const SgTpDev &d, const SgTpSort &g, int c, const float *__restrict__ xyz, int n)
+{
+    const int a = sg_comb[c][0], b = sg_comb[c][1];
+    const float u = (xyz[3 * (size_t)n + a] - d.a0[a]) * d.ascale[a] - 1.0f;
+    const float v = (xyz[3 * (size_t)n + b] - d.a0[b]) * d.ascale[b] - 1.0f;
+    SgTexel t;
+    sg_texel(u, v, g.Wf[c], g.Hf[c], t);
+    uint32_t key = (uint32_t)(t.y0 * g.Wf[c] + t.x0);
+    for (int i = 0; i < g.nsub[c]; i++) {
+        const int s = g.sub_scale[c][i];
+        sg_texel(u, v, d.res[s][a], d.res[s][b], t);
+        key = (key << 2) | (uint32_t)((t.x0 & 1) | ((t.y0 & 1) << 1));
+    }
+    return key;
+}
 __global__ void __launch_bounds__(256)
-sg_triplane_bwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const float *__restrict__ fm,
-                       const float *__restrict__ dfeats, float *__restrict__ gfm, float *__restrict__ dxyz)
+sg_tp_cell_count_kernel(SgTpDev d, SgTpSort g, int N, const float *__restrict__ xyz, uint32_t *__restrict__ count,
+                        uint32_t *__restrict__ keys, uint32_t *__restrict__ rank)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (n >= N) return;
+    const uint32_t key = sg_tp_sort_key(d, g, c, xyz, n);
+    keys[(size_t)c * N + n] = key;
+    rank[(size_t)c * N + n] = atomicAdd(&count[g.start_off[c] + key], 1u);
+}
+// exclusive scan of the key counters in two launches: sums of 1024-key blocks, then every block adds up the block sums
+// in front of it (<= nkeys / 1024 words) and scans its own keys.  start[i] = number of points with key < i, i in [0, nkeys].
+__global__ void __launch_bounds__(256)
+sg_tp_cell_bsum_kernel(SgTpSort g, const uint32_t *__restrict__ count, uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t sW[4];
+    const int c = blockIdx.y, nkeys = g.nkeys[c];
+    const int i0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    if ((int)blockIdx.x * 1024 > nkeys) return;
+    const uint32_t *cnt = count + g.start_off[c];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) sum += i0 + k < nkeys ? cnt[i0 + k] : 0u;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if ((threadIdx.x & 63) == 0) sW[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[g.bsum_off[c] + blockIdx.x] = sW[0] + sW[1] + sW[2] + sW[3];
+}
+__global__ void __launch_bounds__(256)
+sg_tp_cell_scan_kernel(SgTpSort g, const uint32_t *__restrict__ count, const uint32_t *__restrict__ bsum,
+                       uint32_t *__restrict__ start)
+{
+    __shared__ uint32_t sW[4];
+    __shared__ uint32_t sPre;
+    const int c = blockIdx.y, nkeys = g.nkeys[c];
+    const int base = blockIdx.x * 1024;
+    if (base > nkeys) return;
+    const uint32_t *cnt = count + g.start_off[c];
+    uint32_t pre = 0;
+    for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) pre += bsum[g.bsum_off[c] + i];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) pre += __shfl_xor(pre, o, 64);
+    if (lane == 0) sW[wave] = pre;
+    __syncthreads();
+    if (threadIdx.x == 0) sPre = sW[0] + sW[1] + sW[2] + sW[3];
+    __syncthreads();
+    const int i0 = base + threadIdx.x * 4;
+    uint32_t v[4], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { v[k] = i0 + k < nkeys ? cnt[i0 + k] : 0u; sum += v[k]; }
+    uint32_t incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    __syncthreads();
+    if (lane == 63) sW[wave] = incl;
+    __syncthreads();
+    uint32_t ex = sPre + incl - sum;
+    for (int w = 0; w < wave; w++) ex += sW[w];
+    uint32_t *st = start + g.start_off[c];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { if (i0 + k <= nkeys) st[i0 + k] = ex; ex += v[k]; }
+}
+// pos[c][n] = position of point n in the sorted order of projection c
+__global__ void __launch_bounds__(256)
+sg_tp_cell_pos_kernel(SgTpSort g, int N, const uint32_t *__restrict__ start, const uint32_t *__restrict__ keys,
+                      uint32_t *__restrict__ rank_pos)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+    if (n >= N) return;
+    const uint32_t k = start[g.start_off[c] + keys[(size_t)c * N + n]] + rank_pos[(size_t)c * N + n];
+    rank_pos[(size_t)c * N + n] = k < (uint32_t)N ? k : (uint32_t)N - 1u;
+}
+
+// per point (32 lanes = 32 features): G rows + dL/dxyz.  Same arithmetic as the scatter kernel above.
+__global__ void __launch_bounds__(256)
+sg_tp_bwd_point_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const float *__restrict__ fm,
+                       const float *__restrict__ dfeats, const uint32_t *__restrict__ pos, float *__restrict__ G,
+                       float4 *__restrict__ cellrec, float *__restrict__ dxyz)
 {
     const int n = blockIdx.x * 8 + (threadIdx.x >> 5), f = threadIdx.x & 31;
     if (n >= N) return;
@@ -110,7 +247,7 @@ sg_triplane_bwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
 #pragma unroll
     for (int a = 0; a < 3; a++) p[a] = (xyz[3 * (size_t)n + a] - d.a0[a]) * d.ascale[a] - 1.0f;
     const int F = d.n_scales * SG_TP_FEAT;
-    float dp[3] = { 0.0f, 0.0f, 0.0f };                    // this lane's share of dL/d(normalised coordinate)
+    float dp[3] = { 0.0f, 0.0f, 0.0f };
     for (int s = 0; s < d.n_scales; s++) {
         SgTexel t[3];
         float v[3][4], interp[3];
@@ -131,13 +268,14 @@ sg_triplane_bwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
             const int a = sg_comb[c][0], b = sg_comb[c][1];
             const int W = d.res[s][a];
             const float gi = g * interp[(c + 1) % 3] * interp[(c + 2) % 3];      // dL/d interp_c
-            float *gp = gfm + d.fm_off[s][c];
+            // the row and its (cell, weights) record go to the point's slot in the SORTED order of projection c: the
+            // scatter kernel then streams both (random 128-B writes here are fire-and-forget; random reads there were not)
+            const size_t slot = (size_t)(s * 3 + c) * N + pos[(size_t)c * N + n];
+            G[slot * 32 + f] = gi;
             const float wx = t[c].wx, wy = t[c].wy;
-            unsafeAtomicAdd(&gp[((size_t)t[c].y0 * W + t[c].x0) * 32 + f], gi * ((1.0f - wx) * (1.0f - wy)));
-            unsafeAtomicAdd(&gp[((size_t)t[c].y0 * W + t[c].x1) * 32 + f], gi * (wx * (1.0f - wy)));
-            unsafeAtomicAdd(&gp[((size_t)t[c].y1 * W + t[c].x0) * 32 + f], gi * ((1.0f - wx) * wy));
-            unsafeAtomicAdd(&gp[((size_t)t[c].y1 * W + t[c].x1) * 32 + f], gi * (wx * wy));
-            // d interp / d ix = (v01 - v00)(1 - wy) + (v11 - v10) wy ;  d / d iy = (v10 - v00)(1 - wx) + (v11 - v01) wx
+            if (f == 0)
+                cellrec[slot] = make_float4(__uint_as_float((uint32_t)(t[c].y0 * W + t[c].x0)),
+                                            __uint_as_float((uint32_t)(t[c].y1 * W + t[c].x1)), wx, wy);
             dp[a] += gi * ((v[c][1] - v[c][0]) * (1.0f - wy) + (v[c][3] - v[c][2]) * wy) * t[c].gx;
             dp[b] += gi * ((v[c][2] - v[c][0]) * (1.0f - wx) + (v[c][3] - v[c][1]) * wx) * t[c].gy;
         }
@@ -147,9 +285,71 @@ sg_triplane_bwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
         for (int a = 0; a < 3; a++) {
             float r = dp[a];
 #pragma unroll
-            for (int o = 16; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);       // over the 32 features of this point
+            for (int o = 16; o > 0; o >>= 1) r += __shfl_xor(r, o, 64);
             if (f == 0) dxyz[3 * (size_t)n + a] = r * d.ascale[a];
         }
+    }
+}
+
+#define SG_TP_RUN 32                   // consecutive sorted points per half-wave
+// blockIdx.y = plane (s, c).  Every half-wave (32 lanes = 32 features) walks SG_TP_RUN consecutive slots of the
+// projection's sorted order -- G rows and (cell, weights) records are sequential in memory -- and keeps the four
+// corner sums of the CURRENT texel cell in registers; they leave through one row of float atomics per corner only when
+// the cell changes.  Consecutive points share the cell of every level most of the time: the avatar's 1.7e8 atomics
+// become a few million, and the work is balanced by construction (points, not texels, are dealt out).
+__global__ void __launch_bounds__(256)
+sg_tp_sorted_scatter_kernel(SgTpDev d, int N, const float *__restrict__ G, const float4 *__restrict__ cellrec,
+                            float *__restrict__ gfm)
+{
+    const int sc = blockIdx.y, s = sc / 3, c = sc % 3;
+    const int f = threadIdx.x & 31;
+    const int k0 = (blockIdx.x * 8 + (threadIdx.x >> 5)) * SG_TP_RUN;
+    if (k0 >= N) return;
+    const int k1 = min(k0 + SG_TP_RUN, N);
+    const float *Gp = G + (size_t)sc * N * 32;
+    const float4 *rp = cellrec + (size_t)sc * N;
+    float *gp = gfm + d.fm_off[s][c];
+    const int W = d.res[s][sg_comb[c][0]];
+    uint32_t c00 = 0xffffffffu, c11 = 0;
+    float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
+    for (int k = k0; k < k1; k += 8) {
+        float4 r[8];
+        float gi[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int kk = min(k + j, k1 - 1);
+            r[j] = rp[kk];
+            gi[j] = k + j < k1 ? Gp[(size_t)kk * 32 + f] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (k + j >= k1) break;
+            const uint32_t n00 = __float_as_uint(r[j].x), n11 = __float_as_uint(r[j].y);
+            if (n00 != c00) {
+                if (c00 != 0xffffffffu) {
+                    // corners: (y0,x0) = c00, (y1,x1) = c11, (y0,x1) = c00 + dx, (y1,x0) = c11 - dx, dx = x1 - x0
+                    const uint32_t dx = (c11 - c00) % (uint32_t)W;
+                    unsafeAtomicAdd(&gp[(size_t)c00 * 32 + f], acc00);
+                    unsafeAtomicAdd(&gp[(size_t)(c00 + dx) * 32 + f], acc01);
+                    unsafeAtomicAdd(&gp[(size_t)(c11 - dx) * 32 + f], acc10);
+                    unsafeAtomicAdd(&gp[(size_t)c11 * 32 + f], acc11);
+                }
+                c00 = n00; c11 = n11;
+                acc00 = acc01 = acc10 = acc11 = 0.0f;
+            }
+            const float wx = r[j].z, wy = r[j].w;
+            acc00 += gi[j] * ((1.0f - wx) * (1.0f - wy));
+            acc01 += gi[j] * (wx * (1.0f - wy));
+            acc10 += gi[j] * ((1.0f - wx) * wy);
+            acc11 += gi[j] * (wx * wy);
+        }
+    }
+    if (c00 != 0xffffffffu) {
+        const uint32_t dx = (c11 - c00) % (uint32_t)W;
+        unsafeAtomicAdd(&gp[(size_t)c00 * 32 + f], acc00);
+        unsafeAtomicAdd(&gp[(size_t)(c00 + dx) * 32 + f], acc01);
+        unsafeAtomicAdd(&gp[(size_t)(c11 - dx) * 32 + f], acc10);
+        unsafeAtomicAdd(&gp[(size_t)c11 * 32 + f], acc11);
     }
 }
 
@@ -267,12 +467,15 @@ size_t sg_triplane_ws_bytes_impl(const SgTriplane *tp)
 static void sg_tp_upload(const SgTriplane *tp, const SgTpDev &d, float *fm, hipStream_t st)
 {
     const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    SgTpPlanes P;
+    int maxHW = 0;
     for (int s = 0; s < tp->n_scales; s++)
         for (int c = 0; c < 3; c++) {
             const int HW = tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]];
-            hipLaunchKernelGGL(sg_plane_to_fm_kernel, dim3((HW + 31) / 32), dim3(256), 0, st, tp->planes[s][c],
-                               fm + d.fm_off[s][c], HW);
+            P.src[s * 3 + c] = tp->planes[s][c]; P.dst[s * 3 + c] = fm + d.fm_off[s][c]; P.HW[s * 3 + c] = HW;
+            maxHW = HW > maxHW ? HW : maxHW;
         }
+    hipLaunchKernelGGL(sg_plane_to_fm_kernel, dim3((maxHW + 31) / 32, tp->n_scales * 3), dim3(256), 0, st, P);
 }
 void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st)
 {
@@ -282,23 +485,81 @@ void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void 
     sg_tp_upload(tp, d, fm, st);
     hipLaunchKernelGGL(sg_triplane_fwd_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, feats);
 }
+static void sg_tp_sort_layout(const SgTriplane *tp, SgTpSort *g, size_t *cell_words, size_t *bsum_words)
+{
+    const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    size_t o = 0, ob = 0;
+    for (int c = 0; c < 3; c++) {
+        int wf = 2, hf = 2;
+        for (int s = 0; s < tp->n_scales; s++) {
+            wf = tp->res[s][comb[c][0]] > wf ? tp->res[s][comb[c][0]] : wf;
+            hf = tp->res[s][comb[c][1]] > hf ? tp->res[s][comb[c][1]] : hf;
+        }
+        g->Wf[c] = wf; g->Hf[c] = hf;
+        g->nsub[c] = 0;
+        for (int s = 0; s < tp->n_scales; s++)
+            if (tp->res[s][comb[c][0]] != wf || tp->res[s][comb[c][1]] != hf) g->sub_scale[c][g->nsub[c]++] = s;
+        // key space capped at 2^24: past that the coarsest sub-keys are dropped (still a valid sort, more cell changes)
+        while (g->nsub[c] > 0 && ((size_t)wf * hf << (2 * g->nsub[c])) > ((size_t)1 << 24)) g->nsub[c]--;
+        g->nkeys[c] = (int)((size_t)wf * hf << (2 * g->nsub[c]));
+        g->start_off[c] = o;
+        o += ((size_t)g->nkeys[c] + 1 + 63) & ~(size_t)63;
+        g->bsum_off[c] = ob;
+        ob += ((size_t)g->nkeys[c] / 1024 + 1 + 63) & ~(size_t)63;
+    }
+    *cell_words = o; *bsum_words = ob;
+}
+// backward workspace: texel-major planes | texel-major gradients | G rows [S*3][N][32] | count | start | block sums |
+// keys | rank / sorted position | (cell, weights) records [S*3][N]
+size_t sg_triplane_bwd_ws_bytes_impl(const SgTriplane *tp, int N)
+{
+    SgTpDev d; SgTpSort g; size_t cw, bw;
+    const size_t floats = sg_tp_layout(tp, &d), n = N > 0 ? N : 1;
+    sg_tp_sort_layout(tp, &g, &cw, &bw);
+    return 2 * sg_align(floats * 4) + sg_align((size_t)tp->n_scales * 3 * n * 32 * 4) + 2 * sg_align(cw * 4) +
+           sg_align(bw * 4) + 2 * sg_align(3 * n * 4) + sg_align((size_t)tp->n_scales * 3 * n * 16);
+}
 int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
                            float *const dplanes[SG_TP_MAXS][3], float *dxyz, hipStream_t st)
 {
-    SgTpDev d;
-    const size_t floats = sg_tp_layout(tp, &d);
-    float *fm = (float *)ws, *gfm = (float *)((char *)ws + sg_align(floats * 4));
-    sg_tp_upload(tp, d, fm, st);                              // (parameters may have changed since the forward call)
-    if (hipMemsetAsync(gfm, 0, floats * 4, st) != hipSuccess) return 1;
-    hipLaunchKernelGGL(sg_triplane_bwd_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, dfeats, gfm, dxyz);
+    SgTpDev d; SgTpSort g; size_t cw, bw;
+    const size_t floats = sg_tp_layout(tp, &d), n = N;
+    sg_tp_sort_layout(tp, &g, &cw, &bw);
+    char *b = (char *)ws;
+    float *fm = (float *)b; b += sg_align(floats * 4);
+    float *gfm = (float *)b; b += sg_align(floats * 4);
+    float *G = (float *)b; b += sg_align((size_t)tp->n_scales * 3 * n * 32 * 4);
+    uint32_t *count = (uint32_t *)b; b += sg_align(cw * 4);
+    uint32_t *start = (uint32_t *)b; b += sg_align(cw * 4);
+    uint32_t *bsum = (uint32_t *)b; b += sg_align(bw * 4);
+    uint32_t *keys = (uint32_t *)b; b += sg_align(3 * n * 4);
+    uint32_t *rank = (uint32_t *)b; b += sg_align(3 * n * 4);          // arrival rank inside the key, then sorted position
+    float4 *cellrec = (float4 *)b;
     const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    sg_tp_upload(tp, d, fm, st);                              // (parameters may have changed since the forward call)
+    if (hipMemsetAsync(count, 0, cw * 4, st) != hipSuccess) return 1;
+    const int nb = (N + 255) / 256;
+    int max_keys = 0;
+    for (int c = 0; c < 3; c++) max_keys = g.nkeys[c] > max_keys ? g.nkeys[c] : max_keys;
+    if (hipMemsetAsync(gfm, 0, floats * 4, st) != hipSuccess) return 1;
+    const int nkb = max_keys / 1024 + 1;
+    hipLaunchKernelGGL(sg_tp_cell_count_kernel, dim3(nb, 3), dim3(256), 0, st, d, g, N, xyz, count, keys, rank);
+    hipLaunchKernelGGL(sg_tp_cell_bsum_kernel, dim3(nkb, 3), dim3(256), 0, st, g, count, bsum);
+    hipLaunchKernelGGL(sg_tp_cell_scan_kernel, dim3(nkb, 3), dim3(256), 0, st, g, count, bsum, start);
+    hipLaunchKernelGGL(sg_tp_cell_pos_kernel, dim3(nb, 3), dim3(256), 0, st, g, N, start, keys, rank);
+    hipLaunchKernelGGL(sg_tp_bwd_point_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, dfeats, rank, G, cellrec,
+                       dxyz);
+    hipLaunchKernelGGL(sg_tp_sorted_scatter_kernel, dim3((N + 8 * SG_TP_RUN - 1) / (8 * SG_TP_RUN), tp->n_scales * 3),
+                       dim3(256), 0, st, d, N, G, cellrec, gfm);
+    SgTpPlanes P;
+    int maxHW = 0;
     for (int s = 0; s < tp->n_scales; s++)
         for (int c = 0; c < 3; c++) {
-            if (!dplanes[s][c]) continue;
             const int HW = tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]];
-            hipLaunchKernelGGL(sg_plane_from_fm_kernel, dim3((HW + 31) / 32), dim3(256), 0, st, gfm + d.fm_off[s][c],
-                               dplanes[s][c], HW);
+            P.src[s * 3 + c] = gfm + d.fm_off[s][c]; P.dst[s * 3 + c] = dplanes[s][c]; P.HW[s * 3 + c] = HW;
+            maxHW = HW > maxHW ? HW : maxHW;
         }
+    hipLaunchKernelGGL(sg_plane_from_fm_kernel, dim3((maxHW + 31) / 32, tp->n_scales * 3), dim3(256), 0, st, P);
     return 0;
 }
 

@@ -74,7 +74,7 @@ class _Triplane(torch.autograd.Function):
         keep = []
         tp = _tp_struct(grids, aabb, keep)
         dev, N = x.device, int(x.shape[0])
-        ws = torch.empty(int(lib.sg_triplane_ws_bytes(C.byref(tp))), dtype=torch.uint8, device=dev)
+        ws = torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
         dplanes = [torch.empty_like(p, dtype=torch.float32) for p in planes]
         arr = ((C.c_void_p * 3) * 4)()
         for s in range(n_scales):

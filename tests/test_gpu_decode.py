@@ -119,3 +119,36 @@ def test_shipped_config_vs_oracle_and_decode_attributes():
     ref_scales = og['scales'].clone(); ref_scales[:, -1] *= 0.5; ref_scales = ref_scales * 2.0
     _close(out["scales"].detach().cpu().numpy(), ref_scales.numpy(), rtol=1e-4, atol_scale=1e-5)
     _close(out["xyz_canon"].detach().cpu().numpy(), (pts_c + og['xyz_offsets']).numpy(), rtol=1e-4, atol_scale=1e-5)
+
+
+def test_triplane_backward_clustered_and_border_points():
+    """The plane gradient is a sort + segmented scatter: a cloud that piles thousands of points on a few texel cells
+    (an avatar in its bounding box), exact duplicates, points on / beyond the box faces and on texel-cell boundaries of
+    every level, N not a multiple of the 32-point runs -- against the CPU oracle.  Non-cubic resolution."""
+    from sings_amd.decode import HexPlaneField
+    dev = _dev()
+    torch.manual_seed(3)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [24, 16, 20], 'multires': [1, 2, 4]}
+    f = HexPlaneField(cfg, bounds=1.0, device=dev)
+    blob = torch.randn(6000, 3) * 0.02 + torch.tensor([0.31, -0.12, 0.05])
+    dup = blob[:500].clone()
+    faces = torch.rand(300, 3) * 2 - 1
+    faces[:100, 0] = 1.0; faces[100:200, 1] = -1.0; faces[200:250, 2] = 1.3; faces[250:, 0] = -1.7
+    lattice = torch.stack(torch.meshgrid(torch.linspace(-1, 1, 24), torch.linspace(-1, 1, 31), torch.linspace(-1, 1, 5),
+                                         indexing="ij"), -1).reshape(-1, 3)       # exact texel coordinates of level 0 in x
+    pts_c = torch.cat([blob, dup, faces, lattice, torch.rand(1237, 3) * 2 - 1])
+    N = pts_c.shape[0]
+    assert N % 32 != 0
+    w_c = torch.randn(N, 96)
+    pts = pts_c.to(dev).requires_grad_(True)
+    feats = f(pts)
+    (feats * w_c.to(dev)).sum().backward()
+    grids_c = [[p.detach().cpu().clone().requires_grad_(True) for p in gp] for gp in f.grids]
+    pc = pts_c.clone().requires_grad_(True)
+    fo = do.triplane_features(pc, grids_c, f.aabb.detach().cpu())
+    (fo * w_c).sum().backward()
+    _close(feats.detach().cpu().numpy(), fo.detach().numpy())
+    _close(pts.grad.cpu().numpy(), pc.grad.numpy(), rtol=1e-4, atol_scale=1e-5)
+    for gp, gc in zip(f.grids, grids_c):
+        for p, q in zip(gp, gc):
+            _close(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-4, atol_scale=2e-5)
