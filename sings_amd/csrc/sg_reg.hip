@@ -366,7 +366,9 @@ sg_cells_finalize_kernel(const SgGrid *__restrict__ grid, const uint32_t *__rest
 // One lane per (cell-sorted) point: grow a cube of cells around the point's cell ring by ring; the K best squared
 // distances sit in registers (sorted insertion).  The search is complete when the K-th best distance is no larger than
 // the distance from the point to the faces of the searched cube.  Lanes of a wave are neighbours in space, so their
-// candidate loads hit the same lines; candidates are fetched four at a time to keep several loads in flight.
+// candidate loads hit the same lines; candidates are fetched four at a time to keep several loads in flight.  Inside a
+// ring, rows and cells farther from the point than its current K-th best are skipped (a dense point finds its K
+// neighbours in its own cell and then touches 2-3 of the 26 cells around it instead of all of them).
 // (Two wave-cooperative variants -- union box per wave, shared (y,z) row groups -- were slower on avatar-like clouds
 //  whose density varies 100x: every sparse lane drags its whole wave through wide boxes.)
 template <int K>
@@ -383,33 +385,63 @@ __device__ __forceinline__ float sg_d2(float4 q, float4 p)
     return dx * dx + dy * dy + dz * dz;
 }
 
+// Two grids over the same cloud: the coarse one (~4N cells) and a fine one (~64N cells, 2.5x smaller cells).  A point
+// whose coarse cell holds more than SG_KNN_DENSE points searches the fine grid: an avatar's density varies 100x (the
+// median coarse cell holds 4 points, 10 % of the points sit in cells of 300+), and a dense point otherwise compares
+// itself with the ~2 500 points of its 27 coarse cells.  Either search is exact -- the level only changes the cost.
+#define SG_KNN_DENSE 24
 template <int K>
 __global__ void __launch_bounds__(256)
-sg_knn_query_kernel(int N, const float4 *__restrict__ sorted, const SgGrid *__restrict__ grid,
-                    const uint2 *__restrict__ cells, float *__restrict__ mean_edge)
+sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__restrict__ grid_c,
+                    const uint2 *__restrict__ cells_c, const float4 *__restrict__ sorted_f,
+                    const SgGrid *__restrict__ grid_f, const uint2 *__restrict__ cells_f, float *__restrict__ mean_edge)
 {
+    // (A variant with 8 lanes per point -- same rows, every 8th candidate each, K-best lists merged per ring -- was
+    //  measured: no faster at 150k points, 13 % slower at 500k; the merges cost what the extra parallelism gains.)
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= N) return;
-    const SgGrid g = *grid;
-    const float4 p = sorted[s];
+    const float4 p = sorted_c[s];
+    SgGrid g = *grid_c;
+    const uint2 *__restrict__ cells = cells_c;
+    const float4 *__restrict__ sorted = sorted_c;
     int c0[3];
     sg_cell_of(g, p.x, p.y, p.z, c0);
+    if (cells_c[(c0[2] * g.dim[1] + c0[1]) * g.dim[0] + c0[0]].y > SG_KNN_DENSE) {
+        g = *grid_f; cells = cells_f; sorted = sorted_f;
+        sg_cell_of(g, p.x, p.y, p.z, c0);
+    }
     const float cx = (p.x - g.lo[0]) * g.inv_h, cy = (p.y - g.lo[1]) * g.inv_h, cz = (p.z - g.lo[2]) * g.inv_h;
     float best[K];
 #pragma unroll
     for (int k = 0; k < K; k++) best[k] = 3e38f;
     const int rmax = max(max(g.dim[0], g.dim[1]), g.dim[2]);
+    const float inv_h2 = g.inv_h * g.inv_h;
     for (int r = 0; r <= rmax; r++) {
         const int x0 = max(c0[0] - r, 0), x1 = min(c0[0] + r, g.dim[0] - 1);
         const int y0 = max(c0[1] - r, 0), y1 = min(c0[1] + r, g.dim[1] - 1);
         const int z0 = max(c0[2] - r, 0), z1 = min(c0[2] + r, g.dim[2] - 1);
-        for (int z = z0; z <= z1; z++)
+        for (int z = z0; z <= z1; z++) {
+            // squared distance (in cell units) from p to the slab of cells z / the row (y, z): rows and cells that lie
+            // farther than the current K-th best (inf until K points are known) cannot improve it and are skipped
+            // (0.999 / 1.001: rounding of the cell maths)
+            const float ez = fmaxf(fmaxf((float)z - cz, cz - (float)(z + 1)), 0.0f);
             for (int y = y0; y <= y1; y++) {
+                const float ey = fmaxf(fmaxf((float)y - cy, cy - (float)(y + 1)), 0.0f);
+                const float lim = best[K - 1] * inv_h2;
+                const float dyz = (ey * ey + ez * ez) * 0.999f;
+                if (dyz >= lim) continue;
                 const bool shell_row = (abs(z - c0[2]) == r) || (abs(y - c0[1]) == r);
                 const uint32_t row = (uint32_t)((z * g.dim[1] + y) * g.dim[0]);
                 if (shell_row) {
-                    // the whole x range belongs to the ring and is ONE contiguous run of the sorted array
-                    const uint2 ca = cells[row + x0], cb = cells[row + x1];
+                    // the x range of the ring, cut to the cells within the K-th best distance, is ONE contiguous run of
+                    // the sorted array
+                    int xa = x0, xb = x1;
+                    if (lim < 1e30f) {
+                        const float rad = sqrtf(lim - dyz) * 1.001f + 1e-3f;
+                        xa = max(xa, (int)floorf(cx - rad)); xb = min(xb, (int)floorf(cx + rad));
+                        if (xa > xb) continue;
+                    }
+                    const uint2 ca = cells[row + xa], cb = cells[row + xb];
                     uint32_t t = ca.x;
                     const uint32_t e = cb.x + cb.y;
                     for (; t + 4 <= e; t += 4) {
@@ -423,11 +455,14 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted, const SgGrid *__re
                     for (int side = 0; side < 2; side++) {
                         const int x = side ? c0[0] + r : c0[0] - r;
                         if (x < 0 || x >= g.dim[0]) continue;
+                        const float ex = fmaxf(fmaxf((float)x - cx, cx - (float)(x + 1)), 0.0f);
+                        if (dyz + ex * ex * 0.999f >= best[K - 1] * inv_h2) continue;
                         const uint2 cc = cells[row + x];
                         for (uint32_t t = cc.x; t < cc.x + cc.y; t++) sg_knn_insert<K>(sg_d2(sorted[t], p), best);
                     }
                 }
             }
+        }
         // distance from p to the nearest face of the searched cube that is not the grid boundary
         float reach = 3e38f;
         if (c0[0] - r > 0) reach = fminf(reach, cx - (float)(c0[0] - r));
@@ -505,36 +540,34 @@ void sg_launch_l2norm(int N, const float *off, const float *scales, const float 
                            d_scales, d_opacity);
 }
 
-// workspace of the k-NN search: grid struct, partials, per-point cell / rank, sorted points, cell counters + starts
+// workspace of the k-NN search: partials, then per grid (coarse, fine): grid struct, per-point cell / rank, sorted points,
+// cell counters + starts + block sums + (start, count) pairs
 static inline int sg_knn_max_cells(int N) { long long c = 4LL * N; if (c < 4096) c = 4096; if (c > (1 << 23)) c = 1 << 23; return (int)c; }
+static inline int sg_knn_max_cells_fine(int N) { long long c = 64LL * N; if (c < 4096) c = 4096; if (c > (1 << 25)) c = 1 << 25; return (int)c; }
+static size_t sg_knn_grid_bytes(size_t n, size_t mc)
+{
+    return 256 + 2 * sg_align(n * 4) + sg_align(n * 16) + 2 * sg_align(mc * 4) + sg_align(((mc + 1023) / 1024) * 4) + sg_align(mc * 8);
+}
 size_t sg_knn_ws_bytes_impl(int N)
 {
-    const size_t n = N > 0 ? N : 1, mc = sg_knn_max_cells(N);
-    return 256 + sg_align((size_t)sg_nb(N) * 32) + 2 * sg_align(n * 4) + sg_align(n * 16) + 2 * sg_align(mc * 4) +
-           sg_align(((mc + 1023) / 1024) * 4) + sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4) + sg_align(n * 4) +
-           sg_align(mc * 8);
+    const size_t n = N > 0 ? N : 1;
+    return sg_align((size_t)sg_nb(N) * 32) + sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4) + sg_align(n * 4) +
+           sg_knn_grid_bytes(n, sg_knn_max_cells(N)) + sg_knn_grid_bytes(n, sg_knn_max_cells_fine(N));
 }
-
-int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
-                       const float *upstream, float *d_scales, hipStream_t st)
+struct SgKnnGrid { SgGrid *grid; float4 *sorted; uint2 *cells; };
+// bounding box partials -> grid -> counting sort of the points by cell
+static int sg_knn_build(int N, const float *xyz, const float *bpart, size_t mc, char *&b, SgKnnGrid *out, hipStream_t st)
 {
-    if (K != 9 && K != 5 && K != 17) return 1;
-    const size_t n = N, mc = sg_knn_max_cells(N);
-    char *b = (char *)ws;
+    const size_t n = N;
     SgGrid *grid = (SgGrid *)b; b += 256;
-    float *bpart = (float *)b; b += sg_align((size_t)sg_nb(N) * 32);
     uint32_t *cell_of = (uint32_t *)b; b += sg_align(n * 4);
     uint32_t *rank_in = (uint32_t *)b; b += sg_align(n * 4);
     float4 *sorted = (float4 *)b; b += sg_align(n * 16);
     uint32_t *count = (uint32_t *)b; b += sg_align(mc * 4);
     uint32_t *start = (uint32_t *)b; b += sg_align(mc * 4);
     uint32_t *bsum = (uint32_t *)b; b += sg_align(((mc + 1023) / 1024) * 4);
-    float *partial = (float *)b; b += sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4);
-    float *medge = mean_edge_out ? mean_edge_out : (float *)b;
-    b += sg_align(n * 4);
-    uint2 *cells = (uint2 *)b;
+    uint2 *cells = (uint2 *)b; b += sg_align(mc * 8);
     const int nb = sg_nb(N), ncb = (int)((mc + 1023) / 1024);
-    hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(nb), dim3(256), 0, st, N, xyz, bpart);
     hipLaunchKernelGGL(sg_grid_setup_kernel, dim3(1), dim3(256), 0, st, bpart, nb, N, (int)mc, grid);
     if (hipMemsetAsync(count, 0, mc * 4, st) != hipSuccess) return 2;
     hipLaunchKernelGGL(sg_cell_count_kernel, dim3(nb), dim3(256), 0, st, N, xyz, grid, cell_of, rank_in, count);
@@ -542,9 +575,29 @@ int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void
     hipLaunchKernelGGL(sg_cells_scan2_kernel, dim3(1), dim3(1024), 0, st, grid, bsum);
     hipLaunchKernelGGL(sg_cell_scatter_kernel, dim3(nb), dim3(256), 0, st, N, xyz, cell_of, rank_in, start, bsum, sorted);
     hipLaunchKernelGGL(sg_cells_finalize_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, st, grid, count, start, bsum, cells);
-    if (K == 9) hipLaunchKernelGGL(sg_knn_query_kernel<9>, dim3(nb), dim3(256), 0, st, N, sorted, grid, cells, medge);
-    else if (K == 5) hipLaunchKernelGGL(sg_knn_query_kernel<5>, dim3(nb), dim3(256), 0, st, N, sorted, grid, cells, medge);
-    else hipLaunchKernelGGL(sg_knn_query_kernel<17>, dim3(nb), dim3(256), 0, st, N, sorted, grid, cells, medge);
+    out->grid = grid; out->sorted = sorted; out->cells = cells;
+    return 0;
+}
+
+int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
+                       const float *upstream, float *d_scales, hipStream_t st)
+{
+    if (K != 9 && K != 5 && K != 17) return 1;
+    const size_t n = N;
+    char *b = (char *)ws;
+    float *bpart = (float *)b; b += sg_align((size_t)sg_nb(N) * 32);
+    float *partial = (float *)b; b += sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4);
+    float *medge = mean_edge_out ? mean_edge_out : (float *)b;
+    b += sg_align(n * 4);
+    const int nb = sg_nb(N);
+    hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(nb), dim3(256), 0, st, N, xyz, bpart);
+    SgKnnGrid gc, gf;
+    const int nbq = nb;
+    if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells(N), b, &gc, st)) return 2;
+    if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells_fine(N), b, &gf, st)) return 2;
+    if (K == 9) hipLaunchKernelGGL(sg_knn_query_kernel<9>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
+    else if (K == 5) hipLaunchKernelGGL(sg_knn_query_kernel<5>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
+    else hipLaunchKernelGGL(sg_knn_query_kernel<17>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
     if (scales && (loss || d_scales)) {
         hipLaunchKernelGGL(sg_edge_loss_kernel, dim3(nb), dim3(256), 0, st, N, scales, medge, upstream, d_scales, partial);
         if (loss) hipLaunchKernelGGL(sg_scalar_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f / (float)N, loss);

@@ -14,7 +14,8 @@ def timeit(f, n=30):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e6
 
 
-for N in (150000, 500000):
+SIZES = [int(a) for a in sys.argv[1:]] or [150000, 500000]
+for N in SIZES:
     s = avatar_scene(N=N, J=52)
     x = torch.from_numpy(s["xyz_canon"]).to(dev)
     sc = torch.from_numpy(s["scales"]).to(dev).requires_grad_(True)
