@@ -683,6 +683,73 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     if (half == 0) bpartial[(size_t)blockIdx.x * cout_pad + o] = bsum;
 }
 
+// Heads with <= 4 outputs (xyz offsets, scale, opacity): the product is a handful of dot products per input column --
+// a streaming read of x (HBM-bound) instead of a 32-row MFMA tile of which 1-3 rows are used (80 us for 128 inputs).
+// Thread = one float4 of input columns x one of 256 / (Cin / 4) row phases; fixed-order tree over the phases in LDS.
+template <int CO>
+__global__ void __launch_bounds__(256)
+sg_wgrad_small_kernel(int N, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
+                      float *__restrict__ partial, float *__restrict__ bpartial)
+{
+    __shared__ float4 sAcc[CO][256];
+    __shared__ float sB[CO][256];
+    const int c4n = Cin >> 2, c4 = threadIdx.x % c4n, ph = threadIdx.x / c4n, nph = 256 / c4n;
+    float4 acc[CO];
+    float bs[CO];
+#pragma unroll
+    for (int c = 0; c < CO; c++) { acc[c] = make_float4(0, 0, 0, 0); bs[c] = 0.0f; }
+    if (ph < nph) {
+        const int stride = gridDim.x * nph;
+        int r = blockIdx.x * nph + ph;
+        for (; r + 3 * stride < N; r += 4 * stride) {
+            float4 xv[4];
+            float g[4][CO];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                xv[u] = *(const float4 *)(x + (size_t)(r + u * stride) * Cin + 4 * c4);
+#pragma unroll
+                for (int c = 0; c < CO; c++) g[u][c] = dz[(size_t)(r + u * stride) * CO + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+#pragma unroll
+                for (int c = 0; c < CO; c++) {
+                    acc[c].x += g[u][c] * xv[u].x; acc[c].y += g[u][c] * xv[u].y;
+                    acc[c].z += g[u][c] * xv[u].z; acc[c].w += g[u][c] * xv[u].w;
+                    bs[c] += g[u][c];
+                }
+        }
+        for (; r < N; r += stride) {
+            const float4 xv = *(const float4 *)(x + (size_t)r * Cin + 4 * c4);
+#pragma unroll
+            for (int c = 0; c < CO; c++) {
+                const float g = dz[(size_t)r * CO + c];
+                acc[c].x += g * xv.x; acc[c].y += g * xv.y; acc[c].z += g * xv.z; acc[c].w += g * xv.w;
+                bs[c] += g;
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CO; c++) { sAcc[c][threadIdx.x] = acc[c]; sB[c][threadIdx.x] = bs[c]; }
+    __syncthreads();
+    if (ph == 0) {
+#pragma unroll
+        for (int c = 0; c < CO; c++) {
+            float4 t = make_float4(0, 0, 0, 0);
+            for (int q = 0; q < nph; q++) {
+                const float4 v = sAcc[c][q * c4n + c4];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            *(float4 *)(partial + ((size_t)blockIdx.x * CO + c) * Cin + 4 * c4) = t;
+            if (c4 == 0) {                                     // every phase saw the same dz rows only once: column 0's copy
+                float b = 0.0f;
+                for (int q = 0; q < nph; q++) b += sB[c][q * c4n];
+                bpartial[(size_t)blockIdx.x * CO + c] = b;
+            }
+        }
+    }
+}
+
 // 16 output elements x 16 slices of the per-workgroup partials per 256-thread workgroup (fixed slices, fixed order):
 // the sum over <= 256 partials is latency-bound, so it is spread over many short chains
 __global__ void __launch_bounds__(256)
@@ -727,12 +794,24 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
                           hipStream_t st)
 {
     if (Cin % 32 != 0 || Cin > 128 || Cout > 128 || Cout < 1) return 1;
-    const int cp = ((Cout + 31) / 32) * 32, nwg = sg_wg_count(N), ti = Cin / 32;
+    int cp = ((Cout + 31) / 32) * 32;
+    const int nwg = sg_wg_count(N), ti = Cin / 32;
     float *partial = (float *)ws;
     float *bpartial = (float *)((char *)ws + sg_align((size_t)nwg * cp * Cin * 4));
+    if (Cout <= 4) {
+        // (partials are [nwg][Cout][Cin] here: the reduce kernel takes the row pitch as a parameter)
+        switch (Cout) {
+        case 1: hipLaunchKernelGGL(sg_wgrad_small_kernel<1>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
+        case 2: hipLaunchKernelGGL(sg_wgrad_small_kernel<2>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
+        case 3: hipLaunchKernelGGL(sg_wgrad_small_kernel<3>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
+        default: hipLaunchKernelGGL(sg_wgrad_small_kernel<4>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
+        }
+        cp = Cout;
+    } else {
 #define SG_WGK(T) hipLaunchKernelGGL(sg_wgrad_kernel<T>, dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
-    switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
+        switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
 #undef SG_WGK
+    }
     hipLaunchKernelGGL(sg_wgrad_reduce_kernel, dim3((Cout * Cin + Cout + 15) / 16), dim3(256), 0, st, partial, bpartial, nwg,
                        Cout, Cin, cp, dW, db);
     return 0;

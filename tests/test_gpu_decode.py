@@ -152,3 +152,25 @@ def test_triplane_backward_clustered_and_border_points():
     for gp, gc in zip(f.grids, grids_c):
         for p, q in zip(gp, gc):
             _close(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-4, atol_scale=2e-5)
+
+
+def test_weight_grad_shapes():
+    """sg_weight_grad over the shapes the decoders use and the edges of its two code paths (<= 4 outputs: streaming
+    dot products; more: MFMA tiles): dW = dz^T x, db = column sums, against float64."""
+    import ctypes as C
+    from sings_amd import _lib
+    dev = _dev()
+    lib = _lib.load()
+    torch.manual_seed(5)
+    for N in (1, 37, 10007):
+        for Cin in (32, 64, 96, 128):
+            for Cout in (1, 2, 3, 4, 5, 48, 128):
+                dz = torch.randn(N, Cout, device=dev); x = torch.randn(N, Cin, device=dev)
+                dW = torch.empty(Cout, Cin, device=dev); db = torch.empty(Cout, device=dev)
+                ws = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
+                _lib.check(lib.sg_weight_grad(N, Cout, Cin, C.c_void_p(dz.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                              C.c_void_p(dW.data_ptr()), C.c_void_p(db.data_ptr()),
+                                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "weight gradient")
+                ref = dz.double().t() @ x.double()
+                _close(dW.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol_scale=1e-5, what=f"dW {N} {Cout} {Cin}")
+                _close(db.cpu().numpy(), dz.double().sum(0).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, what=f"db {N} {Cout} {Cin}")
