@@ -455,6 +455,55 @@ def test_engine_step_replays_from_a_hip_graph():
     assert eng.num_rendered() <= eng.cap
 
 
+def test_views_in_flight_on_two_streams_match_sequential_runs():
+    """bench.py renders the views of a step through one engine per view (own workspaces, own row of a shared gradient
+    buffer) spread over two HIP streams.  The library keeps no state between calls, so views in flight at the same time
+    must give bit for bit what the same engines give one after the other on one stream."""
+    from sings_amd.engine import RasterEngine
+    dev = _dev()
+    s = synthetic_scene(20000, 512, 384, 3, 21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(s["dL_dimage"])
+    K = 4
+    per = 20000 * (3 + 3 + 4 + 1 + 3 * 16)
+    grads = torch.zeros((K, per), device=dev)
+    engs = []
+    for v in range(K):
+        sv = dict(s)
+        view = s["viewmatrix"].copy(); view[3, 0] = 0.05 * v
+        sv["viewmatrix"] = view
+        sv["projmatrix"] = (view @ (np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"])).astype(np.float32)
+        sv["campos"] = np.linalg.inv(view)[3, :3].astype(np.float32)
+        e = RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=8 * 20000 + 65536, grad_flat=grads[v])
+        e.set_camera(_settings(sv, dev))
+        engs.append(e)
+    for e in engs:                                               # sequential reference
+        e.forward(*ins); e.backward(*ins, dL)
+    torch.cuda.synchronize()
+    ref_g = grads.clone(); ref_c = [e.color.clone() for e in engs]
+    assert not torch.equal(ref_c[0], ref_c[1])                   # (the cameras really differ)
+    grads.zero_()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    cur = torch.cuda.current_stream(dev)
+    for rep in range(3):
+        for st in streams:
+            st.wait_stream(cur)
+        for v, e in enumerate(engs):
+            with torch.cuda.stream(streams[v % 2]):
+                e.forward(*ins); e.backward(*ins, dL)
+        for st in streams:
+            cur.wait_stream(st)
+    total = torch.sum(grads, dim=0)
+    torch.cuda.synchronize()
+    assert torch.equal(grads, ref_g)
+    for e, c in zip(engs, ref_c):
+        assert torch.equal(e.color, c)
+    assert torch.equal(total, torch.sum(ref_g, dim=0))
+    with pytest.raises(ValueError):
+        RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=1024, grad_flat=torch.zeros(7, device=dev))
+
+
 @pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 4096, 4097])
 def test_list_lengths_on_internal_boundaries(n):
     """A tile whose list has exactly n entries, n on the boundaries of the wave sort / depth segments (256) and of the
