@@ -4,15 +4,16 @@ configs[2]; SURVEY.md 8(d) scene S(200000,1920,1080,3,seed=3)), 1..8 MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the hot path over one BATCH of views per rank (default 4 views, `--views-per-step`): for
+One "step" = one pass of the hot path over one BATCH of views per rank (default 8 views, `--views-per-step`): for
 every view the rasterizer forward (preprocess -> tile binning -> alpha composite) + backward (composite bwd ->
 per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside
-the timed region; the views of a batch are spread over `--streams` HIP streams (default 2: the latency-bound binning
-kernels and the tile-imbalance tails of one view overlap the other's composite; +15 % views/s on one GPU) and their
-gradients are summed in one pass.  `--views-per-step 1` is the reference's one frame per step
-(gs_trainer.py:207-215); "ms_per_view" = ms_per_step / views.  With N > 1 every (rank, view) pair renders a
-DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the canonical-Gaussian gradients of the
-batch with ONE RCCL all-reduce per step ("scaling": "weak": the batch per rank is fixed).
+the timed region; the views of a batch are dealt round-robin to `--streams` HIP streams (default 3: the latency-bound
+binning kernels and the tile-imbalance tails of one view overlap the composite of the others; 2 640 -> 3 270 views/s
+on one GPU, sweep in DESIGN.md section 5) and their gradients are summed in one pass.  `--views-per-step 1 --streams 1`
+is the reference's one frame per step (gs_trainer.py:207-215); "ms_per_view" = ms_per_step / views.  With N > 1 every
+(rank, view) pair renders a DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the
+canonical-Gaussian gradients of the batch with ONE RCCL all-reduce per step, i.e. the 47 MB all-reduce is paid once
+per 8 views ("scaling": "weak": the batch per rank is fixed).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline     - dominant kernel: algorithmic bytes / its mean launch duration,
@@ -64,10 +65,10 @@ def main():
     ap.add_argument("--morton", action="store_true", help="avatar / train workloads: store the canonical Gaussians in Morton order")
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
-    ap.add_argument("--views-per-step", type=int, default=4,
+    ap.add_argument("--views-per-step", type=int, default=8,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
                          "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are summed in one pass at the end of the step)")
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",

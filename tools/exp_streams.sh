@@ -1,8 +1,8 @@
 #!/bin/bash
-# GPU box: views-per-step / streams sweep of the default raster workload
+# GPU box: views-per-step / streams sweep of the default raster workload:  bash tools/exp_streams.sh "1 1" "4 2" ...
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/exp_streams; mkdir -p $OUT
-for cfg in "1 1" "4 1" "4 2" "4 4" "8 4" "8 8"; do
+for cfg in "$@"; do
   set -- $cfg
   python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --views-per-step $1 --streams $2 > $OUT/k$1_s$2.json 2> $OUT/k$1_s$2.err
   python3 - <<PY
