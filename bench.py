@@ -446,26 +446,55 @@ def main_avatar(a):
             tile_mean, tile_max = _tile_list_stats(eng, W, H)
     del eng
     torch.cuda.empty_cache()
-    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096)
-    eng.set_camera(rs)
+    # one engine (workspaces) + loss engine per view of the batch, each writing its own row of `grads`; the views are dealt
+    # round-robin to the streams; one pass sums the rows, one all-reduce per step (same scheme as the raster workload)
+    k_views = max(1, a.views_per_step)
+    n_streams = max(1, min(a.streams, k_views))
+    per_view = N * (3 + 3 + 1 + 3 * sh.shape[1])
+    grads = torch.empty((k_views, per_view), dtype=torch.float32, device=dev)
+    acc = torch.empty(per_view, dtype=torch.float32, device=dev) if k_views > 1 else grads[0]
+    from sings_amd.photo_loss import PhotoLossEngine
+    engs, losses = [], []
+    for v in range(k_views):
+        e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v])
+        e.set_camera(rs)
+        engs.append(e)
+        losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
+    eng = engs[0]
+    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
     shard = FrameSharder(F, world, rank, seed=0)
     fp = FrameParallel() if dist is not None else None
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
-    # mask, forward and gradient -> backward (SURVEY.md 8d "Timing"); weights human.loss.l1_w / ssim_w
-    from sings_amd.photo_loss import PhotoLossEngine
-    loss = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2)
+    # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
     gt_rgb = torch.rand((3, H, W), device=dev)
     yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
     mask = ((((xx - W / 2) / (W / 4)) ** 2 + ((yy - H / 2) / (H / 2.2)) ** 2) < 1).float().contiguous()
     bg_t = t(s["bg"])
 
+    def one_view(v, frame):
+        e = engs[v]
+        e.set_frame(xyz, None, w, A_all[frame], smpl_scale, transl)
+        e.forward(sh, op, sc)
+        dLi = losses[v](e.color, gt_rgb, mask, bg_t)
+        e.backward(sh, op, sc, dLi)
+
     def step(i):
-        eng.set_frame(xyz, None, w, A_all[shard.frame(i)], smpl_scale, transl)
-        eng.forward(sh, op, sc)
-        dLi = loss(eng.color, gt_rgb, mask, bg_t)
-        eng.backward(sh, op, sc, dLi)
+        if n_streams == 1:
+            for v in range(k_views):
+                one_view(v, shard.frame(i * k_views + v))
+        else:
+            cur = torch.cuda.current_stream(dev)
+            for st in streams:
+                st.wait_stream(cur)
+            for v in range(k_views):
+                with torch.cuda.stream(streams[v % n_streams]):
+                    one_view(v, shard.frame(i * k_views + v))
+            for st in streams:
+                cur.wait_stream(st)
+        if k_views > 1:
+            torch.sum(grads, dim=0, out=acc)
         if fp is not None:
-            fp.all_reduce_grads(eng.grad_flat)
+            fp.all_reduce_grads(acc)
 
     for i in range(a.warmup):
         step(i)
@@ -485,24 +514,24 @@ def main_avatar(a):
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
-    assert eng.num_rendered() <= eng.cap
+    assert all(e.num_rendered() <= e.cap for e in engs)
     lib = _lib.load()
     lib.sg_profile_enable(1)
     for i in range(a.steps):
-        step(i)
+        one_view(0, shard.frame(i))
     ms = (C.c_double * _lib.NUM_KERNELS)(); cnt = (C.c_int64 * _lib.NUM_KERNELS)()
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
     lib.sg_profile_enable(0)
     kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
     if rank == 0:
         out = {"metric": "train-step views/sec (LBS-fused fwd + L1/SSIM loss + bwd), avatar ~150k Gaussians x 120 AMASS frames",
-               "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f32", "data": "synthetic",
+               "value": world * a.steps * k_views / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+               "ms_per_step": el / a.steps * 1e3, "ms_per_view": el / a.steps * 1e3 / k_views, "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H} fx=fy=5000, {F} AMASS frames, SH deg 0, fused LBS+raster "
                                       f"fwd + L1/SSIM loss + bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
                           "width": W, "height": H, "max_num_rendered": Rmax, "tile_list_mean": tile_mean, "tile_list_max": tile_max,
-                          "parallelism": f"dp{world}"},
+                          "views_per_step": k_views, "streams": n_streams, "parallelism": f"dp{world}"},
                "kernel_ms": kern}
         if world == 1 and not a.no_cpu_baseline:
             from oracle import lbs_project_torch as lp

@@ -106,7 +106,7 @@ class SkinnedEngine:
     transforms in, image + flat canonical-Gaussian gradient buffer out.  Flat layout (floats): xyz_canon 3P,
     scales 3P, opacity P, sh 3MP, [rot_canon 9P].  dL/dA [J,16] and dL/dtransl [3] are per-frame (not all-reduced)."""
 
-    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False):
+    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False, grad_flat=None):
         self.lib = _lib.load()
         self.P, self.J, self.W, self.H, self.M = int(P), int(J), int(W), int(H), int(sh_coeffs)
         self.dev = torch.device(device)
@@ -121,7 +121,10 @@ class SkinnedEngine:
         self.color = torch.empty((3, self.H, self.W), **f32)
         self.radii = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
         per = 3 + 3 + 1 + 3 * self.M + (9 if with_rot else 0)
-        self.grad_flat = torch.empty(self.P * per, **f32)
+        if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
+                                      or not grad_flat.is_contiguous() or grad_flat.device != self.dev):
+            raise ValueError(f"grad_flat must be a contiguous fp32 tensor of {self.P * per} elements on {self.dev}")
+        self.grad_flat = torch.empty(self.P * per, **f32) if grad_flat is None else grad_flat.view(-1)
         o = 0
 
         def carve(n, *shape):
