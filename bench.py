@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are summed in one pass at the end of the step)")
+    ap.add_argument("--eager", action="store_true", help="train workload: launch the ~600 kernels of a step from Python instead of "
+                    "replaying the step from a captured HIP graph (the default; host-speed independent)")
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
@@ -358,11 +360,46 @@ def main_train(a):
     bg_t, smpl_scale, transl = t(s["bg"]), t(s["smpl_scale"]), t(s["transl"])
     shard = FrameSharder(F, world, rank, seed=0)
 
-    def step(i):
+    # No host synchronisation inside a step: one synchronous step sizes the pair capacity, then the rasterizer's pair-count
+    # check is deferred (sings_amd.rasterizer.set_deferred_overflow_check) and polled once after the timed region.
+    from sings_amd import rasterizer as _rz
+    A_static = A_all[0].clone()
+
+    def step_body():
         for p in params:
             p.grad = None
-        loss, ld, ex = step_mod(A_all[shard.frame(i)], rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
+        loss, ld, ex = step_mod(A_static, rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
         loss.backward()
+        return ld
+
+    cap_pairs = 0
+    for f in range(0, F, 8):                                     # synchronous sizing steps: 1.25 x the largest pair count
+        A_static.copy_(A_all[f])
+        step_body()
+        cap_pairs = max(cap_pairs, _rz._capacity_hint[dev.index])
+    torch.cuda.synchronize()
+    _rz.set_deferred_overflow_check(True, capacity_pairs=cap_pairs)
+    graph, ld_static = None, None
+    if not a.eager:
+        # the whole step (decode -> raster -> losses -> backward, ~600 launches) replayed from ONE HIP graph
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step_body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            ld_static = step_body()
+
+    def step(i):
+        A_static.copy_(A_all[shard.frame(i)])
+        if graph is not None:
+            graph.replay()
+            ld = ld_static
+        else:
+            ld = step_body()
         if dist is not None:
             flat = torch.cat([p.grad.reshape(-1) for p in params])
             dist.all_reduce(flat)
@@ -386,6 +423,7 @@ def main_train(a):
         tt = torch.tensor([el], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    R_last = _rz.check_deferred_overflow(dev)                    # raises if a timed step overflowed the pair capacity
     if rank == 0:
         nparam = sum(p.numel() for p in params)
         out = ({
@@ -395,7 +433,8 @@ def main_train(a):
             "data": "synthetic",
             "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H}, tri-plane 32 x (64,128,256)^2 x 3, decoders 96-128-128 / "
                                    f"96-64-64, SH deg 0, {F} AMASS frames, no optimiser step, frame-parallel dp{world}",
-                       "gaussians": N, "trainable_parameters": nparam, "parallelism": f"dp{world}"},
+                       "gaussians": N, "trainable_parameters": nparam, "num_rendered_last": R_last, "hip_graph": not a.eager,
+                       "parallelism": f"dp{world}"},
             "losses": {k: float(v.detach()) for k, v in ld.items()}})
     if dist is not None:
         dist.destroy_process_group()

@@ -104,8 +104,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
     // header + tile counters zeroed every call (stream-ordered)
-    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
-    if (e != hipSuccess) return sg_fail("memset", e);
+    sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
@@ -187,8 +186,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
-    hipError_t e = hipMemsetAsync(b.header, 0, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
-    if (e != hipSuccess) return sg_fail("memset", e);
+    sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, 0, st);
@@ -380,6 +378,26 @@ extern "C" int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float
 }
 
 // ---- per-kernel event timing ------------------------------------------------------------
+__global__ void __launch_bounds__(256) sg_zero_kernel(uint32_t *__restrict__ p, size_t words)
+{
+    // 16-B stores over the aligned middle, 4-B stores at the ragged ends
+    const size_t head = ((16 - ((uintptr_t)p & 15)) & 15) >> 2;
+    const size_t h = head < words ? head : words, v4 = (words - h) >> 2, tail = h + 4 * v4;
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n = (size_t)gridDim.x * 256;
+    if (i < h) p[i] = 0u;
+    uint4 *q = (uint4 *)(p + h);
+    for (size_t k = i; k < v4; k += n) q[k] = make_uint4(0u, 0u, 0u, 0u);
+    if (tail + i < words) p[tail + i] = 0u;
+}
+void sg_zero_async(void *p, size_t bytes, hipStream_t st)
+{
+    const size_t words = bytes >> 2;
+    if (!words) return;
+    size_t blocks = (words / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(sg_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)p, words);
+}
+
 static bool g_prof_on = false;
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[SG_NUM_KERNELS];
 static hipEvent_t g_prof_open[SG_NUM_KERNELS];

@@ -125,6 +125,10 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
                               float *dL_drots, float *dL_dcov3D, hipStream_t st);
 
 // per-kernel event timing (sg_api.hip)
+// Zero `bytes` (a multiple of 4) at the 4-byte aligned address p with a KERNEL.  Not hipMemsetAsync: a step replayed from
+// a HIP graph went wrong on ROCm 7.2 as soon as the host had synchronised once between two replays when the graph
+// contained memset nodes (tools/graph_gap.py reproduces it); a kernel node has no such problem and is no slower.
+void sg_zero_async(void *p, size_t bytes, hipStream_t st);
 void sg_prof_begin(int id, hipStream_t st);
 void sg_prof_end(int id, hipStream_t st);
 

@@ -537,11 +537,11 @@ int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *
     float4 *cellrec = (float4 *)b;
     const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
     sg_tp_upload(tp, d, fm, st);                              // (parameters may have changed since the forward call)
-    if (hipMemsetAsync(count, 0, cw * 4, st) != hipSuccess) return 1;
+    sg_zero_async(count, cw * 4, st);
     const int nb = (N + 255) / 256;
     int max_keys = 0;
     for (int c = 0; c < 3; c++) max_keys = g.nkeys[c] > max_keys ? g.nkeys[c] : max_keys;
-    if (hipMemsetAsync(gfm, 0, floats * 4, st) != hipSuccess) return 1;
+    sg_zero_async(gfm, floats * 4, st);
     const int nkb = max_keys / 1024 + 1;
     hipLaunchKernelGGL(sg_tp_cell_count_kernel, dim3(nb, 3), dim3(256), 0, st, d, g, N, xyz, count, keys, rank);
     hipLaunchKernelGGL(sg_tp_cell_bsum_kernel, dim3(nkb, 3), dim3(256), 0, st, g, count, bsum);

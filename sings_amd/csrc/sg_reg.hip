@@ -569,7 +569,7 @@ static int sg_knn_build(int N, const float *xyz, const float *bpart, size_t mc, 
     uint2 *cells = (uint2 *)b; b += sg_align(mc * 8);
     const int nb = sg_nb(N), ncb = (int)((mc + 1023) / 1024);
     hipLaunchKernelGGL(sg_grid_setup_kernel, dim3(1), dim3(256), 0, st, bpart, nb, N, (int)mc, grid);
-    if (hipMemsetAsync(count, 0, mc * 4, st) != hipSuccess) return 2;
+    sg_zero_async(count, mc * 4, st);
     hipLaunchKernelGGL(sg_cell_count_kernel, dim3(nb), dim3(256), 0, st, N, xyz, grid, cell_of, rank_in, count);
     hipLaunchKernelGGL(sg_cells_scan1_kernel, dim3(ncb), dim3(256), 0, st, grid, count, start, bsum);
     hipLaunchKernelGGL(sg_cells_scan2_kernel, dim3(1), dim3(1024), 0, st, grid, bsum);

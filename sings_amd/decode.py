@@ -39,11 +39,28 @@ def _tp_struct(grids, aabb, keep):
             t = planes[c].detach().contiguous().float()
             keep.append(t)
             tp.planes[s][c] = t.data_ptr()
-    a = aabb.detach().float().cpu()
+    a = _aabb_host(aabb)
     for r in range(2):
         for k in range(3):
-            tp.aabb[r][k] = float(a[r, k])
+            tp.aabb[r][k] = a[r][k]
     return tp
+
+
+_aabb_cache = {}
+
+
+def _aabb_host(aabb):
+    """Host copy of the (non-trainable) bounding box, read back once per VALUE: a D2H copy in every forward and backward
+    was a host synchronisation twice per training step."""
+    slot, key = (aabb.data_ptr(), str(aabb.device)), aabb._version
+    hit = _aabb_cache.get(slot)
+    if hit is None or hit[0] != key:
+        a = aabb.detach().float().cpu()
+        hit = (key, [[float(a[r, k]) for k in range(3)] for r in range(2)])
+        if len(_aabb_cache) > 64:
+            _aabb_cache.clear()
+        _aabb_cache[slot] = hit
+    return hit[1]
 
 
 class _Triplane(torch.autograd.Function):

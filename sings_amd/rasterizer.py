@@ -35,6 +35,44 @@ class GaussianRasterizationSettings(NamedTuple):
 # capacity (pairs) remembered per device so that steady-state calls never re-run
 _capacity_hint = {}
 
+# Upstream's forward blocks the host once per call (D2H read of the pair count in the middle of it); here that read sits
+# at the END of the forward and the call is re-run with a larger workspace when the count exceeds the capacity.  In
+# DEFERRED mode the forward does not read the count at all: the host never waits for the GPU inside a step (the Python
+# side can run ahead, and a whole step can be captured into a HIP graph).  The price: a frame whose count exceeds the
+# capacity renders the background and gets zero gradients (the kernels never follow partly written lists) until the
+# caller polls ``check_deferred_overflow()`` -- e.g. every few hundred steps, or after densification -- which raises
+# and grows the capacity for the following calls.
+_deferred = {"on": False}
+_pending = {}                          # device index -> (binning workspace, capacity) of the last deferred forward
+
+
+def set_deferred_overflow_check(on=True, capacity_pairs=None, device=None):
+    """Switch the forward of both autograd functions between the synchronous pair-count check (default) and the
+    deferred one.  ``capacity_pairs`` presets the capacity (otherwise the last synchronous call's hint is used)."""
+    _deferred["on"] = bool(on)
+    if capacity_pairs is not None:
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        _capacity_hint[dev.index] = int(capacity_pairs)
+
+
+def check_deferred_overflow(device=None):
+    """Pair count of the last deferred forward on ``device`` (one D2H read = one host synchronisation).  Raises
+    RuntimeError if it exceeded the capacity, after growing the capacity used by the following calls."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if dev.index not in _pending:
+        return None
+    binning, cap = _pending[dev.index]
+    nr = C.c_int64(0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().sg_read_num_rendered(_ptr(binning), C.byref(nr), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                   "read R")
+    R = int(nr.value)
+    if R > cap:
+        _capacity_hint[dev.index] = int(R * 1.25) + 1024
+        raise RuntimeError(f"sings_amd: the last deferred forward produced {R} (tile, Gaussian) pairs for a capacity of {cap}: "
+                           f"it rendered the background and no gradients; the capacity is now {_capacity_hint[dev.index]}")
+    return R
+
 
 def _ptr(t):
     return None if t is None or t.numel() == 0 else C.c_void_p(t.data_ptr())
@@ -97,6 +135,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         cap = max(_capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
+        deferred = _deferred["on"]
         with torch.cuda.device(dev):
             while True:
                 L = _lib.layout(P, W, H, cap)
@@ -107,12 +146,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 _lib.check(lib.sg_rasterize_forward(
                     C.byref(s), P, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
                     _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(geom), _ptr(binning), cap, _ptr(img),
-                    _ptr(color), _ptr(radii), int(bool(write_point_keys)), C.byref(nr), stream), "forward")
-                R = int(nr.value)
-                if R <= cap:
+                    _ptr(color), _ptr(radii), int(bool(write_point_keys)), None if deferred else C.byref(nr), stream), "forward")
+                R = None if deferred else int(nr.value)
+                if deferred or R <= cap:
                     break
                 cap = int(R * 1.25) + 1024          # workspace too small: grow and re-run
-        _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
+        if deferred:
+            _pending[dev.index] = (binning, cap)
+        else:
+            _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
         ctx.raster_settings = rs
         ctx.num_rendered = R
         ctx.capacity = cap

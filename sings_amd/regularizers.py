@@ -73,6 +73,7 @@ class L2Norm(torch.nn.Module):
         super().__init__()
         self._l = (lambda_xyz_offsets, lambda_scales_diff, lambda_max_scale, max_scale_threshold, lambda_min_opacity,
                    min_opacity_threshold)
+        self._lam = {}                 # device -> the six scalars on that device (uploaded once, not per call)
 
     def forward(self, human_gs_out):
         lib = _lib.load()
@@ -81,7 +82,9 @@ class L2Norm(torch.nn.Module):
         op = human_gs_out['opacity'].contiguous().float() if 'opacity' in human_gs_out else None
         _need_gpu(off, "L2Norm")
         dev, N = off.device, int(off.shape[0])
-        lam = torch.tensor(self._l, dtype=torch.float32, device=dev)
+        lam = self._lam.get(dev)
+        if lam is None:
+            lam = self._lam[dev] = torch.tensor(self._l, dtype=torch.float32, device=dev)
         ws = torch.empty(int(lib.sg_reg_ws_bytes(N)), dtype=torch.uint8, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         d_off, d_sc = torch.empty_like(off), torch.empty_like(sc)

@@ -12,7 +12,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .rasterizer import _capacity_hint, _f32, _ptr, _settings_struct
+from .rasterizer import _capacity_hint, _deferred, _f32, _pending, _ptr, _settings_struct
 
 
 def _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs, keep):
@@ -60,6 +60,7 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
         pxyz, pq, psc = (e(P, 3), e(P, 4), e(P, 3)) if return_posed else (None, None, None)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         cap = max(_capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
+        deferred = _deferred["on"]                              # see rasterizer.set_deferred_overflow_check
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             while True:
@@ -70,12 +71,16 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                 nr = C.c_int64(0)
                 _lib.check(lib.sg_skinned_forward(C.byref(s), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales),
                                                   _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii),
-                                                  _ptr(pxyz), _ptr(pq), _ptr(psc), C.byref(nr), stream), "skinned forward")
-                R = int(nr.value)
-                if R <= cap:
+                                                  _ptr(pxyz), _ptr(pq), _ptr(psc), None if deferred else C.byref(nr), stream),
+                           "skinned forward")
+                R = None if deferred else int(nr.value)
+                if deferred or R <= cap:
                     break
                 cap = int(R * 1.25) + 1024
-        _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
+        if deferred:
+            _pending[dev.index] = (binning, cap)
+        else:
+            _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
         ctx.rs, ctx.cap, ctx.M, ctx.num_rendered = rs, cap, M, R
         ctx.has_rot = rotmat_canon is not None
         ctx.has_ext = ext_tfs is not None

@@ -453,6 +453,15 @@ def test_engine_step_replays_from_a_hip_graph():
     torch.cuda.synchronize()
     assert torch.equal(color_g, eng.color) and torch.equal(grad_g, eng.grad_flat)
     assert eng.num_rendered() <= eng.cap
+    # replays separated by host synchronisations (a training loop that reads a loss value every step): with
+    # hipMemsetAsync nodes in the graph every replay after the first synchronisation came out wrong on ROCm 7.2 --
+    # the workspaces' counters are therefore zeroed by a kernel (sg_zero_async)
+    R = eng.num_rendered()
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        assert eng.num_rendered() == R
+        assert torch.equal(color_g, eng.color) and torch.equal(grad_g, eng.grad_flat)
 
 
 def test_views_in_flight_on_two_streams_match_sequential_runs():
