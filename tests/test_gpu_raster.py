@@ -506,6 +506,12 @@ def test_views_in_flight_on_two_streams_match_sequential_runs():
     total = torch.sum(grads, dim=0)
     torch.cuda.synchronize()
     assert torch.equal(grads, ref_g)
+    # the same through the library's helper
+    from sings_amd.engine import ViewBatch
+    grads.zero_()
+    acc = ViewBatch(engs, grads, streams=3).run(lambda v, e: (e.forward(*ins), e.backward(*ins, dL)))
+    torch.cuda.synchronize()
+    assert torch.equal(grads, ref_g) and torch.equal(acc, total)
     for e, c in zip(engs, ref_c):
         assert torch.equal(e.color, c)
     assert torch.equal(total, torch.sum(ref_g, dim=0))
