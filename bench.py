@@ -71,6 +71,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are summed in one pass at the end of the step)")
+    ap.add_argument("--regularisers", action="store_true",
+                    help="raster workload: also run the geometry-preserving regularisers (exact k-NN Gaussian edge loss + L2Norm, "
+                         "value and gradient) once per step on a side stream -- BASELINE configs[4] is "
+                         "--gaussians 500000 --width 2048 --height 2048 --regularisers")
     ap.add_argument("--eager", action="store_true", help="train workload: launch the ~600 kernels of a step from Python instead of "
                     "replaying the step from a captured HIP graph (the default; host-speed independent)")
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
@@ -160,12 +164,33 @@ def main():
         if not a.forward_only:
             e.backward(means3D, shs, opac, scales, rots, dL)
 
+    reg = None
+    if a.regularisers:
+        # per optimisation step, not per view: Gaussian positions / scales / opacities are the same for all views
+        from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm
+        reg_mods = (GaussiansEdgeLoss(), L2Norm())
+        reg_sc = scales.clone().requires_grad_(True); reg_off = (0.002 * torch.randn_like(means3D)).requires_grad_(True)
+        reg_side = torch.cuda.Stream(dev)
+
+        def reg():
+            reg_sc.grad = None; reg_off.grad = None
+            loss = reg_mods[0]({"xyz_canon": means3D, "scales": reg_sc}) + reg_mods[1]({"xyz_offsets": reg_off, "scales": reg_sc,
+                                                                                        "opacity": opac})
+            loss.backward()
+
     def step():
+        if reg is not None:
+            cur = torch.cuda.current_stream(dev)
+            reg_side.wait_stream(cur)
+            with torch.cuda.stream(reg_side):
+                reg()
         if graph is not None:
             graph.replay()
             acc = eng.grad_flat
         else:
             acc = batch.run(one_view)
+        if reg is not None:
+            cur.wait_stream(reg_side)
         if fp is not None:
             fp.all_reduce_grads(acc)
 
@@ -244,7 +269,7 @@ def main():
         "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, fwd+bwd, "
                                f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "tile_list_mean": tile_mean,
-                   "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams,
+                   "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams, "regularisers": bool(a.regularisers),
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
                    "parallelism": f"dp{world}"},
         "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
