@@ -174,3 +174,31 @@ def test_weight_grad_shapes():
                 ref = dz.double().t() @ x.double()
                 _close(dW.cpu().numpy(), ref.cpu().numpy(), rtol=1e-5, atol_scale=1e-5, what=f"dW {N} {Cout} {Cin}")
                 _close(db.cpu().numpy(), dz.double().sum(0).cpu().numpy(), rtol=1e-5, atol_scale=1e-5, what=f"db {N} {Cout} {Cin}")
+
+
+@pytest.mark.parametrize("res,multires", [([8, 8, 8], [1]), ([8, 6, 10], [1, 2]), ([16, 12, 20], [1, 2, 4, 8]),
+                                          ([96, 64, 80], [1, 2, 4, 8]), ([5, 7, 3], [4, 1])])
+def test_triplane_plane_configurations(res, multires):
+    """The plane gradient sorts the points by (finest cell, parity of the cell on every coarser level): one level (no
+    sub-key), four levels, non-cubic planes, a finest level that is not the last one, and a key space beyond the 2^24 cap
+    (96 x 8 = 768 texels: the coarsest sub-keys are dropped) -- features and all gradients against the CPU oracle."""
+    from sings_amd.decode import HexPlaneField
+    dev = _dev()
+    torch.manual_seed(11)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': res, 'multires': multires}
+    f = HexPlaneField(cfg, bounds=1.0, device=dev)
+    N = 3001
+    pts_c = torch.cat([torch.rand(N - 600, 3) * 2.2 - 1.1, torch.randn(600, 3) * 0.01 + 0.4])
+    w_c = torch.randn(N, 32 * len(multires))
+    pts = pts_c.to(dev).requires_grad_(True)
+    feats = f(pts)
+    (feats * w_c.to(dev)).sum().backward()
+    grids_c = [[p.detach().cpu().clone().requires_grad_(True) for p in gp] for gp in f.grids]
+    pc = pts_c.clone().requires_grad_(True)
+    fo = do.triplane_features(pc, grids_c, f.aabb.detach().cpu())
+    (fo * w_c).sum().backward()
+    _close(feats.detach().cpu().numpy(), fo.detach().numpy())
+    _close(pts.grad.cpu().numpy(), pc.grad.numpy(), rtol=1e-4, atol_scale=1e-5)
+    for gp, gc in zip(f.grids, grids_c):
+        for p, q in zip(gp, gc):
+            _close(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-4, atol_scale=2e-5)
