@@ -519,6 +519,48 @@ def test_views_in_flight_on_two_streams_match_sequential_runs():
         RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=1024, grad_flat=torch.zeros(7, device=dev))
 
 
+def test_deferred_overflow_check():
+    """Deferred mode: the forward never reads the pair count (no host synchronisation inside a step).  A call whose count
+    exceeds the capacity renders the background; check_deferred_overflow() reports it once, grows the capacity, and the
+    next call is complete and equal to the synchronous result."""
+    from sings_amd import rasterizer as rz
+    from sings_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(4000, 160, 128, 1, 29)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    args = dict(means3D=t(s["means3D"]), means2D=torch.zeros(4000, 3, device=dev), opacities=t(s["opacities"]), shs=t(s["shs"]),
+                scales=t(s["scales"]), rotations=t(s["rotations"]))
+    ref, _ = GaussianRasterizer(rs)(**args)                      # synchronous mode (default)
+    hint = dict(rz._capacity_hint)
+    try:
+        rz.set_deferred_overflow_check(True, capacity_pairs=1, device=dev)
+        rz._capacity_hint[dev.index] = 1
+        # (the wrapper never goes below max(hint, 4 P + tiles, 2^16) pairs: make the scene exceed that floor instead)
+        big = synthetic_scene(30000, 160, 128, 1, 31)
+        big["scales"] = big["scales"] * 6.0
+        bargs = dict(means3D=t(big["means3D"]), means2D=torch.zeros(30000, 3, device=dev), opacities=t(big["opacities"]),
+                     shs=t(big["shs"]), scales=t(big["scales"]), rotations=t(big["rotations"]))
+        brs = _settings(big, dev)
+        img, _ = GaussianRasterizer(brs)(**bargs)
+        bgv = t(big["bg"])[:, None, None].expand(3, big["H"], big["W"])
+        with pytest.raises(RuntimeError, match="deferred forward produced"):
+            rz.check_deferred_overflow(dev)
+        assert torch.equal(img, bgv)                             # overflow: background, nothing followed stale lists
+        img2, _ = GaussianRasterizer(brs)(**bargs)               # capacity has grown
+        R = rz.check_deferred_overflow(dev)
+        assert R is not None and R > 4 * 30000 + 80 and not torch.equal(img2, bgv)
+        rz.set_deferred_overflow_check(False)
+        img3, _ = GaussianRasterizer(brs)(**bargs)
+        assert torch.equal(img2, img3)
+        out, _ = GaussianRasterizer(rs)(**args)
+        assert torch.equal(out, ref)
+    finally:
+        rz.set_deferred_overflow_check(False)
+        rz._capacity_hint.clear(); rz._capacity_hint.update(hint)
+        rz._pending.clear()
+
+
 @pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 4096, 4097])
 def test_list_lengths_on_internal_boundaries(n):
     """A tile whose list has exactly n entries, n on the boundaries of the wave sort / depth segments (256) and of the
