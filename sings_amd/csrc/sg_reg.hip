@@ -396,8 +396,11 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
                     const uint2 *__restrict__ cells_c, const float4 *__restrict__ sorted_f,
                     const SgGrid *__restrict__ grid_f, const uint2 *__restrict__ cells_f, float *__restrict__ mean_edge)
 {
-    // (A variant with 8 lanes per point -- same rows, every 8th candidate each, K-best lists merged per ring -- was
-    //  measured: no faster at 150k points, 13 % slower at 500k; the merges cost what the extra parallelism gains.)
+    // Measured and not adopted: 8 lanes per point (same rows, every 8th candidate each, K-best lists merged per ring): no
+    // faster at 150k points, 13 % slower at 500k; cell look-ups of three rows issued together + the next four candidates
+    // in flight during the inserts: 15 % slower (the bound is looser while a group is in flight, and the code grows).
+    // Where the time goes at 150k (ring count capped in a debug build): grids 130 us, own cell 18 us, ring 1 210 us,
+    // rings >= 2 90 us (the sparse tail).
     const int s = blockIdx.x * 256 + threadIdx.x;
     if (s >= N) return;
     const float4 p = sorted_c[s];
