@@ -519,6 +519,39 @@ def test_views_in_flight_on_two_streams_match_sequential_runs():
         RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=1024, grad_flat=torch.zeros(7, device=dev))
 
 
+def test_against_frozen_oracle_vectors():
+    """The HIP path through the drop-in autograd surface against the committed fixture tests/golden/raster_golden.npz (G6:
+    frozen outputs of the restatement): radii / rectangles / sorted lists / tile ranges bit for bit, RGB within 1e-5 away
+    from the hard thresholds, gradients within the parity tolerance."""
+    import os
+    from sings_amd.inspect_ws import forward_with_state
+    from sings_amd.rasterizer import GaussianRasterizer
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "raster_golden.npz"))
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    for tag in ("a", "b", "c"):
+        N, W, H, deg, seed = (int(v) for v in G[f"{tag}_case"])
+        s = synthetic_scene(N, W, H, deg, seed)
+        rs = _settings(s, dev)
+        st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]), rotations=t(s["rotations"]))
+        assert st["R"] == int(G[f"{tag}_R"])
+        np.testing.assert_array_equal(st["radii"].cpu().numpy(), G[f"{tag}_radii"])
+        np.testing.assert_array_equal(st["point_list"].cpu().numpy(), G[f"{tag}_point_list"])
+        np.testing.assert_array_equal(st["ranges"].cpu().numpy(), G[f"{tag}_ranges"])
+        strict = G[f"{tag}_margin"] >= 2e-5
+        err = np.abs(st["color"].cpu().numpy() - G[f"{tag}_color"]).max(0)
+        assert err[strict].max() <= RGB_TOL, (tag, err[strict].max())
+        req = lambda a: t(a).requires_grad_(True)
+        m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+        color, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m, requires_grad=True), opacities=op, shs=sh,
+                                          scales=sc, rotations=rt)
+        color.backward(t(G[f"{tag}_dL"]))
+        for name, a in (("dL_dmeans3D", m.grad), ("dL_dscales", sc.grad), ("dL_drots", rt.grad), ("dL_dopacity", op.grad),
+                        ("dL_dsh", sh.grad)):
+            b = G[f"{tag}_{name}"].astype(np.float64); a = a.cpu().numpy().astype(np.float64)
+            assert (np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-6 * np.abs(b).max()).all(), (tag, name, np.abs(a - b).max())
+
+
 def test_deferred_overflow_check():
     """Deferred mode: the forward never reads the pair count (no host synchronisation inside a step).  A call whose count
     exceeds the capacity renders the background; check_deferred_overflow() reports it once, grows the capacity, and the
