@@ -1,0 +1,116 @@
+"""Golden vectors for the render glue: the REFERENCE's own get_render_pkg / render
+(sings/rec/renderer/gs_renderer_single.py:12-107) executed in the build container, on CPU, with
+ * `diff_gaussian_rasterization` provided by an oracle-backed stand-in (the C restatement behind the upstream Python
+   surface: GaussianRasterizationSettings, GaussianRasterizer, an autograd.Function with upstream's argument / gradient order),
+ * the file's two `device="cuda"` literals (:48, :50) patched to "cpu" in memory (the source text is read from
+   /root/reference at generation time only and is not stored).
+What is pinned is the GLUE -- key names, dtypes, default background, the means2D / retain_grad trick and what ends up in
+viewspace_points.grad, tanfov from fov, 2-D feats -> colors_precomp, the final clamp and its effect on the gradients.  The
+raster arithmetic underneath is the unpinned restatement.
+    python tests/golden/gen_render_glue_golden.py        (needs /root/reference)
+"""
+import math, os, sys, types
+from typing import NamedTuple
+import numpy as np
+import torch
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from oracle import raster_oracle as ro
+from sings_amd.camera import make_camera
+from sings_amd.scene import synthetic_scene
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class _OracleRaster(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, rs):
+        n = lambda t: None if t is None or t.numel() == 0 else t.detach().numpy()
+        o = ro.forward(n(means3D), n(opacities), n(rs.viewmatrix), n(rs.projmatrix), n(rs.campos), rs.image_width, rs.image_height,
+                       rs.tanfovx, rs.tanfovy, n(rs.bg), scales=n(scales), rotations=n(rotations), shs=n(sh),
+                       sh_degree=rs.sh_degree, colors_precomp=n(colors_precomp), scale_modifier=rs.scale_modifier)
+        ctx.o = o
+        ctx.has = (sh is not None, colors_precomp is not None)
+        radii = torch.from_numpy(o["radii"].astype(np.int32))
+        ctx.mark_non_differentiable(radii)
+        return torch.from_numpy(o["color"].copy()), radii
+
+    @staticmethod
+    def backward(ctx, g_color, _):
+        g = ro.backward(ctx.o, g_color.contiguous().numpy())
+        T = lambda a: None if a is None else torch.from_numpy(np.ascontiguousarray(a))
+        m2d = g["dL_dmean2D"].copy()            # already upstream's [P,3]: xy scaled by (0.5 W, 0.5 H), z = 0
+        m2d[:, 2] = 0
+        return (T(g["dL_dmeans3D"]), T(m2d), T(g["dL_dsh"]) if ctx.has[0] else None, T(g["dL_dcolor"]) if ctx.has[1] else None,
+                T(g["dL_dopacity"]), T(g["dL_dscales"]), T(g["dL_drots"]), None)
+
+
+class GaussianRasterizer(torch.nn.Module):
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None):
+        return _OracleRaster.apply(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, self.raster_settings)
+
+
+stand_in = types.ModuleType("diff_gaussian_rasterization")
+stand_in.GaussianRasterizationSettings = GaussianRasterizationSettings
+stand_in.GaussianRasterizer = GaussianRasterizer
+sys.modules["diff_gaussian_rasterization"] = stand_in
+src = open("/root/reference/sings/rec/renderer/gs_renderer_single.py").read()
+assert src.count('device="cuda"') == 2
+ref = types.ModuleType("ref_gs_renderer_single")
+exec(compile(src.replace('device="cuda"', 'device="cpu"'), "gs_renderer_single.py", "exec"), ref.__dict__)
+
+W, H, N, deg, seed = 112, 80, 1800, 2, 41
+s = synthetic_scene(N, W, H, deg, seed)
+cam = make_camera(np.eye(4, dtype=np.float32), 1.2 * W, 1.2 * W, W / 2, H / 2, W, H)
+T = lambda a: torch.from_numpy(np.ascontiguousarray(a))
+data = dict(fovx=cam["fovx"], fovy=cam["fovy"], image_height=H, image_width=W, world_view_transform=T(cam["world_view_transform"]),
+            full_proj_transform=T(cam["full_proj_transform"]), camera_center=T(cam["camera_center"]))
+out = {"case": np.array([N, W, H, deg, seed]), "bg": np.array([0.3, 0.6, 0.1], np.float32)}
+# 1. get_render_pkg, SH features, explicit background, backward
+req = lambda a: T(a).requires_grad_(True)
+gs = dict(xyz=req(s["means3D"]), shs=req(s["shs"]), opacity=req(s["opacities"]), scales=req(s["scales"]), rotq=req(s["rotations"]),
+          active_sh_degree=deg)
+pkg = ref.get_render_pkg(data, gs, T(out["bg"]))
+o = ro.forward(s["means3D"], s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], W, H,
+               math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), out["bg"], scales=s["scales"], rotations=s["rotations"],
+               shs=s["shs"], sh_degree=deg)
+strict = o["margin"] >= 2e-5
+dL = s["dL_dimage"][:, :H, :W].copy(); dL[:, ~strict] = 0
+(pkg["render"] * T(dL)).sum().backward()
+out["sh_keys"] = np.array(sorted(pkg.keys()))
+out["sh_dtypes"] = np.array([f"{k}:{str(pkg[k].dtype)}" for k in sorted(pkg.keys())])
+out["sh_render"] = pkg["render"].detach().numpy(); out["sh_radii"] = pkg["radii"].numpy()
+out["sh_visibility_filter"] = pkg["visibility_filter"].numpy(); out["sh_strict"] = strict; out["sh_dL"] = dL
+out["sh_viewspace_grad"] = pkg["viewspace_points"].grad.numpy()
+for k in ("xyz", "shs", "opacity", "scales", "rotq"):
+    out[f"sh_grad_{k}"] = gs[k].grad.numpy()
+# 2. render() with 2-D feats (-> colors_precomp) and the default background (None -> zeros)
+rgb = np.random.RandomState(7).rand(N, 3).astype(np.float32)
+with torch.no_grad():
+    p2 = ref.render(T(s["means3D"]), T(rgb), T(s["opacities"]), T(s["scales"]), T(s["rotations"]), data, scaling_modifier=0.8)
+out["rgb_feats"] = rgb; out["rgb_render"] = p2["render"].numpy(); out["rgb_radii"] = p2["radii"].numpy()
+out["rgb_keys"] = np.array(sorted(p2.keys()))
+o2 = ro.forward(s["means3D"], s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], W, H,
+                math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), np.zeros(3, np.float32), scales=s["scales"],
+                rotations=s["rotations"], colors_precomp=rgb, scale_modifier=0.8)
+out["rgb_strict"] = o2["margin"] >= 2e-5
+np.savez_compressed(os.path.join(HERE, "render_glue_golden.npz"), **out)
+print("keys", list(out["sh_keys"]), list(out["sh_dtypes"]), "saturated pixels", int(((o["color"] <= 0) | (o["color"] >= 1)).sum()))

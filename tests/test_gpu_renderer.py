@@ -161,3 +161,45 @@ def test_render_then_fused_photometric_loss_matches_torch_chain():
     for a, b in zip(grads[0][1:], grads[1][1:]):
         scale = np.abs(b).max()
         assert (np.abs(a - b) <= 2e-4 * np.abs(b) + 2e-5 * scale).all()
+
+
+def test_render_glue_against_the_references_own_render():
+    """tests/golden/render_glue_golden.npz holds what the REFERENCE's get_render_pkg / render (gs_renderer_single.py:12-107)
+    returned in the build container (CPU, `diff_gaussian_rasterization` = an oracle-backed stand-in, gen_render_glue_golden.py):
+    same keys and dtypes, same image after the clamp, same radii / visibility, same viewspace_points.grad and input gradients
+    through the clamp; 2-D feats go to colors_precomp, bg_color=None means black, scaling_modifier is passed on."""
+    import os
+    from sings_amd.renderer import get_render_pkg, render
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "render_glue_golden.npz"))
+    dev = torch.device("cuda:0")
+    N, W, H, deg, seed = (int(v) for v in G["case"])
+    s = synthetic_scene(N, W, H, deg, seed)
+    cam, data = _data(dev, W, H)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    req = lambda a: t(a).requires_grad_(True)
+    gs = dict(xyz=req(s["means3D"]), shs=req(s["shs"]), opacity=req(s["opacities"]), scales=req(s["scales"]), rotq=req(s["rotations"]),
+              active_sh_degree=deg)
+    pkg = get_render_pkg(data, gs, t(G["bg"]))
+    assert set(pkg) >= set(str(k) for k in G["sh_keys"])
+    for kd in G["sh_dtypes"]:
+        k, d = str(kd).split(":")
+        assert str(pkg[k].dtype) == d, (k, pkg[k].dtype, d)
+    strict = G["sh_strict"]
+    assert np.abs(pkg["render"].detach().cpu().numpy() - G["sh_render"]).max(0)[strict].max() <= 1e-5
+    np.testing.assert_array_equal(pkg["radii"].cpu().numpy(), G["sh_radii"])
+    np.testing.assert_array_equal(pkg["visibility_filter"].cpu().numpy(), G["sh_visibility_filter"])
+    assert pkg["human_radii"] is pkg["radii"] and pkg["human_visibility_filter"] is pkg["visibility_filter"]
+    (pkg["render"] * t(G["sh_dL"])).sum().backward()
+
+    def close(a, b, what):
+        a = a.cpu().numpy().astype(np.float64); b = b.astype(np.float64)
+        ok = np.abs(a - b) <= 5e-4 * np.abs(b) + 1e-4 * np.abs(b).max()
+        assert ok.mean() > 0.9995, (what, np.abs(a - b).max())    # pixels within rounding of the 0 / 1 clamp may saturate on one side only
+    close(pkg["viewspace_points"].grad, G["sh_viewspace_grad"], "viewspace")
+    for k in ("xyz", "shs", "opacity", "scales", "rotq"):
+        close(gs[k].grad, G[f"sh_grad_{k}"], k)
+    with torch.no_grad():
+        p2 = render(t(s["means3D"]), t(G["rgb_feats"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"]), data, scaling_modifier=0.8)
+    assert set(p2) >= set(str(k) for k in G["rgb_keys"])
+    np.testing.assert_array_equal(p2["radii"].cpu().numpy(), G["rgb_radii"])
+    assert np.abs(p2["render"].cpu().numpy() - G["rgb_render"]).max(0)[G["rgb_strict"]].max() <= 1e-5
