@@ -24,12 +24,18 @@ def get_render_pkg(data, human_gs_out, bg_color, scaling_modifier=1.0):
     return render_pkg
 
 
-def get_render_pkgs(data, human_gs_outs, bg_color, scaling_modifier=1.0):
-    """Several avatars in one frame: concatenate then rasterize once (gs_renderer_multiple.py:12-68)."""
-    cat = lambda k: torch.cat([h[k] for h in human_gs_outs], dim=0)
+def get_render_pkgs(data, human_gs_out_list, trans_list, rot_list, bg_color, scaling_modifier=1.0, render_mode='multi-person'):
+    """Several avatars in one frame (gs_renderer_multiple.py:12-68, same signature): every avatar's ``xyz`` is translated
+    IN PLACE by its entry of ``trans_list`` (:25-27; ``rot_list`` is accepted and unused, as in the reference), then the
+    avatars are concatenated and rasterized once."""
+    for out, trans in zip(human_gs_out_list, trans_list):
+        out['xyz'] += trans[None]
+    if render_mode != 'multi-person':
+        raise ValueError(f'Unknown render mode: {render_mode}')
+    cat = lambda k: torch.cat([h[k] for h in human_gs_out_list], dim=0).contiguous()
     render_pkg = render(means3D=cat('xyz'), feats=cat('shs'), opacity=cat('opacity'), scales=cat('scales'),
                         rotations=cat('rotq'), data=data, scaling_modifier=scaling_modifier, bg_color=bg_color,
-                        active_sh_degree=human_gs_outs[0]['active_sh_degree'])
+                        active_sh_degree=human_gs_out_list[0]['active_sh_degree'])
     render_pkg['human_visibility_filter'] = render_pkg['visibility_filter']
     render_pkg['human_radii'] = render_pkg['radii']
     return render_pkg

@@ -112,5 +112,22 @@ o2 = ro.forward(s["means3D"], s["opacities"], cam["world_view_transform"], cam["
                 math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), np.zeros(3, np.float32), scales=s["scales"],
                 rotations=s["rotations"], colors_precomp=rgb, scale_modifier=0.8)
 out["rgb_strict"] = o2["margin"] >= 2e-5
+# 3. the multi-avatar twin (gs_renderer_multiple.py:12-68): two avatars, per-avatar translation applied in place
+src_m = open("/root/reference/sings/rec/renderer/gs_renderer_multiple.py").read()
+assert src_m.count('device="cuda"') == 2
+ref_m = types.ModuleType("ref_gs_renderer_multiple")
+exec(compile(src_m.replace('device="cuda"', 'device="cpu"'), "gs_renderer_multiple.py", "exec"), ref_m.__dict__)
+cut = 700
+trans = np.array([[0.05, -0.02, 0.1], [-0.3, 0.1, 0.4]], np.float32)
+part = lambda a, b: dict(xyz=T(s["means3D"][a:b]).clone(), shs=T(s["shs"][a:b]), opacity=T(s["opacities"][a:b]),
+                         scales=T(s["scales"][a:b]), rotq=T(s["rotations"][a:b]), active_sh_degree=deg)
+with torch.no_grad():
+    pm = ref_m.get_render_pkgs(data, [part(0, cut), part(cut, N)], [T(trans[0]), T(trans[1])], [None, None], T(out["bg"]))
+moved = s["means3D"].copy(); moved[:cut] += trans[0]; moved[cut:] += trans[1]
+om = ro.forward(moved, s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], W, H,
+                math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), out["bg"], scales=s["scales"], rotations=s["rotations"],
+                shs=s["shs"], sh_degree=deg)
+out["multi_cut"] = np.array(cut); out["multi_trans"] = trans; out["multi_keys"] = np.array(sorted(pm.keys()))
+out["multi_render"] = pm["render"].numpy(); out["multi_radii"] = pm["radii"].numpy(); out["multi_strict"] = om["margin"] >= 2e-5
 np.savez_compressed(os.path.join(HERE, "render_glue_golden.npz"), **out)
 print("keys", list(out["sh_keys"]), list(out["sh_dtypes"]), "saturated pixels", int(((o["color"] <= 0) | (o["color"] >= 1)).sum()))

@@ -56,7 +56,8 @@ def test_get_render_pkg_keys_dtypes_and_densification_outputs():
     # several avatars in one frame: concatenation then one raster call (gs_renderer_multiple.py:12-68)
     half = lambda d, a, b: {k: (v[a:b] if torch.is_tensor(v) else v) for k, v in d.items()}
     with torch.no_grad():
-        p2 = get_render_pkgs(data, [half(gs, 0, 1000), half(gs, 1000, 2500)], bg)
+        zero = torch.zeros(3, device=dev)
+        p2 = get_render_pkgs(data, [half(gs, 0, 1000), half(gs, 1000, 2500)], [zero, zero], [None, None], bg)
         p1 = get_render_pkg(data, gs, bg)
     assert torch.equal(p1["render"], p2["render"]) and torch.equal(p1["radii"], p2["radii"])
 
@@ -203,3 +204,17 @@ def test_render_glue_against_the_references_own_render():
     assert set(p2) >= set(str(k) for k in G["rgb_keys"])
     np.testing.assert_array_equal(p2["radii"].cpu().numpy(), G["rgb_radii"])
     assert np.abs(p2["render"].cpu().numpy() - G["rgb_render"]).max(0)[G["rgb_strict"]].max() <= 1e-5
+    # the multi-avatar twin (gs_renderer_multiple.py:12-68): two avatars, translated in place, one raster call
+    from sings_amd.renderer import get_render_pkgs
+    cut = int(G["multi_cut"])
+    part = lambda a, b: dict(xyz=t(s["means3D"][a:b]) + 0, shs=t(s["shs"][a:b]), opacity=t(s["opacities"][a:b]),
+                             scales=t(s["scales"][a:b]), rotq=t(s["rotations"][a:b]), active_sh_degree=deg)
+    outs = [part(0, cut), part(cut, N)]
+    with torch.no_grad():
+        pm = get_render_pkgs(data, outs, [t(G["multi_trans"][0]), t(G["multi_trans"][1])], [None, None], t(G["bg"]))
+    assert set(pm) >= set(str(k) for k in G["multi_keys"])
+    np.testing.assert_array_equal(pm["radii"].cpu().numpy(), G["multi_radii"])
+    assert np.abs(pm["render"].cpu().numpy() - G["multi_render"]).max(0)[G["multi_strict"]].max() <= 1e-5
+    assert torch.allclose(outs[1]["xyz"], t(s["means3D"][cut:]) + t(G["multi_trans"][1])[None])     # translated in place (:25-27)
+    with pytest.raises(ValueError):
+        get_render_pkgs(data, outs, [t(G["multi_trans"][0])] * 2, [None, None], t(G["bg"]), render_mode="single-person")
