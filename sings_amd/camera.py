@@ -91,7 +91,7 @@ def get_static_camera(img_size=512, fov=0.4, device="cuda"):
     return {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in d.items()}
 
 
-def get_rotating_camera(img_size=512, fov=0.4, dist=5.0, device="cuda", nframes=40, angle_limit=None):
+def get_rotating_camera(img_size=512, fov=0.4, dist=5.0, device="cuda", nframes=40, angle_limit=2 * math.pi):
     """sings/rec/datasets/utils.py:60-120: nframes cameras orbiting the origin at height -0.25, distance `dist` (the
     reference's ``rot_z`` is a rotation about the y axis; y and z of the camera frame are flipped)."""
     import math

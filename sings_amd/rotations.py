@@ -12,7 +12,8 @@ import torch
 import torch.nn.functional as F
 
 
-def quaternion_to_matrix(q):
+def quaternion_to_matrix(quaternions):
+    q = quaternions
     r, i, j, k = torch.unbind(q, -1)
     two_s = 2.0 / (q * q).sum(-1)
     o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
@@ -43,8 +44,8 @@ def matrix_to_quaternion(matrix):
     return quat_candidates[F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(batch_dim + (4,))
 
 
-def standardize_quaternion(q):
-    return torch.where(q[..., 0:1] < 0, -q, q)
+def standardize_quaternion(quaternions):
+    return torch.where(quaternions[..., 0:1] < 0, -quaternions, quaternions)
 
 
 def quaternion_raw_multiply(a, b):
@@ -72,19 +73,20 @@ def axis_angle_to_quaternion(axis_angle):
     return torch.cat([torch.cos(half), axis_angle * _sin_half_over_angle(angles, half)], dim=-1)
 
 
-def quaternion_to_axis_angle(q):
+def quaternion_to_axis_angle(quaternions):
+    q = quaternions
     norms = torch.norm(q[..., 1:], p=2, dim=-1, keepdim=True)
     half = torch.atan2(norms, q[..., :1])
     angles = 2 * half
     return q[..., 1:] / _sin_half_over_angle(angles, half)
 
 
-def axis_angle_to_matrix(aa):
-    return quaternion_to_matrix(axis_angle_to_quaternion(aa))
+def axis_angle_to_matrix(axis_angle):
+    return quaternion_to_matrix(axis_angle_to_quaternion(axis_angle))
 
 
-def matrix_to_axis_angle(m):
-    return quaternion_to_axis_angle(matrix_to_quaternion(m))
+def matrix_to_axis_angle(matrix):
+    return quaternion_to_axis_angle(matrix_to_quaternion(matrix))
 
 
 def rotation_6d_to_matrix(d6):
@@ -94,13 +96,13 @@ def rotation_6d_to_matrix(d6):
     return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
 
 
-def matrix_to_rotation_6d(m):
-    return m[..., :2, :].clone().reshape(m.size()[:-2] + (6,))
+def matrix_to_rotation_6d(matrix):
+    return matrix[..., :2, :].clone().reshape(matrix.size()[:-2] + (6,))
 
 
 def axis_angle_to_rotation_6d(aa):
     return matrix_to_rotation_6d(axis_angle_to_matrix(aa))
 
 
-def rotation_6d_to_axis_angle(d6):
-    return matrix_to_axis_angle(rotation_6d_to_matrix(d6))
+def rotation_6d_to_axis_angle(rot6d):
+    return matrix_to_axis_angle(rotation_6d_to_matrix(rot6d))
