@@ -120,8 +120,18 @@ typedef struct SgSkinInputs {
     const float *ext_scale;   /* [1]  /  forward only (the reference uses them under no_grad) */
 } SgSkinInputs;
 
-/* floats the caller must provide as `skin_ws` to sg_skinned_backward */
+/* floats the caller must provide as `skin_ws` to sg_skinned_backward (and as `ws` to sg_lbs_backward) */
 size_t sg_skin_ws_floats(int P);
+
+/* Stand-alone lbs_extra (sings/rec/utils/body_model/lbs.py:59-74, call sites sings_hybrid.py:400-406, :526-533), for
+ * callers that keep SinGS.forward unchanged: T [P,16] = lbs_weights [P,J] . A [J,16] (row-major 4x4 per point; may be NULL)
+ * and verts [P,3] = (T [v;1])[:3].  Backward: upstream gradients dT [P,16] and / or dverts [P,3] (either may be NULL)
+ * -> dv [P,3] (may be NULL) and dA [J,16]; lbs_weights get no gradient (the reference detaches them, sings_hybrid.py:724).
+ * 1 <= J <= 64.  Deterministic (fixed-order reduction of dA, no atomics). */
+int sg_lbs_forward(int P, int J, const float *lbs_weights, const float *A, const float *v, float *T_out, float *verts_out,
+                   void *stream);
+int sg_lbs_backward(int P, int J, const float *lbs_weights, const float *A, const float *v, const float *dT,
+                    const float *dverts, float *ws, float *dv, float *dA, void *stream);
 
 /* Forward.  `scales` are the CANONICAL scales [P,3]; optional outputs posed_xyz [P,3],
  * posed_rotq [P,4] (real first, not normalised), posed_scales [P,3] may be NULL. */

@@ -269,6 +269,26 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
     return 0;
 }
 
+// ---- stand-alone lbs_extra (a9)
+extern "C" int sg_lbs_forward(int P, int J, const float *lbs_weights, const float *A, const float *v, float *T_out,
+                              float *verts_out, void *stream)
+{
+    if (P <= 0 || J < 1 || J > 64 || !lbs_weights || !A || !v || !verts_out)
+        return sg_fail("sg_lbs_forward: bad argument (1 <= J <= 64)", hipSuccess);
+    sg_launch_lbs_fwd(P, J, lbs_weights, A, v, T_out, verts_out, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_lbs_forward", e);
+}
+extern "C" int sg_lbs_backward(int P, int J, const float *lbs_weights, const float *A, const float *v, const float *dT,
+                               const float *dverts, float *ws, float *dv, float *dA, void *stream)
+{
+    if (P <= 0 || J < 1 || J > 64 || !lbs_weights || !A || !v || !ws || !dA || (!dT && !dverts))
+        return sg_fail("sg_lbs_backward: bad argument (1 <= J <= 64)", hipSuccess);
+    sg_launch_lbs_bwd(P, J, lbs_weights, A, v, dT, dverts, ws, dv, dA, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_lbs_backward", e);
+}
+
 // ---- attribute decode (f3)
 extern "C" size_t sg_triplane_ws_bytes(const SgTriplane *tp) { return sg_tp_check(tp) ? 0 : sg_triplane_ws_bytes_impl(tp); }
 extern "C" size_t sg_triplane_bwd_ws_bytes(const SgTriplane *tp, int N)

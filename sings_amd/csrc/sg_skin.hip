@@ -475,6 +475,130 @@ sg_skin_reduce2_kernel(const float *__restrict__ part, int slab_stride, int J, f
     else if (dL_dtransl) dL_dtransl[i - nA] = t;
 }
 
+// ---- stand-alone lbs_extra (sings/rec/utils/body_model/lbs.py:59-74) ---------------------------------------------
+// For callers that keep SinGS.forward as it is (sings_hybrid.py:400-406) instead of the fused path: T[N,4,4] = W . A and
+// verts = (T [v;1])[:3] in one pass (the reference: expand + matmul + cat + matmul + slice, T and v_homo through HBM
+// twice), and the transpose for autograd.  Same MFMA contraction as above, all 16 columns kept.
+#define SG_T16STRIDE 17
+__device__ __forceinline__ void sg_skin_T16(const float *__restrict__ W, int J, int P, int g0, int lane,
+                                            const float *__restrict__ sA, float *__restrict__ sW,
+                                            float *__restrict__ sT, float T[16])
+{
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[b] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    const int nchunk = (J + 15) >> 4;
+    for (int c = 0; c < nchunk; c++) {
+        sg_stage_w_chunk(W, J, P, g0, c, lane, sW);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            float bv = sA[(c * 16 + 4 * kk + (lane >> 4)) * 16 + (lane & 15)];
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                float av = sW[(16 * b + (lane & 15)) * SG_WSTRIDE + 4 * kk + (lane >> 4)];
+                acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[b], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) sT[(16 * b + 4 * (lane >> 4) + r) * SG_T16STRIDE + (lane & 15)] = acc[b][r];
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 16; i++) T[i] = sT[lane * SG_T16STRIDE + i];
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(SG_SKIN_THREADS)
+sg_lbs_fwd_kernel(int P, int J, const float *__restrict__ W, const float *__restrict__ A, const float *__restrict__ v,
+                  float *__restrict__ T_out, float *__restrict__ verts)
+{
+    __shared__ float sA[SG_JMAX * 16];
+    __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
+    __shared__ float sT[SG_SKIN_WAVES][64 * SG_T16STRIDE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64, idx = g0 + lane;
+    const int Jp = ((J + 15) >> 4) << 4;
+    for (int i = threadIdx.x; i < Jp * 16; i += blockDim.x) sA[i] = i < J * 16 ? A[i] : 0.0f;
+    __syncthreads();
+    float T[16];
+    sg_skin_T16(W, J, P, g0, lane, sA, sW[wave], sT[wave], T);
+    if (idx >= P) return;
+    const float x = v[3 * idx], y = v[3 * idx + 1], z = v[3 * idx + 2];
+    if (T_out) {
+        float4 *o = (float4 *)(T_out + (size_t)idx * 16);
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[r] = make_float4(T[4 * r], T[4 * r + 1], T[4 * r + 2], T[4 * r + 3]);
+    }
+    // (T @ [v;1]): four products summed left to right, as torch.matmul's K = 4 reduction
+#pragma unroll
+    for (int r = 0; r < 3; r++) verts[3 * idx + r] = ((T[4 * r] * x + T[4 * r + 1] * y) + T[4 * r + 2] * z) + T[4 * r + 3];
+}
+
+// dT_in [P,16] and / or dverts_in [P,3] (either may be NULL) -> dv [P,3], per-wave dA slabs (summed by the reduce kernels)
+__global__ void __launch_bounds__(SG_SKIN_THREADS)
+sg_lbs_bwd_kernel(int P, int J, const float *__restrict__ W, const float *__restrict__ A, const float *__restrict__ v,
+                  const float *__restrict__ dT_in, const float *__restrict__ dverts_in, float *__restrict__ dv,
+                  float *__restrict__ slab, int slab_stride)
+{
+    __shared__ float sA[SG_JMAX * 16];
+    __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
+    __shared__ float sT[SG_SKIN_WAVES][64 * SG_T16STRIDE];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64, idx = g0 + lane;
+    const int Jp = ((J + 15) >> 4) << 4;
+    for (int i = threadIdx.x; i < Jp * 16; i += blockDim.x) sA[i] = i < J * 16 ? A[i] : 0.0f;
+    __syncthreads();
+    float T[16], dT[16];
+    sg_skin_T16(W, J, P, g0, lane, sA, sW[wave], sT[wave], T);
+    const bool live = idx < P;
+#pragma unroll
+    for (int i = 0; i < 16; i++) dT[i] = (live && dT_in) ? dT_in[(size_t)idx * 16 + i] : 0.0f;
+    if (live && dverts_in) {
+        const float g[3] = { dverts_in[3 * idx], dverts_in[3 * idx + 1], dverts_in[3 * idx + 2] };
+        const float vh[4] = { v[3 * idx], v[3 * idx + 1], v[3 * idx + 2], 1.0f };
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++) dT[4 * r + cc] += g[r] * vh[cc];
+        if (dv) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) dv[3 * idx + cc] = (T[cc] * g[0] + T[4 + cc] * g[1]) + T[8 + cc] * g[2];
+        }
+    } else if (live && dv) {
+        dv[3 * idx] = 0.0f; dv[3 * idx + 1] = 0.0f; dv[3 * idx + 2] = 0.0f;
+    }
+    float *sdT = sT[wave];
+#pragma unroll
+    for (int i = 0; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
+    float *out = slab + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
+    const int nchunk = (J + 15) >> 4;
+    for (int cch = 0; cch < nchunk; cch++) {
+        sg_stage_w_chunk(W, J, P, g0, cch, lane, sW[wave]);
+        __builtin_amdgcn_s_waitcnt(0);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            float av = sW[wave][(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];
+            float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int cch = nchunk; cch < SG_JMAX / 16; cch++)                      // rows the reduce kernels also read
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = 0.0f;
+    if (lane < 4) out[SG_JMAX * 16 + lane] = 0.0f;
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
@@ -519,4 +643,22 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                        dL_dA, dL_dtransl);
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
+}
+
+void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(sg_lbs_fwd_kernel, dim3((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), dim3(SG_SKIN_THREADS), 0, st, P, J, W,
+                       A, v, T_out, verts);
+}
+void sg_launch_lbs_bwd(int P, int J, const float *W, const float *A, const float *v, const float *dT, const float *dverts,
+                       float *slab, float *dv, float *dA, hipStream_t st)
+{
+    if (P <= 0) return;
+    const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
+    hipLaunchKernelGGL(sg_lbs_bwd_kernel, dim3(nblocks), dim3(SG_SKIN_THREADS), 0, st, P, J, W, A, v, dT, dverts, dv, slab, stride);
+    float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;
+    hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4), dim3(256), 0, st, slab,
+                       nblocks * SG_SKIN_WAVES, stride, part);
+    hipLaunchKernelGGL(sg_skin_reduce2_kernel, dim3((J * 16 + 3 + 63) / 64), dim3(64), 0, st, part, stride, J, dA, (float *)nullptr);
 }
