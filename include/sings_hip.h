@@ -133,6 +133,13 @@ int sg_lbs_forward(int P, int J, const float *lbs_weights, const float *A, const
 int sg_lbs_backward(int P, int J, const float *lbs_weights, const float *A, const float *v, const float *dT,
                     const float *dverts, float *ws, float *dv, float *dA, void *stream);
 
+/* Stand-alone matrix_to_quaternion (sings/rec/utils/geometry/rotations.py:98-149; call site sings_hybrid.py:419):
+ * matrices [N,9] row-major -> quaternions [N,4] (real first), bit-identical to the reference expression evaluated by
+ * torch on the same GPU; backward
+ * dq [N,4] -> dmatrices [N,9] (autograd of that expression: only the selected candidate receives gradient). */
+int sg_matrix_to_quaternion(int N, const float *matrices, float *quaternions, void *stream);
+int sg_matrix_to_quaternion_backward(int N, const float *matrices, const float *dq, float *dmatrices, void *stream);
+
 /* Forward.  `scales` are the CANONICAL scales [P,3]; optional outputs posed_xyz [P,3],
  * posed_rotq [P,4] (real first, not normalised), posed_scales [P,3] may be NULL. */
 int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,

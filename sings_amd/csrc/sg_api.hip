@@ -289,6 +289,22 @@ extern "C" int sg_lbs_backward(int P, int J, const float *lbs_weights, const flo
     return e == hipSuccess ? 0 : sg_fail("sg_lbs_backward", e);
 }
 
+// ---- stand-alone matrix_to_quaternion (a11)
+extern "C" int sg_matrix_to_quaternion(int N, const float *matrices, float *quaternions, void *stream)
+{
+    if (N <= 0 || !matrices || !quaternions) return sg_fail("sg_matrix_to_quaternion: bad argument", hipSuccess);
+    sg_launch_m2q(N, matrices, nullptr, quaternions, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_matrix_to_quaternion", e);
+}
+extern "C" int sg_matrix_to_quaternion_backward(int N, const float *matrices, const float *dq, float *dmatrices, void *stream)
+{
+    if (N <= 0 || !matrices || !dq || !dmatrices) return sg_fail("sg_matrix_to_quaternion_backward: bad argument", hipSuccess);
+    sg_launch_m2q(N, matrices, dq, dmatrices, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_matrix_to_quaternion_backward", e);
+}
+
 // ---- attribute decode (f3)
 extern "C" size_t sg_triplane_ws_bytes(const SgTriplane *tp) { return sg_tp_check(tp) ? 0 : sg_triplane_ws_bytes_impl(tp); }
 extern "C" size_t sg_triplane_bwd_ws_bytes(const SgTriplane *tp, int N)

@@ -599,6 +599,44 @@ sg_lbs_bwd_kernel(int P, int J, const float *__restrict__ W, const float *__rest
     if (lane < 4) out[SG_JMAX * 16 + lane] = 0.0f;
 }
 
+// ---- stand-alone matrix_to_quaternion (rotations.py:98-149) -------------------------------------------------
+// One lane per matrix (the reference: ~25 element-wise / indexing kernels each way).  Same operation order as the torch
+// expression -> bit-identical quaternions (golden G1).
+__global__ void __launch_bounds__(256)
+sg_m2q_fwd_kernel(int N, const float *__restrict__ m, float *__restrict__ q)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float mm[9], qq[4], qab;
+    int best;
+#pragma unroll
+    for (int k = 0; k < 9; k++) mm[k] = m[9 * (size_t)i + k];
+    sg_m2q(mm, qq, best, qab);
+    *(float4 *)(q + 4 * (size_t)i) = make_float4(qq[0], qq[1], qq[2], qq[3]);
+}
+__global__ void __launch_bounds__(256)
+sg_m2q_bwd_kernel(int N, const float *__restrict__ m, const float *__restrict__ dq, float *__restrict__ dm)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    float mm[9], qq[4], qab, g[4], d[9];
+    int best;
+#pragma unroll
+    for (int k = 0; k < 9; k++) mm[k] = m[9 * (size_t)i + k];
+    sg_m2q(mm, qq, best, qab);
+    const float4 gq = *(const float4 *)(dq + 4 * (size_t)i);
+    g[0] = gq.x; g[1] = gq.y; g[2] = gq.z; g[3] = gq.w;
+    sg_m2q_bwd(qq, best, qab, g, d);
+#pragma unroll
+    for (int k = 0; k < 9; k++) dm[9 * (size_t)i + k] = d[k];
+}
+void sg_launch_m2q(int N, const float *m, const float *dq, float *out, hipStream_t st)
+{
+    if (N <= 0) return;
+    if (dq) hipLaunchKernelGGL(sg_m2q_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, m, dq, out);
+    else hipLaunchKernelGGL(sg_m2q_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, m, out);
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,

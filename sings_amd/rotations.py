@@ -29,7 +29,49 @@ def _sqrt_positive_part(x):
     return ret
 
 
+class _M2Q(torch.autograd.Function):
+    """matrix_to_quaternion on the MI355X: one kernel each way instead of ~25 (sg_matrix_to_quaternion[_backward])."""
+
+    @staticmethod
+    def forward(ctx, matrix):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        m = matrix.contiguous()
+        N = m.numel() // 9
+        q = torch.empty(m.shape[:-2] + (4,), dtype=torch.float32, device=m.device)
+        with torch.cuda.device(m.device):
+            _lib.check(lib.sg_matrix_to_quaternion(N, C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream)), "matrix_to_quaternion")
+        ctx.save_for_backward(m)
+        return q
+
+    @staticmethod
+    def backward(ctx, dq):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        (m,) = ctx.saved_tensors
+        dq = dq.contiguous().float()
+        dm = torch.empty_like(m)
+        with torch.cuda.device(m.device):
+            _lib.check(lib.sg_matrix_to_quaternion_backward(m.numel() // 9, C.c_void_p(m.data_ptr()), C.c_void_p(dq.data_ptr()),
+                                                            C.c_void_p(dm.data_ptr()),
+                                                            C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream)),
+                       "matrix_to_quaternion backward")
+        return dm
+
+
 def matrix_to_quaternion(matrix):
+    """rotations.py:98-149.  fp32 matrices on the GPU go through the HIP kernel (per-Gaussian rotations: [N,3,3] with
+    N ~ 1e5, sings_hybrid.py:419); anything else (fp64, CPU-side pose bookkeeping of a few joints) through the same
+    expression in torch.  On the GPU both give bit-identical fp32 quaternions (within one ulp of the CPU golden G1)."""
+    if matrix.is_cuda and matrix.dtype == torch.float32 and matrix.numel() >= 9:
+        return _M2Q.apply(matrix)
+    return _matrix_to_quaternion_torch(matrix)
+
+
+def _matrix_to_quaternion_torch(matrix):
     batch_dim = matrix.shape[:-2]
     m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch_dim + (9,)), dim=-1)
     q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
