@@ -597,9 +597,9 @@ def test_deferred_overflow_check():
 @pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 4096, 4097])
 def test_list_lengths_on_internal_boundaries(n):
     """A tile whose list has exactly n entries, n on the boundaries of the wave sort / depth segments (256) and of the
-    sort chunks (4096): binning bit-exact, image and gradients vs the oracle (the sweep of tools/fuzz_parity.py)."""
+    sort chunks (4096): binning bit-exact, image and gradients vs the oracle (the sweep of tests/tools/fuzz_parity.py)."""
     import importlib.util, os
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(__file__)), "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     R, mx = fz.check(fz.crafted(n, n), f"crafted {n}")
     assert mx >= n

@@ -1,9 +1,9 @@
-"""Times the attribute decode on the GPU box: python tools/decode_time.py
+"""Times the attribute decode on the GPU box: python tests/tools/decode_time.py
 ours = HIP tri-plane + bias/activation kernels + library GEMMs; eager = the reference's formulation (the oracle's torch
 ops: 9 x F.grid_sample, nn.Linear, GELU) on the same GPU; cpu = the same on the host for a bounded sample."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import decode_oracle as do
 from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField, decode_attributes
 dev = torch.device("cuda:0")

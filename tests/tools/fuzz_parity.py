@@ -1,10 +1,10 @@
-"""Randomised HIP-vs-oracle parity sweep (GPU box): python tools/fuzz_parity.py [n_cases]
+"""Randomised HIP-vs-oracle parity sweep (GPU box): python tests/tools/fuzz_parity.py [n_cases]
 Random scene sizes / SH degrees / densities / opacity scales, plus crafted tiles whose list length sits exactly on the
 internal boundaries (256 = wave sort / depth segment, 4096 = sort chunk).  Checks per case: binning bit-exact, RGB <= 2e-5
 off borderline pixels, gradients within tolerance.  Exit code 1 on the first failure (prints the case)."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import raster_oracle as ro
 from sings_amd.scene import synthetic_scene
 from sings_amd.inspect_ws import forward_with_state

@@ -1,7 +1,7 @@
-"""Times the stand-alone lbs_extra (GPU box): python tools/lbs_time.py -- HIP op vs the reference formulation in torch eager."""
+"""Times the stand-alone lbs_extra (GPU box): python tests/tools/lbs_time.py -- HIP op vs the reference formulation in torch eager."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import lbs_oracle as lo
 from sings_amd.lbs import lbs_extra
 dev = torch.device("cuda:0")
