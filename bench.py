@@ -587,13 +587,24 @@ def main_avatar(a):
                     T(s["lbs_weights"]), A_all[0].cpu().view(J, 4, 4), T(s["smpl_scale"]), T(s["transl"]),
                     T(cam["world_view_transform"]), T(cam["full_proj_transform"]), T(cam["camera_center"]), W, H,
                     math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5))
-            ts = []
-            for _ in range(3):
-                t1 = time.perf_counter(); lp.lbs_project(*args); ts.append(time.perf_counter() - t1)
-            tm = sorted(ts)[len(ts) // 2]
+            def median_ms(argv, reps):
+                lp.lbs_project(*argv)                                    # (first call: thread pool start-up)
+                ts = []
+                for _ in range(reps):
+                    t1 = time.perf_counter(); lp.lbs_project(*argv); ts.append(time.perf_counter() - t1)
+                return sorted(ts)[len(ts) // 2] * 1e3
+            tm = median_ms(args, 5) * 1e-3
+            # median of 10 runs at N = 6 890 (the SMPL template), 50 k and 200 k points (the first N of the
+            # avatar cloud, tiled past 150 k)
+            sweep = {}
+            for n in (6890, 50000, 200000):
+                idx = torch.arange(n) % N
+                sub = tuple(x[idx] if torch.is_tensor(x) and x.dim() > 0 and x.shape[0] == N else x for x in args)
+                sweep[str(n)] = round(median_ms(sub, 10), 3)
             out["cpu_baseline"] = {"value": 1.0 / tm, "unit": "frames/s (LBS + project only, no raster)", "cores": nthr,
                                    "kind": "port", "sample": f"PyTorch-CPU LBS+project (BASELINE.md section 3), N={N}, J={J}, "
-                                   f"median of 3 ({tm * 1e3:.1f} ms), torch {torch.__version__}"}
+                                   f"median of 5 ({tm * 1e3:.1f} ms), torch {torch.__version__}",
+                                   "median_ms_by_points": sweep, "host_cpus": os.cpu_count()}
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
