@@ -390,19 +390,34 @@ __device__ __forceinline__ float sg_d2(float4 q, float4 p)
 // median coarse cell holds 4 points, 10 % of the points sit in cells of 300+), and a dense point otherwise compares
 // itself with the ~2 500 points of its 27 coarse cells.  Either search is exact -- the level only changes the cost.
 #define SG_KNN_DENSE 24
+#define SG_KNN_SUB 4                   // lanes that search for one point: the ROWS of a ring are dealt to them
+template <int K>
+__device__ __forceinline__ void sg_knn_merge_group(float best[K])
+{
+#pragma unroll
+    for (int o = 1; o < SG_KNN_SUB; o <<= 1) {
+        float other[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) other[k] = __shfl_xor(best[k], o, 64);
+#pragma unroll
+        for (int k = 0; k < K; k++) sg_knn_insert<K>(other[k], best);
+    }
+}
 template <int K>
 __global__ void __launch_bounds__(256)
 sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__restrict__ grid_c,
                     const uint2 *__restrict__ cells_c, const float4 *__restrict__ sorted_f,
                     const SgGrid *__restrict__ grid_f, const uint2 *__restrict__ cells_f, float *__restrict__ mean_edge)
 {
-    // Measured and not adopted: 8 lanes per point (same rows, every 8th candidate each, K-best lists merged per ring): no
-    // faster at 150k points, 13 % slower at 500k; cell look-ups of three rows issued together + the next four candidates
-    // in flight during the inserts: 15 % slower (the bound is looser while a group is in flight, and the code grows).
-    // Where the time goes at 150k (ring count capped in a debug build): grids 130 us, own cell 18 us, ring 1 210 us,
-    // rings >= 2 90 us (the sparse tail).
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= N) return;
+    // SG_KNN_SUB lanes per point.  What a lane spends its time on is the chain row -> cell look-up -> candidates ->
+    // next row (ring 1 alone: 9 rows, 210 of the kernel's 320 us with one lane per point and 2.3 waves per SIMD); the
+    // rows of a ring are therefore dealt round-robin to the lanes of the point, each keeps the K best of ITS rows of
+    // the current ring (`mine`), the lists are merged at the end of the ring into `best` (identical in the group).
+    // 150k / 500k avatar points, whole k-NN: 1 lane 450 / 1 465 us, 4 lanes 353 / 1 048, 8 lanes 394 / 1 057, 16 lanes
+    // 461 / 1 376.  (Dealing the CANDIDATES of a row to 8 lanes instead left the chain as long as it was: no gain.  Cell
+    // look-ups of three rows issued together + the next four candidates in flight during the inserts: 15 % slower.)
+    const int gid = blockIdx.x * 256 + threadIdx.x, j = gid & (SG_KNN_SUB - 1);
+    const int s = min(gid / SG_KNN_SUB, N - 1);                  // (the tail group repeats the last point: harmless)
     const float4 p = sorted_c[s];
     SgGrid g = *grid_c;
     const uint2 *__restrict__ cells = cells_c;
@@ -414,58 +429,68 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
         sg_cell_of(g, p.x, p.y, p.z, c0);
     }
     const float cx = (p.x - g.lo[0]) * g.inv_h, cy = (p.y - g.lo[1]) * g.inv_h, cz = (p.z - g.lo[2]) * g.inv_h;
-    float best[K];
+    float best[K], mine[K];
 #pragma unroll
-    for (int k = 0; k < K; k++) best[k] = 3e38f;
+    for (int k = 0; k < K; k++) { best[k] = 3e38f; mine[k] = 3e38f; }
     const int rmax = max(max(g.dim[0], g.dim[1]), g.dim[2]);
     const float inv_h2 = g.inv_h * g.inv_h;
     for (int r = 0; r <= rmax; r++) {
         const int x0 = max(c0[0] - r, 0), x1 = min(c0[0] + r, g.dim[0] - 1);
         const int y0 = max(c0[1] - r, 0), y1 = min(c0[1] + r, g.dim[1] - 1);
         const int z0 = max(c0[2] - r, 0), z1 = min(c0[2] + r, g.dim[2] - 1);
-        for (int z = z0; z <= z1; z++) {
-            // squared distance (in cell units) from p to the slab of cells z / the row (y, z): rows and cells that lie
-            // farther than the current K-th best (inf until K points are known) cannot improve it and are skipped
-            // (0.999 / 1.001: rounding of the cell maths)
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        for (int i = j; i < nrows; i += SG_KNN_SUB) {
+            const int z = z0 + i / ny, y = y0 + i % ny;
+            // squared distance (in cell units) from p to the row of cells (y, z): rows and cells farther than the K-th best
+            // so far (finished rings and this lane's rows of the current one; inf until K points are known) cannot improve
+            // the result and are skipped (0.999 / 1.001: rounding of the cell maths)
             const float ez = fmaxf(fmaxf((float)z - cz, cz - (float)(z + 1)), 0.0f);
-            for (int y = y0; y <= y1; y++) {
-                const float ey = fmaxf(fmaxf((float)y - cy, cy - (float)(y + 1)), 0.0f);
-                const float lim = best[K - 1] * inv_h2;
-                const float dyz = (ey * ey + ez * ez) * 0.999f;
-                if (dyz >= lim) continue;
-                const bool shell_row = (abs(z - c0[2]) == r) || (abs(y - c0[1]) == r);
-                const uint32_t row = (uint32_t)((z * g.dim[1] + y) * g.dim[0]);
-                if (shell_row) {
-                    // the x range of the ring, cut to the cells within the K-th best distance, is ONE contiguous run of
-                    // the sorted array
-                    int xa = x0, xb = x1;
-                    if (lim < 1e30f) {
-                        const float rad = sqrtf(lim - dyz) * 1.001f + 1e-3f;
-                        xa = max(xa, (int)floorf(cx - rad)); xb = min(xb, (int)floorf(cx + rad));
-                        if (xa > xb) continue;
-                    }
-                    const uint2 ca = cells[row + xa], cb = cells[row + xb];
-                    uint32_t t = ca.x;
-                    const uint32_t e = cb.x + cb.y;
-                    for (; t + 4 <= e; t += 4) {
-                        const float4 q0 = sorted[t], q1 = sorted[t + 1], q2 = sorted[t + 2], q3 = sorted[t + 3];
-                        sg_knn_insert<K>(sg_d2(q0, p), best); sg_knn_insert<K>(sg_d2(q1, p), best);
-                        sg_knn_insert<K>(sg_d2(q2, p), best); sg_knn_insert<K>(sg_d2(q3, p), best);
-                    }
-                    for (; t < e; t++) sg_knn_insert<K>(sg_d2(sorted[t], p), best);
-                } else {
-                    // interior row: only the two end cells (if they are at distance r in x)
-                    for (int side = 0; side < 2; side++) {
-                        const int x = side ? c0[0] + r : c0[0] - r;
-                        if (x < 0 || x >= g.dim[0]) continue;
-                        const float ex = fmaxf(fmaxf((float)x - cx, cx - (float)(x + 1)), 0.0f);
-                        if (dyz + ex * ex * 0.999f >= best[K - 1] * inv_h2) continue;
-                        const uint2 cc = cells[row + x];
-                        for (uint32_t t = cc.x; t < cc.x + cc.y; t++) sg_knn_insert<K>(sg_d2(sorted[t], p), best);
+            const float ey = fmaxf(fmaxf((float)y - cy, cy - (float)(y + 1)), 0.0f);
+            const float lim = fminf(best[K - 1], mine[K - 1]) * inv_h2;
+            const float dyz = (ey * ey + ez * ez) * 0.999f;
+            if (dyz >= lim) continue;
+            const bool shell_row = (abs(z - c0[2]) == r) || (abs(y - c0[1]) == r);
+            const uint32_t row = (uint32_t)((z * g.dim[1] + y) * g.dim[0]);
+            if (shell_row) {
+                // the x range of the ring, cut to the cells within the K-th best distance, is ONE contiguous run of the
+                // sorted array
+                int xa = x0, xb = x1;
+                if (lim < 1e30f) {
+                    const float rad = sqrtf(lim - dyz) * 1.001f + 1e-3f;
+                    xa = max(xa, (int)floorf(cx - rad)); xb = min(xb, (int)floorf(cx + rad));
+                    if (xa > xb) continue;
+                }
+                const uint2 ca = cells[row + xa], cb = cells[row + xb];
+                uint32_t t = ca.x;
+                const uint32_t e = cb.x + cb.y;
+                for (; t + 4 <= e; t += 4) {
+                    const float4 q0 = sorted[t], q1 = sorted[t + 1], q2 = sorted[t + 2], q3 = sorted[t + 3];
+                    const float d0 = sg_d2(q0, p), d1 = sg_d2(q1, p), d2 = sg_d2(q2, p), d3 = sg_d2(q3, p);
+                    if (d0 < best[K - 1]) sg_knn_insert<K>(d0, mine);
+                    if (d1 < best[K - 1]) sg_knn_insert<K>(d1, mine);
+                    if (d2 < best[K - 1]) sg_knn_insert<K>(d2, mine);
+                    if (d3 < best[K - 1]) sg_knn_insert<K>(d3, mine);
+                }
+                for (; t < e; t++) { const float d = sg_d2(sorted[t], p); if (d < best[K - 1]) sg_knn_insert<K>(d, mine); }
+            } else {
+                // interior row: only the two end cells (if they are at distance r in x)
+                for (int side = 0; side < 2; side++) {
+                    const int x = side ? c0[0] + r : c0[0] - r;
+                    if (x < 0 || x >= g.dim[0]) continue;
+                    const float ex = fmaxf(fmaxf((float)x - cx, cx - (float)(x + 1)), 0.0f);
+                    if (dyz + ex * ex * 0.999f >= fminf(best[K - 1], mine[K - 1]) * inv_h2) continue;
+                    const uint2 cc = cells[row + x];
+                    for (uint32_t t = cc.x; t < cc.x + cc.y; t++) {
+                        const float d = sg_d2(sorted[t], p);
+                        if (d < best[K - 1]) sg_knn_insert<K>(d, mine);
                     }
                 }
             }
         }
+        // this ring's candidates: K best of the group's lists, then into the running list; the lanes' lists start empty again
+        sg_knn_merge_group<K>(mine);
+#pragma unroll
+        for (int k = 0; k < K; k++) { sg_knn_insert<K>(mine[k], best); mine[k] = 3e38f; }
         // distance from p to the nearest face of the searched cube that is not the grid boundary
         float reach = 3e38f;
         if (c0[0] - r > 0) reach = fminf(reach, cx - (float)(c0[0] - r));
@@ -482,7 +507,7 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
     float m = 0.0f;
 #pragma unroll
     for (int k = 1; k < K; k++) m += sqrtf(best[k]);
-    mean_edge[__float_as_uint(p.w)] = m / (float)(K - 1);
+    if (j == 0 && gid / SG_KNN_SUB < N) mean_edge[__float_as_uint(p.w)] = m / (float)(K - 1);
 }
 
 // loss = mean((s_i - l_i)^2), dL/ds_i = 2 (s_i - l_i) / N   (edge lengths are detached in the reference)
@@ -595,7 +620,7 @@ int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void
     const int nb = sg_nb(N);
     hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(nb), dim3(256), 0, st, N, xyz, bpart);
     SgKnnGrid gc, gf;
-    const int nbq = nb;
+    const int nbq = (int)(((size_t)N * SG_KNN_SUB + 255) / 256);
     if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells(N), b, &gc, st)) return 2;
     if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells_fine(N), b, &gf, st)) return 2;
     if (K == 9) hipLaunchKernelGGL(sg_knn_query_kernel<9>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
