@@ -598,20 +598,22 @@ void sg_launch_bias_act_bwd(int N, int C, int act, const float *z, const float *
 typedef float sg_v16f __attribute__((ext_vector_type(16)));
 #define SG_WG_ROWS 256
 
-template <int TI>
+// RR = rows of x / dz per round (one barrier per round): 32 for <= 96 input columns, 16 for 128 (measured: 604 -> 550 us
+// over the nine decoder layers at 150k points; 64 rows lose again)
+template <int TI, int RR>
 __global__ void __launch_bounds__(256)
 sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
                 float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad)
 {
     // the four waves need the same 16 rows of x per round: they go through LDS once (double-buffered, one barrier per
     // round) instead of being read from L2/HBM by every wave (4x the traffic made the direct version bandwidth-bound)
-    __shared__ float sX[2][16][TI * 32 + 4];
+    __shared__ float sX[2][RR][TI * 32 + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = 32 * wave < cout_pad;
     const int o = 32 * wave + (lane & 31), half = lane >> 5;
     const bool ok_o = active && o < Cout;
     constexpr int CIN = TI * 32;
-    constexpr int F4 = 16 * CIN / 4;                 // float4 elements of one 16-row slab
+    constexpr int F4 = RR * CIN / 4;          // float4 elements of one slab
     constexpr int PER = (F4 + 255) / 256;            // per thread
     sg_v16f acc[TI];
 #pragma unroll
@@ -637,10 +639,10 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
                 if (f < F4) *(float4 *)&sX[buf][row][4 * c4] = xr[q];
             }
         };
-        float an[8];
+        float an[RR / 2];
         auto fetch_a = [&](int n) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < RR / 2; u++) {
                 const int row = n + 2 * u + half;
                 an[u] = (ok_o && row < r1) ? dz[(size_t)row * Cout + o] : 0.0f;
             }
@@ -651,21 +653,21 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
         stash(0);
         __syncthreads();
         int buf = 0;
-        for (int n = r0; n < r1; n += 16, buf ^= 1) {
-            float a[8];
+        for (int n = r0; n < r1; n += RR, buf ^= 1) {
+            float a[RR / 2];
 #pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = an[u];
-            if (n + 16 < r1) { fetch(n + 16); fetch_a(n + 16); }      // next round's operands are in flight during the MFMAs
+            for (int u = 0; u < RR / 2; u++) a[u] = an[u];
+            if (n + RR < r1) { fetch(n + RR); fetch_a(n + RR); }      // next round's operands are in flight during the MFMAs
             if (active) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
+                for (int u = 0; u < RR / 2; u++) {
                     bsum += a[u];
 #pragma unroll
                     for (int t = 0; t < TI; t++)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
                 }
             }
-            if (n + 16 < r1) stash(buf ^ 1);
+            if (n + RR < r1) stash(buf ^ 1);
             __syncthreads();
         }
     }
@@ -808,7 +810,7 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
         }
         cp = Cout;
     } else {
-#define SG_WGK(T) hipLaunchKernelGGL(sg_wgrad_kernel<T>, dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
+#define SG_WGK(T) hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32)>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
         switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
 #undef SG_WGK
     }
