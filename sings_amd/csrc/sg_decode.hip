@@ -622,42 +622,41 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
     float bsum = 0.0f;
     (void)Cin;
-    for (int r0 = blockIdx.x * SG_WG_ROWS; r0 < N; r0 += gridDim.x * SG_WG_ROWS) {
-        const int r1 = min(r0 + SG_WG_ROWS, N);
-        float4 xr[PER];
-        auto fetch = [&](int n) {
+    // every workgroup takes ONE contiguous, equally long range of rows (slices of 256 rows dealt round-robin left 74 of the
+    // 512 workgroups with two slices at 150k rows: the kernel took as long as they did)
+    const int chunk = (((N + (int)gridDim.x - 1) / (int)gridDim.x + 2 * RR - 1) / (2 * RR)) * (2 * RR);
+    {
+        const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, N);
+        // two register sets (E, O): while round n computes out of LDS, the operands of round n + 1 sit in one set (stashed
+        // to the other LDS buffer at the end of the round) and the loads of round n + 2 are in flight into the other --
+        // a round's MFMAs (0.85 us) are shorter than a memory round trip, one round of look-ahead left the waves waiting
+        float4 xrE[PER], xrO[PER];
+        float anE[RR / 2], anO[RR / 2];
+        auto fetch = [&](float4 (&xr)[PER], float (&an)[RR / 2], int n) {
 #pragma unroll
             for (int q = 0; q < PER; q++) {
                 const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
                 xr[q] = (f < F4 && n + row < r1) ? *(const float4 *)(x + (size_t)(n + row) * CIN + 4 * c4) : make_float4(0, 0, 0, 0);
             }
-        };
-        auto stash = [&](int buf) {
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
-                if (f < F4) *(float4 *)&sX[buf][row][4 * c4] = xr[q];
-            }
-        };
-        float an[RR / 2];
-        auto fetch_a = [&](int n) {
 #pragma unroll
             for (int u = 0; u < RR / 2; u++) {
                 const int row = n + 2 * u + half;
                 an[u] = (ok_o && row < r1) ? dz[(size_t)row * Cout + o] : 0.0f;
             }
         };
-        fetch(r0);
-        fetch_a(r0);
-        __syncthreads();                             // previous slice's last round is consumed
-        stash(0);
-        __syncthreads();
-        int buf = 0;
-        for (int n = r0; n < r1; n += RR, buf ^= 1) {
+        auto stash = [&](const float4 (&xr)[PER], int buf) {
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
+                if (f < F4) *(float4 *)&sX[buf][row][4 * c4] = xr[q];
+            }
+        };
+        // round n: a-values from `cur` (its x rows are in sX[buf]); `oth` holds round n + 1
+        auto round = [&](float4 (&xc)[PER], float (&ac)[RR / 2], const float4 (&xo)[PER], int n, int buf) {
             float a[RR / 2];
 #pragma unroll
-            for (int u = 0; u < RR / 2; u++) a[u] = an[u];
-            if (n + RR < r1) { fetch(n + RR); fetch_a(n + RR); }      // next round's operands are in flight during the MFMAs
+            for (int u = 0; u < RR / 2; u++) a[u] = ac[u];
+            if (n + 2 * RR < r1) fetch(xc, ac, n + 2 * RR);
             if (active) {
 #pragma unroll
                 for (int u = 0; u < RR / 2; u++) {
@@ -667,8 +666,16 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
                 }
             }
-            if (n + RR < r1) stash(buf ^ 1);
+            if (n + RR < r1) stash(xo, buf ^ 1);
             __syncthreads();
+        };
+        fetch(xrE, anE, r0);
+        if (r0 + RR < r1) fetch(xrO, anO, r0 + RR);
+        stash(xrE, 0);
+        __syncthreads();
+        for (int n = r0; n < r1; n += 2 * RR) {
+            round(xrE, anE, xrO, n, 0);
+            if (n + RR < r1) round(xrO, anO, xrE, n + RR, 1);
         }
     }
     if (!active) return;
