@@ -598,8 +598,9 @@ void sg_launch_bias_act_bwd(int N, int C, int act, const float *z, const float *
 typedef float sg_v16f __attribute__((ext_vector_type(16)));
 #define SG_WG_ROWS 256
 
-// RR = rows of x / dz per round (one barrier per round): 32 for <= 96 input columns, 16 for 128 (measured: 604 -> 550 us
-// over the nine decoder layers at 150k points; 64 rows lose again)
+// RR = rows of x / dz per round (one barrier per round): 32 for <= 96 input columns, 16 for 128 (64 rows lose again).
+// Nine decoder layers at 150k points: 604 us (16-row rounds, one round of look-ahead, 256-row slices dealt round-robin)
+// -> 550 (round size) -> 484 (two rounds of look-ahead) -> 423 us (one equally long row range per workgroup)
 template <int TI, int RR>
 __global__ void __launch_bounds__(256)
 sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
