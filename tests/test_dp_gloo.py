@@ -80,3 +80,16 @@ def test_sharder_is_deterministic_and_rank_consistent():
     for t in range(30):
         fr = a.frames_of_step(t)
         assert len(set(fr)) == 8 and fr[3] == a.frame(t)
+
+
+def test_batched_steps_cover_every_frame_once():
+    """bench.py / ViewBatch: rank r renders frames FrameSharder.frame(K * t + v), v < K, at step t (K views per rank and
+    step): within an epoch of 120 frames every (rank, step, view) slot is a different frame and all frames are rendered."""
+    W, K, F = 8, 3, 120
+    sh = [FrameSharder(F, W, r, seed=4) for r in range(W)]
+    seen = []
+    for t in range(F // (W * K)):
+        step = [sh[r].frame(K * t + v) for r in range(W) for v in range(K)]
+        assert len(set(step)) == W * K
+        seen += step
+    assert sorted(seen) == list(range(F))
