@@ -133,6 +133,17 @@ int sg_lbs_forward(int P, int J, const float *lbs_weights, const float *A, const
 int sg_lbs_backward(int P, int J, const float *lbs_weights, const float *A, const float *v, const float *dT,
                     const float *dverts, float *ws, float *dv, float *dA, void *stream);
 
+/* SMPL(-H) kinematic chain (sings/rec/utils/body_model/smpl.py:415-513: batch_rodrigues + batch_rigid_transform, what
+ * SMPL.forward / SMPLH.forward produce as `A`, smpl_layer.py:492-600): pose [B,J,3] axis-angle, joints_rest [J,3],
+ * parents [J] (parents[0] < 0, parents[i] < i) -> A [B,J,16] = G - pad(G [J;0]), optionally right-multiplied per joint by
+ * post [J,16] (inv(A_t2cano) of sings_hybrid.py:398-399; may be NULL).  One launch instead of ~100 (forward) / ~300
+ * (autograd).  Backward: dA [B,J,16] -> dpose [B,J,3] and, if djoints != NULL, the per-frame djoints [B,J,3] (the caller
+ * sums over B).  1 <= J <= 64. */
+int sg_joint_transforms(int B, int J, const float *pose, const float *joints_rest, const int32_t *parents, const float *post,
+                        float *A_out, void *stream);
+int sg_joint_transforms_backward(int B, int J, const float *pose, const float *joints_rest, const int32_t *parents,
+                                 const float *post, const float *dA, float *dpose, float *djoints, void *stream);
+
 /* Stand-alone matrix_to_quaternion (sings/rec/utils/geometry/rotations.py:98-149; call site sings_hybrid.py:419):
  * matrices [N,9] row-major -> quaternions [N,4] (real first), bit-identical to the reference expression evaluated by
  * torch on the same GPU; backward

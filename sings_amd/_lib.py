@@ -44,7 +44,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
-           "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
+           "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad")
 NUM_KERNELS = 8
@@ -88,6 +88,8 @@ def load():
     lib.sg_photo_loss.restype = C.c_int
     lib.sg_matrix_to_quaternion.argtypes = [i32, vp, vp, vp]; lib.sg_matrix_to_quaternion.restype = C.c_int
     lib.sg_matrix_to_quaternion_backward.argtypes = [i32, vp, vp, vp, vp]; lib.sg_matrix_to_quaternion_backward.restype = C.c_int
+    lib.sg_joint_transforms.argtypes = [i32, i32] + [vp] * 6; lib.sg_joint_transforms.restype = C.c_int
+    lib.sg_joint_transforms_backward.argtypes = [i32, i32] + [vp] * 8; lib.sg_joint_transforms_backward.restype = C.c_int
     lib.sg_lbs_forward.argtypes = [i32, i32] + [vp] * 6; lib.sg_lbs_forward.restype = C.c_int
     lib.sg_lbs_backward.argtypes = [i32, i32] + [vp] * 9; lib.sg_lbs_backward.restype = C.c_int
     lib.sg_triplane_ws_bytes.argtypes = [C.POINTER(SgTriplane)]; lib.sg_triplane_ws_bytes.restype = sz

@@ -289,6 +289,26 @@ extern "C" int sg_lbs_backward(int P, int J, const float *lbs_weights, const flo
     return e == hipSuccess ? 0 : sg_fail("sg_lbs_backward", e);
 }
 
+// ---- SMPL kinematic chain (a10)
+extern "C" int sg_joint_transforms(int B, int J, const float *pose, const float *joints_rest, const int32_t *parents,
+                                   const float *post, float *A_out, void *stream)
+{
+    if (B <= 0 || J < 1 || J > 64 || !pose || !joints_rest || !parents || !A_out)
+        return sg_fail("sg_joint_transforms: bad argument (1 <= J <= 64)", hipSuccess);
+    sg_launch_joint_transforms(B, J, pose, joints_rest, (const int *)parents, post, nullptr, A_out, nullptr, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_joint_transforms", e);
+}
+extern "C" int sg_joint_transforms_backward(int B, int J, const float *pose, const float *joints_rest, const int32_t *parents,
+                                            const float *post, const float *dA, float *dpose, float *djoints, void *stream)
+{
+    if (B <= 0 || J < 1 || J > 64 || !pose || !joints_rest || !parents || !dA || !dpose)
+        return sg_fail("sg_joint_transforms_backward: bad argument (1 <= J <= 64)", hipSuccess);
+    sg_launch_joint_transforms(B, J, pose, joints_rest, (const int *)parents, post, dA, dpose, djoints, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_joint_transforms_backward", e);
+}
+
 // ---- stand-alone matrix_to_quaternion (a11)
 extern "C" int sg_matrix_to_quaternion(int N, const float *matrices, float *quaternions, void *stream)
 {

@@ -129,6 +129,8 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
 // a HIP graph went wrong on ROCm 7.2 as soon as the host had synchronised once between two replays when the graph
 // contained memset nodes (tools/graph_gap.py reproduces it); a kernel node has no such problem and is no slower.
 void sg_zero_async(void *p, size_t bytes, hipStream_t st);
+void sg_launch_joint_transforms(int B, int J, const float *pose, const float *joints, const int *parents, const float *post,
+                                const float *dA, float *out0, float *out1, hipStream_t st);
 void sg_launch_m2q(int N, const float *m, const float *dq, float *out, hipStream_t st);
 void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st);
 void sg_launch_lbs_bwd(int P, int J, const float *W, const float *A, const float *v, const float *dT, const float *dverts,

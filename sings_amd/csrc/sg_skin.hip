@@ -637,6 +637,256 @@ void sg_launch_m2q(int N, const float *m, const float *dq, float *out, hipStream
     else hipLaunchKernelGGL(sg_m2q_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, m, out);
 }
 
+// ---- SMPL(-H) kinematic chain (sings/rec/utils/body_model/smpl.py:415-513) ------------------------------------
+// pose [B,J,3] axis-angle + rest joints [J,3] + parents -> A [B,J,16] = G - pad(G [J;0]) (x post[j] if given: the
+// per-joint inv(A_t2cano) of sings_hybrid.py:398-399).  torch runs this as ~100 tiny launches per call (Rodrigues, J - 1
+// dependent 4x4 products, the correction) and three times that for autograd: launch latency, ~1 ms per frame.  Here:
+// one wave per frame, lane = joint; the chain is walked in joint order (parents[i] < i) through LDS.
+struct SgRod { float R[9], th, d[3], s, c; };
+__device__ __forceinline__ void sg_rodrigues(const float v[3], SgRod &o)
+{
+    // batch_rodrigues (smpl.py:415-446): angle = |v + 1e-8|, axis = v / angle
+    const float a0 = v[0] + 1e-8f, a1 = v[1] + 1e-8f, a2 = v[2] + 1e-8f;
+    o.th = sqrtf(a0 * a0 + a1 * a1 + a2 * a2);
+    o.d[0] = v[0] / o.th; o.d[1] = v[1] / o.th; o.d[2] = v[2] / o.th;
+    o.s = sinf(o.th); o.c = cosf(o.th);
+    const float K[9] = { 0, -o.d[2], o.d[1], o.d[2], 0, -o.d[0], -o.d[1], o.d[0], 0 };
+    const float oc = 1.0f - o.c;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const float kk = K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc] + K[3 * r + 2] * K[6 + cc];
+            o.R[3 * r + cc] = (r == cc ? 1.0f : 0.0f) + o.s * K[3 * r + cc] + oc * kk;
+        }
+}
+// dL/dR [9] -> dL/dv [3]
+__device__ __forceinline__ void sg_rodrigues_bwd(const float v[3], const SgRod &o, const float M[9], float dv[3])
+{
+    const float K[9] = { 0, -o.d[2], o.d[1], o.d[2], 0, -o.d[0], -o.d[1], o.d[0], 0 };
+    float K2[9], mk = 0.0f, mk2 = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            K2[3 * r + cc] = K[3 * r] * K[cc] + K[3 * r + 1] * K[3 + cc] + K[3 * r + 2] * K[6 + cc];
+            mk += M[3 * r + cc] * K[3 * r + cc]; mk2 += M[3 * r + cc] * K2[3 * r + cc];
+        }
+    const float oc = 1.0f - o.c;
+    float dK[9];                                                  // s M + (1 - c) (M K^T + K^T M)
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            float a = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 3; k++) a += M[3 * r + k] * K[3 * cc + k] + K[3 * k + r] * M[3 * k + cc];
+            dK[3 * r + cc] = o.s * M[3 * r + cc] + oc * a;
+        }
+    const float dd[3] = { dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1] };
+    float dth = o.c * mk + o.s * mk2;
+    const float ith = 1.0f / o.th;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dth -= dd[k] * v[k] * ith * ith;
+#pragma unroll
+    for (int k = 0; k < 3; k++) dv[k] = dd[k] * ith + dth * (v[k] + 1e-8f) * ith;
+}
+// C[3x4] = A[3x4] o B[3x4] as rigid 4x4 products (bottom rows 0 0 0 1)
+__device__ __forceinline__ void sg_mul34(const float *A, const float *B, float *Cm)
+{
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++)
+            Cm[4 * r + cc] = (A[4 * r] * B[cc] + A[4 * r + 1] * B[4 + cc]) + A[4 * r + 2] * B[8 + cc] + (cc == 3 ? A[4 * r + 3] : 0.0f);
+    }
+}
+__global__ void __launch_bounds__(64)
+sg_joint_transforms_fwd_kernel(int J, const float *__restrict__ pose, const float *__restrict__ joints, const int *__restrict__ parents,
+                               const float *__restrict__ post, float *__restrict__ A_out)
+{
+    __shared__ float sG[64][13];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const bool on = j < J;
+    float T[12], G[12];
+    const int par = on ? parents[j] : -1;
+    float Jj[3] = { 0, 0, 0 };
+    if (on) {
+        const float v[3] = { pose[((size_t)b * J + j) * 3], pose[((size_t)b * J + j) * 3 + 1], pose[((size_t)b * J + j) * 3 + 2] };
+        SgRod ro;
+        sg_rodrigues(v, ro);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Jj[k] = joints[3 * j + k];
+            T[4 * k] = ro.R[3 * k]; T[4 * k + 1] = ro.R[3 * k + 1]; T[4 * k + 2] = ro.R[3 * k + 2];
+            T[4 * k + 3] = Jj[k] - (par >= 0 ? joints[3 * par + k] : 0.0f);
+        }
+    }
+    for (int i = 0; i < J; i++) {
+        if (j == i) {
+            if (par < 0) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) G[k] = T[k];
+            } else {
+                float P[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) P[k] = sG[par][k];
+                sg_mul34(P, T, G);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) sG[j][k] = G[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!on) return;
+    // A = G - pad(G [J;0]): same rotation, translation t - R J
+#pragma unroll
+    for (int r = 0; r < 3; r++) G[4 * r + 3] -= (G[4 * r] * Jj[0] + G[4 * r + 1] * Jj[1]) + G[4 * r + 2] * Jj[2];
+    float *o = A_out + ((size_t)b * J + j) * 16;
+    if (post) {
+        const float *Pm = post + (size_t)j * 16;                  // full 4x4: A (bottom row 0 0 0 1) @ post
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int cc = 0; cc < 4; cc++)
+                o[4 * r + cc] = ((G[4 * r] * Pm[cc] + G[4 * r + 1] * Pm[4 + cc]) + G[4 * r + 2] * Pm[8 + cc]) + G[4 * r + 3] * Pm[12 + cc];
+#pragma unroll
+        for (int cc = 0; cc < 4; cc++) o[12 + cc] = Pm[12 + cc];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 12; k++) o[k] = G[k];
+        o[12] = 0.0f; o[13] = 0.0f; o[14] = 0.0f; o[15] = 1.0f;
+    }
+}
+// dA [B,J,16] -> dpose [B,J,3], djoints [B,J,3] (per frame; the caller sums over B)
+__global__ void __launch_bounds__(64)
+sg_joint_transforms_bwd_kernel(int J, const float *__restrict__ pose, const float *__restrict__ joints, const int *__restrict__ parents,
+                               const float *__restrict__ post, const float *__restrict__ dA, float *__restrict__ dpose,
+                               float *__restrict__ djoints)
+{
+    __shared__ float sG[64][13], sD[64][13], sJ[64][4];
+    const int b = blockIdx.x, j = threadIdx.x;
+    const bool on = j < J;
+    float T[12], G[12], dG[12];
+    const int par = on ? parents[j] : -1;
+    float Jj[3] = { 0, 0, 0 }, v[3] = { 0, 0, 0 };
+    SgRod ro;
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) v[k] = pose[((size_t)b * J + j) * 3 + k];
+        sg_rodrigues(v, ro);
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            Jj[k] = joints[3 * j + k];
+            T[4 * k] = ro.R[3 * k]; T[4 * k + 1] = ro.R[3 * k + 1]; T[4 * k + 2] = ro.R[3 * k + 2];
+            T[4 * k + 3] = Jj[k] - (par >= 0 ? joints[3 * par + k] : 0.0f);
+        }
+    }
+    for (int i = 0; i < J; i++) {                                 // forward chain again (G into LDS)
+        if (j == i) {
+            if (par < 0) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) G[k] = T[k];
+            } else {
+                float P[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) P[k] = sG[par][k];
+                sg_mul34(P, T, G);
+            }
+#pragma unroll
+            for (int k = 0; k < 12; k++) sG[j][k] = G[k];
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // dA (after post) -> dA of the un-multiplied transform (top three rows) -> dG, direct dJ
+    float dJ[3] = { 0, 0, 0 };
+#pragma unroll
+    for (int k = 0; k < 12; k++) dG[k] = 0.0f;
+    if (on) {
+        const float *g = dA + ((size_t)b * J + j) * 16;
+        float dAp[12];
+        if (post) {
+            const float *Pm = post + (size_t)j * 16;              // d(A) = dOut @ post^T, rows 0..2
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    dAp[4 * r + k] = ((g[4 * r] * Pm[4 * k] + g[4 * r + 1] * Pm[4 * k + 1]) + g[4 * r + 2] * Pm[4 * k + 2]) + g[4 * r + 3] * Pm[4 * k + 3];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++) dAp[k] = g[k];
+        }
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                dG[4 * r + cc] = dAp[4 * r + cc] - dAp[4 * r + 3] * Jj[cc];
+                dJ[cc] -= G[4 * r + cc] * dAp[4 * r + 3];
+            }
+            dG[4 * r + 3] = dAp[4 * r + 3];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) sD[j][k] = dG[k];
+    sJ[j][0] = 0.0f; sJ[j][1] = 0.0f; sJ[j][2] = 0.0f;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    float dT[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) dT[k] = 0.0f;
+    for (int i = J - 1; i >= 0; i--) {                            // reverse chain: children have larger indices
+        if (j == i) {
+#pragma unroll
+            for (int k = 0; k < 12; k++) dG[k] = sD[j][k];
+            if (par < 0) {
+#pragma unroll
+                for (int k = 0; k < 12; k++) dT[k] = dG[k];
+            } else {
+                float P[12];
+#pragma unroll
+                for (int k = 0; k < 12; k++) P[k] = sG[par][k];
+                // G = P o T:  dT.R = P.R^T dG.R, dT.t = P.R^T dG.t;  dP.R += dG.R T.R^T + dG.t T.t^T, dP.t += dG.t
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++)
+                        dT[4 * r + cc] = (P[r] * dG[cc] + P[4 + r] * dG[4 + cc]) + P[8 + r] * dG[8 + cc];
+#pragma unroll
+                for (int r = 0; r < 3; r++) {
+#pragma unroll
+                    for (int cc = 0; cc < 3; cc++)
+                        sD[par][4 * r + cc] += ((dG[4 * r] * T[4 * cc] + dG[4 * r + 1] * T[4 * cc + 1]) + dG[4 * r + 2] * T[4 * cc + 2]) +
+                                               dG[4 * r + 3] * T[4 * cc + 3];
+                    sD[par][4 * r + 3] += dG[4 * r + 3];
+                }
+                // T.t = J_j - J_parent
+#pragma unroll
+                for (int k = 0; k < 3; k++) sJ[par][k] -= dT[4 * k + 3];
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!on) return;
+    const float M[9] = { dT[0], dT[1], dT[2], dT[4], dT[5], dT[6], dT[8], dT[9], dT[10] };
+    float dv[3];
+    sg_rodrigues_bwd(v, ro, M, dv);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        dpose[((size_t)b * J + j) * 3 + k] = dv[k];
+        if (djoints) djoints[((size_t)b * J + j) * 3 + k] = dJ[k] + dT[4 * k + 3] + sJ[j][k];
+    }
+}
+void sg_launch_joint_transforms(int B, int J, const float *pose, const float *joints, const int *parents, const float *post,
+                                const float *dA, float *out0, float *out1, hipStream_t st)
+{
+    if (B <= 0) return;
+    if (dA) hipLaunchKernelGGL(sg_joint_transforms_bwd_kernel, dim3(B), dim3(64), 0, st, J, pose, joints, parents, post, dA, out0, out1);
+    else hipLaunchKernelGGL(sg_joint_transforms_fwd_kernel, dim3(B), dim3(64), 0, st, J, pose, joints, parents, post, out0);
+}
+
 // ---- launchers ---------------------------------------------------------------------------
 void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,

@@ -28,7 +28,11 @@ def amass_to_smpl_pose(poses156):
 
 
 def joint_transforms_batch(poses, joints_rest, parents=SMPL_PARENTS):
-    """poses [B, J*3] axis-angle, joints_rest [J,3] -> A [B,J,4,4]; J-1 batched matmuls for the whole chunk."""
+    """poses [B, J*3] axis-angle, joints_rest [J,3] -> A [B,J,4,4].  fp32 on the GPU: ONE launch (sg_joint_transforms, one wave
+    per frame); otherwise J-1 batched matmuls for the whole chunk in torch."""
+    if poses.is_cuda and poses.dtype == torch.float32 and joints_rest.dtype == torch.float32 and joints_rest.shape[0] <= 64:
+        from .body import joint_transforms_hip
+        return joint_transforms_hip(poses, joints_rest, parents)
     B = poses.shape[0]
     J = joints_rest.shape[0]
     R = rodrigues(poses.reshape(B * J, 3)).view(B, J, 3, 3)

@@ -114,3 +114,38 @@ def test_matrix_to_quaternion_golden_and_gradient():
     # batch dimensions and the torch path (fp64 / CPU) keep working
     assert R.matrix_to_quaternion(m.view(16, 16, 3, 3)).shape == (16, 16, 4)
     assert R.matrix_to_quaternion(m.cpu().double()).dtype == torch.float64
+
+
+@pytest.mark.parametrize("J,B", [(24, 5), (52, 3), (64, 1), (1, 2)])
+def test_joint_transforms_kernel_vs_torch_chain(J, B):
+    """sg_joint_transforms (body.joint_transforms_hip): the kinematic chain of smpl.py:415-513 in one launch, against the torch
+    restatement (pinned to golden G2 by tests/test_oracle_lbs.py) in fp64 -- values, gradients w.r.t. pose and rest joints,
+    the optional per-joint right factor; random trees in topological order; zero poses (the 1e-8 of batch_rodrigues)."""
+    from sings_amd import body
+    dev = _dev()
+    rs = np.random.RandomState(J * 7 + B)
+    parents = (-1,) + tuple(int(rs.randint(0, i)) for i in range(1, J)) if J != 24 else body.SMPL_PARENTS
+    pose_n = (0.6 * rs.randn(B, J * 3)).astype(np.float32); pose_n[0, :6] = 0.0
+    jr_n = rs.randn(J, 3).astype(np.float32); post_n = (np.eye(4)[None] + 0.2 * rs.randn(J, 4, 4)).astype(np.float32)
+    g_n = rs.randn(B, J, 4, 4).astype(np.float32)
+    for use_post in (False, True):
+        pose = torch.from_numpy(pose_n).to(dev).requires_grad_(True); jr = torch.from_numpy(jr_n).to(dev).requires_grad_(True)
+        post = torch.from_numpy(post_n).to(dev) if use_post else None
+        A = body.joint_transforms_hip(pose, jr, parents, post)
+        (A * torch.from_numpy(g_n).to(dev)).sum().backward()
+        p64 = torch.from_numpy(pose_n).double().requires_grad_(True); j64 = torch.from_numpy(jr_n).double().requires_grad_(True)
+        ref = torch.stack([body._joint_transforms_torch(p64[b], j64, parents) for b in range(B)])
+        if use_post:
+            ref = ref @ torch.from_numpy(post_n).double()[None]
+        (ref * torch.from_numpy(g_n).double()).sum().backward()
+
+        def close(a, b, what):
+            a = a.detach().cpu().numpy().astype(np.float64); b = b.detach().numpy()
+            assert (np.abs(a - b) <= 3e-5 * np.abs(b) + 3e-6 * np.abs(b).max()).all(), (what, use_post, np.abs(a - b).max())
+        close(A, ref, "A"); close(pose.grad, p64.grad, "dpose"); close(jr.grad, j64.grad, "djoints")
+    # the drop-in entry points route GPU fp32 tensors through the kernel and agree with the torch path
+    one = body.joint_transforms(torch.from_numpy(pose_n[B - 1]).to(dev), torch.from_numpy(jr_n).to(dev), parents)
+    np.testing.assert_allclose(one.cpu().numpy(), body._joint_transforms_torch(torch.from_numpy(pose_n[B - 1]), torch.from_numpy(jr_n), parents).numpy(),
+                               rtol=2e-5, atol=2e-5)
+    with pytest.raises(ValueError):
+        body.joint_transforms_hip(torch.zeros(1, 9, device=dev), torch.zeros(3, 3, device=dev), (-1, 2, 0))
