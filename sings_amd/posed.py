@@ -9,7 +9,7 @@
    fused call per frame (trainer counterpart: gs_trainer.py:664-728); posed means / quaternions never exist in HBM.
    ``streams > 1`` renders that many frames at a time on separate HIP streams through pre-allocated engines
    (``FrameAnimator``): an avatar frame is a chain of short, latency-bound kernels and a few very long tile lists, so
-   frames in flight together fill the GPU (150k-Gaussian avatar, 120 frames: 2 260 -> 7 600 frames/s with 4 streams).
+   frames in flight together fill the GPU (150k-Gaussian avatar, 120 frames: 3 100 -> 8 550 frames/s with 4 streams).
 """
 import numpy as np
 import torch
