@@ -389,7 +389,7 @@ def main_train(a):
             p.grad = None
         loss, ld, ex = step_mod(A_static, rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
         loss.backward()
-        return ld
+        return {k: v.detach().clone() for k, v in ld.items()}      # (no autograd graph kept alive across the end of a capture)
 
     cap_pairs = 0
     for f in range(0, F, 8):                                     # synchronous sizing steps: 1.25 x the largest pair count

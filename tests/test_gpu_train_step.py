@@ -99,3 +99,74 @@ def test_full_step_matches_oracle_chain():
     for gp, gc in zip(tri.grids, grids):
         for p, q in zip(gp, gc):
             close("plane", p.grad, q.grad)
+
+
+def test_full_step_replays_from_a_hip_graph():
+    """The composed step incl. the regularisers on their side stream captured into ONE HIP graph (deferred pair-count check,
+    no host round trip inside a step): replays separated by host synchronisations and by a change of the frame (joint
+    transforms updated IN PLACE) give the loss and gradients of the directly launched step."""
+    from sings_amd import rasterizer as rz
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm
+    from sings_amd.scene import avatar_scene
+    from sings_amd.train_step import AvatarStep
+    from sings_amd.body import joint_transforms
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    s = avatar_scene(N=6000, J=24, W=128, H=224, seed=5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [16, 16, 16], 'multires': [1, 2]}
+    tri = HexPlaneField(cfg, bounds=1.2, device=dev); geo = GeometryDecoder(64).to(dev); app = AppearanceDecoder(64).to(dev)
+    with torch.no_grad():
+        geo.scales[2].bias.fill_(-4.5); geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()
+    step = AvatarStep(t(s["xyz_canon"]), t(s["lbs_weights"]), tri, geo, app, l2_norm=L2Norm(), gaussian_connect=GaussiansEdgeLoss(),
+                      gaussian_connect_w=1.0).to(dev)
+    params = [p for p in step.parameters() if p.requires_grad]
+    cam = s["cam"]
+    rset = GaussianRasterizationSettings(
+        image_height=s["H"], image_width=s["W"], tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    rs = np.random.RandomState(1)
+    jr = t(s["joints_rest"])
+    frames = [joint_transforms(t(rs.normal(0, 0.15, 72).astype(np.float32)), jr, tuple(s["parents"])) for _ in range(2)]
+    gt = torch.rand(3, s["H"], s["W"], device=dev); ones = torch.ones(s["H"], s["W"], device=dev)
+    bg, sc, tr = t(s["bg"]), t(s["smpl_scale"]), t(s["transl"])
+    A_static = frames[0].clone()
+
+    def body():
+        for p in params:
+            p.grad = None
+        loss, ld, ex = step(A_static, rset, gt, ones, bg, smpl_scale=sc, transl=tr)
+        loss.backward()
+        return loss.detach().clone()     # (nothing of the autograd graph may stay alive across the end of the capture:
+                                         #  returning `loss` itself crashed hipStreamEndCapture in this test)
+
+    hint = dict(rz._capacity_hint)
+    try:
+        ref = []
+        for f in frames:                                          # eager references (synchronous mode)
+            A_static.copy_(f)
+            l = body(); torch.cuda.synchronize()
+            ref.append((float(l), [p.grad.clone() for p in params]))
+        rz.set_deferred_overflow_check(True, capacity_pairs=int(max(rz._capacity_hint.values()) * 1.5))
+        A_static.copy_(frames[0])
+        side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            body()
+        torch.cuda.current_stream(dev).wait_stream(side); torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss_static = body()
+        for k in (0, 1, 1, 0):
+            A_static.copy_(frames[k])
+            g.replay(); torch.cuda.synchronize()
+            assert rz.check_deferred_overflow(dev) > 0
+            assert abs(float(loss_static) - ref[k][0]) <= 1e-6 * abs(ref[k][0]), (k, float(loss_static), ref[k][0])
+            for p, r in zip(params, ref[k][1]):
+                d = (p.grad - r).abs().max().item()
+                assert d <= 1e-5 * r.abs().max().item() + 1e-12, (k, d)      # (tri-plane sums: atomics order)
+    finally:
+        rz.set_deferred_overflow_check(False)
+        rz._capacity_hint.clear(); rz._capacity_hint.update(hint); rz._pending.clear()
