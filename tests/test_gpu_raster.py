@@ -346,20 +346,21 @@ def test_segmented_backward_with_early_termination(opacity_scale):
         _grad_close(name, a.cpu().numpy().reshape(b.shape), b, rtol=1e-3, atol=6e-6)
 
 
-def test_cfg3_full_size_properties():
-    """BASELINE configs[1] at full size (200 k Gaussians, 1920x1080, SH degree 3) -- too big for the CPU oracle in a
-    test, so size-independent properties: every tile range is strictly sorted by (depth bits, Gaussian id), every
+@pytest.mark.parametrize("N,W,H,seed", [(200000, 1920, 1080, 3), (500000, 2048, 2048, 5)])
+def test_cfg3_full_size_properties(N, W, H, seed):
+    """BASELINE configs[2] and configs[4] at full size (200 k Gaussians @ 1920x1080; 500 k @ 2048x2048 = 16 384 tiles, the
+    packed-counter regime; SH degree 3) -- too big for the CPU oracle in a test, so size-independent properties: every tile range is strictly sorted by (depth bits, Gaussian id), every
     Gaussian appears exactly once in each tile of its rectangle and nowhere else, R = sum of tiles touched, two runs are
     bitwise identical, and the backward pass is linear in dL/dimage."""
     from sings_amd.inspect_ws import forward_with_state
     from sings_amd.engine import RasterEngine
     dev = _dev()
-    s = synthetic_scene(200000, 1920, 1080, 3, 3)
+    s = synthetic_scene(N, W, H, 3, seed)
     rs = _settings(s, dev)
     t = lambda a: torch.from_numpy(a).to(dev)
     ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
-    st = forward_with_state(rs, ins[0], ins[2], shs=ins[1], scales=ins[3], rotations=ins[4], capacity=4 * 200000)
-    R, W, H = st["R"], s["W"], s["H"]
+    st = forward_with_state(rs, ins[0], ins[2], shs=ins[1], scales=ins[3], rotations=ins[4], capacity=5 * N)
+    R = st["R"]
     gx = (W + 15) // 16
     radii = st["radii"].cpu().numpy(); rwh = st["rect_wh"].cpu().numpy(); rmin = st["rect_min"].cpu().numpy()
     tt = np.where(radii > 0, (rwh & 0xffff) * (rwh >> 16), 0).astype(np.int64)
@@ -384,7 +385,7 @@ def test_cfg3_full_size_properties():
     assert (np.bincount(pl, minlength=len(tt)) == tt).all()
     assert len(np.unique(tile_of * (1 << 20) + pl)) == R                          # no duplicate (tile, Gaussian)
     # determinism + linearity of the backward through the pre-allocated engine
-    eng = RasterEngine(200000, W, H, 16, dev, capacity_pairs=R + 4096)
+    eng = RasterEngine(N, W, H, 16, dev, capacity_pairs=R + 4096)
     eng.set_camera(rs)
     rng = np.random.RandomState(0)
     d1 = t(s["dL_dimage"]); d2 = t(rng.standard_normal(s["dL_dimage"].shape).astype(np.float32))
