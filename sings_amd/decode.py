@@ -157,13 +157,18 @@ class _LinearAct(torch.autograd.Function):
         lib = _lib.load()
         x = x.contiguous().float()
         dev, N, Cout = x.device, int(x.shape[0]), int(W.shape[0])
-        y = torch.mm(x, W.t())
-        z = torch.empty_like(y) if act != ACT_NONE else None
-        h = y                                                    # in place: y is not needed afterwards
+        # bias in the GEMM's epilogue (torch.addmm); the activation kernel then only reads z and writes h, and a layer
+        # without activation needs no second pass at all
+        z = torch.addmm(b.float(), x, W.t()) if b is not None else torch.mm(x, W.t())
         ro = row_offset.contiguous().float().reshape(-1) if row_offset is not None else None
-        with torch.cuda.device(dev):
-            _lib.check(lib.sg_bias_act_forward(N, Cout, act, _ptr(y), _ptr(b), _ptr(ro), _ptr(z), _ptr(h), _stream(dev)),
-                       "bias/act forward")
+        if act == ACT_NONE:
+            h = z
+        else:
+            h = torch.empty_like(z)
+            with torch.cuda.device(dev):
+                _lib.check(lib.sg_bias_act_forward(N, Cout, act, _ptr(z), None, _ptr(ro), None, _ptr(h), _stream(dev)),
+                           "bias/act forward")
+        z = z if act != ACT_NONE else None
         ctx.save_for_backward(x, W, z if z is not None else h, ro if ro is not None else torch.empty(0, device=dev))
         ctx.act, ctx.has_ro, ctx.has_b = act, ro is not None, b is not None
         return h
