@@ -123,7 +123,7 @@ sg_triplane_fwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
 //   2. sg_tp_bwd_point_kernel   per point: recompute the interpolation, dL/dxyz, and ONE 128-B row per plane
 //                               dL/dfeat * (product of the other two planes) plus a 16-B (cell, weights) record, both
 //                               stored at the point's SORTED slot of that plane (random 128-B writes are fire-and-forget);
-//   3. sg_tp_sorted_scatter_kernel   a half-wave streams 32 consecutive slots (rows and records are sequential in memory)
+//   3. sg_tp_sorted_scatter_kernel   a half-wave streams SG_TP_RUN consecutive slots (rows and records are sequential in memory)
 //                               and keeps the corner sums of the current texel cell in registers; a row of float atomics
 //                               leaves only when the cell changes: ~2.5e7 atomics instead of 1.7e8 on the avatar, which is
 //                               what is left of the kernel's time (46 us of streaming + ~120 us at the ~0.8 TB/s the
@@ -131,7 +131,8 @@ sg_triplane_fwd_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
 //                               workgroup per 8x8 texel block, LDS accumulators, no global atomics at all) -- an avatar
 //                               fills ~2 % of the texels, so ~100 workgroups did all the work (19 ms); rows left in point
 //                               order and gathered through the permutation (152 us of dependent random reads).
-//   Avatar cloud, 150k points: 1 180 us (plain scatter) -> 533 us.
+//   Avatar cloud, 150k points: 1 180 us (plain scatter) -> 533 us (32-point runs) -> 411 us (128-point runs: every run
+//   boundary is a flush of four rows, and there are 9 planes x N / run of them).
 // Sum order inside a texel is not fixed: reproducible to rounding, like the scatter and the reference.
 struct SgTpSort {                      // per projection c: fine grid = max over the scales of the resolutions
     int Wf[3], Hf[3];
@@ -291,7 +292,7 @@ sg_tp_bwd_point_kernel(SgTpDev d, int N, const float *__restrict__ xyz, const fl
     }
 }
 
-#define SG_TP_RUN 32                   // consecutive sorted points per half-wave
+#define SG_TP_RUN 128                  // consecutive sorted points per half-wave
 // blockIdx.y = plane (s, c).  Every half-wave (32 lanes = 32 features) walks SG_TP_RUN consecutive slots of the
 // projection's sorted order -- G rows and (cell, weights) records are sequential in memory -- and keeps the four
 // corner sums of the CURRENT texel cell in registers; they leave through one row of float atomics per corner only when
