@@ -385,11 +385,12 @@ __device__ __forceinline__ float sg_d2(float4 q, float4 p)
     return dx * dx + dy * dy + dz * dz;
 }
 
-// Two grids over the same cloud: the coarse one (~4N cells) and a fine one (~64N cells, 2.5x smaller cells).  A point
+// Two grids over the same cloud: the coarse one (~4N cells) and a fine one (~32N cells, 2x smaller cells).  A point
 // whose coarse cell holds more than SG_KNN_DENSE points searches the fine grid: an avatar's density varies 100x (the
 // median coarse cell holds 4 points, 10 % of the points sit in cells of 300+), and a dense point otherwise compares
-// itself with the ~2 500 points of its 27 coarse cells.  Either search is exact -- the level only changes the cost.
-#define SG_KNN_DENSE 24
+// itself with the ~2 500 points of its 27 coarse cells.  Either search is exact -- the level only changes the cost
+// (threshold / fine-grid size swept: 24 / 64N 353 us, 16 / 32N 330 us at 150k avatar points; 128N and 16N lose).
+#define SG_KNN_DENSE 16
 #define SG_KNN_SUB 4                   // lanes that search for one point: the ROWS of a ring are dealt to them
 template <int K>
 __device__ __forceinline__ void sg_knn_merge_group(float best[K])
@@ -571,7 +572,7 @@ void sg_launch_l2norm(int N, const float *off, const float *scales, const float 
 // workspace of the k-NN search: partials, then per grid (coarse, fine): grid struct, per-point cell / rank, sorted points,
 // cell counters + starts + block sums + (start, count) pairs
 static inline int sg_knn_max_cells(int N) { long long c = 4LL * N; if (c < 4096) c = 4096; if (c > (1 << 23)) c = 1 << 23; return (int)c; }
-static inline int sg_knn_max_cells_fine(int N) { long long c = 64LL * N; if (c < 4096) c = 4096; if (c > (1 << 25)) c = 1 << 25; return (int)c; }
+static inline int sg_knn_max_cells_fine(int N) { long long c = 32LL * N; if (c < 4096) c = 4096; if (c > (1 << 25)) c = 1 << 25; return (int)c; }
 static size_t sg_knn_grid_bytes(size_t n, size_t mc)
 {
     return 256 + 2 * sg_align(n * 4) + sg_align(n * 16) + 2 * sg_align(mc * 4) + sg_align(((mc + 1023) / 1024) * 4) + sg_align(mc * 8);
