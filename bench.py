@@ -4,37 +4,50 @@ configs[2]; SURVEY.md 8(d) scene S(200000,1920,1080,3,seed=3)), 1..8 MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts N fresh rank processes (one per GPU,
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set; it has not touched the GPU itself), waits, relays rank 0's JSON line and
+exits non-zero if any rank failed.  Under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the
+ranks are already there; either way every rank checks `world == --gpus` and the line carries what the collective layer
+saw (`rccl_world`, `dist_backend`).
+
 One "step" = one pass of the hot path over one BATCH of views per rank (default 8 views, `--views-per-step`): for
 every view the rasterizer forward (preprocess -> tile binning -> alpha composite) + backward (composite bwd ->
 per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside
 the timed region; the views of a batch are dealt round-robin to `--streams` HIP streams (default 3: the latency-bound
-binning kernels and the tile-imbalance tails of one view overlap the composite of the others; 2 640 -> 3 270 views/s
-on one GPU, sweep in DESIGN.md section 5) and their gradients are summed in one pass.  `--views-per-step 1 --streams 1`
-is the reference's one frame per step (gs_trainer.py:207-215); "ms_per_view" = ms_per_step / views.  With N > 1 every
-(rank, view) pair renders a DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the
-canonical-Gaussian gradients of the batch with ONE RCCL all-reduce per step, i.e. the 47 MB all-reduce is paid once
-per 8 views ("scaling": "weak": the batch per rank is fixed).
+binning kernels and the tile-imbalance tails of one view overlap the composite of the others) and their gradient rows
+are folded, in view order, on a communication stream while later views still render (sings_amd.dp.GradientPipeline).
+`--views-per-step 1 --streams 1` is the reference's one frame per step (gs_trainer.py:207-215); the default run times
+that too, after the batched region, and reports it as `train_step_ms_one_view`.  With N > 1 every (rank, view) pair
+renders a DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the canonical-Gaussian gradients of
+the batch with ONE RCCL all-reduce per step (chunked behind the last view's fold), i.e. the 47 MB all-reduce is paid
+once per 8 views ("scaling": "weak": the batch per rank is fixed).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
-  roofline     - dominant kernel: algorithmic bytes / its mean launch duration,
-                 measured live with HIP events on the launch stream, vs the 8 TB/s HBM peak
-  cpu_baseline - the CPU oracle (scalar C port, 1 core) timed on three full views of the same workload (~11 s)
+  roofline      - dominant kernel (the backward composite) against the bound that actually limits it: VALU issue
+                  (wave64 VALU instructions per launch from the committed PMC pass x the guide's 2 cycles per
+                  instruction / (duration x 2.4 GHz x 1024 SIMDs); duration measured live with HIP events on the launch stream)
+  roofline_hbm  - the same kernel's algorithmic bytes / duration against the 8 TB/s HBM peak (SURVEY.md 8(d) figure)
+  cpu_baseline  - PyTorch-CPU "LBS + project" (oracle/lbs_project_torch.py) on all host cores, median of 10 at
+                  N = 6 890 / 50 k / 200 k; the scalar C raster oracle (1 core, full views) rides along as an extra key
+  allreduce_*   - stand-alone collective time, the part of it the step cannot hide, bytes, per-link bound
 """
 import argparse
 import ctypes as C
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 HBM_COPY_GBS = 6290.0
+XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
+VALU_CYCLES_GUIDE = 2.0        # MI355X_MICROARCH.md constants table: one wave64 v_fma_f32 issues in 2 cycles
+VALU_CYCLES_MIX = 2.9          # tools/valu_probe.hip: measured issue cost of the backward composite's instruction mix
 
 
 def algorithmic_bytes(N, H, W, R, deg):
@@ -52,11 +65,11 @@ def algorithmic_bytes(N, H, W, R, deg):
     return per, total
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--gaussians", type=int, default=200000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -70,7 +83,11 @@ def main():
                          "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views")
     ap.add_argument("--streams", type=int, default=3,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
-                         "workspaces; the per-view gradients are summed in one pass at the end of the step)")
+                         "workspaces; the per-view gradients are folded on a communication stream)")
+    ap.add_argument("--reduce-chunks", type=int, default=4,
+                    help="pieces the last view's fold + all-reduce is pipelined in (sings_amd.dp.GradientPipeline)")
+    ap.add_argument("--one-shot-reduce", action="store_true",
+                    help="pre-round-2 schedule for comparison: fold all rows after the last view, then ONE all-reduce")
     ap.add_argument("--regularisers", action="store_true",
                     help="raster workload: also run the geometry-preserving regularisers (exact k-NN Gaussian edge loss + L2Norm, "
                          "value and gradient) once per step on a side stream -- BASELINE configs[4] is "
@@ -80,29 +97,152 @@ def main():
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
-    a = ap.parse_args()
-    if a.workload == "avatar":
-        return main_avatar(a)
-    if a.workload == "train":
-        return main_train(a)
+    return ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` (N > 1, not under a launcher): start N rank processes and relay rank 0's line.
+
+    Runs BEFORE anything in this process has initialised the GPU (no HIP call, no torch.cuda.is_available(); torch is not
+    even imported yet), and never exec()s: the ranks are ordinary children.  Ranks share a device only when the box has
+    fewer GPUs than ranks (single-GPU test boxes); RCCL refuses two ranks on one device, so that oversubscribed mode uses
+    host-staged gloo collectives and says so in the JSON line."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    import tempfile
+    out0 = tempfile.TemporaryFile()
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    # wait for all ranks; if one dies, the others would sit in a collective until its timeout: stop exactly those PIDs
+    rcs = [None] * a.gpus
+    while any(rc is None for rc in rcs):
+        for r, p in enumerate(procs):
+            if rcs[r] is None:
+                rcs[r] = p.poll()
+        if any(rc not in (None, 0) for rc in rcs):
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    p.terminate()
+            for r, p in enumerate(procs):
+                if rcs[r] is None:
+                    try:
+                        rcs[r] = p.wait(timeout=20)
+                    except subprocess.TimeoutExpired:
+                        p.kill(); rcs[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    text = out0.read().decode(errors="replace")
+    lines = [ln for ln in text.splitlines() if ln.strip()]
+    if any(rcs):
+        print(text, file=sys.stderr)
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+    if not lines or not lines[-1].lstrip().startswith("{"):
+        raise SystemExit("bench.py: rank 0 printed no JSON line")
+    for ln in lines[:-1]:
+        print(ln)
+    print(lines[-1], flush=True)
+
+
+def dist_setup(a):
+    """One process per GPU.  Returns (rank, world, device, dist module or None, info dict for the JSON line)."""
+    import torch
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
+    ndev = torch.cuda.device_count()
+    if ndev == 0 or not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("SINGS_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path on 1 GPU
+    oversub = world > ndev
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
+    dist, info = None, {"rccl_world": None, "dist_backend": None, "dist_world": 1, "ranks_per_device": 1}
+    if world > 1 or os.environ.get("SINGS_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if oversub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if dist.get_world_size() != a.gpus:
+            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+        info = {"rccl_world": None if oversub else dist.get_world_size(), "dist_backend": dist.get_backend(),
+                "dist_world": dist.get_world_size(), "ranks_per_device": -(-world // ndev)}
+    return rank, world, dev, dist, info
+
+
+def timed_region(dist, dev, steps, step):
+    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
+    import torch
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    return el
+
+
+def allreduce_probe(fp, buf, iters=10):
+    """Stand-alone collective on the step's gradient buffer: ms per call (device events; MAX over ranks is implied by the
+    collective itself), bytes, and the xGMI per-link lower bound 2 (S/W) / 153 GB/s of a reduce-scatter + all-gather that
+    uses every link of the fully connected mesh."""
+    import torch
+    if fp is None or fp.world == 1:
+        return None
+    scratch = buf.clone()
+    for _ in range(3):
+        fp.all_reduce_grads(scratch)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fp.all_reduce_grads(scratch)
+    e1.record()
+    torch.cuda.synchronize()
+    S = buf.numel() * buf.element_size()
+    return {"allreduce_ms": e0.elapsed_time(e1) / iters, "allreduce_bytes": S, "allreduce_algorithm": fp.algorithm,
+            "allreduce_per_link_bound_ms": 2.0 * (S / fp.world) / (XGMI_LINK_GBS * 1e9) * 1e3}
+
+
+def main():
+    a = parse_args()
+    if a.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(a)
+    if a.workload == "avatar":
+        return main_avatar(a)
+    if a.workload == "train":
+        return main_train(a)
+    return main_raster(a)
+
+
+def main_raster(a):
+    import numpy as np
+    import torch
+    rank, world, dev, dist, dinfo = dist_setup(a)
 
     from sings_amd import _lib
-    from sings_amd.engine import RasterEngine
+    from sings_amd.engine import RasterEngine, ViewBatch
     from sings_amd.rasterizer import GaussianRasterizationSettings
     from sings_amd.scene import synthetic_scene
 
@@ -140,14 +280,13 @@ def main():
     fp = None
     if dist is not None:
         from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"))
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
 
     n_streams = max(1, min(a.streams, k_views))
     per_view = N * (3 + 3 + 4 + 1 + 3 * shs.shape[1])
-    from sings_amd.engine import ViewBatch
     # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on different
     # streams share no state) writing its gradients into its own row of `grads`; ViewBatch deals them to the streams and
-    # sums the rows in ONE pass
+    # folds the rows (+ all-reduce) on a communication stream
     grads = ViewBatch.gradient_rows(k_views, per_view, dev)
     engs = []
     for v in range(k_views):
@@ -155,7 +294,7 @@ def main():
         e.set_camera(camera(rank * k_views + v)[3])
         engs.append(e)
     eng = engs[0]
-    batch = ViewBatch(engs, grads, n_streams)
+    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
 
     graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
 
@@ -178,7 +317,7 @@ def main():
                                                                                         "opacity": opac})
             loss.backward()
 
-    def step():
+    def step(_i=0):
         if reg is not None:
             cur = torch.cuda.current_stream(dev)
             reg_side.wait_stream(cur)
@@ -186,38 +325,55 @@ def main():
                 reg()
         if graph is not None:
             graph.replay()
-            acc = eng.grad_flat
+            if fp is not None:
+                fp.all_reduce_grads(eng.grad_flat)
+        elif a.one_shot_reduce:
+            batch.run_unreduced(one_view)
+            batch.pipe.one_shot()
         else:
-            acc = batch.run(one_view)
+            batch.run(one_view)
         if reg is not None:
             cur.wait_stream(reg_side)
-        if fp is not None:
-            fp.all_reduce_grads(acc)
 
     for _ in range(a.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el = timed_region(dist, dev, a.steps, step)
     assert all(e.num_rendered() <= e.cap for e in engs)
+    ms_per_step = el / a.steps * 1e3
+    views_s = world * a.steps * k_views / el
 
-    # per-kernel durations: HIP events around every launch, on the launch stream (separate pass)
+    # the reference's unit of work, one frame per optimisation step (gs_trainer.py:207-215): view 0 alone on the current
+    # stream, (+ the all-reduce of its gradients with several ranks), same number of views as the batched region
+    def step_one_view(_i=0):
+        one_view(0, eng)
+        if fp is not None:
+            fp.all_reduce_grads(eng.grad_flat)
+    n_one = max(20, min(a.steps * k_views, 2000))
+    for _ in range(10):
+        step_one_view()
+    el_one = timed_region(dist, dev, n_one, step_one_view)
+
+    # collective: stand-alone time and the part of it the batched step cannot hide
+    comm = allreduce_probe(fp, batch.acc)
+    if comm is not None and graph is None and not a.one_shot_reduce:
+        batch.pipe.enable_timing(True)
+        ex = []
+        for _ in range(10):
+            torch.cuda.synchronize()
+            dist.barrier()
+            step()
+            torch.cuda.synchronize()
+            ex.append(batch.pipe.exposed_ms())
+        batch.pipe.enable_timing(False)
+        comm["allreduce_exposed_ms"] = sorted(ex)[len(ex) // 2]
+        comm["allreduce_hidden_note"] = ("folds of views 0..k-2 run under later views; the last fold is pipelined with the "
+                                         f"collective in {len(batch.pipe.bounds)} chunks; exposed = last view's gradients "
+                                         "ready -> reduced sum ready (median of 10 synchronised steps)")
+
+    # per-kernel durations: HIP events around every launch, on the launch stream (separate pass, one view at a time)
     lib = _lib.load()
     lib.sg_profile_enable(1)
-    for _ in range(a.steps):
+    for _ in range(max(20, min(a.steps, 100))):
         one_view(0, eng)
     ms = (C.c_double * _lib.NUM_KERNELS)()
     cnt = (C.c_int64 * _lib.NUM_KERNELS)()
@@ -235,73 +391,137 @@ def main():
         total_bytes = N * (44 + 12 * (deg + 1) ** 2 + 4 + 2 * 75) + H * W * 12 + R * 16
     dom = max(("sg_preprocess_fwd_kernel", "sg_render_fwd_kernel", "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel"),
               key=lambda k: kern[k])
-    achieved = per[dom] / (kern[dom] * 1e-3) / 1e9
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "hbm_traffic.json")      # PMC-derived bytes per launch, if collected
-    if os.path.exists(tj):
-        try:
-            traffic = json.load(open(tj)).get(dom)
-        except Exception:
-            traffic = None
-    ms_per_step = el / a.steps * 1e3
-    views_s = world * a.steps * k_views / el
-    # secondary bound of the dominant kernel ("VALU/LDS issue ... report alongside, not the score"): VALU
-    # wave-instructions per launch from the committed PMC pass / (duration x 2.4 GHz x 1024 SIMDs), against the issue cost
-    # of its instruction mix measured with tools/valu_probe.hip (2.9 cycles per wave64 instruction)
-    valu = None
-    try:
-        import csv
-        for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_pmc_SQ.csv")):
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", fn))):
-                if r["kernel"] == dom and r["Counter_Name"] == "SQ_INSTS_VALU":
-                    instr = float(r["mean"])
-                    cpi = kern[dom] * 1e-3 * 2.4e9 * 1024 / instr
-                    valu = {"kind": "valu_issue", "source": f"profiles/{fn}", "valu_wave_instructions_per_launch": instr,
-                            "cycles_per_instruction": cpi, "issue_cost_of_the_mix": 2.9, "frac": 2.9 / cpi}
-    except Exception:
-        valu = None
+    pmc = _committed_pmc(dom)
+    hbm = {"bound": "hbm", "kernel": dom, "achieved": per[dom] / (kern[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": per[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("traffic"),
+           "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]}
+    roofline = hbm
+    if pmc.get("valu") and (N, W, H, deg) == (200000, 1920, 1080, 3) and dom in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
+        # the composite kernels are bounded by VALU issue, not bytes: instructions the kernel executes
+        # per launch (PMC pass of THIS configuration, committed under profiles/) over the live duration, against the rate
+        # at which 1024 SIMDs issue wave64 VALU instructions
+        instr = pmc["valu"]
+        rate = instr / (kern[dom] * 1e-3) / 1e9                                     # G wave-instructions / s
+        peak = SIMDS * CLOCK_HZ / VALU_CYCLES_GUIDE / 1e9
+        roofline = {"bound": "valu", "kernel": dom, "achieved": rate, "peak": peak, "unit": "G wave64-instr/s",
+                    "frac": rate / peak, "traffic": pmc.get("traffic"), "kernel_ms": kern[dom],
+                    "valu_wave_instructions_per_launch": instr, "source": pmc.get("valu_source"),
+                    "cycles_per_instruction": kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr,
+                    "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
+                    "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / (kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr),
+                    "note": "peak = guide's 2 cycles per wave64 VALU instruction; frac_vs_measured_mix_cost uses the 2.9 cycles "
+                            "tools/valu_probe.hip measures for this kernel's instruction mix"}
     out = {
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
         "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": ms_per_step, "ms_per_view": ms_per_step / k_views, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": ms_per_step, "ms_per_view": ms_per_step / k_views,
+        "train_step_ms_one_view": el_one / n_one * 1e3, "views_per_s_one_view_per_step": world * n_one / el_one,
+        "timed_region_s": el, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, fwd+bwd, "
+        "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, "
+                               f"{'forward only' if a.forward_only else 'fwd+bwd'}, "
                                f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "tile_list_mean": tile_mean,
                    "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams, "regularisers": bool(a.regularisers),
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
+                   "reduction": "one_shot" if a.one_shot_reduce or graph is not None else f"pipelined/{len(batch.pipe.bounds)}",
                    "parallelism": f"dp{world}"},
-        "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom], "secondary_bound": valu},
+        "roofline": roofline, "roofline_hbm": hbm,
         "roofline_whole_pass": {"algorithmic_bytes_per_view": total_bytes,
                                 "achieved_GBs": total_bytes * views_s / world / 1e9,
                                 "frac_of_8TBs": total_bytes * views_s / world / 1e9 / HBM_PEAK_GBS,
                                 "frac_of_measured_copy_6.29TBs": total_bytes * views_s / world / 1e9 / HBM_COPY_GBS},
         "kernel_ms": kern,
     }
+    out.update(dinfo)
+    if comm is not None:
+        out.update(comm)
     if world == 1 and not a.no_cpu_baseline:
-        from oracle import raster_oracle as ro
-        n_cpu = 3                                              # bounded sample: the first 3 cameras of the batch (~11 s)
-        t0 = time.perf_counter()
-        for v in range(n_cpu):
-            cv, cp, cc, _ = camera(v)
-            o = ro.forward(s["means3D"], s["opacities"], cv, cp, cc, W, H, s["tanfovx"], s["tanfovy"], s["bg"],
-                           scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=deg, want_margin=False)
-            ro.backward(o, s["dL_dimage"])
-        tc = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": n_cpu / tc, "unit": "views/s", "cores": 1, "kind": "port",
-                               "sample": f"{n_cpu} full views fwd+bwd of the same scene with the scalar C oracle ({tc:.1f} s)",
-                               "host_cpus": os.cpu_count()}
+        out["cpu_baseline"] = cpu_baseline(s, camera, deg, W, H)
     if dist is not None:
         dist.destroy_process_group()
     _emit(out)
 
 
+def _committed_pmc(kernel):
+    """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of the cfg3
+    bench command (profiles/*_pmc_SQ.csv, profiles/hbm_traffic.json; tools/pmc_summary.py writes them)."""
+    import csv
+    res = {}
+    pdir = os.path.join(ROOT, "profiles")
+    try:
+        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv")):
+            for r in csv.DictReader(open(os.path.join(pdir, fn))):
+                if r["kernel"] == kernel and r["Counter_Name"] == "SQ_INSTS_VALU":
+                    res["valu"], res["valu_source"] = float(r["mean"]), f"profiles/{fn}"
+    except Exception:
+        pass
+    try:
+        res["traffic"] = json.load(open(os.path.join(pdir, "hbm_traffic.json"))).get(kernel)
+    except Exception:
+        pass
+    return res
+
+
+def cpu_baseline(s, camera, deg, W, H):
+    """SURVEY.md 8(d) / BASELINE.md section 3: PyTorch-CPU "LBS + project" -- skinning (W.A, T[v;1]), rotation compose,
+    matrix_to_quaternion, then cull / project / cov3D / cov2D / radius / SH -- on ALL host cores, median of 10 runs at
+    N = 6 890, 50 k and 200 k Gaussians of the benchmark scene (its first N Gaussians and its camera; J = 52 seeded sparse
+    skinning weights and near-identity joint transforms stand in for the pose, the arithmetic does not depend on their
+    values).  The scalar C restatement of the whole rasterizer (1 core, full views fwd+bwd) rides along as an extra key."""
+    import numpy as np
+    import torch
+    from oracle import lbs_project_torch as lp
+    from oracle import raster_oracle as ro
+    T = torch.from_numpy
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    Ntot, J = s["means3D"].shape[0], 52
+    rsd = np.random.RandomState(11)
+    w = np.zeros((Ntot, J), np.float32)
+    ja, jb = rsd.randint(0, J, Ntot), rsd.randint(0, J, Ntot)
+    u = rsd.rand(Ntot).astype(np.float32)
+    w[np.arange(Ntot), ja] = u; w[np.arange(Ntot), jb] += 1 - u
+    A = np.tile(np.eye(4, dtype=np.float32), (J, 1, 1)); A[:, :3, 3] = rsd.normal(0, 1e-3, (J, 3))
+    cv, cp, cc, _ = camera(0)
+    sweep = {}
+    for n in (6890, 50000, 200000):
+        idx = np.arange(n) % Ntot
+        args = (T(s["means3D"][idx]), torch.eye(3)[None].repeat(n, 1, 1), T(s["scales"][idx]), T(s["opacities"][idx]),
+                T(s["shs"][idx]), deg, T(w[idx]), T(A), torch.ones(1), torch.zeros(3), T(cv), T(cp), T(cc), W, H,
+                s["tanfovx"], s["tanfovy"])
+        lp.lbs_project(*args)                                   # (first call: thread pool start-up)
+        ts = []
+        for _ in range(10):
+            t1 = time.perf_counter(); lp.lbs_project(*args); ts.append(time.perf_counter() - t1)
+        sweep[str(n)] = round(sorted(ts)[len(ts) // 2] * 1e3, 3)
+    cpu_model = ""
+    try:
+        cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
+    except Exception:
+        pass
+    n_cpu = 3                                                    # bounded sample: the first 3 cameras of the batch (~11 s)
+    t0 = time.perf_counter()
+    for v in range(n_cpu):
+        v_, p_, c_, _ = camera(v)
+        o = ro.forward(s["means3D"], s["opacities"], v_, p_, c_, W, H, s["tanfovx"], s["tanfovy"], s["bg"],
+                       scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=deg, want_margin=False)
+        ro.backward(o, s["dL_dimage"])
+    tc = time.perf_counter() - t0
+    ms200 = sweep[str(200000)]
+    return {"value": 1e3 / ms200, "unit": "frames/s (PyTorch-CPU LBS + project only: no binning, no composite, no backward)",
+            "cores": cores, "kind": "port",
+            "sample": f"oracle/lbs_project_torch.py, J={J}, SH deg {deg}, median of 10 runs per size, N=200000: {ms200} ms",
+            "median_ms_by_points": sweep, "cpu_model": cpu_model, "torch": torch.__version__, "host_cpus": os.cpu_count(),
+            "raster_oracle_1core": {"value": n_cpu / tc, "unit": "views/s", "cores": 1, "kind": "port",
+                                    "sample": f"{n_cpu} full views fwd+bwd of the same scene with the scalar C oracle ({tc:.1f} s)"}}
+
+
 def _tile_list_stats(eng, W, H):
     """mean / max length of the per-tile depth-sorted lists of the engine's last forward (reported with
     every number); read from the tile ranges in the binning workspace."""
+    import torch
     T = ((W + 15) // 16) * ((H + 15) // 16)
     rg = eng.binning[eng.L.bin_ranges:eng.L.bin_ranges + 8 * T].view(torch.int32).view(T, 2)
     n = (rg[:, 1] - rg[:, 0]).clamp_(min=0)
@@ -319,29 +539,14 @@ def _emit(obj):
     print(json.dumps(obj), flush=True)
 
 
-def _dist_setup():
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1 or os.environ.get("SINGS_BENCH_FORCE_DIST"):
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    return rank, world, dev, dist
-
-
 def main_train(a):
     """Extra workload: ONE COMPLETE training step of an avatar through autograd -- tri-plane + decoder decode of all
     Gaussians, fused LBS + raster forward, clamp + L1 + SSIM, L2Norm + Gaussian edge regularisers, backward through all
     of it to the planes / decoder weights / anchors (SURVEY.md 3.1 without optimiser and densification)."""
     import math
-    rank, world, dev, dist = _dist_setup()
+    import numpy as np
+    import torch
+    rank, world, dev, dist, dinfo = dist_setup(a)
     from sings_amd.body import joint_transforms
     from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
     from sings_amd.dp import FrameSharder
@@ -412,6 +617,13 @@ def main_train(a):
         with torch.cuda.graph(graph):
             ld_static = step_body()
 
+    fp = None
+    if dist is not None:
+        from sings_amd.dp import FrameParallel
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
+        sizes = [p.numel() for p in params]
+        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
+
     def step(i):
         A_static.copy_(A_all[shard.frame(i)])
         if graph is not None:
@@ -419,29 +631,23 @@ def main_train(a):
             ld = ld_static
         else:
             ld = step_body()
-        if dist is not None:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
+        if fp is not None:
+            # parameter-level gradients: gathered into ONE preallocated flat buffer, one collective, scattered back
+            gl = [p.grad for p in params]
+            torch.cat([g.reshape(-1) for g in gl], out=flat)
+            fp.all_reduce_grads(flat)
+            torch._foreach_copy_(gl, [c.view_as(g) for c, g in zip(flat.split(sizes), gl)])
         return ld
 
     for i in range(a.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        ld = step(a.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    last = {}
+
+    def timed_step(i):
+        last["ld"] = step(a.warmup + i)
+    el = timed_region(dist, dev, a.steps, timed_step)
+    ld = last["ld"]
+    comm = allreduce_probe(fp, flat) if fp is not None else None
     R_last = _rz.check_deferred_overflow(dev)                    # raises if a timed step overflowed the pair capacity
     if rank == 0:
         nparam = sum(p.numel() for p in params)
@@ -455,6 +661,9 @@ def main_train(a):
                        "gaussians": N, "trainable_parameters": nparam, "num_rendered_last": R_last, "hip_graph": not a.eager,
                        "parallelism": f"dp{world}"},
             "losses": {k: float(v.detach()) for k, v in ld.items()}})
+        out.update(dinfo)
+        if comm is not None:
+            out.update(comm)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:
@@ -464,7 +673,9 @@ def main_train(a):
 def main_avatar(a):
     """BASELINE configs[3]: frame-parallel training step of an avatar through the LBS-fused kernels."""
     import math
-    rank, world, dev, dist = _dist_setup()
+    import numpy as np
+    import torch
+    rank, world, dev, dist, dinfo = dist_setup(a)
     from sings_amd import _lib
     from sings_amd.body import joint_transforms
     from sings_amd.dp import FrameParallel, FrameSharder
@@ -519,9 +730,10 @@ def main_avatar(a):
         engs.append(e)
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
     eng = engs[0]
-    batch = ViewBatch(engs, grads, n_streams)
     shard = FrameSharder(F, world, rank, seed=0)
-    fp = FrameParallel() if dist is not None else None
+    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
+          if dist is not None else None)
+    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
     # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
     gt_rgb = torch.rand((3, H, W), device=dev)
@@ -537,28 +749,12 @@ def main_avatar(a):
         e.backward(sh, op, sc, dLi)
 
     def step(i):
-        acc = batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
-        if fp is not None:
-            fp.all_reduce_grads(acc)
+        batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
 
     for i in range(a.warmup):
         step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(a.steps):
-        step(a.warmup + i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
+    el = timed_region(dist, dev, a.steps, lambda i: step(a.warmup + i))
+    comm = allreduce_probe(fp, batch.acc)
     assert all(e.num_rendered() <= e.cap for e in engs)
     lib = _lib.load()
     lib.sg_profile_enable(1)
@@ -578,6 +774,9 @@ def main_avatar(a):
                           "width": W, "height": H, "max_num_rendered": Rmax, "tile_list_mean": tile_mean, "tile_list_max": tile_max,
                           "views_per_step": k_views, "streams": n_streams, "parallelism": f"dp{world}"},
                "kernel_ms": kern}
+        out.update(dinfo)
+        if comm is not None:
+            out.update(comm)
         if world == 1 and not a.no_cpu_baseline:
             from oracle import lbs_project_torch as lp
             T = torch.from_numpy

@@ -108,9 +108,11 @@ int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, voi
  * (gs_renderer_single.py:87-95): posed means / quaternions / T[N,4,4] stay in registers. */
 typedef struct SgSkinInputs {
     int32_t J;                /* joints: 24 (SMPL) or 52 (SMPL-H); <= 64 */
-    int32_t reserved;
+    int32_t rot_format;       /* SG_ROT_CANON_MATRIX (0) or SG_ROT_CANON_6D (1): layout of rot_canon */
     const float *xyz_canon;   /* [P,3] canonical means */
-    const float *rot_canon;   /* [P,9] row-major canonical rotation matrices, NULL = identity (isotropic) */
+    const float *rot_canon;   /* NULL = identity (isotropic, sings_hybrid.py:358-361); [P,9] row-major rotation matrices; or
+                                 [P,6] in the decoder's 6-D form -- rotation_6d_to_matrix (sings_hybrid.py:356-357,
+                                 rotations.py:545-566) is then evaluated inside the kernel and dL_drot_canon is [P,6] */
     const float *lbs_weights; /* [P,J] skinning weights */
     const float *A;           /* [J,16] row-major cano->pose joint transforms (A_t2pose @ inv_A_t2cano) */
     const float *smpl_scale;  /* [1] or NULL */
@@ -119,6 +121,7 @@ typedef struct SgSkinInputs {
     const float *ext_rot;     /* [9]   > ext_tfs of sings_hybrid.py:421-428, all or none;   */
     const float *ext_scale;   /* [1]  /  forward only (the reference uses them under no_grad) */
 } SgSkinInputs;
+enum { SG_ROT_CANON_MATRIX = 0, SG_ROT_CANON_6D = 1 };
 
 /* floats the caller must provide as `skin_ws` to sg_skinned_backward (and as `ws` to sg_lbs_backward) */
 size_t sg_skin_ws_floats(int P);
@@ -150,6 +153,24 @@ int sg_joint_transforms_backward(int B, int J, const float *pose, const float *j
  * dq [N,4] -> dmatrices [N,9] (autograd of that expression: only the selected candidate receives gradient). */
 int sg_matrix_to_quaternion(int N, const float *matrices, float *quaternions, void *stream);
 int sg_matrix_to_quaternion_backward(int N, const float *matrices, const float *dq, float *dmatrices, void *stream);
+
+/* The other conversions of sings/rec/utils/geometry/rotations.py on the path, one launch each way (the reference
+ * runs each as 10-25 element-wise torch kernels).  `op`:
+ *   SG_ROT_QUATERNION_TO_MATRIX      :38-66    in [N,4] (real first, any norm)  -> out [N,9] row-major
+ *   SG_ROT_6D_TO_MATRIX              :545-566  in [N,6] (a1, a2)                 -> out [N,9], rows b1, b2, b1 x b2
+ *                                              (every Gaussian, sings_hybrid.py:356-357)
+ *   SG_ROT_AXIS_ANGLE_TO_QUATERNION  :482-511  in [N,3]                          -> out [N,4]
+ *   SG_ROT_QUATERNION_TO_AXIS_ANGLE  :514-545  in [N,4]                          -> out [N,3]
+ * sg_rotation_convert: value.  sg_rotation_convert_backward: d_out [N, out width] -> d_in [N, in width], the gradient
+ * torch.autograd gives for the reference expression.  sg_quaternion_multiply: standardize(a * b) (:393-407 with :357,
+ * :372-390), a, b, out [N,4]; its backward writes da and db. */
+enum { SG_ROT_QUATERNION_TO_MATRIX = 0, SG_ROT_6D_TO_MATRIX = 1, SG_ROT_AXIS_ANGLE_TO_QUATERNION = 2,
+       SG_ROT_QUATERNION_TO_AXIS_ANGLE = 3 };
+int sg_rotation_convert(int op, int N, const float *in, float *out, void *stream);
+int sg_rotation_convert_backward(int op, int N, const float *in, const float *d_out, float *d_in, void *stream);
+int sg_quaternion_multiply(int N, const float *a, const float *b, float *out, void *stream);
+int sg_quaternion_multiply_backward(int N, const float *a, const float *b, const float *d_out, float *da, float *db,
+                                    void *stream);
 
 /* Forward.  `scales` are the CANONICAL scales [P,3]; optional outputs posed_xyz [P,3],
  * posed_rotq [P,4] (real first, not normalised), posed_scales [P,3] may be NULL. */
@@ -189,6 +210,13 @@ size_t sg_photo_loss_ws_bytes(int width, int height);
 int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                   const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out, float *losses,
                   const float *upstream, float *dL_draw, void *stream);
+/* The gradient alone, for an autograd backward whose upstream weights are only known later (loss.backward() of
+ * sum(loss_dict.values()), gs_trainer.py:240-262): `ws` is the workspace a forward-only sg_photo_loss call on the SAME
+ * inputs left behind (window statistics + loss scalars; not modified), `upstream` [2] device memory (NULL = (1, 1)).
+ * Forward + this call cost what the fused call costs, and nothing has to be read back to compare the two weights. */
+int sg_photo_loss_backward(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                           const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
+                           void *stream);
 
 /* ---- geometry-preserving regularisers, value + gradient ---------------------------------
  * Replace sings/rec/losses/loss_items.py (called from gs_trainer.py:355-399).  All pointers device memory;

@@ -30,7 +30,7 @@ class SgLayout(C.Structure):
 
 
 class SgSkinInputs(C.Structure):
-    _fields_ = [("J", C.c_int32), ("reserved", C.c_int32)] + [(n, C.c_void_p) for n in (
+    _fields_ = [("J", C.c_int32), ("rot_format", C.c_int32)] + [(n, C.c_void_p) for n in (
         "xyz_canon", "rot_canon", "lbs_weights", "A", "smpl_scale", "transl", "ext_trans", "ext_rot", "ext_scale")]
 
 
@@ -43,8 +43,8 @@ class SgTriplane(C.Structure):
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
            "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
-           "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
-           "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
+           "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
+           "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad")
 NUM_KERNELS = 8
@@ -86,6 +86,8 @@ def load():
     lib.sg_photo_loss_ws_bytes.restype = sz
     lib.sg_photo_loss.argtypes = [i32, i32, C.c_float, C.c_float] + [vp] * 11
     lib.sg_photo_loss.restype = C.c_int
+    lib.sg_photo_loss_backward.argtypes = [i32, i32, C.c_float, C.c_float] + [vp] * 8
+    lib.sg_photo_loss_backward.restype = C.c_int
     lib.sg_matrix_to_quaternion.argtypes = [i32, vp, vp, vp]; lib.sg_matrix_to_quaternion.restype = C.c_int
     lib.sg_matrix_to_quaternion_backward.argtypes = [i32, vp, vp, vp, vp]; lib.sg_matrix_to_quaternion_backward.restype = C.c_int
     lib.sg_joint_transforms.argtypes = [i32, i32] + [vp] * 6; lib.sg_joint_transforms.restype = C.c_int

@@ -115,10 +115,7 @@ def cano_to_pose(A_t2pose, A_t2cano):
 
 
 def rotation_6d_to_matrix(d6):
-    """sings/rec/utils/geometry/rotations.py:545-566 (Zhou et al. 6-D rotation): Gram-Schmidt of the two 3-vectors."""
-    a1, a2 = d6[..., :3], d6[..., 3:]
-    b1 = torch.nn.functional.normalize(a1, dim=-1)
-    b2 = a2 - (b1 * a2).sum(-1, keepdim=True) * b1
-    b2 = torch.nn.functional.normalize(b2, dim=-1)
-    b3 = torch.cross(b1, b2, dim=-1)
-    return torch.stack((b1, b2, b3), dim=-2)
+    """sings/rec/utils/geometry/rotations.py:545-566 (call site sings_hybrid.py:356-357, every Gaussian): the HIP kernel of
+    sings_amd.rotations (one launch each way); kept here under its round-1 name."""
+    from .rotations import rotation_6d_to_matrix as _hip
+    return _hip(d6)

@@ -109,7 +109,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     SG_CHECK_LAST("preprocess_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
     SG_CHECK_LAST("binning", s, st);
-    sg_launch_render_fwd(c, g, b, cap, im, out_color, st);
+    sg_launch_render_fwd(c, g, b, cap, im, out_color, write_point_keys, st);
     SG_CHECK_LAST("render_fwd", s, st);
     if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
     return 0;
@@ -159,6 +159,7 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
 static int sg_check_skin(const SgSkinInputs *k, int P, bool fwd)
 {
     if (!k || k->J <= 0 || k->J > 64) return 1;
+    if (k->rot_format != SG_ROT_CANON_MATRIX && k->rot_format != SG_ROT_CANON_6D) return 1;
     if (P > 0 && (!k->xyz_canon || !k->lbs_weights || !k->A)) return 1;
     int e = (k->ext_trans != nullptr) + (k->ext_rot != nullptr) + (k->ext_scale != nullptr);
     if (e != 0 && e != 3) return 1;
@@ -191,7 +192,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SG_CHECK_LAST("skin_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, 0, st);
     SG_CHECK_LAST("binning", s, st);
-    sg_launch_render_fwd(c, g, b, cap, im, out_color, st);
+    sg_launch_render_fwd(c, g, b, cap, im, out_color, 0, st);
     SG_CHECK_LAST("render_fwd", s, st);
     if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
     return 0;
@@ -269,6 +270,18 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
     return 0;
 }
 
+extern "C" int sg_photo_loss_backward(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                                      const float *mask, const float *bg, const void *ws, const float *upstream,
+                                      float *dL_draw, void *stream)
+{
+    if (width <= 0 || height <= 0) return sg_fail("sg_photo_loss_backward: bad image size", hipSuccess);
+    if (!raw || !gt_rgb || !mask || !bg || !ws || !dL_draw) return sg_fail("sg_photo_loss_backward: null pointer", hipSuccess);
+    sg_launch_photo_loss_bwd(width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, upstream, dL_draw, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sg_fail("sg_photo_loss_backward", e);
+    return 0;
+}
+
 // ---- stand-alone lbs_extra (a9)
 extern "C" int sg_lbs_forward(int P, int J, const float *lbs_weights, const float *A, const float *v, float *T_out,
                               float *verts_out, void *stream)
@@ -323,6 +336,37 @@ extern "C" int sg_matrix_to_quaternion_backward(int N, const float *matrices, co
     sg_launch_m2q(N, matrices, dq, dmatrices, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_matrix_to_quaternion_backward", e);
+}
+
+// ---- the other rotation conversions (a11)
+extern "C" int sg_rotation_convert(int op, int N, const float *in, float *out, void *stream)
+{
+    if (N <= 0 || !in || !out) return sg_fail("sg_rotation_convert: bad argument", hipSuccess);
+    if (sg_launch_rot_map(op, N, in, nullptr, out, (hipStream_t)stream)) return sg_fail("sg_rotation_convert: unknown op", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_rotation_convert", e);
+}
+extern "C" int sg_rotation_convert_backward(int op, int N, const float *in, const float *d_out, float *d_in, void *stream)
+{
+    if (N <= 0 || !in || !d_out || !d_in) return sg_fail("sg_rotation_convert_backward: bad argument", hipSuccess);
+    if (sg_launch_rot_map(op, N, in, d_out, d_in, (hipStream_t)stream)) return sg_fail("sg_rotation_convert_backward: unknown op", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_rotation_convert_backward", e);
+}
+extern "C" int sg_quaternion_multiply(int N, const float *a, const float *b, float *out, void *stream)
+{
+    if (N <= 0 || !a || !b || !out) return sg_fail("sg_quaternion_multiply: bad argument", hipSuccess);
+    sg_launch_qmul(N, a, b, nullptr, out, nullptr, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_quaternion_multiply", e);
+}
+extern "C" int sg_quaternion_multiply_backward(int N, const float *a, const float *b, const float *d_out, float *da, float *db,
+                                               void *stream)
+{
+    if (N <= 0 || !a || !b || !d_out || !da || !db) return sg_fail("sg_quaternion_multiply_backward: bad argument", hipSuccess);
+    sg_launch_qmul(N, a, b, d_out, da, db, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_quaternion_multiply_backward", e);
 }
 
 // ---- attribute decode (f3)

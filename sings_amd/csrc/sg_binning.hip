@@ -10,14 +10,17 @@
 //               arrival rank in the tile -- a RETURNING atomic on the tile counter, or (few tiles) an LDS histogram per
 //               workgroup + one global atomic per touched tile -- and is recorded as (Gaussian, tile, rank) in
 //               Gaussian-major order, load-balanced per wave
-//   2. scan   : a few workgroups turn counts into [start,end) ranges, R, and the per-tile plans of the work lists
-//   3. scatter: one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id; + work lists
-//   4. sort   : one wave per tile sorts its segment in LDS (bitonic, u64 keys); lists longer than 256: one workgroup
-//               per 4096-entry chunk, longer still: chunks merged by rank; writes point_list (+ upstream-format keys)
+//   2. scan + scatter, ONE launch (sg_scan_scatter_kernel): every workgroup turns the T tile counts into the exclusive
+//               prefix it needs -- in its own LDS, T words, L2-resident reads -- instead of waiting for a scan kernel;
+//               then one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id.  The per-tile
+//               outputs (ranges, plans, work lists, R) are written by the workgroups between them.
+//   3. sort   : lists of <= 256 entries are sorted by the forward composite kernel itself, in the LDS of the tile's
+//               workgroup, just before it gathers the records (sg_sort.h; no launch, no extra pass over the keys);
+//               longer lists: one workgroup per 4096-entry chunk (bitonic), longer still: chunks merged by rank.
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
-#include "sg_common.h"
+// (Round 1 ran scan / scatter / sort / rank as four launches: 10 + 12 + 18 + 4 us at cfg3, all latency.)
+#include "sg_sort.h"
 
-#define SG_WSORT_MAX 256       // longest list sorted by a single wave
 #define SG_SORT_THREADS 1024   // longer lists: one 1024-thread workgroup per chunk of
 #define SG_SORT_LDS 4096       // u64 entries sorted in LDS (32 KiB)
 
@@ -167,7 +170,104 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
     }
 }
 
-// ---- per-tile sort ---------------------------------------------------------------------
+// ---- scan + scatter in one launch ---------------------------------------------------------
+// Every workgroup: (1) copies the T tile counts into LDS, (2) thread t sums the derived quantities of its tpt
+// consecutive tiles, the workgroup scans the 1024 partial sums, (3) thread t walks its tiles again and leaves the
+// exclusive pair prefix (= cursor) in LDS; the threads with t % gridDim == blockIdx ALSO write their tiles' outputs
+// (ranges, cursor, checkpoint slot, plan, work-list entries), so the T tiles are written once, by all workgroups
+// between them; (4) the workgroup scatters its share of the pairs with the cursors in LDS.  No workgroup waits for
+// another one.  LDS: 4 T bytes (T <= SG_SS_MAX_TILES; larger images take the two-kernel path below).
+#define SG_SS_THREADS 1024
+#define SG_SS_MAX_TILES 32768
+__global__ void __launch_bounds__(SG_SS_THREADS)
+sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
+                       uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap, uint32_t sort_cap,
+                       uint32_t rank_cap, uint4 *__restrict__ plan, uint32_t *__restrict__ ck_start, uint32_t items_cap,
+                       const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
+                       const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
+                       uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
+                       uint32_t *__restrict__ items)
+{
+    constexpr int NQ = SG_SCAN_NQ;
+    extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
+    __shared__ uint32_t wsum[NQ][SG_SS_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[t];
+    __syncthreads();
+    const int tpt = (T + SG_SS_THREADS - 1) / SG_SS_THREADS;
+    const int t0 = tid * tpt < T ? tid * tpt : T, t1 = t0 + tpt < T ? t0 + tpt : T;
+    uint32_t own[NQ] = { 0, 0, 0, 0, 0 };
+    for (int t = t0; t < t1; t++) {
+        uint32_t q[NQ];
+        sg_scan_derive(sStart[t], q);
+#pragma unroll
+        for (int a = 0; a < NQ; a++) own[a] += q[a];
+    }
+    uint32_t incl[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) incl[a] = own[a];
+#pragma unroll 1
+    for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+        for (int a = 0; a < NQ; a++) {
+            const uint32_t u = __shfl_up(incl[a], o, 64);
+            if (lane >= o) incl[a] += u;
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int a = 0; a < NQ; a++) wsum[a][wid] = incl[a];
+    }
+    __syncthreads();
+    uint32_t run[NQ], tot[NQ];
+#pragma unroll
+    for (int a = 0; a < NQ; a++) {
+        uint32_t woff = 0, all = 0;
+#pragma unroll 1
+        for (int w = 0; w < SG_SS_THREADS / 64; w++) { const uint32_t x = wsum[a][w]; woff += w < wid ? x : 0u; all += x; }
+        run[a] = woff + incl[a] - own[a];
+        tot[a] = all;
+    }
+    const bool writer = (uint32_t)tid % gridDim.x == blockIdx.x;
+    for (int t = t0; t < t1; t++) {
+        const uint32_t v = sStart[t];
+        uint32_t q[NQ];
+        sg_scan_derive(v, q);
+        if (writer) {
+            const uint32_t s = run[0] < cap ? run[0] : cap, e = run[0] + v < cap ? run[0] + v : cap;
+            ranges[t] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
+            cursor[t] = run[0];
+            ck_start[t] = q[2] ? run[2] : 0xffffffffu;
+            plan[t] = make_uint4(run[1], run[3], run[4], v);
+            for (uint32_t sg = 0; sg < q[1]; sg++)
+                if (run[1] + sg < items_cap) items[run[1] + sg] = (uint32_t)t | (sg << 20);
+            for (uint32_t c = 0; c < q[3]; c++) {
+                if (run[3] + c < sort_cap) sort_items[run[3] + c] = make_uint2((uint32_t)t, c);
+                if (q[4] && run[4] + c < rank_cap) rank_items[run[4] + c] = make_uint2((uint32_t)t, c);
+            }
+        }
+        sStart[t] = run[0];
+#pragma unroll
+        for (int a = 0; a < NQ; a++) run[a] += q[a];
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        header[0] = tot[0];
+        header[1] = tot[0] > cap ? 1u : 0u;
+        header[3] = (uint32_t)T;
+        header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
+        header[5] = tot[1] < items_cap ? tot[1] : items_cap;
+        header[6] = tot[4] < rank_cap ? tot[4] : rank_cap;
+    }
+    __syncthreads();
+    const uint32_t R = tot[0] < cap ? tot[0] : cap;
+    for (uint32_t i = blockIdx.x * SG_SS_THREADS + tid; i < R; i += gridDim.x * SG_SS_THREADS) {
+        const uint32_t gid = pair_gid[i];
+        const uint32_t slot = sStart[pair_tile[i]] + pair_local[i];
+        if (slot < cap) pair_keys[slot] = ((uint64_t)__float_as_uint(depth[gid]) << 32) | gid;
+    }
+}
+
+// ---- long lists ---------------------------------------------------------------------------
 
 // Bitonic sort of s[0, n2) (n2 a power of two <= SG_SORT_LDS) by the whole SG_SORT_THREADS workgroup.
 // Wave w owns the comparators of a contiguous block of B = 128 * cpt elements: every stage with 2j <= B touches only
@@ -199,54 +299,18 @@ __device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid)
 }
 
 
-// lists of at most SG_WSORT_MAX entries: one wave per tile, bitonic in the wave's slice of LDS, no workgroup barriers
-__device__ __forceinline__ void sg_tile_sort_wave(int tile, uint64_t *__restrict__ s, int lane, const uint2 *__restrict__ ranges,
-                                                  const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
-                                                  uint64_t *__restrict__ point_keys)
-{
-    const uint2 r = ranges[tile];
-    const int n = (int)(r.y - r.x);
-    if (n == 0 || n > SG_WSORT_MAX) return;
-    int n2 = 1; while (n2 < n) n2 <<= 1;
-    for (int i = lane; i < n2; i += 64) s[i] = i < n ? pair_keys[r.x + i] : ~0ull;
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    for (int k = 2; k <= n2; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int t = lane; t < (n2 >> 1); t += 64) {
-                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
-                bool up = (i & k) == 0;
-                uint64_t a = s[i], b = s[ixj];
-                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-            }
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-            __builtin_amdgcn_wave_barrier();
-        }
-    for (int i = lane; i < n; i += 64) {
-        uint64_t kx = s[i];
-        point_list[r.x + i] = (uint32_t)kx;
-        if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (kx >> 32);
-    }
-}
-
-// One launch for both kinds of list.  Workgroups [0, wave_blocks): 16 short lists each, one per wave (above).  The
-// others: one workgroup per work item (tile, chunk of SG_SORT_LDS entries) of the lists longer than SG_WSORT_MAX,
-// items written by the scatter kernel; a list of one chunk is sorted and written out, the chunks of a longer list are
-// sorted in place and merged by sg_tile_rank_kernel.
+// Lists longer than SG_WSORT_MAX (the forward composite sorts the others itself): one workgroup per work item (tile,
+// chunk of SG_SORT_LDS entries), items written by the scan; a list of one chunk is sorted and written out, the chunks of
+// a longer list are sorted in place and merged by sg_tile_rank_kernel.  Exits at once when there is no such list.
 __global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_sort_kernel(int T, int wave_blocks, const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
+sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
                     const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
                     uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
 {
     __shared__ uint64_t s[SG_SORT_LDS];
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < wave_blocks) {
-        const int tile = blockIdx.x * (SG_SORT_THREADS / 64) + (tid >> 6);
-        if (tile < T) sg_tile_sort_wave(tile, s + (tid >> 6) * SG_WSORT_MAX, tid & 63, ranges, pair_keys, point_list, point_keys);
-        return;
-    }
-    const uint32_t nitems = header[4];
-    for (uint32_t li = blockIdx.x - wave_blocks; li < nitems; li += gridDim.x - wave_blocks) {
+    const uint32_t nitems = header[1] ? 0u : header[4];
+    for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
         const uint2 it = sort_items[li];
         const int tile = (int)it.x;
         const uint2 r = ranges[tile];
@@ -282,7 +346,7 @@ sg_tile_rank_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict
     __shared__ uint64_t s[SG_SORT_LDS];
     constexpr int KPT = SG_SORT_LDS / SG_SORT_THREADS;
     const int tid = threadIdx.x;
-    const uint32_t nitems = header[6];
+    const uint32_t nitems = header[1] ? 0u : header[6];
     for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
         const uint2 it = rank_items[li];
         const int tile = (int)it.x;
@@ -328,35 +392,45 @@ sg_tile_rank_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict
 void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st)
 {
-    (void)radii;
+    (void)radii; (void)P;
     const int T = c.gx * c.gy;
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
-    sg_prof_begin(SG_K_TILE_SCAN, st);
-    const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;       // at most 64 (1024-thread) / 256 (256-thread) workgroups
-#define SG_SCAN_GRID(BS) ((T + (BS) * tpt - 1) / ((BS) * tpt) > 0 ? (T + (BS) * tpt - 1) / ((BS) * tpt) : 1)
-#define SG_SCAN(BS) hipLaunchKernelGGL((sg_tile_scan_kernel<BS>), dim3(SG_SCAN_GRID(BS)), dim3(BS), 0, st, T, tpt, b.tile_count, \
-                                       b.ranges, b.cursor, b.header, cap32, sg_sort_items_cap(T, cap),                 \
-                                       sg_rank_items_cap(cap), b.plan, b.ck_start, sg_items_cap(T, cap))
-    if (T <= SG_HIST_TILES_MAX) SG_SCAN(256); else SG_SCAN(1024);
-#undef SG_SCAN
-#undef SG_SCAN_GRID
-    sg_prof_end(SG_K_TILE_SCAN, st);
-    sg_prof_begin(SG_K_TILE_SCATTER, st);
-    {
+    if (T <= SG_SS_MAX_TILES) {
+        static bool attr_set = false;                     // 4 T bytes of dynamic LDS (up to 128 KiB)
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void *)sg_scan_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SG_SS_MAX_TILES * 4);
+            attr_set = true;
+        }
+        sg_prof_begin(SG_K_TILE_SCAN, st);
+        size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
+        const int grid = (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
+        hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
+                           b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
+                           sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
+                           b.rank_items, b.items);
+        sg_prof_end(SG_K_TILE_SCAN, st);
+    } else {
+        sg_prof_begin(SG_K_TILE_SCAN, st);
+        const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;
+        const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
+        hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, tpt, b.tile_count, b.ranges, b.cursor,
+                           b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
+                           sg_items_cap(T, cap));
+        sg_prof_end(SG_K_TILE_SCAN, st);
+        sg_prof_begin(SG_K_TILE_SCATTER, st);
         size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
         hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
                            b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
                            sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap));
+        sg_prof_end(SG_K_TILE_SCATTER, st);
     }
-    sg_prof_end(SG_K_TILE_SCATTER, st);
+    // lists longer than 256 entries (the composite kernel sorts the others): both kernels exit at once when there are none
     sg_prof_begin(SG_K_TILE_SORT, st);
-    static_assert(SG_WSORT_MAX * (SG_SORT_THREADS / 64) <= SG_SORT_LDS, "16 wave slices fit the sort buffer");
-    const int wave_blocks = (T + SG_SORT_THREADS / 64 - 1) / (SG_SORT_THREADS / 64);
     const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
-    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(wave_blocks + sgrid), dim3(SG_SORT_THREADS), 0, st, T, wave_blocks, b.header,
-                       b.sort_items, b.ranges, b.pair_keys, b.point_list, pk);
+    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items, b.ranges,
+                       b.pair_keys, b.point_list, pk);
     const uint32_t rgrid = sg_rank_items_cap(cap) < 128 ? sg_rank_items_cap(cap) : 128;
     hipLaunchKernelGGL(sg_tile_rank_kernel, dim3(rgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.rank_items,
                        b.ranges, b.pair_keys, b.point_list, pk);

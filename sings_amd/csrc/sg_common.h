@@ -113,7 +113,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
                        int write_keys, hipStream_t st);
 static inline uint32_t sg_cap32(size_t cap) { return cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap; }
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
-                          hipStream_t st);
+                          int write_keys, hipStream_t st);
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, float *grec, hipStream_t st);
 void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
@@ -132,6 +132,8 @@ void sg_zero_async(void *p, size_t bytes, hipStream_t st);
 void sg_launch_joint_transforms(int B, int J, const float *pose, const float *joints, const int *parents, const float *post,
                                 const float *dA, float *out0, float *out1, hipStream_t st);
 void sg_launch_m2q(int N, const float *m, const float *dq, float *out, hipStream_t st);
+int sg_launch_rot_map(int op, int N, const float *in, const float *g, float *out, hipStream_t st);
+void sg_launch_qmul(int N, const float *a, const float *b, const float *g, float *out0, float *out1, hipStream_t st);
 void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st);
 void sg_launch_lbs_bwd(int P, int J, const float *W, const float *A, const float *v, const float *dT, const float *dverts,
                        float *slab, float *dv, float *dA, hipStream_t st);
@@ -172,6 +174,9 @@ int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void
 void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                           const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
                           float *losses, const float *upstream, float *dL_draw, hipStream_t st);
+void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                              const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
+                              hipStream_t st);
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
                         const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,

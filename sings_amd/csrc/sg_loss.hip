@@ -256,9 +256,7 @@ size_t sg_photo_loss_ws_bytes_impl(int W, int H)
     return sg_align(9 * hw * 4) + sg_align(nb * 16) + 256;
 }
 
-void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
-                          const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
-                          float *losses, const float *upstream, float *dL_draw, hipStream_t st)
+static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w)
 {
     SgLossArgs a;
     a.W = W; a.H = H; a.l1_w = l1_w; a.ssim_w = ssim_w;
@@ -268,6 +266,31 @@ void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *r
         for (int x = 0; x < 11; x++) s += g[x];
         for (int x = 0; x < 11; x++) a.w[x] = g[x] / s;
     }
+    return a;
+}
+
+// gradient pass alone over the workspace of an earlier forward-only call (window statistics + scalars)
+void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                              const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
+                              hipStream_t st)
+{
+    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w);
+    const size_t hw = (size_t)W * H;
+    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3), block(256);
+    const int nb = (int)(grid.x * grid.y * grid.z);
+    const char *b = (const char *)ws;
+    const float *maps = (const float *)b;
+    const float *scalars = (const float *)(b + sg_align(9 * hw * 4) + sg_align((size_t)nb * 16));
+    sg_prof_begin(SG_K_PHOTO_LOSS, st);
+    hipLaunchKernelGGL(sg_ssim_grad_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, scalars, upstream, dL_draw);
+    sg_prof_end(SG_K_PHOTO_LOSS, st);
+}
+
+void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                          const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
+                          float *losses, const float *upstream, float *dL_draw, hipStream_t st)
+{
+    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w);
     const size_t hw = (size_t)W * H;
     dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3), block(256);
     const int nb = (int)(grid.x * grid.y * grid.z);

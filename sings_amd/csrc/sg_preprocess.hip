@@ -17,15 +17,28 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
 {
     extern __shared__ uint32_t sg_hist_lds[];               // hist_tiles words (0: per-pair global atomics)
     __shared__ uint32_t scratch_all[4][192];
+    __shared__ float rows_lds[D == 3 ? 4 : 1][D == 3 ? 32 * SG_ROW_LDS : 1];      // SH row transpose (degree 3 only)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool live = idx < P;
     constexpr int nc = (D + 1) * (D + 1);
     float sh[nc * 3];
-    if (shs && live) {
-        const float *src = shs + (size_t)idx * c.M * 3;
+    if constexpr (D == 3) {
+        if (shs && c.M == 16) {                             // the reference's layout [P,16,3]: coalesced rows (wave-uniform)
+            float4 v[12];
+            sg_rows48_fetch(shs, idx - lane, P, lane, v);
+            sg_rows48_rows(v, lane, rows_lds[wave], sh);
+        } else if (shs && live) {
+            const float *src = shs + (size_t)idx * c.M * 3;
 #pragma unroll
-        for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+            for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+        }
+    } else {
+        if (shs && live) {
+            const float *src = shs + (size_t)idx * c.M * 3;
+#pragma unroll
+            for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+        }
     }
     SgProj o;
     o.mr = 0; o.tt = 0; o.clampbits = 0; o.x0 = o.y0 = o.x1 = o.y1 = 0;
@@ -107,23 +120,22 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
             s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
             q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
         }
-        if (shs) {
+        if (shs && !staged) {
             const float *src = shs + (size_t)idx * Mrows * 3;
-            if (staged) {
 #pragma unroll
-                for (int k = 0; k < nc * 3 / 4; k++) {
-                    float4 v = ((const float4 *)src)[k];
-                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
-            }
+            for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
         }
+    }
+    float4 shv[D == 3 ? 12 : 1];
+    if constexpr (D == 3) {
+        if (staged) sg_rows48_fetch(shs, g0, P, lane, shv);   // coalesced; transposed into per-lane rows after the records
     }
     // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
     float a9[9];
     sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+    if constexpr (D == 3) {
+        if (staged) sg_rows48_rows(shv, lane, L, sh);
+    }
     // 2. the chain rule
     if (vis)
         sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,

@@ -23,7 +23,7 @@
 //    as a 48-byte record at the Gaussian-major slot reserved in the forward pass.  No float atomics
 //    (memory-side atomics cap at ~1.3 TB/s on MI355X and scattered single-row adds are 17x slower);
 //    gradients are bitwise reproducible.
-#include "sg_common.h"
+#include "sg_sort.h"
 
 #define SG_FB 256         // forward: list entries staged per batch (one per thread)
 #define SG_BB 128         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
@@ -133,7 +133,8 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
-                     const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
+                     const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
+                     uint64_t *__restrict__ point_keys, const float4 *__restrict__ recA,
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
@@ -167,7 +168,21 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // whose list is thousands of entries long runs alone on its CU -- nothing else hides the two dependent loads)
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
     float pc = 0.0f;
-    if (tid < n) {
+    static_assert(SG_WSORT_MAX <= SG_FB && (SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 16, "sort buffers alias sA");
+    if (n > 0 && n <= SG_WSORT_MAX) {
+        // Short list (every list at cfg3): this workgroup sorts the tile's keys itself, in LDS, and hands the order to
+        // the backward pass through point_list -- the separate sort pass of round 1 (18 us, all latency) is gone and the
+        // sort of one tile overlaps the compositing of the other tiles resident on the CU.
+        uint64_t *sKey = (uint64_t *)sA;                    // aliases the staging buffer: consumed before the first batch
+        sg_sort_short_list(pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
+        if (tid < n) {
+            const uint64_t key = sKey[tid];
+            const uint32_t gid = (uint32_t)key;
+            point_list[range.x + tid] = gid;
+            if (point_keys) point_keys[range.x + tid] = ((uint64_t)tile << 32) | (key >> 32);
+            pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
+        }
+    } else if (tid < n) {                                   // long list: sorted by sg_tile_sort_kernel / sg_tile_rank_kernel
         const uint32_t gid = point_list[range.x + tid];
         pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
     }
@@ -229,14 +244,15 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
 
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
-                          hipStream_t st)
+                          int write_keys, hipStream_t st)
 {
     static_assert(SG_FB == SG_SEG, "forward batches are the checkpoint granularity");
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
-                       b.point_list, g.recA, g.recB, g.recC, c.bg, out_color, im.final_T, im.n_contrib,
+                       b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
+                       c.bg, out_color, im.final_T, im.n_contrib,
                        b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }

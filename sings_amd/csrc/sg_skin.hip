@@ -11,6 +11,7 @@
 // transpose dA[J x 16] = W^T . dT in backward likewise.  W is streamed once per pass in 64-B row
 // segments through LDS (HBM-bound: 4J bytes per Gaussian dominate).
 #include "sg_project.h"
+#include "sg_rot.h"
 
 #define SG_SKIN_THREADS 256
 #define SG_SKIN_WAVES 4
@@ -20,7 +21,7 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct SgSkin {
-    int J;
+    int J, rot6d;            // rot6d: rot_canon is [P,6] (Zhou et al. 6-D form, rotation_6d_to_matrix fused in)
     const float *xyz_canon, *rot_canon, *lbs_w, *A, *smpl_scale, *transl, *ext_trans, *ext_rot, *ext_scale;
 };
 
@@ -197,8 +198,15 @@ __device__ __forceinline__ void sg_pose_gaussian(const SgSkin &k, int idx, const
         for (int i = 0; i < 3; i++) o.p[i] = o.p[i] + k.transl[i];
     }
     if (k.rot_canon) {
+        if (k.rot6d) {       // sings_hybrid.py:356-357 fused in: the [N,3,3] matrices never exist in HBM
+            float d6[6];
 #pragma unroll
-        for (int i = 0; i < 9; i++) o.Rc[i] = k.rot_canon[9 * (size_t)idx + i];
+            for (int i = 0; i < 6; i++) d6[i] = k.rot_canon[6 * (size_t)idx + i];
+            sg_r6d2m(d6, o.Rc);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; i++) o.Rc[i] = k.rot_canon[9 * (size_t)idx + i];
+        }
 #pragma unroll
         for (int i = 0; i < 3; i++)
 #pragma unroll
@@ -365,8 +373,17 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         }
         dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
         if (dL_drot_canon) {
+            if (k.rot6d) {
+                float d6[6], dd[6];
 #pragma unroll
-            for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i];
+                for (int i = 0; i < 6; i++) d6[i] = k.rot_canon[6 * (size_t)idx + i];
+                sg_r6d2m_bwd(d6, dRc, dd);
+#pragma unroll
+                for (int i = 0; i < 6; i++) dL_drot_canon[6 * (size_t)idx + i] = dd[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i];
+            }
         }
         dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
         dL_dopacity[idx] = dop;
@@ -893,8 +910,8 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                         float *posed_rotq, float *posed_scales, hipStream_t st)
 {
     if (P <= 0) return;
-    SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
-                 in->ext_trans, in->ext_rot, in->ext_scale };
+    SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
+                 in->transl, in->ext_trans, in->ext_rot, in->ext_scale };
     dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
     const int T = c.gx * c.gy, ht = sg_lds_hist((size_t)T) ? T : 0;
 #define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
@@ -915,8 +932,8 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                         float *dL_dtransl, hipStream_t st)
 {
     if (P <= 0) return;
-    SgSkin k = { in->J, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale, in->transl,
-                 nullptr, nullptr, nullptr };
+    SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
+                 in->transl, nullptr, nullptr, nullptr };
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
 #define SG_SB(DD) hipLaunchKernelGGL(sg_skin_bwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, scales, radii, g,       \

@@ -46,17 +46,21 @@ def _tp_struct(grids, aabb, keep):
     return tp
 
 
+import weakref
+
 _aabb_cache = {}
 
 
 def _aabb_host(aabb):
     """Host copy of the (non-trainable) bounding box, read back once per VALUE: a D2H copy in every forward and backward
-    was a host synchronisation twice per training step."""
+    was a host synchronisation twice per training step.  An entry belongs to ONE tensor object (weak reference + version
+    counter): a different tensor that later lands at the same address (a second HexPlaneField after the first was freed;
+    a fresh tensor's version is 0 too) never sees the old bounds."""
     slot, key = (aabb.data_ptr(), str(aabb.device)), aabb._version
     hit = _aabb_cache.get(slot)
-    if hit is None or hit[0] != key:
+    if hit is None or hit[0] != key or hit[2]() is not aabb:
         a = aabb.detach().float().cpu()
-        hit = (key, [[float(a[r, k]) for k in range(3)] for r in range(2)])
+        hit = (key, [[float(a[r, k]) for k in range(3)] for r in range(2)], weakref.ref(aabb))
         if len(_aabb_cache) > 64:
             _aabb_cache.clear()
         _aabb_cache[slot] = hit

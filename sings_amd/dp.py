@@ -42,7 +42,7 @@ class FrameSharder:
 
 
 class FrameParallel:
-    def __init__(self, group=None, average=False, algorithm="all_reduce"):
+    def __init__(self, group=None, average=False, algorithm="all_reduce", host_staged=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU, backend 'nccl' = RCCL)")
         self.group = group
@@ -52,31 +52,55 @@ class FrameParallel:
         if algorithm not in ("all_reduce", "rs_ag"):
             raise ValueError("algorithm must be 'all_reduce' or 'rs_ag'")
         self.algorithm = algorithm
-        self._pad = None
+        # host_staged: device tensors take their collectives through a host copy (synchronous).  Only for process groups
+        # whose backend cannot see device memory -- gloo, used when several ranks have to share ONE GPU (single-GPU test
+        # boxes: RCCL refuses two ranks on a device).  Never the multi-GPU path.
+        self.host_staged = bool(host_staged)
 
-    def all_reduce_grads(self, flat):
+    def all_reduce_grads(self, flat, async_op=False):
         """Sum (or mean) of the flat canonical-Gaussian gradient buffer over all ranks, in place.
 
-        'rs_ag' = reduce-scatter + all-gather on a world-size-padded copy: on the fully connected xGMI
-        mesh (7 links x ~153 GB/s per GPU) each rank exchanges 1/W of the buffer with every peer over a
-        different link; 'all_reduce' leaves the schedule to RCCL."""
+        'rs_ag' = reduce-scatter + all-gather: on the fully connected xGMI mesh (7 links x ~153 GB/s per
+        GPU) each rank exchanges 1/W of the buffer with every peer over a different link; 'all_reduce'
+        leaves the schedule to RCCL.  The collective runs in place on ``flat``; when its length is not a
+        multiple of the world size only the ragged tail (< W elements) takes a second, tiny all-reduce --
+        the bulk is never copied.  ``async_op=True`` (device tensors): the collectives are queued on the
+        backend's stream behind the work of the CURRENT stream and a list of work handles is returned;
+        ``FrameParallel.wait(handles, flat)`` makes the current stream wait for them (and applies the
+        mean)."""
         if self.world == 1:
-            return flat
+            return [] if async_op else flat
+        if self.host_staged and flat.is_cuda:
+            h = flat.detach().cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average and not async_op:
+                h.div_(self.world)
+            flat.copy_(h)
+            return [] if async_op else flat
+        works = []
         if self.algorithm == "all_reduce":
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
         else:
-            n = flat.numel()
-            per = (n + self.world - 1) // self.world
-            if self._pad is None or self._pad.numel() != per * self.world or self._pad.device != flat.device:
-                self._pad = torch.zeros(per * self.world, dtype=flat.dtype, device=flat.device)
-            self._pad[:n].copy_(flat)
-            shard = torch.empty(per, dtype=flat.dtype, device=flat.device)
-            dist.reduce_scatter_tensor(shard, self._pad, op=dist.ReduceOp.SUM, group=self.group)
-            dist.all_gather_into_tensor(self._pad, shard, group=self.group)
-            flat.copy_(self._pad[:n])
+            n, w = flat.numel(), self.world
+            main = n // w * w
+            if main:
+                body = flat[:main]
+                shard = body.view(w, main // w)[self.rank]
+                works.append(dist.reduce_scatter_tensor(shard, body, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+                works.append(dist.all_gather_into_tensor(body, shard, group=self.group, async_op=async_op))
+            if n - main:
+                works.append(dist.all_reduce(flat[main:], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op))
+        if async_op:
+            return works
         if self.average:
             flat.div_(self.world)
         return flat
+
+    def wait(self, works, flat=None):
+        for w in works:
+            w.wait()
+        if flat is not None and self.average and self.world > 1:
+            flat.div_(self.world)
 
     def reduce_densification_stats(self, xyz_gradient_accum, denom, max_radii2D):
         """sum / sum / max over ranks, in place (identical topology decisions on every rank)."""
@@ -96,3 +120,121 @@ class FrameParallel:
             t = t.cuda()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return float(t.item()) / (self.world if op == "mean" else 1)
+
+
+class GradientPipeline:
+    """Gradient rows of the K views of one step -> ONE summed (and, with W > 1 ranks, all-reduced) buffer, off the
+    critical path of the rendering streams ("overlapped with the tail of backward-preprocess").
+
+    The views of a step finish one after another (sings_amd.engine.ViewBatch deals them to a few HIP streams).  As soon as
+    view v's backward has been queued, ``view_done(v)`` records an event on ITS stream; a dedicated communication stream
+    waits for that event and folds row v into ``acc`` (``acc = row_0``, ``acc += row_v`` -- always in view order, so the
+    sum is bit-identical however the views were interleaved, and identical to ``one_shot``).  Everything but the LAST
+    view's fold is hidden under the rendering of later views.  The last fold is done chunk by chunk and every chunk goes
+    into its collective the moment it is complete, so the fold of chunk c+1 runs under the transfer of chunk c.  What
+    cannot be hidden is one full-size all-reduce after the last view: every gradient element depends on the last
+    backward kernel of the last view, and the optimiser needs the reduced sum before the next forward (exposure is
+    reported by ``timings()``: bench.py prints it next to the stand-alone all-reduce time).
+
+    Works on CPU tensors too (no streams; used by the gloo tests)."""
+
+    def __init__(self, rows, frame_parallel=None, chunks=4):
+        if rows.dim() != 2:
+            raise ValueError("rows must be [views, floats_per_view]")
+        self.rows, self.fp = rows, frame_parallel
+        self.k, self.n = rows.shape
+        self.cuda = rows.is_cuda
+        # one view per step: the row IS the sum (no fold, no copy)
+        self.acc = rows[0] if self.k == 1 else torch.empty(self.n, dtype=rows.dtype, device=rows.device)
+        world = 1 if frame_parallel is None else frame_parallel.world
+        c = max(1, int(chunks)) if world > 1 else 1
+        step = -(-self.n // c)
+        step = -(-step // (world * 64)) * (world * 64)           # chunk boundaries the rs_ag schedule divides, 256-B aligned
+        self.bounds = [(lo, min(lo + step, self.n)) for lo in range(0, self.n, step)]
+        if self.cuda:
+            self.comm = torch.cuda.Stream(rows.device)
+            self._ev = [torch.cuda.Event() for _ in range(self.k)]
+            self._t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        self._next = 0
+        self._works = []
+        self._timed = False
+
+    # -- per step -----------------------------------------------------------------------------------------------------
+    def begin(self):
+        """Call on the stream the step was forked from, before the first view is launched."""
+        self._next = 0
+        if self.cuda:
+            self.comm.wait_stream(torch.cuda.current_stream(self.rows.device))
+
+    def view_done(self, v):
+        """Call on the stream view v ran on, right after its backward was queued; views must be reported in order."""
+        if v != self._next:
+            raise RuntimeError(f"views must be reported in order (expected {self._next}, got {v})")
+        self._next += 1
+        last = v == self.k - 1
+        if not self.cuda:
+            self._fold(v, last)
+            return
+        self._ev[v].record(torch.cuda.current_stream(self.rows.device))
+        with torch.cuda.stream(self.comm):
+            self.comm.wait_event(self._ev[v])
+            if last and self._timed:
+                self._t[0].record(self.comm)                     # = the moment the last view's gradients exist
+            self._fold(v, last)
+
+    def _fold(self, v, last):
+        row = self.rows[v]
+        if not last:
+            if v == 0:
+                self.acc.copy_(row)
+            else:
+                self.acc.add_(row)
+            return
+        for lo, hi in self.bounds:
+            a = self.acc[lo:hi]
+            if v == 0:
+                if self.k > 1:
+                    a.copy_(row[lo:hi])
+            else:
+                a.add_(row[lo:hi])
+            if self.fp is not None:
+                if self.cuda:                                    # queued behind this fold; the next fold does not wait for it
+                    self._works += self.fp.all_reduce_grads(a, async_op=True)
+                else:
+                    self.fp.all_reduce_grads(a)
+
+    def finish(self):
+        """Join: the caller's current stream waits for the reduced sum.  Returns ``acc``."""
+        if self._next != self.k:
+            raise RuntimeError(f"only {self._next} of {self.k} views were reported")
+        if self.cuda:
+            with torch.cuda.stream(self.comm):
+                if self.fp is not None:
+                    self.fp.wait(self._works, None)
+                    if self.fp.average and self.fp.world > 1:
+                        self.acc.div_(self.fp.world)
+                self._works = []
+                if self._timed:
+                    self._t[1].record(self.comm)
+            torch.cuda.current_stream(self.rows.device).wait_stream(self.comm)
+        return self.acc
+
+    def one_shot(self):
+        """Reference schedule: fold all rows in view order, then ONE collective over the whole buffer (what the
+        pipelined schedule must reproduce bit for bit; also the pre-round-2 behaviour of bench.py)."""
+        if self.k > 1:
+            self.acc.copy_(self.rows[0])
+        for v in range(1, self.k):
+            self.acc.add_(self.rows[v])
+        if self.fp is not None:
+            self.fp.all_reduce_grads(self.acc)
+        return self.acc
+
+    # -- measurement --------------------------------------------------------------------------------------------------
+    def enable_timing(self, on=True):
+        self._timed = bool(on) and self.cuda
+
+    def exposed_ms(self):
+        """After a synchronised step run with timing enabled: time from "last view's gradients exist" to "reduced sum
+        ready" on the communication stream = the part of the reduction nothing can hide."""
+        return self._t[0].elapsed_time(self._t[1])

@@ -106,7 +106,7 @@ class SkinnedEngine:
     transforms in, image + flat canonical-Gaussian gradient buffer out.  Flat layout (floats): xyz_canon 3P,
     scales 3P, opacity P, sh 3MP, [rot_canon 9P].  dL/dA [J,16] and dL/dtransl [3] are per-frame (not all-reduced)."""
 
-    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False, grad_flat=None):
+    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9):
         self.lib = _lib.load()
         self.P, self.J, self.W, self.H, self.M = int(P), int(J), int(W), int(H), int(sh_coeffs)
         self.dev = torch.device(device)
@@ -120,7 +120,8 @@ class SkinnedEngine:
         self.skin_ws = torch.empty(int(self.lib.sg_skin_ws_floats(self.P)), **f32)
         self.color = torch.empty((3, self.H, self.W), **f32)
         self.radii = torch.empty((self.P,), dtype=torch.int32, device=self.dev)
-        per = 3 + 3 + 1 + 3 * self.M + (9 if with_rot else 0)
+        rot_width = int(rot_width)                               # 9: rotation matrices, 6: the decoder's 6-D form
+        per = 3 + 3 + 1 + 3 * self.M + (rot_width if with_rot else 0)
         if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
                                       or not grad_flat.is_contiguous() or grad_flat.device != self.dev):
             raise ValueError(f"grad_flat must be a contiguous fp32 tensor of {self.P * per} elements on {self.dev}")
@@ -133,7 +134,7 @@ class SkinnedEngine:
             return v
         self.d_xyz = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
         self.d_opacity = carve(self.P, self.P, 1); self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
-        self.d_rot = carve(self.P * 9, self.P, 9) if with_rot else None
+        self.d_rot = carve(self.P * rot_width, self.P, rot_width) if with_rot else None
         self.d_means2D = torch.empty((self.P, 3), **f32)
         self.d_A = torch.empty((self.J, 16), **f32); self.d_transl = torch.empty(3, **f32)
         self._keep = []; self._s = None; self._k = None
@@ -179,41 +180,53 @@ class ViewBatch:
     library keeps no state between calls, and every engine owns its workspaces -- so the views are dealt round-robin to
     ``streams`` streams and fill each other's holes (one MI355X: +24 % views/s at cfg3, +77 % frames/s for the avatar),
     bit-identical to running them one after the other.  ``run`` forks from the caller's current stream, launches
-    ``fn(v, engine)`` for every view on its stream, joins, and sums the per-view gradient rows into ``acc`` in one pass;
-    nothing synchronises with the host.
+    ``fn(v, engine)`` for every view on its stream and joins; the per-view gradient rows are folded into ``acc`` in view
+    order on a communication stream as the views finish and -- given a ``FrameParallel`` -- all-reduced over the ranks
+    there (sings_amd.dp.GradientPipeline); nothing synchronises with the host.
 
         grads = ViewBatch.gradient_rows(views, per_view_floats, device)
         engines = [RasterEngine(..., grad_flat=grads[v]) for v in range(views)]        # or SkinnedEngine
-        batch = ViewBatch(engines, grads, streams=3)
-        acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))                 # -> all-reduce acc, optimiser step
+        batch = ViewBatch(engines, grads, streams=3, frame_parallel=FrameParallel())    # None on one GPU
+        acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))                 # summed over views and ranks -> optimiser
     """
 
     @staticmethod
     def gradient_rows(views, per_view, device):
         return torch.empty((int(views), int(per_view)), dtype=torch.float32, device=device)
 
-    def __init__(self, engines, grads, streams=3):
+    def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4):
+        from .dp import GradientPipeline
         if len(engines) != grads.shape[0]:
             raise ValueError("one engine per gradient row")
         self.engines, self.grads = list(engines), grads
         self.dev = grads.device
         self.n = max(1, min(int(streams), len(self.engines)))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
-        self.acc = torch.empty(grads.shape[1], dtype=torch.float32, device=self.dev) if len(self.engines) > 1 else grads[0]
+        # the rows are folded into `acc` (and, with several ranks, all-reduced) on a communication stream while later
+        # views still render: sings_amd.dp.GradientPipeline
+        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
+        self.acc = self.pipe.acc
+
+    def run_unreduced(self, fn):
+        """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``."""
+        cur = torch.cuda.current_stream(self.dev)
+        for st in self.streams:
+            st.wait_stream(cur)
+        for v, e in enumerate(self.engines):
+            with torch.cuda.stream(self.streams[v % self.n] if self.streams else cur):
+                fn(v, e)
+        for st in self.streams:
+            cur.wait_stream(st)
 
     def run(self, fn):
-        if self.n == 1:
-            for v, e in enumerate(self.engines):
+        cur = torch.cuda.current_stream(self.dev)
+        self.pipe.begin()
+        for st in self.streams:
+            st.wait_stream(cur)
+        for v, e in enumerate(self.engines):
+            with torch.cuda.stream(self.streams[v % self.n] if self.streams else cur):
                 fn(v, e)
-        else:
-            cur = torch.cuda.current_stream(self.dev)
-            for st in self.streams:
-                st.wait_stream(cur)
-            for v, e in enumerate(self.engines):
-                with torch.cuda.stream(self.streams[v % self.n]):
-                    fn(v, e)
-            for st in self.streams:
-                cur.wait_stream(st)
-        if len(self.engines) > 1:
-            torch.sum(self.grads, dim=0, out=self.acc)
-        return self.acc
+                self.pipe.view_done(v)
+        for st in self.streams:
+            cur.wait_stream(st)
+        return self.pipe.finish()

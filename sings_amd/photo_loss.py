@@ -8,8 +8,9 @@ renderer's final clamp (gs_renderer_single.py:96):
     loss_dict['ssim'] = ssim_w * (1 - ssim(pred, gt)) * mask.sum() / (H * W)
 
 ``photometric_loss`` takes the UNCLAMPED rasterizer output (the clamp is fused) and returns the reference's
-``loss_dict`` / ``extras_dict`` entries; both loss tensors carry autograd back to ``raw``.  The forward call computes
-the gradient in the same pass over the image, so backward only scales it.  LPIPS (a VGG network) is not provided.
+``loss_dict`` / ``extras_dict`` entries; both loss tensors carry autograd back to ``raw``.  The forward leaves its
+window statistics in a workspace and backward runs the gradient pass over them (sg_photo_loss_backward), with the
+upstream weights as device scalars: no host synchronisation anywhere.  LPIPS (a VGG network) is not provided.
 No CPU fallback: the HIP library must be present.
 """
 import ctypes as C
@@ -34,18 +35,17 @@ class _PhotoLoss(torch.autograd.Function):
         dev = raw.device
         ws = torch.empty(int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
         losses = torch.empty(4, dtype=torch.float32, device=dev)
-        grad = torch.empty_like(raw)
         pred = torch.empty_like(raw) if want_images else None
         gt = torch.empty_like(raw) if want_images else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.sg_photo_loss(W, H, float(l1_w), float(ssim_w), _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg),
-                                         _ptr(ws), _ptr(pred), _ptr(gt), _ptr(losses), None, _ptr(grad), stream),
+                                         _ptr(ws), _ptr(pred), _ptr(gt), _ptr(losses), None, None, stream),
                        "photo loss")
-        # grad = d(l1 term + ssim term)/d raw; the two terms are separated again in backward only if their upstream
-        # gradients differ (they never do in the reference: loss = sum(loss_dict.values()))
-        ctx.save_for_backward(grad)
-        ctx.args = (raw, gt_rgb, mask, bg, float(l1_w), float(ssim_w), W, H)
+        # the window statistics stay in `ws`; backward runs the gradient pass over them with the two upstream weights as
+        # DEVICE scalars -- nothing is read back to find out whether they are equal (a host synchronisation per step)
+        ctx.save_for_backward(raw, gt_rgb, mask, bg, ws)
+        ctx.args = (float(l1_w), float(ssim_w), W, H)
         outs = (losses[0], losses[1], losses[2], losses[3])
         if want_images:
             ctx.mark_non_differentiable(pred, gt)
@@ -54,22 +54,18 @@ class _PhotoLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_l1, g_ssim, g_raw_l1=None, g_ssim_mean=None, *unused):
-        (grad,) = ctx.saved_tensors
-        same = bool(torch.equal(g_l1, g_ssim)) if (g_l1 is not None and g_ssim is not None) else False
-        if same:
-            return grad * g_l1, None, None, None, None, None, None
-        # general case: one more call with explicit upstream weights
-        raw, gt_rgb, mask, bg, l1_w, ssim_w, W, H = ctx.args
+        raw, gt_rgb, mask, bg, ws = ctx.saved_tensors
+        l1_w, ssim_w, W, H = ctx.args
         lib = _lib.load()
         dev = raw.device
-        up = torch.stack([g_l1 if g_l1 is not None else torch.zeros((), device=dev),
-                          g_ssim if g_ssim is not None else torch.zeros((), device=dev)]).float().contiguous()
-        ws = torch.empty(int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
+        zero = torch.zeros((), dtype=torch.float32, device=dev)
+        up = torch.stack([zero if g_l1 is None else g_l1.reshape(()).float(),
+                          zero if g_ssim is None else g_ssim.reshape(()).float()]).contiguous()
         out = torch.empty_like(raw)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(lib.sg_photo_loss(W, H, l1_w, ssim_w, _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg), _ptr(ws),
-                                         None, None, None, _ptr(up), _ptr(out), stream), "photo loss backward")
+            _lib.check(lib.sg_photo_loss_backward(W, H, l1_w, ssim_w, _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg), _ptr(ws),
+                                                  _ptr(up), _ptr(out), stream), "photo loss backward")
         return out, None, None, None, None, None, None
 
 

@@ -140,12 +140,14 @@ class FrameAnimator:
                 ev = torch.cuda.Event()
                 ev.record(st)
             img.record_stream(cur)
-            q.append((i, job, img, ev, slot))
+            q.append((i, job, img, ev, slot, e.cap))          # (the capacity THIS frame was rendered with)
 
         def pop():
-            i, job, img, ev, slot = q.popleft()
+            i, job, img, ev, slot, cap_used = q.popleft()
             ev.synchronize()
-            if int(slot[0]) > self.cap:                          # rare: grow the workspaces, render this frame again
+            # compared with the capacity of the engine that rendered it: an earlier pop may have grown self.cap while this
+            # frame was still queued, and a count between the two capacities means a background-only image
+            if int(slot[0]) > cap_used:                          # rare: grow the workspaces, render this frame again
                 torch.cuda.synchronize(self.dev)
                 need = int(slot[0])
                 self._engines(self.shape[1], self.shape[2], self.shape[3], need + need // 4 + 1024)

@@ -208,10 +208,15 @@ class RegionLaplacianLoss_v2(torch.nn.Module):
 
 
 class _MeshEdges:
+    """CSR of a mesh's unique edges on the device (``MeshEdges`` for callers that build it once per topology)."""
+
     def __init__(self, num_verts, edges, dev):
         row_ptr, col = _csr(num_verts, edges)
         self.V, self.E = int(num_verts), int(np.asarray(edges).reshape(-1, 2).shape[0])
         self.row_ptr = torch.from_numpy(row_ptr).to(dev); self.col = torch.from_numpy(col).to(dev)
+
+
+MeshEdges = _MeshEdges
 
 
 def mesh_edge_loss(verts, edges, _cache={}):
@@ -221,12 +226,23 @@ def mesh_edge_loss(verts, edges, _cache={}):
     x = verts.contiguous().float()
     _need_gpu(x, "mesh_edge_loss")
     dev = x.device
-    e = edges.detach().cpu().numpy() if torch.is_tensor(edges) else np.asarray(edges)
-    key = (id(edges), int(x.shape[0]), str(dev))
-    if key not in _cache:
-        _cache.clear()
-        _cache[key] = _MeshEdges(int(x.shape[0]), e, dev)
-    m = _cache[key]
+    if isinstance(edges, _MeshEdges):                   # built once by the caller: MeshEdges(num_verts, edges, device)
+        m = edges
+    else:
+        # look the CSR up FIRST; the edge list is converted (a D2H copy + host synchronisation for a device tensor) only on a
+        # miss.  Key: storage address + version counter + shape of a tensor, so that a recycled Python id or an in-place
+        # edit cannot hit a stale entry; the cached entry keeps the tensor alive, so its address cannot be reused meanwhile.
+        if torch.is_tensor(edges):
+            key = ("t", edges.data_ptr(), edges._version, tuple(edges.shape), str(edges.device), int(x.shape[0]), str(dev))
+        else:
+            e_np = np.ascontiguousarray(np.asarray(edges))
+            key = ("n", e_np.shape, hash(e_np.tobytes()), int(x.shape[0]), str(dev))
+        hit = _cache.get(key)
+        if hit is None:
+            e_np = edges.detach().cpu().numpy() if torch.is_tensor(edges) else e_np
+            _cache.clear()
+            hit = _cache[key] = (_MeshEdges(int(x.shape[0]), e_np, dev), edges)
+        m = hit[0]
     ws = torch.empty(int(lib.sg_reg_ws_bytes(m.V)), dtype=torch.uint8, device=dev)
     loss = torch.empty(1, dtype=torch.float32, device=dev); dx = torch.empty_like(x)
     with torch.cuda.device(dev):

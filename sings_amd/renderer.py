@@ -11,7 +11,7 @@ import math
 import torch
 
 from .rasterizer import GaussianRasterizationSettings, GaussianRasterizer
-from .skinned import rasterize_skinned_gaussians, _RasterizeSkinnedGaussians
+from .skinned import rasterize_skinned_gaussians
 
 
 def get_render_pkg(data, human_gs_out, bg_color, scaling_modifier=1.0):
@@ -70,24 +70,22 @@ def render(means3D, feats, opacity, scales, rotations, data, scaling_modifier=1.
             "visibility_filter": radii > 0, "radii": radii}
 
 
-class _ViewspaceGrad:
-    """Stand-in for ``viewspace_points`` of the fused path: ``.grad`` is filled by backward
-    (consumer: SinGS.add_densification_stats, sings_hybrid.py:1013-1015)."""
-
-    @property
-    def grad(self):
-        return _RasterizeSkinnedGaussians.last_viewspace_grad
-
-
 def get_render_pkg_fused(data, canon, A_cano2pose, bg_color, smpl_scale=None, transl=None, ext_tfs=None,
                          scaling_modifier=1.0, return_posed=False):
     """canon: dict(xyz_canon, rotmat_canon|None, scales, opacity, shs, lbs_weights, active_sh_degree)."""
     rs = _settings(data, bg_color, scaling_modifier, canon['active_sh_degree'])
-    out = rasterize_skinned_gaussians(canon['xyz_canon'], canon.get('rotmat_canon'), canon['scales'], canon['opacity'],
+    # per-call holder of the screen-space gradient, exactly the reference's idiom (gs_renderer_single.py:50-56)
+    xyz = canon['xyz_canon']
+    screenspace_points = None
+    if torch.is_grad_enabled() and ext_tfs is None:
+        screenspace_points = torch.zeros_like(xyz, requires_grad=True) + 0
+        screenspace_points.retain_grad()
+    out = rasterize_skinned_gaussians(xyz, canon.get('rotmat_canon'), canon['scales'], canon['opacity'],
                                       canon['shs'], canon['lbs_weights'], A_cano2pose, rs, smpl_scale=smpl_scale,
-                                      transl=transl, ext_tfs=ext_tfs, return_posed=return_posed)
+                                      transl=transl, ext_tfs=ext_tfs, return_posed=return_posed,
+                                      means2D=screenspace_points)
     radii = out[1]
-    pkg = {"render": torch.clamp(out[0], 0.0, 1.0), "render_raw": out[0], "viewspace_points": _ViewspaceGrad(),
+    pkg = {"render": torch.clamp(out[0], 0.0, 1.0), "render_raw": out[0], "viewspace_points": screenspace_points,
            "visibility_filter": radii > 0,
            "radii": radii, "human_visibility_filter": radii > 0, "human_radii": radii}
     if return_posed:

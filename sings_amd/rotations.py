@@ -1,126 +1,169 @@
-"""Rotation conversions the callers of the render path use: host-side torch, differentiable.
+"""Rotation conversions on the MI355X: the functions of
+``sings/rec/utils/geometry/rotations.py`` the render path and the pose optimisation call, same names and conventions
+(quaternions real part first), each ONE kernel launch forward and one backward (csrc/sg_rot.h / sg_rot.hip,
+``sg_rotation_convert[_backward]``, ``sg_quaternion_multiply[_backward]``, ``sg_matrix_to_quaternion[_backward]``):
 
-Same names, conventions (quaternions real part first) and branch behaviour as
-``sings/rec/utils/geometry/rotations.py`` (pytorch3d-derived): ``quaternion_to_matrix`` :38-66,
-``matrix_to_quaternion`` :98-149, ``standardize_quaternion`` :357, ``quaternion_multiply`` :393-407,
-``axis_angle_to_quaternion`` :482-511, ``quaternion_to_axis_angle`` :514-545, ``axis_angle_to_matrix`` :450,
-``matrix_to_axis_angle`` :466, ``rotation_6d_to_matrix`` :545-566, ``matrix_to_rotation_6d`` :569-585, and the 6-D <->
-axis-angle pair the pose optimisation uses (:596-603).  Pinned by tests/golden/rot_cam_golden.npz.
-(The device kernels carry their own copies of matrix_to_quaternion / quaternion_multiply, csrc/sg_skin.hip.)
+    quaternion_to_matrix :38-66        matrix_to_quaternion :98-149       standardize_quaternion :357
+    quaternion_multiply :393-407       axis_angle_to_quaternion :482-511  quaternion_to_axis_angle :514-545
+    axis_angle_to_matrix :450          matrix_to_axis_angle :466          rotation_6d_to_matrix :545-566
+    matrix_to_rotation_6d :569-585     axis_angle_to_rotation_6d / rotation_6d_to_axis_angle :596-603
+
+Inputs are fp32 tensors on the GPU with any leading batch shape; gradients are what torch.autograd gives for the
+reference expressions.  There is NO CPU / eager path: host tensors raise (the torch restatement used to check these
+kernels lives in oracle/rotations_oracle.py and is test infrastructure).
 """
+import ctypes as C
+
 import torch
-import torch.nn.functional as F
+
+from . import _lib
+
+_Q2M, _R6D2M, _AA2Q, _Q2AA = 0, 1, 2, 3           # SG_ROT_* of include/sings_hip.h
+_WIDTH = {_Q2M: (4, 9), _R6D2M: (6, 9), _AA2Q: (3, 4), _Q2AA: (4, 3)}
 
 
-def quaternion_to_matrix(quaternions):
-    q = quaternions
-    r, i, j, k = torch.unbind(q, -1)
-    two_s = 2.0 / (q * q).sum(-1)
-    o = torch.stack((1 - two_s * (j * j + k * k), two_s * (i * j - k * r), two_s * (i * k + j * r),
-                     two_s * (i * j + k * r), 1 - two_s * (i * i + k * k), two_s * (j * k - i * r),
-                     two_s * (i * k - j * r), two_s * (j * k + i * r), 1 - two_s * (i * i + j * j)), -1)
-    return o.reshape(q.shape[:-1] + (3, 3))
+def _check(t, width, name):
+    if not torch.is_tensor(t):
+        raise TypeError(f"{name} must be a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"sings_amd.rotations.{name}: tensors must live on the MI355X (no CPU fallback; got {t.device})")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"sings_amd.rotations.{name}: float32 only (got {t.dtype})")
+    if t.shape[-1] != width:
+        raise ValueError(f"sings_amd.rotations.{name}: last dimension must be {width}, got {tuple(t.shape)}")
+    return t.contiguous()
 
 
-def _sqrt_positive_part(x):
-    ret = torch.zeros_like(x)
-    pos = x > 0
-    ret[pos] = torch.sqrt(x[pos])
-    return ret
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+class _Convert(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op):
+        lib = _lib.load()
+        ni, no = _WIDTH[op]
+        n = x.numel() // ni
+        out = torch.empty(x.shape[:-1] + (no,), dtype=torch.float32, device=x.device)
+        if n:
+            with torch.cuda.device(x.device):
+                _lib.check(lib.sg_rotation_convert(op, n, _p(x), _p(out), _stream(x.device)), "rotation convert")
+        ctx.op = op
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        (x,) = ctx.saved_tensors
+        ni, _ = _WIDTH[ctx.op]
+        n = x.numel() // ni
+        g = g.contiguous().float()
+        dx = torch.empty_like(x)
+        if n:
+            with torch.cuda.device(x.device):
+                _lib.check(lib.sg_rotation_convert_backward(ctx.op, n, _p(x), _p(g), _p(dx), _stream(x.device)),
+                           "rotation convert backward")
+        return dx, None
 
 
 class _M2Q(torch.autograd.Function):
-    """matrix_to_quaternion on the MI355X: one kernel each way instead of ~25 (sg_matrix_to_quaternion[_backward])."""
-
     @staticmethod
-    def forward(ctx, matrix):
-        import ctypes as C
-        from . import _lib
+    def forward(ctx, m):
         lib = _lib.load()
-        m = matrix.contiguous()
-        N = m.numel() // 9
+        n = m.numel() // 9
         q = torch.empty(m.shape[:-2] + (4,), dtype=torch.float32, device=m.device)
-        with torch.cuda.device(m.device):
-            _lib.check(lib.sg_matrix_to_quaternion(N, C.c_void_p(m.data_ptr()), C.c_void_p(q.data_ptr()),
-                                                   C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream)), "matrix_to_quaternion")
+        if n:
+            with torch.cuda.device(m.device):
+                _lib.check(lib.sg_matrix_to_quaternion(n, _p(m), _p(q), _stream(m.device)), "matrix_to_quaternion")
         ctx.save_for_backward(m)
         return q
 
     @staticmethod
     def backward(ctx, dq):
-        import ctypes as C
-        from . import _lib
         lib = _lib.load()
         (m,) = ctx.saved_tensors
         dq = dq.contiguous().float()
         dm = torch.empty_like(m)
-        with torch.cuda.device(m.device):
-            _lib.check(lib.sg_matrix_to_quaternion_backward(m.numel() // 9, C.c_void_p(m.data_ptr()), C.c_void_p(dq.data_ptr()),
-                                                            C.c_void_p(dm.data_ptr()),
-                                                            C.c_void_p(torch.cuda.current_stream(m.device).cuda_stream)),
-                       "matrix_to_quaternion backward")
+        if m.numel():
+            with torch.cuda.device(m.device):
+                _lib.check(lib.sg_matrix_to_quaternion_backward(m.numel() // 9, _p(m), _p(dq), _p(dm), _stream(m.device)),
+                           "matrix_to_quaternion backward")
         return dm
 
 
+class _QMul(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        lib = _lib.load()
+        out = torch.empty_like(a)
+        if a.numel():
+            with torch.cuda.device(a.device):
+                _lib.check(lib.sg_quaternion_multiply(a.numel() // 4, _p(a), _p(b), _p(out), _stream(a.device)),
+                           "quaternion_multiply")
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        a, b = ctx.saved_tensors
+        g = g.contiguous().float()
+        da, db = torch.empty_like(a), torch.empty_like(b)
+        if a.numel():
+            with torch.cuda.device(a.device):
+                _lib.check(lib.sg_quaternion_multiply_backward(a.numel() // 4, _p(a), _p(b), _p(g), _p(da), _p(db),
+                                                               _stream(a.device)), "quaternion_multiply backward")
+        return da, db
+
+
+def quaternion_to_matrix(quaternions):
+    q = _check(quaternions, 4, "quaternion_to_matrix")
+    return _Convert.apply(q, _Q2M).reshape(q.shape[:-1] + (3, 3))
+
+
 def matrix_to_quaternion(matrix):
-    """rotations.py:98-149.  fp32 matrices on the GPU go through the HIP kernel (per-Gaussian rotations: [N,3,3] with
-    N ~ 1e5, sings_hybrid.py:419); anything else (fp64, CPU-side pose bookkeeping of a few joints) through the same
-    expression in torch.  On the GPU both give bit-identical fp32 quaternions (within one ulp of the CPU golden G1)."""
-    if matrix.is_cuda and matrix.dtype == torch.float32 and matrix.numel() >= 9:
-        return _M2Q.apply(matrix)
-    return _matrix_to_quaternion_torch(matrix)
-
-
-def _matrix_to_quaternion_torch(matrix):
-    batch_dim = matrix.shape[:-2]
-    m00, m01, m02, m10, m11, m12, m20, m21, m22 = torch.unbind(matrix.reshape(batch_dim + (9,)), dim=-1)
-    q_abs = _sqrt_positive_part(torch.stack([1.0 + m00 + m11 + m22, 1.0 + m00 - m11 - m22, 1.0 - m00 + m11 - m22,
-                                             1.0 - m00 - m11 + m22], dim=-1))
-    quat_by_rijk = torch.stack([
-        torch.stack([q_abs[..., 0] ** 2, m21 - m12, m02 - m20, m10 - m01], dim=-1),
-        torch.stack([m21 - m12, q_abs[..., 1] ** 2, m10 + m01, m02 + m20], dim=-1),
-        torch.stack([m02 - m20, m10 + m01, q_abs[..., 2] ** 2, m12 + m21], dim=-1),
-        torch.stack([m10 - m01, m20 + m02, m21 + m12, q_abs[..., 3] ** 2], dim=-1)], dim=-2)
-    flr = torch.tensor(0.1).to(dtype=q_abs.dtype, device=q_abs.device)
-    quat_candidates = quat_by_rijk / (2.0 * q_abs[..., None].max(flr))
-    return quat_candidates[F.one_hot(q_abs.argmax(dim=-1), num_classes=4) > 0.5, :].reshape(batch_dim + (4,))
-
-
-def standardize_quaternion(quaternions):
-    return torch.where(quaternions[..., 0:1] < 0, -quaternions, quaternions)
-
-
-def quaternion_raw_multiply(a, b):
-    aw, ax, ay, az = torch.unbind(a, -1)
-    bw, bx, by, bz = torch.unbind(b, -1)
-    return torch.stack((aw * bw - ax * bx - ay * by - az * bz, aw * bx + ax * bw + ay * bz - az * by,
-                        aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw), -1)
+    if matrix.shape[-2:] != (3, 3):
+        raise ValueError(f"Invalid rotation matrix shape {tuple(matrix.shape)}.")
+    m = _check(matrix.reshape(matrix.shape[:-2] + (9,)), 9, "matrix_to_quaternion")
+    return _M2Q.apply(m.reshape(matrix.shape))
 
 
 def quaternion_multiply(a, b):
-    return standardize_quaternion(quaternion_raw_multiply(a, b))
+    """standardize(a * b), broadcasting the leading dimensions like the reference's torch expression."""
+    a = _check(a, 4, "quaternion_multiply"); b = _check(b, 4, "quaternion_multiply")
+    if a.shape != b.shape:
+        a, b = torch.broadcast_tensors(a, b)
+        a, b = a.contiguous(), b.contiguous()
+    return _QMul.apply(a, b)
 
 
-def _sin_half_over_angle(angles, half_angles):
-    small = angles.abs() < 1e-6
-    out = torch.empty_like(angles)
-    out[~small] = torch.sin(half_angles[~small]) / angles[~small]
-    out[small] = 0.5 - (angles[small] * angles[small]) / 48          # sin(x/2)/x ~ 1/2 - x^2/48
-    return out
+def standardize_quaternion(quaternions):
+    q = _check(quaternions, 4, "standardize_quaternion")
+    return torch.where(q[..., 0:1] < 0, -q, q)
+
+
+def rotation_6d_to_matrix(d6):
+    d = _check(d6, 6, "rotation_6d_to_matrix")
+    return _Convert.apply(d, _R6D2M).reshape(d.shape[:-1] + (3, 3))
+
+
+def matrix_to_rotation_6d(matrix):
+    if not matrix.is_cuda:
+        raise RuntimeError("sings_amd.rotations.matrix_to_rotation_6d: tensors must live on the MI355X (no CPU fallback)")
+    return matrix[..., :2, :].clone().reshape(matrix.size()[:-2] + (6,))      # a copy of the first two rows: no arithmetic
 
 
 def axis_angle_to_quaternion(axis_angle):
-    angles = torch.norm(axis_angle, p=2, dim=-1, keepdim=True)
-    half = angles * 0.5
-    return torch.cat([torch.cos(half), axis_angle * _sin_half_over_angle(angles, half)], dim=-1)
+    return _Convert.apply(_check(axis_angle, 3, "axis_angle_to_quaternion"), _AA2Q)
 
 
 def quaternion_to_axis_angle(quaternions):
-    q = quaternions
-    norms = torch.norm(q[..., 1:], p=2, dim=-1, keepdim=True)
-    half = torch.atan2(norms, q[..., :1])
-    angles = 2 * half
-    return q[..., 1:] / _sin_half_over_angle(angles, half)
+    return _Convert.apply(_check(quaternions, 4, "quaternion_to_axis_angle"), _Q2AA)
 
 
 def axis_angle_to_matrix(axis_angle):
@@ -129,17 +172,6 @@ def axis_angle_to_matrix(axis_angle):
 
 def matrix_to_axis_angle(matrix):
     return quaternion_to_axis_angle(matrix_to_quaternion(matrix))
-
-
-def rotation_6d_to_matrix(d6):
-    a1, a2 = d6[..., :3], d6[..., 3:]
-    b1 = F.normalize(a1, dim=-1)
-    b2 = F.normalize(a2 - (b1 * a2).sum(-1, keepdim=True) * b1, dim=-1)
-    return torch.stack((b1, b2, torch.cross(b1, b2, dim=-1)), dim=-2)
-
-
-def matrix_to_rotation_6d(matrix):
-    return matrix[..., :2, :].clone().reshape(matrix.size()[:-2] + (6,))
 
 
 def axis_angle_to_rotation_6d(aa):

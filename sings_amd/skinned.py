@@ -12,13 +12,17 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .rasterizer import _capacity_hint, _deferred, _f32, _pending, _ptr, _settings_struct
+from . import rasterizer as _rz
+from .rasterizer import _f32, _ptr, _settings_struct
 
 
 def _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs, keep):
+    """rotmat_canon: None (isotropic), [N,9] / [N,3,3] rotation matrices, or [N,6] in the decoder's 6-D form
+    (rotation_6d_to_matrix then runs inside the kernels)."""
     k = _lib.SgSkinInputs()
     A = _f32(A, "A", dev).reshape(-1, 16)
-    k.J = int(A.shape[0]); k.reserved = 0
+    k.J = int(A.shape[0])
+    k.rot_format = 1 if (rotmat_canon is not None and rotmat_canon.shape[-1] == 6 and rotmat_canon.dim() == 2) else 0
     lbs_weights = _f32(lbs_weights, "lbs_weights", dev)
     if lbs_weights.shape != (xyz_canon.shape[0], k.J):
         raise RuntimeError(f"lbs_weights must be [N,{k.J}], got {tuple(lbs_weights.shape)}")
@@ -41,14 +45,20 @@ def _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, trans
 class _RasterizeSkinnedGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, xyz_canon, rotmat_canon, scales, opacities, shs, A, transl, lbs_weights, smpl_scale, ext_tfs,
-                raster_settings, return_posed):
+                raster_settings, return_posed, means2D=None):
         lib = _lib.load()
         dev = xyz_canon.device
         if dev.type != "cuda":
             raise RuntimeError("sings_amd fused LBS+raster runs on the MI355X only; there is no CPU fallback")
         rs = raster_settings
         xyz_canon = _f32(xyz_canon, "xyz_canon", dev)
-        rotmat_canon = None if rotmat_canon is None else _f32(rotmat_canon, "rotmat_canon", dev).reshape(-1, 9)
+        rot_shape = None if rotmat_canon is None else tuple(rotmat_canon.shape)
+        if rotmat_canon is not None:
+            rotmat_canon = _f32(rotmat_canon, "rotmat_canon", dev)
+            if rotmat_canon.shape[-2:] == (3, 3):
+                rotmat_canon = rotmat_canon.reshape(-1, 9)
+            elif rotmat_canon.dim() != 2 or rotmat_canon.shape[1] not in (6, 9):
+                raise RuntimeError(f"rotmat_canon must be [N,3,3], [N,9] or [N,6] (6-D form), got {tuple(rotmat_canon.shape)}")
         scales = _f32(scales, "scales", dev); opacities = _f32(opacities, "opacities", dev); shs = _f32(shs, "shs", dev)
         P = int(xyz_canon.shape[0]); H, W = int(rs.image_height), int(rs.image_width); M = int(shs.shape[1])
         keep = []
@@ -58,9 +68,7 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         pxyz, pq, psc = (e(P, 3), e(P, 4), e(P, 3)) if return_posed else (None, None, None)
-        T = ((W + 15) // 16) * ((H + 15) // 16)
-        cap = max(_capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
-        deferred = _deferred["on"]                              # see rasterizer.set_deferred_overflow_check
+        cap, sync, sig = _rz._forward_plan(dev, P, W, H)     # see rasterizer.set_overflow_check
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             while True:
@@ -71,19 +79,21 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                 nr = C.c_int64(0)
                 _lib.check(lib.sg_skinned_forward(C.byref(s), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales),
                                                   _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii),
-                                                  _ptr(pxyz), _ptr(pq), _ptr(psc), None if deferred else C.byref(nr), stream),
+                                                  _ptr(pxyz), _ptr(pq), _ptr(psc), C.byref(nr) if sync else None, stream),
                            "skinned forward")
-                R = None if deferred else int(nr.value)
-                if deferred or R <= cap:
+                R = int(nr.value) if sync else None
+                if not sync or R <= cap:
                     break
-                cap = int(R * 1.25) + 1024
-        if deferred:
-            _pending[dev.index] = (binning, cap)
-        else:
-            _capacity_hint[dev.index] = max(int(R * 1.25) + 1024, _capacity_hint.get(dev.index, 0) * 3 // 4)
+                cap = int(R * _rz._HEADROOM) + 1024
+            if sync:
+                _rz._forward_done_sync(dev, R, sig)
+            else:
+                _rz._after_forward(dev, binning, cap)
         ctx.rs, ctx.cap, ctx.M, ctx.num_rendered = rs, cap, M, R
         ctx.has_rot = rotmat_canon is not None
         ctx.has_ext = ext_tfs is not None
+        ctx.rot_shape = rot_shape
+        ctx.has_m2d = means2D is not None
         ctx.return_posed = return_posed
         ctx.aux = (lbs_weights, smpl_scale, A.shape, None if transl is None else transl.shape)
         z = torch.empty(0, device=dev)
@@ -111,7 +121,7 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                          transl if transl_shape is not None else None, None, keep)
         e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         d_xyz, d_scales, d_op, d_sh, d_m2d = e(P, 3), e(P, 3), e(P, 1), e(P, ctx.M, 3), e(P, 3)
-        d_rot = e(P, 9) if ctx.has_rot else None
+        d_rot = e(P, int(rotmat_canon.shape[1])) if ctx.has_rot else None
         d_A = e(k.J, 16); d_tr = e(3)
         g_color = _f32(g_color, "grad_out_color", dev)
         g_pxyz = None if g_pxyz is None else _f32(g_pxyz, "grad posed xyz", dev)
@@ -126,22 +136,27 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                 _ptr(binning), ctx.cap, _ptr(img), _ptr(bwd_ws), _ptr(skin_ws), _ptr(g_color), _ptr(g_pxyz), _ptr(g_pq),
                 _ptr(d_xyz), _ptr(d_rot), _ptr(d_scales), _ptr(d_op), _ptr(d_sh), _ptr(d_m2d), _ptr(d_A), _ptr(d_tr),
                 stream), "skinned backward")
-        ctx.viewspace_grad = d_m2d
-        _RasterizeSkinnedGaussians.last_viewspace_grad = d_m2d
-        return (d_xyz, None if d_rot is None else d_rot.view(P, 3, 3), d_scales, d_op.view_as(opacities), d_sh,
-                d_A.view(A_shape), None if transl_shape is None else d_tr.view(transl_shape), None, None, None, None, None)
+        _RasterizeSkinnedGaussians.last_viewspace_grad = d_m2d      # (kept for round-1 callers: last call wins)
+        return (d_xyz, None if d_rot is None else d_rot.view(ctx.rot_shape), d_scales, d_op.view_as(opacities), d_sh,
+                d_A.view(A_shape), None if transl_shape is None else d_tr.view(transl_shape), None, None, None, None, None,
+                d_m2d if ctx.has_m2d else None)
 
 
 _RasterizeSkinnedGaussians.last_viewspace_grad = None
 
 
 def rasterize_skinned_gaussians(xyz_canon, rotmat_canon, scales, opacities, shs, lbs_weights, A_cano2pose,
-                                raster_settings, smpl_scale=None, transl=None, ext_tfs=None, return_posed=False):
+                                raster_settings, smpl_scale=None, transl=None, ext_tfs=None, return_posed=False,
+                                means2D=None):
     """color, radii[, posed_xyz, posed_rotq, posed_scales] = fused LBS + rasterization of one posed frame.
 
-    ``rotmat_canon=None`` means isotropic Gaussians (identity canonical rotation, sings_hybrid.py:358-361).
-    After ``backward`` the screen-space gradient the densifier reads (``viewspace_points.grad`` in the
-    reference, sings_hybrid.py:1013-1015) is at ``_RasterizeSkinnedGaussians.last_viewspace_grad``.
+    ``rotmat_canon=None`` means isotropic Gaussians (identity canonical rotation, sings_hybrid.py:358-361); a ``[N,6]``
+    tensor is the geometry decoder's 6-D output: ``rotation_6d_to_matrix`` (sings_hybrid.py:356-357) is then evaluated
+    inside the kernels, forward and backward, and the gradient comes back in 6-D form.
+    ``means2D``: optional ``[N,3]`` tensor with ``requires_grad`` (values unused) that receives the screen-space
+    gradient the densifier reads as ITS gradient -- the reference's ``viewspace_points`` idiom
+    (gs_renderer_single.py:50-56, consumer sings_hybrid.py:1013-1015), one holder per call, so several views of a
+    step keep their own statistics.
     """
     return _RasterizeSkinnedGaussians.apply(xyz_canon, rotmat_canon, scales, opacities, shs, A_cano2pose, transl,
-                                            lbs_weights, smpl_scale, ext_tfs, raster_settings, return_posed)
+                                            lbs_weights, smpl_scale, ext_tfs, raster_settings, return_posed, means2D)

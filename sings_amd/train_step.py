@@ -37,12 +37,9 @@ class AvatarStep(torch.nn.Module):
     def forward(self, A_cano2pose, raster_settings, gt_rgb, mask, bg_color, smpl_scale=None, transl=None):
         attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
                                   self.scaling_multiplier)
-        iso = attrs["rot6d_canon"] is None
-        if not iso:
-            from .body import rotation_6d_to_matrix
-            rot = rotation_6d_to_matrix(attrs["rot6d_canon"])
-        else:
-            rot = None
+        # anisotropic: the decoder's 6-D rotations go to the fused kernels as they are (rotation_6d_to_matrix of
+        # sings_hybrid.py:356-357 runs inside them); isotropic: None
+        rot = attrs["rot6d_canon"]
         reg = {}
 
         def regularisers():

@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sings_amd.dp import FrameParallel, FrameSharder
+from sings_amd.dp import FrameParallel, FrameSharder, GradientPipeline
 
 
 def _free_port():
@@ -93,3 +93,72 @@ def test_batched_steps_cover_every_frame_once():
         assert len(set(step)) == W * K
         seen += step
     assert sorted(seen) == list(range(F))
+
+
+def _pipeline_worker(rank, world, port, algorithm, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        res = []
+        for k, n, chunks in ((1, 1003, 4), (5, 1003, 4), (8, 4099, 3), (3, 130, 7)):
+            g = torch.Generator().manual_seed(100 * rank + k)
+            rows = torch.randn((k, n), generator=g) * torch.logspace(-3, 3, n)        # fp32 sums that depend on the order
+            fp = FrameParallel(algorithm=algorithm)
+            ref = GradientPipeline(rows.clone(), fp, chunks=chunks).one_shot().clone()
+            live = rows.clone()
+            pipe = GradientPipeline(live, fp, chunks=chunks)
+            for _ in range(2):                                                        # two steps through the same object
+                live.copy_(rows)                                                      # (every backward rewrites its row)
+                pipe.begin()
+                for v in range(k):
+                    pipe.view_done(v)
+                got = pipe.finish().clone()
+            res.append((k, n, ref.numpy(), got.numpy(), rows.numpy()))
+        out.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_pipeline(algorithm):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, algorithm, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for case in range(len(res[0])):
+        k, n, ref0, got0, rows0 = res[0][case]
+        _, _, ref1, got1, rows1 = res[1][case]
+        # the pipelined schedule (fold per view, chunked collectives) == fold everything, then one collective: bit for bit
+        assert np.array_equal(ref0, got0) and np.array_equal(ref1, got1)
+        assert np.array_equal(got0, got1)                                            # both ranks hold the same sum
+        def fold(rows):
+            a = rows[0].copy()
+            for v in range(1, k):
+                a = a + rows[v]
+            return a
+        assert np.array_equal(got0, fold(rows0) + fold(rows1))                       # view order inside a rank, then ranks
+
+
+def test_pipelined_reduction_matches_one_shot_all_reduce():
+    _run_pipeline("all_reduce")
+
+
+def test_pipelined_reduction_matches_one_shot_rs_ag():
+    _run_pipeline("rs_ag")
+
+
+def test_pipeline_rejects_out_of_order_and_missing_views():
+    import pytest
+    pipe = GradientPipeline(torch.zeros((3, 10)))
+    pipe.begin()
+    pipe.view_done(0)
+    with pytest.raises(RuntimeError):
+        pipe.view_done(2)
+    with pytest.raises(RuntimeError):
+        pipe.finish()

@@ -94,26 +94,28 @@ def test_matrix_to_quaternion_golden_and_gradient():
     function, run on the CPU, on 256 seeded matrices incl. non-orthonormal ones: within one ulp (7 of 1024 words differ by the
     last bit, exactly where torch's own GPU kernels differ from its CPU kernels), BIT-identical to the reference expression
     evaluated by torch on the same GPU -- and its backward against torch autograd (all four candidate branches, the floor)."""
+    from oracle import rotations_oracle as RO
     from sings_amd import rotations as R
     dev = _dev()
     m = torch.from_numpy(G["g1_mats"]).to(dev)
     q = R.matrix_to_quaternion(m)
     np.testing.assert_allclose(q.cpu().numpy(), G["g1_m2q"], rtol=1.3e-7, atol=0)
-    assert torch.equal(q, R._matrix_to_quaternion_torch(m))
+    assert torch.equal(q, RO.matrix_to_quaternion(m))
     rs = np.random.RandomState(4)
     big = torch.from_numpy(np.concatenate([G["g1_mats"], 0.05 * rs.randn(64, 3, 3).astype(np.float32),        # floor branch
-                                           R.axis_angle_to_matrix(torch.from_numpy(3.1 * rs.randn(2000, 3).astype(np.float32))).numpy()]))
+                                           RO.axis_angle_to_matrix(torch.from_numpy(3.1 * rs.randn(2000, 3).astype(np.float32))).numpy()]))
     g = torch.from_numpy(rs.randn(big.shape[0], 4).astype(np.float32))
     a = big.to(dev).requires_grad_(True)
     (R.matrix_to_quaternion(a) * g.to(dev)).sum().backward()
     b = big.clone().requires_grad_(True)
-    qb = R._matrix_to_quaternion_torch(b)
+    qb = RO.matrix_to_quaternion(b)
     (qb * g).sum().backward()
     assert len(set(np.abs(qb.detach().numpy()).argmax(1).tolist())) == 4               # every candidate branch is exercised
     np.testing.assert_allclose(a.grad.cpu().numpy(), b.grad.numpy(), rtol=2e-6, atol=2e-6)
-    # batch dimensions and the torch path (fp64 / CPU) keep working
+    # batch dimensions; host tensors are refused (no CPU path in the product)
     assert R.matrix_to_quaternion(m.view(16, 16, 3, 3)).shape == (16, 16, 4)
-    assert R.matrix_to_quaternion(m.cpu().double()).dtype == torch.float64
+    with pytest.raises(RuntimeError):
+        R.matrix_to_quaternion(m.cpu())
 
 
 @pytest.mark.parametrize("J,B", [(24, 5), (52, 3), (64, 1), (1, 2)])

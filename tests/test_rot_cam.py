@@ -1,14 +1,30 @@
-"""CPU: host-side rotation conversions (sings_amd/rotations.py) and orbit / static cameras (sings_amd/camera.py) against
-golden vectors produced by the reference's own functions (tests/golden/gen_rot_cam_golden.py)."""
+"""CPU: the ORACLE's rotation conversions (oracle/rotations_oracle.py -- what the HIP kernels of sings_amd/rotations.py are
+checked against in tests/test_gpu_rotations.py) and the orbit / static cameras (sings_amd/camera.py) against golden
+vectors produced by the reference's own functions (tests/golden/gen_rot_cam_golden.py)."""
 import os
 
 import numpy as np
 import torch
 
-from sings_amd import camera, rotations as R
+from oracle import rotations_oracle as R
+from sings_amd import camera
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rot_cam_golden.npz"))
 T = lambda k: torch.from_numpy(G[k])
+
+
+def test_product_rotations_refuse_host_tensors():
+    """sings_amd.rotations is HIP only: no CPU / eager path behind the product API."""
+    import pytest
+    from sings_amd import rotations as P
+    for fn, w in ((P.quaternion_to_matrix, 4), (P.rotation_6d_to_matrix, 6), (P.axis_angle_to_quaternion, 3),
+                  (P.quaternion_to_axis_angle, 4)):
+        with pytest.raises(RuntimeError):
+            fn(torch.zeros(2, w))
+    with pytest.raises(RuntimeError):
+        P.matrix_to_quaternion(torch.eye(3)[None])
+    with pytest.raises(RuntimeError):
+        P.quaternion_multiply(torch.zeros(2, 4), torch.zeros(2, 4))
 
 
 def test_rotation_conversions_match_reference():
@@ -22,6 +38,12 @@ def test_rotation_conversions_match_reference():
     eq(R.matrix_to_axis_angle(R.rotation_6d_to_matrix(T("d6"))), "m_to_aa")
     eq(R.matrix_to_rotation_6d(R.rotation_6d_to_matrix(T("d6"))), "m_to_d6")
     eq(R.standardize_quaternion(T("q")), "q_std")
+    G1 = np.load(os.path.join(os.path.dirname(__file__), "golden", "lbs_golden.npz"))
+    t1 = lambda k: torch.from_numpy(G1[k])
+    np.testing.assert_array_equal(R.matrix_to_quaternion(t1("g1_mats")).numpy(), G1["g1_m2q"])
+    np.testing.assert_array_equal(R.quaternion_multiply(t1("g1_qa"), t1("g1_qb")).numpy(), G1["g1_qmul"])
+    np.testing.assert_allclose(R.rotation_6d_to_matrix(t1("g1_d6")).numpy(), G1["g1_d6_to_mat"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(R.quaternion_to_matrix(t1("g1_qa")).numpy(), G1["g1_q2m"], rtol=1e-6, atol=1e-7)
     # round trip and differentiability
     aa = T("aa")[4:].clone().requires_grad_(True)
     back = R.rotation_6d_to_axis_angle(R.axis_angle_to_rotation_6d(aa))
