@@ -9,7 +9,8 @@
  * `main`); its source is absent from /root/reference and the reference holds no golden
  * vectors for it.  This file restates the PUBLISHED algorithm of that package (digest in
  * SURVEY.md Appendix A.1-A.5).  It is validated by analytic cases, fp64 finite
- * differences of its explicit backward, and a vectorised twin (oracle/raster_torch.py).
+ * differences of its explicit backward, and an independent vectorised twin whose gradients come
+ * from autograd (oracle/raster_torch.py, compared in tests/test_oracle_raster_twin.py).
  *
  * This file is included twice by raster_oracle.c with REAL = float / double.
  * All arithmetic is written operation-by-operation (compile with -ffp-contract=off) so
@@ -499,7 +500,10 @@ void FN(sgo_preprocess_bwd)(int P, int D, int M,
                     GR[3 * a2 + k] = Gs[3 * a2] * R[k] + Gs[3 * a2 + 1] * R[3 + k] + Gs[3 * a2 + 2] * R[6 + k];
             for (int k = 0; k < 3; k++) {
                 REAL rgr = R[k] * GR[k] + R[3 + k] * GR[3 + k] + R[6 + k] * GR[6 + k];
-                dL_dscales[3 * i + k] = scale_modifier * (REAL)2 * s[k] * rgr;
+                /* upstream's computeCov3D backward: dot(Rt[k], dL_dMt[k]) = the gradient w.r.t. the MODIFIED scale
+                 * s = mod * scale, reported as dL/dscale without the factor mod (the derivative of its own forward would
+                 * carry it; identical at mod = 1, the only value the reference differentiates at) */
+                dL_dscales[3 * i + k] = (REAL)2 * s[k] * rgr;
                 for (int a2 = 0; a2 < 3; a2++) dR[3 * a2 + k] = (REAL)2 * GR[3 * a2 + k] * s[k] * s[k];
             }
             REAL r = q[0], x = q[1], y = q[2], z = q[3];

@@ -32,6 +32,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
 {
     if (!L || P < 0 || width <= 0 || height <= 0) return sg_fail("sg_layout", hipSuccess);
     const size_t gx = (width + SG_TILE - 1) / SG_TILE, gy = (height + SG_TILE - 1) / SG_TILE, T = gx * gy;
+    if (T >= SG_MAX_TILES) return sg_fail("sg_layout: image has 2^20 tiles or more (work items pack the tile id into 20 bits)", hipSuccess);
     const size_t Pn = P > 0 ? P : 1, hw = (size_t)width * height;
     size_t o = 0;
     L->geom_recA = o; o = sg_align(o + Pn * 16);
@@ -74,6 +75,7 @@ static int sg_make_cam(const SgRasterSettings *s, SgCam *c)
     if (s->sh_degree < 0 || s->sh_degree > 3) return 1;
     c->W = s->image_width; c->H = s->image_height;
     c->gx = (c->W + SG_TILE - 1) / SG_TILE; c->gy = (c->H + SG_TILE - 1) / SG_TILE;
+    if ((size_t)c->gx * (size_t)c->gy >= SG_MAX_TILES) return 1;      // tile id | segment << 20 (backward work items)
     c->tanfovx = s->tanfovx; c->tanfovy = s->tanfovy;
     c->fx = (float)c->W / (2.0f * s->tanfovx); c->fy = (float)c->H / (2.0f * s->tanfovy);
     c->mod = s->scale_modifier; c->D = s->sh_degree; c->M = s->sh_coeffs;

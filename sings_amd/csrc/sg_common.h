@@ -7,6 +7,9 @@
 #include "../../include/sings_hip.h"
 
 #define SG_WAVE 64
+// backward work items are tile | depth segment << 20: images of 2^20 tiles or more (> 16k x 16k pixels) are rejected by
+// sg_layout / every entry point instead of aliasing tile ids
+#define SG_MAX_TILES (1u << 20)
 // Tile lists longer than SG_SEG entries are cut into depth segments of SG_SEG entries: the forward checkpoints the
 // per-pixel (T, colour) at every segment boundary, the backward runs one workgroup per (tile, segment).
 #define SG_SEG 256

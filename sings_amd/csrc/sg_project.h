@@ -420,7 +420,7 @@ __device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3],
 #pragma unroll
         for (int k = 0; k < 3; k++) {
             float rgr = R[k] * GR[k] + R[3 + k] * GR[3 + k] + R[6 + k] * GR[6 + k];
-            dsc[k] = c.mod * 2.0f * s[k] * rgr;
+            dsc[k] = 2.0f * s[k] * rgr;       // w.r.t. the MODIFIED scale, as upstream reports it (no factor mod)
 #pragma unroll
             for (int a2 = 0; a2 < 3; a2++) dR[3 * a2 + k] = 2.0f * GR[3 * a2 + k] * s[k] * s[k];
         }

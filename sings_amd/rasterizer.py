@@ -145,7 +145,7 @@ def _forward_plan(dev, P, W, H):
         _drain_async(dev)
     cap = max(_capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
     sig = (P, W, H)
-    first = sig not in _seen.setdefault(dev.index, set())
+    first = sig not in _seen.setdefault(dev.index, set()) or dev.index not in _capacity_hint
     sync = mode == "sync" or (mode == "async" and first)
     if torch.cuda.is_current_stream_capturing():
         sync = False
@@ -155,6 +155,15 @@ def _forward_plan(dev, P, W, H):
 def _forward_done_sync(dev, R, sig):
     _seen[dev.index].add(sig)
     _grow(dev.index, R)
+
+
+def reset_overflow_state(device=None):
+    """Forget capacities, checked signatures and pending results (tests; after a change of scene scale)."""
+    for d in (_capacity_hint, _seen, _pending, _accum, _accum_cap):
+        if device is None:
+            d.clear()
+        else:
+            d.pop(torch.device(device).index, None)
 
 
 def check_deferred_overflow(device=None):
@@ -173,9 +182,9 @@ def check_deferred_overflow(device=None):
     if acc is None:
         return None
     R, flag = (int(v) for v in acc.cpu())
-    cap = _accum_cap.pop(dev.index, None)
+    cap = _accum_cap.get(dev.index)                    # (not reset: a captured step replays with the capacity it was captured with)
     acc.zero_()
-    if cap is None:
+    if cap is None or (R == 0 and flag == 0):
         return None
     _grow(dev.index, R)
     if flag or R > cap:

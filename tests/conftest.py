@@ -15,3 +15,17 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def repo_root():
     return ROOT
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """Borderline-pixel census of the image parity tests (tests/test_gpu_raster.py::_check_image): how many pixels sat
+    within 2e-5 of a hard threshold in the oracle, and how many of those actually differed by more than 1e-5."""
+    import sys
+    mod = sys.modules.get("test_gpu_raster") or sys.modules.get("tests.test_gpu_raster")
+    rows = getattr(mod, "BORDERLINE", None) if mod else None
+    if rows:
+        terminalreporter.write_sep("-", "borderline pixels (oracle threshold margin < 2e-5): test, count / pixels, of which > 1e-5 off")
+        for name, nb, npx, nd in rows:
+            terminalreporter.write_line(f"{name}: {nb} / {npx}, {nd} differ")
+        terminalreporter.write_line(f"total: {sum(r[1] for r in rows)} borderline of {sum(r[2] for r in rows)} pixels, "
+                                    f"{sum(r[3] for r in rows)} differ by more than 1e-5")

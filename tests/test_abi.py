@@ -34,6 +34,21 @@ def test_layout_is_consistent():
         assert getattr(L, f) % 256 == 0
     with pytest.raises(RuntimeError):
         _lib.layout(10, 0, 10, 10)
+    # work items pack the tile id into 20 bits: 2^20 tiles or more are rejected, one tile less is accepted
+    _lib.layout(10, 16 * 1023, 16 * 1025, 10)                      # 1023 * 1025 = 2^20 - 1 tiles
+    with pytest.raises(RuntimeError, match="2\\^20 tiles"):
+        _lib.layout(10, 16 * 1024, 16 * 1024, 10)
+    # ... and by the entry points themselves (validated before anything is launched or dereferenced)
+    import ctypes as C
+    lib = _lib.load()
+    st = _lib.SgRasterSettings()
+    st.image_height = st.image_width = 16 * 1024
+    st.tanfovx = st.tanfovy = 0.5; st.scale_modifier = 1.0; st.sh_degree = 0; st.sh_coeffs = 1
+    st.bg = st.viewmatrix = st.projmatrix = st.campos = 0x1000                   # never dereferenced
+    fake = C.c_void_p(0x1000)
+    rc = lib.sg_rasterize_forward(C.byref(st), 1, fake, fake, None, fake, fake, fake, None, fake, fake, 10, fake, fake, fake, 0,
+                                  None, None)
+    assert rc != 0 and b"bad settings" in lib.sg_last_error()
 
 
 def test_python_surface_matches_upstream_package():

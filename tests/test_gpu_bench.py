@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SMALL = ["--gaussians", "20000", "--width", "640", "--height", "368", "--steps", "3", "--warmup", "1"]
 
 
-def _bench(*argv, env=None, timeout=900):
+def _bench(*argv, env=None, timeout=600):
     e = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         e.pop(k, None)
@@ -35,7 +35,8 @@ def test_single_gpu_line_carries_the_contract():
     assert j["unit"] == "views/s" and j["dtype"] == "f32" and j["vs_baseline"] is None
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(j["roofline"])
     cb = j["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == os.cpu_count() and set(cb["median_ms_by_points"]) == {"6890", "50000", "200000"}
+    assert cb["kind"] == "port" and cb["cores"] in (cb["usable_cores"], 16) and cb["usable_cores"] <= os.cpu_count()
+    assert set(cb["median_ms_by_points"]) == {"6890", "50000", "200000"}
     assert cb["raster_oracle_1core"]["cores"] == 1
 
 

@@ -65,11 +65,21 @@ def _check_forward_state(s, st, o):
     np.testing.assert_array_equal(st["point_keys"].cpu().numpy().astype(np.uint64), o["keys"])
 
 
+BORDERLINE = []        # (test id, borderline pixels, pixels): written to the report by conftest.pytest_terminal_summary
+
+
 def _check_image(color, final_T, n_contrib, o):
+    """RGB <= 1e-5 on every pixel whose hard-threshold decisions (alpha >= 1/255, T >= 1e-4, power <= 0) have a relative
+    margin >= 2e-5 in the oracle.  The others ("borderline": fp32 exp noise can flip the decision) may differ by one
+    splat's contribution; their NUMBER is recorded per test and bounded by what was observed across the suite on the
+    MI355X (at most 3 pixels in 1e5: allowance 8 + 1e-4 of the image -- 0.1 % of a frame in round 1)."""
+    import os
     diff = np.abs(color - o["color"]).max(0)
     border = o["margin"] < BORDER
     nb = int(border.sum())
-    assert nb <= max(16, 1e-3 * border.size), f"{nb} borderline pixels"
+    BORDERLINE.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], nb, int(border.size),
+                       int((diff[border] > RGB_TOL).sum()) if nb else 0))
+    assert nb <= 8 + 1e-4 * border.size, f"{nb} borderline pixels of {border.size}"
     strict = ~border
     assert diff[strict].max() <= RGB_TOL, f"RGB L_inf {diff[strict].max()} at {np.argwhere(diff == diff[strict].max())[:3]}"
     assert diff.max() <= 5e-2
@@ -101,12 +111,13 @@ def test_forward_state_and_image(N, W, H, deg, seed):
     _check_image(st["color"].cpu().numpy(), st["final_T"].cpu().numpy(), st["n_contrib"].cpu().numpy(), o)
 
 
-def test_forward_backward_autograd_api():
-    """GaussianRasterizer (the reference-facing API) forward + backward vs oracle, scale_modifier != 1."""
+@pytest.mark.parametrize("mod", [1.0, 0.5, 1.7])
+def test_forward_backward_autograd_api(mod):
+    """GaussianRasterizer (the reference-facing API) forward + backward vs oracle, at scale_modifier = 1 and != 1 (the
+    scale gradient is then the one upstream reports: w.r.t. the modified scale, no factor scale_modifier)."""
     from diff_gaussian_rasterization import GaussianRasterizer
     dev = _dev()
     s = synthetic_scene(4000, 160, 128, 3, 21)
-    mod = 1.0
     o = _oracle(s, scale_modifier=mod)
     g = ro.backward(o, s["dL_dimage"])
     rs = _settings(s, dev, scale_modifier=mod)
@@ -269,7 +280,7 @@ def test_capacity_growth_and_empty_input():
     s["scales"] = (s["scales"] * 30).astype(np.float32)                 # big splats: R exceeds the first-guess capacity
     o = _oracle(s)
     assert o["R"] > 4 * 3000 + 80 + (1 << 16)
-    rz._capacity_hint.clear()
+    rz.reset_overflow_state()
     rs = _settings(s, dev)
     t = lambda a: torch.from_numpy(a).to(dev)
     color, radii = GaussianRasterizer(rs)(means3D=t(s["means3D"]), means2D=t(s["means3D"]), opacities=t(s["opacities"]),
@@ -591,8 +602,54 @@ def test_deferred_overflow_check():
         assert torch.equal(out, ref)
     finally:
         rz.set_deferred_overflow_check(False)
-        rz._capacity_hint.clear(); rz._capacity_hint.update(hint)
-        rz._pending.clear()
+        rz.reset_overflow_state()
+        rz._capacity_hint.update(hint)
+
+
+def test_async_overflow_check_is_the_default_and_reports_late():
+    """Default mode: the FIRST forward of a (device, P, image size) reads the pair count before returning and sizes the
+    capacity with 2x headroom; later forwards copy (R, flag) to pinned memory behind their kernels and return at once.
+    Several forwards may be issued before anything is looked at and none of their results is lost (round 1 kept only the
+    last one): a frame that overflowed renders the background, the NEXT call reports it (RuntimeWarning) and has a
+    capacity that fits."""
+    import warnings
+    from sings_amd import rasterizer as rz
+    from sings_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    assert rz._mode["mode"] == "async"
+    rz.reset_overflow_state()
+    big = synthetic_scene(30000, 160, 128, 1, 31)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    def args(scale):
+        return dict(means3D=t(big["means3D"]), means2D=torch.zeros(30000, 3, device=dev), opacities=t(big["opacities"]),
+                    shs=t(big["shs"]), scales=t(big["scales"] * scale), rotations=t(big["rotations"]))
+    brs = _settings(big, dev)
+    bgv = t(big["bg"])[:, None, None].expand(3, big["H"], big["W"])
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            small, _ = GaussianRasterizer(brs)(**args(0.3))          # first call of this signature: synchronous
+            assert not rz._pending.get(dev.index)
+            cap0 = rz._capacity_hint[dev.index]
+            small2, _ = GaussianRasterizer(brs)(**args(0.3))         # asynchronous from now on
+            assert len(rz._pending[dev.index]) == 1 and torch.equal(small, small2)
+            huge, _ = GaussianRasterizer(brs)(**args(8.0))           # > 2x the pairs: overflows the capacity, not yet known
+        assert torch.equal(huge, bgv)
+        with warnings.catch_warnings(record=True) as rec:            # reported by whichever later call finds the copy done
+            warnings.simplefilter("always")
+            also, _ = GaussianRasterizer(brs)(**args(0.3))
+            torch.cuda.synchronize()
+            redo, _ = GaussianRasterizer(brs)(**args(8.0))           # capacity grown by now
+        assert sum("rendered the background" in str(w.message) for w in rec) == 1
+        assert torch.equal(also, small)
+        assert rz._capacity_hint[dev.index] > cap0 and not torch.equal(redo, bgv)
+        rz.set_overflow_check("sync")
+        ref, _ = GaussianRasterizer(brs)(**args(8.0))
+        assert torch.equal(redo, ref)
+        assert rz.check_deferred_overflow(dev) is not None           # drains what is pending; nothing overflowed since
+    finally:
+        rz.set_overflow_check("async")
+        rz.reset_overflow_state()
 
 
 @pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 4096, 4097])

@@ -169,4 +169,4 @@ def test_full_step_replays_from_a_hip_graph():
                 assert d <= 1e-5 * r.abs().max().item() + 1e-12, (k, d)      # (tri-plane sums: atomics order)
     finally:
         rz.set_deferred_overflow_check(False)
-        rz._capacity_hint.clear(); rz._capacity_hint.update(hint); rz._pending.clear()
+        rz.reset_overflow_state(); rz._capacity_hint.update(hint)

