@@ -303,7 +303,9 @@ def main_raster(a):
     engs = []
     for v in range(k_views):
         e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v])
-        e.set_camera(camera(rank * k_views + v)[3])
+        # the sizing pass knows the longest tile list (135 at cfg3): with 1.5x margin for the other cameras of the batch no
+        # list can need the long-list sort kernels (checked on the device; a violation surfaces in num_rendered() below)
+        e.set_camera(camera(rank * k_views + v)[3], short_lists=tile_max * 1.5 <= 256)
         engs.append(e)
     eng = engs[0]
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
@@ -353,7 +355,7 @@ def main_raster(a):
     _log(f"timed region ({a.steps} steps)")
     el = timed_region(dist, dev, a.steps, step)
     _log(f"{el / a.steps * 1e3:.3f} ms per step; one view per step")
-    assert all(e.num_rendered() <= e.cap for e in engs)
+    assert all(0 <= e.num_rendered() <= e.cap for e in engs), "pair capacity / short-list hint violated"
     ms_per_step = el / a.steps * 1e3
     views_s = world * a.steps * k_views / el
 

@@ -42,7 +42,7 @@ typedef struct SgRasterSettings {
     int32_t sh_coeffs;     /* M: rows allocated per Gaussian in `shs` ([P,M,3]) */
     int32_t prefiltered;
     int32_t debug;         /* 1: synchronise + check after every kernel */
-    int32_t reserved;
+    int32_t flags;         /* SG_FLAG_* (0 = none) */
     const float *bg;         /* [3]  */
     const float *viewmatrix; /* [16] row-major torch tensor = column-major matrix */
     const float *projmatrix; /* [16] */
@@ -67,6 +67,19 @@ typedef struct SgLayout {
 const char *sg_version(void);
 const char *sg_last_error(void);
 
+/* SG_FLAG_SHORT_LISTS: the caller asserts that no tile's list exceeds 256 entries (known from an earlier forward of the
+ * same scene: a pre-sized engine).  The two kernels that sort longer lists are then not launched at all -- such lists are
+ * sorted by the compositing workgroups themselves -- which saves their launch latency (3.6 us of a 350-us cfg3 view).  If a
+ * longer list does turn up the forward does NOT follow it: it renders the background, writes no gradients, and
+ * sg_read_num_rendered / num_rendered_host report SG_NUM_RENDERED_LONG_LIST (re-run without the flag). */
+#define SG_FLAG_SHORT_LISTS 1
+/* SG_FLAG_WS_CLEAN: the caller vouches that the counters at the head of `binning_ws` (the first sg_layout().bin_ranges
+ * bytes) are zero: the workspace was zero-filled there after allocation, or its last use was a forward of this library that
+ * returned 0 -- every forward leaves them zeroed (its last kernel clears what the next forward's first kernel counts into).
+ * The per-call zeroing launch (~7 us of a 350-us cfg3 view, launch gap included) is then skipped.  Without the flag
+ * the workspace may hold anything. */
+#define SG_FLAG_WS_CLEAN 2
+#define SG_NUM_RENDERED_LONG_LIST (-2)
 /* Workspace sizing.  capacity_pairs = upper bound on R = sum of tiles touched. */
 int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out);
 
@@ -98,7 +111,8 @@ int sg_rasterize_backward(const SgRasterSettings *s, int P, const float *means3D
 int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                     uint8_t *present, void *stream);
 
-/* Reads R written by the last forward into this binning workspace (synchronises). */
+/* Reads R written by the last forward into this binning workspace (synchronises); SG_NUM_RENDERED_LONG_LIST if that
+ * forward ran with SG_FLAG_SHORT_LISTS and met a longer list. */
 int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream);
 
 /* ---- LBS-fused path: canonical Gaussians + joint transforms in, image out ------------------

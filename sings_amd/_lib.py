@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsings_hip.so")
+# SINGS_HIP_LIB: another build of the SAME library (kernel experiments: tools/build_variants.sh); never a fallback
+LIB_PATH = os.environ.get("SINGS_HIP_LIB") or os.path.join(_HERE, "libsings_hip.so")
 _lib = None
 
 
@@ -17,7 +18,7 @@ class SgRasterSettings(C.Structure):
         ("image_height", C.c_int32), ("image_width", C.c_int32),
         ("tanfovx", C.c_float), ("tanfovy", C.c_float), ("scale_modifier", C.c_float),
         ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
-        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("reserved", C.c_int32),
+        ("prefiltered", C.c_int32), ("debug", C.c_int32), ("flags", C.c_int32),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
     ]
 
@@ -48,6 +49,9 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_triplane_backward", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad")
 NUM_KERNELS = 8
+FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
+FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
+NUM_RENDERED_LONG_LIST = -2          # SG_NUM_RENDERED_LONG_LIST
 
 
 def load():

@@ -78,7 +78,7 @@ static int sg_make_cam(const SgRasterSettings *s, SgCam *c)
     if ((size_t)c->gx * (size_t)c->gy >= SG_MAX_TILES) return 1;      // tile id | segment << 20 (backward work items)
     c->tanfovx = s->tanfovx; c->tanfovy = s->tanfovy;
     c->fx = (float)c->W / (2.0f * s->tanfovx); c->fy = (float)c->H / (2.0f * s->tanfovy);
-    c->mod = s->scale_modifier; c->D = s->sh_degree; c->M = s->sh_coeffs;
+    c->mod = s->scale_modifier; c->D = s->sh_degree; c->M = s->sh_coeffs; c->flags = s->flags;
     c->view = s->viewmatrix; c->proj = s->projmatrix; c->campos = s->campos; c->bg = s->bg;
     return 0;
 }
@@ -105,8 +105,9 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
-    // header + tile counters zeroed every call (stream-ordered)
-    sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
+    // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
+    // leaves them zeroed for the next call)
+    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
@@ -119,11 +120,11 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
 
 extern "C" int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream)
 {
-    uint32_t r = 0;
-    hipError_t e = hipMemcpyAsync(&r, binning_ws, 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    uint32_t r[2] = { 0, 0 };                                // header words 0 (R) and 1 (bit 0: R > capacity, bit 1: long list)
+    hipError_t e = hipMemcpyAsync(r, binning_ws, 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return sg_fail("sg_read_num_rendered", e);
-    *num_rendered_host = (int64_t)r;
+    *num_rendered_host = (r[1] & 2u) ? (int64_t)SG_NUM_RENDERED_LONG_LIST : (int64_t)r[0];
     return 0;
 }
 
@@ -151,7 +152,7 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
     sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
     SG_CHECK_LAST("render_bwd", s, st);
     sg_launch_preprocess_bwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
-                             (const float *)bwd_ws, cap, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
+                             (const float *)bwd_ws, cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                              cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);
@@ -189,7 +190,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
-    sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
+    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, 0, st);
@@ -224,7 +225,7 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
     SgImg im = sg_img_view((void *)image_ws, L);
     sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
     SG_CHECK_LAST("render_bwd", s, st);
-    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, (const float *)bwd_ws, cap, dL_dposed_xyz_in, dL_dposed_rotq_in,
+    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, (const float *)bwd_ws, cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
                        skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
                        dL_dtransl, st);
     SG_CHECK_LAST("skin_bwd", s, st);

@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(SG_SCAN_BS)
 sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
-                    uint32_t *__restrict__ ck_start, uint32_t items_cap)
+                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists)
 {
     constexpr int NQ = SG_SCAN_NQ;
     __shared__ uint32_t wsum[NQ][SG_SCAN_BS / 64];
@@ -132,7 +132,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         header[0] = carry[0];
-        header[1] = carry[0] > cap ? 1u : 0u;
+        header[1] = (carry[0] > cap ? 1u : 0u) | (short_lists && carry[3] ? 2u : 0u);
         header[3] = (uint32_t)T;
         header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
         header[5] = carry[1] < items_cap ? carry[1] : items_cap;
@@ -186,7 +186,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items)
+                       uint32_t *__restrict__ items, int short_lists)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
@@ -197,6 +197,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
     const int tpt = (T + SG_SS_THREADS - 1) / SG_SS_THREADS;
     const int t0 = tid * tpt < T ? tid * tpt : T, t1 = t0 + tpt < T ? t0 + tpt : T;
     uint32_t own[NQ] = { 0, 0, 0, 0, 0 };
+#pragma unroll 8
     for (int t = t0; t < t1; t++) {
         uint32_t q[NQ];
         sg_scan_derive(sStart[t], q);
@@ -219,14 +220,27 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
         for (int a = 0; a < NQ; a++) wsum[a][wid] = incl[a];
     }
     __syncthreads();
+    // the 16 wave totals: lane w < 16 holds wave w's total, a 16-lane scan gives every wave its offset -- five pipelined
+    // LDS reads and four shuffle steps instead of 80 dependent LDS round trips (this kernel is pure latency)
     uint32_t run[NQ], tot[NQ];
+    {
+        uint32_t wt[NQ], wi[NQ];
 #pragma unroll
-    for (int a = 0; a < NQ; a++) {
-        uint32_t woff = 0, all = 0;
+        for (int a = 0; a < NQ; a++) { wt[a] = lane < SG_SS_THREADS / 64 ? wsum[a][lane] : 0u; wi[a] = wt[a]; }
 #pragma unroll 1
-        for (int w = 0; w < SG_SS_THREADS / 64; w++) { const uint32_t x = wsum[a][w]; woff += w < wid ? x : 0u; all += x; }
-        run[a] = woff + incl[a] - own[a];
-        tot[a] = all;
+        for (int o = 1; o < SG_SS_THREADS / 64; o <<= 1) {
+#pragma unroll
+            for (int a = 0; a < NQ; a++) {
+                const uint32_t u = __shfl_up(wi[a], o, 64);
+                if (lane >= o) wi[a] += u;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < NQ; a++) {
+            const uint32_t woff = __shfl(wi[a] - wt[a], wid, 64);
+            tot[a] = __shfl(wi[a], SG_SS_THREADS / 64 - 1, 64);
+            run[a] = woff + incl[a] - own[a];
+        }
     }
     const bool writer = (uint32_t)tid % gridDim.x == blockIdx.x;
     for (int t = t0; t < t1; t++) {
@@ -252,7 +266,9 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
     }
     if (blockIdx.x == 0 && tid == 0) {
         header[0] = tot[0];
-        header[1] = tot[0] > cap ? 1u : 0u;
+        // bit 0: more pairs than the workspace holds; bit 1: a list needs the long-list kernels the caller told us to skip.
+        // Either way the lists are incomplete / unsorted and the composite kernels touch nothing.
+        header[1] = (tot[0] > cap ? 1u : 0u) | (short_lists && tot[3] ? 2u : 0u);
         header[3] = (uint32_t)T;
         header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
         header[5] = tot[1] < items_cap ? tot[1] : items_cap;
@@ -396,7 +412,8 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const int T = c.gx * c.gy;
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
-    if (T <= SG_SS_MAX_TILES) {
+    const int short_lists = (c.flags & SG_FLAG_SHORT_LISTS) ? 1 : 0;
+    if (T <= SG_SS_MAX_TILES && !(SG_EXP & 4)) {
         static bool attr_set = false;                     // 4 T bytes of dynamic LDS (up to 128 KiB)
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void *)sg_scan_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SG_SS_MAX_TILES * 4);
@@ -408,7 +425,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items);
+                           b.rank_items, b.items, short_lists);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -416,7 +433,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
         hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, tpt, b.tile_count, b.ranges, b.cursor,
                            b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
-                           sg_items_cap(T, cap));
+                           sg_items_cap(T, cap), short_lists);
         sg_prof_end(SG_K_TILE_SCAN, st);
         sg_prof_begin(SG_K_TILE_SCATTER, st);
         size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
@@ -427,6 +444,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 256 entries (the composite kernel sorts the others): both kernels exit at once when there are none
+    if ((SG_EXP & 64) || short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
     const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
     hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items, b.ranges,

@@ -7,6 +7,12 @@
 #include "../../include/sings_hip.h"
 
 #define SG_WAVE 64
+// Kernel experiments (tools/build_variants.sh builds libsings_hip_exp<N>.so with -DSG_EXP=<N>; the product is SG_EXP = 0):
+//   4 scan and scatter as two launches     8 / 16 / 32 forward preprocess without pair expansion / allocator / SH (timing only,
+//   WRONG results)     64 long-list sort + merge kernels not launched (valid while every tile list has <= 256 entries)
+#ifndef SG_EXP
+#define SG_EXP 0
+#endif
 // backward work items are tile | depth segment << 20: images of 2^20 tiles or more (> 16k x 16k pixels) are rejected by
 // sg_layout / every entry point instead of aliasing tile ids
 #define SG_MAX_TILES (1u << 20)
@@ -101,7 +107,7 @@ static inline SgImg sg_img_view(void *ws, const SgLayout &L)
 
 // Kernel parameter block for per-Gaussian kernels
 struct SgCam {
-    int W, H, gx, gy;
+    int W, H, gx, gy, flags;
     float tanfovx, tanfovy, fx, fy, mod;
     int D, M;
     const float *view, *proj, *campos, *bg;
@@ -122,7 +128,7 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
 void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, const float *grec, size_t cap,
+                              const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, hipStream_t st);
@@ -181,7 +187,7 @@ void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const floa
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
                               hipStream_t st);
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
+                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header, const float *dposed_xyz_in,
                         const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, hipStream_t st);

@@ -17,25 +17,26 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
 {
     extern __shared__ uint32_t sg_hist_lds[];               // hist_tiles words (0: per-pair global atomics)
     __shared__ uint32_t scratch_all[4][192];
-    __shared__ float rows_lds[D == 3 ? 4 : 1][D == 3 ? 32 * SG_ROW_LDS : 1];      // SH row transpose (degree 3 only)
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
     const bool live = idx < P;
     constexpr int nc = (D + 1) * (D + 1);
     float sh[nc * 3];
-    if constexpr (D == 3) {
-        if (shs && c.M == 16) {                             // the reference's layout [P,16,3]: coalesced rows (wave-uniform)
-            float4 v[12];
-            sg_rows48_fetch(shs, idx - lane, P, lane, v);
-            sg_rows48_rows(v, lane, rows_lds[wave], sh);
-        } else if (shs && live) {
-            const float *src = shs + (size_t)idx * c.M * 3;
+    if (SG_EXP & 32) {
 #pragma unroll
-            for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
-        }
-    } else {
-        if (shs && live) {
-            const float *src = shs + (size_t)idx * c.M * 3;
+        for (int k = 0; k < nc * 3; k++) sh[k] = 0.1f;
+    } else if (shs && live) {
+        const float *src = shs + (size_t)idx * c.M * 3;
+        if (D == 3 && c.M == 16) {
+            // the reference's layout [P,16,3]: a row is 192 B, 16-B aligned -> twelve 16-B loads per lane.  (Staging the
+            // wave's 64 rows through LDS as coalesced 1-KiB pieces was measured too: 39.4 vs 39.0 us -- the one-row-per-lane
+            // form does not bound this kernel; the pair expansion's scattered returning atomics do: 16 of its 39 us.)
+#pragma unroll
+            for (int k = 0; k < nc * 3 / 4; k++) {
+                const float4 v = ((const float4 *)src)[k];
+                sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+            }
+        } else {
 #pragma unroll
             for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
         }
@@ -82,7 +83,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                          const int32_t *__restrict__ radii, SgGeom g, const float4 *__restrict__ grec,
-                         size_t cap, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
@@ -102,7 +103,9 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 #pragma unroll
     for (int k = 0; k < 6; k++) G.g6[k] = 0;
     G.g2[0] = G.g2[1] = 0; G.dop = 0;
-    const bool vis = live && radii[idx] > 0;
+    // after a forward that overflowed (header[1] != 0) the backward composite wrote no records: every gradient is ZERO, the
+    // stale contents of the record buffer are never summed (asynchronous overflow check: rasterizer.py)
+    const bool vis = live && radii[idx] > 0 && header[1] == 0u;
     const int Mrows = c.M;
     constexpr int nc = (D + 1) * (D + 1);
     const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
@@ -120,22 +123,23 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
             s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
             q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
         }
-        if (shs && !staged) {
+        if (shs) {
             const float *src = shs + (size_t)idx * Mrows * 3;
+            if (staged) {
 #pragma unroll
-            for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+                for (int k = 0; k < nc * 3 / 4; k++) {
+                    float4 v = ((const float4 *)src)[k];
+                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+            }
         }
-    }
-    float4 shv[D == 3 ? 12 : 1];
-    if constexpr (D == 3) {
-        if (staged) sg_rows48_fetch(shs, g0, P, lane, shv);   // coalesced; transposed into per-lane rows after the records
     }
     // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
     float a9[9];
     sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
-    if constexpr (D == 3) {
-        if (staged) sg_rows48_rows(shv, lane, L, sh);
-    }
     // 2. the chain rule
     if (vis)
         sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
@@ -179,7 +183,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, const float *grec, size_t cap,
+                              const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, hipStream_t st)
@@ -189,7 +193,7 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
     dim3 grid((P + 255) / 256), block(256);
 #define SG_PB(DD) hipLaunchKernelGGL(sg_preprocess_bwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
-                                     (const float4 *)grec, cap, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     (const float4 *)grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
     int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);

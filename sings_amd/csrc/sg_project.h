@@ -122,7 +122,8 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
-        sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
+        if (SG_EXP & 16) sBlockBase = blockIdx.x * 1100u;
+        else sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
     }
     __syncthreads();
     uint32_t base = sBlockBase;
@@ -138,6 +139,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
+    if ((SG_EXP & 8) && !hist) return;
     if (total == 0 && !hist) return;              // wave-uniform (with the LDS histogram the workgroup barriers follow)
     sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -210,46 +212,6 @@ __device__ __forceinline__ void sg_rows48_load(const float *__restrict__ base, i
             const int row = f / 12, c4 = f - row * 12;
             *(float4 *)(l + row * SG_ROW_LDS + 4 * c4) = v;
         }
-    }
-}
-// Coalesced read of the wave's 64 SH rows ([P,16,3] fp32 = 48 floats per Gaussian) into PER-LANE rows, in two steps so
-// that the global loads are all issued before anything waits on them:
-//   sg_rows48_fetch : 12 float4 per lane, lane l of piece i loads float4 number i*64 + l of the wave's contiguous
-//                     12-KiB block (8 cache lines per wave-instruction instead of 64 for one-row-per-lane loads --
-//                     the per-lane form kept the texture addresser busy for ~20 of the 36 us of the forward preprocess)
-//   sg_rows48_rows  : transposes them through `l` (32 * SG_ROW_LDS floats of wave-private LDS) in two halves of 32
-//                     rows; afterwards lane l holds row l (48 floats) in sh[]
-__device__ __forceinline__ void sg_rows48_fetch(const float *__restrict__ base, int g0, int P, int lane, float4 v[12])
-{
-    const float4 *src = (const float4 *)(base + (size_t)g0 * 48);
-    const int nf4 = (P - g0 < 64 ? P - g0 : 64) * 12;
-#pragma unroll
-    for (int i = 0; i < 12; i++) {
-        const int f = i * 64 + lane;
-        v[i] = f < nf4 ? src[f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    }
-}
-__device__ __forceinline__ void sg_rows48_rows(const float4 v[12], int lane, float *__restrict__ l, float sh[48])
-{
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const int f = i * 64 + lane;                   // float4 index inside this half (32 rows x 12)
-            const int row = f / 12, c4 = f - row * 12;
-            *(float4 *)(l + row * SG_ROW_LDS + 4 * c4) = v[6 * h + i];
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        if ((lane >> 5) == h) {
-#pragma unroll
-            for (int k = 0; k < 12; k++) {
-                const float4 t = *(const float4 *)(l + (lane & 31) * SG_ROW_LDS + 4 * k);
-                sh[4 * k] = t.x; sh[4 * k + 1] = t.y; sh[4 * k + 2] = t.z; sh[4 * k + 3] = t.w;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
     }
 }
 // stores `rows` (<= 64) rows starting at Gaussian g0

@@ -139,7 +139,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                     const uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask)
+                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
 {
     __shared__ float4 sA[SG_FB];
     __shared__ float4 sB[SG_FB];
@@ -151,6 +151,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const int tile = sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // The counters the NEXT forward's preprocess counts into are consumed by now (the scan ran before this kernel): leave
+    // them zeroed, so that a caller who keeps its workspace can skip the zeroing launch (SG_FLAG_WS_CLEAN).
+    if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
     const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
     const bool inside = px < W && py < H;
@@ -253,7 +256,7 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                        c.bg, out_color, im.final_T, im.n_contrib,
-                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask);
+                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 

@@ -290,7 +290,7 @@ template <int D>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
                    const int32_t *__restrict__ radii, SgGeom g, const float4 *__restrict__ grec, size_t cap,
-                   const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+                   const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
                    float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
@@ -316,7 +316,7 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     const int Mrows = c.M;
     constexpr int nc = (D + 1) * (D + 1);
     // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
-    const bool vis = live && radii[idx] > 0;
+    const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
     const float4 rc = vis ? g.recC[idx] : make_float4(0, 0, 0, 0);
     float a9[9];
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -926,8 +926,8 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
 size_t sg_skin_slab_floats(int P) { return ((size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES + SG_RED_GROUPS) * (SG_JMAX * 16 + 4); }
 
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const float *dposed_xyz_in,
-                        const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
+                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
+                        const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, hipStream_t st)
 {
@@ -937,7 +937,7 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
 #define SG_SB(DD) hipLaunchKernelGGL(sg_skin_bwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
-                                     (const float4 *)grec, cap, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,          \
+                                     (const float4 *)grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
                                      dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }

@@ -128,17 +128,24 @@ class GradientPipeline:
 
     The views of a step finish one after another (sings_amd.engine.ViewBatch deals them to a few HIP streams).  As soon as
     view v's backward has been queued, ``view_done(v)`` records an event on ITS stream; a dedicated communication stream
-    waits for that event and folds row v into ``acc`` (``acc = row_0``, ``acc += row_v`` -- always in view order, so the
-    sum is bit-identical however the views were interleaved, and identical to ``one_shot``).  Everything but the LAST
-    view's fold is hidden under the rendering of later views.  The last fold is done chunk by chunk and every chunk goes
-    into its collective the moment it is complete, so the fold of chunk c+1 runs under the transfer of chunk c.  What
-    cannot be hidden is one full-size all-reduce after the last view: every gradient element depends on the last
-    backward kernel of the last view, and the optimiser needs the reduced sum before the next forward (exposure is
-    reported by ``timings()``: bench.py prints it next to the stand-alone all-reduce time).
+    waits for those events and folds the rows into ``acc`` in a FIXED order (so the sum is bit-identical however the views
+    were interleaved, and identical to ``one_shot``):
+
+        acc  = rows[0] + ... + rows[h-1]     one pass, as soon as the first h = K - tail views are done (hidden under the
+                                             `tail` views that are still rendering: one view per rendering stream)
+        acc += rows[v]   for v = h .. K-2    as each of them finishes (hidden under the views after it)
+        acc += rows[K-1]                     chunk by chunk; every chunk goes into its collective the moment it is
+                                             complete, so the fold of chunk c+1 runs under the transfer of chunk c
+
+    (Folding EVERY view on arrival was measured first: 2 917 instead of 3 117 views/s at cfg3 on one GPU -- eight
+    141-MB read-modify-write passes per step take more HBM time from the latency-bound binning kernels than the single
+    423-MB pass they replace.)  What cannot be hidden is one full-size all-reduce after the last view: every gradient
+    element depends on the last backward kernel of the last view, and the optimiser needs the reduced sum before the next
+    forward (exposure is reported by ``exposed_ms()``: bench.py prints it next to the stand-alone all-reduce time).
 
     Works on CPU tensors too (no streams; used by the gloo tests)."""
 
-    def __init__(self, rows, frame_parallel=None, chunks=4):
+    def __init__(self, rows, frame_parallel=None, chunks=4, tail=1):
         if rows.dim() != 2:
             raise ValueError("rows must be [views, floats_per_view]")
         self.rows, self.fp = rows, frame_parallel
@@ -146,6 +153,7 @@ class GradientPipeline:
         self.cuda = rows.is_cuda
         # one view per step: the row IS the sum (no fold, no copy)
         self.acc = rows[0] if self.k == 1 else torch.empty(self.n, dtype=rows.dtype, device=rows.device)
+        self.head = max(1, self.k - max(1, int(tail))) if self.k > 1 else 1      # views folded in the first pass
         world = 1 if frame_parallel is None else frame_parallel.world
         c = max(1, int(chunks)) if world > 1 else 1
         step = -(-self.n // c)
@@ -171,32 +179,38 @@ class GradientPipeline:
         if v != self._next:
             raise RuntimeError(f"views must be reported in order (expected {self._next}, got {v})")
         self._next += 1
-        last = v == self.k - 1
         if not self.cuda:
-            self._fold(v, last)
+            self._fold(v)
             return
         self._ev[v].record(torch.cuda.current_stream(self.rows.device))
+        if v < self.head - 1:
+            return                                               # folded together with the rest of the head
         with torch.cuda.stream(self.comm):
-            self.comm.wait_event(self._ev[v])
-            if last and self._timed:
+            for u in (range(self.head) if v == self.head - 1 else (v,)):
+                self.comm.wait_event(self._ev[u])
+            if v == self.k - 1 and self._timed:
                 self._t[0].record(self.comm)                     # = the moment the last view's gradients exist
-            self._fold(v, last)
+            self._fold(v)
 
-    def _fold(self, v, last):
-        row = self.rows[v]
-        if not last:
-            if v == 0:
-                self.acc.copy_(row)
+    def _fold(self, v):
+        last = v == self.k - 1
+        if self.k == 1:
+            pass                                                 # acc is rows[0]
+        elif v < self.head - 1:
+            return
+        elif v == self.head - 1:
+            if self.head == 1:
+                self.acc.copy_(self.rows[0])
             else:
-                self.acc.add_(row)
+                torch.sum(self.rows[:self.head], dim=0, out=self.acc)
+        elif not last:
+            self.acc.add_(self.rows[v])
+        if not last:
             return
         for lo, hi in self.bounds:
             a = self.acc[lo:hi]
-            if v == 0:
-                if self.k > 1:
-                    a.copy_(row[lo:hi])
-            else:
-                a.add_(row[lo:hi])
+            if self.k > 1 and self.head < self.k:
+                a.add_(self.rows[v][lo:hi])
             if self.fp is not None:
                 if self.cuda:                                    # queued behind this fold; the next fold does not wait for it
                     self._works += self.fp.all_reduce_grads(a, async_op=True)
@@ -220,12 +234,15 @@ class GradientPipeline:
         return self.acc
 
     def one_shot(self):
-        """Reference schedule: fold all rows in view order, then ONE collective over the whole buffer (what the
-        pipelined schedule must reproduce bit for bit; also the pre-round-2 behaviour of bench.py)."""
+        """Reference schedule: the same folds in the same order after ALL views are done, then ONE collective over the whole
+        buffer (what the pipelined schedule must reproduce bit for bit; the pre-round-2 behaviour of bench.py)."""
         if self.k > 1:
-            self.acc.copy_(self.rows[0])
-        for v in range(1, self.k):
-            self.acc.add_(self.rows[v])
+            if self.head == 1:
+                self.acc.copy_(self.rows[0])
+            else:
+                torch.sum(self.rows[:self.head], dim=0, out=self.acc)
+            for v in range(self.head, self.k):
+                self.acc.add_(self.rows[v])
         if self.fp is not None:
             self.fp.all_reduce_grads(self.acc)
         return self.acc

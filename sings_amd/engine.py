@@ -26,6 +26,8 @@ class RasterEngine:
         u8 = dict(dtype=torch.uint8, device=self.dev)
         self.geom = torch.empty(L.geom_bytes, **u8)
         self.binning = torch.empty(L.bin_bytes, **u8)
+        self.binning[:L.bin_ranges].zero_()                  # counters zeroed ONCE; every forward leaves them zeroed
+        self._clean = True                                   # (SG_FLAG_WS_CLEAN: no per-call zeroing launch)
         self.img = torch.empty(L.img_bytes, **u8)
         self.bwd_ws = torch.empty(L.bwd_bytes, **u8)
         f32 = dict(dtype=torch.float32, device=self.dev)
@@ -52,19 +54,26 @@ class RasterEngine:
         self._keep = []
         self._s = None
 
-    def set_camera(self, raster_settings):
+    def set_camera(self, raster_settings, short_lists=False):
+        """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 256 entries; the
+        two long-list sort launches are then skipped (SG_FLAG_SHORT_LISTS).  A longer list makes ``num_rendered()`` return
+        ``_lib.NUM_RENDERED_LONG_LIST`` (the frame rendered the background): call set_camera again without the hint."""
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+        self._hint = _lib.FLAG_SHORT_LISTS if short_lists else 0
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
     def forward(self, means3D, shs, opacities, scales, rotations, sync_num_rendered=False):
         nr = C.c_int64(-1)
+        self._s.flags = self._hint | (_lib.FLAG_WS_CLEAN if self._clean else 0)
+        self._clean = False                                  # (stays False if the call below raises)
         _lib.check(self.lib.sg_rasterize_forward(
             C.byref(self._s), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales), _ptr(rotations),
             None, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii),
             0, C.byref(nr) if sync_num_rendered else None, self._stream()), "forward")
+        self._clean = True
         return int(nr.value)
 
     def backward(self, means3D, shs, opacities, scales, rotations, dL_dcolor):
@@ -116,6 +125,7 @@ class SkinnedEngine:
         u8 = dict(dtype=torch.uint8, device=self.dev)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.geom = torch.empty(L.geom_bytes, **u8); self.binning = torch.empty(L.bin_bytes, **u8)
+        self.binning[:L.bin_ranges].zero_(); self._clean = True          # SG_FLAG_WS_CLEAN, as in RasterEngine
         self.img = torch.empty(L.img_bytes, **u8); self.bwd_ws = torch.empty(L.bwd_bytes, **u8)
         self.skin_ws = torch.empty(int(self.lib.sg_skin_ws_floats(self.P)), **f32)
         self.color = torch.empty((3, self.H, self.W), **f32)
@@ -153,10 +163,13 @@ class SkinnedEngine:
 
     def forward(self, shs, opacities, scales, sync_num_rendered=False):
         nr = C.c_int64(-1)
+        self._s.flags = _lib.FLAG_WS_CLEAN if self._clean else 0
+        self._clean = False
         _lib.check(self.lib.sg_skinned_forward(
             C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.geom),
             _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
             C.byref(nr) if sync_num_rendered else None, self._stream()), "skinned forward")
+        self._clean = True
         return int(nr.value)
 
     def backward(self, shs, opacities, scales, dL_dcolor):
@@ -204,7 +217,7 @@ class ViewBatch:
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
         # the rows are folded into `acc` (and, with several ranks, all-reduced) on a communication stream while later
         # views still render: sings_amd.dp.GradientPipeline
-        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
+        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks, tail=self.n)
         self.acc = self.pipe.acc
 
     def run_unreduced(self, fn):

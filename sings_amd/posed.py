@@ -52,6 +52,56 @@ def joint_transforms_batch(poses, joints_rest, parents=SMPL_PARENTS):
     return G - torch.cat([torch.zeros(B, J, 4, 3, dtype=G.dtype, device=G.device), corr], -1)
 
 
+def forward_chunk(gs_attrs, lbs_weights, A_t2pose, inv_A_t2cano=None, transl=None, smpl_scale=None, ext_tfs=None,
+                  isotropic=False, active_sh_degree=0):
+    """The batched deformation of ``SinGS.forward_chunk`` (sings/rec/models/sings_hybrid.py:474-569) for callers that want
+    the reference's dict of POSED Gaussians for B frames at once (gs_trainer.py:695-714 then renders them one by one);
+    ``animate_chunk`` below is the fused alternative that never materialises them.
+
+    gs_attrs: dict(xyz_canon [N,3], xyz_offsets, rot6d_canon [N,6] | None, scales [N,3], opacity [N,1], shs [N,M,3]);
+    A_t2pose [B,J,4,4]: the joint transforms the reference takes from ``smpl_template(...).A`` (here:
+    ``joint_transforms_batch``; shape blending needs the licensed SMPL model and stays with the caller);
+    inv_A_t2cano [J,4,4] | None; transl [B,3], smpl_scale [B,1], ext_tfs = (trans [B,3], rotmat [B,3,3], scale [B,1]).
+    Returns the reference's keys with the same shapes ([B,N,...], canonical tensors expanded, not copied).
+    Device work: ``sg_lbs_forward`` per frame (T and vertices in one kernel, W.A on the matrix cores), the rotation kernels
+    of sings_amd.rotations for 6-D -> matrix, matrix -> quaternion ([B*N] in one launch) and the quaternion product."""
+    from . import rotations as R
+    from .lbs import lbs_extra
+    xyz_canon = gs_attrs['xyz_canon']
+    dev = xyz_canon.device
+    if dev.type != "cuda":
+        raise RuntimeError("sings_amd.posed.forward_chunk runs on the MI355X only; there is no CPU fallback")
+    B, N = int(A_t2pose.shape[0]), int(xyz_canon.shape[0])
+    rot6d = gs_attrs.get('rot6d_canon')
+    if not isotropic:
+        rotmat_canon = R.rotation_6d_to_matrix(rot6d)
+        rotq_canon = R.matrix_to_quaternion(rotmat_canon)
+    else:
+        rotmat_canon = torch.eye(3, device=dev).unsqueeze(0).repeat(N, 1, 1)
+        rotq_canon = torch.zeros(N, 4, device=dev)
+    scales = gs_attrs['scales'].unsqueeze(0).expand(B, -1, -1)
+    A = A_t2pose if inv_A_t2cano is None else A_t2pose @ inv_A_t2cano.unsqueeze(0)
+    xyz, _, lbs_T, _, _ = lbs_extra(A, xyz_canon.unsqueeze(0).expand(B, -1, -1), None, lbs_weights, None, disable_posedirs=True)
+    if smpl_scale is not None:
+        xyz = xyz * smpl_scale.unsqueeze(-1)
+        scales = scales * smpl_scale.unsqueeze(-1)
+    if transl is not None:
+        xyz = xyz + transl.unsqueeze(1)
+    rotq = R.matrix_to_quaternion(lbs_T[..., :3, :3] @ rotmat_canon.unsqueeze(0))
+    if ext_tfs is not None:
+        trans, rotmat, scale = ext_tfs
+        xyz = trans[:, None, :] + scale[:, None] * (rotmat[:, None, ...] @ xyz[..., None]).squeeze(-1)
+        scales = scale[..., None] * scales
+        rotq = R.quaternion_multiply(R.matrix_to_quaternion(rotmat.contiguous())[:, None, :], rotq)
+    return {
+        'xyz': xyz, 'xyz_canon': xyz_canon.unsqueeze(0).expand(B, -1, -1), 'xyz_offsets': gs_attrs.get('xyz_offsets'),
+        'scales': scales, 'scales_canon': scales,                    # (the reference returns the scaled tensor under both keys)
+        'rotq': rotq, 'rotq_canon': rotq_canon,
+        'shs': gs_attrs['shs'].unsqueeze(0).expand(B, -1, -1, -1), 'opacity': gs_attrs['opacity'].unsqueeze(0).expand(B, -1, -1),
+        'active_sh_degree': active_sh_degree,
+    }
+
+
 class FrameAnimator:
     """Forward-only rendering of posed frames, ``streams`` frames in flight: one pre-allocated SkinnedEngine (workspaces)
     per stream, nothing allocated or synchronised per frame except one read of the pair counts per round (a frame whose

@@ -218,7 +218,7 @@ def _settings_struct(rs, dev, sh_coeffs, keep):
     s.tanfovx = float(rs.tanfovx); s.tanfovy = float(rs.tanfovy)
     s.scale_modifier = float(rs.scale_modifier)
     s.sh_degree = int(rs.sh_degree); s.sh_coeffs = int(sh_coeffs)
-    s.prefiltered = int(bool(rs.prefiltered)); s.debug = int(bool(rs.debug)); s.reserved = 0
+    s.prefiltered = int(bool(rs.prefiltered)); s.debug = int(bool(rs.debug)); s.flags = 0
     s.bg = bg.data_ptr(); s.viewmatrix = vm.data_ptr(); s.projmatrix = pm.data_ptr(); s.campos = cp.data_ptr()
     return s
 

@@ -100,20 +100,20 @@ def _pipeline_worker(rank, world, port, algorithm, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         res = []
-        for k, n, chunks in ((1, 1003, 4), (5, 1003, 4), (8, 4099, 3), (3, 130, 7)):
+        for k, n, chunks, tail in ((1, 1003, 4, 1), (5, 1003, 4, 1), (8, 4099, 3, 3), (3, 130, 7, 3), (2, 77, 2, 1), (6, 513, 1, 2)):
             g = torch.Generator().manual_seed(100 * rank + k)
             rows = torch.randn((k, n), generator=g) * torch.logspace(-3, 3, n)        # fp32 sums that depend on the order
             fp = FrameParallel(algorithm=algorithm)
-            ref = GradientPipeline(rows.clone(), fp, chunks=chunks).one_shot().clone()
+            ref = GradientPipeline(rows.clone(), fp, chunks=chunks, tail=tail).one_shot().clone()
             live = rows.clone()
-            pipe = GradientPipeline(live, fp, chunks=chunks)
+            pipe = GradientPipeline(live, fp, chunks=chunks, tail=tail)
             for _ in range(2):                                                        # two steps through the same object
                 live.copy_(rows)                                                      # (every backward rewrites its row)
                 pipe.begin()
                 for v in range(k):
                     pipe.view_done(v)
                 got = pipe.finish().clone()
-            res.append((k, n, ref.numpy(), got.numpy(), rows.numpy()))
+            res.append((k, n, ref.numpy(), got.numpy(), rows.numpy(), pipe.head))
         out.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -132,17 +132,17 @@ def _run_pipeline(algorithm):
         p.join(60)
         assert p.exitcode == 0
     for case in range(len(res[0])):
-        k, n, ref0, got0, rows0 = res[0][case]
-        _, _, ref1, got1, rows1 = res[1][case]
+        k, n, ref0, got0, rows0, head = res[0][case]
+        _, _, ref1, got1, rows1, _ = res[1][case]
         # the pipelined schedule (fold per view, chunked collectives) == fold everything, then one collective: bit for bit
         assert np.array_equal(ref0, got0) and np.array_equal(ref1, got1)
         assert np.array_equal(got0, got1)                                            # both ranks hold the same sum
-        def fold(rows):
-            a = rows[0].copy()
-            for v in range(1, k):
+        def fold(rows):                                                              # head in one pass, then view by view
+            a = torch.sum(torch.from_numpy(rows[:head]), dim=0).numpy() if head > 1 else rows[0].copy()
+            for v in range(head, k):
                 a = a + rows[v]
             return a
-        assert np.array_equal(got0, fold(rows0) + fold(rows1))                       # view order inside a rank, then ranks
+        assert np.array_equal(got0, fold(rows0) + fold(rows1))                       # inside a rank, then the ranks
 
 
 def test_pipelined_reduction_matches_one_shot_all_reduce():
