@@ -15,11 +15,11 @@ every view the rasterizer forward (preprocess -> tile binning -> alpha composite
 per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside
 the timed region; the views of a batch are dealt round-robin to `--streams` HIP streams (default 3: the latency-bound
 binning kernels and the tile-imbalance tails of one view overlap the composite of the others) and their gradient rows
-are folded, in view order, on a communication stream while later views still render (sings_amd.dp.GradientPipeline).
+are folded in one pass once the views have joined (sings_amd.dp.GradientPipeline).
 `--views-per-step 1 --streams 1` is the reference's one frame per step (gs_trainer.py:207-215); the default run times
 that too, after the batched region, and reports it as `train_step_ms_one_view`.  With N > 1 every (rank, view) pair
 renders a DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the canonical-Gaussian gradients of
-the batch with ONE RCCL all-reduce per step (chunked behind the last view's fold), i.e. the 47 MB all-reduce is paid
+the batch with ONE RCCL all-reduce per step (in chunks, each behind its part of the fold), i.e. the 47 MB all-reduce is paid
 once per 8 views ("scaling": "weak": the batch per rank is fixed).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
@@ -384,9 +384,9 @@ def main_raster(a):
             ex.append(batch.pipe.exposed_ms())
         batch.pipe.enable_timing(False)
         comm["allreduce_exposed_ms"] = sorted(ex)[len(ex) // 2]
-        comm["allreduce_hidden_note"] = ("folds of views 0..k-2 run under later views; the last fold is pipelined with the "
-                                         f"collective in {len(batch.pipe.bounds)} chunks; exposed = last view's gradients "
-                                         "ready -> reduced sum ready (median of 10 synchronised steps)")
+        comm["allreduce_hidden_note"] = (f"the fold of the k rows is pipelined with the collective in {len(batch.pipe.bounds)} "
+                                         "chunks; exposed = last view's gradients ready -> reduced sum ready (median of 10 "
+                                         "synchronised steps; includes the fold)")
 
     # per-kernel durations: HIP events around every launch, on the launch stream (separate pass, one view at a time)
     lib = _lib.load()
@@ -443,7 +443,7 @@ def main_raster(a):
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "tile_list_mean": tile_mean,
                    "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams, "regularisers": bool(a.regularisers),
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
-                   "reduction": "one_shot" if a.one_shot_reduce or graph is not None else f"pipelined/{len(batch.pipe.bounds)}",
+                   "reduction": "one_shot" if a.one_shot_reduce or graph is not None else f"fold+collective in {len(batch.pipe.bounds)} chunk(s)",
                    "parallelism": f"dp{world}"},
         "roofline": roofline, "roofline_hbm": hbm,
         "roofline_whole_pass": {"algorithmic_bytes_per_view": total_bytes,

@@ -294,6 +294,19 @@ int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias
 int sg_bias_act_backward(int N, int C, int act, const float *z, const float *row_offset, const float *dh, void *ws,
                          float *dz, float *dbias, void *stream);
 
+/* One decoder layer (nn.Linear + activation, modules/decoders.py:41-49, 75-94) as ONE kernel each way on the matrix cores
+ * (v_mfma_f32_32x32x2_f32, fp32): bias and activation in the GEMM's epilogue, the activation derivative in the prologue of
+ * the input-gradient GEMM.  x [N,Cin], W [Cout,Cin] (nn.Linear.weight), bias [Cout] | NULL, 1 <= Cin, Cout <= 128; `act`
+ * and `row_offset` as for sg_bias_act_*.
+ *   forward : h_out [N,Cout] = act(x W^T + bias); aux_out [N,Cout] | NULL receives what the backward needs besides h:
+ *             GELU: gelu'(z) itself (the erf is evaluated once, here), softplus: z; nothing for act = 0 and sigmoid (NULL).
+ *   backward: aux = the forward's aux_out (GELU, softplus) or its h_out (sigmoid: s' = h (1 - h)); NULL when act = 0.
+ *             dz_out [N,Cout] | NULL = dh * act' (input of sg_weight_grad; NULL when act = 0: dz is dh), dx_out [N,Cin] = dz W. */
+int sg_linear_forward(int N, int Cin, int Cout, int act, const float *x, const float *W, const float *bias,
+                      const float *row_offset, float *aux_out, float *h_out, void *stream);
+int sg_linear_backward(int N, int Cin, int Cout, int act, const float *aux, const float *row_offset, const float *dh,
+                       const float *W, float *dz_out, float *dx_out, void *stream);
+
 /* Weight / bias gradient of one decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz (db may be NULL);
  * dz [N,Cout], x [N,Cin]; Cin in {32, 64, 96, 128}, Cout <= 128.  fp32 on the matrix cores, deterministic.
  * `ws`: sg_weight_grad_ws_bytes(N, Cout, Cin). */

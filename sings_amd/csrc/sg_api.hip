@@ -341,6 +341,27 @@ extern "C" int sg_matrix_to_quaternion_backward(int N, const float *matrices, co
     return e == hipSuccess ? 0 : sg_fail("sg_matrix_to_quaternion_backward", e);
 }
 
+// ---- decoder layers as fused MFMA kernels (f3)
+extern "C" int sg_linear_forward(int N, int Cin, int Cout, int act, const float *x, const float *W, const float *bias,
+                                 const float *row_offset, float *z_out, float *h_out, void *stream)
+{
+    if (N <= 0 || !x || !W || !h_out || act < 0 || act > 3) return sg_fail("sg_linear_forward: bad argument", hipSuccess);
+    if (sg_launch_linear_fwd(N, Cin, Cout, act, x, W, bias, row_offset, z_out, h_out, (hipStream_t)stream))
+        return sg_fail("sg_linear_forward: 1 <= Cin, Cout <= 128", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_linear_forward", e);
+}
+extern "C" int sg_linear_backward(int N, int Cin, int Cout, int act, const float *z, const float *row_offset, const float *dh,
+                                  const float *W, float *dz_out, float *dx_out, void *stream)
+{
+    if (N <= 0 || !dh || !W || !dx_out || act < 0 || act > 3 || (act != 0 && !z))
+        return sg_fail("sg_linear_backward: bad argument", hipSuccess);
+    if (sg_launch_linear_bwd(N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out, (hipStream_t)stream))
+        return sg_fail("sg_linear_backward: 1 <= Cin, Cout <= 128", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_linear_backward", e);
+}
+
 // ---- the other rotation conversions (a11)
 extern "C" int sg_rotation_convert(int op, int N, const float *in, float *out, void *stream)
 {

@@ -1,0 +1,254 @@
+// The decoders' linear layers on the matrix cores, bias and activation fused in:
+//   forward   h = act(x W^T + b)                         modules/decoders.py:41-49, 75-94 (nn.Linear + GELU / Sigmoid)
+//   backward  dz = dh * act'(z),  dx = dz W              autograd of the same lines
+// replacing, per layer, a library GEMM + an element-wise pass each way (round 1: torch.addmm / torch.mm + sg_bias_act_*:
+// 0.62 + 0.41 ms of the 2.96-ms training step).  fp32 in, fp32 out, v_mfma_f32_32x32x2_f32 (exact fp32 products).
+//
+// One kernel, two instantiations of the same tile loop:   Y[N, CO] = X'[N, CK] . M^T,   M [CO, CK]
+//   forward : X' = x,                M = W   [Cout, Cin]      epilogue: z = Y + b, h = act(z)
+//   backward: X' = dh * act'(z),     M = W^T [Cin, Cout]      prologue also stores dz (the weight-gradient kernel reads it)
+// The forward leaves behind what makes act' ONE multiplication in the backward ("aux"): GELU -> gelu'(z) itself (the erf is
+// evaluated once, in the forward's epilogue), sigmoid -> nothing (s' = h (1 - h) from the saved output), softplus -> z.
+// Layer widths are <= 128, so the whole of M fits the register file of a workgroup: wave w keeps ITS 32 output columns
+// of M -- CK/2 registers per lane, already in MFMA A-operand layout -- for the whole kernel; only the points stream.
+// A tile of 32 PT points x CK inputs goes through LDS once (coalesced 16-B loads, shared by the four waves) and is read back
+// as the B operand with one ds_read_b128 per four MFMAs: the reduction index is PERMUTED (MFMA step s multiplies inputs s
+// and CK/2 + s), so the four values a lane needs next are adjacent.  The 32 x 32 result tiles return through LDS so
+// that z / h / dx leave as whole 16-B-per-lane rows.  Loads of the next tile are in flight during the MFMAs.
+#include "sg_common.h"
+
+typedef float sg_v16f __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float sgl_gelu(float z) { return 0.5f * z * (1.0f + erff(z * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sgl_gelu_grad(float z)
+{
+    const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+    return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+// act: 0 identity, 1 GELU (erf), 2 sigmoid(z + row_offset), 3 log(exp(z) + 1)   (same codes as sg_bias_act_*)
+__device__ __forceinline__ float sgl_act(int act, float z, float ro)
+{
+    if (act == 1) return sgl_gelu(z);
+    if (act == 2) return 1.0f / (1.0f + expf(-(z + ro)));
+    if (act == 3) return logf(expf(z) + 1.0f);
+    return z;
+}
+// derivative from the forward's aux value: act 1: aux = gelu'(z); act 2: aux = h = sigmoid(.); act 3: aux = z
+__device__ __forceinline__ float sgl_act_grad_aux(int act, float aux)
+{
+    if (act == 1) return aux;
+    if (act == 2) return aux * (1.0f - aux);
+    if (act == 3) { const float e = expf(aux); return e / (e + 1.0f); }
+    return 1.0f;
+}
+
+#define SGL_MAXC 128
+#define SGL_TILE 4352                // floats per LDS tile: 32 x (128 + 4), 64 x (64 + 4), 128 x (32 + 1) all fit (3 x 17 KiB per workgroup)
+// 32-point tiles a workgroup handles per round: one wave per (column block, point tile), limited by the LDS tile
+__host__ __device__ inline int sgl_point_tiles(int TO, int CKP)
+{
+    int pt = 4 / TO;
+    while (pt > 1 && (32 * pt * (CKP + 4) > SGL_TILE || 32 * pt * (32 * TO + 1) > SGL_TILE)) pt >>= 1;
+    return pt;
+}
+
+// NQ = CKP / 8 (CKP = CK rounded up to a multiple of 8): float4 reads per lane and tile; BWD: the backward instantiation
+template <int NQ, bool BWD>
+__global__ void __launch_bounds__(256)
+sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
+                 const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
+                 const float *__restrict__ row_offset, float *__restrict__ out0, float *__restrict__ out1)
+{
+    constexpr int CKP = NQ * 8, HALF = CKP / 2;
+    __shared__ float sX[2][SGL_TILE];                                      // X' tile [32 PT points][CKP + 4], double-buffered; the Y tile
+                                                                           // [32 PT points][32 TO + 1] reuses the buffer just consumed
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int TO = (CO + 31) / 32;                                         // 32-column blocks of the output (1..4)
+    const int PT = sgl_point_tiles(TO, CKP);                               // 32-point tiles per round (waves beyond TO PT idle in the MFMA part)
+    const int cb = wave % TO, pt = wave / TO;                              // this wave: column block, point tile
+    const bool active = pt < PT;
+    const int R = 32 * PT;                                                 // points per round
+    const int XS = CKP + 4, YS = 32 * TO + 1;
+    const int j = lane & 31, h = lane >> 5;
+    // ---- this wave's 32 columns of M as MFMA A operands: a[s] = M(32 cb + j, h HALF + s)
+    float a[HALF];
+    {
+        const int co = 32 * cb + j;
+#pragma unroll
+        for (int s = 0; s < HALF; s++) {
+            const int k = h * HALF + s;
+            a[s] = (active && co < CO && k < CK) ? Mw[(size_t)co * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+        }
+    }
+    const int f4_per_row = CKP / 4;
+    const int nf4 = R * f4_per_row;                                        // float4 elements of one X' tile
+    constexpr int PTMAX = SGL_TILE / (32 * (CKP + 4)) >= 4 ? 4 : (SGL_TILE / (32 * (CKP + 4)) >= 2 ? 2 : 1);
+    constexpr int PER = (PTMAX * 32 * CKP / 4 + 255) / 256;                // float4 per thread and tile (<= 4)
+    const bool vec = (CK & 3) == 0;
+    float4 xr[PER], zr[BWD ? PER : 1];
+    // fetch: the loads only (they stay in flight during the MFMAs of the current tile); stash: act' (backward), dz out, LDS
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int f = tid + 256 * q;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), zz = v;
+            if (f < nf4) {
+                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
+                if (n < N && c < CK) {
+                    if (vec) {
+                        v = *(const float4 *)(X + (size_t)n * CK + c);
+                        if (BWD && act != 0) zz = *(const float4 *)(Z + (size_t)n * CK + c);
+                    } else {
+                        float e[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, g[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (c + u < CK) {
+                                e[u] = X[(size_t)n * CK + c + u];
+                                if (BWD && act != 0) g[u] = Z[(size_t)n * CK + c + u];
+                            }
+                        v = make_float4(e[0], e[1], e[2], e[3]); zz = make_float4(g[0], g[1], g[2], g[3]);
+                    }
+                }
+            }
+            xr[q] = v;
+            if (BWD) zr[q] = zz;
+        }
+    };
+    auto stash = [&](int buf, int n0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int f = tid + 256 * q;
+            if (f < nf4) {
+                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
+                float4 v = xr[q];
+                if (BWD && act != 0) {
+                    const float4 zz = zr[q];
+                    v.x *= sgl_act_grad_aux(act, zz.x); v.y *= sgl_act_grad_aux(act, zz.y);
+                    v.z *= sgl_act_grad_aux(act, zz.z); v.w *= sgl_act_grad_aux(act, zz.w);
+                    if (out1 && n < N && c < CK) {                                                   // dz
+                        if (vec) *(float4 *)(out1 + (size_t)n * CK + c) = v;
+                        else {
+                            const float e[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                            for (int u = 0; u < 4; u++) if (c + u < CK) out1[(size_t)n * CK + c + u] = e[u];
+                        }
+                    }
+                }
+                *(float4 *)&sX[buf][row * XS + c] = v;
+            }
+        }
+    };
+    const int ntiles = (N + R - 1) / R;
+    int tile = blockIdx.x;
+    if (tile < ntiles) { fetch(tile * R); stash(0, tile * R); }
+    __syncthreads();
+    int buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int n0 = tile * R, next = tile + gridDim.x;
+        if (next < ntiles) fetch(next * R);                                // in flight during the MFMAs below
+        sg_v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        if (active) {
+            const float *xrow = &sX[buf][(32 * pt + j) * XS + h * HALF];   // B operand: X'[point j][h HALF + s]
+#pragma unroll
+            for (int q = 0; q < NQ; q++) {
+                const float4 b = *(const float4 *)(xrow + 4 * q);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q], b.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 1], b.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 2], b.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], b.w, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();                                                   // every wave has read its B operands: the buffer is free
+        float *sDyn = sX[buf];
+        if (active) {
+            // D: lane l, register r -> output column 32 cb + 8 (r / 4) + 4 (l / 32) + r % 4, point 32 pt + l % 32
+#pragma unroll
+            for (int r = 0; r < 16; r++)
+                sDyn[(32 * pt + j) * YS + 32 * cb + 8 * (r >> 2) + 4 * h + (r & 3)] = acc[r];
+        }
+        __syncthreads();
+        // ---- epilogue: whole rows of the Y tile leave with 16-B stores (scalar tail when CO is not a multiple of 4)
+        {
+            const int cq = (CO + 3) / 4, total = R * cq;
+            for (int f = tid; f < total; f += 256) {
+                const int row = f / cq, c = 4 * (f - row * cq), n = n0 + row;
+                if (n >= N) continue;
+                float y[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) y[u] = c + u < CO ? sDyn[row * YS + c + u] : 0.0f;
+                if (!BWD) {
+                    const float ro = (act == 2 && row_offset) ? row_offset[n] : 0.0f;
+                    float hh[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (bias && c + u < CO) y[u] += bias[c + u];
+                        if (act == 1) {                                    // h and gelu'(z) share the erf
+                            const float zz = y[u], cdf = 0.5f * (1.0f + erff(zz * 0.70710678118654752440f));
+                            hh[u] = zz * cdf;
+                            y[u] = cdf + zz * 0.39894228040143267794f * __expf(-0.5f * zz * zz);      // aux = gelu'(z)
+                        } else hh[u] = sgl_act(act, y[u], ro);
+                    }
+                    if ((CO & 3) == 0) {
+                        if (out1) *(float4 *)(out1 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);        // z
+                        *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(hh[0], hh[1], hh[2], hh[3]);               // h
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (c + u < CO) { if (out1) out1[(size_t)n * CO + c + u] = y[u]; out0[(size_t)n * CO + c + u] = hh[u]; }
+                    }
+                } else {
+                    if ((CO & 3) == 0) *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);  // dx
+                    else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) if (c + u < CO) out0[(size_t)n * CO + c + u] = y[u];
+                    }
+                }
+            }
+        }
+        if (next < ntiles) stash(buf ^ 1, next * R);
+        __syncthreads();
+    }
+}
+
+template <bool BWD>
+static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, const float *Z, const float *Mw, int s_co, int s_ck,
+                            const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st)
+{
+    if (N <= 0) return 0;
+    if (CK < 1 || CK > SGL_MAXC || CO < 1 || CO > SGL_MAXC) return 1;
+    const int nq = (CK + 7) / 8;
+    const int nqt = nq <= 1 ? 1 : (nq <= 4 ? 4 : (nq <= 6 ? 6 : (nq <= 8 ? 8 : (nq <= 12 ? 12 : 16))));
+    const int TO = (CO + 31) / 32, PT = sgl_point_tiles(TO, nqt * 8), R = 32 * PT;
+    const int ntiles = (N + R - 1) / R;
+    const int grid = ntiles < 768 ? ntiles : 768;                           // 3 resident workgroups per CU, persistent over tiles
+    const size_t dyn = 0;
+#define SGL_GO(NQv)                                                                                                       \
+    hipLaunchKernelGGL((sg_linear_kernel<NQv, BWD>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, Mw, s_co, s_ck, \
+                       bias, row_offset, out0, out1)
+    if (nq <= 1) SGL_GO(1);
+    else if (nq <= 4) SGL_GO(4);
+    else if (nq <= 6) SGL_GO(6);
+    else if (nq <= 8) SGL_GO(8);
+    else if (nq <= 12) SGL_GO(12);
+    else SGL_GO(16);
+#undef SGL_GO
+    return 0;
+}
+
+// forward: x [N,Cin], W [Cout,Cin], bias [Cout] | NULL -> h_out [N,Cout]; aux_out | NULL: what the backward needs besides h
+// (act 1: gelu'(z); otherwise the pre-activation z)
+int sg_launch_linear_fwd(int N, int Cin, int Cout, int act, const float *x, const float *W, const float *bias,
+                         const float *row_offset, float *z_out, float *h_out, hipStream_t st)
+{
+    return sg_linear_launch<false>(N, Cin, Cout, act, x, nullptr, W, Cin, 1, bias, row_offset, h_out, z_out, st);
+}
+// backward: dh, aux [N,Cout] (act 1: the forward's aux; act 2: h; act 3: z), W [Cout,Cin] -> dz_out [N,Cout] = dh * act'
+// (may be NULL), dx_out [N,Cin] = dz W
+int sg_launch_linear_bwd(int N, int Cin, int Cout, int act, const float *z, const float *row_offset, const float *dh,
+                         const float *W, float *dz_out, float *dx_out, hipStream_t st)
+{
+    // Y = dx [N, CO = Cin], X' = dz [N, CK = Cout], M(co = input column, ck = output column) = W[ck][co]
+    return sg_linear_launch<true>(N, Cout, Cin, act, dh, z, W, 1, Cin, nullptr, row_offset, dx_out, dz_out, st);
+}

@@ -154,52 +154,60 @@ class HexPlaneField(nn.Module):
 
 
 class _LinearAct(torch.autograd.Function):
-    """h = act(x @ W^T + b): library GEMM + fused HIP bias/activation; backward likewise."""
+    """h = act(x @ W^T + b) as ONE kernel on the matrix cores (sg_linear_forward: bias + activation in the GEMM's epilogue);
+    backward: sg_linear_backward (dz = dh * act' in the prologue of dx = dz W, dz stored once) + sg_weight_grad.
+    No library GEMM, no separate element-wise pass (round 1: torch.addmm / torch.mm + sg_bias_act_*).  The forward saves
+    ``aux``: gelu'(z) for GELU (so the backward's act' is one multiplication), the output h for the sigmoid, z otherwise."""
 
     @staticmethod
     def forward(ctx, x, W, b, act, row_offset):
         lib = _lib.load()
+        if not x.is_cuda:
+            raise RuntimeError("sings_amd.decode: tensors must live on the GPU (no CPU fallback)")
         x = x.contiguous().float()
-        dev, N, Cout = x.device, int(x.shape[0]), int(W.shape[0])
-        # bias in the GEMM's epilogue (torch.addmm); the activation kernel then only reads z and writes h, and a layer
-        # without activation needs no second pass at all
-        z = torch.addmm(b.float(), x, W.t()) if b is not None else torch.mm(x, W.t())
+        Wc = W.contiguous().float()
+        bc = None if b is None else b.contiguous().float()
+        dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
         ro = row_offset.contiguous().float().reshape(-1) if row_offset is not None else None
-        if act == ACT_NONE:
-            h = z
-        else:
-            h = torch.empty_like(z)
-            with torch.cuda.device(dev):
-                _lib.check(lib.sg_bias_act_forward(N, Cout, act, _ptr(z), None, _ptr(ro), None, _ptr(h), _stream(dev)),
-                           "bias/act forward")
-        z = z if act != ACT_NONE else None
-        ctx.save_for_backward(x, W, z if z is not None else h, ro if ro is not None else torch.empty(0, device=dev))
-        ctx.act, ctx.has_ro, ctx.has_b = act, ro is not None, b is not None
+        h = torch.empty((N, Cout), dtype=torch.float32, device=dev)
+        aux = torch.empty_like(h) if act in (ACT_GELU, ACT_SOFTPLUS_REF) else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_linear_forward(N, Cin, Cout, act, _ptr(x), _ptr(Wc), _ptr(bc), _ptr(ro), _ptr(aux), _ptr(h),
+                                             _stream(dev)), "linear forward")
+        if act == ACT_SIGMOID:
+            aux = h
+        ctx.save_for_backward(x, Wc, aux if aux is not None else torch.empty(0, device=dev))
+        ctx.act, ctx.has_b = act, b is not None
         return h
 
     @staticmethod
     def backward(ctx, dh):
         lib = _lib.load()
-        x, W, z, ro = ctx.saved_tensors
-        dev, N, Cout = x.device, int(x.shape[0]), int(W.shape[0])
+        x, W, aux = ctx.saved_tensors
+        dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
         dh = dh.contiguous().float()
-        Cin = int(W.shape[1])
-        if ctx.act != ACT_NONE:
-            dz = torch.empty_like(dh)
-            ws = torch.empty(int(lib.sg_bias_act_ws_bytes(N, Cout)), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
-                _lib.check(lib.sg_bias_act_backward(N, Cout, ctx.act, _ptr(z), _ptr(ro) if ctx.has_ro else None, _ptr(dh),
-                                                    _ptr(ws), _ptr(dz), None, _stream(dev)), "bias/act backward")
-        else:
-            dz = dh
-        dx = torch.mm(dz, W) if ctx.needs_input_grad[0] else None
-        dW = db = None
-        if ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2]):
-            # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
-            dW = torch.empty_like(W, dtype=torch.float32)
-            db = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b else None
-            ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
-            with torch.cuda.device(dev):
+        act = ctx.act
+        need_dx = ctx.needs_input_grad[0]
+        need_dw = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
+        dz = torch.empty_like(dh) if act != ACT_NONE else dh
+        dx = None
+        with torch.cuda.device(dev):
+            if need_dx:
+                dx = torch.empty((N, Cin), dtype=torch.float32, device=dev)
+                _lib.check(lib.sg_linear_backward(N, Cin, Cout, act, _ptr(aux) if act != ACT_NONE else None, None, _ptr(dh), _ptr(W),
+                                                  _ptr(dz) if act != ACT_NONE else None, _ptr(dx), _stream(dev)), "linear backward")
+            elif act == ACT_GELU:                                   # first layer of a decoder: only dz = dh * gelu'(z) is needed
+                torch.mul(dh, aux, out=dz)
+            elif act == ACT_SIGMOID:
+                torch.mul(dh, aux * (1.0 - aux), out=dz)
+            elif act == ACT_SOFTPLUS_REF:
+                torch.mul(dh, torch.sigmoid(aux), out=dz)
+            dW = db = None
+            if need_dw:
+                # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
+                dW = torch.empty_like(W, dtype=torch.float32)
+                db = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b else None
+                ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
                 _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
                            "weight gradient")
         return dx, dW, db, None, None

@@ -123,29 +123,26 @@ class FrameParallel:
 
 
 class GradientPipeline:
-    """Gradient rows of the K views of one step -> ONE summed (and, with W > 1 ranks, all-reduced) buffer, off the
-    critical path of the rendering streams ("overlapped with the tail of backward-preprocess").
+    """Gradient rows of the K views of one step -> ONE summed (and, with W > 1 ranks, all-reduced) buffer
+    (SURVEY.md 8(e)).  Runs on the CALLER's stream, after the views have been joined into it:
 
-    The views of a step finish one after another (sings_amd.engine.ViewBatch deals them to a few HIP streams).  As soon as
-    view v's backward has been queued, ``view_done(v)`` records an event on ITS stream; a dedicated communication stream
-    waits for those events and folds the rows into ``acc`` in a FIXED order (so the sum is bit-identical however the views
-    were interleaved, and identical to ``one_shot``):
+        for every chunk c:   acc[c] = rows[0][c] + ... + rows[K-1][c]      (one pass over the chunk, fixed order)
+                             all-reduce(acc[c]) queued asynchronously      (RCCL's own stream, behind this fold)
+        wait for the collectives
 
-        acc  = rows[0] + ... + rows[h-1]     one pass, as soon as the first h = K - tail views are done (hidden under the
-                                             `tail` views that are still rendering: one view per rendering stream)
-        acc += rows[v]   for v = h .. K-2    as each of them finishes (hidden under the views after it)
-        acc += rows[K-1]                     chunk by chunk; every chunk goes into its collective the moment it is
-                                             complete, so the fold of chunk c+1 runs under the transfer of chunk c
+    so the fold of chunk c+1 runs under the transfer of chunk c, and with one rank this is the plain one-pass sum.
+    What no schedule can hide is one full-size all-reduce after the last view: every gradient element depends on the last
+    backward kernel of the last view, and the optimiser needs the reduced sum before the next forward.
 
-    (Folding EVERY view on arrival was measured first: 2 917 instead of 3 117 views/s at cfg3 on one GPU -- eight
-    141-MB read-modify-write passes per step take more HBM time from the latency-bound binning kernels than the single
-    423-MB pass they replace.)  What cannot be hidden is one full-size all-reduce after the last view: every gradient
-    element depends on the last backward kernel of the last view, and the optimiser needs the reduced sum before the next
-    forward (exposure is reported by ``exposed_ms()``: bench.py prints it next to the stand-alone all-reduce time).
+    Two schedules that fold rows EARLIER, on a dedicated communication stream fed by per-view events, were built and
+    measured on the MI355X and are not in the tree: folding every view on arrival 2 917 views/s, folding all but the views
+    still in flight 3 060, against 3 278 for this one (cfg3, 8 views, 3 streams, one GPU); the avatar step lost 27 %.
+    Two causes: the extra 141-MB read-modify-write passes compete with the latency-bound binning kernels of the views
+    still rendering, and -- larger -- a FIFTH stream next to the caller's and the three rendering streams: HIP multiplexes
+    streams onto four hardware queues, so the communication stream shares a queue with a rendering stream and its
+    event waits stall that stream's kernels.  Works on CPU tensors too (gloo tests)."""
 
-    Works on CPU tensors too (no streams; used by the gloo tests)."""
-
-    def __init__(self, rows, frame_parallel=None, chunks=4, tail=1):
+    def __init__(self, rows, frame_parallel=None, chunks=4):
         if rows.dim() != 2:
             raise ValueError("rows must be [views, floats_per_view]")
         self.rows, self.fp = rows, frame_parallel
@@ -153,96 +150,42 @@ class GradientPipeline:
         self.cuda = rows.is_cuda
         # one view per step: the row IS the sum (no fold, no copy)
         self.acc = rows[0] if self.k == 1 else torch.empty(self.n, dtype=rows.dtype, device=rows.device)
-        self.head = max(1, self.k - max(1, int(tail))) if self.k > 1 else 1      # views folded in the first pass
         world = 1 if frame_parallel is None else frame_parallel.world
         c = max(1, int(chunks)) if world > 1 else 1
         step = -(-self.n // c)
         step = -(-step // (world * 64)) * (world * 64)           # chunk boundaries the rs_ag schedule divides, 256-B aligned
         self.bounds = [(lo, min(lo + step, self.n)) for lo in range(0, self.n, step)]
         if self.cuda:
-            self.comm = torch.cuda.Stream(rows.device)
-            self._ev = [torch.cuda.Event() for _ in range(self.k)]
-            self._t = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        self._next = 0
-        self._works = []
+            self._t = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self._timed = False
 
-    # -- per step -----------------------------------------------------------------------------------------------------
-    def begin(self):
-        """Call on the stream the step was forked from, before the first view is launched."""
-        self._next = 0
-        if self.cuda:
-            self.comm.wait_stream(torch.cuda.current_stream(self.rows.device))
-
-    def view_done(self, v):
-        """Call on the stream view v ran on, right after its backward was queued; views must be reported in order."""
-        if v != self._next:
-            raise RuntimeError(f"views must be reported in order (expected {self._next}, got {v})")
-        self._next += 1
-        if not self.cuda:
-            self._fold(v)
-            return
-        self._ev[v].record(torch.cuda.current_stream(self.rows.device))
-        if v < self.head - 1:
-            return                                               # folded together with the rest of the head
-        with torch.cuda.stream(self.comm):
-            for u in (range(self.head) if v == self.head - 1 else (v,)):
-                self.comm.wait_event(self._ev[u])
-            if v == self.k - 1 and self._timed:
-                self._t[0].record(self.comm)                     # = the moment the last view's gradients exist
-            self._fold(v)
-
-    def _fold(self, v):
-        last = v == self.k - 1
-        if self.k == 1:
-            pass                                                 # acc is rows[0]
-        elif v < self.head - 1:
-            return
-        elif v == self.head - 1:
-            if self.head == 1:
-                self.acc.copy_(self.rows[0])
-            else:
-                torch.sum(self.rows[:self.head], dim=0, out=self.acc)
-        elif not last:
-            self.acc.add_(self.rows[v])
-        if not last:
-            return
+    def reduce(self):
+        """Call on the stream the views were joined into.  Returns ``acc`` (ready on that stream)."""
+        works = []
+        if self.cuda and self._timed:
+            self._t[0].record(torch.cuda.current_stream(self.rows.device))      # = the last view's gradients exist
         for lo, hi in self.bounds:
             a = self.acc[lo:hi]
-            if self.k > 1 and self.head < self.k:
-                a.add_(self.rows[v][lo:hi])
+            if self.k > 1:
+                torch.sum(self.rows[:, lo:hi], dim=0, out=a)
             if self.fp is not None:
-                if self.cuda:                                    # queued behind this fold; the next fold does not wait for it
-                    self._works += self.fp.all_reduce_grads(a, async_op=True)
+                if self.cuda:
+                    works += self.fp.all_reduce_grads(a, async_op=True)        # the next chunk's fold does not wait for it
                 else:
                     self.fp.all_reduce_grads(a)
-
-    def finish(self):
-        """Join: the caller's current stream waits for the reduced sum.  Returns ``acc``."""
-        if self._next != self.k:
-            raise RuntimeError(f"only {self._next} of {self.k} views were reported")
-        if self.cuda:
-            with torch.cuda.stream(self.comm):
-                if self.fp is not None:
-                    self.fp.wait(self._works, None)
-                    if self.fp.average and self.fp.world > 1:
-                        self.acc.div_(self.fp.world)
-                self._works = []
-                if self._timed:
-                    self._t[1].record(self.comm)
-            torch.cuda.current_stream(self.rows.device).wait_stream(self.comm)
+        if self.fp is not None and self.cuda:
+            self.fp.wait(works, None)
+            if self.fp.average and self.fp.world > 1:
+                self.acc.div_(self.fp.world)
+        if self.cuda and self._timed:
+            self._t[1].record(torch.cuda.current_stream(self.rows.device))
         return self.acc
 
     def one_shot(self):
-        """Reference schedule: the same folds in the same order after ALL views are done, then ONE collective over the whole
-        buffer (what the pipelined schedule must reproduce bit for bit; the pre-round-2 behaviour of bench.py)."""
+        """Reference schedule: fold everything, then ONE collective over the whole buffer (what ``reduce`` must reproduce
+        bit for bit; the pre-round-2 behaviour of bench.py)."""
         if self.k > 1:
-            if self.head == 1:
-                self.acc.copy_(self.rows[0])
-            else:
-                torch.sum(self.rows[:self.head], dim=0, out=self.acc)
-            for v in range(self.head, self.k):
-                self.acc.add_(self.rows[v])
+            torch.sum(self.rows, dim=0, out=self.acc)
         if self.fp is not None:
             self.fp.all_reduce_grads(self.acc)
         return self.acc
@@ -253,5 +196,5 @@ class GradientPipeline:
 
     def exposed_ms(self):
         """After a synchronised step run with timing enabled: time from "last view's gradients exist" to "reduced sum
-        ready" on the communication stream = the part of the reduction nothing can hide."""
+        ready" = the part of the reduction nothing can hide."""
         return self._t[0].elapsed_time(self._t[1])

@@ -193,9 +193,10 @@ class ViewBatch:
     library keeps no state between calls, and every engine owns its workspaces -- so the views are dealt round-robin to
     ``streams`` streams and fill each other's holes (one MI355X: +24 % views/s at cfg3, +77 % frames/s for the avatar),
     bit-identical to running them one after the other.  ``run`` forks from the caller's current stream, launches
-    ``fn(v, engine)`` for every view on its stream and joins; the per-view gradient rows are folded into ``acc`` in view
-    order on a communication stream as the views finish and -- given a ``FrameParallel`` -- all-reduced over the ranks
-    there (sings_amd.dp.GradientPipeline); nothing synchronises with the host.
+    ``fn(v, engine)`` for every view on its stream and joins; the per-view gradient rows are then folded into ``acc`` in a
+    fixed order and -- given a ``FrameParallel`` -- all-reduced over the ranks, chunk by chunk, the fold of one chunk under
+    the transfer of the one before (sings_amd.dp.GradientPipeline); nothing synchronises with the host.  (No further
+    stream: the caller's + three rendering streams are the four hardware queues HIP schedules onto.)
 
         grads = ViewBatch.gradient_rows(views, per_view_floats, device)
         engines = [RasterEngine(..., grad_flat=grads[v]) for v in range(views)]        # or SkinnedEngine
@@ -215,31 +216,26 @@ class ViewBatch:
         self.dev = grads.device
         self.n = max(1, min(int(streams), len(self.engines)))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
-        # the rows are folded into `acc` (and, with several ranks, all-reduced) on a communication stream while later
-        # views still render: sings_amd.dp.GradientPipeline
-        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks, tail=self.n)
+        # the rows are folded into `acc` (and, with several ranks, all-reduced chunk by chunk) on the caller's stream once
+        # the views have joined it: sings_amd.dp.GradientPipeline
+        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
         self.acc = self.pipe.acc
 
     def run_unreduced(self, fn):
         """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``."""
+        if not self.streams:
+            for v, e in enumerate(self.engines):
+                fn(v, e)
+            return
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             st.wait_stream(cur)
         for v, e in enumerate(self.engines):
-            with torch.cuda.stream(self.streams[v % self.n] if self.streams else cur):
+            with torch.cuda.stream(self.streams[v % self.n]):
                 fn(v, e)
         for st in self.streams:
             cur.wait_stream(st)
 
     def run(self, fn):
-        cur = torch.cuda.current_stream(self.dev)
-        self.pipe.begin()
-        for st in self.streams:
-            st.wait_stream(cur)
-        for v, e in enumerate(self.engines):
-            with torch.cuda.stream(self.streams[v % self.n] if self.streams else cur):
-                fn(v, e)
-                self.pipe.view_done(v)
-        for st in self.streams:
-            cur.wait_stream(st)
-        return self.pipe.finish()
+        self.run_unreduced(fn)
+        return self.pipe.reduce()

@@ -53,7 +53,6 @@ _mode = {"mode": "async", "on_overflow": "warn"}
 _seen = {}                             # device index -> set of (P, W, H) signatures already checked synchronously
 _pending = {}                          # device index -> list of [pinned (R, flag), event, cap] of async forwards
 _accum = {}                            # device index -> int32[2] device tensor: max R, OR of flags (deferred mode)
-_accum_cap = {}                        # device index -> smallest capacity used since the last poll
 _HEADROOM = 2.0
 _ring = {}                             # device index -> [pinned int32[_RING, 2], next slot]
 _RING = 16
@@ -124,7 +123,6 @@ def _after_forward(dev, binning, cap):
         if acc is None:
             acc = _accum[dev.index] = torch.zeros(2, dtype=torch.int32, device=dev)
         torch.maximum(acc, hdr, out=acc)               # R < 2^31; one tiny launch, capturable into a HIP graph
-        _accum_cap[dev.index] = min(_accum_cap.get(dev.index, cap), cap)
         return
     ring = _ring.get(dev.index)
     if ring is None:
@@ -159,7 +157,7 @@ def _forward_done_sync(dev, R, sig):
 
 def reset_overflow_state(device=None):
     """Forget capacities, checked signatures and pending results (tests; after a change of scene scale)."""
-    for d in (_capacity_hint, _seen, _pending, _accum, _accum_cap):
+    for d in (_capacity_hint, _seen, _pending, _accum):
         if device is None:
             d.clear()
         else:
@@ -181,14 +179,13 @@ def check_deferred_overflow(device=None):
     acc = _accum.get(dev.index)
     if acc is None:
         return None
-    R, flag = (int(v) for v in acc.cpu())
-    cap = _accum_cap.get(dev.index)                    # (not reset: a captured step replays with the capacity it was captured with)
-    acc.zero_()
-    if cap is None or (R == 0 and flag == 0):
+    R, flag = (int(v) for v in acc.cpu())              # largest R, OR of the overflow flags (each set on the device against
+    acc.zero_()                                        # the capacity THAT forward ran with) since the last poll
+    if R == 0 and flag == 0:
         return None
     _grow(dev.index, R)
-    if flag or R > cap:
-        raise RuntimeError(f"sings_amd: a deferred forward produced {R} (tile, Gaussian) pairs for a capacity of {cap}: "
+    if flag:
+        raise RuntimeError(f"sings_amd: a deferred forward produced up to {R} (tile, Gaussian) pairs, more than its capacity: "
                            f"it rendered the background and no gradients; the capacity is now {_capacity_hint[dev.index]}")
     return R
 

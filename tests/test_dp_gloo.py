@@ -100,20 +100,17 @@ def _pipeline_worker(rank, world, port, algorithm, out):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         res = []
-        for k, n, chunks, tail in ((1, 1003, 4, 1), (5, 1003, 4, 1), (8, 4099, 3, 3), (3, 130, 7, 3), (2, 77, 2, 1), (6, 513, 1, 2)):
+        for k, n, chunks in ((1, 1003, 4), (5, 1003, 4), (8, 4099, 3), (3, 130, 7), (2, 77, 2), (6, 513, 1)):
             g = torch.Generator().manual_seed(100 * rank + k)
             rows = torch.randn((k, n), generator=g) * torch.logspace(-3, 3, n)        # fp32 sums that depend on the order
             fp = FrameParallel(algorithm=algorithm)
-            ref = GradientPipeline(rows.clone(), fp, chunks=chunks, tail=tail).one_shot().clone()
+            ref = GradientPipeline(rows.clone(), fp, chunks=chunks).one_shot().clone()
             live = rows.clone()
-            pipe = GradientPipeline(live, fp, chunks=chunks, tail=tail)
+            pipe = GradientPipeline(live, fp, chunks=chunks)
             for _ in range(2):                                                        # two steps through the same object
                 live.copy_(rows)                                                      # (every backward rewrites its row)
-                pipe.begin()
-                for v in range(k):
-                    pipe.view_done(v)
-                got = pipe.finish().clone()
-            res.append((k, n, ref.numpy(), got.numpy(), rows.numpy(), pipe.head))
+                got = pipe.reduce().clone()
+            res.append((k, n, ref.numpy(), got.numpy(), rows.numpy(), len(pipe.bounds)))
         out.put((rank, res))
     finally:
         dist.destroy_process_group()
@@ -132,17 +129,14 @@ def _run_pipeline(algorithm):
         p.join(60)
         assert p.exitcode == 0
     for case in range(len(res[0])):
-        k, n, ref0, got0, rows0, head = res[0][case]
+        k, n, ref0, got0, rows0, nchunks = res[0][case]
         _, _, ref1, got1, rows1, _ = res[1][case]
-        # the pipelined schedule (fold per view, chunked collectives) == fold everything, then one collective: bit for bit
+        # chunk-wise fold + chunk-wise collectives == fold everything, then one collective: bit for bit
         assert np.array_equal(ref0, got0) and np.array_equal(ref1, got1)
         assert np.array_equal(got0, got1)                                            # both ranks hold the same sum
-        def fold(rows):                                                              # head in one pass, then view by view
-            a = torch.sum(torch.from_numpy(rows[:head]), dim=0).numpy() if head > 1 else rows[0].copy()
-            for v in range(head, k):
-                a = a + rows[v]
-            return a
+        fold = lambda rows: torch.sum(torch.from_numpy(rows), dim=0).numpy() if k > 1 else rows[0]
         assert np.array_equal(got0, fold(rows0) + fold(rows1))                       # inside a rank, then the ranks
+        assert nchunks >= 1
 
 
 def test_pipelined_reduction_matches_one_shot_all_reduce():
@@ -151,14 +145,3 @@ def test_pipelined_reduction_matches_one_shot_all_reduce():
 
 def test_pipelined_reduction_matches_one_shot_rs_ag():
     _run_pipeline("rs_ag")
-
-
-def test_pipeline_rejects_out_of_order_and_missing_views():
-    import pytest
-    pipe = GradientPipeline(torch.zeros((3, 10)))
-    pipe.begin()
-    pipe.view_done(0)
-    with pytest.raises(RuntimeError):
-        pipe.view_done(2)
-    with pytest.raises(RuntimeError):
-        pipe.finish()

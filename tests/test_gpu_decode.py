@@ -202,3 +202,38 @@ def test_triplane_plane_configurations(res, multires):
     for gp, gc in zip(f.grids, grids_c):
         for p, q in zip(gp, gc):
             _close(p.grad.cpu().numpy(), q.grad.numpy(), rtol=1e-4, atol_scale=2e-5)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,act", [(1000, 96, 128, 1), (4097, 128, 128, 1), (333, 128, 3, 0), (2050, 128, 6, 0),
+                                            (777, 128, 1, 0), (5000, 96, 64, 1), (1234, 64, 64, 1), (999, 64, 48, 0),
+                                            (640, 64, 1, 2), (31, 128, 128, 3), (50000, 128, 128, 1)])
+def test_fused_linear_layer_kernels_vs_torch(N, Cin, Cout, act):
+    """sg_linear_forward / sg_linear_backward (one MFMA kernel per layer and direction, bias + activation fused) against the
+    same layer in torch fp64 on the CPU: h, the saved pre-activation, dx, dW, db."""
+    from sings_amd.decode import linear_act
+    dev = _dev()
+    g = torch.Generator().manual_seed(N + Cin + Cout + act)
+    lin = torch.nn.Linear(Cin, Cout)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(Cout, Cin, generator=g) / Cin ** 0.5); lin.bias.copy_(torch.randn(Cout, generator=g))
+    x = torch.randn(N, Cin, generator=g)
+    ro = torch.randn(N, 1, generator=g) if act == 2 else None
+    up = torch.randn(N, Cout, generator=g)
+    # reference in fp64
+    l64 = torch.nn.Linear(Cin, Cout).double()
+    l64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    x64 = x.double().requires_grad_(True)
+    z = l64(x64)
+    if act == 1: h64 = torch.nn.functional.gelu(z)
+    elif act == 2: h64 = torch.sigmoid(z + ro.double())
+    elif act == 3: h64 = torch.log(torch.exp(z) + 1)
+    else: h64 = z
+    (h64 * up.double()).sum().backward()
+    lin = lin.to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    h = linear_act(xd, lin, act, None if ro is None else ro.to(dev))
+    (h * up.to(dev)).sum().backward()
+    _close(h.detach().cpu().numpy(), h64.detach().numpy(), rtol=2e-5, atol_scale=2e-6, what="h")
+    _close(xd.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="dx")
+    _close(lin.weight.grad.cpu().numpy(), l64.weight.grad.numpy(), rtol=3e-5, atol_scale=3e-6, what="dW")
+    _close(lin.bias.grad.cpu().numpy(), l64.bias.grad.numpy(), rtol=3e-5, atol_scale=3e-6, what="db")

@@ -105,3 +105,65 @@ def test_full_size_properties_150k():
     d = knn_mean_edge((2.0 * x).contiguous())
     assert torch.allclose(d, 2.0 * a, rtol=1e-6, atol=0)
     assert float(a.min()) >= 0 and torch.isfinite(a).all()
+
+
+def test_cfg5_regularisers_value_and_gradient_at_500k_points():
+    """BASELINE configs[4]: the geometry-preserving regulariser backward at 500 k Gaussians (the cfg5 scene's own points and
+    scales).  The whole cloud cannot be checked by brute force, so: (i) exactness of the k-NN on a 20 k SUBSAMPLE of the
+    same cloud against fp64 brute force; (ii) at full size, determinism, permutation invariance and exact power-of-two
+    scaling of the neighbour distances; (iii) GaussiansEdgeLoss + L2Norm value and gradient at 500 k against the closed
+    form of loss_items.py:57-90,  loss = mean((s_0 - d)^2),  dL/ds_0 = 2 (s_0 - d) / N  (first scale component only),
+    evaluated in fp64 from the kernel's own (verified) neighbour distances, and against the oracle's autograd on the
+    subsample."""
+    from oracle import reg_oracle as ro
+    from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm, knn_mean_edge
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    s = synthetic_scene(500000, 2048, 2048, 3, 5)
+    xyz_n, sc_n, op_n = s["means3D"], s["scales"], s["opacities"]
+    x = torch.from_numpy(xyz_n).to(dev)
+    # (i) subsample: exact against brute force
+    sub = np.random.RandomState(0).choice(500000, 20000, replace=False)
+    xs = torch.from_numpy(xyz_n[sub])
+    d = torch.cdist(xs.double(), xs.double())
+    ref = torch.topk(d, 9, dim=1, largest=False).values[:, 1:].mean(1).numpy()
+    got = knn_mean_edge(xs.to(dev)).cpu().numpy()
+    np.testing.assert_allclose(got, ref, rtol=3e-6, atol=1e-9)
+    # (ii) full size: invariances
+    a = knn_mean_edge(x)
+    assert torch.equal(a, knn_mean_edge(x)) and torch.isfinite(a).all() and float(a.min()) >= 0
+    perm = torch.randperm(500000, generator=torch.Generator().manual_seed(1)).to(dev)
+    assert torch.allclose(knn_mean_edge(x[perm].contiguous()), a[perm], rtol=1e-6, atol=0)
+    assert torch.allclose(knn_mean_edge((0.5 * x).contiguous()), 0.5 * a, rtol=1e-6, atol=0)
+    # (iii) value + gradient at full size
+    sc = torch.from_numpy(sc_n).to(dev).requires_grad_(True)
+    off = (0.002 * torch.randn(500000, 3, generator=torch.Generator().manual_seed(2))).to(dev).requires_grad_(True)
+    op = torch.from_numpy(op_n).to(dev).requires_grad_(True)
+    edge = GaussiansEdgeLoss()({'xyz_canon': x, 'scales': sc})
+    l2 = L2Norm()({'xyz_offsets': off, 'scales': sc, 'opacity': op})
+    (edge + l2).backward()
+    g_total = sc.grad.clone()
+    sc2 = torch.from_numpy(sc_n).to(dev).requires_grad_(True)
+    GaussiansEdgeLoss()({'xyz_canon': x, 'scales': sc2}).backward()
+    d64 = a.double().cpu(); s64 = torch.from_numpy(sc_n).double()
+    s0 = s64[:, 0]
+    loss_ref = ((s0 - d64) ** 2).mean()
+    assert abs(edge.item() - loss_ref.item()) <= 3e-6 * abs(loss_ref.item())
+    g_ref = np.zeros((500000, 3)); g_ref[:, 0] = (2.0 * (s0 - d64) / 500000.0).numpy()
+    _close(sc2.grad.cpu().numpy(), g_ref)
+    # L2Norm: pure torch in the reference -> the oracle restatement (pinned by reg_golden.npz) on the CPU, full size
+    # (in fp64: a fp32 norm over 1.5e6 numbers carries ~1e-5 of rounding itself)
+    ins = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in (("xyz_offsets", off), ("scales", sc), ("opacity", op))}
+    l2_ref = ro.l2norm(ins)
+    l2_ref.backward()
+    assert abs(l2.item() - l2_ref.item()) <= 3e-6 * abs(l2_ref.item())
+    _close(off.grad.cpu().numpy(), ins["xyz_offsets"].grad.numpy())
+    _close(op.grad.cpu().numpy(), ins["opacity"].grad.numpy())
+    _close((g_total - sc2.grad).cpu().numpy(), ins["scales"].grad.numpy())
+    # subsample: the oracle's own autograd (k-NN restated from its published definition) for value and gradient
+    scs = torch.from_numpy(sc_n[sub]).requires_grad_(True)
+    lo, _ = ro.gaussians_edge_loss({'xyz_canon': xs, 'scales': scs}); lo.backward()
+    scd = torch.from_numpy(sc_n[sub]).to(dev).requires_grad_(True)
+    ld = GaussiansEdgeLoss()({'xyz_canon': xs.to(dev), 'scales': scd}); ld.backward()
+    assert abs(ld.item() - lo.item()) <= 3e-6 * abs(lo.item())
+    _close(scd.grad.cpu().numpy(), scs.grad.numpy())

@@ -14,7 +14,8 @@ views, cur = [], []
 for st, en, name in rows:
     if not name.startswith("sg_"):
         continue
-    if name.startswith("sg_zero_kernel") and cur:
+    if name.startswith(("sg_zero_kernel", "sg_preprocess_fwd_kernel", "sg_skin_fwd_kernel")) and cur and \
+            not (name.startswith(("sg_preprocess_fwd_kernel", "sg_skin_fwd_kernel")) and cur[-1][2].startswith("sg_zero_kernel")):
         views.append(cur); cur = []
     cur.append((st, en, name))
 if cur:
