@@ -1,13 +1,11 @@
 #!/bin/bash
-# On the GPU box: batched-mode sweep of the cfg3 bench (views per step x streams x reduction schedule).
-out=gpurun_out/${1:-batch}; mkdir -p $out
+# On the GPU box: batched-mode sweep of the cfg3 bench (views per step x streams).
 run() { python bench.py --no-cpu-baseline --steps 100 "$@" 2>/dev/null | python -c "import json,sys; j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%-44s %8.1f views/s  %.4f ms/view  one-view %.4f' % ('$*', j['value'], j['ms_per_view'], j['train_step_ms_one_view']))"; }
 run
-run --one-shot-reduce
 run --streams 2
 run --streams 4
-run --streams 2 --one-shot-reduce
-run --views-per-step 6 --streams 3
 run --views-per-step 12 --streams 3
+run --views-per-step 12 --streams 4
+run --views-per-step 16 --streams 4
 run --views-per-step 4 --streams 2
-run
+run --one-shot-reduce
