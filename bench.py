@@ -292,7 +292,7 @@ def main_raster(a):
     fp = None
     if dist is not None:
         from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
 
     n_streams = max(1, min(a.streams, k_views))
     per_view = N * (3 + 3 + 4 + 1 + 3 * shs.shape[1])
@@ -694,7 +694,7 @@ def main_train(a):
     fp = None
     if dist is not None:
         from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
         sizes = [p.numel() for p in params]
         flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
 
@@ -805,7 +805,7 @@ def main_avatar(a):
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
     eng = engs[0]
     shard = FrameSharder(F, world, rank, seed=0)
-    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "rs_ag"), host_staged=dist.get_backend() != "nccl")
+    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
           if dist is not None else None)
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
