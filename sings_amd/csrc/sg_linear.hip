@@ -13,8 +13,9 @@
 // of M -- CK/2 registers per lane, already in MFMA A-operand layout -- for the whole kernel; only the points stream.
 // A tile of 32 PT points x CK inputs goes through LDS once (coalesced 16-B loads, shared by the four waves) and is read back
 // as the B operand with one ds_read_b128 per four MFMAs: the reduction index is PERMUTED (MFMA step s multiplies inputs s
-// and CK/2 + s), so the four values a lane needs next are adjacent.  The 32 x 32 result tiles return through LDS so
-// that z / h / dx leave as whole 16-B-per-lane rows.  Loads of the next tile are in flight during the MFMAs.
+// and CK/2 + s), so the four values a lane needs next are adjacent.  The 32 x 32 result tiles leave straight from the
+// accumulator registers: a lane holds four consecutive output columns of one point four times -> 16-B stores.  Loads of the
+// next tile are in flight during the MFMAs; the waves of a workgroup meet only at the X' tile.
 #include "sg_common.h"
 
 typedef float sg_v16f __attribute__((ext_vector_type(16)));
@@ -24,6 +25,20 @@ __device__ __forceinline__ float sgl_gelu_grad(float z)
 {
     const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
     return cdf + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+// GELU and its derivative from ONE evaluation of erf: h = z Phi(z), h' = Phi(z) + z phi(z), Phi = (1 + erf(z / sqrt 2)) / 2.
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. fp32 round-off of Phi): 1 - (a1 t + ... + a5 t^5) e^(-x^2),
+// t = 1 / (1 + p |x|); the e^(-x^2) = e^(-z^2 / 2) it needs is the one phi(z) needs.
+__device__ __forceinline__ void sgl_gelu_both(float z, float &h, float &dh)
+{
+    const float x = fabsf(z) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, x, 1.0f));
+    const float e = __expf(-x * x);
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float erfa = fmaf(-poly, e, 1.0f);                               // erf(|x|)
+    const float cdf = 0.5f * (1.0f + copysignf(erfa, z));
+    h = z * cdf;
+    dh = fmaf(z * 0.39894228040143267794f, e, cdf);
 }
 // act: 0 identity, 1 GELU (erf), 2 sigmoid(z + row_offset), 3 log(exp(z) + 1)   (same codes as sg_bias_act_*)
 __device__ __forceinline__ float sgl_act(int act, float z, float ro)
@@ -48,13 +63,13 @@ __device__ __forceinline__ float sgl_act_grad_aux(int act, float aux)
 __host__ __device__ inline int sgl_point_tiles(int TO, int CKP)
 {
     int pt = 4 / TO;
-    while (pt > 1 && (32 * pt * (CKP + 4) > SGL_TILE || 32 * pt * (32 * TO + 1) > SGL_TILE)) pt >>= 1;
+    while (pt > 1 && 32 * pt * (CKP + 4) > SGL_TILE) pt >>= 1;
     return pt;
 }
 
 // NQ = CKP / 8 (CKP = CK rounded up to a multiple of 8): float4 reads per lane and tile; BWD: the backward instantiation
 template <int NQ, bool BWD>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)          // <= 168 VGPRs: three waves per SIMD (the 64 weight registers are the bulk)
 sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
                  const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
                  const float *__restrict__ row_offset, float *__restrict__ out0, float *__restrict__ out1)
@@ -68,7 +83,7 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
     const int cb = wave % TO, pt = wave / TO;                              // this wave: column block, point tile
     const bool active = pt < PT;
     const int R = 32 * PT;                                                 // points per round
-    const int XS = CKP + 4, YS = 32 * TO + 1;
+    const int XS = CKP + 4;
     const int j = lane & 31, h = lane >> 5;
     // ---- this wave's 32 columns of M as MFMA A operands: a[s] = M(32 cb + j, h HALF + s)
     float a[HALF];
@@ -79,6 +94,13 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
             const int k = h * HALF + s;
             a[s] = (active && co < CO && k < CK) ? Mw[(size_t)co * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
         }
+    }
+    // the 16 bias values of this lane's output columns (forward)
+    float bv[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int c = 32 * cb + 8 * (r >> 2) + 4 * h + (r & 3);
+        bv[r] = (!BWD && bias && active && c < CO) ? bias[c] : 0.0f;
     }
     const int f4_per_row = CKP / 4;
     const int nf4 = R * f4_per_row;                                        // float4 elements of one X' tile
@@ -160,56 +182,52 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[4 * q + 3], b.w, acc, 0, 0, 0);
             }
         }
-        __syncthreads();                                                   // every wave has read its B operands: the buffer is free
-        float *sDyn = sX[buf];
+        // The next tile goes into the other LDS buffer NOW (last read one iteration ago, a barrier since): this wait covers the
+        // prefetch loads only -- the stores below are issued after it and complete under the next tile's MFMAs (s_waitcnt vmcnt
+        // counts loads and stores together: with the stores first, every tile waited for its own HBM write-backs: 40 % of the
+        // wave cycles were parked there, SQ_WAIT_ANY).
+        if (next < ntiles) stash(buf ^ 1, next * R);
+        // ---- epilogue straight from the accumulator: lane l holds, for g = 0..3, the four CONSECUTIVE output columns
+        //      32 cb + 8 g + 4 (l / 32) + {0..3} of point 32 pt + l % 32 -> one 16-B store per g and output array.  The eight
+        //      16-B pieces of a 128-B line come from the same wave within a few instructions (L2 merges them); no LDS round
+        //      trip, no barrier: the waves of a workgroup only meet at the X' tile.
         if (active) {
-            // D: lane l, register r -> output column 32 cb + 8 (r / 4) + 4 (l / 32) + r % 4, point 32 pt + l % 32
+            const int n = n0 + 32 * pt + j;
+            if (n < N) {
+                const float ro = (!BWD && act == 2 && row_offset) ? row_offset[n] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; r++)
-                sDyn[(32 * pt + j) * YS + 32 * cb + 8 * (r >> 2) + 4 * h + (r & 3)] = acc[r];
-        }
-        __syncthreads();
-        // ---- epilogue: whole rows of the Y tile leave with 16-B stores (scalar tail when CO is not a multiple of 4)
-        {
-            const int cq = (CO + 3) / 4, total = R * cq;
-            for (int f = tid; f < total; f += 256) {
-                const int row = f / cq, c = 4 * (f - row * cq), n = n0 + row;
-                if (n >= N) continue;
-                float y[4];
+                for (int g = 0; g < 4; g++) {
+                    const int c = 32 * cb + 8 * g + 4 * h;
+                    if (c >= CO) continue;
+                    float y[4] = { acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3] };
+                    if (!BWD) {
+                        float hh[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) y[u] = c + u < CO ? sDyn[row * YS + c + u] : 0.0f;
-                if (!BWD) {
-                    const float ro = (act == 2 && row_offset) ? row_offset[n] : 0.0f;
-                    float hh[4];
+                        for (int u = 0; u < 4; u++) {
+                            y[u] += bv[4 * g + u];
+                            if (act == 1) sgl_gelu_both(y[u], hh[u], y[u]);           // h and aux = gelu'(z) share one erf
+                            else hh[u] = sgl_act(act, y[u], ro);
+                        }
+                        if ((CO & 3) == 0) {
+                            if (out1) *(float4 *)(out1 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);    // aux
+                            *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(hh[0], hh[1], hh[2], hh[3]);           // h
+                        } else {
 #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (bias && c + u < CO) y[u] += bias[c + u];
-                        if (act == 1) {                                    // h and gelu'(z) share the erf
-                            const float zz = y[u], cdf = 0.5f * (1.0f + erff(zz * 0.70710678118654752440f));
-                            hh[u] = zz * cdf;
-                            y[u] = cdf + zz * 0.39894228040143267794f * __expf(-0.5f * zz * zz);      // aux = gelu'(z)
-                        } else hh[u] = sgl_act(act, y[u], ro);
-                    }
-                    if ((CO & 3) == 0) {
-                        if (out1) *(float4 *)(out1 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);        // z
-                        *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(hh[0], hh[1], hh[2], hh[3]);               // h
+                            for (int u = 0; u < 4; u++)
+                                if (c + u < CO) { if (out1) out1[(size_t)n * CO + c + u] = y[u]; out0[(size_t)n * CO + c + u] = hh[u]; }
+                        }
                     } else {
+                        if ((CO & 3) == 0) *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);  // dx
+                        else {
 #pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (c + u < CO) { if (out1) out1[(size_t)n * CO + c + u] = y[u]; out0[(size_t)n * CO + c + u] = hh[u]; }
-                    }
-                } else {
-                    if ((CO & 3) == 0) *(float4 *)(out0 + (size_t)n * CO + c) = make_float4(y[0], y[1], y[2], y[3]);  // dx
-                    else {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) if (c + u < CO) out0[(size_t)n * CO + c + u] = y[u];
+                            for (int u = 0; u < 4; u++) if (c + u < CO) out0[(size_t)n * CO + c + u] = y[u];
+                        }
                     }
                 }
             }
         }
-        if (next < ntiles) stash(buf ^ 1, next * R);
-        __syncthreads();
-    }
+        __syncthreads();                                                   // every wave has read its B operands of this tile;
+    }                                                                      // the next tile's are in place
 }
 
 template <bool BWD>
