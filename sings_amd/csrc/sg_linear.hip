@@ -17,6 +17,7 @@
 // accumulator registers: a lane holds four consecutive output columns of one point four times -> 16-B stores.  Loads of the
 // next tile are in flight during the MFMAs; the waves of a workgroup meet only at the X' tile.
 #include "sg_common.h"
+#include <type_traits>
 
 typedef float sg_v16f __attribute__((ext_vector_type(16)));
 
@@ -164,6 +165,7 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
     int tile = blockIdx.x;
     if (tile < ntiles) { fetch(tile * R); stash(0, tile * R); }
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0): the weights have landed (see the wide kernel)
     int buf = 0;
     for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
         const int n0 = tile * R, next = tile + gridDim.x;
@@ -230,6 +232,186 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
     }                                                                      // the next tile's are in place
 }
 
+
+// ---- wide outputs (CO a multiple of 32: the trunk layers and every input-gradient product) ------------------------------------
+// Same tile loop, two changes that the phase timings asked for (tools/linear_bench.py + SG_EXP variants, 128 -> 128 at 150 k
+// points: MFMAs alone 41-58 us, epilogue + stores alone 43 us, loads + stores alone 55 us, the kernel 107 us = their SUM):
+//  * the points are the A operand and M the B operand, so the accumulator holds output column 32 cb + j of 16 points and register
+//    r leaves as two 128-B row segments per store instruction -- the full-rate store shape of a 32 x 32 accumulator
+//    (MI355X_MICROARCH.md "access shape") instead of 32-B pieces of 32 rows;
+//  * the epilogue of tile t - 1 (bias, GELU and gelu', stores) is issued BETWEEN the MFMAs of tile t: a wave issues in order, and a
+//    dependent MFMA chain leaves ~60 idle issue cycles per instruction that the previous tile's element-wise work fills; the stores
+//    are buffer stores whose range check drops the rows beyond N and a missing aux array (no branches inside the MFMA block).
+template <int NQ> struct sgl_wide_cfg {
+    static constexpr int CKP = NQ * 8, XS = CKP + 4;
+    static constexpr int FIT = 6656 / (32 * XS);                           // 32-point tiles in 26 KiB (x 2 buffers x 3 workgroups per CU)
+    static constexpr int PTCAP = FIT >= 4 ? 4 : (FIT >= 2 ? 2 : 1);
+    static constexpr int PER = (32 * PTCAP * CKP / 4 + 255) / 256;         // float4 per thread and tile
+};
+__host__ __device__ inline int sgl_wide_point_tiles(int TO, int ptcap) { const int pt = 4 / TO; return pt < ptcap ? pt : ptcap; }
+
+template <int NQ, bool BWD, bool GELU>
+__global__ void __launch_bounds__(256, BWD ? 2 : 3)   // backward: x' and aux prefetch registers on top of the 64 weight registers -> 2 per SIMD, no spills
+sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
+                      const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
+                      float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out)
+{
+    using cfg = sgl_wide_cfg<NQ>;
+    constexpr int CKP = cfg::CKP, HALF = CKP / 2, XS = cfg::XS, PER = cfg::PER;
+    extern __shared__ float sXd[];                                         // [2][R][XS]
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int TO = CO >> 5;                                                // 1..4
+    const int PT = sgl_wide_point_tiles(TO, cfg::PTCAP);
+    const int cb = wave % TO, pt = wave / TO;
+    const bool active = pt < PT;
+    const int R = 32 * PT, TS = R * XS;
+    const int j = lane & 31, h = lane >> 5;
+    const int oc = 32 * cb + j;
+    // this wave's 32 columns of M as the B operand: a[s] = M(oc, h HALF + s)
+    float a[HALF];
+#pragma unroll
+    for (int s = 0; s < HALF; s++) {
+        const int k = h * HALF + s;
+        a[s] = (active && k < CK) ? Mw[(size_t)oc * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+    }
+    const float bv = (!BWD && bias && active) ? bias[oc] : 0.0f;
+    // output arrays as buffers: rows >= N (the ragged last tile) and a missing array fall outside num_records and are dropped
+    const unsigned obytes = (unsigned)N * (unsigned)CO * 4u;
+    const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(out0, 0, out0 ? obytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(out1, 0, out1 ? obytes : 0u, 0x00020000);
+    const int CO4 = CO * 4;
+    const int voff0 = ((32 * pt + 4 * h) * CO + oc) * 4;
+
+    const int f4_per_row = CKP / 4;
+    const int nf4 = R * f4_per_row;
+    const bool vec = (CK & 3) == 0;
+    float4 xr[PER], zr[BWD ? PER : 1];
+    auto fetch = [&](int n0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int f = tid + 256 * q;
+            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), zz = v;
+            if (f < nf4) {
+                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
+                if (n < N && c < CK) {
+                    if (vec) {
+                        v = *(const float4 *)(X + (size_t)n * CK + c);
+                        if (BWD && act != 0) zz = *(const float4 *)(Z + (size_t)n * CK + c);
+                    } else {
+                        float e[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, g[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+                        for (int u = 0; u < 4; u++)
+                            if (c + u < CK) {
+                                e[u] = X[(size_t)n * CK + c + u];
+                                if (BWD && act != 0) g[u] = Z[(size_t)n * CK + c + u];
+                            }
+                        v = make_float4(e[0], e[1], e[2], e[3]); zz = make_float4(g[0], g[1], g[2], g[3]);
+                    }
+                }
+            }
+            xr[q] = v;
+            if (BWD) zr[q] = zz;
+        }
+    };
+    auto stash = [&](int buf, int n0) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int f = tid + 256 * q;
+            if (f < nf4) {
+                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
+                float4 v = xr[q];
+                if (BWD && act != 0) {
+                    const float4 zz = zr[q];
+                    v.x *= sgl_act_grad_aux(act, zz.x); v.y *= sgl_act_grad_aux(act, zz.y);
+                    v.z *= sgl_act_grad_aux(act, zz.z); v.w *= sgl_act_grad_aux(act, zz.w);
+                    if (dz_out && n < N && c < CK) {
+                        if (vec) *(float4 *)(dz_out + (size_t)n * CK + c) = v;
+                        else {
+                            const float e[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                            for (int u = 0; u < 4; u++) if (c + u < CK) dz_out[(size_t)n * CK + c + u] = e[u];
+                        }
+                    }
+                }
+                *(float4 *)&sXd[buf * TS + row * XS + c] = v;
+            }
+        }
+    };
+    // one output register of a finished tile: bias + activation (forward), two 128-B row segments per store
+    auto emit = [&](const sg_v16f &ac, int r, int n0p) {
+        const int vo = voff0 + (n0p + 8 * (r >> 2) + (r & 3)) * CO4;
+        if (!BWD) {
+            float y = ac[r] + bv, hh;
+            if (GELU) sgl_gelu_both(y, hh, y);                              // h and aux = gelu'(z) from one erf
+            else hh = sgl_act(act, y, 0.0f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(hh), rs0, vo, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), rs1, vo, 0, 0);
+        } else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ac[r]), rs0, vo, 0, 0);
+    };
+    // the MFMAs of one tile; EPI: with the previous tile's epilogue spread between them
+    auto mma = [&](auto EPI, int buf, const sg_v16f &accp, int n0p) {
+        sg_v16f acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+        const float *xrow = &sXd[buf * TS + (32 * pt + j) * XS + h * HALF];  // A operand: X'[point j][h HALF + s], inputs permuted
+        float4 b = *(const float4 *)xrow;
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+            float4 bn = b;
+            if (q + 1 < NQ) bn = *(const float4 *)(xrow + 4 * (q + 1));
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[4 * q], acc, 0, 0, 0);
+            if (decltype(EPI)::value) {
+#pragma unroll
+                for (int r = (q * 16) / NQ; r < ((q + 1) * 16) / NQ; r++) emit(accp, r, n0p);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.w, a[4 * q + 3], acc, 0, 0, 0);
+            b = bn;
+        }
+        return acc;
+    };
+    const int ntiles = (N + R - 1) / R;
+    int tile = blockIdx.x;                                                 // grid <= ntiles
+    fetch(tile * R); stash(0, tile * R);
+    __syncthreads();
+    // Every load so far (the weights!) has landed: said HERE, unconditionally, or the compiler -- which cannot see that the
+    // conditional waits above covered them -- puts an s_waitcnt vmcnt(0) in front of the first MFMA of EVERY tile, right behind
+    // the prefetch it was meant to overlap.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
+    sg_v16f accp;
+#pragma unroll
+    for (int r = 0; r < 16; r++) accp[r] = 0.0f;
+    int n0p = -1, buf = 0;
+    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
+        const int next = tile + gridDim.x;
+        if (next < ntiles) fetch(next * R);                                // in flight during the MFMAs below
+        if (BWD) {
+            // no element-wise work to hide: dx leaves as soon as the tile's MFMAs are done (the stores are asynchronous)
+            if (active) {
+                const sg_v16f acc = mma(std::false_type{}, buf, accp, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) emit(acc, r, tile * R);
+            }
+            if (next < ntiles) stash(buf ^ 1, next * R);
+            __syncthreads();
+        } else {
+            sg_v16f acc = accp;
+            if (active) {
+                if (n0p >= 0) acc = mma(std::true_type{}, buf, accp, n0p);
+                else acc = mma(std::false_type{}, buf, accp, 0);
+            }
+            if (next < ntiles) stash(buf ^ 1, next * R);                   // the other buffer: last read one iteration ago
+            __syncthreads();
+            accp = acc; n0p = tile * R;
+        }
+    }
+    if (!BWD && active && n0p >= 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) emit(accp, r, n0p);
+    }
+}
+
 template <bool BWD>
 static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, const float *Z, const float *Mw, int s_co, int s_ck,
                             const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st)
@@ -237,6 +419,34 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
     if (N <= 0) return 0;
     if (CK < 1 || CK > SGL_MAXC || CO < 1 || CO > SGL_MAXC) return 1;
     const int nq = (CK + 7) / 8;
+    if ((CO & 31) == 0 && !(act == 2 && row_offset) && ((long long)N + 128) * CO * 4 < 0x7fffffffLL) {
+        // wide outputs: forward h -> out0, aux -> out1; backward dx -> out0, dz -> out1
+#define SGL_WIDE(NQv)                                                                                                      \
+        do {                                                                                                                \
+            using cfg = sgl_wide_cfg<NQv>;                                                                                  \
+            const int R = 32 * sgl_wide_point_tiles(CO >> 5, cfg::PTCAP), ntiles = (N + R - 1) / R;                         \
+            const int gmax = BWD ? 512 : 768;                                                                               \
+            const int grid = ntiles < gmax ? ntiles : gmax;                                                                 \
+            const size_t dyn = (size_t)2 * R * cfg::XS * sizeof(float);                                                     \
+            if (BWD)                                                                                                        \
+                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, true, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                                   Mw, s_co, s_ck, bias, out0, (float *)nullptr, out1);                                     \
+            else if (act == 1)                                                                                              \
+                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, true>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr);                                     \
+            else                                                                                                            \
+                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr);                                     \
+        } while (0)
+        if (nq <= 1) SGL_WIDE(1);
+        else if (nq <= 4) SGL_WIDE(4);
+        else if (nq <= 6) SGL_WIDE(6);
+        else if (nq <= 8) SGL_WIDE(8);
+        else if (nq <= 12) SGL_WIDE(12);
+        else SGL_WIDE(16);
+#undef SGL_WIDE
+        return 0;
+    }
     const int nqt = nq <= 1 ? 1 : (nq <= 4 ? 4 : (nq <= 6 ? 6 : (nq <= 8 ? 8 : (nq <= 12 ? 12 : 16))));
     const int TO = (CO + 31) / 32, PT = sgl_point_tiles(TO, nqt * 8), R = 32 * PT;
     const int ntiles = (N + R - 1) / R;
