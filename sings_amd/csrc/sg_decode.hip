@@ -601,22 +601,25 @@ typedef float sg_v16f __attribute__((ext_vector_type(16)));
 
 // RR = rows of x / dz per round (one barrier per round): 32 for <= 96 input columns, 16 for 128 (64 rows lose again).
 // Nine decoder layers at 150k points: 604 us (16-row rounds, one round of look-ahead, 256-row slices dealt round-robin)
-// -> 550 (round size) -> 484 (two rounds of look-ahead) -> 423 us (one equally long row range per workgroup)
+// -> 550 (round size) -> 484 (two rounds of look-ahead) -> 423 us (one equally long row range per workgroup).
+// Round 2: every load is a BUFFER load on a descriptor of the workgroup's own row range -- rows beyond it read as zero, so the
+// loop has no bounds branches at all and the compiler can count its s_waitcnt vmcnt(n) (with a branch per load it fell back to
+// vmcnt(0) right behind the look-ahead loads, which therefore never overlapped anything).
 template <int TI, int RR>
 __global__ void __launch_bounds__(256)
 sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
-                float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad)
+                float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad, int chunk)
 {
-    // the four waves need the same 16 rows of x per round: they go through LDS once (double-buffered, one barrier per
+    // the four waves need the same RR rows of x per round: they go through LDS once (double-buffered, one barrier per
     // round) instead of being read from L2/HBM by every wave (4x the traffic made the direct version bandwidth-bound)
     __shared__ float sX[2][RR][TI * 32 + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool active = 32 * wave < cout_pad;
     const int o = 32 * wave + (lane & 31), half = lane >> 5;
-    const bool ok_o = active && o < Cout;
     constexpr int CIN = TI * 32;
     constexpr int F4 = RR * CIN / 4;          // float4 elements of one slab
-    constexpr int PER = (F4 + 255) / 256;            // per thread
+    static_assert(F4 % 256 == 0, "a slab is a whole number of float4 per thread");
+    constexpr int PER = F4 / 256;
     sg_v16f acc[TI];
 #pragma unroll
     for (int t = 0; t < TI; t++)
@@ -624,63 +627,70 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
         for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
     float bsum = 0.0f;
     (void)Cin;
-    // every workgroup takes ONE contiguous, equally long range of rows (slices of 256 rows dealt round-robin left 74 of the
-    // 512 workgroups with two slices at 150k rows: the kernel took as long as they did)
-    const int chunk = (((N + (int)gridDim.x - 1) / (int)gridDim.x + 2 * RR - 1) / (2 * RR)) * (2 * RR);
-    {
-        const int r0 = blockIdx.x * chunk, r1 = min(r0 + chunk, N);
-        // two register sets (E, O): while round n computes out of LDS, the operands of round n + 1 sit in one set (stashed
-        // to the other LDS buffer at the end of the round) and the loads of round n + 2 are in flight into the other --
-        // a round's MFMAs (0.85 us) are shorter than a memory round trip, one round of look-ahead left the waves waiting
-        float4 xrE[PER], xrO[PER];
-        float anE[RR / 2], anO[RR / 2];
-        auto fetch = [&](float4 (&xr)[PER], float (&an)[RR / 2], int n) {
+    // every workgroup takes ONE contiguous range of `chunk` rows (the last one may be short)
+    const int r0 = blockIdx.x * chunk, len = min(chunk, N - r0);
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + (size_t)r0 * CIN), 0, len * CIN * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void *)(dz + (size_t)r0 * Cout), 0, len * Cout * 4, 0x00020000);
+    const int zoff = (active && o < Cout) ? (half * Cout + o) * 4 : 0x7ffffff0;   // columns beyond Cout: out of range = 0
+    int xoff[PER];
 #pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
-                xr[q] = (f < F4 && n + row < r1) ? *(const float4 *)(x + (size_t)(n + row) * CIN + 4 * c4) : make_float4(0, 0, 0, 0);
-            }
+    for (int q = 0; q < PER; q++) {
+        const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
+        xoff[q] = (row * CIN + 4 * c4) * 4;
+    }
+    // two register sets (E, O): while round n computes out of LDS, the operands of round n + 1 sit in one set (stashed
+    // to the other LDS buffer at the end of the round) and the loads of round n + 2 are in flight into the other --
+    // a round's MFMAs (0.85 us) are shorter than a memory round trip, one round of look-ahead left the waves waiting
+    float4 xrE[PER], xrO[PER];
+    float anE[RR / 2], anO[RR / 2];
+    auto fetch = [&](float4 (&xr)[PER], float (&an)[RR / 2], int n) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[q] + n * (CIN * 4), 0, 0);
+            xr[q] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
+        }
+#pragma unroll
+        for (int u = 0; u < RR / 2; u++)
+            an[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsz, zoff + (n + 2 * u) * (Cout * 4), 0, 0));
+    };
+    auto stash = [&](const float4 (&xr)[PER], int buf) {
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
+            *(float4 *)&sX[buf][row][4 * c4] = xr[q];
+        }
+    };
+    // round n: a-values from `cur` (its x rows are in sX[buf]); `oth` holds round n + 1
+    auto round = [&](float4 (&xc)[PER], float (&ac)[RR / 2], const float4 (&xo)[PER], int n, int buf) {
+        float a[RR / 2];
+#pragma unroll
+        for (int u = 0; u < RR / 2; u++) a[u] = ac[u];
+        fetch(xc, ac, n + 2 * RR);
+        if (SG_EXP & 32768) { __builtin_amdgcn_s_sleep(96); bsum += a[0]; }
+        if (active && !(SG_EXP & 16384)) {
 #pragma unroll
             for (int u = 0; u < RR / 2; u++) {
-                const int row = n + 2 * u + half;
-                an[u] = (ok_o && row < r1) ? dz[(size_t)row * Cout + o] : 0.0f;
+                bsum += a[u];
+#pragma unroll
+                for (int t = 0; t < TI; t++)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
             }
-        };
-        auto stash = [&](const float4 (&xr)[PER], int buf) {
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const int f = threadIdx.x + 256 * q, row = f / (CIN / 4), c4 = f - row * (CIN / 4);
-                if (f < F4) *(float4 *)&sX[buf][row][4 * c4] = xr[q];
-            }
-        };
-        // round n: a-values from `cur` (its x rows are in sX[buf]); `oth` holds round n + 1
-        auto round = [&](float4 (&xc)[PER], float (&ac)[RR / 2], const float4 (&xo)[PER], int n, int buf) {
-            float a[RR / 2];
-#pragma unroll
-            for (int u = 0; u < RR / 2; u++) a[u] = ac[u];
-            if (n + 2 * RR < r1) fetch(xc, ac, n + 2 * RR);
-            if (active) {
-#pragma unroll
-                for (int u = 0; u < RR / 2; u++) {
-                    bsum += a[u];
-#pragma unroll
-                    for (int t = 0; t < TI; t++)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
-                }
-            }
-            if (n + RR < r1) stash(xo, buf ^ 1);
-            __syncthreads();
-        };
-        fetch(xrE, anE, r0);
-        if (r0 + RR < r1) fetch(xrO, anO, r0 + RR);
+        }
+        stash(xo, buf ^ 1);
+        __syncthreads();
+    };
+    if (len > 0) {
+        fetch(xrE, anE, 0);
+        fetch(xrO, anO, RR);
         stash(xrE, 0);
         __syncthreads();
-        for (int n = r0; n < r1; n += 2 * RR) {
+        for (int n = 0; n < len; n += 2 * RR) {
             round(xrE, anE, xrO, n, 0);
-            if (n + RR < r1) round(xrO, anO, xrE, n + RR, 1);
+            if (n + RR >= len) break;                  // (a break, not an `if` around the second round: the back edge keeps its static load count)
+            round(xrO, anO, xrE, n + RR, 1);
         }
     }
-    if (!active) return;
+    if (!active || ((SG_EXP & 8192) && N > 1)) return;
     // D layout of the 32x32 tile: lane l, register r -> row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32
     float *pw = partial + (size_t)blockIdx.x * cout_pad * Cin;
 #pragma unroll
@@ -795,20 +805,32 @@ sg_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restric
     }
 }
 
+// MFMA kernel: ONE workgroup per CU (256 equal row ranges; a range need not be a whole number of rounds -- the rows beyond it read
+// as zero).  A wave's TI independent accumulator chains keep its SIMD's matrix core busy on their own, and the partials -- one
+// Cout x Cin slab per workgroup, written once and read once by the reduce kernel -- are what more workgroups multiply: 768 / 512 /
+// 256 workgroups: 76 / 65 / 59 us for a 128 x 128 layer at 150 k points, of which the reduce is 15 / 11 / 6.
+static inline int sg_wg_chunk(int N, int rr)
+{
+    (void)rr;
+    const int c = (N + 255) / 256;
+    return c < 32 ? 32 : c;
+}
 static inline int sg_wg_count(int N) { const int n = (N + SG_WG_ROWS - 1) / SG_WG_ROWS; return n < 512 ? n : 512; }
+static inline int sg_wg_count_max(int N) { const int n = (N + 31) / 32; return n < 768 ? n : 768; }   // bound over both kernels
 size_t sg_weight_grad_ws_bytes_impl(int N, int Cout, int Cin)
 {
     const size_t cp = (size_t)((Cout + 31) / 32) * 32;
-    return sg_align((size_t)sg_wg_count(N) * cp * Cin * 4) + sg_align((size_t)sg_wg_count(N) * cp * 4);
+    return sg_align((size_t)sg_wg_count_max(N) * cp * Cin * 4) + sg_align((size_t)sg_wg_count_max(N) * cp * 4);
 }
 int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
                           hipStream_t st)
 {
     if (Cin % 32 != 0 || Cin > 128 || Cout > 128 || Cout < 1) return 1;
     int cp = ((Cout + 31) / 32) * 32;
-    const int nwg = sg_wg_count(N), ti = Cin / 32;
+    int nwg = sg_wg_count(N);
+    const int ti = Cin / 32;
     float *partial = (float *)ws;
-    float *bpartial = (float *)((char *)ws + sg_align((size_t)nwg * cp * Cin * 4));
+    float *bpartial = (float *)((char *)ws + sg_align((size_t)sg_wg_count_max(N) * cp * Cin * 4));
     if (Cout <= 4) {
         // (partials are [nwg][Cout][Cin] here: the reduce kernel takes the row pitch as a parameter)
         switch (Cout) {
@@ -819,7 +841,9 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
         }
         cp = Cout;
     } else {
-#define SG_WGK(T) hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32)>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp)
+        const int rr = ti == 4 ? 16 : 32, chunk = sg_wg_chunk(N, rr);
+        nwg = (N + chunk - 1) / chunk;
+#define SG_WGK(T) hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32)>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp, chunk)
         switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
 #undef SG_WGK
     }

@@ -9,7 +9,7 @@ for n in "$@"; do
   d=build/exp/obj$n; mkdir -p $d
   for f in sings_amd/csrc/*.hip; do
     b=$(basename $f .hip)
-    case $b in sg_preprocess|sg_binning|sg_render|sg_skin|sg_api|sg_linear) /opt/rocm/bin/hipcc $FLAGS -DSG_EXP=$n -c $f -o $d/$b.o & ;;
+    case $b in sg_preprocess|sg_binning|sg_render|sg_skin|sg_api|sg_linear|sg_decode) /opt/rocm/bin/hipcc $FLAGS -DSG_EXP=$n -c $f -o $d/$b.o & ;;
       *) [ -f sings_amd/csrc/$b.o ] && cp sings_amd/csrc/$b.o $d/$b.o ;; esac
   done
   wait

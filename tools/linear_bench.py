@@ -46,6 +46,8 @@ def main():
         tb = timed(lambda: lib.sg_linear_backward(N, ci, co, act, p(auxb), None, p(dh), p(W), p(dz) if act else None, p(dx), st))
         bb = 4 * N * (ci + co * (3 if act else 1))
         tw = timed(lambda: lib.sg_weight_grad(N, co, ci, p(dz), p(x), p(ws), p(dW), p(db), st))
+        if os.environ.get("LB_ONLY_WGRAD"):
+            print(f"{ci:4d} -> {co:4d}: wgrad {tw:7.1f} us"); continue
         bw = 4 * N * (ci + co)
         print(f"{ci:4d} -> {co:4d} act {act}:  fwd {tf:7.1f} us ({bf / tf / 1e6:5.2f} TB/s)   bwd {tb:7.1f} us ({bb / tb / 1e6:5.2f} TB/s)"
               f"   wgrad {tw:7.1f} us ({bw / tw / 1e6:5.2f} TB/s)")
