@@ -306,6 +306,10 @@ int sg_linear_forward(int N, int Cin, int Cout, int act, const float *x, const f
                       const float *row_offset, float *aux_out, float *h_out, void *stream);
 int sg_linear_backward(int N, int Cin, int Cout, int act, const float *aux, const float *row_offset, const float *dh,
                        const float *W, float *dz_out, float *dx_out, void *stream);
+/* The same with dx_out += dz W (Cin a multiple of 32): an activation that feeds several layers -- the decoder trunk and its heads,
+ * decoders.py:75-94 -- collects its gradient in ONE array instead of one array per consumer plus autograd's additions. */
+int sg_linear_backward_accumulate(int N, int Cin, int Cout, int act, const float *aux, const float *row_offset, const float *dh,
+                                  const float *W, float *dz_out, float *dx_out, void *stream);
 
 /* Weight / bias gradient of one decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz (db may be NULL);
  * dz [N,Cout], x [N,Cin]; Cin in {32, 64, 96, 128}, Cout <= 128.  fp32 on the matrix cores, deterministic.

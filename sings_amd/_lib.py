@@ -47,7 +47,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
-           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward")
+           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate")
 NUM_KERNELS = 8
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
@@ -111,6 +111,7 @@ def load():
     lib.sg_weight_grad.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]; lib.sg_weight_grad.restype = C.c_int
     lib.sg_linear_forward.argtypes = [i32, i32, i32, i32] + [vp] * 7; lib.sg_linear_forward.restype = C.c_int
     lib.sg_linear_backward.argtypes = [i32, i32, i32, i32] + [vp] * 7; lib.sg_linear_backward.restype = C.c_int
+    lib.sg_linear_backward_accumulate.argtypes = [i32, i32, i32, i32] + [vp] * 7; lib.sg_linear_backward_accumulate.restype = C.c_int
     lib.sg_reg_ws_bytes.argtypes = [i32]; lib.sg_reg_ws_bytes.restype = sz
     lib.sg_knn_ws_bytes.argtypes = [i32]; lib.sg_knn_ws_bytes.restype = sz
     lib.sg_region_laplacian.argtypes = [i32, i32] + [vp] * 11

@@ -351,15 +351,26 @@ extern "C" int sg_linear_forward(int N, int Cin, int Cout, int act, const float 
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_linear_forward", e);
 }
+static int sg_linear_backward_impl(const char *who, int N, int Cin, int Cout, int act, const float *z, const float *row_offset,
+                                   const float *dh, const float *W, float *dz_out, float *dx_out, void *stream, int accumulate)
+{
+    if (N <= 0 || !dh || !W || !dx_out || act < 0 || act > 3 || (act != 0 && !z)) return sg_fail(who, hipSuccess);
+    if (accumulate && (Cin & 31)) return sg_fail("sg_linear_backward_accumulate: Cin must be a multiple of 32", hipSuccess);
+    if (sg_launch_linear_bwd(N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out, (hipStream_t)stream, accumulate))
+        return sg_fail("sg_linear_backward: 1 <= Cin, Cout <= 128 (accumulate: N Cin < 2^29)", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail(who, e);
+}
 extern "C" int sg_linear_backward(int N, int Cin, int Cout, int act, const float *z, const float *row_offset, const float *dh,
                                   const float *W, float *dz_out, float *dx_out, void *stream)
 {
-    if (N <= 0 || !dh || !W || !dx_out || act < 0 || act > 3 || (act != 0 && !z))
-        return sg_fail("sg_linear_backward: bad argument", hipSuccess);
-    if (sg_launch_linear_bwd(N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out, (hipStream_t)stream))
-        return sg_fail("sg_linear_backward: 1 <= Cin, Cout <= 128", hipSuccess);
-    hipError_t e = hipGetLastError();
-    return e == hipSuccess ? 0 : sg_fail("sg_linear_backward", e);
+    return sg_linear_backward_impl("sg_linear_backward: bad argument", N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out, stream, 0);
+}
+extern "C" int sg_linear_backward_accumulate(int N, int Cin, int Cout, int act, const float *z, const float *row_offset,
+                                             const float *dh, const float *W, float *dz_out, float *dx_out, void *stream)
+{
+    return sg_linear_backward_impl("sg_linear_backward_accumulate: bad argument", N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out,
+                                   stream, 1);
 }
 
 // ---- the other rotation conversions (a11)

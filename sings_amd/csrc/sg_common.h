@@ -170,7 +170,7 @@ size_t sg_weight_grad_ws_bytes_impl(int N, int Cout, int Cin);
 int sg_launch_linear_fwd(int N, int Cin, int Cout, int act, const float *x, const float *W, const float *bias,
                          const float *row_offset, float *z_out, float *h_out, hipStream_t st);
 int sg_launch_linear_bwd(int N, int Cin, int Cout, int act, const float *z, const float *row_offset, const float *dh,
-                         const float *W, float *dz_out, float *dx_out, hipStream_t st);
+                         const float *W, float *dz_out, float *dx_out, hipStream_t st, int accumulate);
 int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float *x, void *ws, float *dW, float *db,
                           hipStream_t st);
 size_t sg_reg_ws_bytes_impl(int n);

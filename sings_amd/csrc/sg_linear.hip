@@ -254,7 +254,7 @@ template <int NQ, bool BWD, bool GELU>
 __global__ void __launch_bounds__(256, BWD ? 2 : 3)   // backward: x' and aux prefetch registers on top of the 64 weight registers -> 2 per SIMD, no spills
 sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
                       const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
-                      float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out)
+                      float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out, int accum)
 {
     using cfg = sgl_wide_cfg<NQ>;
     constexpr int CKP = cfg::CKP, HALF = CKP / 2, XS = cfg::XS, PER = cfg::PER;
@@ -389,7 +389,18 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
         if (BWD) {
             // no element-wise work to hide: dx leaves as soon as the tile's MFMAs are done (the stores are asynchronous)
             if (active) {
-                const sg_v16f acc = mma(std::false_type{}, buf, accp, 0);
+                // accumulate (a layer input with several consumers: dx += dz W): the old values are requested before the MFMAs
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; r++) old[r] = 0.0f;
+                if (accum) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs0, voff0 + (tile * R + 8 * (r >> 2) + (r & 3)) * CO4, 0, 0));
+                }
+                sg_v16f acc = mma(std::false_type{}, buf, accp, 0);
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[r] += old[r];
 #pragma unroll
                 for (int r = 0; r < 16; r++) emit(acc, r, tile * R);
             }
@@ -414,7 +425,7 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
 
 template <bool BWD>
 static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, const float *Z, const float *Mw, int s_co, int s_ck,
-                            const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st)
+                            const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st, int accum = 0)
 {
     if (N <= 0) return 0;
     if (CK < 1 || CK > SGL_MAXC || CO < 1 || CO > SGL_MAXC) return 1;
@@ -430,13 +441,13 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
             const size_t dyn = (size_t)2 * R * cfg::XS * sizeof(float);                                                     \
             if (BWD)                                                                                                        \
                 hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, true, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, (float *)nullptr, out1);                                     \
+                                   Mw, s_co, s_ck, bias, out0, (float *)nullptr, out1, accum);                                     \
             else if (act == 1)                                                                                              \
                 hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, true>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr);                                     \
+                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr, 0);                                     \
             else                                                                                                            \
                 hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr);                                     \
+                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr, 0);                                     \
         } while (0)
         if (nq <= 1) SGL_WIDE(1);
         else if (nq <= 4) SGL_WIDE(4);
@@ -447,6 +458,7 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
 #undef SGL_WIDE
         return 0;
     }
+    if (accum) return 2;                                                    // only the wide kernel accumulates
     const int nqt = nq <= 1 ? 1 : (nq <= 4 ? 4 : (nq <= 6 ? 6 : (nq <= 8 ? 8 : (nq <= 12 ? 12 : 16))));
     const int TO = (CO + 31) / 32, PT = sgl_point_tiles(TO, nqt * 8), R = 32 * PT;
     const int ntiles = (N + R - 1) / R;
@@ -475,8 +487,8 @@ int sg_launch_linear_fwd(int N, int Cin, int Cout, int act, const float *x, cons
 // backward: dh, aux [N,Cout] (act 1: the forward's aux; act 2: h; act 3: z), W [Cout,Cin] -> dz_out [N,Cout] = dh * act'
 // (may be NULL), dx_out [N,Cin] = dz W
 int sg_launch_linear_bwd(int N, int Cin, int Cout, int act, const float *z, const float *row_offset, const float *dh,
-                         const float *W, float *dz_out, float *dx_out, hipStream_t st)
+                         const float *W, float *dz_out, float *dx_out, hipStream_t st, int accumulate)
 {
     // Y = dx [N, CO = Cin], X' = dz [N, CK = Cout], M(co = input column, ck = output column) = W[ck][co]
-    return sg_linear_launch<true>(N, Cout, Cin, act, dh, z, W, 1, Cin, nullptr, row_offset, dx_out, dz_out, st);
+    return sg_linear_launch<true>(N, Cout, Cin, act, dh, z, W, 1, Cin, nullptr, row_offset, dx_out, dz_out, st, accumulate);
 }

@@ -153,68 +153,127 @@ class HexPlaneField(nn.Module):
     get_density = forward
 
 
+def _lin_fwd(x, W, b, act, row_offset):
+    """h = act(x W^T + b) in one kernel (sg_linear_forward); returns (h, aux, Wc): aux is what the backward needs besides x --
+    gelu'(z) for GELU (so the backward's act' is one multiplication), the output h for the sigmoid, z for the softplus."""
+    lib = _lib.load()
+    if not x.is_cuda:
+        raise RuntimeError("sings_amd.decode: tensors must live on the GPU (no CPU fallback)")
+    Wc = W.contiguous().float()
+    bc = None if b is None else b.contiguous().float()
+    dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
+    ro = row_offset.contiguous().float().reshape(-1) if row_offset is not None else None
+    h = torch.empty((N, Cout), dtype=torch.float32, device=dev)
+    aux = torch.empty_like(h) if act in (ACT_GELU, ACT_SOFTPLUS_REF) else None
+    with torch.cuda.device(dev):
+        _lib.check(lib.sg_linear_forward(N, Cin, Cout, act, _ptr(x), _ptr(Wc), _ptr(bc), _ptr(ro), _ptr(aux), _ptr(h),
+                                         _stream(dev)), "linear forward")
+    if act == ACT_SIGMOID:
+        aux = h
+    return h, aux, Wc
+
+
+def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
+    """dz = dh * act'(z) in the prologue of dx = dz W (sg_linear_backward), then dW = dz^T x, db = column sums (sg_weight_grad).
+    ``dx_into``: an existing [N,Cin] gradient this layer ADDS its dx to (sg_linear_backward_accumulate)."""
+    lib = _lib.load()
+    dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
+    dh = dh.contiguous().float()
+    dz = torch.empty_like(dh) if act != ACT_NONE else dh
+    dx = None
+    with torch.cuda.device(dev):
+        if need_dx:
+            acc = dx_into is not None
+            dx = dx_into if acc else torch.empty((N, Cin), dtype=torch.float32, device=dev)
+            fn = lib.sg_linear_backward_accumulate if acc else lib.sg_linear_backward
+            _lib.check(fn(N, Cin, Cout, act, _ptr(aux) if act != ACT_NONE else None, None, _ptr(dh), _ptr(W),
+                          _ptr(dz) if act != ACT_NONE else None, _ptr(dx), _stream(dev)), "linear backward")
+        elif act == ACT_GELU:                                   # a layer whose input needs no gradient: only dz = dh * gelu'(z)
+            torch.mul(dh, aux, out=dz)
+        elif act == ACT_SIGMOID:
+            torch.mul(dh, aux * (1.0 - aux), out=dz)
+        elif act == ACT_SOFTPLUS_REF:
+            torch.mul(dh, torch.sigmoid(aux), out=dz)
+        dW = db = None
+        if need_dw:
+            # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
+            dW = torch.empty_like(W, dtype=torch.float32)
+            db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+            ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
+            _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
+                       "weight gradient")
+    return dx, dW, db
+
+
 class _LinearAct(torch.autograd.Function):
     """h = act(x @ W^T + b) as ONE kernel on the matrix cores (sg_linear_forward: bias + activation in the GEMM's epilogue);
     backward: sg_linear_backward (dz = dh * act' in the prologue of dx = dz W, dz stored once) + sg_weight_grad.
-    No library GEMM, no separate element-wise pass (round 1: torch.addmm / torch.mm + sg_bias_act_*).  The forward saves
-    ``aux``: gelu'(z) for GELU (so the backward's act' is one multiplication), the output h for the sigmoid, z otherwise."""
+    No library GEMM, no separate element-wise pass (round 1: torch.addmm / torch.mm + sg_bias_act_*)."""
 
     @staticmethod
     def forward(ctx, x, W, b, act, row_offset):
-        lib = _lib.load()
-        if not x.is_cuda:
-            raise RuntimeError("sings_amd.decode: tensors must live on the GPU (no CPU fallback)")
         x = x.contiguous().float()
-        Wc = W.contiguous().float()
-        bc = None if b is None else b.contiguous().float()
-        dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
-        ro = row_offset.contiguous().float().reshape(-1) if row_offset is not None else None
-        h = torch.empty((N, Cout), dtype=torch.float32, device=dev)
-        aux = torch.empty_like(h) if act in (ACT_GELU, ACT_SOFTPLUS_REF) else None
-        with torch.cuda.device(dev):
-            _lib.check(lib.sg_linear_forward(N, Cin, Cout, act, _ptr(x), _ptr(Wc), _ptr(bc), _ptr(ro), _ptr(aux), _ptr(h),
-                                             _stream(dev)), "linear forward")
-        if act == ACT_SIGMOID:
-            aux = h
-        ctx.save_for_backward(x, Wc, aux if aux is not None else torch.empty(0, device=dev))
+        h, aux, Wc = _lin_fwd(x, W, b, act, row_offset)
+        ctx.save_for_backward(x, Wc, aux if aux is not None else torch.empty(0, device=x.device))
         ctx.act, ctx.has_b = act, b is not None
         return h
 
     @staticmethod
     def backward(ctx, dh):
-        lib = _lib.load()
         x, W, aux = ctx.saved_tensors
-        dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
-        dh = dh.contiguous().float()
-        act = ctx.act
-        need_dx = ctx.needs_input_grad[0]
         need_dw = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
-        dz = torch.empty_like(dh) if act != ACT_NONE else dh
-        dx = None
-        with torch.cuda.device(dev):
-            if need_dx:
-                dx = torch.empty((N, Cin), dtype=torch.float32, device=dev)
-                _lib.check(lib.sg_linear_backward(N, Cin, Cout, act, _ptr(aux) if act != ACT_NONE else None, None, _ptr(dh), _ptr(W),
-                                                  _ptr(dz) if act != ACT_NONE else None, _ptr(dx), _stream(dev)), "linear backward")
-            elif act == ACT_GELU:                                   # first layer of a decoder: only dz = dh * gelu'(z) is needed
-                torch.mul(dh, aux, out=dz)
-            elif act == ACT_SIGMOID:
-                torch.mul(dh, aux * (1.0 - aux), out=dz)
-            elif act == ACT_SOFTPLUS_REF:
-                torch.mul(dh, torch.sigmoid(aux), out=dz)
-            dW = db = None
-            if need_dw:
-                # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
-                dW = torch.empty_like(W, dtype=torch.float32)
-                db = torch.empty(Cout, dtype=torch.float32, device=dev) if ctx.has_b else None
-                ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
-                _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
-                           "weight gradient")
+        dx, dW, db = _lin_bwd(x, W, aux, ctx.act, ctx.has_b, dh, ctx.needs_input_grad[0], need_dw)
         return dx, dW, db, None, None
 
 
 def linear_act(x, lin, act=ACT_NONE, row_offset=None):
     return _LinearAct.apply(x, lin.weight, lin.bias, act, row_offset)
+
+
+class _LinearFan(torch.autograd.Function):
+    """Several layers reading the SAME activation (the decoder trunk and its heads, decoders.py:41-49, 75-94; the tri-plane
+    features and the two decoders, sings_hybrid.py:259-262): forward = one sg_linear_forward per layer; backward: the first
+    consumer writes dx, the others ADD theirs into the same array (sg_linear_backward_accumulate) -- one [N,Cin] gradient
+    instead of one per consumer plus autograd's element-wise additions (two 77-MB passes per trunk at 150 k points)."""
+
+    @staticmethod
+    def forward(ctx, x, acts, row_offsets, *wb):
+        x = x.contiguous().float()
+        outs, saved = [], [x]
+        for i, act in enumerate(acts):
+            h, aux, Wc = _lin_fwd(x, wb[2 * i], wb[2 * i + 1], act, row_offsets[i])
+            outs.append(h)
+            saved += [Wc, aux if aux is not None else torch.empty(0, device=x.device)]
+        ctx.save_for_backward(*saved)
+        ctx.acts, ctx.has_b = tuple(acts), tuple(wb[2 * i + 1] is not None for i in range(len(acts)))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dhs):
+        x = ctx.saved_tensors[0]
+        need_dx = ctx.needs_input_grad[0]
+        can_acc = (int(x.shape[1]) & 31) == 0
+        dx, grads = None, []
+        for i, act in enumerate(ctx.acts):
+            W, aux = ctx.saved_tensors[1 + 2 * i], ctx.saved_tensors[2 + 2 * i]
+            need_dw = ctx.needs_input_grad[3 + 2 * i] or (ctx.has_b[i] and ctx.needs_input_grad[4 + 2 * i])
+            if dhs[i] is None:
+                grads += [None, None]
+                continue
+            dxi, dW, db = _lin_bwd(x, W, aux, act, ctx.has_b[i], dhs[i], need_dx, need_dw,
+                                   dx_into=dx if (can_acc and dx is not None) else None)
+            if need_dx:
+                dx = dxi if (dx is None or can_acc) else dx + dxi
+            grads += [dW, db]
+        return (dx, None, None, *grads)
+
+
+def linear_fan(x, layers):
+    """layers: [(nn.Linear, act, row_offset | None), ...] -> tuple of outputs, one per layer, all reading x."""
+    wb = []
+    for lin, _, _ in layers:
+        wb += [lin.weight, lin.bias]
+    return _LinearFan.apply(x, tuple(a for _, a, _ in layers), tuple(r for _, _, r in layers), *wb)
 
 
 class AppearanceDecoder(nn.Module):
@@ -238,15 +297,21 @@ class AppearanceDecoder(nn.Module):
             o = linear_act(self._trunk(x), self.opacity)
             self.opacity_offset = torch.where(o > 0, torch.zeros_like(o), -o)
 
-    def forward(self, x):
-        x = self._trunk(x)
-        shs = linear_act(x, self.shs).reshape(-1, 16, 3)
+    def heads(self, x):
+        """the heads on the trunk output x: one fan (their input gradients are accumulated in place)."""
         if not self.fixed_opacity:
             off = self.opacity_offset if torch.is_tensor(self.opacity_offset) else None
-            opacity = linear_act(x, self.opacity, ACT_SIGMOID, off)
+            shs, opacity = linear_fan(x, [(self.shs, ACT_NONE, None), (self.opacity, ACT_SIGMOID, off)])
         else:
+            shs = linear_act(x, self.shs)
             opacity = torch.ones((x.shape[0], 1), device=x.device)
-        return {'shs': shs, 'opacity': opacity}
+        return {'shs': shs.reshape(-1, 16, 3), 'opacity': opacity}
+
+    def forward(self, x, first=None):
+        """``first``: the output of net[0] + GELU when the caller computed it (decode_attributes fans the tri-plane features
+        out to both decoders' first layers)."""
+        h1 = linear_act(x, self.net[0], ACT_GELU) if first is None else first
+        return self.heads(linear_act(h1, self.net[2], ACT_GELU))
 
 
 class GeometryDecoder(nn.Module):
@@ -260,11 +325,16 @@ class GeometryDecoder(nn.Module):
             self.rotations = nn.Sequential(nn.Linear(hidden_dim, 6))
         self.scales = nn.Sequential(nn.Linear(hidden_dim, hidden_dim), nn.GELU(), nn.Linear(hidden_dim, 1 if isotropic else 3))
 
-    def forward(self, x):
-        x = linear_act(linear_act(x, self.net[0], ACT_GELU), self.net[2], ACT_GELU)
-        xyz_offsets = linear_act(x, self.xyz_offsets)
-        rotations = linear_act(x, self.rotations[0]) if not self.isotropic else None
-        s1 = linear_act(x, self.scales[0], ACT_GELU)
+    def forward(self, x, first=None):
+        h1 = linear_act(x, self.net[0], ACT_GELU) if first is None else first
+        x = linear_act(h1, self.net[2], ACT_GELU)
+        # the heads read the same trunk output: one fan, the wide layer first (it writes dx, the narrow heads add to it)
+        layers = [(self.scales[0], ACT_GELU, None), (self.xyz_offsets, ACT_NONE, None)]
+        if not self.isotropic:
+            layers.append((self.rotations[0], ACT_NONE, None))
+        outs = linear_fan(x, layers)
+        s1, xyz_offsets = outs[0], outs[1]
+        rotations = outs[2] if not self.isotropic else None
         scales_aux = linear_act(s1, self.scales[2])
         # scales = log(exp(scales_aux) + 1): the activation kernel on the bias-added value (identity GEMM avoided)
         scales = _Act.apply(scales_aux, ACT_SOFTPLUS_REF)
@@ -306,8 +376,10 @@ class _Act(torch.autograd.Function):
 def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_factor=1.0, scaling_multiplier=None):
     """SinGS.get_gs_attrs for one level (sings_hybrid.py:249-313): the dict the LBS/render path consumes."""
     tri_feats = triplane(xyz)
-    g = geometry_dec(tri_feats)
-    a = appearance_dec(tri_feats)
+    # both decoders' first layers read the tri-plane features: one fan, one feature gradient
+    g1, a1 = linear_fan(tri_feats, [(geometry_dec.net[0], ACT_GELU, None), (appearance_dec.net[0], ACT_GELU, None)])
+    g = geometry_dec(tri_feats, first=g1)
+    a = appearance_dec(tri_feats, first=a1)
     scales = g['scales']
     if thickness_factor != 1.0:
         scales = torch.cat([scales[:, :-1], scales[:, -1:] * thickness_factor], dim=1)

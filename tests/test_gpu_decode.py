@@ -237,3 +237,39 @@ def test_fused_linear_layer_kernels_vs_torch(N, Cin, Cout, act):
     _close(xd.grad.cpu().numpy(), x64.grad.numpy(), rtol=2e-5, atol_scale=2e-6, what="dx")
     _close(lin.weight.grad.cpu().numpy(), l64.weight.grad.numpy(), rtol=3e-5, atol_scale=3e-6, what="dW")
     _close(lin.bias.grad.cpu().numpy(), l64.bias.grad.numpy(), rtol=3e-5, atol_scale=3e-6, what="db")
+
+
+@pytest.mark.parametrize("N,Cin", [(3000, 128), (4099, 64), (777, 96)])
+def test_linear_fan_accumulates_input_gradient_like_separate_layers(N, Cin):
+    """Several layers on one activation (trunk + heads, decoders.py:75-94): `linear_fan` lets the consumers add their dx into one
+    array (sg_linear_backward_accumulate) -- same outputs and gradients as torch's fp64 layers + autograd's sum, ragged N."""
+    from sings_amd.decode import ACT_GELU, ACT_NONE, ACT_SIGMOID, linear_fan
+    dev = _dev()
+    torch.manual_seed(N + Cin)
+    lins = [torch.nn.Linear(Cin, 128), torch.nn.Linear(Cin, 3), torch.nn.Linear(Cin, 48), torch.nn.Linear(Cin, 1)]
+    acts = [ACT_GELU, ACT_NONE, ACT_NONE, ACT_SIGMOID]
+    off = torch.rand(N, 1) * 0.3
+    x = torch.randn(N, Cin)
+    ups = [torch.randn(N, l.out_features) for l in lins]
+    # fp64 reference
+    xr = x.double().requires_grad_(True)
+    ref_out, loss = [], 0.0
+    for l, a, u in zip(lins, acts, ups):
+        z = xr @ l.weight.double().T + l.bias.double()
+        h = torch.nn.functional.gelu(z) if a == ACT_GELU else (torch.sigmoid(z + off.double()) if a == ACT_SIGMOID else z)
+        ref_out.append(h)
+        loss = loss + (h * u.double()).sum()
+    params = [p for l in lins for p in (l.weight, l.bias)]
+    ref_g = torch.autograd.grad(loss, [xr] + params)
+    # product
+    glins = [torch.nn.Linear(Cin, l.out_features).to(dev) for l in lins]
+    for gl, l in zip(glins, lins):
+        gl.load_state_dict(l.state_dict())
+    xg = x.to(dev).requires_grad_(True)
+    outs = linear_fan(xg, [(gl, a, off.to(dev) if a == ACT_SIGMOID else None) for gl, a in zip(glins, acts)])
+    lossg = sum((o * u.to(dev)).sum() for o, u in zip(outs, ups))
+    gg = torch.autograd.grad(lossg, [xg] + [p for gl in glins for p in (gl.weight, gl.bias)])
+    for o, r in zip(outs, ref_out):
+        _close(o.detach().cpu().numpy(), r.detach().numpy(), what="fan output")
+    for g, r in zip(gg, ref_g):
+        _close(g.cpu().numpy(), r.numpy(), rtol=5e-5, atol_scale=5e-6, what="fan gradient")
