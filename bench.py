@@ -677,6 +677,13 @@ def main_train(a):
         cap_pairs = max(cap_pairs, _rz._capacity_hint[dev.index])
     torch.cuda.synchronize()
     _rz.set_deferred_overflow_check(True, capacity_pairs=cap_pairs)
+    if os.environ.get("SINGS_TORCH_PROFILE"):                    # which torch ops (copies, additions) sit between the library's kernels
+        from torch.profiler import ProfilerActivity, profile
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for _ in range(2):
+                step_body()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60), file=sys.stderr)
     graph, ld_static = None, None
     if not a.eager:
         # the whole step (decode -> raster -> losses -> backward, ~600 launches) replayed from ONE HIP graph

@@ -704,7 +704,7 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     if (half == 0) bpartial[(size_t)blockIdx.x * cout_pad + o] = bsum;
 }
 
-// Heads with <= 4 outputs (xyz offsets, scale, opacity): the product is a handful of dot products per input column --
+// Heads with <= 12 outputs (xyz offsets, rotations, scale, opacity): the product is a handful of dot products per input column --
 // a streaming read of x (HBM-bound) instead of a 32-row MFMA tile of which 1-3 rows are used (80 us for 128 inputs).
 // Thread = one float4 of input columns x one of 256 / (Cin / 4) row phases; fixed-order tree over the phases in LDS.
 template <int CO>
@@ -831,14 +831,14 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
     const int ti = Cin / 32;
     float *partial = (float *)ws;
     float *bpartial = (float *)((char *)ws + sg_align((size_t)sg_wg_count_max(N) * cp * Cin * 4));
-    if (Cout <= 4) {
+    if (Cout <= 12) {
         // (partials are [nwg][Cout][Cin] here: the reduce kernel takes the row pitch as a parameter)
+#define SG_WGS(C) case C: hipLaunchKernelGGL(sg_wgrad_small_kernel<C>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break
         switch (Cout) {
-        case 1: hipLaunchKernelGGL(sg_wgrad_small_kernel<1>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
-        case 2: hipLaunchKernelGGL(sg_wgrad_small_kernel<2>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
-        case 3: hipLaunchKernelGGL(sg_wgrad_small_kernel<3>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
-        default: hipLaunchKernelGGL(sg_wgrad_small_kernel<4>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
+            SG_WGS(1); SG_WGS(2); SG_WGS(3); SG_WGS(4); SG_WGS(5); SG_WGS(6); SG_WGS(7); SG_WGS(8); SG_WGS(9); SG_WGS(10); SG_WGS(11);
+            default: hipLaunchKernelGGL(sg_wgrad_small_kernel<12>, dim3(nwg), dim3(256), 0, st, N, Cin, dz, x, partial, bpartial); break;
         }
+#undef SG_WGS
         cp = Cout;
     } else {
         const int rr = ti == 4 ? 16 : 32, chunk = sg_wg_chunk(N, rr);

@@ -155,8 +155,8 @@ def test_triplane_backward_clustered_and_border_points():
 
 
 def test_weight_grad_shapes():
-    """sg_weight_grad over the shapes the decoders use and the edges of its two code paths (<= 4 outputs: streaming
-    dot products; more: MFMA tiles): dW = dz^T x, db = column sums, against float64."""
+    """sg_weight_grad over the shapes the decoders use and the edges of its two code paths (streaming
+    dot products up to 12 outputs; more: MFMA tiles): dW = dz^T x, db = column sums, against float64."""
     import ctypes as C
     from sings_amd import _lib
     dev = _dev()
@@ -164,7 +164,7 @@ def test_weight_grad_shapes():
     torch.manual_seed(5)
     for N in (1, 37, 10007):
         for Cin in (32, 64, 96, 128):
-            for Cout in (1, 2, 3, 4, 5, 48, 128):
+            for Cout in (1, 2, 3, 4, 5, 6, 9, 12, 13, 48, 128):
                 dz = torch.randn(N, Cout, device=dev); x = torch.randn(N, Cin, device=dev)
                 dW = torch.empty(Cout, Cin, device=dev); db = torch.empty(Cout, device=dev)
                 ws = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
