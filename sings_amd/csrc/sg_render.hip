@@ -27,6 +27,7 @@
 
 #define SG_FB 256         // forward: list entries staged per batch (one per thread)
 #define SG_BB 128         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
+#define SG_UNSET 0xffffffffu   // bit pattern (a NaN) of a quadrant-sum slot nobody wrote
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 
@@ -283,11 +284,15 @@ __device__ __forceinline__ float sg_reduce9(const float v[9], int lane, float *v
     float z = (lane & 8) ? w : u;            // per row: lanes 0-7 <- first value, 8-15 <- second
     z += SG_DPP(z, 0xB1);                    // quad_perm [1,0,3,2]
     z += SG_DPP(z, 0x4E);                    // quad_perm [2,3,0,1]
-    z += SG_DPP(z, 0x141);                   // row_half_mirror
+    // row_half_mirror (as asm: the compiler otherwise splits it into a zeroed register, a DPP move and an add sunk into the
+    // masked store block)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(z));
     float x = v[8];
     x += SG_DPP(x, 0xB1); x += SG_DPP(x, 0x4E); x += SG_DPP(x, 0x141); x += SG_DPP(x, 0x140);
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xA, 0xF, false));
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x143, 0xC, 0xF, false));
+    // rows 1 and 3 add the row in front of them, then rows 2 and 3 add lane 31: lane 63 holds the total.  One masked
+    // v_add_f32_dpp each (the builtin form costs a zeroed register, a masked move and an add per step)
+    asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa\n\ts_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc" : "+v"(x));
     *v8tot = x;
     return z;
 }
@@ -309,13 +314,10 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
                      const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask)
 {
-    __shared__ float4 sA[SG_BB];
-    __shared__ float4 sB[SG_BB];
-    __shared__ float sC[SG_BB];
+    __shared__ float4 sR[SG_BB][3];            // staged entry: (mean x, mean y, A, B) (C, opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_BB];
     __shared__ uint16_t sList[4][SG_BB];
-    __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch
-    __shared__ uint8_t sFlag[4][SG_BB];        // [w][k] != 0: quadrant w wrote sG[w][k]
+    __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
@@ -343,7 +345,8 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const uint32_t ncq = inside ? n_contrib[pid] : 0u;
     const float d0 = inside ? dL_dpix[pid] : 0.0f, d1 = inside ? dL_dpix[hw + pid] : 0.0f, d2 = inside ? dL_dpix[2 * hw + pid] : 0.0f;
     const float tb = Tfin * (bg[0] * d0 + bg[1] * d1 + bg[2] * d2);
-    float Tr = Tfin, S0 = 0.0f, S1 = 0.0f, S2 = 0.0f;
+    // (the colour behind enters the gradient only through <S, dL/dpixel>: ONE running scalar Sd instead of three channels)
+    float Tr = Tfin, Sd = 0.0f;
     // Not the last segment, and this pixel has contributors behind it: start from the forward checkpoint at `hi`.
     // T in front of entry hi; S = colour composited behind it, normalised by that T.  (A pixel with ncq <= hi has
     // nothing behind: final state.  ncq > hi implies the forward reached that boundary with this pixel live.)
@@ -352,7 +355,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         const float4 cf = ckpt[(size_t)cks * 256 + tid];
         const float rT = 1.0f / cb.x;
         Tr = cb.x;
-        S0 = (cf.y - cb.y) * rT; S1 = (cf.z - cb.z) * rT; S2 = (cf.w - cb.w) * rT;
+        Sd = fmaf((cf.w - cb.w) * rT, d2, fmaf((cf.z - cb.z) * rT, d1, (cf.y - cb.y) * rT * d0));
     }
     uint32_t m = ncq;
 #pragma unroll
@@ -369,7 +372,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         const int cnt = hi - base < SG_BB ? hi - base : SG_BB;
         // ---- stage (threads 0..127): records, quadrant mask, gradient-record slot
         uint32_t rslot = 0xffffffffu;
-        float opac = 0.0f;
+        float opac = 0.0f, cA = 0.0f, cB = 0.0f, cC = 0.0f;
         if (tid < cnt) {
             const int e = base + tid;
             const uint32_t gid = point_list[range.x + e];
@@ -382,51 +385,55 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             const uint32_t mk = e < max_contrib ? (uint32_t)pair_mask[range.x + e] : 0u;
             if (mk) {
                 const float4 a = recA[gid], b = recB[gid];
-                opac = b.y;
-                sA[tid] = a; sB[tid] = b; sC[tid] = c4.x;
+                opac = b.y; cA = a.z; cB = a.w; cC = b.x;
+                sR[tid][0] = a; sR[tid][1] = b; sR[tid][2].x = c4.x;
             }
             sM[tid] = mk;
         }
-        if (tid < SG_BB) { sFlag[0][tid] = 0; sFlag[1][tid] = 0; sFlag[2][tid] = 0; sFlag[3][tid] = 0; }
+        if (tid < SG_BB) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
+        }
         __syncthreads();
         // ---- each wave: the entries that can reach its quadrant, back to front
         if (base < maxq) {
             uint16_t *list = sList[wave];
             const int lim = maxq - base < cnt ? maxq - base : cnt;         // entries >= maxq touch no pixel here
             const int nl = sg_compact_quadrant(sM, lim, wave, lane, lt, list, SG_BB);
+            const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the batch
             for (int i = nl - 1; i >= 0; i--) {
-                const int k = list[i];
-                const uint32_t ee = (uint32_t)(base + k);
-                const float4 ga = sA[k], gb = sB[k];
-                const float gc = sC[k];
+                const uint32_t k = list[i];
+                const float4 ga = sR[k][0], gb = sR[k][1];
                 // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
                 const float G = sg_exp(power);
                 const float alpha = fminf(0.99f, gb.y * G);
-                const bool valid = (ee < ncq) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: record stays zero
+                const bool valid = (k < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
+                if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: the slot stays unset
+                const float gc = sR[k][2].x;
                 const float ae = valid ? alpha : 0.0f;
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
                 Tr = Tr * rinv;                                  // T in front of this entry
                 const float dchan = ae * Tr;
-                const float e0 = gb.z - S0, e1 = gb.w - S1, e2 = gc - S2;
-                float dLa = fmaf(e2, d2, fmaf(e1, d1, e0 * d0));
-                S0 = fmaf(ae, e0, S0); S1 = fmaf(ae, e1, S1); S2 = fmaf(ae, e2, S2);
-                dLa = fmaf(-tb, rinv, dLa * Tr);                // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
+                // <colour - colour behind, dL/dpixel>, and the colour behind moves in front of this entry
+                const float e = fmaf(gc, d2, fmaf(gb.w, d1, gb.z * d0)) - Sd;
+                Sd = fmaf(ae, e, Sd);
+                const float dLa = fmaf(-tb, rinv, e * Tr);      // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
                 const float w = valid ? G * dLa : 0.0f;          // = dL/dopacity contribution; dL/dG = o * dLa
-                // v[0..4]: sums of w*m; the per-Gaussian factors (-o W/2, -o H/2, -o/2) are applied once per record
+                // first and second moments of w over the pixels: dL/dmean is a per-entry combination of the first moments
+                // (conic . (sum w dx, sum w dy), applied once per record), and so are the factors (-o W/2, -o H/2, -o/2)
+                const float wx = w * dx, wy = w * dy;
                 float v[9];
-                v[0] = w * fmaf(dy, ga.w, dx * ga.z);
-                v[1] = w * fmaf(dx, ga.w, dy * gb.x);
-                const float wx = w * dx;
-                v[2] = wx * dx; v[3] = wx * dy; v[4] = w * dy * dy;
+                v[0] = wx; v[1] = wy;
+                v[2] = wx * dx; v[3] = wx * dy; v[4] = wy * dy;
                 v[5] = w;
                 v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;
                 float v8;
                 const float z = sg_reduce9(v, lane, &v8);
-                if ((lane & 7) == 0) sG[wave][k][ridx] = z;
-                if (lane == 63) { sG[wave][k][8] = v8; sFlag[wave][k] = 1; }
+                float *slot = sG[wave][k];
+                if ((lane & 7) == 0) slot[ridx] = z;
+                if (lane == 63) slot[8] = v8;
             }
         }
         __syncthreads();
@@ -435,12 +442,13 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             float s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
             for (int w = 0; w < 4; w++)
-                if (sFlag[w][tid]) {
+                if (__float_as_uint(sG[w][tid][8]) != SG_UNSET) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) s[q] += sG[w][tid][q];
                 }
             const float no = -opac, nh = 0.5f * no;              // -opacity, -opacity / 2
-            grec[3 * (size_t)rslot] = make_float4(no * ddelx_dx * s[0], no * ddely_dy * s[1], nh * s[2], nh * s[3]);
+            const float m0 = fmaf(cA, s[0], cB * s[1]), m1 = fmaf(cB, s[0], cC * s[1]);   // conic . first moments
+            grec[3 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s[2], nh * s[3]);
             grec[3 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
             grec[3 * (size_t)rslot + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
         }
