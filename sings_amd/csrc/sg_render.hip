@@ -366,7 +366,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    const int ridx = sg_red_idx(lane);
+    const int cslot = lane == 63 ? 8 : sg_red_idx(lane);
     for (int kb = (hi - 1) / SG_BB; kb >= lo / SG_BB; kb--) {
         const int base = kb * SG_BB;
         const int cnt = hi - base < SG_BB ? hi - base : SG_BB;
@@ -404,6 +404,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             for (int i = nl - 1; i >= 0; i--) {
                 const uint32_t k = list[i];
                 const float4 ga = sR[k][0], gb = sR[k][1];
+                const float gc = sR[k][2].x;
                 // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
                 const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
@@ -411,7 +412,6 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float alpha = fminf(0.99f, gb.y * G);
                 const bool valid = (k < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
                 if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: the slot stays unset
-                const float gc = sR[k][2].x;
                 const float ae = valid ? alpha : 0.0f;
                 const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
                 Tr = Tr * rinv;                                  // T in front of this entry
@@ -431,9 +431,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;
                 float v8;
                 const float z = sg_reduce9(v, lane, &v8);
-                float *slot = sG[wave][k];
-                if ((lane & 7) == 0) slot[ridx] = z;
-                if (lane == 63) slot[8] = v8;
+                float *slot = &sG[wave][k][cslot];               // lanes 0, 8, .., 56: their value's slot; lane 63: slot 8
+                if ((lane & 7) == 0) *slot = z;
+                if (lane == 63) *slot = v8;
             }
         }
         __syncthreads();
