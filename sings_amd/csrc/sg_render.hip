@@ -30,6 +30,16 @@
 #define SG_UNSET 0xffffffffu   // bit pattern (a NaN) of a quadrant-sum slot nobody wrote
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// The composite loops evaluate alpha = min(.99, o 2^p) with p = log2(e) * power: the staging thread scales the conic ONCE per
+// (tile, entry) -- (A', B', C') = (-log2(e)/2 A, -log2(e) B, -log2(e)/2 C) -- and the pixel loop needs five operations,
+// p = (A' dx + B' dy) dx + C' dy dy, instead of eight plus the multiplication by log2(e).  Forward and backward use the SAME
+// expression, so they take the same alpha >= 1/255 decisions.
+#define SG_KA (-0.5f * 1.44269504088896340736f)
+#define SG_KB (-1.44269504088896340736f)
+__device__ __forceinline__ float sg_power2(float Ap, float Bp, float Cp, float dx, float dy)
+{
+    return fmaf(Cp * dy, dy, fmaf(Ap, dx, Bp * dy) * dx);
+}
 
 // XCD-aware map: workgroup b runs on XCD b % 8 (round-robin dispatch).  Each XCD takes runs of SG_XCD_RUN consecutive
 // tiles (neighbouring tiles share Gaussians -> same L2), and the runs are dealt round-robin to the XCDs so that
@@ -115,7 +125,8 @@ __device__ __forceinline__ uint32_t sg_quad_mask(float4 a, float4 b, float X0, f
 }
 
 
-// entries of the staged batch whose mask has bit `w`, compacted in list order (wave-local)
+// entries of the staged batch whose mask has bit `w`, compacted in list order (wave-local); the list holds index * MUL
+template <int MUL>
 __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ sM, int cnt, int w, int lane,
                                                    unsigned long long lt, uint16_t *__restrict__ list, int batch)
 {
@@ -124,7 +135,7 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
         const int idx = c + lane;
         const bool bit = idx < cnt && ((sM[idx] >> w) & 1u);
         const unsigned long long bal = __ballot(bit);
-        if (bit) list[nl + __popcll(bal & lt)] = (uint16_t)idx;
+        if (bit) list[nl + __popcll(bal & lt)] = (uint16_t)(idx * MUL);     // MUL: the caller's record pitch in bytes, or 1
         nl += __popcll(bal);
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);
@@ -142,11 +153,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
                      uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
 {
-    __shared__ float4 sA[SG_FB];
-    __shared__ float4 sB[SG_FB];
-    __shared__ float sC[SG_FB];
+    __shared__ float4 sR[SG_FB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_FB];
-    __shared__ uint16_t sList[4][SG_FB];
+    __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
     __shared__ float4 sBox[4];
     (void)nblocks;
     const int tile = sg_tile_of_block(blockIdx.x);
@@ -172,12 +181,12 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // whose list is thousands of entries long runs alone on its CU -- nothing else hides the two dependent loads)
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
     float pc = 0.0f;
-    static_assert(SG_WSORT_MAX <= SG_FB && (SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 16, "sort buffers alias sA");
+    static_assert(SG_WSORT_MAX <= SG_FB && (SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 48, "sort buffers alias sR");
     if (n > 0 && n <= SG_WSORT_MAX) {
         // Short list (every list at cfg3): this workgroup sorts the tile's keys itself, in LDS, and hands the order to
         // the backward pass through point_list -- the separate sort pass of round 1 (18 us, all latency) is gone and the
         // sort of one tile overlaps the compositing of the other tiles resident on the CU.
-        uint64_t *sKey = (uint64_t *)sA;                    // aliases the staging buffer: consumed before the first batch
+        uint64_t *sKey = (uint64_t *)sR;                    // aliases the staging buffer: consumed before the first batch
         sg_sort_short_list(pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
         if (tid < n) {
             const uint64_t key = sKey[tid];
@@ -198,7 +207,9 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
         const int e = base + tid;
         if (e < n) {
-            sA[tid] = pa; sB[tid] = pb; sC[tid] = pc;
+            sR[tid][0] = make_float4(pa.x, pa.y, SG_KA * pa.z, SG_KB * pa.w);
+            sR[tid][1] = make_float4(SG_KA * pb.x, pb.y, pb.z, pb.w);
+            sR[tid][2].x = pc;
             const uint32_t mk = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
             sM[tid] = mk;
             pair_mask[range.x + e] = (uint8_t)mk;          // the backward composites exactly these (entry, quadrant) pairs
@@ -214,15 +225,17 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             ckpt[(size_t)(cks + (uint32_t)(base / SG_SEG)) * 256 + tid] = make_float4(Tr, C0, C1, C2);
         const int cnt = n - base < SG_FB ? n - base : SG_FB;
         uint16_t *list = sList[wave];
-        const int nl = sg_compact_quadrant(sM, cnt, wave, lane, lt, list, SG_FB);
+        const int nl = sg_compact_quadrant<48>(sM, cnt, wave, lane, lt, list, SG_FB);
+        uint32_t lastk = 0xffffffffu;                      // record offset of the last entry blended in this batch
         for (int i = 0; i < nl; i++) {
-            const int k = list[i];
-            const float4 ga = sA[k], gb = sB[k];
-            const float gc = sC[k];
+            const uint32_t ko = list[i];
+            const float4 *rec = (const float4 *)((const char *)&sR[0][0] + ko);
+            const float4 ga = rec[0], gb = rec[1];
+            const float gc = rec[2].x;
             // straight-line, predicated: no exec-mask branches
             const float dx = ga.x - pxf, dy = ga.y - pyf;
-            const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
-            const float alpha = fminf(0.99f, gb.y * sg_exp(power));
+            const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);
+            const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
             const float test_T = Tr * (1.0f - alpha);
             const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
             const bool term = valid & (test_T < 0.0001f);
@@ -230,9 +243,10 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             const float w = blend ? alpha * Tr : 0.0f;
             C0 = fmaf(gb.z, w, C0); C1 = fmaf(gb.w, w, C1); C2 = fmaf(gc, w, C2);
             Tr = blend ? test_T : Tr;
-            last = blend ? (uint32_t)(base + k + 1) : last;
+            lastk = blend ? ko : lastk;
             done = done | term;
         }
+        if (lastk != 0xffffffffu) last = (uint32_t)base + lastk / 48u + 1u;
     }
     if (cks < ck_cap) ckpt[(size_t)cks * 256 + tid] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
     if (inside) {
@@ -314,7 +328,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
                      const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask)
 {
-    __shared__ float4 sR[SG_BB][3];            // staged entry: (mean x, mean y, A, B) (C, opacity, colour 0, 1) (colour 2, -, -, -)
+    __shared__ float4 sR[SG_BB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_BB];
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch; [8] = SG_UNSET: quadrant w wrote nothing
@@ -386,7 +400,9 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             if (mk) {
                 const float4 a = recA[gid], b = recB[gid];
                 opac = b.y; cA = a.z; cB = a.w; cC = b.x;
-                sR[tid][0] = a; sR[tid][1] = b; sR[tid][2].x = c4.x;
+                sR[tid][0] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
+                sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
+                sR[tid][2].x = c4.x;
             }
             sM[tid] = mk;
         }
@@ -399,7 +415,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         if (base < maxq) {
             uint16_t *list = sList[wave];
             const int lim = maxq - base < cnt ? maxq - base : cnt;         // entries >= maxq touch no pixel here
-            const int nl = sg_compact_quadrant(sM, lim, wave, lane, lt, list, SG_BB);
+            const int nl = sg_compact_quadrant<1>(sM, lim, wave, lane, lt, list, SG_BB);
             const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the batch
             for (int i = nl - 1; i >= 0; i--) {
                 const uint32_t k = list[i];
@@ -407,8 +423,8 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const float gc = sR[k][2].x;
                 // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
                 const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = fmaf(-0.5f, fmaf(ga.z * dx, dx, gb.x * dy * dy), -(ga.w * dx) * dy);
-                const float G = sg_exp(power);
+                const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);   // the forward's expression: same decisions
+                const float G = __builtin_amdgcn_exp2f(power);
                 const float alpha = fminf(0.99f, gb.y * G);
                 const bool valid = (k < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
                 if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: the slot stays unset
