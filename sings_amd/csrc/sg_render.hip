@@ -26,7 +26,7 @@
 #include "sg_sort.h"
 
 #define SG_FB 256         // forward: list entries staged per batch (one per thread)
-#define SG_BB 128         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
+#define SG_BB 64         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
 #define SG_UNSET 0xffffffffu   // bit pattern (a NaN) of a quadrant-sum slot nobody wrote
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
@@ -143,7 +143,7 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
     return nl;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
                      uint64_t *__restrict__ point_keys, const float4 *__restrict__ recA,
@@ -318,7 +318,7 @@ __device__ __forceinline__ int sg_red_idx(int lane)
     return base + 4 * half;
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
