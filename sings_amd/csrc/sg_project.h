@@ -120,34 +120,32 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     if (hist)                                     // few-tiles regime: this workgroup's per-tile pair counts live in LDS
         for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0u;
     __syncthreads();
+    // The allocator's answer is needed only where slots are WRITTEN (recC's offset, the pair records): thread 0 keeps it in a
+    // register until the barrier below, and every wave first issues its returning tile-counter atomics -- the allocator word
+    // serves ~88 requests per microsecond chip-wide (782 workgroups: ~9 us of queue), which used to be a barrier everybody sat at.
+    uint32_t bb = 0u;
     if (threadIdx.x == 0) {
         uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
-        if (SG_EXP & 16) sBlockBase = blockIdx.x * 1100u;
-        else sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
+        if (SG_EXP & 16) bb = blockIdx.x * 1100u;
+        else bb = t ? atomicAdd(&bn.header[2], t) : 0u;
     }
-    __syncthreads();
-    uint32_t base = sBlockBase;
-    for (int w = 0; w < wave_; w++) base += sWaveTot[w];
     const uint32_t rmin = (uint32_t)o.x0 | ((uint32_t)o.y0 << 16);
     const uint32_t rwh = (uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16);
     if (live) {
-        uint32_t goff = base + incl - o.tt;
         radii[idx] = o.mr;
         g.recA[idx] = make_float4(o.pix[0], o.pix[1], o.conic[0], o.conic[1]);
         g.recB[idx] = make_float4(o.conic[2], o.mr ? opac : 0.0f, o.rgb[0], o.rgb[1]);
-        g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(goff), __uint_as_float(rmin), __uint_as_float(rwh));
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
-    if ((SG_EXP & 8) && !hist) return;
-    if (total == 0 && !hist) return;              // wave-uniform (with the LDS histogram the workgroup barriers follow)
+    const bool expand = !((SG_EXP & 8) && !hist) && (total != 0 || hist);     // wave-uniform
     sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
     // four pairs per lane per round: the four returning atomics are in flight together
-    for (uint32_t p0 = 0; p0 < total; p0 += 256) {
-        uint32_t tile[4], local[4], gj[4];
+    uint32_t tile[4], local[4], gj[4];
+    auto take = [&](uint32_t p0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = p0 + 64 * u + lane;
@@ -171,11 +169,22 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                                 : atomicAdd(&bn.tile_count[tile[u]], 1u);
             }
         }
+    };
+    if (expand) take(0u);                              // the first (at cfg3: the only) round is in flight across the barrier
+    if (threadIdx.x == 0) sBlockBase = bb;
+    __syncthreads();
+    uint32_t base = sBlockBase;
+    for (int w = 0; w < wave_; w++) base += sWaveTot[w];
+    if (live) g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(base + incl - o.tt), __uint_as_float(rmin), __uint_as_float(rwh));
+    if (expand) {
+        for (uint32_t p0 = 0; p0 < total; p0 += 256) {
+            if (p0) take(p0);
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const uint32_t p = p0 + 64 * u + lane;
-            const uint32_t slot = base + p;
-            if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
+            for (int u = 0; u < 4; u++) {
+                const uint32_t p = p0 + 64 * u + lane;
+                const uint32_t slot = base + p;
+                if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
+            }
         }
     }
     if (hist) {
