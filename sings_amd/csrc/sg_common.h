@@ -10,6 +10,7 @@
 // Kernel experiments (tools/build_variants.sh builds libsings_hip_exp<N>.so with -DSG_EXP=<N>; the product is SG_EXP = 0):
 //   4 scan and scatter as two launches     8 / 16 / 32 forward preprocess without pair expansion / allocator / SH (timing only,
 //   WRONG results)     64 long-list sort + merge kernels not launched (valid while every tile list has <= 256 entries)
+//   8192 / 16384 / 32768 weight-gradient kernel without the partial stores / without MFMAs / with sleeps instead (timing only)
 #ifndef SG_EXP
 #define SG_EXP 0
 #endif
