@@ -352,6 +352,12 @@ def main_raster(a):
     _log(f"R = {R}; warm-up ({a.warmup} steps of {k_views} views on {n_streams} streams)")
     for _ in range(a.warmup):
         step()
+    if os.environ.get("SINGS_BENCH_HOSTTIME"):                    # how long does the host take to SUBMIT a step? (GPU idle at the start)
+        import time as _t
+        for _ in range(3):
+            torch.cuda.synchronize(dev); t0 = _t.perf_counter(); step(); t1 = _t.perf_counter(); torch.cuda.synchronize(dev)
+            t2 = _t.perf_counter()
+            _log(f"host submission {1e3 * (t1 - t0):.3f} ms, step complete after {1e3 * (t2 - t0):.3f} ms")
     _log(f"timed region ({a.steps} steps)")
     el = timed_region(dist, dev, a.steps, step)
     _log(f"{el / a.steps * 1e3:.3f} ms per step; one view per step")
