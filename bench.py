@@ -674,7 +674,9 @@ def main_train(a):
             p.grad = None
         loss, ld, ex = step_mod(A_static, rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
         loss.backward()
-        return {k: v.detach().clone() for k, v in ld.items()}      # (no autograd graph kept alive across the end of a capture)
+        keys = list(ld.keys())                                      # (no autograd graph kept alive across the end of a capture;
+        vals = torch.stack([ld[k].detach().reshape(()) for k in keys])   # one launch for all the scalars)
+        return {k: vals[i] for i, k in enumerate(keys)}
 
     cap_pairs = 0
     for f in range(0, F, 8):                                     # synchronous sizing steps: 1.25 x the largest pair count
@@ -685,11 +687,22 @@ def main_train(a):
     _rz.set_deferred_overflow_check(True, capacity_pairs=cap_pairs)
     if os.environ.get("SINGS_TORCH_PROFILE"):                    # which torch ops (copies, additions) sit between the library's kernels
         from torch.profiler import ProfilerActivity, profile
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
             for _ in range(2):
                 step_body()
             torch.cuda.synchronize()
-        print(prof.key_averages().table(sort_by="cuda_time_total", row_limit=45, max_name_column_width=60), file=sys.stderr)
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="cuda_time_total", row_limit=120, max_name_column_width=50,
+                                                                 max_shapes_column_width=60), file=sys.stderr)
+        # every aten op that launches something, with the first frame of this repository on its stack
+        seen = {}
+        for ev in prof.events():
+            dt = getattr(ev, "device_time_total", 0) or getattr(ev, "cuda_time_total", 0) or 0
+            if ev.name.startswith("aten::") and dt > 0 and not any(c.name.startswith("aten::") for c in ev.cpu_children):
+                fr = next((f for f in (ev.stack or []) if "/sings_amd/" in f or "bench.py" in f), "?")
+                k = (ev.name, str(ev.input_shapes)[:60], fr.strip()[-90:])
+                c = seen.setdefault(k, [0, 0.0]); c[0] += 1; c[1] += dt
+        for (n, sh, fr), (c, t) in sorted(seen.items(), key=lambda kv: -kv[1][1]):
+            print(f"ATEN {n:22s} x{c:3d} {t:8.1f} us  {sh:60s} {fr}", file=sys.stderr)
     graph, ld_static = None, None
     if not a.eager:
         # the whole step (decode -> raster -> losses -> backward, ~600 launches) replayed from ONE HIP graph

@@ -58,9 +58,11 @@ class _PhotoLoss(torch.autograd.Function):
         l1_w, ssim_w, W, H = ctx.args
         lib = _lib.load()
         dev = raw.device
-        zero = torch.zeros((), dtype=torch.float32, device=dev)
-        up = torch.stack([zero if g_l1 is None else g_l1.reshape(()).float(),
-                          zero if g_ssim is None else g_ssim.reshape(()).float()]).contiguous()
+        if g_l1 is None or g_ssim is None:
+            zero = torch.zeros((), dtype=torch.float32, device=dev)
+            g_l1 = zero if g_l1 is None else g_l1
+            g_ssim = zero if g_ssim is None else g_ssim
+        up = torch.stack([g_l1.reshape(()).float(), g_ssim.reshape(()).float()])
         out = torch.empty_like(raw)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

@@ -71,6 +71,6 @@ class AvatarStep(torch.nn.Module):
         elif has_reg:
             regularisers()
         loss_dict.update(reg)
-        loss = sum(loss_dict.values())
+        loss = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()      # two launches, not one addition per term
         loss_dict["loss"] = loss
         return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
