@@ -86,6 +86,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--morton", action="store_true", help="avatar / train workloads: store the canonical Gaussians in Morton order")
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
+    ap.add_argument("--no-wgrad-overlap", action="store_true",
+                    help="train workload: weight-gradient kernels on the backward stream instead of a side stream")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
@@ -628,7 +630,8 @@ def main_train(a):
     import torch
     rank, world, dev, dist, dinfo = dist_setup(a)
     from sings_amd.body import joint_transforms
-    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField, overlap_weight_grads
+    overlap_weight_grads(not a.no_wgrad_overlap)     # (the step sets every .grad to None first: the mode's precondition)
     from sings_amd.dp import FrameSharder
     from sings_amd.rasterizer import GaussianRasterizationSettings
     from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm

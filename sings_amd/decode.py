@@ -173,6 +173,36 @@ def _lin_fwd(x, W, b, act, row_offset):
     return h, aux, Wc
 
 
+# ---- weight gradients beside the backward chain -----------------------------------------------------------------------------
+# dW = dz^T x is needed by nobody downstream in the backward pass, and sg_weight_grad is bound by the matrix cores (one workgroup
+# per CU) while the input-gradient kernels of the layers in front of it are bound by HBM: run on a second stream it fills the idle
+# half of either.  Opt-in (`overlap_weight_grads(True)`): the gradients are complete when backward() RETURNS (the streams join in
+# an end-of-backward callback), so parameters must not carry a .grad that autograd would add to DURING the pass -- true for the
+# usual `optimizer.zero_grad()` (set_to_none) loop, not for gradient accumulation over several backward() calls.
+_WG = {"on": False, "streams": {}, "armed": False}
+
+
+def overlap_weight_grads(flag=True):
+    """Run the decoders' weight-gradient kernels on a side stream, concurrently with the rest of the backward pass."""
+    _WG["on"] = bool(flag)
+
+
+def _wg_join():
+    _WG["armed"] = False
+    for dev_index, side in _WG["streams"].items():
+        torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(side)
+
+
+def _wg_stream(dev):
+    side = _WG["streams"].get(dev.index)
+    if side is None:
+        side = _WG["streams"][dev.index] = torch.cuda.Stream(dev)
+    if not _WG["armed"]:
+        torch.autograd.Variable._execution_engine.queue_callback(_wg_join)     # joins when this backward pass ends
+        _WG["armed"] = True
+    return side
+
+
 def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
     """dz = dh * act'(z) in the prologue of dx = dz W (sg_linear_backward), then dW = dz^T x, db = column sums (sg_weight_grad).
     ``dx_into``: an existing [N,Cin] gradient this layer ADDS its dx to (sg_linear_backward_accumulate)."""
@@ -200,8 +230,18 @@ def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
             dW = torch.empty_like(W, dtype=torch.float32)
             db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
             ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
-            _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
-                       "weight gradient")
+            if _WG["on"]:
+                side, cur = _wg_stream(dev), torch.cuda.current_stream(dev)
+                side.wait_stream(cur)                                # dz (and x) are complete on the backward stream
+                with torch.cuda.stream(side):
+                    _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db),
+                                                  C.c_void_p(side.cuda_stream)), "weight gradient")
+                for t in (dz, x, ws2, dW, db):
+                    if t is not None:
+                        t.record_stream(side)
+            else:
+                _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
+                           "weight gradient")
     return dx, dW, db
 
 

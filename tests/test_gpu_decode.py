@@ -273,3 +273,35 @@ def test_linear_fan_accumulates_input_gradient_like_separate_layers(N, Cin):
         _close(o.detach().cpu().numpy(), r.detach().numpy(), what="fan output")
     for g, r in zip(gg, ref_g):
         _close(g.cpu().numpy(), r.numpy(), rtol=5e-5, atol_scale=5e-6, what="fan gradient")
+
+
+def test_weight_gradients_on_a_side_stream_match_the_inline_ones():
+    """decode.overlap_weight_grads(True): sg_weight_grad runs beside the backward chain and joins when backward() returns --
+    bit-identical parameter gradients (the kernels are deterministic), also when the pass runs twice in a row."""
+    from sings_amd import decode
+    dev = _dev()
+    torch.manual_seed(3)
+    g = decode.GeometryDecoder(n_features=96, isotropic=False).to(dev)
+    a = decode.AppearanceDecoder(n_features=96).to(dev)
+    x = torch.randn(20000, 96, device=dev)
+
+    def grads():
+        for p in list(g.parameters()) + list(a.parameters()):
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        g1, a1 = decode.linear_fan(xi, [(g.net[0], decode.ACT_GELU, None), (a.net[0], decode.ACT_GELU, None)])
+        og, oa = g(xi, first=g1), a(xi, first=a1)
+        loss = sum((v * v).sum() for v in (og['xyz_offsets'], og['rotations'], og['scales'], oa['shs'], oa['opacity']))
+        loss.backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in list(g.parameters()) + list(a.parameters())] + [xi.grad.clone()]
+
+    ref = grads()
+    decode.overlap_weight_grads(True)
+    try:
+        for _ in range(2):
+            got = grads()
+            for r, t in zip(ref, got):
+                assert torch.equal(r, t)
+    finally:
+        decode.overlap_weight_grads(False)
