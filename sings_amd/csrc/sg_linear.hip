@@ -250,8 +250,9 @@ template <int NQ> struct sgl_wide_cfg {
 };
 __host__ __device__ inline int sgl_wide_point_tiles(int TO, int ptcap) { const int pt = 4 / TO; return pt < ptcap ? pt : ptcap; }
 
-template <int NQ, bool BWD, bool GELU>
-__global__ void __launch_bounds__(256, BWD ? 2 : 3)   // backward: x' and aux prefetch registers on top of the 64 weight registers -> 2 per SIMD, no spills
+template <int NQ, bool BWD, bool GELU, bool VEC>
+__global__ void __launch_bounds__(256, (BWD || NQ == 12) ? 2 : 3)   // two register sets of look-ahead next to the weight registers: backward (x' and aux) and
+                                                                    // the 96-input forward (64-point tiles) run two waves per SIMD, no spills
 sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
                       const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
                       float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out, int accum)
@@ -282,59 +283,75 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     const int CO4 = CO * 4;
     const int voff0 = ((32 * pt + 4 * h) * CO + oc) * 4;
 
+    // ---- the X' tile: TWO tiles of look-ahead in registers (sets E and O).  With one tile in flight per workgroup the kernel moved
+    // in-flight bytes / latency = 12.6 MB / 4.3 us = 2.9 TB/s however the rest was arranged (PMC: every byte algorithmic, matrix cores
+    // busy 39 %).  Every load and store of the loop is a buffer operation whose range check stands in for the bounds tests (rows
+    // beyond N, a missing array), so the loop body has no branch around a memory instruction and hipcc can count its
+    // s_waitcnt vmcnt(n) -- with a branch it falls back to vmcnt(0), i.e. to waiting for the look-ahead it just issued.
     const int f4_per_row = CKP / 4;
     const int nf4 = R * f4_per_row;
-    const bool vec = (CK & 3) == 0;
-    float4 xr[PER], zr[BWD ? PER : 1];
-    auto fetch = [&](int n0) {
+    const unsigned xbytes = (unsigned)N * (unsigned)CK * 4u;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsz = __builtin_amdgcn_make_buffer_rsrc((void *)Z, 0, (BWD && act != 0 && Z) ? xbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsd = __builtin_amdgcn_make_buffer_rsrc(dz_out, 0, (BWD && act != 0 && dz_out) ? xbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(out0, 0, (BWD && accum) ? obytes : 0u, 0x00020000);   // old dx (accumulate)
+    const int CK4 = CK * 4;
+    int xoff[PER], lofs[PER];                                             // byte offset inside a tile (out of range: not this thread's), LDS float index
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const int f = tid + 256 * q, row = f / f4_per_row, c = 4 * (f - row * f4_per_row);
+        xoff[q] = (f < nf4 && c < CK) ? (row * CK + c) * 4 : 0x7ffffff0;
+        lofs[q] = f < nf4 ? row * XS + c : -1;
+    }
+    constexpr bool vec = VEC;                                              // CK a multiple of 4 (compile time: no branch around a load)
+    auto ld4 = [&](const __amdgpu_buffer_rsrc_t &rs, int off) {
+        float4 v;
+        if (vec) {
+            const auto u = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0);
+            v = make_float4(__uint_as_float(u[0]), __uint_as_float(u[1]), __uint_as_float(u[2]), __uint_as_float(u[3]));
+        } else {                                                           // CK not a multiple of 4: element loads; the row end by the column test
+            const int c = (off % CK4) >> 2;                                // (off < 2^31: a real offset)
+            float e[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                e[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (off != 0x7ffffff0 && c + u < CK) ? off + 4 * u : 0x7ffffff0, 0, 0));
+            v = make_float4(e[0], e[1], e[2], e[3]);
+        }
+        return v;
+    };
+    float4 xrE[PER], xrO[PER], zrE[BWD ? PER : 1], zrO[BWD ? PER : 1];
+    auto fetch = [&](float4 (&xr)[PER], float4 (&zr)[BWD ? PER : 1], int n0) {
+        const int t0 = n0 * CK4;                                           // (n0 <= N + 2 grid tiles: the launch keeps this below 2^31)
 #pragma unroll
         for (int q = 0; q < PER; q++) {
-            const int f = tid + 256 * q;
-            float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f), zz = v;
-            if (f < nf4) {
-                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
-                if (n < N && c < CK) {
-                    if (vec) {
-                        v = *(const float4 *)(X + (size_t)n * CK + c);
-                        if (BWD && act != 0) zz = *(const float4 *)(Z + (size_t)n * CK + c);
-                    } else {
-                        float e[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, g[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-                        for (int u = 0; u < 4; u++)
-                            if (c + u < CK) {
-                                e[u] = X[(size_t)n * CK + c + u];
-                                if (BWD && act != 0) g[u] = Z[(size_t)n * CK + c + u];
-                            }
-                        v = make_float4(e[0], e[1], e[2], e[3]); zz = make_float4(g[0], g[1], g[2], g[3]);
-                    }
-                }
-            }
-            xr[q] = v;
-            if (BWD) zr[q] = zz;
+            const int off = xoff[q] == 0x7ffffff0 ? 0x7ffffff0 : xoff[q] + t0;
+            xr[q] = ld4(rsx, off);
+            if (BWD) zr[q] = ld4(rsz, off);
         }
     };
-    auto stash = [&](int buf, int n0) {
+    auto stash = [&](const float4 (&xr)[PER], const float4 (&zr)[BWD ? PER : 1], int buf, int n0) {
+        const int t0 = n0 * CK4;
 #pragma unroll
         for (int q = 0; q < PER; q++) {
-            const int f = tid + 256 * q;
-            if (f < nf4) {
-                const int row = f / f4_per_row, c = 4 * (f - row * f4_per_row), n = n0 + row;
-                float4 v = xr[q];
-                if (BWD && act != 0) {
-                    const float4 zz = zr[q];
-                    v.x *= sgl_act_grad_aux(act, zz.x); v.y *= sgl_act_grad_aux(act, zz.y);
-                    v.z *= sgl_act_grad_aux(act, zz.z); v.w *= sgl_act_grad_aux(act, zz.w);
-                    if (dz_out && n < N && c < CK) {
-                        if (vec) *(float4 *)(dz_out + (size_t)n * CK + c) = v;
-                        else {
-                            const float e[4] = { v.x, v.y, v.z, v.w };
+            float4 v = xr[q];
+            if (BWD && act != 0) {
+                const float4 zz = zr[q];
+                v.x *= sgl_act_grad_aux(act, zz.x); v.y *= sgl_act_grad_aux(act, zz.y);
+                v.z *= sgl_act_grad_aux(act, zz.z); v.w *= sgl_act_grad_aux(act, zz.w);
+                const int off = xoff[q] == 0x7ffffff0 ? 0x7ffffff0 : xoff[q] + t0;
+                if (vec) {
+                    typedef unsigned sgl_u4 __attribute__((ext_vector_type(4)));
+                    const sgl_u4 u = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rsd, off, 0, 0);                       // dz
+                } else {
+                    const float e[4] = { v.x, v.y, v.z, v.w };
+                    const int c = (off % CK4) >> 2;
 #pragma unroll
-                            for (int u = 0; u < 4; u++) if (c + u < CK) dz_out[(size_t)n * CK + c + u] = e[u];
-                        }
-                    }
+                    for (int u = 0; u < 4; u++)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[u]), rsd, (off != 0x7ffffff0 && c + u < CK) ? off + 4 * u : 0x7ffffff0, 0, 0);
                 }
-                *(float4 *)&sXd[buf * TS + row * XS + c] = v;
             }
+            if (lofs[q] >= 0) *(float4 *)&sXd[buf * TS + lofs[q]] = v;
         }
     };
     // one output register of a finished tile: bias + activation (forward), two 128-B row segments per store
@@ -371,53 +388,56 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
         }
         return acc;
     };
-    const int ntiles = (N + R - 1) / R;
+    const int ntiles = (N + R - 1) / R, G = gridDim.x;
     int tile = blockIdx.x;                                                 // grid <= ntiles
-    fetch(tile * R); stash(0, tile * R);
+    fetch(xrE, zrE, tile * R);
+    fetch(xrO, zrO, (tile + G) * R);                                       // (beyond the last tile: out of range, zeros)
+    stash(xrE, zrE, 0, tile * R);
     __syncthreads();
-    // Every load so far (the weights!) has landed: said HERE, unconditionally, or the compiler -- which cannot see that the
-    // conditional waits above covered them -- puts an s_waitcnt vmcnt(0) in front of the first MFMA of EVERY tile, right behind
-    // the prefetch it was meant to overlap.
+    // Everything issued so far (the weights!) has landed: said HERE, once, or the compiler -- merging the loop entry with the back
+    // edge -- keeps a conservative wait in front of the first MFMA of every tile.
     __builtin_amdgcn_s_waitcnt(0x0F70);                                    // vmcnt(0)
     sg_v16f accp;
 #pragma unroll
     for (int r = 0; r < 16; r++) accp[r] = 0.0f;
-    int n0p = -1, buf = 0;
-    for (; tile < ntiles; tile += gridDim.x, buf ^= 1) {
-        const int next = tile + gridDim.x;
-        if (next < ntiles) fetch(next * R);                                // in flight during the MFMAs below
+    int n0p = N;                                                           // no finished tile yet
+    // one tile: the loads of tile + 2 G go out, the tile in LDS buffer `buf` is multiplied, tile + G moves from registers to LDS
+    auto round = [&](float4 (&xa)[PER], float4 (&za)[BWD ? PER : 1], const float4 (&xb)[PER], const float4 (&zb)[BWD ? PER : 1],
+                     int t, int buf) {
+        fetch(xa, za, (t + 2 * G) * R);
         if (BWD) {
-            // no element-wise work to hide: dx leaves as soon as the tile's MFMAs are done (the stores are asynchronous)
+            // no element-wise work to hide: dx leaves as soon as the tile's MFMAs are done (the stores are asynchronous);
+            // accumulate (a layer input with several consumers, dx += dz W): the old values are requested before the MFMAs
             if (active) {
-                // accumulate (a layer input with several consumers: dx += dz W): the old values are requested before the MFMAs
                 float old[16];
 #pragma unroll
-                for (int r = 0; r < 16; r++) old[r] = 0.0f;
-                if (accum) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs0, voff0 + (tile * R + 8 * (r >> 2) + (r & 3)) * CO4, 0, 0));
-                }
+                for (int r = 0; r < 16; r++)
+                    old[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsa, voff0 + (t * R + 8 * (r >> 2) + (r & 3)) * CO4, 0, 0));
                 sg_v16f acc = mma(std::false_type{}, buf, accp, 0);
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[r] += old[r];
 #pragma unroll
-                for (int r = 0; r < 16; r++) emit(acc, r, tile * R);
+                for (int r = 0; r < 16; r++) emit(acc, r, t * R);
             }
-            if (next < ntiles) stash(buf ^ 1, next * R);
+            stash(xb, zb, buf ^ 1, (t + G) * R);
             __syncthreads();
         } else {
+            // (the first tile runs the same block with n0p = N: its "previous tile" stores fall outside the arrays and are dropped --
+            // a separate epilogue-free block would be a second path with a different store count, and the compiler would wait at the
+            // stash for the lower one)
             sg_v16f acc = accp;
-            if (active) {
-                if (n0p >= 0) acc = mma(std::true_type{}, buf, accp, n0p);
-                else acc = mma(std::false_type{}, buf, accp, 0);
-            }
-            if (next < ntiles) stash(buf ^ 1, next * R);                   // the other buffer: last read one iteration ago
+            if (active) acc = mma(std::true_type{}, buf, accp, n0p);
+            stash(xb, zb, buf ^ 1, (t + G) * R);                           // the other buffer: last read one iteration ago
             __syncthreads();
-            accp = acc; n0p = tile * R;
+            accp = acc; n0p = t * R;
         }
+    };
+    for (; tile < ntiles; tile += 2 * G) {
+        round(xrE, zrE, xrO, zrO, tile, 0);
+        if (tile + G >= ntiles) break;                                     // (a break, not an `if` around the second half: the back edge keeps its counts)
+        round(xrO, zrO, xrE, zrE, tile + G, 1);
     }
-    if (!BWD && active && n0p >= 0) {
+    if (!BWD && active) {
 #pragma unroll
         for (int r = 0; r < 16; r++) emit(accp, r, n0p);
     }
@@ -432,22 +452,25 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
     const int nq = (CK + 7) / 8;
     if ((CO & 31) == 0 && !(act == 2 && row_offset) && ((long long)N + 128) * CO * 4 < 0x7fffffffLL) {
         // wide outputs: forward h -> out0, aux -> out1; backward dx -> out0, dz -> out1
+#define SGL_WIDE_GO(NQv, B, G, o0, o1, dz, acc)                                                                              \
+        do {                                                                                                                \
+            if ((CK & 3) == 0)                                                                                              \
+                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, B, G, true>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc);                                                  \
+            else                                                                                                            \
+                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, B, G, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc);                                                  \
+        } while (0)
 #define SGL_WIDE(NQv)                                                                                                      \
         do {                                                                                                                \
             using cfg = sgl_wide_cfg<NQv>;                                                                                  \
             const int R = 32 * sgl_wide_point_tiles(CO >> 5, cfg::PTCAP), ntiles = (N + R - 1) / R;                         \
-            const int gmax = BWD ? 512 : 768;                                                                               \
+            const int gmax = (BWD || NQv == 12) ? 512 : 768;                                                                \
             const int grid = ntiles < gmax ? ntiles : gmax;                                                                 \
             const size_t dyn = (size_t)2 * R * cfg::XS * sizeof(float);                                                     \
-            if (BWD)                                                                                                        \
-                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, true, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, (float *)nullptr, out1, accum);                                     \
-            else if (act == 1)                                                                                              \
-                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, true>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr, 0);                                     \
-            else                                                                                                            \
-                hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, false, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, out0, out1, (float *)nullptr, 0);                                     \
+            if (BWD) SGL_WIDE_GO(NQv, true, false, out0, (float *)nullptr, out1, accum);                                    \
+            else if (act == 1) SGL_WIDE_GO(NQv, false, true, out0, out1, (float *)nullptr, 0);                              \
+            else SGL_WIDE_GO(NQv, false, false, out0, out1, (float *)nullptr, 0);                                           \
         } while (0)
         if (nq <= 1) SGL_WIDE(1);
         else if (nq <= 4) SGL_WIDE(4);
@@ -456,6 +479,7 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
         else if (nq <= 12) SGL_WIDE(12);
         else SGL_WIDE(16);
 #undef SGL_WIDE
+#undef SGL_WIDE_GO
         return 0;
     }
     if (accum) return 2;                                                    // only the wide kernel accumulates
