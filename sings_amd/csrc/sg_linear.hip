@@ -90,10 +90,20 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
     float a[HALF];
     {
         const int co = 32 * cb + j;
+        if (m_ck_stride == 1 && (m_co_stride & 3) == 0 && (CK & 3) == 0) {   // forward, row-major W: a lane's registers are consecutive in memory
 #pragma unroll
-        for (int s = 0; s < HALF; s++) {
-            const int k = h * HALF + s;
-            a[s] = (active && co < CO && k < CK) ? Mw[(size_t)co * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+            for (int s = 0; s < HALF; s += 4) {
+                const int k = h * HALF + s;
+                const float4 w4 = (active && co < CO && k < CK) ? *(const float4 *)(Mw + (size_t)co * m_co_stride + k)
+                                                                 : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                a[s] = w4.x; a[s + 1] = w4.y; a[s + 2] = w4.z; a[s + 3] = w4.w;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < HALF; s++) {
+                const int k = h * HALF + s;
+                a[s] = (active && co < CO && k < CK) ? Mw[(size_t)co * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+            }
         }
     }
     // the 16 bias values of this lane's output columns (forward)
@@ -270,10 +280,21 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     const int oc = 32 * cb + j;
     // this wave's 32 columns of M as the B operand: a[s] = M(oc, h HALF + s)
     float a[HALF];
+    if (VEC && m_ck_stride == 1 && (m_co_stride & 3) == 0) {
+        // forward orientation (M = W, row-major): a lane's registers are consecutive in memory -> 16-B loads.  As 4-B loads (64 per
+        // lane, every one of them 64 different cache lines per wave) the 768 workgroups spent ~15 us of a 128 -> 128 layer fetching W.
 #pragma unroll
-    for (int s = 0; s < HALF; s++) {
-        const int k = h * HALF + s;
-        a[s] = (active && k < CK) ? Mw[(size_t)oc * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+        for (int s = 0; s < HALF; s += 4) {
+            const int k = h * HALF + s;
+            const float4 w4 = (active && k < CK) ? *(const float4 *)(Mw + (size_t)oc * m_co_stride + k) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            a[s] = w4.x; a[s + 1] = w4.y; a[s + 2] = w4.z; a[s + 3] = w4.w;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < HALF; s++) {
+            const int k = h * HALF + s;
+            a[s] = (active && k < CK) ? Mw[(size_t)oc * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+        }
     }
     const float bv = (!BWD && bias && active) ? bias[oc] : 0.0f;
     // output arrays as buffers: rows >= N (the ragged last tile) and a missing array fall outside num_records and are dropped
@@ -426,6 +447,17 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
             // a separate epilogue-free block would be a second path with a different store count, and the compiler would wait at the
             // stash for the lower one)
             sg_v16f acc = accp;
+            if (SG_EXP & 256) {
+                if (active) {
+                    acc = mma(std::false_type{}, buf, accp, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; r++) emit(acc, r, t * R);
+                }
+                stash(xb, zb, buf ^ 1, (t + G) * R);
+                __syncthreads();
+                n0p = N;
+                return;
+            }
             if (active) acc = mma(std::true_type{}, buf, accp, n0p);
             stash(xb, zb, buf ^ 1, (t + G) * R);                           // the other buffer: last read one iteration ago
             __syncthreads();
@@ -465,7 +497,7 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
         do {                                                                                                                \
             using cfg = sgl_wide_cfg<NQv>;                                                                                  \
             const int R = 32 * sgl_wide_point_tiles(CO >> 5, cfg::PTCAP), ntiles = (N + R - 1) / R;                         \
-            const int gmax = (BWD || NQv == 12) ? 512 : 768;                                                                \
+            const int gmax = 512;            /* two workgroups per CU: every workgroup loads the whole of M first */       \
             const int grid = ntiles < gmax ? ntiles : gmax;                                                                 \
             const size_t dyn = (size_t)2 * R * cfg::XS * sizeof(float);                                                     \
             if (BWD) SGL_WIDE_GO(NQv, true, false, out0, (float *)nullptr, out1, accum);                                    \
