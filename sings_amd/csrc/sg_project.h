@@ -282,7 +282,23 @@ __device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ g
     for (uint32_t c0 = wlo; c0 < whi; c0 += SG_REC_CHUNK) {
         const uint32_t n = whi - c0 < SG_REC_CHUNK ? whi - c0 : SG_REC_CHUNK;
         const float4 *src = grec + 3 * (size_t)c0;
-        for (uint32_t f = lane; f < 3 * n; f += 64) ((float4 *)l)[f] = src[f];
+        // all six 16-B loads of the chunk are issued before the first one is used (as a loop the compiler emitted load -> wait ->
+        // LDS write, ONE request in flight per wave: a memory latency per KiB); indices are clamped instead of tested, so nothing
+        // branches around a load, and the surplus lanes rewrite the last element
+        {
+            float4 v[SG_REC_CHUNK * 3 / 64];
+            const uint32_t last = 3 * n - 1;
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK * 3 / 64; i++) {
+                const uint32_t f = (uint32_t)lane + 64u * i;
+                v[i] = src[f < last ? f : last];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK * 3 / 64; i++) {
+                const uint32_t f = (uint32_t)lane + 64u * i;
+                ((float4 *)l)[f < last ? f : last] = v[i];
+            }
+        }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const uint32_t k0 = lo > c0 ? lo : c0, k1 = hi < c0 + n ? hi : c0 + n;
