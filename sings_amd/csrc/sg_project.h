@@ -120,15 +120,9 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     if (hist)                                     // few-tiles regime: this workgroup's per-tile pair counts live in LDS
         for (int t = threadIdx.x; t < T; t += blockDim.x) hist[t] = 0u;
     __syncthreads();
-    // The allocator's answer is needed only where slots are WRITTEN (recC's offset, the pair records): thread 0 keeps it in a
-    // register until the barrier below, and every wave first issues its returning tile-counter atomics -- the allocator word
-    // serves ~88 requests per microsecond chip-wide (782 workgroups: ~9 us of queue), which used to be a barrier everybody sat at.
-    uint32_t bb = 0u;
-    if (threadIdx.x == 0) {
-        uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
-        if (SG_EXP & 16) bb = blockIdx.x * 1100u;
-        else bb = t ? atomicAdd(&bn.header[2], t) : 0u;
-    }
+    // The allocator's answer is needed only where slots are WRITTEN (recC's offset, the pair records): every wave first issues its
+    // returning tile-counter atomics -- the allocator word serves ~88 requests per microsecond chip-wide (782 workgroups: ~9 us of
+    // queue), which used to be a barrier everybody sat at.
     const uint32_t rmin = (uint32_t)o.x0 | ((uint32_t)o.y0 << 16);
     const uint32_t rwh = (uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16);
     if (live) {
@@ -171,7 +165,14 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         }
     };
     if (expand) take(0u);                              // the first (at cfg3: the only) round is in flight across the barrier
-    if (threadIdx.x == 0) sBlockBase = bb;
+    // the allocator request goes out BEHIND this wave's tile-counter atomics (hipcc waits for a returning atomic right where it
+    // is issued -- its wave-aggregation wrapper reads the result with v_readfirstlane -- so issued first it stalled wave 0 in front
+    // of its own tile atomics: the workgroup's critical path was the allocator queue PLUS a round of tile atomics)
+    if (threadIdx.x == 0) {
+        uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
+        if (SG_EXP & 16) sBlockBase = blockIdx.x * 1100u;
+        else sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
+    }
     __syncthreads();
     uint32_t base = sBlockBase;
     for (int w = 0; w < wave_; w++) base += sWaveTot[w];
