@@ -313,15 +313,21 @@ sg_tp_sorted_scatter_kernel(SgTpDev d, int N, const float *__restrict__ G, const
     const int W = d.res[s][sg_comb[c][0]];
     uint32_t c00 = 0xffffffffu, c11 = 0;
     float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
-    for (int k = k0; k < k1; k += 8) {
-        float4 r[8];
-        float gi[8];
+    // eight slots per round, the NEXT round's sixteen loads in flight while this one is accumulated (indices clamped, not tested:
+    // no load behind a branch); without the look-ahead every round of eight points started with a full memory latency
+    float4 r[8], rn[8];
+    float gi[8], gn[8];
+    auto fetch = [&](float4 (&rr)[8], float (&gg)[8], int k) {
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             const int kk = min(k + j, k1 - 1);
-            r[j] = rp[kk];
-            gi[j] = k + j < k1 ? Gp[(size_t)kk * 32 + f] : 0.0f;
+            rr[j] = rp[kk];
+            gg[j] = Gp[(size_t)kk * 32 + f];
         }
+    };
+    fetch(r, gi, k0);
+    for (int k = k0; k < k1; k += 8) {
+        fetch(rn, gn, min(k + 8, k1 - 1));
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             if (k + j >= k1) break;
@@ -344,6 +350,8 @@ sg_tp_sorted_scatter_kernel(SgTpDev d, int N, const float *__restrict__ G, const
             acc10 += gi[j] * ((1.0f - wx) * wy);
             acc11 += gi[j] * (wx * wy);
         }
+#pragma unroll
+        for (int j = 0; j < 8; j++) { r[j] = rn[j]; gi[j] = gn[j]; }
     }
     if (c00 != 0xffffffffu) {
         const uint32_t dx = (c11 - c00) % (uint32_t)W;
