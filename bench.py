@@ -47,7 +47,9 @@ HBM_COPY_GBS = 6290.0
 XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU
 SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
 VALU_CYCLES_GUIDE = 2.0        # MI355X_MICROARCH.md constants table: one wave64 v_fma_f32 issues in 2 cycles
-VALU_CYCLES_MIX = 2.9          # tools/valu_probe.hip: measured issue cost of the backward composite's instruction mix
+VALU_CYCLES_MIX = 3.6          # issue cost of the backward composite's instruction mix, from tools/valu_probe.hip's per-kind costs: per
+                               # pass 6 lane swaps x 8.2 + 13 DPP x 4.2 + exp2, rcp x 8.2 + 6 cmp / select x 3.9 + ~45 plain x 2.6 cycles over 72
+                               # instructions (round 1's 95-instruction pass: 2.9 -- the instructions removed since were the cheap ones)
 
 
 _T0 = time.perf_counter()
@@ -435,8 +437,8 @@ def main_raster(a):
                     "cycles_per_instruction": kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr,
                     "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
                     "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / (kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr),
-                    "note": "peak = guide's 2 cycles per wave64 VALU instruction; frac_vs_measured_mix_cost uses the 2.9 cycles "
-                            "tools/valu_probe.hip measures for this kernel's instruction mix"}
+                    "note": "peak = guide's 2 cycles per wave64 VALU instruction; frac_vs_measured_mix_cost uses the 3.6 cycles per "
+                            "instruction that tools/valu_probe.hip's per-kind costs give for this kernel's instruction mix"}
     out = {
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
