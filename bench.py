@@ -632,8 +632,10 @@ def main_train(a):
     import torch
     rank, world, dev, dist, dinfo = dist_setup(a)
     from sings_amd.body import joint_transforms
-    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField, overlap_weight_grads
+    from sings_amd.decode import (AppearanceDecoder, GeometryDecoder, HexPlaneField, overlap_weight_grads,
+                                  prepare_triplane_backward_early)
     overlap_weight_grads(not a.no_wgrad_overlap)     # (the step sets every .grad to None first: the mode's precondition)
+    prepare_triplane_backward_early(not a.no_wgrad_overlap)   # (every captured forward is followed by its backward)
     from sings_amd.dp import FrameSharder
     from sings_amd.rasterizer import GaussianRasterizationSettings
     from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm

@@ -283,6 +283,12 @@ size_t sg_triplane_bwd_ws_bytes(const SgTriplane *tp, int N);
 int sg_triplane_forward(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, void *stream);
 int sg_triplane_backward(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
                          float *const dplanes[4][3], float *dxyz, void *stream);
+/* The same in two calls on ONE workspace: `_prepare` (texel-major planes, zeroed gradient planes, the three counting sorts of the
+ * points) needs only the points and the planes -- a quarter of the backward, all latency -- and may run any time after the forward,
+ * e.g. on a side stream while the decoders work; `_prepared` then needs dL/dfeats.  The planes must not change in between. */
+int sg_triplane_backward_prepare(const SgTriplane *tp, int N, const float *xyz, void *ws, void *stream);
+int sg_triplane_backward_prepared(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                                  float *const dplanes[4][3], float *dxyz, void *stream);
 /* Bias + activation around the decoders' library GEMMs (modules/decoders.py:16-110).  act: 0 identity, 1 GELU (erf),
  * 2 sigmoid(z + row_offset[n]) (AppearanceDecoder.opacity_offset; row_offset may be NULL), 3 log(exp(z) + 1).
  * forward: z = y + bias (stored if z_out != NULL), h = act(z); y, z_out, h_out [N,C] (h_out may alias y).

@@ -428,6 +428,23 @@ extern "C" int sg_triplane_backward(const SgTriplane *tp, int N, const float *xy
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_triplane_backward", e);
 }
+extern "C" int sg_triplane_backward_prepare(const SgTriplane *tp, int N, const float *xyz, void *ws, void *stream)
+{
+    if (sg_tp_check(tp)) return sg_fail("sg_triplane_backward_prepare: bad plane description", hipSuccess);
+    if (N <= 0 || !xyz || !ws) return sg_fail("sg_triplane_backward_prepare: bad argument", hipSuccess);
+    sg_launch_triplane_bwd_prepare(tp, N, xyz, ws, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_triplane_backward_prepare", e);
+}
+extern "C" int sg_triplane_backward_prepared(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                                             float *const dplanes[4][3], float *dxyz, void *stream)
+{
+    if (sg_tp_check(tp)) return sg_fail("sg_triplane_backward_prepared: bad plane description", hipSuccess);
+    if (N <= 0 || !xyz || !ws || !dfeats || !dplanes) return sg_fail("sg_triplane_backward_prepared: bad argument", hipSuccess);
+    sg_launch_triplane_bwd_run(tp, N, xyz, ws, dfeats, dplanes, dxyz, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_triplane_backward_prepared", e);
+}
 extern "C" size_t sg_bias_act_ws_bytes(int N, int C) { return sg_bias_act_ws_bytes_impl(N > 0 ? N : 1, C > 0 ? C : 1); }
 extern "C" int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
                                    float *z_out, float *h_out, void *stream)

@@ -162,6 +162,9 @@ size_t sg_triplane_bwd_ws_bytes_impl(const SgTriplane *tp, int N);
 void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st);
 int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
                            float *const dplanes[4][3], float *dxyz, hipStream_t st);
+int sg_launch_triplane_bwd_prepare(const SgTriplane *tp, int N, const float *xyz, void *ws, hipStream_t st);
+int sg_launch_triplane_bwd_run(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                           float *const dplanes[4][3], float *dxyz, hipStream_t st);
 size_t sg_bias_act_ws_bytes_impl(int N, int C);
 void sg_launch_bias_act_fwd(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
                             float *z_out, float *h_out, hipStream_t st);

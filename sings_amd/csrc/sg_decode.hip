@@ -528,48 +528,71 @@ size_t sg_triplane_bwd_ws_bytes_impl(const SgTriplane *tp, int N)
     return 2 * sg_align(floats * 4) + sg_align((size_t)tp->n_scales * 3 * n * 32 * 4) + 2 * sg_align(cw * 4) +
            sg_align(bw * 4) + 2 * sg_align(3 * n * 4) + sg_align((size_t)tp->n_scales * 3 * n * 16);
 }
-int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
-                           float *const dplanes[SG_TP_MAXS][3], float *dxyz, hipStream_t st)
+// The backward in two halves.  `prepare` needs only the points and the planes -- texel-major copy of the planes, zeroed gradient
+// planes, the three counting sorts -- and can run any time after the forward (e.g. on a side stream under the decoders: it is a
+// quarter of the backward and pure latency); `run` needs dL/dfeats.
+struct SgTpBwdWs { float *fm, *gfm, *G; uint32_t *count, *start, *bsum, *keys, *rank; float4 *cellrec; };
+static size_t sg_tp_bwd_carve(const SgTriplane *tp, int N, void *ws, SgTpDev *d, SgTpSort *g, SgTpBwdWs *w, size_t *cw_out)
 {
-    SgTpDev d; SgTpSort g; size_t cw, bw;
-    const size_t floats = sg_tp_layout(tp, &d), n = N;
-    sg_tp_sort_layout(tp, &g, &cw, &bw);
+    size_t cw, bw;
+    const size_t floats = sg_tp_layout(tp, d), n = N;
+    sg_tp_sort_layout(tp, g, &cw, &bw);
     char *b = (char *)ws;
-    float *fm = (float *)b; b += sg_align(floats * 4);
-    float *gfm = (float *)b; b += sg_align(floats * 4);
-    float *G = (float *)b; b += sg_align((size_t)tp->n_scales * 3 * n * 32 * 4);
-    uint32_t *count = (uint32_t *)b; b += sg_align(cw * 4);
-    uint32_t *start = (uint32_t *)b; b += sg_align(cw * 4);
-    uint32_t *bsum = (uint32_t *)b; b += sg_align(bw * 4);
-    uint32_t *keys = (uint32_t *)b; b += sg_align(3 * n * 4);
-    uint32_t *rank = (uint32_t *)b; b += sg_align(3 * n * 4);          // arrival rank inside the key, then sorted position
-    float4 *cellrec = (float4 *)b;
-    const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
-    sg_tp_upload(tp, d, fm, st);                              // (parameters may have changed since the forward call)
-    sg_zero_async(count, cw * 4, st);
+    w->fm = (float *)b; b += sg_align(floats * 4);
+    w->gfm = (float *)b; b += sg_align(floats * 4);
+    w->G = (float *)b; b += sg_align((size_t)tp->n_scales * 3 * n * 32 * 4);
+    w->count = (uint32_t *)b; b += sg_align(cw * 4);
+    w->start = (uint32_t *)b; b += sg_align(cw * 4);
+    w->bsum = (uint32_t *)b; b += sg_align(bw * 4);
+    w->keys = (uint32_t *)b; b += sg_align(3 * n * 4);
+    w->rank = (uint32_t *)b; b += sg_align(3 * n * 4);          // arrival rank inside the key, then sorted position
+    w->cellrec = (float4 *)b;
+    *cw_out = cw;
+    return floats;
+}
+int sg_launch_triplane_bwd_prepare(const SgTriplane *tp, int N, const float *xyz, void *ws, hipStream_t st)
+{
+    SgTpDev d; SgTpSort g; SgTpBwdWs w; size_t cw;
+    const size_t floats = sg_tp_bwd_carve(tp, N, ws, &d, &g, &w, &cw);
+    sg_tp_upload(tp, d, w.fm, st);                            // (parameters may have changed since the forward call)
+    sg_zero_async(w.count, cw * 4, st);
     const int nb = (N + 255) / 256;
     int max_keys = 0;
     for (int c = 0; c < 3; c++) max_keys = g.nkeys[c] > max_keys ? g.nkeys[c] : max_keys;
-    sg_zero_async(gfm, floats * 4, st);
+    sg_zero_async(w.gfm, floats * 4, st);
     const int nkb = max_keys / 1024 + 1;
-    hipLaunchKernelGGL(sg_tp_cell_count_kernel, dim3(nb, 3), dim3(256), 0, st, d, g, N, xyz, count, keys, rank);
-    hipLaunchKernelGGL(sg_tp_cell_bsum_kernel, dim3(nkb, 3), dim3(256), 0, st, g, count, bsum);
-    hipLaunchKernelGGL(sg_tp_cell_scan_kernel, dim3(nkb, 3), dim3(256), 0, st, g, count, bsum, start);
-    hipLaunchKernelGGL(sg_tp_cell_pos_kernel, dim3(nb, 3), dim3(256), 0, st, g, N, start, keys, rank);
-    hipLaunchKernelGGL(sg_tp_bwd_point_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, dfeats, rank, G, cellrec,
+    hipLaunchKernelGGL(sg_tp_cell_count_kernel, dim3(nb, 3), dim3(256), 0, st, d, g, N, xyz, w.count, w.keys, w.rank);
+    hipLaunchKernelGGL(sg_tp_cell_bsum_kernel, dim3(nkb, 3), dim3(256), 0, st, g, w.count, w.bsum);
+    hipLaunchKernelGGL(sg_tp_cell_scan_kernel, dim3(nkb, 3), dim3(256), 0, st, g, w.count, w.bsum, w.start);
+    hipLaunchKernelGGL(sg_tp_cell_pos_kernel, dim3(nb, 3), dim3(256), 0, st, g, N, w.start, w.keys, w.rank);
+    return 0;
+}
+int sg_launch_triplane_bwd_run(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                               float *const dplanes[SG_TP_MAXS][3], float *dxyz, hipStream_t st)
+{
+    SgTpDev d; SgTpSort g; SgTpBwdWs w; size_t cw;
+    sg_tp_bwd_carve(tp, N, ws, &d, &g, &w, &cw);
+    const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
+    hipLaunchKernelGGL(sg_tp_bwd_point_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, w.fm, dfeats, w.rank, w.G, w.cellrec,
                        dxyz);
     hipLaunchKernelGGL(sg_tp_sorted_scatter_kernel, dim3((N + 8 * SG_TP_RUN - 1) / (8 * SG_TP_RUN), tp->n_scales * 3),
-                       dim3(256), 0, st, d, N, G, cellrec, gfm);
+                       dim3(256), 0, st, d, N, w.G, w.cellrec, w.gfm);
     SgTpPlanes P;
     int maxHW = 0;
     for (int s = 0; s < tp->n_scales; s++)
         for (int c = 0; c < 3; c++) {
             const int HW = tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]];
-            P.src[s * 3 + c] = gfm + d.fm_off[s][c]; P.dst[s * 3 + c] = dplanes[s][c]; P.HW[s * 3 + c] = HW;
+            P.src[s * 3 + c] = w.gfm + d.fm_off[s][c]; P.dst[s * 3 + c] = dplanes[s][c]; P.HW[s * 3 + c] = HW;
             maxHW = HW > maxHW ? HW : maxHW;
         }
     hipLaunchKernelGGL(sg_plane_from_fm_kernel, dim3((maxHW + 31) / 32, tp->n_scales * 3), dim3(256), 0, st, P);
     return 0;
+}
+int sg_launch_triplane_bwd(const SgTriplane *tp, int N, const float *xyz, void *ws, const float *dfeats,
+                           float *const dplanes[SG_TP_MAXS][3], float *dxyz, hipStream_t st)
+{
+    sg_launch_triplane_bwd_prepare(tp, N, xyz, ws, st);
+    return sg_launch_triplane_bwd_run(tp, N, xyz, ws, dfeats, dplanes, dxyz, st);
 }
 
 void sg_launch_bias_act_fwd(int N, int C, int act, const float *y, const float *bias, const float *row_offset,

@@ -67,6 +67,25 @@ def _aabb_host(aabb):
     return hit[1]
 
 
+# ---- the point-only half of the tri-plane backward, early -------------------------------------------------------------------
+# A quarter of the tri-plane backward (texel-major planes, zeroed gradient planes, three counting sorts of the points: ~120 us at
+# 150 k points, all latency) needs neither dL/dfeats nor anything else the backward pass produces: it is launched from the FORWARD on
+# a side stream, where the decoders' forward hides it, and the backward only waits for its event.  On by default outside HIP-graph
+# capture; inside a capture (where an unjoined side stream is an error if backward() never runs) only after
+# `prepare_triplane_backward_early(True)`; `False` turns it off everywhere.
+_TP = {"mode": None, "streams": {}}
+
+
+def prepare_triplane_backward_early(flag=True):
+    _TP["mode"] = bool(flag)
+
+
+def _tp_early(dev):
+    if _TP["mode"] is False:
+        return False
+    return True if _TP["mode"] else not torch.cuda.is_current_stream_capturing()
+
+
 class _Triplane(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, aabb, n_scales, *planes):
@@ -84,6 +103,23 @@ class _Triplane(torch.autograd.Function):
             _lib.check(lib.sg_triplane_forward(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(feats), _stream(dev)), "triplane forward")
         ctx.save_for_backward(x, aabb, *planes)
         ctx.n_scales = n_scales
+        ctx.early = None
+        if any(ctx.needs_input_grad) and _tp_early(dev):
+            bws = torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
+            side = _TP["streams"].get(dev.index)
+            if side is None:
+                side = _TP["streams"][dev.index] = torch.cuda.Stream(dev)
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)
+            with torch.cuda.device(dev), torch.cuda.stream(side):
+                _lib.check(lib.sg_triplane_backward_prepare(C.byref(tp), N, _ptr(x), _ptr(bws), C.c_void_p(side.cuda_stream)),
+                           "triplane backward (prepare)")
+                ev = torch.cuda.Event()
+                ev.record(side)
+            bws.record_stream(side); x.record_stream(side)
+            for p in planes:
+                p.record_stream(side)
+            ctx.early = (bws, ev)
         return feats
 
     @staticmethod
@@ -95,7 +131,8 @@ class _Triplane(torch.autograd.Function):
         keep = []
         tp = _tp_struct(grids, aabb, keep)
         dev, N = x.device, int(x.shape[0])
-        ws = torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
+        early = ctx.early
+        ws = early[0] if early else torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
         dplanes = [torch.empty_like(p, dtype=torch.float32) for p in planes]
         arr = ((C.c_void_p * 3) * 4)()
         for s in range(n_scales):
@@ -104,8 +141,13 @@ class _Triplane(torch.autograd.Function):
         dxyz = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         df = dfeats.contiguous().float()
         with torch.cuda.device(dev):
-            _lib.check(lib.sg_triplane_backward(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(df), C.byref(arr), _ptr(dxyz),
-                                                _stream(dev)), "triplane backward")
+            if early:
+                torch.cuda.current_stream(dev).wait_event(early[1])      # the prepared half (launched by the forward)
+                ctx.early = None
+                fn = lib.sg_triplane_backward_prepared
+            else:
+                fn = lib.sg_triplane_backward
+            _lib.check(fn(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(df), C.byref(arr), _ptr(dxyz), _stream(dev)), "triplane backward")
         return (dxyz, None, None) + tuple(dplanes)
 
 

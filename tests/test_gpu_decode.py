@@ -305,3 +305,35 @@ def test_weight_gradients_on_a_side_stream_match_the_inline_ones():
                 assert torch.equal(r, t)
     finally:
         decode.overlap_weight_grads(False)
+
+
+def test_triplane_backward_prepared_early_or_inline():
+    """The point-only half of the tri-plane backward is launched by the forward on a side stream by default
+    (decode.prepare_triplane_backward_early); switched off, the backward does everything itself: the same gradients
+    (plane gradients to rounding -- float atomics --, point gradients bit-identical)."""
+    from sings_amd import decode
+    dev = _dev()
+    torch.manual_seed(11)
+    f = _field(dev)
+    x0 = (torch.rand(30000, 3, device=dev) * 2.2 - 1.1)
+    with torch.no_grad():
+        g = torch.randn_like(f(x0))
+
+    def grads():
+        for p in f.parameters():
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        f(x).backward(g)
+        torch.cuda.synchronize()
+        return x.grad.clone(), [p.grad.clone() for p in f.parameters() if p.requires_grad]
+
+    try:
+        decode.prepare_triplane_backward_early(False)
+        dx0, dp0 = grads()
+        decode.prepare_triplane_backward_early(True)
+        dx1, dp1 = grads()
+    finally:
+        decode._TP["mode"] = None
+    assert torch.equal(dx0, dx1)
+    for a, b in zip(dp0, dp1):
+        _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="plane gradient")
