@@ -177,9 +177,14 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     uint32_t base = sBlockBase;
     for (int w = 0; w < wave_; w++) base += sWaveTot[w];
     if (live) g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(base + incl - o.tt), __uint_as_float(rmin), __uint_as_float(rwh));
+    // round 0 (all of the wave's pairs at cfg3 / most of them on an avatar) stays in registers until its ranks are final: with the
+    // LDS histogram they are rebased here instead of being written, re-read and rewritten
+    uint32_t tile0[4], local0[4], gj0[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { tile0[u] = tile[u]; local0[u] = local[u]; gj0[u] = gj[u]; }
     if (expand) {
-        for (uint32_t p0 = 0; p0 < total; p0 += 256) {
-            if (p0) take(p0);
+        for (uint32_t p0 = 256; p0 < total; p0 += 256) {
+            take(p0);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t p = p0 + 64 * u + lane;
@@ -190,16 +195,38 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     }
     if (hist) {
         // one global returning atomic per (workgroup, touched tile) instead of one per pair -- on an avatar frame the
-        // per-pair atomics were 55 of the 80 us of this kernel -- then the workgroup-local ranks are rebased
+        // per-pair atomics were 55 of the 80 us of this kernel -- then the workgroup-local ranks are rebased.  Eight tiles per
+        // thread and round, the atomics of a round all in flight before the first answer is used (one at a time they were T / 256
+        // dependent round trips per thread).
         __syncthreads();
-        for (int t = threadIdx.x; t < T; t += blockDim.x) {
-            const uint32_t c = hist[t];
-            if (c) hist[t] = atomicAdd(&bn.tile_count[t], c);
+        for (int t0 = threadIdx.x; t0 < T; t0 += 8 * blockDim.x) {
+            uint32_t cnt[8], ans[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int t = t0 + u * blockDim.x;
+                cnt[u] = t < T ? hist[t] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) ans[u] = cnt[u] ? atomicAdd(&bn.tile_count[t0 + u * blockDim.x], cnt[u]) : 0u;
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (cnt[u]) hist[t0 + u * blockDim.x] = ans[u];
         }
         __syncthreads();
-        for (uint32_t p = lane; p < total; p += 64) {           // a lane re-reads exactly the slots it wrote above
+        for (uint32_t p = 256 + lane; p < total; p += 64) {      // later rounds: a lane re-reads exactly the slots it wrote above
             const uint32_t slot = base + p;
             if (slot < cap) bn.pair_local[slot] += hist[bn.pair_tile[slot]];
+        }
+    }
+    if (expand) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t p = 64 * u + lane;
+            const uint32_t slot = base + p;
+            if (p < total && slot < cap) {
+                bn.pair_gid[slot] = gj0[u]; bn.pair_tile[slot] = tile0[u];
+                bn.pair_local[slot] = local0[u] + (hist ? hist[tile0[u]] : 0u);
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
