@@ -814,16 +814,26 @@ sg_wgrad_reduce_kernel(const float *__restrict__ partial, const float *__restric
     const int total = Cout * Cin;
     const int per = (nwg + 15) / 16, w0 = sl * per, w1 = min(w0 + per, nwg);
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-    if (e < total) {
-        const int o = e / Cin, c = e - o * Cin;
-        const float *p = partial + (size_t)o * Cin + c;
-        const size_t st = (size_t)cout_pad * Cin;
-        int w = w0;
-        for (; w + 3 < w1; w += 4) { s0 += p[w * st]; s1 += p[(w + 1) * st]; s2 += p[(w + 2) * st]; s3 += p[(w + 3) * st]; }
-        for (; w < w1; w++) s0 += p[w * st];
-    } else if (db && e < total + Cout) {
-        const int o = e - total;
-        for (int w = w0; w < w1; w++) s0 += bpartial[(size_t)w * cout_pad + o];
+    // sixteen partials per round, every load issued before the first addition (clamped indices, zero weights beyond the slice): with
+    // <= 256 workgroups a slice IS one round -- as a 4-at-a-time loop it was four dependent memory round trips, the whole kernel
+    if (e < total || (db && e < total + Cout)) {
+        const bool isw = e < total;
+        const int o = isw ? e / Cin : e - total, c = isw ? e - o * Cin : 0;
+        const float *p = isw ? partial + (size_t)o * Cin + c : bpartial + o;
+        const size_t st = isw ? (size_t)cout_pad * Cin : (size_t)cout_pad;
+        for (int w = w0; w < w1; w += 16) {
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int wi = w + i < w1 ? w + i : w1 - 1;
+                v[i] = p[(size_t)wi * st];
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i += 4) {
+                s0 += w + i < w1 ? v[i] : 0.0f; s1 += w + i + 1 < w1 ? v[i + 1] : 0.0f;
+                s2 += w + i + 2 < w1 ? v[i + 2] : 0.0f; s3 += w + i + 3 < w1 ? v[i + 3] : 0.0f;
+            }
+        }
     }
     sS[sl][el] = (s0 + s1) + (s2 + s3);
     __syncthreads();
