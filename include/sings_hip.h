@@ -67,7 +67,7 @@ typedef struct SgLayout {
 const char *sg_version(void);
 const char *sg_last_error(void);
 
-/* SG_FLAG_SHORT_LISTS: the caller asserts that no tile's list exceeds 256 entries (known from an earlier forward of the
+/* SG_FLAG_SHORT_LISTS: the caller asserts that no tile's list exceeds 1024 entries (256 is what callers in this repository test for) (known from an earlier forward of the
  * same scene: a pre-sized engine).  The two kernels that sort longer lists are then not launched at all -- such lists are
  * sorted by the compositing workgroups themselves -- which saves their launch latency (3.6 us of a 350-us cfg3 view).  If a
  * longer list does turn up the forward does NOT follow it: it renders the background, writes no gradients, and

@@ -14,7 +14,7 @@
 //               prefix it needs -- in its own LDS, T words, L2-resident reads -- instead of waiting for a scan kernel;
 //               then one lane per PAIR, no atomics: pair_keys[start[tile] + rank] = depth_bits<<32 | id.  The per-tile
 //               outputs (ranges, plans, work lists, R) are written by the workgroups between them.
-//   3. sort   : lists of <= 256 entries are sorted by the forward composite kernel itself, in the LDS of the tile's
+//   3. sort   : lists of <= 1024 entries are sorted by the forward composite kernel itself, in the LDS of the tile's
 //               workgroup, just before it gathers the records (sg_sort.h; no launch, no extra pass over the keys);
 //               longer lists: one workgroup per 4096-entry chunk (bitonic), longer still: chunks merged by rank.
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
@@ -443,7 +443,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
                            sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap));
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
-    // lists longer than 256 entries (the composite kernel sorts the others): both kernels exit at once when there are none
+    // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none
     if ((SG_EXP & 64) || short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
     const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs

@@ -181,19 +181,19 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // whose list is thousands of entries long runs alone on its CU -- nothing else hides the two dependent loads)
     float4 pa = make_float4(0, 0, 0, 0), pb = pa;
     float pc = 0.0f;
-    static_assert(SG_WSORT_MAX <= SG_FB && (SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 48, "sort buffers alias sR");
+    static_assert((SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 48, "sort buffers alias sR");
     if (n > 0 && n <= SG_WSORT_MAX) {
-        // Short list (every list at cfg3): this workgroup sorts the tile's keys itself, in LDS, and hands the order to
+        // Short list (<= 1024 entries: every list at cfg3, most of an avatar's): this workgroup sorts the tile's keys itself, in LDS, and hands the order to
         // the backward pass through point_list -- the separate sort pass of round 1 (18 us, all latency) is gone and the
         // sort of one tile overlaps the compositing of the other tiles resident on the CU.
         uint64_t *sKey = (uint64_t *)sR;                    // aliases the staging buffer: consumed before the first batch
         sg_sort_short_list(pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
-        if (tid < n) {
-            const uint64_t key = sKey[tid];
+        for (int i = tid; i < n; i += SG_FB) {              // (later batches read their ids back from point_list: the barrier at
+            const uint64_t key = sKey[i];                   //  the top of the batch loop orders these stores in front of those loads)
             const uint32_t gid = (uint32_t)key;
-            point_list[range.x + tid] = gid;
-            if (point_keys) point_keys[range.x + tid] = ((uint64_t)tile << 32) | (key >> 32);
-            pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
+            point_list[range.x + i] = gid;
+            if (point_keys) point_keys[range.x + i] = ((uint64_t)tile << 32) | (key >> 32);
+            if (i == tid) { pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x; }
         }
     } else if (tid < n) {                                   // long list: sorted by sg_tile_sort_kernel / sg_tile_rank_kernel
         const uint32_t gid = point_list[range.x + tid];

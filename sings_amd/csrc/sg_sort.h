@@ -4,7 +4,7 @@
 #pragma once
 #include "sg_common.h"
 
-#define SG_WSORT_MAX 256       // longest list a composite workgroup sorts itself
+#define SG_WSORT_MAX 1024      // longest list a composite workgroup sorts itself (8 KiB of keys in the staging buffer)
 #define SG_RANKSORT_MAX 128    // up to here: rank sort (every thread counts the smaller keys); beyond: one-wave bitonic
 
 // One WAVE sorts s[0, n2) (n2 a power of two <= SG_WSORT_MAX, padded with ~0) -- no workgroup barriers.
@@ -29,7 +29,8 @@ __device__ __forceinline__ void sg_bitonic_wave(uint64_t *__restrict__ s, int n2
 //    independent LDS reads per thread instead of the ~28 dependent compare-exchange rounds of a bitonic network -- a
 //    third of the latency at the mean list length of cfg3 (96) for the same number of vector instructions, and two
 //    waves share the work;
-//  * longer: wave 0 runs the bitonic network (n^2 comparisons would cost more vector issue than they save latency).
+//  * 129 .. 256: wave 0 runs the bitonic network (n^2 comparisons would cost more vector issue than they save latency);
+//  * 257 .. 1024: the same network on the whole workgroup.
 __device__ __forceinline__ void sg_sort_short_list(const uint64_t *__restrict__ src, int n, uint64_t *__restrict__ s,
                                                    uint64_t *__restrict__ tmp, int tid)
 {
@@ -51,8 +52,24 @@ __device__ __forceinline__ void sg_sort_short_list(const uint64_t *__restrict__ 
         return;
     }
     int n2 = 1; while (n2 < n) n2 <<= 1;
-    if (tid < n2) s[tid] = tid < n ? src[tid] : ~0ull;
+    for (int i = tid; i < n2; i += 256) s[i] = i < n ? src[i] : ~0ull;
     __syncthreads();
-    if (tid < 64) sg_bitonic_wave(s, n2, tid);
-    __syncthreads();
+    if (n2 <= 256) {
+        if (tid < 64) sg_bitonic_wave(s, n2, tid);
+        __syncthreads();
+        return;
+    }
+    // 257 .. 1024 entries (an avatar's typical tile): the bitonic network on all four waves, n2 / 512 comparators per thread and
+    // stage.  In round 1 these lists went to sg_tile_sort_kernel -- one 1024-thread workgroup per tile, ~1200 of them on an avatar
+    // frame, 60-90 us between the scan and the composite; here a tile's sort overlaps the compositing of the other tiles on its CU.
+    for (int k = 2; k <= n2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += 256) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
+                const bool up = (i & k) == 0;
+                const uint64_t a = s[i], b = s[ixj];
+                if ((a > b) == up) { s[i] = b; s[ixj] = a; }
+            }
+            __syncthreads();
+        }
 }
