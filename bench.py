@@ -308,8 +308,9 @@ def main_raster(a):
     for v in range(k_views):
         e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v])
         # the sizing pass knows the longest tile list (135 at cfg3): with 1.5x margin for the other cameras of the batch no
-        # list can need the long-list sort kernels (checked on the device; a violation surfaces in num_rendered() below)
-        e.set_camera(camera(rank * k_views + v)[3], short_lists=tile_max * 1.5 <= 256)
+        # list can need the long-list sort kernels (lists <= 1024 are sorted by the compositing workgroups; checked on the device, a
+        # violation surfaces in num_rendered() below)
+        e.set_camera(camera(rank * k_views + v)[3], short_lists=tile_max * 1.5 <= 1024)
         engs.append(e)
     eng = engs[0]
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)

@@ -55,8 +55,8 @@ class RasterEngine:
         self._s = None
 
     def set_camera(self, raster_settings, short_lists=False):
-        """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 256 entries; the
-        two long-list sort launches are then skipped (SG_FLAG_SHORT_LISTS).  A longer list makes ``num_rendered()`` return
+        """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 1024 entries (what the
+        compositing workgroups sort themselves); the two long-list sort launches are then skipped (SG_FLAG_SHORT_LISTS).  A longer list makes ``num_rendered()`` return
         ``_lib.NUM_RENDERED_LONG_LIST`` (the frame rendered the background): call set_camera again without the hint."""
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
