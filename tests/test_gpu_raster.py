@@ -478,8 +478,8 @@ def test_engine_step_replays_from_a_hip_graph():
 
 
 def test_short_lists_hint_skips_the_long_sort_and_is_checked_on_the_device():
-    """SG_FLAG_SHORT_LISTS (RasterEngine.set_camera(short_lists=True)): with every tile list <= 256 entries the result is
-    bit for bit the one without the hint (the long-list sort launches are simply not issued); when a longer list turns up
+    """SG_FLAG_SHORT_LISTS (RasterEngine.set_camera(short_lists=True)): with every tile list <= 1024 entries (what the compositing workgroups
+    sort themselves) the result is bit for bit the one without the hint (the long-list sort launches are simply not issued); when a longer list turns up
     nothing follows the unsorted list -- background image, zero work in backward -- and the pair count reads back as
     NUM_RENDERED_LONG_LIST."""
     from sings_amd import _lib
@@ -507,7 +507,7 @@ def test_short_lists_hint_skips_the_long_sort_and_is_checked_on_the_device():
     eng.set_camera(_settings(s2, dev))
     eng.forward(*ins2)
     n = eng.binning[eng.L.bin_ranges:eng.L.bin_ranges + 8 * 16 * 12].view(torch.int32).view(-1, 2)
-    assert int((n[:, 1] - n[:, 0]).max()) > 256 and eng.num_rendered() > 0
+    assert int((n[:, 1] - n[:, 0]).max()) > 1024 and eng.num_rendered() > 0
     eng.set_camera(_settings(s2, dev), short_lists=True)
     eng.forward(*ins2); eng.backward(*ins2, dL)
     assert eng.num_rendered() == _lib.NUM_RENDERED_LONG_LIST
