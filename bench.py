@@ -53,6 +53,15 @@ VALU_CYCLES_MIX = 3.6          # issue cost of the backward composite's instruct
 
 
 _T0 = time.perf_counter()
+# SINGS_BENCH_FORCE_DIST=1: initialise the process group and ISSUE every collective even with one rank (RCCL accepts a one-rank
+# communicator), so that the nccl branches -- init_process_group("nccl", device_id), async all-reduce / in-place reduce-scatter +
+# all-gather on device views, work handles, the device-side MAX of the timed region -- run on a single-GPU box
+# (tests/test_gpu_bench.py); the line then carries rccl_world = 1 and the allreduce_* keys.
+FORCE_DIST = bool(os.environ.get("SINGS_BENCH_FORCE_DIST"))
+# one schema for every N: the collective keys are present (null) when no collective ran
+COMM_KEYS = ("allreduce_ms", "allreduce_bytes", "allreduce_algorithm", "allreduce_per_link_bound_ms", "allreduce_exposed_ms")
+MIN_TIMED_S = 0.5              # the timed region is repeated (whole regions of exactly --steps steps) until it adds up to this
+MAX_REPEATS = 200
 
 
 def _log(msg):
@@ -74,6 +83,19 @@ def algorithmic_bytes(N, H, W, R, deg):
     }
     total = N * (2 * inb + gout + 4 + 2 * rec) + hw * 40 + R * 20
     return per, total
+
+
+def algorithmic_bytes_skinned(N, H, W, R, deg, J, has_rot=False):
+    """The same for the LBS-fused path (last sentences): + N (12 + [36] + 4 J) read forward and again backward
+    (xyz_canon, [R_canon], skinning weights), + N (12 [+ 36]) written backward (dL/dxyz_canon [, dL/dR_canon]); posed means /
+    quaternions are never materialised: - N 28 read per pass, - N 28 of gradient writes."""
+    per, total = algorithmic_bytes(N, H, W, R, deg)
+    extra_in = N * (12 + (36 if has_rot else 0) + 4 * J) - N * 28
+    extra_out = N * (12 + (36 if has_rot else 0)) - N * 28
+    per = dict(per)
+    per["sg_preprocess_fwd_kernel"] += extra_in
+    per["sg_preprocess_bwd_kernel"] += extra_in + extra_out
+    return per, total + 2 * extra_in + extra_out
 
 
 def parse_args():
@@ -107,6 +129,9 @@ def parse_args():
                          "--gaussians 500000 --width 2048 --height 2048 --regularisers")
     ap.add_argument("--eager", action="store_true", help="train workload: launch the ~600 kernels of a step from Python instead of "
                     "replaying the step from a captured HIP graph (the default; host-speed independent)")
+    ap.add_argument("--grad-hash", action="store_true",
+                    help="raster / avatar workloads: after the timed region run step 0 once more and report the sha256 of the reduced "
+                         "gradient buffer (`grad_sha256`; the backward is bitwise reproducible)")
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
@@ -176,7 +201,7 @@ def dist_setup(a):
     torch.cuda.set_device(local_rank % ndev)
     dev = torch.device("cuda", local_rank % ndev)
     dist, info = None, {"rccl_world": None, "dist_backend": None, "dist_world": 1, "ranks_per_device": 1}
-    if world > 1 or os.environ.get("SINGS_BENCH_FORCE_DIST"):      # the env knob exercises the RCCL path with one rank
+    if world > 1 or FORCE_DIST:                                    # the env knob exercises the RCCL path with one rank
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
@@ -214,12 +239,36 @@ def timed_region(dist, dev, steps, step):
     return el
 
 
+def timed_repeats(dist, dev, steps, step, min_s=None):
+    """The timed region, repeated: whole regions of EXACTLY `steps` steps (each bracketed by barrier + synchronize, MAX over
+    ranks) until they add up to MIN_TIMED_S seconds and there are at least two.  The driver's `--steps 20` is 42 ms of work
+    for a 2-ms step -- one region of that length moves by +-1.5 % with the box; the line reports the MEDIAN region (and min /
+    max).  Every rank sees the same (reduced) durations, so all ranks take the same number of repetitions."""
+    min_s = MIN_TIMED_S if min_s is None else min_s
+    els = []
+    while True:
+        els.append(timed_region(dist, dev, steps, step))
+        if (len(els) >= 2 and sum(els) >= min_s) or len(els) >= MAX_REPEATS:
+            return els
+
+
+def _median(v):
+    v = sorted(v)
+    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
+
+
+def _grad_sha256(t):
+    """sha256 of a device buffer's bytes (tests: the forced one-rank RCCL run must reproduce the no-dist gradients bit for bit)."""
+    import hashlib
+    return hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()
+
+
 def allreduce_probe(fp, buf, iters=10):
     """Stand-alone collective on the step's gradient buffer: ms per call (device events; MAX over ranks is implied by the
     collective itself), bytes, and the xGMI per-link lower bound 2 (S/W) / 153 GB/s of a reduce-scatter + all-gather that
     uses every link of the fully connected mesh."""
     import torch
-    if fp is None or fp.world == 1:
+    if fp is None or not fp.active:
         return None
     scratch = buf.clone()
     for _ in range(3):
@@ -296,7 +345,8 @@ def main_raster(a):
     fp = None
     if dist is not None:
         from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
+                           force=FORCE_DIST)
 
     n_streams = max(1, min(a.streams, k_views))
     per_view = N * (3 + 3 + 4 + 1 + 3 * shs.shape[1])
@@ -363,12 +413,18 @@ def main_raster(a):
             torch.cuda.synchronize(dev); t0 = _t.perf_counter(); step(); t1 = _t.perf_counter(); torch.cuda.synchronize(dev)
             t2 = _t.perf_counter()
             _log(f"host submission {1e3 * (t1 - t0):.3f} ms, step complete after {1e3 * (t2 - t0):.3f} ms")
-    _log(f"timed region ({a.steps} steps)")
-    el = timed_region(dist, dev, a.steps, step)
-    _log(f"{el / a.steps * 1e3:.3f} ms per step; one view per step")
+    _log(f"timed region ({a.steps} steps, repeated until {MIN_TIMED_S} s)")
+    els = timed_repeats(dist, dev, a.steps, step)
+    el = _median(els)
+    _log(f"{el / a.steps * 1e3:.3f} ms per step (median of {len(els)} regions); one view per step")
     assert all(0 <= e.num_rendered() <= e.cap for e in engs), "pair capacity / short-list hint violated"
     ms_per_step = el / a.steps * 1e3
     views_s = world * a.steps * k_views / el
+    grad_hash = None
+    if a.grad_hash:
+        step()
+        torch.cuda.synchronize()
+        grad_hash = _grad_sha256(eng.grad_flat if graph is not None else batch.acc)
 
     # the reference's unit of work, one frame per optimisation step (gs_trainer.py:207-215): view 0 alone on the current
     # stream, (+ the all-reduce of its gradients with several ranks), same number of views as the batched region
@@ -379,7 +435,7 @@ def main_raster(a):
     n_one = max(20, min(a.steps * k_views, 2000))
     for _ in range(10):
         step_one_view()
-    el_one = timed_region(dist, dev, n_one, step_one_view)
+    el_one = _median(timed_repeats(dist, dev, n_one, step_one_view, min_s=0.25))
 
     # collective: stand-alone time and the part of it the batched step cannot hide
     _log("collective probe / per-kernel event pass")
@@ -418,35 +474,15 @@ def main_raster(a):
     per, total_bytes = algorithmic_bytes(N, H, W, R, deg)
     if a.forward_only:                                          # B_f = N (in + 4 + 2 rec) + HW 12 + R 16
         total_bytes = N * (44 + 12 * (deg + 1) ** 2 + 4 + 2 * 75) + H * W * 12 + R * 16
-    dom = max(("sg_preprocess_fwd_kernel", "sg_render_fwd_kernel", "sg_render_bwd_kernel", "sg_preprocess_bwd_kernel"),
-              key=lambda k: kern[k])
-    pmc = _committed_pmc(dom)
-    hbm = {"bound": "hbm", "kernel": dom, "achieved": per[dom] / (kern[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "frac": per[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("traffic"),
-           "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]}
-    roofline = hbm
-    if pmc.get("valu") and (N, W, H, deg) == (200000, 1920, 1080, 3) and dom in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
-        # the composite kernels are bounded by VALU issue, not bytes: instructions the kernel executes
-        # per launch (PMC pass of THIS configuration, committed under profiles/) over the live duration, against the rate
-        # at which 1024 SIMDs issue wave64 VALU instructions
-        instr = pmc["valu"]
-        rate = instr / (kern[dom] * 1e-3) / 1e9                                     # G wave-instructions / s
-        peak = SIMDS * CLOCK_HZ / VALU_CYCLES_GUIDE / 1e9
-        roofline = {"bound": "valu", "kernel": dom, "achieved": rate, "peak": peak, "unit": "G wave64-instr/s",
-                    "frac": rate / peak, "traffic": pmc.get("traffic"), "kernel_ms": kern[dom],
-                    "valu_wave_instructions_per_launch": instr, "source": pmc.get("valu_source"),
-                    "cycles_per_instruction": kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr,
-                    "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
-                    "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / (kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr),
-                    "note": "peak = guide's 2 cycles per wave64 VALU instruction; frac_vs_measured_mix_cost uses the 3.6 cycles per "
-                            "instruction that tools/valu_probe.hip's per-kind costs give for this kernel's instruction mix"}
+    roofline, hbm = build_roofline(kern, per, {"workload": "raster", "gaussians": N, "width": W, "height": H, "sh_degree": deg})
     out = {
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
         "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "ms_per_view": ms_per_step / k_views,
         "train_step_ms_one_view": el_one / n_one * 1e3, "views_per_s_one_view_per_step": world * n_one / el_one,
-        "timed_region_s": el, "higher_is_better": True, "scaling": "weak",
+        "timed_region_s": sum(els), "repeats": len(els), "ms_per_step_min": min(els) / a.steps * 1e3,
+        "ms_per_step_max": max(els) / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, "
                                f"{'forward only' if a.forward_only else 'fwd+bwd'}, "
@@ -464,8 +500,11 @@ def main_raster(a):
         "kernel_ms": kern,
     }
     out.update(dinfo)
+    out.update({k: None for k in COMM_KEYS})
     if comm is not None:
         out.update(comm)
+    if grad_hash is not None:
+        out["grad_sha256"] = grad_hash
     if world == 1 and not a.no_cpu_baseline:
         _log("CPU baseline (child process, bounded)")
         out["cpu_baseline"] = cpu_baseline(s, camera, deg, W, H)
@@ -475,24 +514,104 @@ def main_raster(a):
     _emit(out)
 
 
-def _committed_pmc(kernel):
-    """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of the cfg3
-    bench command (profiles/*_pmc_SQ.csv, profiles/hbm_traffic.json; tools/pmc_summary.py writes them)."""
+PMC_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
+               "sings_amd/csrc/sg_project.h", "sings_amd/csrc/sg_preprocess.hip", "sings_amd/csrc/sg_skin.hip",
+               "sings_amd/csrc/sg_common.h", "sings_amd/csrc/sg_math.h")
+
+
+def git_blob_sha1(path):
+    """The hash `git hash-object` gives the file (no git needed on the GPU box)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes(root=ROOT):
+    return {rel: git_blob_sha1(os.path.join(root, rel)) for rel in PMC_SOURCES}
+
+
+def _meta_status(meta, cfg, root=ROOT):
+    """None if the PMC pass described by `meta` (sidecar written by tools/pmc_summary.py: configuration it ran + git blob
+    hashes of the kernel sources it profiled) is a pass of THIS configuration over THIS tree; otherwise the reason."""
+    if not isinstance(meta, dict) or "sources" not in meta or "config" not in meta:
+        return "no sidecar (configuration and kernel-source hashes of the PMC pass unknown)"
+    if any(meta["config"].get(k) != v for k, v in cfg.items()):
+        return f"PMC pass of another configuration ({meta['config']})"
+    cur = source_hashes(root)
+    changed = sorted(rel for rel, h in meta["sources"].items() if cur.get(rel) != h)
+    if changed:
+        return "kernel sources changed since the PMC pass: " + ", ".join(os.path.basename(c) for c in changed)
+    return None
+
+
+def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
+    """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of THIS configuration
+    (profiles/<tag>_pmc_SQ.csv + <tag>_pmc_SQ.meta.json, profiles/hbm_traffic.json with its "_meta"; tools/pmc_summary.py writes
+    them).  A pass whose sidecar names another configuration, or whose recorded source hashes differ from the tree, is NOT
+    used: the counts describe other kernels -- the caller then falls back to the HBM roofline and says why (`stale`)."""
     import csv
-    res = {}
-    pdir = os.path.join(ROOT, "profiles")
+    res = {"stale": None}
+    pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
+    why = "no committed *_pmc_SQ.csv"
     try:
         for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv")):
+            try:
+                meta = json.load(open(os.path.join(pdir, fn[:-4] + ".meta.json")))
+            except Exception:
+                meta = None
+            st = _meta_status(meta, cfg, root)
+            if st is not None:
+                why = f"profiles/{fn}: {st}"
+                continue
             for r in csv.DictReader(open(os.path.join(pdir, fn))):
-                if r["kernel"] == kernel and r["Counter_Name"] == "SQ_INSTS_VALU":
+                if r["kernel"].split("<")[0] == kernel and r["Counter_Name"] == "SQ_INSTS_VALU":
                     res["valu"], res["valu_source"] = float(r["mean"]), f"profiles/{fn}"
-    except Exception:
-        pass
+    except Exception as e:
+        why = f"{type(e).__name__}: {e}"
+    if "valu" not in res:
+        res["stale"] = why
     try:
-        res["traffic"] = json.load(open(os.path.join(pdir, "hbm_traffic.json"))).get(kernel)
+        tj = json.load(open(os.path.join(pdir, "hbm_traffic.json")))
+        st = _meta_status(tj.get("_meta"), cfg, root)
+        if st is None:
+            res["traffic"] = next((v for k, v in tj.items() if k.split("<")[0] == kernel), None)
+        else:
+            res["traffic_stale"] = st
     except Exception:
         pass
     return res
+
+
+def build_roofline(kern, per, cfg):
+    """(roofline, roofline_hbm) of the dominant kernel.  roofline_hbm: its algorithmic bytes (SURVEY.md 8(d) split, `per`) over
+    its live HIP-event duration against 8 TB/s.  roofline: the same, unless the dominant kernel is a composite kernel AND a PMC
+    pass of this very configuration and tree is committed -- then the bound that actually limits it, VALU issue."""
+    dom = max((k for k in per if k in kern), key=lambda k: kern[k])
+    pmc = _committed_pmc(dom, cfg)
+    hbm = {"bound": "hbm", "kernel": dom, "achieved": per[dom] / (kern[dom] * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": per[dom] / (kern[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": pmc.get("traffic"),
+           "algorithmic_bytes_per_launch": per[dom], "kernel_ms": kern[dom]}
+    if pmc.get("traffic_stale"):
+        hbm["traffic_note"] = "profiles/hbm_traffic.json not used: " + pmc["traffic_stale"]
+    if dom not in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
+        return hbm, hbm
+    if not pmc.get("valu"):
+        return dict(hbm, note="the composite kernels are VALU-issue bound (DESIGN.md section 4); the VALU roofline is omitted "
+                              "because no PMC pass matches this run -- " + str(pmc["stale"])), hbm
+    # the composite kernels are bounded by VALU issue, not bytes: instructions the kernel executes per launch (PMC pass of
+    # THIS configuration and tree, committed under profiles/) over the live duration, against the rate at which 1024 SIMDs
+    # issue wave64 VALU instructions
+    instr = pmc["valu"]
+    rate = instr / (kern[dom] * 1e-3) / 1e9                                     # G wave-instructions / s
+    peak = SIMDS * CLOCK_HZ / VALU_CYCLES_GUIDE / 1e9
+    cpi = kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr
+    return {"bound": "valu", "kernel": dom, "achieved": rate, "peak": peak, "unit": "G wave64-instr/s",
+            "frac": rate / peak, "traffic": pmc.get("traffic"), "kernel_ms": kern[dom],
+            "valu_wave_instructions_per_launch": instr, "source": pmc.get("valu_source"),
+            "cycles_per_instruction": cpi, "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
+            "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / cpi,
+            "note": "peak = guide's 2 cycles per wave64 VALU instruction; frac_vs_measured_mix_cost uses the cycles per "
+                    "instruction that tools/valu_probe.hip's per-kind costs give for this kernel's instruction mix"}, hbm
 
 
 def usable_cores():
@@ -633,8 +752,8 @@ def main_train(a):
     import torch
     rank, world, dev, dist, dinfo = dist_setup(a)
     from sings_amd.body import joint_transforms
-    from sings_amd.decode import (AppearanceDecoder, GeometryDecoder, HexPlaneField, overlap_weight_grads,
-                                  prepare_triplane_backward_early)
+    from sings_amd.decode import (AppearanceDecoder, GeometryDecoder, HexPlaneField, arena_sync, overlap_weight_grads,
+                                  prepare_triplane_backward_early, set_gradient_arena)
     overlap_weight_grads(not a.no_wgrad_overlap)     # (the step sets every .grad to None first: the mode's precondition)
     prepare_triplane_backward_early(not a.no_wgrad_overlap)   # (every captured forward is followed by its backward)
     from sings_amd.dp import FrameSharder
@@ -672,7 +791,19 @@ def main_train(a):
     bg_t, smpl_scale, transl = t(s["bg"]), t(s["smpl_scale"]), t(s["transl"])
     shard = FrameSharder(F, world, rank, seed=0)
 
-    # No host synchronisation inside a step: one synchronous step sizes the pair capacity, then the rasterizer's pair-count
+    # (before the first backward and before the capture: the gradient arena decides where the large gradients are WRITTEN)
+    fp = None
+    if dist is not None:
+        from sings_amd.dp import FrameParallel
+        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
+                           force=FORCE_DIST)
+        # parameter-level gradients live in ONE flat buffer: the kernels that produce the large ones (tri-plane scatter, weight
+        # gradients) write straight into it (sings_amd.decode.set_gradient_arena), so p.grad is a view of `flat` and the
+        # collective needs no gather / scatter passes; what torch's own backward produced (biases, anchors: < 1 %) is copied
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+        grad_views = set_gradient_arena(params, flat)
+
+    # No host synchronisation inside a step: synchronous steps size the pair capacity, then the rasterizer's pair-count
     # check is deferred (sings_amd.rasterizer.set_deferred_overflow_check) and polled once after the timed region.
     from sings_amd import rasterizer as _rz
     A_static = A_all[0].clone()
@@ -687,7 +818,8 @@ def main_train(a):
         return {k: vals[i] for i, k in enumerate(keys)}
 
     cap_pairs = 0
-    for f in range(0, F, 8):                                     # synchronous sizing steps: 1.25 x the largest pair count
+    _rz.set_overflow_check("sync")                               # every sizing step reads its pair count before it returns, so
+    for f in range(0, F, 8):                                     # _capacity_hint (2 x the largest count) has seen them all
         A_static.copy_(A_all[f])
         step_body()
         cap_pairs = max(cap_pairs, _rz._capacity_hint[dev.index])
@@ -725,13 +857,6 @@ def main_train(a):
         with torch.cuda.graph(graph):
             ld_static = step_body()
 
-    fp = None
-    if dist is not None:
-        from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
-        sizes = [p.numel() for p in params]
-        flat = torch.empty(sum(sizes), dtype=torch.float32, device=dev)
-
     def step(i):
         A_static.copy_(A_all[shard.frame(i)])
         if graph is not None:
@@ -740,11 +865,9 @@ def main_train(a):
         else:
             ld = step_body()
         if fp is not None:
-            # parameter-level gradients: gathered into ONE preallocated flat buffer, one collective, scattered back
-            gl = [p.grad for p in params]
-            torch.cat([g.reshape(-1) for g in gl], out=flat)
+            arena_sync(params, grad_views, True)
             fp.all_reduce_grads(flat)
-            torch._foreach_copy_(gl, [c.view_as(g) for c, g in zip(flat.split(sizes), gl)])
+            arena_sync(params, grad_views, False)
         return ld
 
     for i in range(a.warmup):
@@ -753,23 +876,30 @@ def main_train(a):
 
     def timed_step(i):
         last["ld"] = step(a.warmup + i)
-    el = timed_region(dist, dev, a.steps, timed_step)
+    els = timed_repeats(dist, dev, a.steps, timed_step)
+    el = _median(els)
     ld = last["ld"]
     comm = allreduce_probe(fp, flat) if fp is not None else None
+    inplace = (sum(p.grad.numel() * 4 for p, v in zip(params, grad_views) if p.grad is not None and p.grad.data_ptr() == v.data_ptr())
+               if fp is not None else None)
     R_last = _rz.check_deferred_overflow(dev)                    # raises if a timed step overflowed the pair capacity
     if rank == 0:
         nparam = sum(p.numel() for p in params)
         out = ({
             "metric": "full train-step views/sec (decode + LBS-fused raster + L1/SSIM + regularisers, fwd+bwd), avatar ~150k Gaussians",
             "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "ms_per_step": el / a.steps * 1e3, "timed_region_s": sum(els), "repeats": len(els),
+            "ms_per_step_min": min(els) / a.steps * 1e3, "ms_per_step_max": max(els) / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H}, tri-plane 32 x (64,128,256)^2 x 3, decoders 96-128-128 / "
                                    f"96-64-64, SH deg 0, {F} AMASS frames, no optimiser step, frame-parallel dp{world}",
                        "gaussians": N, "trainable_parameters": nparam, "num_rendered_last": R_last, "hip_graph": not a.eager,
+                       "gradient_bytes_written_in_place": inplace,
                        "parallelism": f"dp{world}"},
             "losses": {k: float(v.detach()) for k, v in ld.items()}})
         out.update(dinfo)
+        out.update({k: None for k in COMM_KEYS})
         if comm is not None:
             out.update(comm)
     if dist is not None:
@@ -839,8 +969,8 @@ def main_avatar(a):
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
     eng = engs[0]
     shard = FrameSharder(F, world, rank, seed=0)
-    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl")
-          if dist is not None else None)
+    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
+                        force=FORCE_DIST) if dist is not None else None)
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
     # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
@@ -861,9 +991,24 @@ def main_avatar(a):
 
     for i in range(a.warmup):
         step(i)
-    el = timed_region(dist, dev, a.steps, lambda i: step(a.warmup + i))
+    els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i))
+    el = _median(els)
     comm = allreduce_probe(fp, batch.acc)
     assert all(e.num_rendered() <= e.cap for e in engs)
+    grad_hash = None
+    if a.grad_hash:
+        step(0)
+        torch.cuda.synchronize()
+        grad_hash = _grad_sha256(batch.acc)
+    # the reference's unit of work: ONE frame per optimisation step on the current stream (gs_trainer.py:207-215)
+    def step_one_frame(i):
+        one_view(0, shard.frame(i))
+        if fp is not None:
+            fp.all_reduce_grads(eng.grad_flat)
+    n_one = max(20, min(a.steps * k_views, 2000))
+    for i in range(10):
+        step_one_frame(i)
+    el_one = _median(timed_repeats(dist, dev, n_one, step_one_frame, min_s=0.25))
     lib = _lib.load()
     lib.sg_profile_enable(1)
     for i in range(a.steps):
@@ -875,16 +1020,29 @@ def main_avatar(a):
     if rank == 0:
         out = {"metric": "train-step views/sec (LBS-fused fwd + L1/SSIM loss + bwd), avatar ~150k Gaussians x 120 AMASS frames",
                "value": world * a.steps * k_views / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-               "ms_per_step": el / a.steps * 1e3, "ms_per_view": el / a.steps * 1e3 / k_views, "higher_is_better": True,
+               "ms_per_step": el / a.steps * 1e3, "ms_per_view": el / a.steps * 1e3 / k_views,
+               "train_step_ms_one_view": el_one / n_one * 1e3, "timed_region_s": sum(els), "repeats": len(els),
+               "ms_per_step_min": min(els) / a.steps * 1e3, "ms_per_step_max": max(els) / a.steps * 1e3, "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H} fx=fy=5000, {F} AMASS frames, SH deg 0, fused LBS+raster "
                                       f"fwd + L1/SSIM loss + bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
                           "width": W, "height": H, "max_num_rendered": Rmax, "tile_list_mean": tile_mean, "tile_list_max": tile_max,
                           "views_per_step": k_views, "streams": n_streams, "parallelism": f"dp{world}"},
                "kernel_ms": kern}
+        per, total_bytes = algorithmic_bytes_skinned(N, H, W, Rmax, 0, J)
+        out["roofline"], out["roofline_hbm"] = build_roofline(
+            kern, per, {"workload": "avatar", "gaussians": N, "width": W, "height": H, "sh_degree": 0})
+        fps = out["value"] / world
+        out["roofline_whole_pass"] = {"algorithmic_bytes_per_view": total_bytes, "achieved_GBs": total_bytes * fps / 1e9,
+                                      "frac_of_8TBs": total_bytes * fps / 1e9 / HBM_PEAK_GBS,
+                                      "note": "raster + fused LBS bytes at the largest R of the sequence; the L1 + SSIM loss inside "
+                                              "the timed step (HW 40 B algorithmic) is not counted"}
         out.update(dinfo)
+        out.update({k: None for k in COMM_KEYS})
         if comm is not None:
             out.update(comm)
+        if grad_hash is not None:
+            out["grad_sha256"] = grad_hash
         if world == 1 and not a.no_cpu_baseline:
             from oracle import lbs_project_torch as lp
             T = torch.from_numpy

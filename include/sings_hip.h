@@ -47,6 +47,15 @@ typedef struct SgRasterSettings {
     const float *viewmatrix; /* [16] row-major torch tensor = column-major matrix */
     const float *projmatrix; /* [16] */
     const float *campos;     /* [3]  */
+    /* Optional early pair count (both NULL = off).  `count_signal` is the DEVICE address, `count_signal_host` the host address of
+     * ONE 64-bit word of pinned, mapped, coherent host memory (sg_signal_alloc).  A forward called with num_rendered_host != NULL
+     * clears the word, and its binning kernel stores (1 << 63 | flags << 32 | R) there the moment the pair count exists -- after
+     * the per-Gaussian kernel and the tile scan, a third of the way into a cfg3 forward -- so the call returns R WITHOUT
+     * synchronising the stream: the composite kernel is still running while the caller already queues its next work.  This is
+     * what lets the drop-in autograd wrapper keep upstream's guarantee (upstream blocks the host mid-forward for R: never a
+     * frame rendered with a too small workspace) at nearly the speed of never looking. */
+    unsigned long long *count_signal;
+    volatile unsigned long long *count_signal_host;
 } SgRasterSettings;
 
 /* Byte offsets inside the opaque workspaces (exposed for tests / debugging only). */
@@ -67,8 +76,8 @@ typedef struct SgLayout {
 const char *sg_version(void);
 const char *sg_last_error(void);
 
-/* SG_FLAG_SHORT_LISTS: the caller asserts that no tile's list exceeds 1024 entries (256 is what callers in this repository test for) (known from an earlier forward of the
- * same scene: a pre-sized engine).  The two kernels that sort longer lists are then not launched at all -- such lists are
+/* SG_FLAG_SHORT_LISTS: the caller asserts that no tile's list exceeds 1024 entries -- what a compositing workgroup sorts
+ * itself -- (known from an earlier forward of the same scene: a pre-sized engine).  The two kernels that sort longer lists are then not launched at all -- such lists are
  * sorted by the compositing workgroups themselves -- which saves their launch latency (3.6 us of a 350-us cfg3 view).  If a
  * longer list does turn up the forward does NOT follow it: it renders the background, writes no gradients, and
  * sg_read_num_rendered / num_rendered_host report SG_NUM_RENDERED_LONG_LIST (re-run without the flag). */
@@ -86,8 +95,9 @@ int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out
 /* Forward: replaces _C.rasterize_gaussians.  Exactly one of (shs | colors_precomp) and one
  * of (scales+rotations | cov3D_precomp) is non-NULL, as GaussianRasterizer.forward enforces.
  * out_color [3,H,W], radii [P] are fully written.  If num_rendered_host != NULL the call
- * synchronises the stream and stores R there (R > capacity_pairs => results invalid, retry
- * with a larger workspace; status stays 0).  point_keys_out: optional [capacity] u64
+ * stores R there before it returns (R > capacity_pairs => results invalid, retry with a larger
+ * workspace; status stays 0): by synchronising the stream, or -- with SgRasterSettings.count_signal
+ * set -- as soon as the binning kernel has published the count, the rest of the forward still running.  point_keys_out: optional [capacity] u64
  * receiving the upstream-format sorted keys (tile << 32 | depth bits). */
 int sg_rasterize_forward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
                          const float *colors_precomp, const float *opacities, const float *scales,
@@ -114,6 +124,11 @@ int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const 
 /* Reads R written by the last forward into this binning workspace (synchronises); SG_NUM_RENDERED_LONG_LIST if that
  * forward ran with SG_FLAG_SHORT_LISTS and met a longer list. */
 int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream);
+
+/* `slots` 64-bit words of pinned, mapped, coherent host memory for SgRasterSettings.count_signal: *host_out is the address the
+ * host polls, *device_out the address kernels store to (the same memory).  Caller-owned until sg_signal_free(*host_out). */
+int sg_signal_alloc(int slots, void **host_out, void **device_out);
+int sg_signal_free(void *host);
 
 /* ---- LBS-fused path: canonical Gaussians + joint transforms in, image out ------------------
  * Replaces the LBS block of SinGS.forward (sings/rec/models/sings_hybrid.py:398-428; lbs_extra at

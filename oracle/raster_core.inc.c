@@ -264,18 +264,23 @@ void FN(sgo_preprocess)(int P, int D, int M,
 /* ------------------------------------------------------------------ A.3 forward render */
 /* margin[pix] (optional): smallest relative distance of any threshold decision taken for
  * this pixel (alpha vs 1/255, test_T vs 1e-4, power vs 0) -- lets tests tell a genuine
- * mismatch from a borderline flip caused by a 1-ulp exp difference. */
+ * mismatch from a borderline flip caused by a 1-ulp exp difference.
+ * flip[pix] (optional, with `border`): an upper bound on how far the pixel's colour can move if
+ * the decisions whose margin is below `border` are taken the other way -- per such decision the
+ * contribution of the one splat concerned, alpha T (|c| + cmax) (cmax = largest colour / background
+ * component: what can stand behind it), or 2 T cmax for the early-termination test (the tail
+ * behind it is blended or replaced by the background). */
 void FN(sgo_render_fwd)(int W, int H, const uint32_t *ranges, const uint32_t *point_list,
                         const REAL *xy, const REAL *feat, const REAL *conic_opacity,
                         const REAL *bg, REAL *out_color, REAL *final_T, uint32_t *n_contrib,
-                        REAL *margin)
+                        REAL *margin, REAL border, REAL cmax, REAL *flip)
 {
     const int gx = (W + SG_BLOCK - 1) / SG_BLOCK;
     for (int py = 0; py < H; py++)
         for (int px = 0; px < W; px++) {
             int tile = (py / SG_BLOCK) * gx + (px / SG_BLOCK);
             uint32_t s = ranges[2 * tile], e = ranges[2 * tile + 1];
-            REAL T = 1, C[3] = { 0, 0, 0 }, mg = 1;
+            REAL T = 1, C[3] = { 0, 0, 0 }, mg = 1, fl = 0;
             uint32_t contributor = 0, last = 0;
             for (uint32_t k = s; k < e; k++) {
                 contributor++;
@@ -285,14 +290,23 @@ void FN(sgo_render_fwd)(int W, int H, const uint32_t *ranges, const uint32_t *po
                 REAL q1 = (REAL)-0.5 * (co[0] * dx * dx + co[2] * dy * dy), q2 = co[1] * dx * dy;
                 REAL power = q1 - q2;
                 REAL pscale = FABS(q1) + FABS(q2);
-                if (pscale > 0) { REAL m = FABS(power) / pscale; if (m < mg && power > (REAL)-1e-3) mg = m; }
+                REAL cabs = FABS(feat[3 * g]);
+                if (FABS(feat[3 * g + 1]) > cabs) cabs = FABS(feat[3 * g + 1]);
+                if (FABS(feat[3 * g + 2]) > cabs) cabs = FABS(feat[3 * g + 2]);
+                if (pscale > 0) {
+                    REAL m = FABS(power) / pscale;
+                    if (power > (REAL)-1e-3) {
+                        if (m < mg) mg = m;
+                        if (m < border) { REAL a0 = co[3] > (REAL)0.99 ? (REAL)0.99 : co[3]; fl += a0 * T * (cabs + cmax); }
+                    }
+                }
                 if (power > 0) continue;
                 REAL alpha = co[3] * EXP(power);
                 if (alpha > (REAL)0.99) alpha = (REAL)0.99;
-                { REAL m = FABS(alpha * (REAL)255 - (REAL)1); if (m < mg) mg = m; }
+                { REAL m = FABS(alpha * (REAL)255 - (REAL)1); if (m < mg) mg = m; if (m < border) fl += alpha * T * (cabs + cmax); }
                 if (alpha < (REAL)1 / (REAL)255) continue;
                 REAL test_T = T * ((REAL)1 - alpha);
-                { REAL m = FABS(test_T * (REAL)10000 - (REAL)1); if (m < mg) mg = m; }
+                { REAL m = FABS(test_T * (REAL)10000 - (REAL)1); if (m < mg) mg = m; if (m < border) fl += (REAL)2 * T * cmax; }
                 if (test_T < (REAL)0.0001) break;
                 for (int c = 0; c < 3; c++) C[c] += feat[3 * g + c] * alpha * T;
                 T = test_T;
@@ -302,6 +316,7 @@ void FN(sgo_render_fwd)(int W, int H, const uint32_t *ranges, const uint32_t *po
             final_T[pid] = T; n_contrib[pid] = last;
             for (int c = 0; c < 3; c++) out_color[(size_t)c * H * W + pid] = C[c] + T * bg[c];
             if (margin) margin[pid] = mg;
+            if (flip) flip[pid] = fl;
         }
 }
 

@@ -47,8 +47,10 @@ def higher_msb(n):
 
 def forward(means3D, opacities, view, proj, campos, W, H, tanfovx, tanfovy, bg,
             scales=None, rotations=None, shs=None, sh_degree=0, colors_precomp=None,
-            cov3D_precomp=None, scale_modifier=1.0, dtype=np.float32, want_margin=True):
-    """Full forward.  Returns a dict with every intermediate of SURVEY.md App. A.1-A.3."""
+            cov3D_precomp=None, scale_modifier=1.0, dtype=np.float32, want_margin=True, border=2e-5):
+    """Full forward.  Returns a dict with every intermediate of SURVEY.md App. A.1-A.3.  ``margin`` [H,W]: smallest relative
+    distance of a pixel's hard-threshold decisions from their thresholds; ``flip`` [H,W]: bound on the colour change if the
+    decisions closer than ``border`` go the other way (one splat's contribution each)."""
     L = lib()
     f64 = dtype == np.float64
     sfx = "_f64" if f64 else "_f32"
@@ -89,9 +91,12 @@ def forward(means3D, opacities, view, proj, campos, W, H, tanfovx, tanfovy, bg,
     o["color"] = np.zeros((3, H, W), dtype); o["final_T"] = np.zeros((H, W), dtype)
     o["n_contrib"] = np.zeros((H, W), np.uint32)
     o["margin"] = np.ones((H, W), dtype) if want_margin else None
+    o["flip"] = np.zeros((H, W), dtype) if want_margin else None
+    cmax = float(max(np.abs(o["rgb"]).max() if P else 0.0, np.abs(bg).max()))
     getattr(L, "sgo_render_fwd" + sfx)(
         C.c_int(W), C.c_int(H), _p(o["ranges"]), _p(o["point_list"]), _p(o["xy"]), _p(o["rgb"]),
-        _p(o["conic_opacity"]), _p(bg), _p(o["color"]), _p(o["final_T"]), _p(o["n_contrib"]), _p(o["margin"]))
+        _p(o["conic_opacity"]), _p(bg), _p(o["color"]), _p(o["final_T"]), _p(o["n_contrib"]), _p(o["margin"]),
+        real(border), real(cmax), _p(o["flip"]))
     o["_in"] = dict(means3D=means3D, opacities=opacities, scales=scales, rotations=rotations, shs=shs,
                     colors_precomp=colors_precomp, cov3D_precomp=cov3D_precomp, view=view, proj=proj,
                     campos=campos, bg=bg, tanfovx=tanfovx, tanfovy=tanfovy, scale_modifier=scale_modifier,

@@ -20,6 +20,7 @@ class SgRasterSettings(C.Structure):
         ("sh_degree", C.c_int32), ("sh_coeffs", C.c_int32),
         ("prefiltered", C.c_int32), ("debug", C.c_int32), ("flags", C.c_int32),
         ("bg", C.c_void_p), ("viewmatrix", C.c_void_p), ("projmatrix", C.c_void_p), ("campos", C.c_void_p),
+        ("count_signal", C.c_void_p), ("count_signal_host", C.c_void_p),
     ]
 
 
@@ -42,7 +43,7 @@ class SgTriplane(C.Structure):
 
 # every symbol include/sings_hip.h declares
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
-           "sg_mark_visible", "sg_read_num_rendered", "sg_profile_enable", "sg_profile_collect",
+           "sg_mark_visible", "sg_read_num_rendered", "sg_signal_alloc", "sg_signal_free", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
@@ -76,6 +77,8 @@ def load():
                                           [vp, vp, vp, sz, vp, vp, vp] + [vp] * 8 + [vp])
     lib.sg_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.sg_read_num_rendered.argtypes = [vp, C.POINTER(C.c_int64), vp]
+    lib.sg_signal_alloc.argtypes = [i32, C.POINTER(vp), C.POINTER(vp)]; lib.sg_signal_alloc.restype = C.c_int
+    lib.sg_signal_free.argtypes = [vp]; lib.sg_signal_free.restype = C.c_int
     lib.sg_profile_enable.argtypes = [i32]
     lib.sg_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
     lib.sg_kernel_name.argtypes = [i32]

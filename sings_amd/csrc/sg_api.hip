@@ -2,6 +2,7 @@
 // reference interfaces each entry point replaces).
 #include "sg_common.h"
 
+#include <chrono>
 #include <stdio.h>
 #include <string.h>
 #include <utility>
@@ -80,7 +81,59 @@ static int sg_make_cam(const SgRasterSettings *s, SgCam *c)
     c->fx = (float)c->W / (2.0f * s->tanfovx); c->fy = (float)c->H / (2.0f * s->tanfovy);
     c->mod = s->scale_modifier; c->D = s->sh_degree; c->M = s->sh_coeffs; c->flags = s->flags;
     c->view = s->viewmatrix; c->proj = s->projmatrix; c->campos = s->campos; c->bg = s->bg;
+    c->count_signal = nullptr;
     return 0;
+}
+
+// Early pair count (SgRasterSettings.count_signal): armed only for calls that want R back, cleared before the first launch.
+static void sg_arm_count(const SgRasterSettings *s, SgCam *c, const int64_t *num_rendered_host)
+{
+    if (!num_rendered_host || !s->count_signal || !s->count_signal_host) return;
+    __atomic_store_n(s->count_signal_host, 0ull, __ATOMIC_RELEASE);
+    c->count_signal = s->count_signal;
+}
+
+// R for the caller: from the published word once it arrives (no stream synchronisation), otherwise -- no signal word, debug
+// mode, or nothing after SG_SIGNAL_TIMEOUT_MS (a kernel that failed to launch never publishes) -- the synchronous read.
+#define SG_SIGNAL_TIMEOUT_MS 50.0
+static int sg_finish_count(const SgRasterSettings *s, const SgCam &c, const void *binning_ws, int64_t *num_rendered_host, void *stream)
+{
+    if (!num_rendered_host) return 0;
+    if (c.count_signal) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spin = 0;; spin++) {
+            const unsigned long long v = __atomic_load_n(s->count_signal_host, __ATOMIC_ACQUIRE);
+            if (v >> 63) {
+                const uint32_t flags = (uint32_t)(v >> 32) & 0x7fffffffu;
+                *num_rendered_host = (flags & 2u) ? (int64_t)SG_NUM_RENDERED_LONG_LIST : (int64_t)(v & 0xffffffffull);
+                return 0;
+            }
+            if ((spin & 63u) == 63u) {
+                if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > SG_SIGNAL_TIMEOUT_MS) break;
+            } else {
+                __builtin_ia32_pause();
+            }
+        }
+    }
+    return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
+}
+
+extern "C" int sg_signal_alloc(int slots, void **host_out, void **device_out)
+{
+    if (slots <= 0 || !host_out || !device_out) return sg_fail("sg_signal_alloc", hipSuccess);
+    void *h = nullptr, *d = nullptr;
+    hipError_t e = hipHostMalloc(&h, (size_t)slots * 8, hipHostMallocMapped | hipHostMallocCoherent);
+    if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+    if (e != hipSuccess) { if (h) (void)hipHostFree(h); return sg_fail("sg_signal_alloc", e); }
+    memset(h, 0, (size_t)slots * 8);
+    *host_out = h; *device_out = d;
+    return 0;
+}
+extern "C" int sg_signal_free(void *host)
+{
+    if (!host) return 0;
+    hipError_t e = hipHostFree(host);
+    return e == hipSuccess ? 0 : sg_fail("sg_signal_free", e);
 }
 
 extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
@@ -107,6 +160,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     SgImg im = sg_img_view(image_ws, L);
     // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
     // leaves them zeroed for the next call)
+    sg_arm_count(s, &c, num_rendered_host);
     if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
@@ -114,8 +168,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     SG_CHECK_LAST("binning", s, st);
     sg_launch_render_fwd(c, g, b, cap, im, out_color, write_point_keys, st);
     SG_CHECK_LAST("render_fwd", s, st);
-    if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
-    return 0;
+    return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
 }
 
 extern "C" int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream)
@@ -190,6 +243,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SgGeom g = sg_geom_view(geom_ws, L);
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
+    sg_arm_count(s, &c, num_rendered_host);
     if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
     sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);
@@ -197,8 +251,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SG_CHECK_LAST("binning", s, st);
     sg_launch_render_fwd(c, g, b, cap, im, out_color, 0, st);
     SG_CHECK_LAST("render_fwd", s, st);
-    if (num_rendered_host) return sg_read_num_rendered(binning_ws, num_rendered_host, stream);
-    return 0;
+    return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
 }
 
 extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,

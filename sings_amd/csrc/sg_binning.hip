@@ -43,12 +43,19 @@ __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ
     q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = nch; q[4] = nch > 1 ? nch : 0u;
 }
 
+// Early pair count: one 64-bit system-scope store to a mapped, coherent host word (valid bit | flags << 32 | R) -- visible to a
+// polling host thread while this kernel and the composite behind it are still running.
+__device__ __forceinline__ void sg_publish_count(unsigned long long *signal, uint32_t R, uint32_t flags)
+{
+    if (signal) __hip_atomic_store(signal, (1ull << 63) | ((unsigned long long)flags << 32) | R, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <int SG_SCAN_BS>
 __global__ void __launch_bounds__(SG_SCAN_BS)
 sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
-                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists)
+                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal)
 {
     constexpr int NQ = SG_SCAN_NQ;
     __shared__ uint32_t wsum[NQ][SG_SCAN_BS / 64];
@@ -132,7 +139,9 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         header[0] = carry[0];
-        header[1] = (carry[0] > cap ? 1u : 0u) | (short_lists && carry[3] ? 2u : 0u);
+        const uint32_t hflags = (carry[0] > cap ? 1u : 0u) | (short_lists && carry[3] ? 2u : 0u);
+        header[1] = hflags;
+        sg_publish_count(signal, carry[0], hflags);
         header[3] = (uint32_t)T;
         header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
         header[5] = carry[1] < items_cap ? carry[1] : items_cap;
@@ -186,7 +195,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items, int short_lists)
+                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
@@ -268,7 +277,9 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
         header[0] = tot[0];
         // bit 0: more pairs than the workspace holds; bit 1: a list needs the long-list kernels the caller told us to skip.
         // Either way the lists are incomplete / unsorted and the composite kernels touch nothing.
-        header[1] = (tot[0] > cap ? 1u : 0u) | (short_lists && tot[3] ? 2u : 0u);
+        const uint32_t hflags = (tot[0] > cap ? 1u : 0u) | (short_lists && tot[3] ? 2u : 0u);
+        header[1] = hflags;
+        sg_publish_count(signal, tot[0], hflags);         // the host may be waiting for exactly this (SgRasterSettings.count_signal)
         header[3] = (uint32_t)T;
         header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
         header[5] = tot[1] < items_cap ? tot[1] : items_cap;
@@ -413,19 +424,22 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
     const int short_lists = (c.flags & SG_FLAG_SHORT_LISTS) ? 1 : 0;
-    if (T <= SG_SS_MAX_TILES && !(SG_EXP & 4)) {
-        static bool attr_set = false;                     // 4 T bytes of dynamic LDS (up to 128 KiB)
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void *)sg_scan_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SG_SS_MAX_TILES * 4);
-            attr_set = true;
-        }
+    // 4 T bytes of dynamic LDS (up to 128 KiB).  Above the default 64-KiB limit (images of >= ~16 k tiles: 2048 x 2048) the
+    // kernel needs its limit raised -- per DEVICE and not remembered in a process-wide flag (a second GPU used from the same
+    // process, or a failed call, must not leave the launch below without it): asked for whenever it is needed (a host-side
+    // table update, no stream operation), and if the runtime refuses, the two-kernel path below does the same job.
+    bool fused = T <= SG_SS_MAX_TILES;
+    if (fused && (size_t)T * 4 + 1024 > 64 * 1024)
+        fused = hipFuncSetAttribute((const void *)sg_scan_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    SG_SS_MAX_TILES * 4) == hipSuccess;
+    if (fused) {
         sg_prof_begin(SG_K_TILE_SCAN, st);
         size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
         const int grid = (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, short_lists);
+                           b.rank_items, b.items, short_lists, c.count_signal);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -433,7 +447,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
         hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, tpt, b.tile_count, b.ranges, b.cursor,
                            b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
-                           sg_items_cap(T, cap), short_lists);
+                           sg_items_cap(T, cap), short_lists, c.count_signal);
         sg_prof_end(SG_K_TILE_SCAN, st);
         sg_prof_begin(SG_K_TILE_SCATTER, st);
         size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
@@ -444,7 +458,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none
-    if ((SG_EXP & 64) || short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
+    if (short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
     const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
     hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items, b.ranges,

@@ -7,12 +7,10 @@
 #include "../../include/sings_hip.h"
 
 #define SG_WAVE 64
-// Kernel experiments (tools/build_variants.sh builds libsings_hip_exp<N>.so with -DSG_EXP=<N>; the product is SG_EXP = 0):
-//   4 scan and scatter as two launches     8 / 16 / 32 forward preprocess without pair expansion / allocator / SH (timing only,
-//   WRONG results)     64 long-list sort + merge kernels not launched (valid while every tile list has <= 256 entries)
-//   8192 / 16384 / 32768 weight-gradient kernel without the partial stores / without MFMAs / with sleeps instead (timing only)
-#ifndef SG_EXP
-#define SG_EXP 0
+// (The compile-time experiment switches of rounds 1-2 -- SG_EXP bits that compiled phases of a kernel out for timing -- are no
+// longer in the product sources; the measurements they produced are in DESIGN.md section 4, the variants in the git history.)
+#ifdef SG_EXP
+#error "SG_EXP experiment variants were removed from the product sources"
 #endif
 // backward work items are tile | depth segment << 20: images of 2^20 tiles or more (> 16k x 16k pixels) are rejected by
 // sg_layout / every entry point instead of aliasing tile ids
@@ -112,6 +110,7 @@ struct SgCam {
     float tanfovx, tanfovy, fx, fy, mod;
     int D, M;
     const float *view, *proj, *campos, *bg;
+    unsigned long long *count_signal;      // mapped host word the tile scan publishes (valid bit | flags << 32 | R) to, or null
 };
 
 // launchers (defined in the .hip files)

@@ -697,8 +697,7 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
 #pragma unroll
         for (int u = 0; u < RR / 2; u++) a[u] = ac[u];
         fetch(xc, ac, n + 2 * RR);
-        if (SG_EXP & 32768) { __builtin_amdgcn_s_sleep(96); bsum += a[0]; }
-        if (active && !(SG_EXP & 16384)) {
+        if (active) {
 #pragma unroll
             for (int u = 0; u < RR / 2; u++) {
                 bsum += a[u];
@@ -721,7 +720,7 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
             round(xrO, anO, xrE, n + RR, 1);
         }
     }
-    if (!active || ((SG_EXP & 8192) && N > 1)) return;
+    if (!active) return;
     // D layout of the 32x32 tile: lane l, register r -> row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32
     float *pw = partial + (size_t)blockIdx.x * cout_pad * Cin;
 #pragma unroll

@@ -244,7 +244,7 @@ sg_linear_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, co
 
 
 // ---- wide outputs (CO a multiple of 32: the trunk layers and every input-gradient product) ------------------------------------
-// Same tile loop, two changes that the phase timings asked for (tools/linear_bench.py + SG_EXP variants, 128 -> 128 at 150 k
+// Same tile loop, two changes that the phase timings asked for (tools/linear_bench.py + phase-ablation builds, 128 -> 128 at 150 k
 // points: MFMAs alone 41-58 us, epilogue + stores alone 43 us, loads + stores alone 55 us, the kernel 107 us = their SUM):
 //  * the points are the A operand and M the B operand, so the accumulator holds output column 32 cb + j of 16 points and register
 //    r leaves as two 128-B row segments per store instruction -- the full-rate store shape of a 32 x 32 accumulator
@@ -447,17 +447,6 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
             // a separate epilogue-free block would be a second path with a different store count, and the compiler would wait at the
             // stash for the lower one)
             sg_v16f acc = accp;
-            if (SG_EXP & 256) {
-                if (active) {
-                    acc = mma(std::false_type{}, buf, accp, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; r++) emit(acc, r, t * R);
-                }
-                stash(xb, zb, buf ^ 1, (t + G) * R);
-                __syncthreads();
-                n0p = N;
-                return;
-            }
             if (active) acc = mma(std::true_type{}, buf, accp, n0p);
             stash(xb, zb, buf ^ 1, (t + G) * R);                           // the other buffer: last read one iteration ago
             __syncthreads();
@@ -482,7 +471,11 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
     if (N <= 0) return 0;
     if (CK < 1 || CK > SGL_MAXC || CO < 1 || CO > SGL_MAXC) return 1;
     const int nq = (CK + 7) / 8;
-    if ((CO & 31) == 0 && !(act == 2 && row_offset) && ((long long)N + 128) * CO * 4 < 0x7fffffffLL) {
+    // buffer descriptors and tile offsets are 32-bit byte quantities on BOTH sides: X / aux / dz rows are CK floats, outputs CO floats,
+    // and the look-ahead fetches reach up to two rounds of tiles (2 x 512 workgroups x 128 rows) past N before the range check
+    // drops them -- so the bound is on max(CK, CO); larger problems take the narrow kernel below (64-bit addressing)
+    const long long cmax = CK > CO ? CK : CO;
+    if ((CO & 31) == 0 && !(act == 2 && row_offset) && ((long long)N + 2 * 512 * 128) * cmax * 4 < 0x7fffffffLL) {
         // wide outputs: forward h -> out0, aux -> out1; backward dx -> out0, dz -> out1
 #define SGL_WIDE_GO(NQv, B, G, o0, o1, dz, acc)                                                                              \
         do {                                                                                                                \

@@ -22,10 +22,7 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
     const bool live = idx < P;
     constexpr int nc = (D + 1) * (D + 1);
     float sh[nc * 3];
-    if (SG_EXP & 32) {
-#pragma unroll
-        for (int k = 0; k < nc * 3; k++) sh[k] = 0.1f;
-    } else if (shs && live) {
+    if (shs && live) {
         const float *src = shs + (size_t)idx * c.M * 3;
         if (D == 3 && c.M == 16) {
             // the reference's layout [P,16,3]: a row is 192 B, 16-B aligned -> twelve 16-B loads per lane.  (Staging the

@@ -132,7 +132,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
-    const bool expand = !((SG_EXP & 8) && !hist) && (total != 0 || hist);     // wave-uniform
+    const bool expand = total != 0 || hist;     // wave-uniform
     sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
@@ -170,8 +170,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     // of its own tile atomics: the workgroup's critical path was the allocator queue PLUS a round of tile atomics)
     if (threadIdx.x == 0) {
         uint32_t t = sWaveTot[0] + sWaveTot[1] + sWaveTot[2] + sWaveTot[3];
-        if (SG_EXP & 16) sBlockBase = blockIdx.x * 1100u;
-        else sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
+        sBlockBase = t ? atomicAdd(&bn.header[2], t) : 0u;
     }
     __syncthreads();
     uint32_t base = sBlockBase;

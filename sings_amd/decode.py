@@ -86,6 +86,57 @@ def _tp_early(dev):
     return True if _TP["mode"] else not torch.cuda.is_current_stream_capturing()
 
 
+# ---- gradient arena ----------------------------------------------------------------------------------------------------------
+# Frame-parallel training reduces the parameter gradients with ONE collective over ONE flat buffer.  Instead of
+# gathering the .grad tensors into that buffer and scattering them back every step (two extra passes over 35 MB), the kernels that
+# PRODUCE the large gradients -- the tri-plane scatter (33 of the 35 MB) and the decoders' weight gradients -- write them straight
+# into the caller's buffer: `set_gradient_arena(params, flat)` registers a slot per parameter, the backward functions below hand
+# autograd a fresh view of the slot (AccumulateGrad adopts it without a copy when .grad is None, the precondition the training
+# step already guarantees), so `p.grad` IS a piece of `flat`.  Gradients produced elsewhere (biases, anchors) are small; the
+# caller copies those into their slots (`arena_sync`).
+_ARENA = {}                            # parameter storage address -> (flat, offset, shape)
+
+
+def set_gradient_arena(params, flat):
+    """Register (or, with ``params=None``, drop) the flat gradient buffer.  Returns the per-parameter views of ``flat``."""
+    _ARENA.clear()
+    if params is None:
+        return []
+    views, o = [], 0
+    for p in params:
+        n = p.numel()
+        if not p.is_contiguous():
+            raise ValueError("gradient arena: parameters must be contiguous")
+        _ARENA[p.data_ptr()] = (flat, o, tuple(p.shape))
+        views.append(flat[o:o + n].view(p.shape))
+        o += n
+    if o != flat.numel() or flat.dtype != torch.float32:
+        raise ValueError("gradient arena: `flat` must be fp32 with exactly sum(p.numel()) elements")
+    return views
+
+
+def _arena_out(param_like):
+    """A FRESH view of the arena slot of the parameter `param_like` aliases (autograd adopts a gradient tensor without copying
+    only if nobody else holds that tensor object), or a new tensor when there is no arena / no slot."""
+    hit = _ARENA.get(param_like.data_ptr())
+    if hit is None or hit[2] != tuple(param_like.shape) or hit[0].device != param_like.device:
+        return torch.empty_like(param_like, dtype=torch.float32)
+    flat, o, shape = hit
+    return flat[o:o + param_like.numel()].view(shape)
+
+
+def arena_sync(params, views, to_arena=True):
+    """Gradients that did not land in their slot (produced by torch's own backward functions): copy them in (before the
+    collective) / back out (after it) with one multi-tensor launch."""
+    pairs = [(p.grad, v) for p, v in zip(params, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
+    if pairs:
+        if to_arena:
+            torch._foreach_copy_([v for _, v in pairs], [g for g, _ in pairs])
+        else:
+            torch._foreach_copy_([g for g, _ in pairs], [v for _, v in pairs])
+    return len(pairs)
+
+
 class _Triplane(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pts, aabb, n_scales, *planes):
@@ -133,7 +184,7 @@ class _Triplane(torch.autograd.Function):
         dev, N = x.device, int(x.shape[0])
         early = ctx.early
         ws = early[0] if early else torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
-        dplanes = [torch.empty_like(p, dtype=torch.float32) for p in planes]
+        dplanes = [_arena_out(p) for p in planes]                    # (straight into the caller's flat buffer, if registered)
         arr = ((C.c_void_p * 3) * 4)()
         for s in range(n_scales):
             for c in range(3):
@@ -269,7 +320,7 @@ def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
         dW = db = None
         if need_dw:
             # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
-            dW = torch.empty_like(W, dtype=torch.float32)
+            dW = _arena_out(W)
             db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
             ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
             if _WG["on"]:

@@ -42,7 +42,7 @@ class FrameSharder:
 
 
 class FrameParallel:
-    def __init__(self, group=None, average=False, algorithm="all_reduce", host_staged=False):
+    def __init__(self, group=None, average=False, algorithm="all_reduce", host_staged=False, force=False):
         if not dist.is_initialized():
             raise RuntimeError("torch.distributed is not initialised (one process per GPU, backend 'nccl' = RCCL)")
         self.group = group
@@ -56,6 +56,16 @@ class FrameParallel:
         # whose backend cannot see device memory -- gloo, used when several ranks have to share ONE GPU (single-GPU test
         # boxes: RCCL refuses two ranks on a device).  Never the multi-GPU path.
         self.host_staged = bool(host_staged)
+        # force: issue every collective even in a ONE-rank group (RCCL accepts a one-rank communicator; the result equals the
+        # input bit for bit).  This is how the nccl branches below -- async all-reduce, in-place reduce-scatter + all-gather,
+        # work handles, chunked pipeline -- are executed on a single-GPU box (tests/test_gpu_bench.py, bench.py under
+        # SINGS_BENCH_FORCE_DIST=1); without it a world of one returns before touching the backend.
+        self.force = bool(force)
+
+    @property
+    def active(self):
+        """True when all_reduce_grads really issues collectives (several ranks, or a forced one-rank group)."""
+        return self.world > 1 or self.force
 
     def all_reduce_grads(self, flat, async_op=False):
         """Sum (or mean) of the flat canonical-Gaussian gradient buffer over all ranks, in place.
@@ -68,7 +78,7 @@ class FrameParallel:
         backend's stream behind the work of the CURRENT stream and a list of work handles is returned;
         ``FrameParallel.wait(handles, flat)`` makes the current stream wait for them (and applies the
         mean)."""
-        if self.world == 1:
+        if not self.active:
             return [] if async_op else flat
         if self.host_staged and flat.is_cuda:
             h = flat.detach().cpu()
@@ -104,7 +114,7 @@ class FrameParallel:
 
     def reduce_densification_stats(self, xyz_gradient_accum, denom, max_radii2D):
         """sum / sum / max over ranks, in place (identical topology decisions on every rank)."""
-        if self.world == 1:
+        if not self.active:
             return
         dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=self.group)
         dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=self.group)
@@ -151,7 +161,7 @@ class GradientPipeline:
         # one view per step: the row IS the sum (no fold, no copy)
         self.acc = rows[0] if self.k == 1 else torch.empty(self.n, dtype=rows.dtype, device=rows.device)
         world = 1 if frame_parallel is None else frame_parallel.world
-        c = max(1, int(chunks)) if world > 1 else 1
+        c = max(1, int(chunks)) if frame_parallel is not None and frame_parallel.active else 1
         step = -(-self.n // c)
         step = -(-step // (world * 64)) * (world * 64)           # chunk boundaries the rs_ag schedule divides, 256-B aligned
         self.bounds = [(lo, min(lo + step, self.n)) for lo in range(0, self.n, step)]
@@ -182,8 +192,12 @@ class GradientPipeline:
         return self.acc
 
     def one_shot(self):
-        """Reference schedule: fold everything, then ONE collective over the whole buffer (what ``reduce`` must reproduce
-        bit for bit; the pre-round-2 behaviour of bench.py)."""
+        """Reference schedule: fold everything, then ONE collective over the whole buffer (the pre-round-2 behaviour of
+        bench.py).  ``reduce`` gives the same SUM; bit-identical to this only where the backend's reduction order does not
+        depend on an element's position in the buffer -- true for two ranks (one addition per element: what
+        tests/test_dp_gloo.py checks) and for a forced one-rank group, NOT in general for RCCL ring / tree schedules with more
+        ranks, where chunking changes which rank adds first: there both schedules are deterministic per configuration, and
+        equal only to rounding."""
         if self.k > 1:
             torch.sum(self.rows, dim=0, out=self.acc)
         if self.fp is not None:

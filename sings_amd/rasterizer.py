@@ -34,32 +34,50 @@ class GaussianRasterizationSettings(NamedTuple):
 
 # ---- pair capacity and the overflow check -------------------------------------------------------------------------
 # The workspaces of a call are sized for `cap` (tile, Gaussian) pairs; the forward reports the count R it produced.
-# Upstream blocks the host in the MIDDLE of every forward to read R.  Here the mode decides when R is read:
-#   "async"    (default) the forward copies (R, overflow flag) to pinned host memory behind its kernels and returns at once;
-#              the value is looked at when the NEXT forward on the device is issued (the copy has long finished by then:
-#              a backward and an optimiser step lie in between), so the host never waits for the GPU inside a step and
-#              an unmodified training script runs at the speed of a pre-sized engine (0.36 instead of 0.49 ms per cfg3
-#              view).  The capacity keeps 2x headroom over the largest count seen and the FIRST call of every
-#              (device, P, image size) is checked synchronously, so an overflow needs a > 2x jump between two
-#              consecutive frames; if it happens that frame rendered the background and got zero gradients (the kernels
-#              never follow partly written lists) -- reported by a RuntimeWarning (or RuntimeError with
-#              ``set_overflow_check("async", on_overflow="raise")``) at the next call, and the capacity grows.
-#   "sync"     read R at the END of every forward and re-run with a larger workspace if needed (round-1 default):
-#              never a wrong frame, but the host cannot queue the backward while the forward runs.
-#   "deferred" no host read at all (a whole step can be captured into a HIP graph): every forward folds (R, flag) into a
-#              per-device accumulator ON THE DEVICE; ``check_deferred_overflow()`` reads and resets it.
+# Upstream blocks the host in the MIDDLE of every forward to read R and so never renders with a too small buffer.  Here
+# the mode decides when R is read:
+#   "sync"     (default; the drop-in guarantee) every forward knows R before it returns and re-runs with a larger
+#              workspace if needed: NEVER a wrong frame, whatever the script does between frames.  The count does not wait
+#              for the forward to finish: the binning kernel publishes it to a pinned, mapped host word the moment it
+#              exists (SgRasterSettings.count_signal, include/sings_hip.h) -- a third of the way into a cfg3 forward -- and
+#              the call returns while the composite kernel is still running, so the host queues the loss and the backward
+#              behind it instead of starting them after a full stream synchronisation (round 1 / 2's "sync").
+#   "async"    opt-in: the forward copies (R, overflow flag) to pinned host memory behind its kernels and returns at once;
+#              the value is looked at when the NEXT forward on the device is issued.  The capacity keeps 2x headroom over
+#              the largest count seen and the FIRST call of every (device, P, image size) is checked synchronously, so an
+#              overflow needs a > 2x jump between two consecutive frames; if it happens, THAT frame rendered the background
+#              and got zero gradients (the kernels never follow partly written lists) and the next call raises RuntimeError
+#              (``on_overflow="warn"``: a RuntimeWarning instead) after growing the capacity.
+#   "deferred" opt-in: no host read at all (a whole step can be captured into a HIP graph): every forward folds (R, flag)
+#              into a per-device accumulator ON THE DEVICE; ``check_deferred_overflow()`` reads and resets it.
 _capacity_hint = {}                    # device index -> pairs
-_mode = {"mode": "async", "on_overflow": "warn"}
+_mode = {"mode": "sync", "on_overflow": "raise"}
 _seen = {}                             # device index -> set of (P, W, H) signatures already checked synchronously
 _pending = {}                          # device index -> list of [pinned (R, flag), event, cap] of async forwards
 _accum = {}                            # device index -> int32[2] device tensor: max R, OR of flags (deferred mode)
 _HEADROOM = 2.0
 _ring = {}                             # device index -> [pinned int32[_RING, 2], next slot]
 _RING = 16
+_signal = {}                           # device index -> [host address, device address, next slot] of the early-count words
+_SIGNAL_SLOTS = 64
 
 
-def set_overflow_check(mode="async", on_overflow=None, capacity_pairs=None, device=None):
-    """Select when the pair count of a forward is checked against the capacity: "async" | "sync" | "deferred"."""
+def _signal_slot(dev):
+    """(device address, host address) of the next early-count word of ``dev`` (a ring: a "sync" forward consumes its word
+    before it returns, so slots are only shared by calls that are 64 forwards apart)."""
+    sg = _signal.get(dev.index)
+    if sg is None:
+        h, d = C.c_void_p(), C.c_void_p()
+        with torch.cuda.device(dev):
+            _lib.check(_lib.load().sg_signal_alloc(_SIGNAL_SLOTS, C.byref(h), C.byref(d)), "sg_signal_alloc")
+        sg = _signal[dev.index] = [h.value, d.value, 0]
+    k = sg[2] % _SIGNAL_SLOTS
+    sg[2] += 1
+    return sg[1] + 8 * k, sg[0] + 8 * k
+
+
+def set_overflow_check(mode="sync", on_overflow=None, capacity_pairs=None, device=None):
+    """Select when the pair count of a forward is checked against the capacity: "sync" (default) | "async" | "deferred"."""
     if mode not in ("async", "sync", "deferred"):
         raise ValueError("mode must be 'async', 'sync' or 'deferred'")
     _mode["mode"] = mode
@@ -73,8 +91,8 @@ def set_overflow_check(mode="async", on_overflow=None, capacity_pairs=None, devi
 
 
 def set_deferred_overflow_check(on=True, capacity_pairs=None, device=None):
-    """Round-1 name: ``on`` selects "deferred", otherwise back to the default "async"."""
-    set_overflow_check("deferred" if on else "async", capacity_pairs=capacity_pairs, device=device)
+    """Round-1 name: ``on`` selects "deferred", otherwise back to the default "sync"."""
+    set_overflow_check("deferred" if on else "sync", capacity_pairs=capacity_pairs, device=device)
 
 
 def _grow(dev_index, R):
@@ -217,7 +235,13 @@ def _settings_struct(rs, dev, sh_coeffs, keep):
     s.sh_degree = int(rs.sh_degree); s.sh_coeffs = int(sh_coeffs)
     s.prefiltered = int(bool(rs.prefiltered)); s.debug = int(bool(rs.debug)); s.flags = 0
     s.bg = bg.data_ptr(); s.viewmatrix = vm.data_ptr(); s.projmatrix = pm.data_ptr(); s.campos = cp.data_ptr()
+    s.count_signal = None; s.count_signal_host = None
     return s
+
+
+def _arm_early_count(s, dev):
+    """Give the settings of a forward that wants R back an early-count word (see "sync" above)."""
+    s.count_signal, s.count_signal_host = _signal_slot(dev)
 
 
 def _empty_to_none(t):
@@ -251,6 +275,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         cap, sync, sig = _forward_plan(dev, P, W, H)
         with torch.cuda.device(dev):
+            if sync and not rs.debug:
+                _arm_early_count(s, dev)
             while True:
                 L = _lib.layout(P, W, H, cap)
                 geom = torch.empty(L.geom_bytes, dtype=torch.uint8, device=dev)

@@ -71,6 +71,8 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
         cap, sync, sig = _rz._forward_plan(dev, P, W, H)     # see rasterizer.set_overflow_check
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            if sync and not rs.debug:
+                _rz._arm_early_count(s, dev)
             while True:
                 L = _lib.layout(P, W, H, cap)
                 geom = torch.empty(L.geom_bytes, dtype=torch.uint8, device=dev)
@@ -136,13 +138,9 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                 _ptr(binning), ctx.cap, _ptr(img), _ptr(bwd_ws), _ptr(skin_ws), _ptr(g_color), _ptr(g_pxyz), _ptr(g_pq),
                 _ptr(d_xyz), _ptr(d_rot), _ptr(d_scales), _ptr(d_op), _ptr(d_sh), _ptr(d_m2d), _ptr(d_A), _ptr(d_tr),
                 stream), "skinned backward")
-        _RasterizeSkinnedGaussians.last_viewspace_grad = d_m2d      # (kept for round-1 callers: last call wins)
         return (d_xyz, None if d_rot is None else d_rot.view(ctx.rot_shape), d_scales, d_op.view_as(opacities), d_sh,
                 d_A.view(A_shape), None if transl_shape is None else d_tr.view(transl_shape), None, None, None, None, None,
                 d_m2d if ctx.has_m2d else None)
-
-
-_RasterizeSkinnedGaussians.last_viewspace_grad = None
 
 
 def rasterize_skinned_gaussians(xyz_canon, rotmat_canon, scales, opacities, shs, lbs_weights, A_cano2pose,

@@ -24,8 +24,9 @@ def pytest_terminal_summary(terminalreporter, exitstatus, config):
     mod = sys.modules.get("test_gpu_raster") or sys.modules.get("tests.test_gpu_raster")
     rows = getattr(mod, "BORDERLINE", None) if mod else None
     if rows:
-        terminalreporter.write_sep("-", "borderline pixels (oracle threshold margin < 2e-5): test, count / pixels, of which > 1e-5 off")
-        for name, nb, npx, nd in rows:
-            terminalreporter.write_line(f"{name}: {nb} / {npx}, {nd} differ")
+        terminalreporter.write_sep("-", "borderline pixels (oracle threshold margin < 2e-5): test, count / pixels, of which > 1e-5 off, "
+                                        "worst |delta| (each bounded by its borderline splat's contribution)")
+        for name, nb, npx, nd, worst in rows:
+            terminalreporter.write_line(f"{name}: {nb} / {npx}, {nd} differ, worst {worst:.3e}")
         terminalreporter.write_line(f"total: {sum(r[1] for r in rows)} borderline of {sum(r[2] for r in rows)} pixels, "
-                                    f"{sum(r[3] for r in rows)} differ by more than 1e-5")
+                                    f"{sum(r[3] for r in rows)} differ by more than 1e-5, worst {max(r[4] for r in rows):.3e}")

@@ -1,0 +1,106 @@
+"""Host-side logic of bench.py that needs no GPU: the PMC sidecar guard (a committed counter pass is only used for the
+roofline if it profiled THIS configuration and THIS tree), the repeated timed region, the per-kernel byte split."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CFG = {"workload": "raster", "gaussians": 200000, "width": 1920, "height": 1080, "sh_degree": 3}
+
+
+def _profiles(tmp_path, meta, traffic_meta="same"):
+    p = tmp_path / "profiles"
+    p.mkdir()
+    (p / "r99_pmc_SQ.csv").write_text("kernel,Counter_Name,mean,count\n"
+                                      "sg_render_bwd_kernel,SQ_INSTS_VALU,80000000.0,5\n"
+                                      "sg_preprocess_bwd_kernel<3>,SQ_INSTS_VALU,6000000.0,5\n")
+    if meta is not None:
+        (p / "r99_pmc_SQ.meta.json").write_text(json.dumps(meta))
+    t = {"sg_render_bwd_kernel": 123456, "sg_preprocess_bwd_kernel<3>": 777}
+    if traffic_meta is not None:
+        t["_meta"] = meta if traffic_meta == "same" else traffic_meta
+    (p / "hbm_traffic.json").write_text(json.dumps(t))
+    return str(p)
+
+
+def test_matching_sidecar_is_used(tmp_path):
+    meta = {"config": dict(CFG), "sources": bench.source_hashes()}
+    r = bench._committed_pmc("sg_render_bwd_kernel", CFG, _profiles(tmp_path, meta))
+    assert r["stale"] is None and r["valu"] == 8.0e7 and r["traffic"] == 123456
+    # template instances are matched by their base name
+    (tmp_path / "b").mkdir()
+    assert bench._committed_pmc("sg_preprocess_bwd_kernel", CFG, _profiles(tmp_path / "b", meta))["valu"] == 6.0e6
+
+
+def test_tampered_sidecar_drops_the_valu_roofline(tmp_path):
+    """One changed kernel source (here: a hash that is not the tree's) and the committed instruction count is not used:
+    build_roofline falls back to the HBM roofline and says why."""
+    src = bench.source_hashes()
+    src["sings_amd/csrc/sg_render.hip"] = "0" * 40
+    meta = {"config": dict(CFG), "sources": src}
+    pdir = _profiles(tmp_path, meta)
+    r = bench._committed_pmc("sg_render_bwd_kernel", CFG, pdir)
+    assert "valu" not in r and "sg_render.hip" in r["stale"] and "traffic" not in r and "sg_render.hip" in r["traffic_stale"]
+    old = bench._committed_pmc
+    bench._committed_pmc = lambda k, c: old(k, c, pdir)
+    try:
+        kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
+                "sg_preprocess_bwd_kernel": 0.03}
+        per, _ = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
+        roof, hbm = bench.build_roofline(kern, per, CFG)
+    finally:
+        bench._committed_pmc = old
+    assert roof["bound"] == "hbm" and roof["kernel"] == "sg_render_bwd_kernel" and "sg_render.hip" in roof["note"]
+    assert roof["traffic"] is None and abs(roof["frac"] - hbm["frac"]) < 1e-12
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(roof)
+
+
+def test_other_configuration_or_missing_sidecar_is_not_used(tmp_path):
+    meta = {"config": dict(CFG, gaussians=50000), "sources": bench.source_hashes()}
+    r = bench._committed_pmc("sg_render_bwd_kernel", CFG, _profiles(tmp_path, meta))
+    assert "valu" not in r and "another configuration" in r["stale"]
+    (tmp_path / "n").mkdir()
+    r = bench._committed_pmc("sg_render_bwd_kernel", CFG, _profiles(tmp_path / "n", None, traffic_meta=None))
+    assert "valu" not in r and "no sidecar" in r["stale"] and "traffic" not in r
+
+
+def test_committed_passes_have_sidecars():
+    """Every PMC file the bench may read from profiles/ names its configuration and sources (or is ignored)."""
+    pdir = os.path.join(ROOT, "profiles")
+    newest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv"))[-1]
+    meta = json.load(open(os.path.join(pdir, newest[:-4] + ".meta.json")))
+    assert set(meta["sources"]) == set(bench.PMC_SOURCES) and "gaussians" in meta["config"]
+    assert "_meta" in json.load(open(os.path.join(pdir, "hbm_traffic.json")))
+
+
+def test_git_blob_hash_is_gits(tmp_path):
+    f = tmp_path / "x"
+    f.write_bytes(b"hello\n")
+    assert bench.git_blob_sha1(str(f)) == "ce013625030ba8dba906f756967f9e9ca394464a"      # git hash-object of "hello\n"
+
+
+def test_timed_repeats_runs_whole_regions_until_the_minimum(monkeypatch):
+    calls = []
+
+    def fake_region(dist, dev, steps, step):
+        calls.append(steps)
+        return 0.1
+    monkeypatch.setattr(bench, "timed_region", fake_region)
+    els = bench.timed_repeats(None, None, 7, None)
+    assert calls == [7] * 5 and len(els) == 5                   # 5 x 0.1 s reaches MIN_TIMED_S = 0.5
+    calls.clear()
+    monkeypatch.setattr(bench, "timed_region", lambda *a: calls.append(1) or 2.0)
+    assert len(bench.timed_repeats(None, None, 3, None)) == 2   # never fewer than two regions
+    assert bench._median([3.0, 1.0, 2.0]) == 2.0 and bench._median([1.0, 2.0]) == 1.5
+
+
+def test_skinned_byte_split_matches_the_survey_formula():
+    N, H, W, R, J = 150000, 896, 512, 740000, 52
+    per, total = bench.algorithmic_bytes_skinned(N, H, W, R, 0, J)
+    base_per, base_total = bench.algorithmic_bytes(N, H, W, R, 0)
+    extra_read = N * (12 + 4 * J) - N * 28
+    assert per["sg_preprocess_fwd_kernel"] == base_per["sg_preprocess_fwd_kernel"] + extra_read
+    assert total == base_total + 2 * extra_read + N * 12 - N * 28

@@ -145,3 +145,49 @@ def test_pipelined_reduction_matches_one_shot_all_reduce():
 
 def test_pipelined_reduction_matches_one_shot_rs_ag():
     _run_pipeline("rs_ag")
+
+
+def _force_worker(port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        calls = {"all_reduce": 0, "reduce_scatter_tensor": 0, "all_gather_into_tensor": 0}
+        for name in calls:
+            def wrap(fn, name=name):
+                def inner(*a, **k):
+                    calls[name] += 1
+                    return fn(*a, **k)
+                return inner
+            setattr(dist, name, wrap(getattr(dist, name)))
+        res = {}
+        rows = torch.randn(3, 1003)
+        for algo in ("all_reduce", "rs_ag"):
+            lazy = FrameParallel(algorithm=algo)                       # world 1, not forced: returns before the backend
+            assert not lazy.active
+            before = dict(calls)
+            g = rows[0].clone(); lazy.all_reduce_grads(g)
+            assert calls == before and torch.equal(g, rows[0])
+            fp = FrameParallel(algorithm=algo, force=True)
+            assert fp.active
+            g = rows[0].clone(); fp.all_reduce_grads(g)
+            pipe = GradientPipeline(rows.clone(), fp, chunks=4)
+            assert len(pipe.bounds) == 4                               # chunked although there is one rank
+            acc = pipe.reduce().clone()
+            res[algo] = (torch.equal(g, rows[0]), torch.equal(acc, rows.sum(0)), torch.equal(pipe.one_shot(), rows.sum(0)))
+        out.put((res, calls))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_forced_one_rank_group_issues_every_collective():
+    """FrameParallel(force=True): the collectives of both schedules run in a ONE-rank group (what bench.py does on a single-GPU
+    box under SINGS_BENCH_FORCE_DIST=1 so that the nccl branches execute) and are the identity."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_force_worker, args=(_free_port(), q))
+    p.start()
+    res, calls = q.get(timeout=120)
+    p.join(60)
+    assert p.exitcode == 0
+    assert res == {"all_reduce": (True, True, True), "rs_ag": (True, True, True)}
+    assert calls["all_reduce"] >= 6 and calls["reduce_scatter_tensor"] >= 5 and calls["all_gather_into_tensor"] >= 5

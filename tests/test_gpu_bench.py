@@ -41,6 +41,62 @@ def test_single_gpu_line_carries_the_contract():
 
 
 @pytest.mark.gpu
+def test_timed_region_is_repeated_and_the_schema_is_one():
+    """--steps 3 of a small scene is a few milliseconds: the region is repeated (whole regions of 3 steps) until it adds up to
+    0.5 s, the line reports the median; the collective keys exist (null) without a collective."""
+    j = _line(_bench("--gpus", "1", "--no-cpu-baseline", *SMALL))
+    assert j["repeats"] >= 2 and j["timed_region_s"] >= 0.5 and j["steps"] == 3
+    assert j["ms_per_step_min"] <= j["ms_per_step"] <= j["ms_per_step_max"]
+    for k in ("allreduce_ms", "allreduce_bytes", "allreduce_algorithm", "allreduce_per_link_bound_ms", "allreduce_exposed_ms"):
+        assert k in j and j[k] is None
+    assert j["rccl_world"] is None and j["dist_backend"] is None
+    # the small scene has no committed PMC pass: the composite kernel's VALU roofline is omitted, with the reason
+    if j["roofline"]["kernel"] in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
+        assert j["roofline"]["bound"] == "hbm" and "PMC" in j["roofline"]["note"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_rccl_branches_run_with_one_rank(algo):
+    """SINGS_BENCH_FORCE_DIST=1: init_process_group("nccl", device_id=...), FrameParallel's asynchronous all-reduce / in-place
+    reduce-scatter + all-gather on device views, GradientPipeline's chunked fold + collective with RCCL work handles and the
+    device-side MAX of the timed region all EXECUTE, on a one-rank communicator -- and leave the gradients bit-identical to
+    the run without a process group (a one-rank sum is the identity; the backward is bitwise reproducible)."""
+    ref = _line(_bench("--gpus", "1", "--no-cpu-baseline", "--grad-hash", *SMALL))
+    j = _line(_bench("--gpus", "1", "--no-cpu-baseline", "--grad-hash", *SMALL,
+                     env={"SINGS_BENCH_FORCE_DIST": "1", "SINGS_DP_ALGO": algo}))
+    assert j["dist_backend"] == "nccl" and j["rccl_world"] == 1 and j["dist_world"] == 1
+    assert j["allreduce_algorithm"] == algo and j["allreduce_ms"] > 0 and j["allreduce_exposed_ms"] > 0
+    assert j["allreduce_bytes"] == 20000 * 59 * 4
+    assert "4 chunk" in j["config"]["reduction"]
+    assert j["grad_sha256"] == ref["grad_sha256"]
+    assert j["train_step_ms_one_view"] > 0 and j["value"] > 0
+
+
+@pytest.mark.gpu
+def test_rccl_branches_run_with_one_rank_avatar_and_train():
+    """The same for the other two workloads: the avatar step (fused LBS path, 10 floats per Gaussian all-reduced) and the
+    complete training step (parameter gradients written straight into ONE flat buffer -- sings_amd.decode.set_gradient_arena --
+    and all-reduced in place)."""
+    small = ["--gaussians", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    env = {"SINGS_BENCH_FORCE_DIST": "1"}
+    ref = _line(_bench("--workload", "avatar", "--grad-hash", *small))
+    j = _line(_bench("--workload", "avatar", "--grad-hash", *small, env=env))
+    assert j["dist_backend"] == "nccl" and j["rccl_world"] == 1 and j["allreduce_ms"] > 0
+    assert j["allreduce_bytes"] == 20000 * 10 * 4 and j["grad_sha256"] == ref["grad_sha256"]
+    assert j["repeats"] >= 2 and j["roofline"]["kernel"].startswith("sg_") and j["train_step_ms_one_view"] > 0
+    ref = _line(_bench("--workload", "train", *small))
+    assert ref["allreduce_ms"] is None and ref["rccl_world"] is None
+    j = _line(_bench("--workload", "train", *small, env=env))
+    assert j["dist_backend"] == "nccl" and j["rccl_world"] == 1 and j["allreduce_ms"] > 0
+    assert j["allreduce_bytes"] == 4 * j["config"]["trainable_parameters"]
+    # the tri-plane planes and the decoder weights (> 99 % of the parameters) were written in place, the rest copied
+    assert j["config"]["gradient_bytes_written_in_place"] >= 0.95 * j["allreduce_bytes"]
+    for k, v in ref["losses"].items():                               # (the tri-plane backward uses float atomics: not bitwise)
+        assert abs(j["losses"][k] - v) <= 1e-4 * max(1.0, abs(v)), k
+
+
+@pytest.mark.gpu
 def test_gpus_2_starts_two_ranks_and_the_collective_layer_sees_them():
     """`python bench.py --gpus 2` must really run two ranks (round 1 ignored the flag).  A one-GPU box is oversubscribed:
     both ranks share the device and the collectives are host-staged gloo (RCCL refuses two ranks on one device); on a

@@ -65,25 +65,30 @@ def _check_forward_state(s, st, o):
     np.testing.assert_array_equal(st["point_keys"].cpu().numpy().astype(np.uint64), o["keys"])
 
 
-BORDERLINE = []        # (test id, borderline pixels, pixels): written to the report by conftest.pytest_terminal_summary
+BORDERLINE = []        # (test id, borderline pixels, pixels, > 1e-5 off, worst borderline |delta|): report by conftest.pytest_terminal_summary
 
 
 def _check_image(color, final_T, n_contrib, o):
     """RGB <= 1e-5 on every pixel whose hard-threshold decisions (alpha >= 1/255, T >= 1e-4, power <= 0) have a relative
-    margin >= 2e-5 in the oracle.  The others ("borderline": fp32 exp noise can flip the decision) may differ by one
-    splat's contribution; their NUMBER is recorded per test (printed at the end of the run by conftest.py) and bounded by
-    twice what was observed on the MI355X: 81 of 308 800 pixels across the suite, worst 76 of 262 144 = 2.9e-4 at cfg2,
-    NONE of them actually off by more than 1e-5 (round 1 allowed 1e-3 of the image and counted nothing)."""
+    margin >= 2e-5 in the oracle.  The others ("borderline": fp32 exp noise can flip the decision) may differ by the
+    contribution of the splat(s) whose decision is borderline -- the oracle bounds that per pixel (``o["flip"]``:
+    alpha T (|c| + cmax) per borderline alpha / power decision, 2 T cmax per borderline termination) and the pixel must stay
+    within 1e-5 + that bound; their NUMBER and the WORST borderline error are recorded per test (printed at the end of the
+    run by conftest.py).  Observed on the MI355X: ~150 of 2.0 M pixels across the suite, one of them beyond 1e-5."""
     import os
     diff = np.abs(color - o["color"]).max(0)
     border = o["margin"] < BORDER
     nb = int(border.sum())
+    worst = float(diff[border].max()) if nb else 0.0
     BORDERLINE.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], nb, int(border.size),
-                       int((diff[border] > RGB_TOL).sum()) if nb else 0))
+                       int((diff[border] > RGB_TOL).sum()) if nb else 0, worst))
     assert nb <= 8 + 6e-4 * border.size, f"{nb} borderline pixels of {border.size}"
     strict = ~border
     assert diff[strict].max() <= RGB_TOL, f"RGB L_inf {diff[strict].max()} at {np.argwhere(diff == diff[strict].max())[:3]}"
-    assert diff.max() <= 5e-2
+    if nb:
+        over = diff[border] - (RGB_TOL + 1.001 * o["flip"][border])
+        assert over.max() <= 0, (f"a borderline pixel is off by {diff[border][over.argmax()]:.3e}, more than the contribution of its "
+                                 f"borderline splat(s) ({o['flip'][border][over.argmax()]:.3e})")
     assert np.abs(final_T - o["final_T"])[strict].max() <= 1e-5
     assert np.array_equal(n_contrib[strict].astype(np.uint32), o["n_contrib"][strict])
     return nb
@@ -646,17 +651,58 @@ def test_deferred_overflow_check():
         rz._capacity_hint.update(hint)
 
 
-def test_async_overflow_check_is_the_default_and_reports_late():
-    """Default mode: the FIRST forward of a (device, P, image size) reads the pair count before returning and sizes the
-    capacity with 2x headroom; later forwards copy (R, flag) to pinned memory behind their kernels and return at once.
-    Several forwards may be issued before anything is looked at and none of their results is lost (round 1 kept only the
-    last one): a frame that overflowed renders the background, the NEXT call reports it (RuntimeWarning) and has a
-    capacity that fits."""
+def test_default_overflow_mode_never_returns_a_wrong_frame():
+    """The drop-in default ("sync", as upstream: R is known before the forward returns): a frame with > 2x the pairs of
+    anything seen before is re-run with a larger workspace inside the SAME call -- never the background, never zero
+    gradients.  The count comes back through the early-count word (SgRasterSettings.count_signal), i.e. without a stream
+    synchronisation: the composite kernel may still be running when the call returns; results are complete once the
+    stream is."""
+    from sings_amd import rasterizer as rz
+    from sings_amd.rasterizer import GaussianRasterizer
+    dev = _dev()
+    assert rz._mode == {"mode": "sync", "on_overflow": "raise"}
+    rz.reset_overflow_state()
+    big = synthetic_scene(30000, 160, 128, 1, 31)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    def args(scale):
+        return dict(means3D=t(big["means3D"]), means2D=torch.zeros(30000, 3, device=dev), opacities=t(big["opacities"]),
+                    shs=t(big["shs"]), scales=t(big["scales"] * scale).requires_grad_(True), rotations=t(big["rotations"]))
+    brs = _settings(big, dev)
+    bgv = t(big["bg"])[:, None, None].expand(3, big["H"], big["W"])
+    try:
+        small, _ = GaussianRasterizer(brs)(**args(0.3))
+        cap0 = rz._capacity_hint[dev.index]
+        assert rz._signal.get(dev.index) is not None and not rz._pending.get(dev.index)   # early-count words in use, nothing async
+        a8 = args(8.0)
+        huge, _ = GaussianRasterizer(brs)(**a8)                     # > 2x the pairs of the frame before
+        assert rz._capacity_hint[dev.index] > cap0
+        assert not torch.equal(huge, bgv)
+        huge.sum().backward()
+        assert float(a8["scales"].grad.abs().sum()) > 0
+        again, _ = GaussianRasterizer(brs)(**args(8.0))             # same frame, now with a capacity that fits from the start
+        assert torch.equal(huge, again)
+        back, _ = GaussianRasterizer(brs)(**args(0.3))
+        assert torch.equal(back, small)
+        # the same through the synchronous read (debug = True syncs after every kernel and does not arm the word)
+        dbg = brs._replace(debug=True)
+        rz.reset_overflow_state()
+        GaussianRasterizer(dbg)(**args(0.3))
+        huge_d, _ = GaussianRasterizer(dbg)(**args(8.0))
+        assert torch.equal(huge_d, huge)
+    finally:
+        rz.reset_overflow_state()
+
+
+def test_async_overflow_check_is_opt_in_and_raises_late():
+    """Opt-in "async" mode: the FIRST forward of a (device, P, image size) reads the pair count before returning and sizes
+    the capacity with 2x headroom; later forwards copy (R, flag) to pinned memory behind their kernels and return at once.
+    Several forwards may be issued before anything is looked at and none of their results is lost: a frame that overflowed
+    renders the background, and the NEXT call RAISES (on_overflow="raise" is the default; "warn" downgrades it to a
+    RuntimeWarning) with a capacity that fits from then on."""
     import warnings
     from sings_amd import rasterizer as rz
     from sings_amd.rasterizer import GaussianRasterizer
     dev = _dev()
-    assert rz._mode["mode"] == "async"
     rz.reset_overflow_state()
     big = synthetic_scene(30000, 160, 128, 1, 31)
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
@@ -666,36 +712,44 @@ def test_async_overflow_check_is_the_default_and_reports_late():
     brs = _settings(big, dev)
     bgv = t(big["bg"])[:, None, None].expand(3, big["H"], big["W"])
     try:
-        with warnings.catch_warnings():
-            warnings.simplefilter("error")
-            small, _ = GaussianRasterizer(brs)(**args(0.3))          # first call of this signature: synchronous
-            assert not rz._pending.get(dev.index)
-            cap0 = rz._capacity_hint[dev.index]
-            small2, _ = GaussianRasterizer(brs)(**args(0.3))         # asynchronous from now on
-            assert len(rz._pending[dev.index]) == 1 and torch.equal(small, small2)
-            huge, _ = GaussianRasterizer(brs)(**args(8.0))           # > 2x the pairs: overflows the capacity, not yet known
+        rz.set_overflow_check("async")
+        assert rz._mode["on_overflow"] == "raise"
+        small, _ = GaussianRasterizer(brs)(**args(0.3))              # first call of this signature: synchronous
+        assert not rz._pending.get(dev.index)
+        cap0 = rz._capacity_hint[dev.index]
+        small2, _ = GaussianRasterizer(brs)(**args(0.3))             # asynchronous from now on
+        assert len(rz._pending[dev.index]) == 1 and torch.equal(small, small2)
+        huge, _ = GaussianRasterizer(brs)(**args(8.0))               # > 2x the pairs: overflows the capacity, not yet known
         assert torch.equal(huge, bgv)
-        with warnings.catch_warnings(record=True) as rec:            # reported by whichever later call finds the copy done
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="rendered the background"):     # late, but loud
+            GaussianRasterizer(brs)(**args(0.3))
+        assert rz._capacity_hint[dev.index] > cap0
+        redo, _ = GaussianRasterizer(brs)(**args(8.0))               # capacity grown by now
+        assert not torch.equal(redo, bgv)
+        # "warn": the same event as a RuntimeWarning
+        rz.reset_overflow_state()
+        rz.set_overflow_check("async", on_overflow="warn")
+        GaussianRasterizer(brs)(**args(0.3)); GaussianRasterizer(brs)(**args(0.3))
+        huge, _ = GaussianRasterizer(brs)(**args(8.0))
+        torch.cuda.synchronize()
+        with warnings.catch_warnings(record=True) as rec:
             warnings.simplefilter("always")
             also, _ = GaussianRasterizer(brs)(**args(0.3))
-            torch.cuda.synchronize()
-            redo, _ = GaussianRasterizer(brs)(**args(8.0))           # capacity grown by now
-        assert sum("rendered the background" in str(w.message) for w in rec) == 1
-        assert torch.equal(also, small)
-        assert rz._capacity_hint[dev.index] > cap0 and not torch.equal(redo, bgv)
-        rz.set_overflow_check("sync")
+        assert sum("rendered the background" in str(w.message) for w in rec) == 1 and torch.equal(also, small)
+        rz.set_overflow_check("sync", on_overflow="raise")
         ref, _ = GaussianRasterizer(brs)(**args(8.0))
         assert torch.equal(redo, ref)
         assert rz.check_deferred_overflow(dev) is not None           # drains what is pending; nothing overflowed since
     finally:
-        rz.set_overflow_check("async")
+        rz.set_overflow_check("sync", on_overflow="raise")
         rz.reset_overflow_state()
 
 
-@pytest.mark.parametrize("n", [255, 256, 257, 512, 513, 4096, 4097])
+@pytest.mark.parametrize("n", [128, 129, 255, 256, 257, 512, 513, 1024, 1025, 4096, 4097])
 def test_list_lengths_on_internal_boundaries(n):
-    """A tile whose list has exactly n entries, n on the boundaries of the wave sort / depth segments (256) and of the
-    sort chunks (4096): binning bit-exact, image and gradients vs the oracle (the sweep of tests/tools/fuzz_parity.py)."""
+    """A tile whose list has exactly n entries, n on the boundaries of the rank sort (128: SG_RANKSORT_MAX), the one-wave sort /
+    depth segments (256), the in-composite sort (1024: SG_WSORT_MAX) and of the sort chunks (4096): binning bit-exact, image and gradients vs the oracle (the sweep of tests/tools/fuzz_parity.py)."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)

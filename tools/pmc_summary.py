@@ -6,6 +6,19 @@ import csv, json, os, re, sys
 from collections import defaultdict
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+# What the passes profiled: the bench configuration (default: cfg3, the command of tools/collect_profiles.sh; otherwise
+# `workload=avatar gaussians=150000 width=512 height=896 sh_degree=0` style arguments) and the git blob hashes of the kernel
+# sources AS THEY ARE in the tree the passes ran from -- run this script in that tree.  bench.py refuses counts whose sidecar
+# does not match the run (bench._committed_pmc).
+import bench
+config = {"workload": "raster", "gaussians": 200000, "width": 1920, "height": 1080, "sh_degree": 3}
+for kv in sys.argv[3:]:
+    k, v = kv.split("=")
+    config[k] = v if k == "workload" else int(v)
+meta = {"config": config, "sources": bench.source_hashes(root),
+        "command": "rocprofv3 --pmc <set> -- python3 bench.py --steps 5 --warmup 2 --views-per-step 1 --streams 1 --no-cpu-baseline"
+                   + ("" if config["workload"] == "raster" else f" --workload {config['workload']}")}
 
 
 def short(name):
@@ -30,11 +43,13 @@ for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
         for (k, c), (s, n) in sorted(acc.items()):
             fo.write(f"{k},{c},{s / n:.1f},{n}\n")
             means[(k, c)] = s / n
-    print("wrote", out)
+    json.dump(meta, open(out[:-4] + ".meta.json", "w"), indent=1, sort_keys=True)
+    print("wrote", out, "+ .meta.json")
 traffic = {}
 for (k, c) in list(means):
     if c == "FETCH_SIZE" and (k, "WRITE_SIZE") in means:
         traffic[k] = int((2 * means[(k, "FETCH_SIZE")] + means[(k, "WRITE_SIZE")]) * 1024)
 if traffic:
+    traffic["_meta"] = meta
     json.dump(traffic, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
-    print("wrote profiles/hbm_traffic.json", traffic)
+    print("wrote profiles/hbm_traffic.json", {k: v for k, v in traffic.items() if k != "_meta"})
