@@ -61,7 +61,7 @@ FORCE_DIST = bool(os.environ.get("SINGS_BENCH_FORCE_DIST"))
 # one schema for every N: the collective keys are present (null) when no collective ran
 COMM_KEYS = ("allreduce_ms", "allreduce_bytes", "allreduce_algorithm", "allreduce_per_link_bound_ms", "allreduce_exposed_ms")
 MIN_TIMED_S = 0.5              # the timed region is repeated (whole regions of exactly --steps steps) until it adds up to this
-MAX_REPEATS = 200
+MAX_REPEATS = 5000
 
 
 def _log(msg):

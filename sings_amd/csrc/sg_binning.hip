@@ -16,13 +16,13 @@
 //               outputs (ranges, plans, work lists, R) are written by the workgroups between them.
 //   3. sort   : lists of <= 1024 entries are sorted by the forward composite kernel itself, in the LDS of the tile's
 //               workgroup, just before it gathers the records (sg_sort.h; no launch, no extra pass over the keys);
-//               longer lists: one workgroup per 4096-entry chunk (bitonic), longer still: chunks merged by rank.
+//               longer lists (round 3): a BUCKET sort -- sg_tile_partition_kernel splits a list by key value into groups of
+//               <= 1024 entries (one O(n) pass pair per tile), sg_group_sort_kernel sorts every group in LDS, one workgroup
+//               per group, chip-wide.  (Rounds 1-2: bitonic sort of 4096-entry chunks + a rank merge of the chunks:
+//               O(n log^2 n) comparators per tile on ONE workgroup per chunk, 44 + 21 us on an avatar frame.)
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
 // (Round 1 ran scan / scatter / sort / rank as four launches: 10 + 12 + 18 + 4 us at cfg3, all latency.)
 #include "sg_sort.h"
-
-#define SG_SORT_THREADS 1024   // longer lists: one 1024-thread workgroup per chunk of
-#define SG_SORT_LDS 4096       // u64 entries sorted in LDS (32 KiB)
 
 // Exclusive scans over the T tile counts of
 //   q0 pairs (-> ranges, cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
@@ -39,8 +39,8 @@
 __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ])
 {
     const uint32_t seg = sg_nseg(v);
-    const uint32_t nch = v > SG_WSORT_MAX ? (v + SG_SORT_LDS - 1) / SG_SORT_LDS : 0u;
-    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = nch; q[4] = nch > 1 ? nch : 0u;
+    // q3: partition work items (one per list the compositing workgroup does not sort itself); q4: group slots reserved for it
+    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = v > SG_WSORT_MAX ? 1u : 0u; q[4] = sg_group_slots(v);
 }
 
 // Early pair count: one 64-bit system-scope store to a mapped, coherent host word (valid bit | flags << 32 | R) -- visible to a
@@ -165,11 +165,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
         const uint32_t nseg = sg_nseg(pl.w), nit = nseg ? nseg : 1u;
         for (uint32_t sg = 0; sg < nit; sg++)
             if (pl.x + sg < items_cap) items[pl.x + sg] = tile | (sg << 20);
-        const uint32_t nch = pl.w > SG_WSORT_MAX ? (pl.w + SG_SORT_LDS - 1) / SG_SORT_LDS : 0u;
-        for (uint32_t c = 0; c < nch; c++) {
-            if (pl.y + c < sort_cap) sort_items[pl.y + c] = make_uint2(tile, c);
-            if (nch > 1 && pl.z + c < rank_cap) rank_items[pl.z + c] = make_uint2(tile, c);
-        }
+        if (pl.w > SG_WSORT_MAX && pl.y < sort_cap) sort_items[pl.y] = make_uint2(tile, pl.z);     // (tile, first group slot)
     }
     const uint32_t R = header[0] < cap ? header[0] : cap;
     for (uint32_t i = gtid; i < R; i += nthreads) {
@@ -264,10 +260,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
             plan[t] = make_uint4(run[1], run[3], run[4], v);
             for (uint32_t sg = 0; sg < q[1]; sg++)
                 if (run[1] + sg < items_cap) items[run[1] + sg] = (uint32_t)t | (sg << 20);
-            for (uint32_t c = 0; c < q[3]; c++) {
-                if (run[3] + c < sort_cap) sort_items[run[3] + c] = make_uint2((uint32_t)t, c);
-                if (q[4] && run[4] + c < rank_cap) rank_items[run[4] + c] = make_uint2((uint32_t)t, c);
-            }
+            if (q[3] && run[3] < sort_cap) sort_items[run[3]] = make_uint2((uint32_t)t, run[4]);     // (tile, first group slot)
         }
         sStart[t] = run[0];
 #pragma unroll
@@ -294,125 +287,214 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
     }
 }
 
-// ---- long lists ---------------------------------------------------------------------------
+// ---- long lists: bucket sort ---------------------------------------------------------------
+// A list of n > 1024 keys (depth_bits << 32 | gid, unique) is split BY VALUE: bucket = (key - min) >> shift, 1024 buckets over
+// the list's own key range; whole buckets are packed greedily into groups of <= 1024 keys, and every group is sorted on its
+// own by sg_group_sort_kernel.  Groups are ranges of the bucket-ordered array, so the concatenation of the sorted groups IS the
+// sorted list -- no merge.  One workgroup per tile does min / max, histogram, scan, scatter and the packing: three coalesced
+// passes over the tile's keys (L2-resident after the first) instead of O(n log^2 n) comparator stages.
+// A bucket that alone holds more than 1024 keys (a dense depth cluster next to an outlier) is split again over ITS key range
+// (level 1: ping-pong back into the first buffer); what is still too large after that -- > 1024 keys within 2^-20 of the
+// list's key range -- is ordered by counting (every key counts the smaller ones; O(m^2), correct for any input, never seen in a
+// rendered scene; tests/test_gpu_raster.py crafts one).
+// Group slots: the scan reserves sg_group_slots(n) consecutive slots per long tile (plan.z); unused ones are written with
+// length 0, so the group kernel needs no counter and no atomics.  A group item is (first index | buffer flag, length | tile << 11).
+#define SG_PT_THREADS 1024
+#define SG_PT_NB 1024
+#define SG_PT_BIGS 256
+#define SG_GROUP_IN_A 0x80000000u      // group item flag: the group's keys are in pair_keys (level-1 output), else in the scratch
 
-// Bitonic sort of s[0, n2) (n2 a power of two <= SG_SORT_LDS) by the whole SG_SORT_THREADS workgroup.
-// Wave w owns the comparators of a contiguous block of B = 128 * cpt elements: every stage with 2j <= B touches only
-// the wave's own block and needs no workgroup barrier (LDS operations of one wave complete in order), which leaves
-// 14 workgroup barriers instead of 78 at n2 = 4096.
-__device__ __forceinline__ void sg_bitonic_lds(uint64_t *s, int n2, int tid)
+__device__ __forceinline__ uint64_t sg_shfl_xor_u64(uint64_t v, int m)
 {
-    const int cpt = n2 > 2048 ? n2 / 2048 : 1;          // comparators per thread
-    const int wave = tid >> 6, lane = tid & 63;
-    const int B = 128 * cpt;
-    const bool active = wave * B < n2;
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (active) {
-                for (int c = 0; c < cpt; c++) {
-                    const int t = (wave * cpt + c) * 64 + lane;
-                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), ixj = i | j;
-                    const bool up = (i & k) == 0;
-                    const uint64_t a = s[i], b = s[ixj];
-                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-                }
-            }
-            if (2 * j <= B) { __builtin_amdgcn_s_waitcnt(0xC07F); __builtin_amdgcn_wave_barrier(); }
-            else __syncthreads();
+    const uint32_t lo = __shfl_xor((uint32_t)v, m, 64), hi = __shfl_xor((uint32_t)(v >> 32), m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct SgPartLds {
+    uint32_t off[SG_PT_NB + 1];        // exclusive bucket offsets of the current pass
+    uint32_t cur[SG_PT_NB];            // histogram, then scatter cursors
+    uint32_t nx[SG_PT_NB];             // greedy packing: first bucket of the group after the one that starts at this bucket
+    uint32_t wtot[SG_PT_THREADS / 64];
+    uint64_t wmin[SG_PT_THREADS / 64], wmax[SG_PT_THREADS / 64];
+    uint2 bigs[SG_PT_BIGS];            // (start, length) of the buckets of the current pass that hold more than 1024 keys
+    uint2 bigs0[SG_PT_BIGS];           // the level-0 list, kept while the level-1 passes reuse the tables above
+    uint32_t nbig;                     // entries of bigs[] (counts on past SG_PT_BIGS)
+    uint64_t tile[SG_PT_NB];           // counting fallback: one slab of keys
+    uint32_t gslot;                    // next group slot of this tile
+};
+
+// Keys of in[0, m) -> bucket order in out[0, m); groups of whole buckets (<= 1024 keys) are appended to `groups` (slots below gend).
+// `abs0`: index of in[0] / out[0] in the per-pair arrays; `flag`: SG_GROUP_IN_A iff `out` is pair_keys.  Buckets with more than 1024
+// keys are listed in L.bigs / L.nbig (relative to out).  Workgroup-uniform; contains barriers; ends with one.
+__device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t m, uint32_t abs0,
+                                  uint32_t flag, uint32_t tile, SgPartLds &L, uint2 *__restrict__ groups, uint32_t gend, int tid)
+{
+    const int lane = tid & 63, wid = tid >> 6;
+    // 1. key range
+    uint64_t kmin = ~0ull, kmax = 0ull;
+    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) { const uint64_t k = in[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = sg_shfl_xor_u64(kmin, o), b = sg_shfl_xor_u64(kmax, o);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { L.wmin[wid] = kmin; L.wmax[wid] = kmax; }
+    L.cur[tid] = 0u;
+    if (tid == 0) L.nbig = 0u;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < SG_PT_THREADS / 64; w++) { const uint64_t a = L.wmin[w], b = L.wmax[w]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    const uint64_t span = kmax - kmin;
+    const int bits = span ? 64 - __builtin_clzll(span) : 0;
+    const int shift = bits > 10 ? bits - 10 : 0;                       // (span >> shift) < 1024
+    // 2. histogram
+    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) atomicAdd(&L.cur[(uint32_t)((in[i] - kmin) >> shift)], 1u);
+    __syncthreads();
+    // 3. exclusive scan over the 1024 buckets (thread = bucket)
+    const uint32_t cnt = L.cur[tid];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o, 64); if (lane >= o) incl += u; }
+    if (lane == 63) L.wtot[wid] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+#pragma unroll 1
+    for (int w = 0; w < wid; w++) woff += L.wtot[w];
+    const uint32_t excl = woff + incl - cnt;
+    L.off[tid] = excl;
+    if (tid == SG_PT_THREADS - 1) L.off[SG_PT_NB] = excl + cnt;
+    if (cnt > SG_WSORT_MAX) { const uint32_t k = atomicAdd(&L.nbig, 1u); if (k < SG_PT_BIGS) L.bigs[k] = make_uint2(excl, cnt); }
+    __syncthreads();                                                   // (everybody has read its cur[] entry and the wave totals)
+    L.cur[tid] = excl;
+    __syncthreads();
+    // 4. scatter into bucket order (the order inside a bucket is arbitrary: every group is sorted afterwards)
+    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) {
+        const uint64_t k = in[i];
+        out[atomicAdd(&L.cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+    }
+    // 5. greedy packing.  nx[b]: the largest j > b with off[j] - off[b] <= 1024 (binary search; b + 1 if bucket b alone is larger)
+    {
+        int lo = tid + 1, hi = SG_PT_NB;
+        while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (L.off[mid] - excl <= SG_WSORT_MAX) lo = mid; else hi = mid - 1; }
+        L.nx[tid] = (uint32_t)lo;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t g = L.gslot;
+        for (uint32_t b = 0; b < SG_PT_NB;) {
+            const uint32_t j = L.nx[b], s0 = L.off[b], len = L.off[j] - s0;
+            if (len > SG_WSORT_MAX) { b++; continue; }                 // a big bucket (listed in bigs[])
+            if (len && g < gend) groups[g++] = make_uint2((abs0 + s0) | flag, len | (tile << 11));
+            b = j;
         }
-        if (2 * k > B) __syncthreads();                  // the next k starts with a cross-wave stage (or we are done)
+        L.gslot = g;
     }
     __syncthreads();
 }
 
-
-// Lists longer than SG_WSORT_MAX (the forward composite sorts the others itself): one workgroup per work item (tile,
-// chunk of SG_SORT_LDS entries), items written by the scan; a list of one chunk is sorted and written out, the chunks of
-// a longer list are sorted in place and merged by sg_tile_rank_kernel.  Exits at once when there is no such list.
-__global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ sort_items,
-                    const uint2 *__restrict__ ranges, uint64_t *__restrict__ pair_keys,
-                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+// keys buf[0, m) (unsorted) -> point_list / point_keys [abs0, abs0 + m) in ascending order, by counting: O(m^2 / 1024) per thread
+__device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint32_t abs0, uint32_t tile, SgPartLds &L,
+                              uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys, int tid)
 {
-    __shared__ uint64_t s[SG_SORT_LDS];
+    for (uint32_t i0 = 0; i0 < m; i0 += SG_PT_THREADS) {
+        const uint32_t i = i0 + tid;
+        const uint64_t key = i < m ? buf[i] : ~0ull;
+        uint32_t rank = 0;
+        for (uint32_t t0 = 0; t0 < m; t0 += SG_PT_NB) {
+            __syncthreads();
+            L.tile[tid] = t0 + tid < m ? buf[t0 + tid] : ~0ull;
+            __syncthreads();
+            const uint32_t tn = m - t0 < SG_PT_NB ? m - t0 : SG_PT_NB;
+            for (uint32_t j = 0; j < tn; j++) rank += L.tile[j] < key;
+        }
+        if (i < m) {
+            point_list[abs0 + rank] = (uint32_t)key;
+            if (point_keys) point_keys[abs0 + rank] = ((uint64_t)tile << 32) | (key >> 32);
+        }
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(SG_PT_THREADS)
+sg_tile_partition_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ part_items, const uint2 *__restrict__ ranges,
+                         uint64_t *__restrict__ pair_keys, uint64_t *__restrict__ scratch, uint2 *__restrict__ groups,
+                         uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+{
+    __shared__ SgPartLds L;
     const int tid = threadIdx.x;
     const uint32_t nitems = header[1] ? 0u : header[4];
     for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
-        const uint2 it = sort_items[li];
-        const int tile = (int)it.x;
+        const uint2 it = part_items[li];                              // (tile, first reserved group slot)
+        const uint32_t tile = it.x;
         const uint2 r = ranges[tile];
-        const uint32_t n = r.y - r.x, off = it.y * SG_SORT_LDS;
-        if (off >= n) continue;
-        const int m = (int)(n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS);
-        uint64_t *seg = pair_keys + r.x + off;
-        int n2 = 1; while (n2 < m) n2 <<= 1;
+        const uint32_t n = r.y - r.x;
+        const uint32_t g0 = it.y < group_cap ? it.y : group_cap;
+        const uint32_t gend = g0 + sg_group_slots(n) < group_cap ? g0 + sg_group_slots(n) : group_cap;
         __syncthreads();
-        for (int i = tid; i < n2; i += SG_SORT_THREADS) s[i] = i < m ? seg[i] : ~0ull;
+        if (tid == 0) L.gslot = g0;
         __syncthreads();
-        if (m > 1) sg_bitonic_lds(s, n2, tid);
-        if (n <= SG_SORT_LDS) {
-            for (int i = tid; i < m; i += SG_SORT_THREADS) {
-                const uint64_t k = s[i];
-                point_list[r.x + i] = (uint32_t)k;
-                if (point_keys) point_keys[r.x + i] = ((uint64_t)tile << 32) | (k >> 32);
+        // level 0: pair_keys -> scratch
+        sg_partition_pass(pair_keys + r.x, scratch + r.x, n, r.x, 0u, tile, L, groups, gend, tid);
+        const uint32_t nb0 = L.nbig;
+        if (nb0) {
+            // level 1 for every bucket of more than 1024 keys: scratch -> pair_keys over the bucket's own key range.  (The level-1
+            // passes reuse the LDS tables: the level-0 list moves to bigs0 first.)
+            if (tid < SG_PT_BIGS) L.bigs0[tid] = L.bigs[tid];
+            __syncthreads();
+            for (uint32_t k = 0; k < nb0 && k < SG_PT_BIGS; k++) {
+                const uint32_t s0 = L.bigs0[k].x, m = L.bigs0[k].y;
+                __syncthreads();
+                sg_partition_pass(scratch + r.x + s0, pair_keys + r.x + s0, m, r.x + s0, SG_GROUP_IN_A, tile, L, groups, gend, tid);
+                const uint32_t nb1 = L.nbig;
+                if (nb1 > SG_PT_BIGS) {
+                    // more big sub-buckets than the list holds: order the whole bucket by counting (its groups, emitted above, then
+                    // re-sort parts of it into the same places: harmless)
+                    sg_count_sort(pair_keys + r.x + s0, m, r.x + s0, tile, L, point_list, point_keys, tid);
+                } else {
+                    for (uint32_t q = 0; q < nb1; q++) {
+                        const uint32_t s1 = L.bigs[q].x, m1 = L.bigs[q].y;
+                        __syncthreads();
+                        sg_count_sort(pair_keys + r.x + s0 + s1, m1, r.x + s0 + s1, tile, L, point_list, point_keys, tid);
+                    }
+                }
             }
-        } else {
-            for (int i = tid; i < m; i += SG_SORT_THREADS) seg[i] = s[i];
+            if (nb0 > SG_PT_BIGS) {
+                // (a list with more than 256 separate dense clusters of > 1024 keys each: > 262 144 entries in ONE tile.)  The
+                // level-0 list is incomplete: order the whole list by counting, from a copy in pair_keys (the scratch array may be
+                // the point_keys output).
+                __syncthreads();
+                for (uint32_t i = tid; i < n; i += SG_PT_THREADS) pair_keys[r.x + i] = scratch[r.x + i];
+                __syncthreads();
+                sg_count_sort(pair_keys + r.x, n, r.x, tile, L, point_list, point_keys, tid);
+            }
         }
+        __syncthreads();
+        // unused reserved slots: length 0
+        for (uint32_t g = L.gslot + tid; g < gend; g += SG_PT_THREADS) groups[g] = make_uint2(0u, 0u);
     }
 }
 
-// Lists longer than SG_SORT_LDS: one workgroup per (tile, chunk).  Keys are unique (Gaussian id in the low word), so
-// the final position of a key is its index in its own sorted chunk plus the number of smaller keys in every other
-// chunk; each other chunk is brought into LDS once and binary-searched there.
-__global__ void __launch_bounds__(SG_SORT_THREADS)
-sg_tile_rank_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ rank_items,
-                    const uint2 *__restrict__ ranges, const uint64_t *__restrict__ pair_keys,
-                    uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+// One workgroup per group: <= 1024 keys -> sorted, as Gaussian ids into point_list (and upstream-format keys on request).
+__global__ void __launch_bounds__(256)
+sg_group_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ groups, const uint64_t *__restrict__ pair_keys,
+                     const uint64_t *__restrict__ scratch, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
 {
-    __shared__ uint64_t s[SG_SORT_LDS];
-    constexpr int KPT = SG_SORT_LDS / SG_SORT_THREADS;
+    __shared__ uint64_t s[SG_WSORT_MAX + SG_RANKSORT_MAX];
     const int tid = threadIdx.x;
-    const uint32_t nitems = header[1] ? 0u : header[6];
-    for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
-        const uint2 it = rank_items[li];
-        const int tile = (int)it.x;
-        const uint2 r = ranges[tile];
-        const uint32_t n = r.y - r.x, off = it.y * SG_SORT_LDS;
-        if (off >= n) continue;
-        const uint32_t m = n - off < SG_SORT_LDS ? n - off : SG_SORT_LDS;
-        const uint64_t *seg = pair_keys + r.x;
-        uint64_t key[KPT];
-        uint32_t rk[KPT];
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-            const uint32_t i = tid + q * SG_SORT_THREADS;
-            key[q] = i < m ? seg[off + i] : ~0ull;
-            rk[q] = i;
-        }
-        const uint32_t nchunks = (n + SG_SORT_LDS - 1) / SG_SORT_LDS;
-        for (uint32_t c = 0; c < nchunks; c++) {
-            if (c == it.y) continue;
-            const uint32_t co = c * SG_SORT_LDS, cm = n - co < SG_SORT_LDS ? n - co : SG_SORT_LDS;
-            __syncthreads();
-            for (uint32_t i = tid; i < cm; i += SG_SORT_THREADS) s[i] = seg[co + i];
-            __syncthreads();
-#pragma unroll
-            for (int q = 0; q < KPT; q++) {
-                uint32_t lo = 0, hi = cm;
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s[mid] < key[q]) lo = mid + 1; else hi = mid; }
-                rk[q] += lo;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < KPT; q++) {
-            const uint32_t i = tid + q * SG_SORT_THREADS;
-            if (i < m) {
-                point_list[r.x + rk[q]] = (uint32_t)key[q];
-                if (point_keys) point_keys[r.x + rk[q]] = ((uint64_t)tile << 32) | (key[q] >> 32);
-            }
-        }
+    const uint32_t nslots = header[1] ? 0u : header[6];
+    for (uint32_t gi = blockIdx.x; gi < nslots; gi += gridDim.x) {
+        const uint2 g = groups[gi];
+        const uint32_t len = g.y & 0x7ffu, tile = g.y >> 11;
+        if (len == 0u) continue;
+        const uint32_t start = g.x & ~SG_GROUP_IN_A;
+        const uint64_t *src = ((g.x & SG_GROUP_IN_A) ? pair_keys : scratch) + start;
         __syncthreads();
+        sg_sort_short_list(src, (int)len, s, s + SG_WSORT_MAX, tid);     // (all of src is in LDS before anything below is written)
+        for (uint32_t i = tid; i < len; i += 256) {
+            const uint64_t k = s[i];
+            point_list[start + i] = (uint32_t)k;
+            if (point_keys) point_keys[start + i] = ((uint64_t)tile << 32) | (k >> 32);
+        }
     }
 }
 
@@ -460,11 +542,11 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none
     if (short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
-    const uint32_t sgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;     // 2 x 256 CUs
-    hipLaunchKernelGGL(sg_tile_sort_kernel, dim3(sgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.sort_items, b.ranges,
-                       b.pair_keys, b.point_list, pk);
-    const uint32_t rgrid = sg_rank_items_cap(cap) < 128 ? sg_rank_items_cap(cap) : 128;
-    hipLaunchKernelGGL(sg_tile_rank_kernel, dim3(rgrid), dim3(SG_SORT_THREADS), 0, st, b.header, b.rank_items,
-                       b.ranges, b.pair_keys, b.point_list, pk);
+    const uint32_t pgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;
+    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), 0, st, b.header, b.sort_items, b.ranges,
+                       b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk);
+    const uint32_t ggrid = sg_rank_items_cap(cap) < 4096 ? sg_rank_items_cap(cap) : 4096;
+    hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
+                       b.point_list, pk);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

@@ -22,10 +22,13 @@
 __host__ __device__ inline uint32_t sg_nseg(uint32_t n) { return n > SG_SEG && n <= SG_SEG * 4095u ? (n + SG_SEG - 1) / SG_SEG : 0u; }
 // capacities of the work-item list and of the checkpoint buffer (slots of 256 float4) for T tiles / cap pairs
 __host__ __device__ inline uint32_t sg_items_cap(size_t T, size_t cap) { size_t v = T + cap / SG_SEG + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
-// work items of the long-list sort (one per tile with > 256 entries + one per further 4096-entry chunk) and of the
-// chunk merge (lists of more than one chunk)
-__host__ __device__ inline uint32_t sg_sort_items_cap(size_t T, size_t cap) { size_t v = T + cap / 4096 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
-__host__ __device__ inline uint32_t sg_rank_items_cap(size_t cap) { size_t v = cap / 2048 + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
+// Long lists (> 1024 entries: what a compositing workgroup does not sort itself) are bucket-sorted (sg_binning.hip): one
+// partition work item per such tile, and per tile a block of reserved group slots.  A list of n keys needs at most
+// 5 n / 1024 + 1 groups (greedy packing: two neighbouring groups hold > 1024 keys; buckets that are split again break runs).
+__host__ __device__ inline uint32_t sg_group_slots(uint32_t n) { return n > 1024u ? 6u * ((n + 1023u) / 1024u) + 2u : 0u; }
+__host__ __device__ inline uint32_t sg_sort_items_cap(size_t T, size_t cap) { size_t v = (T < cap / 1024 ? T : cap / 1024) + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
+// sum of sg_group_slots over the long tiles: 6 (n / 1024 + 1) + 2 <= 14 n / 1024 for n > 1024
+__host__ __device__ inline uint32_t sg_rank_items_cap(size_t cap) { size_t v = cap / 73 + 16; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (cap / SG_SEG) + 2; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 // Tile counters: one packed word per tile (a Gaussian's tiles are neighbours, so one 64-lane atomic instruction
 // touches few lines).  When the image has few tiles (<= SG_HIST_TILES_MAX) a single tile can collect ~1e4 pairs and a
@@ -55,8 +58,8 @@ struct SgBin {
     uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
     uint32_t *pair_tile;   //       tile id,
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
-    uint2 *sort_items;     // (tile, chunk) of lists too long for the one-wave sort; count in header[4]
-    uint2 *rank_items;     // (tile, chunk) of lists of more than one chunk; count in header[6]
+    uint2 *sort_items;     // (tile, first group slot) of every list of more than 1024 entries; count in header[4]
+    uint2 *rank_items;     // group slots of the bucket sort: (first index | buffer flag, length | tile << 11); reserved count in header[6]
     uint32_t *items;       // backward work items: tile | segment << 20; count in header[5]
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
     uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)

@@ -75,7 +75,7 @@ def test_rccl_branches_run_with_one_rank(algo):
 
 @pytest.mark.gpu
 def test_rccl_branches_run_with_one_rank_avatar_and_train():
-    """The same for the other two workloads: the avatar step (fused LBS path, 10 floats per Gaussian all-reduced) and the
+    """The same for the other two workloads: the avatar step (fused LBS path, 3 + 3 + 1 + 3 * 16 floats per Gaussian all-reduced) and the
     complete training step (parameter gradients written straight into ONE flat buffer -- sings_amd.decode.set_gradient_arena --
     and all-reduced in place)."""
     small = ["--gaussians", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
@@ -83,7 +83,7 @@ def test_rccl_branches_run_with_one_rank_avatar_and_train():
     ref = _line(_bench("--workload", "avatar", "--grad-hash", *small))
     j = _line(_bench("--workload", "avatar", "--grad-hash", *small, env=env))
     assert j["dist_backend"] == "nccl" and j["rccl_world"] == 1 and j["allreduce_ms"] > 0
-    assert j["allreduce_bytes"] == 20000 * 10 * 4 and j["grad_sha256"] == ref["grad_sha256"]
+    assert j["allreduce_bytes"] == 20000 * 55 * 4 and j["grad_sha256"] == ref["grad_sha256"]
     assert j["repeats"] >= 2 and j["roofline"]["kernel"].startswith("sg_") and j["train_step_ms_one_view"] > 0
     ref = _line(_bench("--workload", "train", *small))
     assert ref["allreduce_ms"] is None and ref["rccl_world"] is None

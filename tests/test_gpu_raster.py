@@ -755,3 +755,15 @@ def test_list_lengths_on_internal_boundaries(n):
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
     R, mx = fz.check(fz.crafted(n, n), f"crafted {n}")
     assert mx >= n
+
+
+def test_bucket_sort_of_clustered_depths():
+    """Long lists are bucket-sorted by key value (sg_tile_partition_kernel + sg_group_sort_kernel).  Depth clusters exercise what
+    uniform depths never reach: a bucket of > 1024 keys split again over its own key range (identical depth bits -> by Gaussian
+    id) and the counting order for > 1024 keys on one float code next to another code.  Bit-exact sorted list, image, gradients."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    z = fz.clustered_depths(7)
+    R, mx = fz.check(fz.crafted(z.size, 7, depths=z), "clustered depths")
+    assert mx >= z.size

@@ -51,14 +51,14 @@ def check(s, tag):
     return int(o["R"]), int(tl.max())
 
 
-def crafted(n_in_tile, seed):
+def crafted(n_in_tile, seed, depths=None):
     """n small Gaussians whose 3-sigma squares all lie inside ONE 16x16 tile of a 64x48 image -> that tile's list has
-    exactly n entries (plus a sprinkle elsewhere)."""
+    exactly n entries (plus a sprinkle elsewhere).  `depths`: the view-space z of the n Gaussians (default: uniform in 2..10)."""
     s = synthetic_scene(200, 64, 48, 1, seed)
     rs = np.random.RandomState(seed)
     N = n_in_tile + 200
     fx = 1.2 * 64
-    z = rs.uniform(2, 10, n_in_tile).astype(np.float32)
+    z = rs.uniform(2, 10, n_in_tile).astype(np.float32) if depths is None else np.asarray(depths, np.float32)
     px = rs.uniform(22, 26, n_in_tile); py = rs.uniform(22, 26, n_in_tile)           # tile (1,1) spans 16..31
     x = ((px - 32) / fx * z).astype(np.float32); y = ((py - 24) / fx * z).astype(np.float32)
     means = np.concatenate([np.stack([x, y, z], 1), s["means3D"]]).astype(np.float32)
@@ -69,6 +69,18 @@ def crafted(n_in_tile, seed):
     shs = np.concatenate([rs.normal(0, 0.5, (n_in_tile, 16, 3)).astype(np.float32), s["shs"]])
     out = dict(s); out.update(means3D=means, scales=scales, rotations=rot.astype(np.float32), opacities=op, shs=shs)
     return out
+
+
+def clustered_depths(seed):
+    """Depth distribution that walks the long-list bucket sort (sg_binning.hip) through every level: 1 500 keys with IDENTICAL
+    depth bits (a plane facing the camera: level 0 puts them in one bucket, level 1 splits them by Gaussian id), 3 000 keys on
+    two ADJACENT float codes (level 1 cannot split a code's 1 500 keys any further: ordered by counting), 1 200 spread out,
+    and two outliers that stretch the key range."""
+    rs = np.random.RandomState(seed)
+    a = np.float32(7.0); b = np.nextafter(a, np.float32(8.0))
+    z = np.concatenate([np.full(1500, 5.0, np.float32), np.where(rs.rand(3000) < 0.5, a, b).astype(np.float32),
+                        rs.uniform(3.0, 9.0, 1200).astype(np.float32), np.array([2.0, 9.9], np.float32)])
+    return z[rs.permutation(z.size)]
 
 
 if __name__ == "__main__":
