@@ -329,10 +329,26 @@ struct SgPartLds {
 __device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, uint32_t m, uint32_t abs0,
                                   uint32_t flag, uint32_t tile, SgPartLds &L, uint2 *__restrict__ groups, uint32_t gend, int tid)
 {
+    // A thread's keys: U per sweep, every load of a sweep issued before the first use (as a plain strided loop hipcc emits load ->
+    // wait -> use: one request in flight per wave, a memory latency per key); lists of up to U * 1024 keys -- every list of an avatar
+    // frame -- are read ONCE and stay in registers through range, histogram and scatter.
+    constexpr int U = 8;
+    constexpr uint64_t NONE = ~0ull;                                   // (a real key never has all depth bits set: depth > 0.2)
     const int lane = tid & 63, wid = tid >> 6;
+    const bool resident = m <= (uint32_t)U * SG_PT_THREADS;
+    uint64_t kr[U];
+    auto sweep = [&](uint32_t i0) {
+#pragma unroll
+        for (int u = 0; u < U; u++) { const uint32_t i = i0 + (uint32_t)u * SG_PT_THREADS + tid; kr[u] = i < m ? in[i] : NONE; }
+    };
     // 1. key range
-    uint64_t kmin = ~0ull, kmax = 0ull;
-    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) { const uint64_t k = in[i]; kmin = k < kmin ? k : kmin; kmax = k > kmax ? k : kmax; }
+    uint64_t kmin = NONE, kmax = 0ull;
+    for (uint32_t i0 = 0; i0 < m; i0 += U * SG_PT_THREADS) {
+        sweep(i0);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (kr[u] != NONE) { kmin = kr[u] < kmin ? kr[u] : kmin; kmax = kr[u] > kmax ? kr[u] : kmax; }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const uint64_t a = sg_shfl_xor_u64(kmin, o), b = sg_shfl_xor_u64(kmax, o);
@@ -348,7 +364,12 @@ __device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__r
     const int bits = span ? 64 - __builtin_clzll(span) : 0;
     const int shift = bits > 10 ? bits - 10 : 0;                       // (span >> shift) < 1024
     // 2. histogram
-    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) atomicAdd(&L.cur[(uint32_t)((in[i] - kmin) >> shift)], 1u);
+    for (uint32_t i0 = 0; i0 < m; i0 += U * SG_PT_THREADS) {
+        if (!resident) sweep(i0);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (kr[u] != NONE) atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u);
+    }
     __syncthreads();
     // 3. exclusive scan over the 1024 buckets (thread = bucket)
     const uint32_t cnt = L.cur[tid];
@@ -368,9 +389,11 @@ __device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__r
     L.cur[tid] = excl;
     __syncthreads();
     // 4. scatter into bucket order (the order inside a bucket is arbitrary: every group is sorted afterwards)
-    for (uint32_t i = tid; i < m; i += SG_PT_THREADS) {
-        const uint64_t k = in[i];
-        out[atomicAdd(&L.cur[(uint32_t)((k - kmin) >> shift)], 1u)] = k;
+    for (uint32_t i0 = 0; i0 < m; i0 += U * SG_PT_THREADS) {
+        if (!resident) sweep(i0);
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (kr[u] != NONE) out[atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u)] = kr[u];
     }
     // 5. greedy packing.  nx[b]: the largest j > b with off[j] - off[b] <= 1024 (binary search; b + 1 if bucket b alone is larger)
     {

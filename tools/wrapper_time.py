@@ -31,8 +31,14 @@ def timeit(n=50):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 
 
-print(f"autograd surface, default (asynchronous pair-count check, looked at one call later): {timeit():.3f} ms per view")
-rz.set_overflow_check("sync")
-print(f"autograd surface, synchronous pair-count check (round-1 default):                  {timeit():.3f} ms per view")
+print(f"autograd surface, default 'sync' (early pair count through a mapped host word):   {timeit():.3f} ms per view")
+# the round-1 / round-2 synchronous check for comparison: debug = False, but no early-count word -> stream synchronisation
+_arm = rz._arm_early_count
+rz._arm_early_count = lambda s, dev: None
+print(f"autograd surface, 'sync' by stream synchronisation (round-1 behaviour):             {timeit():.3f} ms per view")
+rz._arm_early_count = _arm
+rz.set_overflow_check("async")
+print(f"autograd surface, 'async' (pair count looked at one call later; opt-in):            {timeit():.3f} ms per view")
 rz.set_overflow_check("deferred")
-print(f"autograd surface, deferred pair-count check (device-side accumulator, polled):     {timeit():.3f} ms per view")
+print(f"autograd surface, 'deferred' (device-side accumulator, polled; opt-in):             {timeit():.3f} ms per view")
+rz.set_overflow_check("sync")
