@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SG_TILE 16            /* BLOCK_X = BLOCK_Y of the upstream rasterizer */
-#define SG_GRAD_REC_FLOATS 12 /* floats per (tile,Gaussian) gradient record     */
+#define SG_GRAD_REC_FLOATS 9  /* floats per (tile,Gaussian) gradient record: two 16-B vectors + one float in a separate plane */
 
 /* Mirrors the 12-field GaussianRasterizationSettings NamedTuple the reference builds at
  * gs_renderer_single.py:69-82 (bg/viewmatrix/projmatrix/campos are device pointers). */
@@ -66,7 +66,7 @@ typedef struct SgLayout {
     size_t bin_header, bin_tile_count, bin_ranges, bin_cursor, bin_pair_keys, bin_point_list,
         bin_point_keys, bin_pair_gid, bin_pair_tile, bin_pair_local,
         bin_sort_items, bin_rank_items, bin_items,      /* work lists: long-list sort chunks, chunk merges, backward segments */
-        bin_ck_start, bin_plan, bin_pair_mask, bin_bytes;
+        bin_ck_start, bin_plan, bin_pair_mask, bin_order, bin_bytes;
     /* image workspace */
     size_t img_final_T, img_n_contrib, img_ckpt, img_bytes;
     /* backward workspace */

@@ -59,13 +59,14 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_ck_start = o; o = sg_align(o + T * 4);
     L->bin_plan = o; o = sg_align(o + T * 16);
     L->bin_pair_mask = o; o = sg_align(o + cap + 1);
+    L->bin_order = o; o = sg_align(o + T * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);
     L->img_n_contrib = o; o = sg_align(o + hw * 4);
     L->img_ckpt = o; o = sg_align(o + (size_t)sg_ckpt_cap(cap) * (256 * 16));
     L->img_bytes = o;
-    L->bwd_bytes = sg_align((cap + 1) * SG_GRAD_REC_FLOATS * 4);
+    L->bwd_bytes = sg_rec_bytes(cap);
     return 0;
 }
 
@@ -202,10 +203,10 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
     SgImg im = sg_img_view((void *)image_ws, L);
-    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
+    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
     SG_CHECK_LAST("render_bwd", s, st);
     sg_launch_preprocess_bwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
-                             (const float *)bwd_ws, cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
+                             sg_rec_view(bwd_ws, cap), cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                              cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);
@@ -276,9 +277,9 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
     SgImg im = sg_img_view((void *)image_ws, L);
-    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, (float *)bwd_ws, st);
+    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
     SG_CHECK_LAST("render_bwd", s, st);
-    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, (const float *)bwd_ws, cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
+    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
                        skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
                        dL_dtransl, st);
     SG_CHECK_LAST("skin_bwd", s, st);

@@ -191,11 +191,14 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal)
+                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal, uint32_t *__restrict__ order)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
     __shared__ uint32_t wsum[NQ][SG_SS_THREADS / 64];
+    __shared__ uint32_t sCls[2][SG_ORDER_CLASSES];           // tiles per work class / cursors (the workgroup that writes `order`)
+    const bool orders = order != nullptr && blockIdx.x == gridDim.x - 1;
+    if (orders && threadIdx.x < SG_ORDER_CLASSES) sCls[0][threadIdx.x] = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[t];
     __syncthreads();
@@ -208,6 +211,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
         sg_scan_derive(sStart[t], q);
 #pragma unroll
         for (int a = 0; a < NQ; a++) own[a] += q[a];
+        if (orders) atomicAdd(&sCls[0][sg_order_class(sStart[t])], 1u);
     }
     uint32_t incl[NQ];
 #pragma unroll
@@ -247,11 +251,23 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
             run[a] = woff + incl[a] - own[a];
         }
     }
+    // The forward composite's schedule (sg_render.hip::sg_tile_of_rank): tiles by descending work class.  One wave scans the
+    // class counts (the barriers above separate it from the counting), every thread then drops its tiles into their class --
+    // the order inside a class is whatever the LDS atomics make it: it moves tiles between CUs, never changes a result.
+    if (orders && tid < 64) {
+        const uint32_t c = tid < SG_ORDER_CLASSES ? sCls[0][tid] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
+        if (tid < SG_ORDER_CLASSES) sCls[1][tid] = inc - c;
+    }
+    if (orders) __syncthreads();
     const bool writer = (uint32_t)tid % gridDim.x == blockIdx.x;
     for (int t = t0; t < t1; t++) {
         const uint32_t v = sStart[t];
         uint32_t q[NQ];
         sg_scan_derive(v, q);
+        if (orders) order[atomicAdd(&sCls[1][sg_order_class(v)], 1u)] = (uint32_t)t;
         if (writer) {
             const uint32_t s = run[0] < cap ? run[0] : cap, e = run[0] + v < cap ? run[0] + v : cap;
             ranges[t] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
@@ -544,7 +560,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, short_lists, c.count_signal);
+                           b.rank_items, b.items, short_lists, c.count_signal, sg_tile_order_used(T) ? b.order : (uint32_t *)nullptr);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);

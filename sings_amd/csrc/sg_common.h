@@ -38,6 +38,13 @@ __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (ca
 // preprocess + 22 us of scan on the avatar frame; the histogram: 43 + 7 us.)
 #define SG_HIST_TILES_MAX 4096
 static inline bool sg_lds_hist(size_t T) { return T <= SG_HIST_TILES_MAX; }
+// The same regime (few tiles, lists of very different lengths: an avatar in front of a background) is where the forward
+// composite's static tile -> CU map leaves CUs idle: there the scan also orders the tiles by work class (list length in steps
+// of 32 entries, saturating at 1536: longer lists end early, their pixels saturate) and the composite deals them out heaviest
+// first, snaking over the CUs (sg_render.hip::sg_tile_of_rank).
+#define SG_ORDER_CLASSES 49
+__host__ __device__ inline uint32_t sg_order_class(uint32_t n) { return (SG_ORDER_CLASSES - 1) - ((n < 1536u ? n : 1536u) >> 5); }   // 0 = heaviest
+static inline bool sg_tile_order_used(size_t T) { return T <= SG_HIST_TILES_MAX; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
@@ -64,6 +71,7 @@ struct SgBin {
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
     uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)
     uint8_t *pair_mask;    // [cap] per sorted list entry: quadrants the forward composited it in (0 if it never staged it)
+    uint32_t *order;       // [T] tiles by descending list length (classes of 32 entries): the forward composite's schedule
 };
 
 struct SgImg {
@@ -73,6 +81,18 @@ struct SgImg {
 };
 
 static inline size_t sg_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Backward workspace: one 36-byte gradient record per (tile, Gaussian) pair -- (d mean2D.x, d mean2D.y, d conic.x, d conic.y)
+// (d conic.w, d opacity, d colour r, g) as two 16-byte vectors in plane `a`, d colour b as one float in plane `b`.  (Rounds 1-2:
+// three 16-byte vectors, the last one 3/4 padding: 12 B per pair written and read for nothing, 18.7 MB per cfg3 view.)
+struct SgRec { float4 *a; float *b; };
+static inline size_t sg_rec_bytes(size_t cap) { return sg_align((cap + 1) * 32) + sg_align((cap + 1) * 4); }
+static inline SgRec sg_rec_view(const void *bwd_ws, size_t cap)
+{
+    SgRec r;
+    r.a = (float4 *)bwd_ws; r.b = (float *)((char *)bwd_ws + sg_align((cap + 1) * 32));
+    return r;
+}
 
 static inline SgGeom sg_geom_view(void *ws, const SgLayout &L)
 {
@@ -96,6 +116,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.sort_items = (uint2 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
+    g.order = (uint32_t *)(b + L.bin_order);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
@@ -127,14 +148,14 @@ static inline uint32_t sg_cap32(size_t cap) { return cap > 0xffffffffull ? 0xfff
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           int write_keys, hipStream_t st);
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
-                          const float *dL_dpix, float *grec, hipStream_t st);
+                          const float *dL_dpix, SgRec grec, hipStream_t st);
 void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
+                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
-                              float *dL_drots, float *dL_dcov3D, hipStream_t st);
+                              float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st);
 
 // per-kernel event timing (sg_api.hip)
 // Zero `bytes` (a multiple of 4) at the 4-byte aligned address p with a KERNEL.  Not hipMemsetAsync: a step replayed from
@@ -197,7 +218,7 @@ void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const floa
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
                               hipStream_t st);
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header, const float *dposed_xyz_in,
+                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const float *dposed_xyz_in,
                         const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
-                        float *dL_dtransl, hipStream_t st);
+                        float *dL_dtransl, int accumulate, hipStream_t st);

@@ -79,11 +79,11 @@ __global__ void __launch_bounds__(256)
 sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         const int32_t *__restrict__ radii, SgGeom g, const float4 *__restrict__ grec,
+                         const int32_t *__restrict__ radii, SgGeom g, SgRec grec,
                          size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
-                         float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
+                         float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D, int accumulate)
 {
     __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -153,20 +153,47 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
-                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32);
+                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, accumulate != 0);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (live) {
             float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+            if (accumulate) {
 #pragma unroll
-            for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
-            for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
+                for (int k = 0; k < nc * 3; k++) dsh_row[k] += dsh[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
+                for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
+            }
         }
     }
     if (!live) return;
-    dL_dmeans3D[3 * idx] = G.dmean[0]; dL_dmeans3D[3 * idx + 1] = G.dmean[1]; dL_dmeans3D[3 * idx + 2] = G.dmean[2];
+    // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
     dL_dmeans2D[3 * idx] = G.g2[0]; dL_dmeans2D[3 * idx + 1] = G.g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
+    if (accumulate) {
+        // the views of one optimisation step share ONE gradient buffer: this view adds to what the views in front of it in the
+        // step's chain left there (the old values are requested together, here: one more memory round trip per wave)
+        float o3[3], os[3], orr[4], oc[3], og[6], oo;
+#pragma unroll
+        for (int k = 0; k < 3; k++) o3[k] = dL_dmeans3D[3 * idx + k];
+        oo = dL_dopacity[idx];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { oc[k] = dL_dcolors ? dL_dcolors[3 * idx + k] : 0.0f; os[k] = dL_dscales ? dL_dscales[3 * idx + k] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) orr[k] = dL_drots ? dL_drots[4 * idx + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) og[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { G.dmean[k] += o3[k]; G.dcol[k] += oc[k]; G.dsc[k] += os[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) G.drot[k] += orr[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) G.g6[k] += og[k];
+        G.dop += oo;
+    }
+    dL_dmeans3D[3 * idx] = G.dmean[0]; dL_dmeans3D[3 * idx + 1] = G.dmean[1]; dL_dmeans3D[3 * idx + 2] = G.dmean[2];
     dL_dopacity[idx] = G.dop;
     if (dL_dcolors) { dL_dcolors[3 * idx] = G.dcol[0]; dL_dcolors[3 * idx + 1] = G.dcol[1]; dL_dcolors[3 * idx + 2] = G.dcol[2]; }
     if (dL_dscales) { dL_dscales[3 * idx] = G.dsc[0]; dL_dscales[3 * idx + 1] = G.dsc[1]; dL_dscales[3 * idx + 2] = G.dsc[2]; }
@@ -180,18 +207,18 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
+                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
-                              float *dL_drots, float *dL_dcov3D, hipStream_t st)
+                              float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st)
 {
     (void)opacities;
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
 #define SG_PB(DD) hipLaunchKernelGGL(sg_preprocess_bwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
-                                     (const float4 *)grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
-                                     dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+                                     grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     dL_dopacity, dL_dscales, dL_drots, dL_dcov3D, accumulate)
     int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (D) { case 0: SG_PB(0); break; case 1: SG_PB(1); break; case 2: SG_PB(2); break; default: SG_PB(3); break; }

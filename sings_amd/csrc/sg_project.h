@@ -251,11 +251,27 @@ __device__ __forceinline__ void sg_rows48_load(const float *__restrict__ base, i
     }
 }
 // stores `rows` (<= 64) rows starting at Gaussian g0
+// accumulate: dst += rows (the gradient buffer is shared by the views of a step: sg_rasterize_backward_gaussians)
 __device__ __forceinline__ void sg_rows48_store(float *__restrict__ base, int g0, int P, int lane,
-                                                const float *__restrict__ l, int rows = 64)
+                                                const float *__restrict__ l, int rows = 64, bool accumulate = false)
 {
     float4 *dst = (float4 *)(base + (size_t)g0 * 48);
     const int nf4 = (P - g0 < rows ? (P - g0 > 0 ? P - g0 : 0) : rows) * 12;
+    if (accumulate) {
+        float4 old[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) { const int f = i * 64 + lane; old[i] = f < nf4 ? dst[f] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#pragma unroll
+        for (int i = 0; i < 12; i++) {
+            const int f = i * 64 + lane;
+            if (f < nf4) {
+                const int row = f / 12, c4 = f - row * 12;
+                const float4 v = *(const float4 *)(l + row * SG_ROW_LDS + 4 * c4);
+                dst[f] = make_float4(old[i].x + v.x, old[i].y + v.y, old[i].z + v.z, old[i].w + v.w);
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 12; i++) {
         const int f = i * 64 + lane;
@@ -271,7 +287,7 @@ struct SgGaussGrad {
 };
 
 // Sum of this Gaussian's (tile,Gaussian) gradient records, fixed order -> deterministic.
-__device__ __forceinline__ void sg_sum_records(const float4 *__restrict__ grec, size_t cap, float4 recC, float a9[9])
+__device__ __forceinline__ void sg_sum_records(SgRec grec, size_t cap, float4 recC, float a9[9])
 {
     uint32_t goff = __float_as_uint(recC.y), wh = __float_as_uint(recC.w);
     uint32_t tt = (wh & 0xffffu) * (wh >> 16);
@@ -280,17 +296,17 @@ __device__ __forceinline__ void sg_sum_records(const float4 *__restrict__ grec, 
     for (uint32_t k = 0; k < tt; k++) {
         size_t r = (size_t)goff + k;
         if (r >= cap) break;
-        float4 r0 = grec[3 * r], r1 = grec[3 * r + 1], r2 = grec[3 * r + 2];
+        float4 r0 = grec.a[2 * r], r1 = grec.a[2 * r + 1];
         a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
-        a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r2.x;
+        a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += grec.b[r];
     }
 }
 
 // Cooperative variant: the wave's records are ONE contiguous range (slots are reserved per wave in lane
 // order), so the wave streams them with 16-B-per-lane loads into LDS (chunks of SG_REC_CHUNK records)
-// and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*12 floats.
+// and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*9 floats.
 #define SG_REC_CHUNK 128
-__device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ grec, size_t cap, bool vis, float4 recC,
+__device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool vis, float4 recC,
                                                     int lane, float *__restrict__ l, float a9[9])
 {
     const uint32_t goff = __float_as_uint(recC.y), wh = __float_as_uint(recC.w);
@@ -308,32 +324,44 @@ __device__ __forceinline__ void sg_sum_records_coop(const float4 *__restrict__ g
     if ((size_t)whi > cap) whi = (uint32_t)cap;
     for (uint32_t c0 = wlo; c0 < whi; c0 += SG_REC_CHUNK) {
         const uint32_t n = whi - c0 < SG_REC_CHUNK ? whi - c0 : SG_REC_CHUNK;
-        const float4 *src = grec + 3 * (size_t)c0;
-        // all six 16-B loads of the chunk are issued before the first one is used (as a loop the compiler emitted load -> wait ->
-        // LDS write, ONE request in flight per wave: a memory latency per KiB); indices are clamped instead of tested, so nothing
-        // branches around a load, and the surplus lanes rewrite the last element
+        const float4 *src = grec.a + 2 * (size_t)c0;
+        const float *srb = grec.b + (size_t)c0;
+        // all four 16-B loads and the two 4-B loads of the chunk are issued before the first one is used (as a loop the compiler
+        // emitted load -> wait -> LDS write, ONE request in flight per wave: a memory latency per KiB); indices are clamped instead
+        // of tested, so nothing branches around a load, and the surplus lanes rewrite the last element
         {
-            float4 v[SG_REC_CHUNK * 3 / 64];
-            const uint32_t last = 3 * n - 1;
+            float4 v[SG_REC_CHUNK * 2 / 64];
+            float w[SG_REC_CHUNK / 64];
+            const uint32_t last = 2 * n - 1;
 #pragma unroll
-            for (int i = 0; i < SG_REC_CHUNK * 3 / 64; i++) {
+            for (int i = 0; i < SG_REC_CHUNK * 2 / 64; i++) {
                 const uint32_t f = (uint32_t)lane + 64u * i;
                 v[i] = src[f < last ? f : last];
             }
 #pragma unroll
-            for (int i = 0; i < SG_REC_CHUNK * 3 / 64; i++) {
+            for (int i = 0; i < SG_REC_CHUNK / 64; i++) {
+                const uint32_t f = (uint32_t)lane + 64u * i;
+                w[i] = srb[f < n - 1 ? f : n - 1];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK * 2 / 64; i++) {
                 const uint32_t f = (uint32_t)lane + 64u * i;
                 ((float4 *)l)[f < last ? f : last] = v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK / 64; i++) {
+                const uint32_t f = (uint32_t)lane + 64u * i;
+                l[SG_REC_CHUNK * 8 + (f < n - 1 ? f : n - 1)] = w[i];
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const uint32_t k0 = lo > c0 ? lo : c0, k1 = hi < c0 + n ? hi : c0 + n;
         for (uint32_t k = k0; k < k1; k++) {
-            const float4 *r = (const float4 *)l + 3 * (k - c0);
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const float4 *r = (const float4 *)l + 2 * (k - c0);
+            const float4 r0 = r[0], r1 = r[1];
             a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
-            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r2.x;
+            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += l[SG_REC_CHUNK * 8 + (k - c0)];
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -20,10 +20,11 @@
 //  * Backward: the 9 per-pixel partials of an entry are summed across the wave's 64 lanes with a
 //    multi-value butterfly (v_permlane32_swap / v_permlane16_swap / DPP: 24 ops for 9 values instead of
 //    54), the <= 4 quadrant sums are combined in LDS in a fixed order and stored ONCE per (tile,Gaussian)
-//    as a 48-byte record at the Gaussian-major slot reserved in the forward pass.  No float atomics
+//    as a 36-byte record at the Gaussian-major slot reserved in the forward pass.  No float atomics
 //    (memory-side atomics cap at ~1.3 TB/s on MI355X and scattered single-row adds are 17x slower);
 //    gradients are bitwise reproducible.
 #include "sg_sort.h"
+#include <stdlib.h>
 
 #define SG_FB 256         // forward: list entries staged per batch (one per thread)
 #define SG_BB 64         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
@@ -56,6 +57,19 @@ __device__ __forceinline__ int sg_tile_of_block(int block)
     // bound by its longest tile (39 serial batches), not by this; see DESIGN.md.
     const int within = (slot + 7 * (slot >> 5)) & (SG_XCD_RUN - 1);
     return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + within;
+}
+
+// Few tiles with very different list lengths (an avatar: T <= 4096, sg_tile_order_used): the static map above leaves the CUs
+// that own background columns idle while the ones under the body composite 5-7 long lists each (per-tile clocks, tools/
+// tile_clock.py: every workgroup of the frame is resident from the first microsecond, the heaviest tile sets the kernel time and
+// the mean CU has 1/1.6 of the heaviest CU's work).  `order` lists the tiles by descending work class (written by the scan);
+// a CU receives blocks j, j + 256, j + 512, ... (j = block mod 256), so round k hands ranks 256 k .. 256 k + 255 to the CUs,
+// alternately ascending and descending: every CU gets one tile of every weight class, heavy next to light.
+__device__ __forceinline__ int sg_tile_of_rank(int block, const uint32_t *__restrict__ order, int T)
+{
+    const int k = block >> 8, j = block & 255;
+    const int r = 256 * k + ((k & 1) ? 255 - j : j);
+    return r < T ? (int)order[r] : T;
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
@@ -151,14 +165,15 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
+                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,
+                     const uint32_t *__restrict__ order)
 {
     __shared__ float4 sR[SG_FB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
     __shared__ float4 sBox[4];
     (void)nblocks;
-    const int tile = sg_tile_of_block(blockIdx.x);
+    const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // The counters the NEXT forward's preprocess counts into are consumed by now (the scan ran before this kernel): leave
@@ -279,6 +294,28 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 // Lists of <= 1024 entries are sorted by this workgroup first (sg_sort.h), longer ones arrive sorted (bucket sort, sg_binning.hip).
 #define SG_FW 1024
 
+#ifdef SG_TILE_CLOCK
+// Measurement build only (tools/tile_clock.py; never the product): per-tile wall clock (100 MHz) of the forward composite.
+__device__ unsigned long long sg_tile_clock[1 << 16][4];
+extern "C" int sg_debug_tile_clock(void *dst, int ntiles)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg_tile_clock), (size_t)ntiles * 32, 0, hipMemcpyDeviceToHost);
+}
+#define SG_CLK_DECL unsigned long long clk0 = wall_clock64(); unsigned clk_w = 0, clk_b = 0; unsigned long long clk_cull = 0, clk_t = 0;
+#define SG_CLK_WINDOW clk_w++; clk_t = wall_clock64();
+#define SG_CLK_CULLED clk_cull += wall_clock64() - clk_t;
+#define SG_CLK_BATCH clk_b++;
+#define SG_CLK_END if (tid == 0 && tile < (1 << 16)) { sg_tile_clock[tile][0] = clk0; sg_tile_clock[tile][1] = wall_clock64(); \
+                                                      sg_tile_clock[tile][2] = (unsigned long long)(unsigned)n | ((unsigned long long)clk_w << 32) | ((unsigned long long)clk_b << 48); \
+                                                      sg_tile_clock[tile][3] = clk_cull | ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4 /* HW_ID */ ) << 40); }
+#else
+#define SG_CLK_DECL
+#define SG_CLK_WINDOW
+#define SG_CLK_CULLED
+#define SG_CLK_BATCH
+#define SG_CLK_END
+#endif
+
 template <int MUL>
 __device__ __forceinline__ int sg_compact_quadrant_b(const uint32_t *__restrict__ sM, int cnt, int w, int lane,
                                                      unsigned long long lt, uint16_t *__restrict__ list, int batch,
@@ -312,7 +349,8 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
                          const float *__restrict__ bg, float *__restrict__ out_color,
                          float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                          const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                         uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
+                         uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,
+                         const uint32_t *__restrict__ order)
 {
     __shared__ float4 sR[SG_FB][3];            // staged survivor: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_FB];
@@ -322,9 +360,10 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
     __shared__ uint16_t sIdx[SG_FW];           //                                        position inside the window
     __shared__ uint32_t sCnt[4][4];            // survivors per (quarter of the window, wave)
     (void)nblocks;
-    const int tile = sg_tile_of_block(blockIdx.x);
+    const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SG_CLK_DECL
     if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }     // (see sg_render_fwd_kernel)
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
     const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
@@ -367,6 +406,7 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
             if (lane == 0) sBox[wave] = bx;
         }
         if (__syncthreads_count(done) == 256) break;       // also: the previous window is fully consumed
+        SG_CLK_WINDOW
         // ---- cull: four entries per thread against the live boxes, two at a time: the gathers of a pair go out together and the
         // tests run one after the other (sched_barrier) -- all four at once need 95 registers (five waves per SIMD), pairs 79 (six)
         uint32_t sv = 0;
@@ -413,6 +453,7 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
             bnd[4] = (int)run;
         }
         const int S = bnd[4];
+        SG_CLK_CULLED
         // ids of the next window: in flight while this one is composited
         if (base + SG_FW < n) {
 #pragma unroll
@@ -434,6 +475,7 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
             }
             if (__syncthreads_count(done) == 256) { all_done = true; break; }      // also: the previous batch is fully consumed
             const int cnt = S - r0 < SG_FB ? S - r0 : SG_FB;
+            SG_CLK_BATCH
             if (tid < cnt) {
                 const uint32_t g = sCand[r0 + tid];
                 const float4 pa = recA[g], pb = recB[g];
@@ -494,6 +536,7 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
         out_color[hw + pid] = fmaf(Tr, bg[1], C1);
         out_color[2 * hw + pid] = fmaf(Tr, bg[2], C2);
     }
+    SG_CLK_END
 }
 
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
@@ -503,21 +546,26 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
 {
     static_assert(SG_FB == SG_SEG, "forward batches are the checkpoint granularity");
     const int T = c.gx * c.gy;
-    const int grid = sg_render_blocks(T);
+    int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
     // A caller that vouches for short lists (SG_FLAG_SHORT_LISTS: a pre-sized engine that has seen the scene, e.g. cfg3 with a
     // longest list of 135) gets the batch-walking kernel: 15 KiB of LDS, eight workgroups per CU.  Everybody else -- the drop-in
     // wrapper, avatar frames -- gets the window kernel, which costs 22 KiB (seven per CU) and handles lists of any length.
-    if (c.flags & SG_FLAG_SHORT_LISTS)
+    const char *e_any = getenv("SG_FWD_ANY"), *e_lpt = getenv("SG_FWD_LPT");          // EXPERIMENT switches (removed once measured)
+    const bool any = e_any ? atoi(e_any) != 0 : !(c.flags & SG_FLAG_SHORT_LISTS);
+    const bool lpt = (e_lpt ? atoi(e_lpt) != 0 : true) && sg_tile_order_used((size_t)T);
+    const uint32_t *order = lpt ? b.order : (const uint32_t *)nullptr;
+    if (lpt) grid = ((T + 255) / 256) * 256;               // whole rounds of 256 ranks (sg_tile_of_rank snakes inside a round)
+    if (!any)
         hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);
     else
         hipLaunchKernelGGL(sg_render_fwd_any_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -570,7 +618,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, const float *__restrict__ final_T,
                      const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
-                     float4 *__restrict__ grec, uint32_t cap, const uint32_t *__restrict__ header,
+                     float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap, const uint32_t *__restrict__ header,
                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
                      const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask)
 {
@@ -710,16 +758,16 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 }
             const float no = -opac, nh = 0.5f * no;              // -opacity, -opacity / 2
             const float m0 = fmaf(cA, s[0], cB * s[1]), m1 = fmaf(cB, s[0], cC * s[1]);   // conic . first moments
-            grec[3 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s[2], nh * s[3]);
-            grec[3 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
-            grec[3 * (size_t)rslot + 2] = make_float4(s[8], 0.0f, 0.0f, 0.0f);
+            grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s[2], nh * s[3]);
+            grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
+            grec_b[rslot] = s[8];
         }
         __syncthreads();
     }
 }
 
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
-                          const float *dL_dpix, float *grec, hipStream_t st)
+                          const float *dL_dpix, SgRec grec, hipStream_t st)
 {
     static_assert(SG_SEG % SG_BB == 0, "segments are whole backward batches");
     const int T = c.gx * c.gy;
@@ -728,6 +776,6 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     sg_prof_begin(SG_K_RENDER_BWD, st);
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
-                       (float4 *)grec, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask);
+                       grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask);
     sg_prof_end(SG_K_RENDER_BWD, st);
 }

@@ -289,11 +289,11 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 template <int D>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
-                   const int32_t *__restrict__ radii, SgGeom g, const float4 *__restrict__ grec, size_t cap,
+                   const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
                    const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
-                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
+                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride, int accumulate)
 {
     __shared__ float sA[SG_JMAX * 16];
     // per wave: [weights tile | T transpose scratch, later the dT tile]; between the two uses the whole 2 x 4.3 KB is
@@ -371,6 +371,13 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
                     dRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
             }
         }
+        // accumulate: the frames of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
+        const float acc = accumulate ? 1.0f : 0.0f;
+        if (accumulate) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) { dxc[i] += dL_dxyz_canon[3 * idx + i]; dsc[i] += dL_dscales[3 * idx + i]; }
+            dop += dL_dopacity[idx];
+        }
         dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
         if (dL_drot_canon) {
             if (k.rot6d) {
@@ -379,12 +386,13 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
                 for (int i = 0; i < 6; i++) d6[i] = k.rot_canon[6 * (size_t)idx + i];
                 sg_r6d2m_bwd(d6, dRc, dd);
 #pragma unroll
-                for (int i = 0; i < 6; i++) dL_drot_canon[6 * (size_t)idx + i] = dd[i];
+                for (int i = 0; i < 6; i++) dL_drot_canon[6 * (size_t)idx + i] = dd[i] + (accumulate ? dL_drot_canon[6 * (size_t)idx + i] : 0.0f);
             } else {
 #pragma unroll
-                for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i];
+                for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i] + (accumulate ? dL_drot_canon[9 * (size_t)idx + i] : 0.0f);
             }
         }
+        (void)acc;
         dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
         dL_dopacity[idx] = dop;
         dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
@@ -400,15 +408,20 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
             }
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
-            sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, sWw, 32);
+            sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, sWw, 32, accumulate != 0);
             __builtin_amdgcn_s_waitcnt(0xC07F);
             __builtin_amdgcn_wave_barrier();
         }
     } else if (live) {
         float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+        if (accumulate) {
 #pragma unroll
-        for (int i = 0; i < nc * 3; i++) dsh_row[i] = dsh[i];
-        for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+            for (int i = 0; i < nc * 3; i++) dsh_row[i] += dsh[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < nc * 3; i++) dsh_row[i] = dsh[i];
+            for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
+        }
     }
     // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
     float *sdT = sTw;
@@ -926,10 +939,10 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
 size_t sg_skin_slab_floats(int P) { return ((size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES + SG_RED_GROUPS) * (SG_JMAX * 16 + 4); }
 
 void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, const float *grec, size_t cap, const uint32_t *header,
+                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
                         const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
-                        float *dL_dtransl, hipStream_t st)
+                        float *dL_dtransl, int accumulate, hipStream_t st)
 {
     if (P <= 0) return;
     SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
@@ -937,8 +950,8 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
 #define SG_SB(DD) hipLaunchKernelGGL(sg_skin_bwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
-                                     (const float4 *)grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
-                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
+                                     grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride, accumulate)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
     float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;

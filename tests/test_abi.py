@@ -29,7 +29,7 @@ def test_layout_is_consistent():
     assert L.bin_ranges - L.bin_tile_count >= T * 4
     assert L.bin_point_list - L.bin_pair_keys >= 50000 * 8
     assert L.img_n_contrib - L.img_final_T >= 1920 * 1080 * 4
-    assert L.bwd_bytes >= 50000 * 48
+    assert 50000 * 36 <= L.bwd_bytes < 50000 * 40
     for f, _ in L._fields_:
         assert getattr(L, f) % 256 == 0
     with pytest.raises(RuntimeError):
