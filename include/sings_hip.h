@@ -117,6 +117,24 @@ int sg_rasterize_backward(const SgRasterSettings *s, int P, const float *means3D
                           float *dL_dopacity, float *dL_dscales, float *dL_drotations,
                           float *dL_dcov3D, void *stream);
 
+/* The two halves of sg_rasterize_backward as separate calls, for callers that render several views of the SAME Gaussians per
+ * optimisation step (frame-parallel training: every rank renders a batch of frames, gs_trainer.py:207-215 is one frame per step):
+ *   _records   : the per-tile composite backward of one view -> one gradient record per (tile, Gaussian) pair in bwd_ws;
+ *   _gaussians : per Gaussian, the sum of its records and the chain rule to the inputs.  accumulate = 0: the gradient outputs are
+ *                written; != 0: the view's gradients are ADDED to what the outputs hold (dL_dmeans2D, the densifier's per-view
+ *                statistic, is always written).  The views of a step can therefore share ONE gradient buffer -- the first view
+ *                writes, the others add, in an order the caller fixes with stream events (deterministic) -- instead of one
+ *                buffer per view and a pass that sums them. */
+int sg_rasterize_backward_records(const SgRasterSettings *s, int P, const void *geom_ws, const void *binning_ws,
+                                  size_t capacity_pairs, const void *image_ws, void *bwd_ws, const float *dL_dout_color,
+                                  void *stream);
+int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                                    const float *colors_precomp, const float *opacities, const float *scales,
+                                    const float *rotations, const float *cov3D_precomp, const int32_t *radii,
+                                    const void *geom_ws, const void *binning_ws, size_t capacity_pairs, const void *bwd_ws,
+                                    int accumulate, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors,
+                                    float *dL_dopacity, float *dL_dscales, float *dL_drotations, float *dL_dcov3D, void *stream);
+
 /* markVisible of the upstream module: present[i] = view-space z > 0.2 */
 int sg_mark_visible(int P, const float *means3D, const float *viewmatrix, const float *projmatrix,
                     uint8_t *present, void *stream);
@@ -222,6 +240,16 @@ int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *sk
                         float *dL_dxyz_canon, float *dL_drot_canon, float *dL_dscales,
                         float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, void *stream);
+
+/* Second half of sg_skinned_backward alone (the first half is sg_rasterize_backward_records): accumulate != 0 adds the frame's
+ * canonical-Gaussian gradients (dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh) to the outputs; dL_dmeans2D, dL_dA
+ * and dL_dtransl are per frame and always written. */
+int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                                  const float *opacities, const float *scales, const int32_t *radii, const void *geom_ws,
+                                  const void *binning_ws, size_t capacity_pairs, const void *bwd_ws, float *skin_ws,
+                                  int accumulate, const float *dL_dposed_xyz_in, const float *dL_dposed_rotq_in,
+                                  float *dL_dxyz_canon, float *dL_drot_canon, float *dL_dscales, float *dL_dopacity,
+                                  float *dL_dsh, float *dL_dmeans2D, float *dL_dA, float *dL_dtransl, void *stream);
 
 /* ---- photometric loss of one view, forward + gradient -------------------------------------------
  * Replaces, for the L1 and SSIM terms of HumanSceneLoss.forward (sings/rec/losses/loss.py:55-69):

@@ -43,6 +43,7 @@ class SgTriplane(C.Structure):
 
 # every symbol include/sings_hip.h declares
 EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
+           "sg_rasterize_backward_records", "sg_rasterize_backward_gaussians", "sg_skinned_backward_gaussians",
            "sg_mark_visible", "sg_read_num_rendered", "sg_signal_alloc", "sg_signal_free", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
@@ -75,6 +76,13 @@ def load():
                                          [vp, vp, sz, vp, vp, vp, i32, C.POINTER(C.c_int64), vp])
     lib.sg_rasterize_backward.argtypes = ([C.POINTER(SgRasterSettings), i32] + [vp] * 7 +
                                           [vp, vp, vp, sz, vp, vp, vp] + [vp] * 8 + [vp])
+    lib.sg_rasterize_backward_records.argtypes = [C.POINTER(SgRasterSettings), i32, vp, vp, sz, vp, vp, vp, vp]
+    lib.sg_rasterize_backward_gaussians.argtypes = ([C.POINTER(SgRasterSettings), i32] + [vp] * 7 + [vp, vp, vp, sz, vp, i32] +
+                                                    [vp] * 8 + [vp])
+    lib.sg_skinned_backward_gaussians.argtypes = ([C.POINTER(SgRasterSettings), i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
+                                                  [vp, vp, vp, sz, vp, vp, i32] + [vp] * 2 + [vp] * 8 + [vp])
+    for f in ("sg_rasterize_backward_records", "sg_rasterize_backward_gaussians", "sg_skinned_backward_gaussians"):
+        getattr(lib, f).restype = C.c_int
     lib.sg_mark_visible.argtypes = [i32, vp, vp, vp, vp, vp]
     lib.sg_read_num_rendered.argtypes = [vp, C.POINTER(C.c_int64), vp]
     lib.sg_signal_alloc.argtypes = [i32, C.POINTER(vp), C.POINTER(vp)]; lib.sg_signal_alloc.restype = C.c_int

@@ -190,7 +190,6 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
                                      float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors, float *dL_dopacity,
                                      float *dL_dscales, float *dL_drotations, float *dL_dcov3D, void *stream)
 {
-    hipStream_t st = (hipStream_t)stream;
     SgCam c;
     if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_backward: bad settings", hipSuccess);
     if (P <= 0) return 0;
@@ -198,6 +197,24 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
         !dL_dmeans2D || !dL_dopacity)
         return sg_fail("sg_rasterize_backward: null pointer", hipSuccess);
     if (shs && !dL_dsh) return sg_fail("sg_rasterize_backward: dL_dsh missing", hipSuccess);
+    int rc = sg_rasterize_backward_records(s, P, geom_ws, binning_ws, cap, image_ws, bwd_ws, dL_dout_color, stream);
+    if (rc) return rc;
+    return sg_rasterize_backward_gaussians(s, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii,
+                                           geom_ws, binning_ws, cap, bwd_ws, 0, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors,
+                                           dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D, stream);
+}
+
+// first half of the backward: per-tile composite -> one gradient record per (tile, Gaussian) pair in bwd_ws
+extern "C" int sg_rasterize_backward_records(const SgRasterSettings *s, int P, const void *geom_ws, const void *binning_ws,
+                                             size_t cap, const void *image_ws, void *bwd_ws, const float *dL_dout_color,
+                                             void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_backward_records: bad settings", hipSuccess);
+    if (P <= 0) return 0;
+    if (!geom_ws || !binning_ws || !image_ws || !bwd_ws || !dL_dout_color)
+        return sg_fail("sg_rasterize_backward_records: null pointer", hipSuccess);
     SgLayout L;
     sg_layout(P, c.W, c.H, cap, &L);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
@@ -205,10 +222,33 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
     SgImg im = sg_img_view((void *)image_ws, L);
     sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
     SG_CHECK_LAST("render_bwd", s, st);
+    return 0;
+}
+
+// second half: per Gaussian, the sum of its records and the chain rule; accumulate != 0: += into the gradient outputs
+extern "C" int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                                               const float *colors_precomp, const float *opacities, const float *scales,
+                                               const float *rotations, const float *cov3D_precomp, const int32_t *radii,
+                                               const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
+                                               int accumulate, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
+                                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                                               float *dL_dcov3D, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_backward_gaussians: bad settings", hipSuccess);
+    if (P <= 0) return 0;
+    if (!means3D || !radii || !geom_ws || !binning_ws || !bwd_ws || !dL_dmeans3D || !dL_dmeans2D || !dL_dopacity)
+        return sg_fail("sg_rasterize_backward_gaussians: null pointer", hipSuccess);
+    if (shs && !dL_dsh) return sg_fail("sg_rasterize_backward_gaussians: dL_dsh missing", hipSuccess);
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgGeom g = sg_geom_view((void *)geom_ws, L);
+    SgBin b = sg_bin_view((void *)binning_ws, L);
     sg_launch_preprocess_bwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
                              sg_rec_view(bwd_ws, cap), cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
-                             cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, st);
+                             cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, accumulate, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);
     return 0;
 }
@@ -272,16 +312,38 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
     if (!shs || !scales || !radii || !geom_ws || !binning_ws || !image_ws || !bwd_ws || !skin_ws || !dL_dout_color ||
         !dL_dxyz_canon || !dL_dscales || !dL_dopacity || !dL_dsh || !dL_dmeans2D || !dL_dA)
         return sg_fail("sg_skinned_backward: null pointer", hipSuccess);
+    (void)st;
+    int rc = sg_rasterize_backward_records(s, P, geom_ws, binning_ws, cap, image_ws, bwd_ws, dL_dout_color, stream);
+    if (rc) return rc;
+    return sg_skinned_backward_gaussians(s, P, skin, shs, opacities, scales, radii, geom_ws, binning_ws, cap, bwd_ws, skin_ws, 0,
+                                         dL_dposed_xyz_in, dL_dposed_rotq_in, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity,
+                                         dL_dsh, dL_dmeans2D, dL_dA, dL_dtransl, stream);
+}
+
+extern "C" int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                                             const float *opacities, const float *scales, const int32_t *radii,
+                                             const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
+                                             float *skin_ws, int accumulate, const float *dL_dposed_xyz_in,
+                                             const float *dL_dposed_rotq_in, float *dL_dxyz_canon, float *dL_drot_canon,
+                                             float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D,
+                                             float *dL_dA, float *dL_dtransl, void *stream)
+{
+    (void)opacities;
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    if (sg_make_cam(s, &c)) return sg_fail("sg_skinned_backward_gaussians: bad settings", hipSuccess);
+    if (sg_check_skin(skin, P, false)) return sg_fail("sg_skinned_backward_gaussians: bad skin inputs (ext_tfs are forward-only)", hipSuccess);
+    if (P <= 0) return 0;
+    if (!shs || !scales || !radii || !geom_ws || !binning_ws || !bwd_ws || !skin_ws || !dL_dxyz_canon || !dL_dscales ||
+        !dL_dopacity || !dL_dsh || !dL_dmeans2D || !dL_dA)
+        return sg_fail("sg_skinned_backward_gaussians: null pointer", hipSuccess);
     SgLayout L;
     sg_layout(P, c.W, c.H, cap, &L);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
-    SgImg im = sg_img_view((void *)image_ws, L);
-    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
-    SG_CHECK_LAST("render_bwd", s, st);
     sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
                        skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
-                       dL_dtransl, st);
+                       dL_dtransl, accumulate, st);
     SG_CHECK_LAST("skin_bwd", s, st);
     return 0;
 }

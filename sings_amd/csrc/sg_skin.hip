@@ -372,7 +372,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
             }
         }
         // accumulate: the frames of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
-        const float acc = accumulate ? 1.0f : 0.0f;
         if (accumulate) {
 #pragma unroll
             for (int i = 0; i < 3; i++) { dxc[i] += dL_dxyz_canon[3 * idx + i]; dsc[i] += dL_dscales[3 * idx + i]; }
@@ -392,7 +391,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
                 for (int i = 0; i < 9; i++) dL_drot_canon[9 * (size_t)idx + i] = dRc[i] + (accumulate ? dL_drot_canon[9 * (size_t)idx + i] : 0.0f);
             }
         }
-        (void)acc;
         dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
         dL_dopacity[idx] = dop;
         dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;

@@ -53,6 +53,7 @@ class RasterEngine:
         self.d_means2D = torch.empty((self.P, 3), **f32)      # densification statistic, not reduced as a weight grad
         self._keep = []
         self._s = None
+        self._chain = None                                    # (accumulate, wait-for event, done event): set by ViewBatch
 
     def set_camera(self, raster_settings, short_lists=False):
         """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 1024 entries (what the
@@ -77,11 +78,22 @@ class RasterEngine:
         return int(nr.value)
 
     def backward(self, means3D, shs, opacities, scales, rotations, dL_dcolor):
-        _lib.check(self.lib.sg_rasterize_backward(
+        """Composite backward (gradient records of this view), then the per-Gaussian chain rule into the gradient buffer.
+        Inside a ``ViewBatch`` whose views share ONE gradient buffer (``chain``) the second half first waits for the view in
+        front of this one in the step's chain and ADDS to the buffer (``sg_rasterize_backward_gaussians(accumulate=1)``)."""
+        _lib.check(self.lib.sg_rasterize_backward_records(
+            C.byref(self._s), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
+            _ptr(dL_dcolor), self._stream()), "backward (records)")
+        accumulate, after, done = self._chain if self._chain is not None else (False, None, None)
+        if after is not None:
+            torch.cuda.current_stream(self.dev).wait_event(after)
+        _lib.check(self.lib.sg_rasterize_backward_gaussians(
             C.byref(self._s), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales), _ptr(rotations),
-            None, _ptr(self.radii), _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
-            _ptr(dL_dcolor), _ptr(self.d_means3D), _ptr(self.d_means2D), _ptr(self.d_sh), None, _ptr(self.d_opacity),
-            _ptr(self.d_scales), _ptr(self.d_rots), None, self._stream()), "backward")
+            None, _ptr(self.radii), _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.bwd_ws), int(accumulate),
+            _ptr(self.d_means3D), _ptr(self.d_means2D), _ptr(self.d_sh), None, _ptr(self.d_opacity),
+            _ptr(self.d_scales), _ptr(self.d_rots), None, self._stream()), "backward (gaussians)")
+        if done is not None:
+            done.record(torch.cuda.current_stream(self.dev))
 
     def num_rendered(self):
         nr = C.c_int64(0)
@@ -148,6 +160,7 @@ class SkinnedEngine:
         self.d_means2D = torch.empty((self.P, 3), **f32)
         self.d_A = torch.empty((self.J, 16), **f32); self.d_transl = torch.empty(3, **f32)
         self._keep = []; self._s = None; self._k = None
+        self._chain = None
 
     def set_camera(self, raster_settings):
         self._keep = []
@@ -173,11 +186,20 @@ class SkinnedEngine:
         return int(nr.value)
 
     def backward(self, shs, opacities, scales, dL_dcolor):
-        _lib.check(self.lib.sg_skinned_backward(
+        """As ``RasterEngine.backward``: records of this frame, then (chained inside a ``ViewBatch``) the per-Gaussian half."""
+        _lib.check(self.lib.sg_rasterize_backward_records(
+            C.byref(self._s), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
+            _ptr(dL_dcolor), self._stream()), "skinned backward (records)")
+        accumulate, after, done = self._chain if self._chain is not None else (False, None, None)
+        if after is not None:
+            torch.cuda.current_stream(self.dev).wait_event(after)
+        _lib.check(self.lib.sg_skinned_backward_gaussians(
             C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.radii),
-            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws), _ptr(self.skin_ws),
-            _ptr(dL_dcolor), None, None, _ptr(self.d_xyz), _ptr(self.d_rot), _ptr(self.d_scales), _ptr(self.d_opacity),
-            _ptr(self.d_sh), _ptr(self.d_means2D), _ptr(self.d_A), _ptr(self.d_transl), self._stream()), "skinned backward")
+            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.bwd_ws), _ptr(self.skin_ws), int(accumulate),
+            None, None, _ptr(self.d_xyz), _ptr(self.d_rot), _ptr(self.d_scales), _ptr(self.d_opacity),
+            _ptr(self.d_sh), _ptr(self.d_means2D), _ptr(self.d_A), _ptr(self.d_transl), self._stream()), "skinned backward (gaussians)")
+        if done is not None:
+            done.record(torch.cuda.current_stream(self.dev))
 
     def num_rendered(self):
         nr = C.c_int64(0)
@@ -193,15 +215,25 @@ class ViewBatch:
     library keeps no state between calls, and every engine owns its workspaces -- so the views are dealt round-robin to
     ``streams`` streams and fill each other's holes (one MI355X: +24 % views/s at cfg3, +77 % frames/s for the avatar),
     bit-identical to running them one after the other.  ``run`` forks from the caller's current stream, launches
-    ``fn(v, engine)`` for every view on its stream and joins; the per-view gradient rows are then folded into ``acc`` in a
-    fixed order and -- given a ``FrameParallel`` -- all-reduced over the ranks, chunk by chunk, the fold of one chunk under
-    the transfer of the one before (sings_amd.dp.GradientPipeline); nothing synchronises with the host.  (No further
-    stream: the caller's + three rendering streams are the four hardware queues HIP schedules onto.)
+    ``fn(v, engine)`` for every view on its stream and joins; nothing synchronises with the host.  (No further stream: the
+    caller's + three rendering streams are the four hardware queues HIP schedules onto.)
 
-        grads = ViewBatch.gradient_rows(views, per_view_floats, device)
-        engines = [RasterEngine(..., grad_flat=grads[v]) for v in range(views)]        # or SkinnedEngine
-        batch = ViewBatch(engines, grads, streams=3, frame_parallel=FrameParallel())    # None on one GPU
-        acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))                 # summed over views and ranks -> optimiser
+    Where the sum over the views is formed:
+
+    * ``chain`` (round 3, default when all engines were built on the SAME ``grad_flat``): the views share ONE gradient buffer.
+      The first view's per-Gaussian backward writes it, every later view's ADDS to it (``sg_*_backward_gaussians(accumulate=1)``)
+      and first waits for the event of the view in front of it -- only that last, short kernel is ordered, the composite kernels
+      still overlap freely -- so the sum is formed in the fixed order 0, 1, .., K-1 (bitwise reproducible) and is complete the
+      moment the last view's backward is: no fold pass after the join (round 2: K rows written, read again and summed,
+      ~95 us of serial tail at cfg3), one row of memory instead of K.
+    * rows (``grads`` is ``[views, per_view]``, one engine per row): the round-2 scheme, folded by ``GradientPipeline``.
+
+    Either way a ``FrameParallel`` all-reduces the summed buffer over the ranks, chunk by chunk.
+
+        acc = ViewBatch.gradient_rows(1, per_view_floats, device)[0]
+        engines = [RasterEngine(..., grad_flat=acc) for v in range(views)]            # or SkinnedEngine
+        batch = ViewBatch(engines, acc, streams=3, frame_parallel=FrameParallel())    # None on one GPU
+        acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))               # summed over views and ranks -> optimiser
     """
 
     @staticmethod
@@ -210,27 +242,41 @@ class ViewBatch:
 
     def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4):
         from .dp import GradientPipeline
-        if len(engines) != grads.shape[0]:
+        self.engines = list(engines)
+        self.chain = grads.dim() == 1 or (grads.shape[0] == 1 and len(self.engines) > 1)
+        if self.chain:
+            grads = grads.view(1, -1)
+            if any(e.grad_flat.data_ptr() != grads.data_ptr() for e in self.engines):
+                raise ValueError("chained views: every engine must be built on the same grad_flat")
+        elif len(self.engines) != grads.shape[0]:
             raise ValueError("one engine per gradient row")
-        self.engines, self.grads = list(engines), grads
+        self.grads = grads
         self.dev = grads.device
         self.n = max(1, min(int(streams), len(self.engines)))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
-        # the rows are folded into `acc` (and, with several ranks, all-reduced chunk by chunk) on the caller's stream once
-        # the views have joined it: sings_amd.dp.GradientPipeline
+        # the sum (rows: folded; chain: already there) is all-reduced chunk by chunk on the caller's stream once the views have
+        # joined it: sings_amd.dp.GradientPipeline
         self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
         self.acc = self.pipe.acc
+        self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
+
+    def _link(self, v, e):
+        if self.chain:
+            # view v adds to the buffer after view v - 1 has (events order only the per-Gaussian halves)
+            e._chain = (v > 0, self._events[v - 1] if v > 0 and self.n > 1 else None, self._events[v] if self.n > 1 else None)
 
     def run_unreduced(self, fn):
         """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``."""
         if not self.streams:
             for v, e in enumerate(self.engines):
+                self._link(v, e)
                 fn(v, e)
             return
         cur = torch.cuda.current_stream(self.dev)
         for st in self.streams:
             st.wait_stream(cur)
         for v, e in enumerate(self.engines):
+            self._link(v, e)
             with torch.cuda.stream(self.streams[v % self.n]):
                 fn(v, e)
         for st in self.streams:

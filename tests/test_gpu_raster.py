@@ -576,6 +576,56 @@ def test_views_in_flight_on_two_streams_match_sequential_runs():
         RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=1024, grad_flat=torch.zeros(7, device=dev))
 
 
+def test_views_of_a_step_add_to_one_gradient_buffer_in_a_fixed_order():
+    """Round 3: the views of a step share ONE gradient buffer (ViewBatch `chain`): view 0's per-Gaussian backward writes it,
+    every later view ADDS to it (sg_rasterize_backward_gaussians(accumulate=1)) after the event of the view in front of it.
+    The result must be, bit for bit, ((g0 + g1) + g2) + g3 of the per-view gradients -- whatever the number of streams, run
+    after run -- and dL/dmeans2D stays per view."""
+    from sings_amd.engine import RasterEngine, ViewBatch
+    dev = _dev()
+    s = synthetic_scene(20000, 512, 384, 3, 21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(s["dL_dimage"])
+    K = 4
+    per = 20000 * (3 + 3 + 4 + 1 + 3 * 16)
+
+    def engines(buffers):
+        engs = []
+        for v in range(K):
+            sv = dict(s)
+            view = s["viewmatrix"].copy(); view[3, 0] = 0.05 * v
+            sv["viewmatrix"] = view
+            sv["projmatrix"] = (view @ (np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"])).astype(np.float32)
+            sv["campos"] = np.linalg.inv(view)[3, :3].astype(np.float32)
+            e = RasterEngine(20000, s["W"], s["H"], 16, dev, capacity_pairs=8 * 20000 + 65536, grad_flat=buffers[v])
+            e.set_camera(_settings(sv, dev))
+            engs.append(e)
+        return engs
+    rows = torch.zeros((K, per), device=dev)
+    per_view = engines([rows[v] for v in range(K)])
+    for e in per_view:
+        e.forward(*ins); e.backward(*ins, dL)
+    torch.cuda.synchronize()
+    want = rows[0].clone()
+    for v in range(1, K):
+        want += rows[v]                                              # ((g0 + g1) + g2) + g3: one rounding per addition, as the kernel
+    m2d = [e.d_means2D.clone() for e in per_view]
+    acc = torch.full((per,), float("nan"), device=dev)               # (never pre-zeroed: view 0 WRITES)
+    shared = engines([acc] * K)
+    for n_streams in (1, 2, 3, 3):
+        acc.fill_(float("nan"))
+        batch = ViewBatch(shared, acc, streams=n_streams)
+        assert batch.chain
+        out = batch.run(lambda v, e: (e.forward(*ins), e.backward(*ins, dL)))
+        torch.cuda.synchronize()
+        assert out.data_ptr() == acc.data_ptr() and torch.equal(acc, want), n_streams
+        for e, m in zip(shared, m2d):
+            assert torch.equal(e.d_means2D, m)
+    with pytest.raises(ValueError):
+        ViewBatch(per_view, acc, streams=2)                          # chained views must share the buffer
+
+
 def test_against_frozen_oracle_vectors():
     """The HIP path through the drop-in autograd surface against the committed fixture tests/golden/raster_golden.npz (G6:
     frozen outputs of the restatement): radii / rectangles / sorted lists / tile ranges bit for bit, RGB within 1e-5 away
