@@ -30,6 +30,29 @@
 #define SG_BB 64         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
 #define SG_UNSET 0xffffffffu   // bit pattern (a NaN) of a quadrant-sum slot nobody wrote
 
+#ifdef SG_TILE_CLOCK
+// Measurement build only (tools/tile_clock.py; never the product): per-tile wall clock (100 MHz) of the forward composite.
+__device__ unsigned long long sg_tile_clock[1 << 16][4];
+extern "C" int sg_debug_tile_clock(void *dst, int ntiles)
+{
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg_tile_clock), (size_t)ntiles * 32, 0, hipMemcpyDeviceToHost);
+}
+#define SG_CLK_DECL unsigned long long clk0 = wall_clock64(); unsigned clk_w = 0, clk_b = 0; unsigned long long clk_cull = 0, clk_t = 0;
+#define SG_CLK_WINDOW clk_w++; clk_t = wall_clock64();
+#define SG_CLK_CULLED clk_cull += wall_clock64() - clk_t;
+#define SG_CLK_BATCH clk_b++;
+#define SG_CLK_END __shared__ unsigned clk_lv[4]; { const unsigned long long lv = __ballot(!done); if (lane == 0) clk_lv[wave] = (unsigned)__popcll(lv); } __syncthreads(); \
+                   const unsigned clk_live = clk_lv[0] + clk_lv[1] + clk_lv[2] + clk_lv[3]; if (tid == 0 && tile < (1 << 16)) { sg_tile_clock[tile][0] = clk0; sg_tile_clock[tile][1] = wall_clock64(); \
+                                                      sg_tile_clock[tile][2] = (unsigned long long)(unsigned)n | ((unsigned long long)clk_w << 32) | ((unsigned long long)clk_b << 48); \
+                                                      sg_tile_clock[tile][3] = clk_cull | ((unsigned long long)clk_live << 40); }
+#else
+#define SG_CLK_DECL
+#define SG_CLK_WINDOW
+#define SG_CLK_CULLED
+#define SG_CLK_BATCH
+#define SG_CLK_END
+#endif
+
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 // The composite loops evaluate alpha = min(.99, o 2^p) with p = log2(e) * power: the staging thread scales the conic ONCE per
 // (tile, entry) -- (A', B', C') = (-log2(e)/2 A, -log2(e) B, -log2(e)/2 C) -- and the pixel loop needs five operations,
@@ -172,10 +195,10 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
     __shared__ float4 sBox[4];
-    (void)nblocks;
     const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    SG_CLK_DECL
     // The counters the NEXT forward's preprocess counts into are consumed by now (the scan ran before this kernel): leave
     // them zeroed, so that a caller who keeps its workspace can skip the zeroing launch (SG_FLAG_WS_CLEAN).
     if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }
@@ -187,6 +210,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // R > capacity: part of the sorted list was never written (the caller re-runs with a larger workspace) --
     // render the background instead of gathering through stale ids
     const int n = header[1] ? 0 : (int)(range.y - range.x);
+    if (nblocks & (1 << 24)) { if (n > 1024) __builtin_amdgcn_s_setprio(3); else if (n > 512) __builtin_amdgcn_s_setprio(2); else if (n > 256) __builtin_amdgcn_s_setprio(1); }
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -220,6 +244,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             if (lane == 0) sBox[wave] = bx;
         }
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
+        SG_CLK_BATCH
         const int e = base + tid;
         if (e < n) {
             sR[tid][0] = make_float4(pa.x, pa.y, SG_KA * pa.z, SG_KB * pa.w);
@@ -272,6 +297,7 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         out_color[hw + pid] = fmaf(Tr, bg[1], C1);
         out_color[2 * hw + pid] = fmaf(Tr, bg[2], C2);
     }
+    SG_CLK_END
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,27 +320,6 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 // Lists of <= 1024 entries are sorted by this workgroup first (sg_sort.h), longer ones arrive sorted (bucket sort, sg_binning.hip).
 #define SG_FW 1024
 
-#ifdef SG_TILE_CLOCK
-// Measurement build only (tools/tile_clock.py; never the product): per-tile wall clock (100 MHz) of the forward composite.
-__device__ unsigned long long sg_tile_clock[1 << 16][4];
-extern "C" int sg_debug_tile_clock(void *dst, int ntiles)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg_tile_clock), (size_t)ntiles * 32, 0, hipMemcpyDeviceToHost);
-}
-#define SG_CLK_DECL unsigned long long clk0 = wall_clock64(); unsigned clk_w = 0, clk_b = 0; unsigned long long clk_cull = 0, clk_t = 0;
-#define SG_CLK_WINDOW clk_w++; clk_t = wall_clock64();
-#define SG_CLK_CULLED clk_cull += wall_clock64() - clk_t;
-#define SG_CLK_BATCH clk_b++;
-#define SG_CLK_END if (tid == 0 && tile < (1 << 16)) { sg_tile_clock[tile][0] = clk0; sg_tile_clock[tile][1] = wall_clock64(); \
-                                                      sg_tile_clock[tile][2] = (unsigned long long)(unsigned)n | ((unsigned long long)clk_w << 32) | ((unsigned long long)clk_b << 48); \
-                                                      sg_tile_clock[tile][3] = clk_cull | ((unsigned long long)__builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 4 /* HW_ID */ ) << 40); }
-#else
-#define SG_CLK_DECL
-#define SG_CLK_WINDOW
-#define SG_CLK_CULLED
-#define SG_CLK_BATCH
-#define SG_CLK_END
-#endif
 
 template <int MUL>
 __device__ __forceinline__ int sg_compact_quadrant_b(const uint32_t *__restrict__ sM, int cnt, int w, int lane,
@@ -359,7 +364,6 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
     __shared__ uint32_t sCand[SG_FW];          // survivors of the window in list order: Gaussian id
     __shared__ uint16_t sIdx[SG_FW];           //                                        position inside the window
     __shared__ uint32_t sCnt[4][4];            // survivors per (quarter of the window, wave)
-    (void)nblocks;
     const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -371,6 +375,7 @@ sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *
     const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     const int n = header[1] ? 0 : (int)(range.y - range.x);
+    if (nblocks & (1 << 24)) { if (n > 1024) __builtin_amdgcn_s_setprio(3); else if (n > 512) __builtin_amdgcn_s_setprio(2); else if (n > 256) __builtin_amdgcn_s_setprio(1); }
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -556,13 +561,15 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const bool lpt = (e_lpt ? atoi(e_lpt) != 0 : true) && sg_tile_order_used((size_t)T);
     const uint32_t *order = lpt ? b.order : (const uint32_t *)nullptr;
     if (lpt) grid = ((T + 255) / 256) * 256;               // whole rounds of 256 ranks (sg_tile_of_rank snakes inside a round)
+    const char *e_prio = getenv("SG_FWD_PRIO");
+    const int kflags = (e_prio && atoi(e_prio)) ? (1 << 24) : 0;
     if (!any)
-        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, kflags, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);
     else
-        hipLaunchKernelGGL(sg_render_fwd_any_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+        hipLaunchKernelGGL(sg_render_fwd_any_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, kflags, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);

@@ -30,7 +30,7 @@ buf = np.zeros((T, 4), np.uint64)
 assert lib.sg_debug_tile_clock(buf.ctypes.data_as(C.c_void_p), T) == 0
 t0, t1 = buf[:, 0].astype(np.int64), buf[:, 1].astype(np.int64)
 n = (buf[:, 2] & 0xffffffff).astype(np.int64); nw = ((buf[:, 2] >> 32) & 0xffff).astype(np.int64); nb = (buf[:, 2] >> 48).astype(np.int64)
-cull = (buf[:, 3] & ((1 << 40) - 1)).astype(np.int64); hw = (buf[:, 3] >> 40).astype(np.int64)
+cull = (buf[:, 3] & ((1 << 40) - 1)).astype(np.int64); livepx = (buf[:, 3] >> 40).astype(np.int64)
 live = t1 > 0
 k0 = t0[live].min()
 dur = (t1 - t0) * 0.01                      # us (100 MHz)
@@ -41,11 +41,13 @@ for lo, hi in ((0, 0), (1, 256), (257, 1024), (1025, 4096), (4097, 1 << 30)):
         print(f"  n {lo:>5}-{hi:<10}: {int(m.sum()):5d} tiles, mean {dur[m].mean():7.1f} us, max {dur[m].max():7.1f} us, windows {nw[m].sum():6d}, "
               f"batches {nb[m].sum():6d}, cull time {cull[m].sum() * 0.01:9.0f} us")
 order = np.argsort(-dur)[:12]
-print("longest tiles: (tile, n, windows, batches, us, of which cull us, start us, end us)")
+print("longest tiles: (tile, n, windows, batches, us, of which cull us, start us, end us, pixels still live at the end)")
 for i in order:
-    print(f"   {i:5d} n={n[i]:6d} w={nw[i]:3d} b={nb[i]:3d} {dur[i]:7.1f} cull {cull[i] * 0.01:6.1f}  [{(t0[i] - k0) * 0.01:6.1f}, {(t1[i] - k0) * 0.01:6.1f}]")
+    print(f"   {i:5d} n={n[i]:6d} w={nw[i]:3d} b={nb[i]:3d} {dur[i]:7.1f} cull {cull[i] * 0.01:6.1f}  [{(t0[i] - k0) * 0.01:6.1f}, {(t1[i] - k0) * 0.01:6.1f}] live {livepx[i]}")
+m = live & (nb >= 3)
+print(f"tiles with >= 3 batches: {int(m.sum())}; of those never saturated (live pixels at the end): {int((m & (livepx > 0)).sum())}; "
+      f"live-pixel histogram of those: {np.percentile(livepx[m & (livepx > 0)], [10, 50, 90]).tolist() if (m & (livepx > 0)).any() else []}")
 late = np.argsort(-t1)[:8]
 print("last to finish:", [(int(i), int(n[i]), round(float((t0[i] - k0) * 0.01), 1), round(float((t1[i] - k0) * 0.01), 1)) for i in late])
-cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | (((hw >> 16) & 0xf) << 7)     # cu_id | se_id | xcc? (HW_ID layout: best effort)
 starts = np.sort((t0[live] - k0) * 0.01)
 print("tile start times (us) percentiles 50/90/99/max:", [round(float(np.percentile(starts, p)), 1) for p in (50, 90, 99, 100)])
