@@ -121,9 +121,9 @@ def parse_args():
                          "workspaces; the per-view gradients are folded on a communication stream)")
     ap.add_argument("--reduce-chunks", type=int, default=4,
                     help="pieces the last view's fold + all-reduce is pipelined in (sings_amd.dp.GradientPipeline)")
-    ap.add_argument("--per-view-rows", action="store_true",
-                    help="round-2 gradient scheme for comparison: every view of a step writes its own gradient row and a fold pass "
-                         "sums the rows after the join (default: the views add to ONE buffer in a fixed, event-ordered chain)")
+    ap.add_argument("--gradient-rows", choices=("streams", "views", "one"), default="streams",
+                    help="where the views of a step are summed: one gradient row per stream (default: later views of a stream add to "
+                         "their stream's row, the fold reads `streams` rows), one per view (round 2), or one buffer for all")
     ap.add_argument("--one-shot-reduce", action="store_true",
                     help="pre-round-2 schedule for comparison: fold all rows after the last view, then ONE all-reduce")
     ap.add_argument("--regularisers", action="store_true",
@@ -356,20 +356,21 @@ def main_raster(a):
     # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on different
     # streams share no state) writing its gradients into its own row of `grads`; ViewBatch deals them to the streams and
     # folds the rows (+ all-reduce) on a communication stream
-    # round 3: ONE gradient buffer for the step -- view 0 writes it, the others add to it in the fixed order 0, 1, .. (events
-    # order only their last, per-Gaussian kernels): no K rows, no fold pass after the join.  --per-view-rows: the round-2 scheme.
-    rows = k_views if a.per_view_rows else 1
+    # round 3: one gradient row per STREAM -- the first view of a stream writes it, the later ones add to it (accumulate mode of
+    # the per-Gaussian backward), so the fold after the join reads `streams` rows, not `views` rows.  --gradient-rows views: the
+    # round-2 scheme; one: a single buffer, the views' last kernels ordered across the streams by events.
+    rows = {"streams": n_streams, "views": k_views, "one": 1}[a.gradient_rows]
     grads = ViewBatch.gradient_rows(rows, per_view, dev)
     engs = []
     for v in range(k_views):
-        e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v if a.per_view_rows else 0])
+        e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
         # the sizing pass knows the longest tile list (135 at cfg3): with 1.5x margin for the other cameras of the batch no
         # list can need the long-list sort kernels (lists <= 1024 are sorted by the compositing workgroups; checked on the device, a
         # violation surfaces in num_rendered() below)
         e.set_camera(camera(rank * k_views + v)[3], short_lists=tile_max * 1.5 <= 1024)
         engs.append(e)
     eng = engs[0]
-    batch = ViewBatch(engs, grads if a.per_view_rows else grads[0], n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
+    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
 
     graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
 
@@ -497,7 +498,7 @@ def main_raster(a):
                    "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams, "regularisers": bool(a.regularisers),
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
                    "reduction": "one_shot" if a.one_shot_reduce or graph is not None else
-                                ("views add to one buffer (chained)" if batch.chain else "fold of per-view rows") + f" + collective in {len(batch.pipe.bounds)} chunk(s)",
+                                f"fold of {rows} gradient row(s) for {k_views} views + collective in {len(batch.pipe.bounds)} chunk(s)",
                    "gradient_rows": rows,
                    "parallelism": f"dp{world}"},
         "roofline": roofline, "roofline_hbm": hbm,
@@ -968,11 +969,11 @@ def main_avatar(a):
     per_view = N * (3 + 3 + 1 + 3 * sh.shape[1])
     from sings_amd.engine import ViewBatch
     from sings_amd.photo_loss import PhotoLossEngine
-    rows = k_views if a.per_view_rows else 1
+    rows = {"streams": n_streams, "views": k_views, "one": 1}[a.gradient_rows]
     grads = ViewBatch.gradient_rows(rows, per_view, dev)
     engs, losses = [], []
     for v in range(k_views):
-        e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v if a.per_view_rows else 0])
+        e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
         e.set_camera(rs)
         engs.append(e)
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
@@ -980,7 +981,7 @@ def main_avatar(a):
     shard = FrameSharder(F, world, rank, seed=0)
     fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
                         force=FORCE_DIST) if dist is not None else None)
-    batch = ViewBatch(engs, grads if a.per_view_rows else grads[0], n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
+    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
     # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
     torch.manual_seed(0)                                             # (the target image: the same in every process)

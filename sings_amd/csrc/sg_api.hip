@@ -59,7 +59,6 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_ck_start = o; o = sg_align(o + T * 4);
     L->bin_plan = o; o = sg_align(o + T * 16);
     L->bin_pair_mask = o; o = sg_align(o + cap + 1);
-    L->bin_order = o; o = sg_align(o + T * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);

@@ -146,6 +146,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
         header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
         header[5] = carry[1] < items_cap ? carry[1] : items_cap;
         header[6] = carry[4] < rank_cap ? carry[4] : rank_cap;
+        header[7] = 0u;
     }
 }
 
@@ -191,14 +192,11 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal, uint32_t *__restrict__ order)
+                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
     __shared__ uint32_t wsum[NQ][SG_SS_THREADS / 64];
-    __shared__ uint32_t sCls[2][SG_ORDER_CLASSES];           // tiles per work class / cursors (the workgroup that writes `order`)
-    const bool orders = order != nullptr && blockIdx.x == gridDim.x - 1;
-    if (orders && threadIdx.x < SG_ORDER_CLASSES) sCls[0][threadIdx.x] = 0u;
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[t];
     __syncthreads();
@@ -211,7 +209,6 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
         sg_scan_derive(sStart[t], q);
 #pragma unroll
         for (int a = 0; a < NQ; a++) own[a] += q[a];
-        if (orders) atomicAdd(&sCls[0][sg_order_class(sStart[t])], 1u);
     }
     uint32_t incl[NQ];
 #pragma unroll
@@ -251,23 +248,11 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
             run[a] = woff + incl[a] - own[a];
         }
     }
-    // The forward composite's schedule (sg_render.hip::sg_tile_of_rank): tiles by descending work class.  One wave scans the
-    // class counts (the barriers above separate it from the counting), every thread then drops its tiles into their class --
-    // the order inside a class is whatever the LDS atomics make it: it moves tiles between CUs, never changes a result.
-    if (orders && tid < 64) {
-        const uint32_t c = tid < SG_ORDER_CLASSES ? sCls[0][tid] : 0u;
-        uint32_t inc = c;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(inc, o, 64); if (lane >= o) inc += u; }
-        if (tid < SG_ORDER_CLASSES) sCls[1][tid] = inc - c;
-    }
-    if (orders) __syncthreads();
     const bool writer = (uint32_t)tid % gridDim.x == blockIdx.x;
     for (int t = t0; t < t1; t++) {
         const uint32_t v = sStart[t];
         uint32_t q[NQ];
         sg_scan_derive(v, q);
-        if (orders) order[atomicAdd(&sCls[1][sg_order_class(v)], 1u)] = (uint32_t)t;
         if (writer) {
             const uint32_t s = run[0] < cap ? run[0] : cap, e = run[0] + v < cap ? run[0] + v : cap;
             ranges[t] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
@@ -293,6 +278,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
         header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
         header[5] = tot[1] < items_cap ? tot[1] : items_cap;
         header[6] = tot[4] < rank_cap ? tot[4] : rank_cap;
+        header[7] = 0u;                                   // groups the partition kernel hands to the group kernel
     }
     __syncthreads();
     const uint32_t R = tot[0] < cap ? tot[0] : cap;
@@ -335,7 +321,6 @@ struct SgPartLds {
     uint2 bigs[SG_PT_BIGS];            // (start, length) of the buckets of the current pass that hold more than 1024 keys
     uint2 bigs0[SG_PT_BIGS];           // the level-0 list, kept while the level-1 passes reuse the tables above
     uint32_t nbig;                     // entries of bigs[] (counts on past SG_PT_BIGS)
-    uint64_t tile[SG_PT_NB];           // counting fallback: one slab of keys
     uint32_t gslot;                    // next group slot of this tile
 };
 
@@ -431,8 +416,83 @@ __device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__r
     __syncthreads();
 }
 
+// A whole list in LDS: keys in[0, n) (n <= SG_PT_U * 1024) -> partitioned into sKeys by the same 1024-bucket split as above, then
+// every key counts the smaller keys of its own bucket: final position = bucket start + that count (keys are unique).  Cost: the
+// sum over the buckets of (keys in it)^2 LDS reads -- a dozen reads per key on a depth-spread list; a bucket of more than
+// SG_PT_DENSE keys (a cluster next to an outlier) makes the caller take the multi-level path instead (returns false, nothing
+// written).  Workgroup-uniform; contains barriers.
+#define SG_PT_U 16
+#define SG_PT_DENSE 2048
+__device__ bool sg_sort_resident(const uint64_t *__restrict__ in, uint32_t n, uint32_t abs0, uint32_t tile, SgPartLds &L,
+                                 uint64_t *__restrict__ sKeys, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
+                                 int tid)
+{
+    constexpr int U = SG_PT_U;
+    constexpr uint64_t NONE = ~0ull;
+    const int lane = tid & 63, wid = tid >> 6;
+    uint64_t kr[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) { const uint32_t i = (uint32_t)u * SG_PT_THREADS + tid; kr[u] = i < n ? in[i] : NONE; }
+    uint64_t kmin = NONE, kmax = 0ull;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kr[u] != NONE) { kmin = kr[u] < kmin ? kr[u] : kmin; kmax = kr[u] > kmax ? kr[u] : kmax; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint64_t a = sg_shfl_xor_u64(kmin, o), b = sg_shfl_xor_u64(kmax, o);
+        kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { L.wmin[wid] = kmin; L.wmax[wid] = kmax; }
+    L.cur[tid] = 0u;
+    if (tid == 0) L.nbig = 0u;
+    __syncthreads();
+#pragma unroll 1
+    for (int w = 0; w < SG_PT_THREADS / 64; w++) { const uint64_t a = L.wmin[w], b = L.wmax[w]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
+    const uint64_t span = kmax - kmin;
+    const int bits = span ? 64 - __builtin_clzll(span) : 0;
+    const int shift = bits > 10 ? bits - 10 : 0;
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kr[u] != NONE) atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u);
+    __syncthreads();
+    const uint32_t cnt = L.cur[tid];
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) L.wtot[wid] = incl;
+    if (cnt > SG_PT_DENSE) atomicAdd(&L.nbig, 1u);
+    __syncthreads();
+    if (L.nbig) { __syncthreads(); return false; }                     // (uniform; the barrier keeps nbig intact until everybody has read it)
+    uint32_t woff = 0;
+#pragma unroll 1
+    for (int w = 0; w < wid; w++) woff += L.wtot[w];
+    const uint32_t excl = woff + incl - cnt;
+    L.off[tid] = excl;
+    if (tid == SG_PT_THREADS - 1) L.off[SG_PT_NB] = excl + cnt;
+    __syncthreads();
+    L.cur[tid] = excl;
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < U; u++)
+        if (kr[u] != NONE) sKeys[atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u)] = kr[u];
+    __syncthreads();
+#pragma unroll 1
+    for (int u = 0; u < U; u++) {
+        const uint64_t key = kr[u];
+        if (key == NONE) continue;
+        const uint32_t b = (uint32_t)((key - kmin) >> shift);
+        const uint32_t s0 = L.off[b], e0 = L.off[b + 1];
+        uint32_t rank = 0;
+        for (uint32_t j = s0; j < e0; j++) rank += sKeys[j] < key;
+        point_list[abs0 + s0 + rank] = (uint32_t)key;
+        if (point_keys) point_keys[abs0 + s0 + rank] = ((uint64_t)tile << 32) | (key >> 32);
+    }
+    __syncthreads();
+    return true;
+}
+
 // keys buf[0, m) (unsorted) -> point_list / point_keys [abs0, abs0 + m) in ascending order, by counting: O(m^2 / 1024) per thread
-__device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint32_t abs0, uint32_t tile, SgPartLds &L,
+__device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint32_t abs0, uint32_t tile, uint64_t *__restrict__ slab,
                               uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys, int tid)
 {
     for (uint32_t i0 = 0; i0 < m; i0 += SG_PT_THREADS) {
@@ -441,10 +501,10 @@ __device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint
         uint32_t rank = 0;
         for (uint32_t t0 = 0; t0 < m; t0 += SG_PT_NB) {
             __syncthreads();
-            L.tile[tid] = t0 + tid < m ? buf[t0 + tid] : ~0ull;
+            slab[tid] = t0 + tid < m ? buf[t0 + tid] : ~0ull;
             __syncthreads();
             const uint32_t tn = m - t0 < SG_PT_NB ? m - t0 : SG_PT_NB;
-            for (uint32_t j = 0; j < tn; j++) rank += L.tile[j] < key;
+            for (uint32_t j = 0; j < tn; j++) rank += slab[j] < key;
         }
         if (i < m) {
             point_list[abs0 + rank] = (uint32_t)key;
@@ -455,11 +515,13 @@ __device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint
 }
 
 __global__ void __launch_bounds__(SG_PT_THREADS)
-sg_tile_partition_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ part_items, const uint2 *__restrict__ ranges,
+sg_tile_partition_kernel(uint32_t *header, const uint2 *__restrict__ part_items, const uint2 *__restrict__ ranges,
                          uint64_t *__restrict__ pair_keys, uint64_t *__restrict__ scratch, uint2 *__restrict__ groups,
-                         uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+                         uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
+                         uint32_t resident_max)
 {
     __shared__ SgPartLds L;
+    extern __shared__ uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
     const int tid = threadIdx.x;
     const uint32_t nitems = header[1] ? 0u : header[4];
     for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
@@ -472,6 +534,12 @@ sg_tile_partition_kernel(const uint32_t *__restrict__ header, const uint2 *__res
         __syncthreads();
         if (tid == 0) L.gslot = g0;
         __syncthreads();
+        // Lists that fit the workgroup's LDS (every list of an avatar frame): sorted right here -- partition into LDS, then every
+        // key counts the smaller keys of ITS bucket (a dozen on average): no second kernel, no trip through memory.
+        if (n <= resident_max && sg_sort_resident(pair_keys + r.x, n, r.x, tile, L, sKeys, point_list, point_keys, tid)) {
+            for (uint32_t g = g0 + tid; g < gend; g += SG_PT_THREADS) groups[g] = make_uint2(0u, 0u);
+            continue;
+        }
         // level 0: pair_keys -> scratch
         sg_partition_pass(pair_keys + r.x, scratch + r.x, n, r.x, 0u, tile, L, groups, gend, tid);
         const uint32_t nb0 = L.nbig;
@@ -488,12 +556,12 @@ sg_tile_partition_kernel(const uint32_t *__restrict__ header, const uint2 *__res
                 if (nb1 > SG_PT_BIGS) {
                     // more big sub-buckets than the list holds: order the whole bucket by counting (its groups, emitted above, then
                     // re-sort parts of it into the same places: harmless)
-                    sg_count_sort(pair_keys + r.x + s0, m, r.x + s0, tile, L, point_list, point_keys, tid);
+                    sg_count_sort(pair_keys + r.x + s0, m, r.x + s0, tile, sKeys, point_list, point_keys, tid);
                 } else {
                     for (uint32_t q = 0; q < nb1; q++) {
                         const uint32_t s1 = L.bigs[q].x, m1 = L.bigs[q].y;
                         __syncthreads();
-                        sg_count_sort(pair_keys + r.x + s0 + s1, m1, r.x + s0 + s1, tile, L, point_list, point_keys, tid);
+                        sg_count_sort(pair_keys + r.x + s0 + s1, m1, r.x + s0 + s1, tile, sKeys, point_list, point_keys, tid);
                     }
                 }
             }
@@ -504,12 +572,13 @@ sg_tile_partition_kernel(const uint32_t *__restrict__ header, const uint2 *__res
                 __syncthreads();
                 for (uint32_t i = tid; i < n; i += SG_PT_THREADS) pair_keys[r.x + i] = scratch[r.x + i];
                 __syncthreads();
-                sg_count_sort(pair_keys + r.x, n, r.x, tile, L, point_list, point_keys, tid);
+                sg_count_sort(pair_keys + r.x, n, r.x, tile, sKeys, point_list, point_keys, tid);
             }
         }
         __syncthreads();
         // unused reserved slots: length 0
         for (uint32_t g = L.gslot + tid; g < gend; g += SG_PT_THREADS) groups[g] = make_uint2(0u, 0u);
+        if (tid == 0 && L.gslot > g0) atomicAdd(&header[7], L.gslot - g0);     // the group kernel has work
     }
 }
 
@@ -520,7 +589,7 @@ sg_group_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restric
 {
     __shared__ uint64_t s[SG_WSORT_MAX + SG_RANKSORT_MAX];
     const int tid = threadIdx.x;
-    const uint32_t nslots = header[1] ? 0u : header[6];
+    const uint32_t nslots = header[1] || header[7] == 0u ? 0u : header[6];    // (header[7]: groups emitted; 0 = every list was sorted in LDS)
     for (uint32_t gi = blockIdx.x; gi < nslots; gi += gridDim.x) {
         const uint2 g = groups[gi];
         const uint32_t len = g.y & 0x7ffu, tile = g.y >> 11;
@@ -560,7 +629,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, short_lists, c.count_signal, sg_tile_order_used(T) ? b.order : (uint32_t *)nullptr);
+                           b.rank_items, b.items, short_lists, c.count_signal);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -582,8 +651,14 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     if (short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
     const uint32_t pgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;
-    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), 0, st, b.header, b.sort_items, b.ranges,
-                       b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk);
+    // 128 KiB of dynamic LDS: a list of up to 16 384 keys is sorted inside the workgroup.  If the runtime refuses the limit (asked
+    // for per launch: per device, no process-wide flag) only the counting slab is allocated and every list takes the multi-level path.
+    uint32_t resident = SG_PT_U * SG_PT_THREADS;
+    if (hipFuncSetAttribute((const void *)sg_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(resident * 8)) != hipSuccess) { (void)hipGetLastError(); resident = SG_PT_NB; }
+    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), (size_t)resident * 8, st, b.header, b.sort_items,
+                       b.ranges, b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
+                       resident > SG_PT_NB ? resident : 0u);
     const uint32_t ggrid = sg_rank_items_cap(cap) < 4096 ? sg_rank_items_cap(cap) : 4096;
     hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
                        b.point_list, pk);

@@ -38,13 +38,6 @@ __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (ca
 // preprocess + 22 us of scan on the avatar frame; the histogram: 43 + 7 us.)
 #define SG_HIST_TILES_MAX 4096
 static inline bool sg_lds_hist(size_t T) { return T <= SG_HIST_TILES_MAX; }
-// The same regime (few tiles, lists of very different lengths: an avatar in front of a background) is where the forward
-// composite's static tile -> CU map leaves CUs idle: there the scan also orders the tiles by work class (list length in steps
-// of 32 entries, saturating at 1536: longer lists end early, their pixels saturate) and the composite deals them out heaviest
-// first, snaking over the CUs (sg_render.hip::sg_tile_of_rank).
-#define SG_ORDER_CLASSES 49
-__host__ __device__ inline uint32_t sg_order_class(uint32_t n) { return (SG_ORDER_CLASSES - 1) - ((n < 1536u ? n : 1536u) >> 5); }   // 0 = heaviest
-static inline bool sg_tile_order_used(size_t T) { return T <= SG_HIST_TILES_MAX; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
@@ -71,7 +64,6 @@ struct SgBin {
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
     uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)
     uint8_t *pair_mask;    // [cap] per sorted list entry: quadrants the forward composited it in (0 if it never staged it)
-    uint32_t *order;       // [T] tiles by descending list length (classes of 32 entries): the forward composite's schedule
 };
 
 struct SgImg {
@@ -116,7 +108,6 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.sort_items = (uint2 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
-    g.order = (uint32_t *)(b + L.bin_order);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)

@@ -24,34 +24,10 @@
 //    (memory-side atomics cap at ~1.3 TB/s on MI355X and scattered single-row adds are 17x slower);
 //    gradients are bitwise reproducible.
 #include "sg_sort.h"
-#include <stdlib.h>
 
 #define SG_FB 256         // forward: list entries staged per batch (one per thread)
 #define SG_BB 64         // backward: entries per batch (bounded by the LDS of the quadrant-sum buffer)
 #define SG_UNSET 0xffffffffu   // bit pattern (a NaN) of a quadrant-sum slot nobody wrote
-
-#ifdef SG_TILE_CLOCK
-// Measurement build only (tools/tile_clock.py; never the product): per-tile wall clock (100 MHz) of the forward composite.
-__device__ unsigned long long sg_tile_clock[1 << 16][4];
-extern "C" int sg_debug_tile_clock(void *dst, int ntiles)
-{
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sg_tile_clock), (size_t)ntiles * 32, 0, hipMemcpyDeviceToHost);
-}
-#define SG_CLK_DECL unsigned long long clk0 = wall_clock64(); unsigned clk_w = 0, clk_b = 0; unsigned long long clk_cull = 0, clk_t = 0;
-#define SG_CLK_WINDOW clk_w++; clk_t = wall_clock64();
-#define SG_CLK_CULLED clk_cull += wall_clock64() - clk_t;
-#define SG_CLK_BATCH clk_b++;
-#define SG_CLK_END __shared__ unsigned clk_lv[4]; { const unsigned long long lv = __ballot(!done); if (lane == 0) clk_lv[wave] = (unsigned)__popcll(lv); } __syncthreads(); \
-                   const unsigned clk_live = clk_lv[0] + clk_lv[1] + clk_lv[2] + clk_lv[3]; if (tid == 0 && tile < (1 << 16)) { sg_tile_clock[tile][0] = clk0; sg_tile_clock[tile][1] = wall_clock64(); \
-                                                      sg_tile_clock[tile][2] = (unsigned long long)(unsigned)n | ((unsigned long long)clk_w << 32) | ((unsigned long long)clk_b << 48); \
-                                                      sg_tile_clock[tile][3] = clk_cull | ((unsigned long long)clk_live << 40); }
-#else
-#define SG_CLK_DECL
-#define SG_CLK_WINDOW
-#define SG_CLK_CULLED
-#define SG_CLK_BATCH
-#define SG_CLK_END
-#endif
 
 __device__ __forceinline__ float sg_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 // The composite loops evaluate alpha = min(.99, o 2^p) with p = log2(e) * power: the staging thread scales the conic ONCE per
@@ -80,19 +56,6 @@ __device__ __forceinline__ int sg_tile_of_block(int block)
     // bound by its longest tile (39 serial batches), not by this; see DESIGN.md.
     const int within = (slot + 7 * (slot >> 5)) & (SG_XCD_RUN - 1);
     return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + within;
-}
-
-// Few tiles with very different list lengths (an avatar: T <= 4096, sg_tile_order_used): the static map above leaves the CUs
-// that own background columns idle while the ones under the body composite 5-7 long lists each (per-tile clocks, tools/
-// tile_clock.py: every workgroup of the frame is resident from the first microsecond, the heaviest tile sets the kernel time and
-// the mean CU has 1/1.6 of the heaviest CU's work).  `order` lists the tiles by descending work class (written by the scan);
-// a CU receives blocks j, j + 256, j + 512, ... (j = block mod 256), so round k hands ranks 256 k .. 256 k + 255 to the CUs,
-// alternately ascending and descending: every CU gets one tile of every weight class, heavy next to light.
-__device__ __forceinline__ int sg_tile_of_rank(int block, const uint32_t *__restrict__ order, int T)
-{
-    const int k = block >> 8, j = block & 255;
-    const int r = 256 * k + ((k & 1) ? 255 - j : j);
-    return r < T ? (int)order[r] : T;
 }
 
 // Which 8x8 quadrants of the tile at (X0,Y0) can this entry reach with alpha >= 1/255?
@@ -188,17 +151,16 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const float *__restrict__ bg, float *__restrict__ out_color,
                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,
-                     const uint32_t *__restrict__ order)
+                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
 {
     __shared__ float4 sR[SG_FB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
     __shared__ float4 sBox[4];
-    const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
+    (void)nblocks;
+    const int tile = sg_tile_of_block(blockIdx.x);
     if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    SG_CLK_DECL
     // The counters the NEXT forward's preprocess counts into are consumed by now (the scan ran before this kernel): leave
     // them zeroed, so that a caller who keeps its workspace can skip the zeroing launch (SG_FLAG_WS_CLEAN).
     if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }
@@ -210,7 +172,6 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     // R > capacity: part of the sorted list was never written (the caller re-runs with a larger workspace) --
     // render the background instead of gathering through stale ids
     const int n = header[1] ? 0 : (int)(range.y - range.x);
-    if (nblocks & (1 << 24)) { if (n > 1024) __builtin_amdgcn_s_setprio(3); else if (n > 512) __builtin_amdgcn_s_setprio(2); else if (n > 256) __builtin_amdgcn_s_setprio(1); }
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -244,7 +205,6 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             if (lane == 0) sBox[wave] = bx;
         }
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
-        SG_CLK_BATCH
         const int e = base + tid;
         if (e < n) {
             sR[tid][0] = make_float4(pa.x, pa.y, SG_KA * pa.z, SG_KB * pa.w);
@@ -297,251 +257,6 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         out_color[hw + pid] = fmaf(Tr, bg[1], C1);
         out_color[2 * hw + pid] = fmaf(Tr, bg[2], C2);
     }
-    SG_CLK_END
-}
-
-// ------------------------------------------------------------------------------------------
-// Forward composite for lists of ANY length (round 3): cull wide, composite dense.
-//
-// The kernel above walks a list in 256-entry batches, and every batch is a dependent chain -- ids -> three record gathers ->
-// rectangle tests -> barrier -> compaction -> loop -- of ~2.4 us whatever survives the tests.  On an avatar frame (few tiles,
-// lists of 10^3..10^4 entries) that chain, not arithmetic, bounds the kernel: a silhouette tile whose background pixels never
-// saturate walks 39 batches of which almost every entry is culled (hidden behind saturated pixels).  Here a list is taken in
-// WINDOWS of 1024 entries:
-//   cull    : every thread tests FOUR entries (ids of the next window already in flight, the eight record gathers of a window
-//             issued together) against the quadrants' live boxes; the survivors are ranked in list order by ballots and one
-//             16-word exchange through LDS, and only (id, position) of a survivor is kept;
-//   stage   : batches of up to 256 SURVIVORS -- a window of a saturated silhouette tile has a handful, a dense window four
-//             batches as before -- gathered again (L2-hot), re-tested against the boxes of that moment, composited by the loop of
-//             the kernel above.
-// The backward pass is unchanged and needs the per-pixel state at every 256th list position (segment checkpoints): a wave stores
-// it when its walk through the compacted list crosses that position -- the survivors of a batch are in list order, so the crossing
-// points are ballot counts (sg_compact_quadrant_b) -- and n_contrib / pair_mask stay in list positions.
-// Lists of <= 1024 entries are sorted by this workgroup first (sg_sort.h), longer ones arrive sorted (bucket sort, sg_binning.hip).
-#define SG_FW 1024
-
-
-template <int MUL>
-__device__ __forceinline__ int sg_compact_quadrant_b(const uint32_t *__restrict__ sM, int cnt, int w, int lane,
-                                                     unsigned long long lt, uint16_t *__restrict__ list, int batch,
-                                                     const int thr[3], int nlb[3])
-{
-    int nl = 0;
-    nlb[0] = nlb[1] = nlb[2] = 0;
-    for (int c = 0; c < batch; c += 64) {
-        const int idx = c + lane;
-        const bool bit = idx < cnt && ((sM[idx] >> w) & 1u);
-        const unsigned long long bal = __ballot(bit);
-        if (bit) list[nl + __popcll(bal & lt)] = (uint16_t)(idx * MUL);
-        nl += __popcll(bal);
-#pragma unroll
-        for (int j = 0; j < 3; j++) {                       // entries of this quadrant in front of staged index thr[j] (scalar)
-            const int t = thr[j] - c;
-            const unsigned long long m = t >= 64 ? ~0ull : (t <= 0 ? 0ull : (1ull << t) - 1ull);
-            nlb[j] += __popcll(bal & m);
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    return nl;
-}
-
-__global__ void __launch_bounds__(256)
-sg_render_fwd_any_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
-                         const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
-                         uint64_t *__restrict__ point_keys, const float4 *__restrict__ recA,
-                         const float4 *__restrict__ recB, const float4 *__restrict__ recC,
-                         const float *__restrict__ bg, float *__restrict__ out_color,
-                         float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                         const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                         uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,
-                         const uint32_t *__restrict__ order)
-{
-    __shared__ float4 sR[SG_FB][3];            // staged survivor: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
-    __shared__ uint32_t sM[SG_FB];
-    __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
-    __shared__ float4 sBox[4];
-    __shared__ uint32_t sCand[SG_FW];          // survivors of the window in list order: Gaussian id
-    __shared__ uint16_t sIdx[SG_FW];           //                                        position inside the window
-    __shared__ uint32_t sCnt[4][4];            // survivors per (quarter of the window, wave)
-    const int tile = order ? sg_tile_of_rank(blockIdx.x, order, T) : sg_tile_of_block(blockIdx.x);
-    if (tile >= T) return;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    SG_CLK_DECL
-    if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }     // (see sg_render_fwd_kernel)
-    const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
-    const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    const int n = header[1] ? 0 : (int)(range.y - range.x);
-    if (nblocks & (1 << 24)) { if (n > 1024) __builtin_amdgcn_s_setprio(3); else if (n > 512) __builtin_amdgcn_s_setprio(2); else if (n > 256) __builtin_amdgcn_s_setprio(1); }
-    const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;
-    float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
-    uint32_t last = 0;
-    bool done = !inside;
-    const unsigned long long lt = (1ull << lane) - 1ull;
-    static_assert((SG_WSORT_MAX + SG_RANKSORT_MAX) * 8 <= SG_FB * 48, "sort buffers alias sR");
-    static_assert(SG_WSORT_MAX <= SG_FW, "a list this workgroup sorts is one window");
-    uint32_t gid[4];                           // this thread's entries of the current window: list positions base + 256 u + tid
-    const bool own_sort = n > 0 && n <= SG_WSORT_MAX;
-    if (own_sort) {
-        uint64_t *sKey = (uint64_t *)sR;                    // aliases the staging buffer: consumed before the first batch is staged
-        sg_sort_short_list(pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int e = 256 * u + tid;
-            gid[u] = 0xffffffffu;
-            if (e < n) {
-                const uint64_t key = sKey[e];
-                gid[u] = (uint32_t)key;
-                point_list[range.x + e] = gid[u];           // the order, for the backward pass
-                if (point_keys) point_keys[range.x + e] = ((uint64_t)tile << 32) | (key >> 32);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int u = 0; u < 4; u++) { const int e = 256 * u + tid; gid[u] = e < n ? point_list[range.x + e] : 0xffffffffu; }
-    }
-    const float X0f = (float)X0, Y0f = (float)Y0;
-    bool all_done = false;
-    for (int base = 0; base < n && !all_done; base += SG_FW) {
-        {
-            const float4 bx = sg_live_box(__ballot(!done), wave);
-            if (lane == 0) sBox[wave] = bx;
-        }
-        if (__syncthreads_count(done) == 256) break;       // also: the previous window is fully consumed
-        SG_CLK_WINDOW
-        // ---- cull: four entries per thread against the live boxes, two at a time: the gathers of a pair go out together and the
-        // tests run one after the other (sched_barrier) -- all four at once need 95 registers (five waves per SIMD), pairs 79 (six)
-        uint32_t sv = 0;
-#pragma unroll
-        for (int h = 0; h < 4; h += 2) {
-            float4 a[2];
-            float2 b[2];
-#pragma unroll
-            for (int u = 0; u < 2; u++)
-                if (gid[h + u] != 0xffffffffu) { a[u] = recA[gid[h + u]]; b[u] = *(const float2 *)&recB[gid[h + u]]; }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                if (gid[h + u] != 0xffffffffu) {
-                    if (sg_quad_mask(a[u], make_float4(b[u].x, b[u].y, 0.0f, 0.0f), X0f, Y0f, sBox)) sv |= 1u << (h + u);
-                    else pair_mask[range.x + base + 256 * (h + u) + tid] = 0;        // never staged: carries no gradient
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        uint32_t pre[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const unsigned long long bal = __ballot((sv >> u) & 1u);
-            pre[u] = (uint32_t)__popcll(bal & lt);
-            if (lane == 0) sCnt[u][wave] = (uint32_t)__popcll(bal);
-        }
-        __syncthreads();
-        int bnd[5];                                         // survivor rank at which quarter u of the window starts; bnd[4]: survivors
-        {
-            uint32_t run = 0;
-#pragma unroll
-            for (int u = 0; u < 4; u++) {
-                // (wave-uniform values read from LDS: kept in scalar registers)
-                const uint32_t c0 = __builtin_amdgcn_readfirstlane(sCnt[u][0]), c1 = __builtin_amdgcn_readfirstlane(sCnt[u][1]),
-                               c2 = __builtin_amdgcn_readfirstlane(sCnt[u][2]), c3 = __builtin_amdgcn_readfirstlane(sCnt[u][3]);
-                bnd[u] = (int)run;
-                if ((sv >> u) & 1u) {
-                    const uint32_t r = run + (wave > 0 ? c0 : 0u) + (wave > 1 ? c1 : 0u) + (wave > 2 ? c2 : 0u) + pre[u];
-                    sCand[r] = gid[u];
-                    sIdx[r] = (uint16_t)(256 * u + tid);
-                }
-                run += c0 + c1 + c2 + c3;
-            }
-            bnd[4] = (int)run;
-        }
-        const int S = bnd[4];
-        SG_CLK_CULLED
-        // ids of the next window: in flight while this one is composited
-        if (base + SG_FW < n) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int e = base + SG_FW + 256 * u + tid; gid[u] = e < n ? point_list[range.x + e] : 0xffffffffu; }
-        }
-        // State in front of list position base + 256 j, for the backward pass of the segments behind it: stored when the walk gets
-        // there (rank bnd[j] of the window's survivors).  j = 0 of the first window is the initial state (not stored).
-        int jb = base == 0 ? 1 : 0;
-        auto checkpoint = [&](int j) {
-            const int p = base + 256 * j;
-            if (p < n && cks != 0xffffffffu && cks + (uint32_t)(p / SG_SEG) < ck_cap && __ballot(done) != ~0ull)
-                ckpt[(size_t)(cks + (uint32_t)(p / SG_SEG)) * 256 + tid] = make_float4(Tr, C0, C1, C2);
-        };
-        for (int r0 = 0; r0 < S; r0 += SG_FB) {
-            // ---- stage up to 256 survivors, re-tested against the boxes of this moment
-            {
-                const float4 bx = sg_live_box(__ballot(!done), wave);
-                if (lane == 0) sBox[wave] = bx;
-            }
-            if (__syncthreads_count(done) == 256) { all_done = true; break; }      // also: the previous batch is fully consumed
-            const int cnt = S - r0 < SG_FB ? S - r0 : SG_FB;
-            SG_CLK_BATCH
-            if (tid < cnt) {
-                const uint32_t g = sCand[r0 + tid];
-                const float4 pa = recA[g], pb = recB[g];
-                const float pc = recC[g].x;
-                sR[tid][0] = make_float4(pa.x, pa.y, SG_KA * pa.z, SG_KB * pa.w);
-                sR[tid][1] = make_float4(SG_KA * pb.x, pb.y, pb.z, pb.w);
-                sR[tid][2].x = pc;
-                const uint32_t mk = sg_quad_mask(pa, pb, X0f, Y0f, sBox);
-                sM[tid] = mk;
-                pair_mask[range.x + base + sIdx[r0 + tid]] = (uint8_t)mk;     // the backward composites exactly these (entry, quadrant) pairs
-            }
-            __syncthreads();
-            int jend = jb;                                   // checkpoints that fall inside this batch: jb .. jend - 1 (uniform)
-            while (jend <= 3 && bnd[jend] < r0 + cnt) jend++;
-            if (__ballot(done) != ~0ull) {                   // (a finished quadrant skips the batch; wave-uniform)
-                int thr[3], nlb[3];
-#pragma unroll
-                for (int j = 0; j < 3; j++) thr[j] = bnd[j + 1] - r0;
-                uint16_t *list = sList[wave];
-                const int nl = sg_compact_quadrant_b<48>(sM, cnt, wave, lane, lt, list, SG_FB, thr, nlb);
-                uint32_t lastk = 0xffffffffu;
-                int i = 0;
-                for (int j = jb; j <= jend; j++) {
-                    const int iend = j == jend ? nl : (j == 0 ? 0 : nlb[j - 1]);
-                    for (; i < iend; i++) {
-                        const uint32_t ko = list[i];
-                        const float4 *rec = (const float4 *)((const char *)&sR[0][0] + ko);
-                        const float4 ga = rec[0], gb = rec[1];
-                        const float gc = rec[2].x;
-                        const float dx = ga.x - pxf, dy = ga.y - pyf;
-                        const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);
-                        const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
-                        const float test_T = Tr * (1.0f - alpha);
-                        const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                        const bool term = valid & (test_T < 0.0001f);
-                        const bool blend = valid & !term;
-                        const float w = blend ? alpha * Tr : 0.0f;
-                        C0 = fmaf(gb.z, w, C0); C1 = fmaf(gb.w, w, C1); C2 = fmaf(gc, w, C2);
-                        Tr = blend ? test_T : Tr;
-                        lastk = blend ? ko : lastk;
-                        done = done | term;
-                    }
-                    if (j < jend) checkpoint(j);
-                }
-                if (lastk != 0xffffffffu) last = (uint32_t)base + (uint32_t)sIdx[r0 + (int)(lastk / 48u)] + 1u;
-            }
-            jb = jend;
-        }
-        if (!all_done)
-            for (; jb <= 3; jb++) checkpoint(jb);           // quarters behind the last survivor
-    }
-    if (cks < ck_cap) ckpt[(size_t)cks * 256 + tid] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
-    if (inside) {
-        const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
-        final_T[pid] = Tr;
-        n_contrib[pid] = last;
-        out_color[pid] = fmaf(Tr, bg[0], C0);
-        out_color[hw + pid] = fmaf(Tr, bg[1], C1);
-        out_color[2 * hw + pid] = fmaf(Tr, bg[2], C2);
-    }
-    SG_CLK_END
 }
 
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
@@ -551,28 +266,12 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
 {
     static_assert(SG_FB == SG_SEG, "forward batches are the checkpoint granularity");
     const int T = c.gx * c.gy;
-    int grid = sg_render_blocks(T);
+    const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    // A caller that vouches for short lists (SG_FLAG_SHORT_LISTS: a pre-sized engine that has seen the scene, e.g. cfg3 with a
-    // longest list of 135) gets the batch-walking kernel: 15 KiB of LDS, eight workgroups per CU.  Everybody else -- the drop-in
-    // wrapper, avatar frames -- gets the window kernel, which costs 22 KiB (seven per CU) and handles lists of any length.
-    const char *e_any = getenv("SG_FWD_ANY"), *e_lpt = getenv("SG_FWD_LPT");          // EXPERIMENT switches (removed once measured)
-    const bool any = e_any ? atoi(e_any) != 0 : !(c.flags & SG_FLAG_SHORT_LISTS);
-    const bool lpt = (e_lpt ? atoi(e_lpt) != 0 : true) && sg_tile_order_used((size_t)T);
-    const uint32_t *order = lpt ? b.order : (const uint32_t *)nullptr;
-    if (lpt) grid = ((T + 255) / 256) * 256;               // whole rounds of 256 ranks (sg_tile_of_rank snakes inside a round)
-    const char *e_prio = getenv("SG_FWD_PRIO");
-    const int kflags = (e_prio && atoi(e_prio)) ? (1 << 24) : 0;
-    if (!any)
-        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, kflags, b.ranges,
-                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
-                           c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);
-    else
-        hipLaunchKernelGGL(sg_render_fwd_any_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, kflags, b.ranges,
-                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
-                           c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count, order);
+    hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+                       b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
+                       c.bg, out_color, im.final_T, im.n_contrib,
+                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 

@@ -218,21 +218,24 @@ class ViewBatch:
     ``fn(v, engine)`` for every view on its stream and joins; nothing synchronises with the host.  (No further stream: the
     caller's + three rendering streams are the four hardware queues HIP schedules onto.)
 
-    Where the sum over the views is formed:
+    Where the sum over the views is formed (``grads`` is ``[rows, per_view]``; engine v is built on row ``v % rows``):
 
-    * ``chain`` (round 3, default when all engines were built on the SAME ``grad_flat``): the views share ONE gradient buffer.
-      The first view's per-Gaussian backward writes it, every later view's ADDS to it (``sg_*_backward_gaussians(accumulate=1)``)
-      and first waits for the event of the view in front of it -- only that last, short kernel is ordered, the composite kernels
-      still overlap freely -- so the sum is formed in the fixed order 0, 1, .., K-1 (bitwise reproducible) and is complete the
-      moment the last view's backward is: no fold pass after the join (round 2: K rows written, read again and summed,
-      ~95 us of serial tail at cfg3), one row of memory instead of K.
-    * rows (``grads`` is ``[views, per_view]``, one engine per row): the round-2 scheme, folded by ``GradientPipeline``.
+    * rows == streams (round 3, what bench.py uses): ONE gradient row per stream.  The first view of a stream WRITES the row,
+      the later views of that stream ADD to it (``sg_*_backward_gaussians(accumulate=1)``; stream order is the only ordering
+      needed), so after the join ``streams`` rows are folded instead of ``views`` rows: the serial tail of a cfg3 step of 8 views
+      on 3 streams reads 3 x 47 MB instead of 8 x 47 MB (the bytes of the other five rows are read by the accumulating kernels,
+      inside the overlapped part of the step).  Fixed assignment and order -> bitwise reproducible.
+    * rows == 1 with several streams: every view adds to the same buffer; an event per view orders the per-Gaussian halves of
+      consecutive views across the streams (no fold at all).  Measured slower than stream rows on the avatar step (the waits
+      couple the streams: 3 821 vs 3 940 frames/s) and on par at cfg3; kept for memory-constrained callers.
+    * rows == views: the round-2 scheme, every view writes its own row.
 
-    Either way a ``FrameParallel`` all-reduces the summed buffer over the ranks, chunk by chunk.
+    Either way a ``FrameParallel`` all-reduces the summed buffer over the ranks, chunk by chunk behind the fold
+    (sings_amd.dp.GradientPipeline).
 
-        acc = ViewBatch.gradient_rows(1, per_view_floats, device)[0]
-        engines = [RasterEngine(..., grad_flat=acc) for v in range(views)]            # or SkinnedEngine
-        batch = ViewBatch(engines, acc, streams=3, frame_parallel=FrameParallel())    # None on one GPU
+        grads = ViewBatch.gradient_rows(streams, per_view_floats, device)
+        engines = [RasterEngine(..., grad_flat=grads[v % streams]) for v in range(views)]     # or SkinnedEngine
+        batch = ViewBatch(engines, grads, streams=streams, frame_parallel=FrameParallel())     # None on one GPU
         acc = batch.run(lambda v, e: (e.forward(...), e.backward(...)))               # summed over views and ranks -> optimiser
     """
 
@@ -243,27 +246,32 @@ class ViewBatch:
     def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4):
         from .dp import GradientPipeline
         self.engines = list(engines)
-        self.chain = grads.dim() == 1 or (grads.shape[0] == 1 and len(self.engines) > 1)
-        if self.chain:
+        if grads.dim() == 1:
             grads = grads.view(1, -1)
-            if any(e.grad_flat.data_ptr() != grads.data_ptr() for e in self.engines):
-                raise ValueError("chained views: every engine must be built on the same grad_flat")
-        elif len(self.engines) != grads.shape[0]:
-            raise ValueError("one engine per gradient row")
+        self.rows = int(grads.shape[0])
+        self.n = max(1, min(int(streams), len(self.engines)))
+        if self.rows not in (1, self.n, len(self.engines)):
+            raise ValueError("gradient rows must be 1, the number of streams or the number of views")
+        for v, e in enumerate(self.engines):
+            if e.grad_flat.data_ptr() != grads[v % self.rows].data_ptr():
+                raise ValueError(f"engine {v} must be built on grad_flat = grads[{v % self.rows}]")
+        self.chain = self.rows == 1 and self.n > 1 and len(self.engines) > 1      # one shared buffer across streams: events
         self.grads = grads
         self.dev = grads.device
-        self.n = max(1, min(int(streams), len(self.engines)))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
-        # the sum (rows: folded; chain: already there) is all-reduced chunk by chunk on the caller's stream once the views have
-        # joined it: sings_amd.dp.GradientPipeline
+        # the rows are folded (one row: nothing to fold) and the sum is all-reduced chunk by chunk on the caller's stream once
+        # the views have joined it: sings_amd.dp.GradientPipeline
         self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
         self.acc = self.pipe.acc
         self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
 
     def _link(self, v, e):
+        # view v adds to its row iff an earlier view of the step wrote it; with one row across several streams the per-Gaussian
+        # half additionally waits for the view in front of it (events order only those last, short kernels)
         if self.chain:
-            # view v adds to the buffer after view v - 1 has (events order only the per-Gaussian halves)
-            e._chain = (v > 0, self._events[v - 1] if v > 0 and self.n > 1 else None, self._events[v] if self.n > 1 else None)
+            e._chain = (v > 0, self._events[v - 1] if v > 0 else None, self._events[v])
+        else:
+            e._chain = (v >= self.rows, None, None)
 
     def run_unreduced(self, fn):
         """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``."""

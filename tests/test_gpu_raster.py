@@ -616,14 +616,25 @@ def test_views_of_a_step_add_to_one_gradient_buffer_in_a_fixed_order():
     for n_streams in (1, 2, 3, 3):
         acc.fill_(float("nan"))
         batch = ViewBatch(shared, acc, streams=n_streams)
-        assert batch.chain
+        assert batch.chain == (n_streams > 1)
         out = batch.run(lambda v, e: (e.forward(*ins), e.backward(*ins, dL)))
         torch.cuda.synchronize()
         assert out.data_ptr() == acc.data_ptr() and torch.equal(acc, want), n_streams
         for e, m in zip(shared, m2d):
             assert torch.equal(e.d_means2D, m)
     with pytest.raises(ValueError):
-        ViewBatch(per_view, acc, streams=2)                          # chained views must share the buffer
+        ViewBatch(per_view, acc, streams=2)                          # views of one row must share the buffer
+    # one row per STREAM (bench.py's default): views 0, 2 -> row 0, views 1, 3 -> row 1, each row in view order, then the fold
+    two = torch.full((2, per), float("nan"), device=dev)
+    by_stream = engines([two[v % 2] for v in range(K)])
+    for rep in range(2):
+        two.fill_(float("nan"))
+        batch = ViewBatch(by_stream, two, streams=2)
+        assert not batch.chain and batch.rows == 2
+        out = batch.run(lambda v, e: (e.forward(*ins), e.backward(*ins, dL)))
+        torch.cuda.synchronize()
+        assert torch.equal(two[0], rows[0] + rows[2]) and torch.equal(two[1], rows[1] + rows[3])
+        assert torch.equal(out, torch.sum(two, dim=0))
 
 
 def test_against_frozen_oracle_vectors():
