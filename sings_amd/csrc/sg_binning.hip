@@ -416,23 +416,29 @@ __device__ void sg_partition_pass(const uint64_t *__restrict__ in, uint64_t *__r
     __syncthreads();
 }
 
-// A whole list in LDS: keys in[0, n) (n <= SG_PT_U * 1024) -> partitioned into sKeys by the same 1024-bucket split as above, then
-// every key counts the smaller keys of its own bucket: final position = bucket start + that count (keys are unique).  Cost: the
-// sum over the buckets of (keys in it)^2 LDS reads -- a dozen reads per key on a depth-spread list; a bucket of more than
-// SG_PT_DENSE keys (a cluster next to an outlier) makes the caller take the multi-level path instead (returns false, nothing
-// written).  Workgroup-uniform; contains barriers.
-#define SG_PT_U 16
-#define SG_PT_DENSE 2048
+// A whole list in LDS: keys in[0, n) (n <= SG_PT_U * 1024) are split into SG_PT_FINE buckets by value -- eight times finer than
+// the multi-level path above: the keys of a tile cluster in depth (the front and the back surface of a limb: 5 000 keys within
+// 7 % of the tile's depth range), and at 1024 buckets every key of such a band shared its bucket with ~75 others -- scattered
+// into sKeys, and every key then counts the smaller keys of its own bucket: final position = bucket start + that count (keys are
+// unique).  Cost: sum over the buckets of (keys in it)^2 LDS reads, ~10 per key.  A bucket of more than SG_PT_DENSE keys (equal
+// depth bits, or a cluster next to a far outlier) makes the caller take the multi-level path instead (returns false, nothing
+// written).  LDS: sKeys [SG_PT_U * 1024] followed by the bucket table [SG_PT_FINE].  Workgroup-uniform; contains barriers.
+#define SG_PT_U 12
+#define SG_PT_FINE 8192
+#define SG_PT_DENSE 1024
 __device__ bool sg_sort_resident(const uint64_t *__restrict__ in, uint32_t n, uint32_t abs0, uint32_t tile, SgPartLds &L,
                                  uint64_t *__restrict__ sKeys, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
                                  int tid)
 {
-    constexpr int U = SG_PT_U;
+    constexpr int U = SG_PT_U, BPT = SG_PT_FINE / SG_PT_THREADS;        // keys / buckets per thread
     constexpr uint64_t NONE = ~0ull;
+    uint32_t *tab = (uint32_t *)(sKeys + (size_t)U * SG_PT_THREADS);    // counts -> cursors -> bucket ends
     const int lane = tid & 63, wid = tid >> 6;
     uint64_t kr[U];
 #pragma unroll
     for (int u = 0; u < U; u++) { const uint32_t i = (uint32_t)u * SG_PT_THREADS + tid; kr[u] = i < n ? in[i] : NONE; }
+#pragma unroll
+    for (int q = 0; q < BPT; q++) tab[q * SG_PT_THREADS + tid] = 0u;
     uint64_t kmin = NONE, kmax = 0ull;
 #pragma unroll
     for (int u = 0; u < U; u++)
@@ -443,47 +449,55 @@ __device__ bool sg_sort_resident(const uint64_t *__restrict__ in, uint32_t n, ui
         kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax;
     }
     if (lane == 0) { L.wmin[wid] = kmin; L.wmax[wid] = kmax; }
-    L.cur[tid] = 0u;
     if (tid == 0) L.nbig = 0u;
     __syncthreads();
 #pragma unroll 1
     for (int w = 0; w < SG_PT_THREADS / 64; w++) { const uint64_t a = L.wmin[w], b = L.wmax[w]; kmin = a < kmin ? a : kmin; kmax = b > kmax ? b : kmax; }
     const uint64_t span = kmax - kmin;
     const int bits = span ? 64 - __builtin_clzll(span) : 0;
-    const int shift = bits > 10 ? bits - 10 : 0;
+    const int shift = bits > 13 ? bits - 13 : 0;                        // (span >> shift) < 8192
+    uint32_t bk[U];
 #pragma unroll
-    for (int u = 0; u < U; u++)
-        if (kr[u] != NONE) atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u);
+    for (int u = 0; u < U; u++) {
+        bk[u] = (uint32_t)((kr[u] - kmin) >> shift);
+        if (kr[u] != NONE) atomicAdd(&tab[bk[u]], 1u);
+    }
     __syncthreads();
-    const uint32_t cnt = L.cur[tid];
-    uint32_t incl = cnt;
+    // exclusive scan: thread t owns buckets [BPT t, BPT t + BPT)
+    uint32_t c[BPT], own = 0;
+    bool dense = false;
+#pragma unroll
+    for (int q = 0; q < BPT; q++) { c[q] = tab[BPT * tid + q]; own += c[q]; dense |= c[q] > SG_PT_DENSE; }
+    uint32_t incl = own;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     if (lane == 63) L.wtot[wid] = incl;
-    if (cnt > SG_PT_DENSE) atomicAdd(&L.nbig, 1u);
+    if (dense) atomicAdd(&L.nbig, 1u);
     __syncthreads();
     if (L.nbig) { __syncthreads(); return false; }                     // (uniform; the barrier keeps nbig intact until everybody has read it)
-    uint32_t woff = 0;
+    uint32_t run = incl - own;
 #pragma unroll 1
-    for (int w = 0; w < wid; w++) woff += L.wtot[w];
-    const uint32_t excl = woff + incl - cnt;
-    L.off[tid] = excl;
-    if (tid == SG_PT_THREADS - 1) L.off[SG_PT_NB] = excl + cnt;
+    for (int w = 0; w < wid; w++) run += L.wtot[w];
+#pragma unroll
+    for (int q = 0; q < BPT; q++) { tab[BPT * tid + q] = run; run += c[q]; }
     __syncthreads();
-    L.cur[tid] = excl;
-    __syncthreads();
+    // scatter; afterwards tab[b] is the END of bucket b (= start of bucket b + 1)
 #pragma unroll
     for (int u = 0; u < U; u++)
-        if (kr[u] != NONE) sKeys[atomicAdd(&L.cur[(uint32_t)((kr[u] - kmin) >> shift)], 1u)] = kr[u];
+        if (kr[u] != NONE) sKeys[atomicAdd(&tab[bk[u]], 1u)] = kr[u];
     __syncthreads();
 #pragma unroll 1
     for (int u = 0; u < U; u++) {
         const uint64_t key = kr[u];
         if (key == NONE) continue;
-        const uint32_t b = (uint32_t)((key - kmin) >> shift);
-        const uint32_t s0 = L.off[b], e0 = L.off[b + 1];
+        const uint32_t s0 = bk[u] ? tab[bk[u] - 1] : 0u, e0 = tab[bk[u]];
         uint32_t rank = 0;
-        for (uint32_t j = s0; j < e0; j++) rank += sKeys[j] < key;
+        uint32_t j = s0;
+        for (; j + 4 <= e0; j += 4) {                                   // four independent LDS reads in flight
+            const uint64_t k0 = sKeys[j], k1 = sKeys[j + 1], k2 = sKeys[j + 2], k3 = sKeys[j + 3];
+            rank += (uint32_t)(k0 < key) + (uint32_t)(k1 < key) + (uint32_t)(k2 < key) + (uint32_t)(k3 < key);
+        }
+        for (; j < e0; j++) rank += sKeys[j] < key;
         point_list[abs0 + s0 + rank] = (uint32_t)key;
         if (point_keys) point_keys[abs0 + s0 + rank] = ((uint64_t)tile << 32) | (key >> 32);
     }
@@ -535,7 +549,7 @@ sg_tile_partition_kernel(uint32_t *header, const uint2 *__restrict__ part_items,
         if (tid == 0) L.gslot = g0;
         __syncthreads();
         // Lists that fit the workgroup's LDS (every list of an avatar frame): sorted right here -- partition into LDS, then every
-        // key counts the smaller keys of ITS bucket (a dozen on average): no second kernel, no trip through memory.
+        // key counts the smaller keys of ITS bucket (ten on average): no second kernel, no trip through memory.
         if (n <= resident_max && sg_sort_resident(pair_keys + r.x, n, r.x, tile, L, sKeys, point_list, point_keys, tid)) {
             for (uint32_t g = g0 + tid; g < gend; g += SG_PT_THREADS) groups[g] = make_uint2(0u, 0u);
             continue;
@@ -651,12 +665,15 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     if (short_lists) return;     // the caller vouches for short lists (checked on the device: header[1] bit 1)
     sg_prof_begin(SG_K_TILE_SORT, st);
     const uint32_t pgrid = sg_sort_items_cap(T, cap) < 512 ? sg_sort_items_cap(T, cap) : 512;
-    // 128 KiB of dynamic LDS: a list of up to 16 384 keys is sorted inside the workgroup.  If the runtime refuses the limit (asked
-    // for per launch: per device, no process-wide flag) only the counting slab is allocated and every list takes the multi-level path.
+    // 128 KiB of dynamic LDS (96 KiB of keys + a 32-KiB bucket table): a list of up to 12 288 keys is sorted inside the workgroup.
+    // If the runtime refuses the limit (asked for per launch: per device, no process-wide flag) only the counting slab is
+    // allocated and every list takes the multi-level path.
     uint32_t resident = SG_PT_U * SG_PT_THREADS;
-    if (hipFuncSetAttribute((const void *)sg_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(resident * 8)) != hipSuccess) { (void)hipGetLastError(); resident = SG_PT_NB; }
-    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), (size_t)resident * 8, st, b.header, b.sort_items,
+    size_t dyn = (size_t)resident * 8 + (size_t)SG_PT_FINE * 4;
+    if (hipFuncSetAttribute((const void *)sg_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
+        (void)hipGetLastError(); resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8;
+    }
+    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
                        b.ranges, b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
                        resident > SG_PT_NB ? resident : 0u);
     const uint32_t ggrid = sg_rank_items_cap(cap) < 4096 ? sg_rank_items_cap(cap) : 4096;
