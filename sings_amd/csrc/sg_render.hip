@@ -143,15 +143,19 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
     return nl;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
-                     const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,
-                     uint64_t *__restrict__ point_keys, const float4 *__restrict__ recA,
-                     const float4 *__restrict__ recB, const float4 *__restrict__ recC,
-                     const float *__restrict__ bg, float *__restrict__ out_color,
-                     float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,
-                     const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,
-                     uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count)
+// PIPE: software-pipelined walk of a quadrant's list (see the loop); the plain loop otherwise.
+#define SG_FWD_PARAMS int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,                          \
+                      const uint64_t *__restrict__ pair_keys, uint32_t *__restrict__ point_list,                         \
+                      uint64_t *__restrict__ point_keys, const float4 *__restrict__ recA,                                \
+                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,                                  \
+                      const float *__restrict__ bg, float *__restrict__ out_color,                                       \
+                      float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,                                     \
+                      const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,                 \
+                      uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count
+#define SG_FWD_ARGS W, H, gx, T, nblocks, ranges, pair_keys, point_list, point_keys, recA, recB, recC, bg, out_color, final_T, \
+                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count
+template <bool PIPE>
+__device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
 {
     __shared__ float4 sR[SG_FB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_FB];
@@ -227,12 +231,8 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         uint16_t *list = sList[wave];
         const int nl = sg_compact_quadrant<48>(sM, cnt, wave, lane, lt, list, SG_FB);
         uint32_t lastk = 0xffffffffu;                      // record offset of the last entry blended in this batch
-        for (int i = 0; i < nl; i++) {
-            const uint32_t ko = list[i];
-            const float4 *rec = (const float4 *)((const char *)&sR[0][0] + ko);
-            const float4 ga = rec[0], gb = rec[1];
-            const float gc = rec[2].x;
-            // straight-line, predicated: no exec-mask branches
+        // one (entry, quadrant) pass -- straight-line, predicated: no exec-mask branches
+        auto pass = [&](const float4 ga, const float4 gb, const float gc, const uint32_t ko) {
             const float dx = ga.x - pxf, dy = ga.y - pyf;
             const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);
             const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
@@ -245,6 +245,37 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             Tr = blend ? test_T : Tr;
             lastk = blend ? ko : lastk;
             done = done | term;
+        };
+        if (PIPE) {
+            // Software pipeline over the quadrant's list: the record of entry i + 1 and the list word of entry i + 2 are
+            // requested BEFORE the arithmetic of entry i (two register sets, A and B, alternate: no copies).  As a plain loop
+            // every pass is list word -> wait -> record -> wait -> 19 VALU: two dependent LDS latencies exposed per pass.  With
+            // eight busy waves on the SIMD other waves fill those stalls; the deepest tiles of an avatar frame run ALONE at the
+            // end of the kernel (per-tile clocks, profiles/r03_fwd_experiments.log: 12 batches in 128 us, one wave per SIMD) and
+            // there the stalls were more than half of every pass.
+            auto rec_of = [&](uint32_t k) { return (const float4 *)((const char *)&sR[0][0] + k); };
+            uint32_t kA = nl > 0 ? list[0] : 0u, kB = nl > 1 ? list[1] : kA;
+            float4 aA = rec_of(kA)[0], bA = rec_of(kA)[1];
+            float cA = rec_of(kA)[2].x;
+            for (int i = 0; i < nl; i += 2) {
+                const float4 aB = rec_of(kB)[0], bB = rec_of(kB)[1];
+                const float cB = rec_of(kB)[2].x;
+                const uint32_t kA2 = list[i + 2 < nl ? i + 2 : nl - 1];
+                __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the requests to just in front of their use)
+                pass(aA, bA, cA, kA);
+                if (i + 1 >= nl) break;
+                aA = rec_of(kA2)[0]; bA = rec_of(kA2)[1]; cA = rec_of(kA2)[2].x;
+                const uint32_t kB2 = list[i + 3 < nl ? i + 3 : nl - 1];
+                __builtin_amdgcn_sched_barrier(0);
+                pass(aB, bB, cB, kB);
+                kA = kA2; kB = kB2;
+            }
+        } else {
+            for (int i = 0; i < nl; i++) {
+                const uint32_t ko = list[i];
+                const float4 *rec = (const float4 *)((const char *)&sR[0][0] + ko);
+                pass(rec[0], rec[1], rec[2].x, ko);
+            }
         }
         if (lastk != 0xffffffffu) last = (uint32_t)base + lastk / 48u + 1u;
     }
@@ -259,6 +290,14 @@ sg_render_fwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     }
 }
 
+// The plain loop at eight waves per SIMD: frames of many tiles (cfg3: 8 160 tiles, lists of ~100 entries, every SIMD busy).
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+sg_render_fwd_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<false>(SG_FWD_ARGS); }
+// The pipelined loop: frames of few tiles with lists of thousands of entries (an avatar in front of a background: T <= 4096, the
+// regime of the LDS histogram in the preprocess), where the kernel ends in a handful of deep tiles, one wave per SIMD.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
+sg_render_fwd_deep_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<true>(SG_FWD_ARGS); }
+
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
 
 void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
@@ -268,10 +307,16 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
-                       b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
-                       c.bg, out_color, im.final_T, im.n_contrib,
-                       b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
+    if (sg_lds_hist((size_t)T))
+        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
+                           c.bg, out_color, im.final_T, im.n_contrib,
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
+    else
+        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
+                           c.bg, out_color, im.final_T, im.n_contrib,
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
