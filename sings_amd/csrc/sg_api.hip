@@ -53,7 +53,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_pair_gid = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_pair_tile = o; o = sg_align(o + (cap + 1) * 4);
     L->bin_pair_local = o; o = sg_align(o + (cap + 1) * 4);
-    L->bin_sort_items = o; o = sg_align(o + (size_t)sg_sort_items_cap(T, cap) * 8);
+    L->bin_sort_items = o; o = sg_align(o + (size_t)sg_sort_items_cap(T, cap) * 16);
     L->bin_rank_items = o; o = sg_align(o + (size_t)sg_rank_items_cap(cap) * 8);
     L->bin_items = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
     L->bin_ck_start = o; o = sg_align(o + T * 4);

@@ -157,7 +157,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
                        const uint32_t *__restrict__ pair_tile, const uint32_t *__restrict__ pair_local,
                        const float *__restrict__ depth, const uint32_t *__restrict__ start,
                        uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
-                       uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
+                       uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
                        uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap)
 {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
@@ -166,7 +166,10 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
         const uint32_t nseg = sg_nseg(pl.w), nit = nseg ? nseg : 1u;
         for (uint32_t sg = 0; sg < nit; sg++)
             if (pl.x + sg < items_cap) items[pl.x + sg] = tile | (sg << 20);
-        if (pl.w > SG_WSORT_MAX && pl.y < sort_cap) sort_items[pl.y] = make_uint2(tile, pl.z);     // (tile, first group slot)
+        if (pl.w > SG_WSORT_MAX && pl.y < sort_cap) {                                              // (tile, first group slot, first entry, entries)
+            const uint32_t s0 = start[tile] < cap ? start[tile] : cap, e0 = start[tile] + pl.w < cap ? start[tile] + pl.w : cap;
+            sort_items[pl.y] = make_uint4(tile, pl.z, s0, e0 - s0);
+        }
     }
     const uint32_t R = header[0] < cap ? header[0] : cap;
     for (uint32_t i = gtid; i < R; i += nthreads) {
@@ -191,7 +194,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
                        uint32_t rank_cap, uint4 *__restrict__ plan, uint32_t *__restrict__ ck_start, uint32_t items_cap,
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
-                       uint64_t *__restrict__ pair_keys, uint2 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
+                       uint64_t *__restrict__ pair_keys, uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
                        uint32_t *__restrict__ items, int short_lists, unsigned long long *signal)
 {
     constexpr int NQ = SG_SCAN_NQ;
@@ -261,7 +264,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
             plan[t] = make_uint4(run[1], run[3], run[4], v);
             for (uint32_t sg = 0; sg < q[1]; sg++)
                 if (run[1] + sg < items_cap) items[run[1] + sg] = (uint32_t)t | (sg << 20);
-            if (q[3] && run[3] < sort_cap) sort_items[run[3]] = make_uint2((uint32_t)t, run[4]);     // (tile, first group slot)
+            if (q[3] && run[3] < sort_cap) sort_items[run[3]] = make_uint4((uint32_t)t, run[4], s, e - s);     // (tile, first group slot, first entry, entries)
         }
         sStart[t] = run[0];
 #pragma unroll
@@ -529,7 +532,7 @@ __device__ void sg_count_sort(const uint64_t *__restrict__ buf, uint32_t m, uint
 }
 
 __global__ void __launch_bounds__(SG_PT_THREADS)
-sg_tile_partition_kernel(uint32_t *header, const uint2 *__restrict__ part_items, const uint2 *__restrict__ ranges,
+sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
                          uint64_t *__restrict__ pair_keys, uint64_t *__restrict__ scratch, uint2 *__restrict__ groups,
                          uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
                          uint32_t resident_max)
@@ -537,12 +540,14 @@ sg_tile_partition_kernel(uint32_t *header, const uint2 *__restrict__ part_items,
     __shared__ SgPartLds L;
     extern __shared__ uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
     const int tid = threadIdx.x;
+    // (a latency chain: the work item carries the list's range itself, and the first item is requested together with the header)
+    uint4 it = part_items[blockIdx.x];
     const uint32_t nitems = header[1] ? 0u : header[4];
     for (uint32_t li = blockIdx.x; li < nitems; li += gridDim.x) {
-        const uint2 it = part_items[li];                              // (tile, first reserved group slot)
+        if (li != blockIdx.x) it = part_items[li];                    // (tile, first reserved group slot, first entry, entries)
         const uint32_t tile = it.x;
-        const uint2 r = ranges[tile];
-        const uint32_t n = r.y - r.x;
+        const uint2 r = make_uint2(it.z, it.z + it.w);
+        const uint32_t n = it.w;
         const uint32_t g0 = it.y < group_cap ? it.y : group_cap;
         const uint32_t gend = g0 + sg_group_slots(n) < group_cap ? g0 + sg_group_slots(n) : group_cap;
         __syncthreads();
@@ -674,9 +679,9 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         (void)hipGetLastError(); resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8;
     }
     hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
-                       b.ranges, b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
+                       b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
                        resident > SG_PT_NB ? resident : 0u);
-    const uint32_t ggrid = sg_rank_items_cap(cap) < 4096 ? sg_rank_items_cap(cap) : 4096;
+    const uint32_t ggrid = sg_rank_items_cap(cap) < 1024 ? sg_rank_items_cap(cap) : 1024;     // (usually nothing to do: header[7])
     hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
                        b.point_list, pk);
     sg_prof_end(SG_K_TILE_SORT, st);

@@ -58,7 +58,7 @@ struct SgBin {
     uint32_t *pair_gid;    // [cap] Gaussian-major pair list written by the preprocess: Gaussian id,
     uint32_t *pair_tile;   //       tile id,
     uint32_t *pair_local;  //       arrival rank inside the tile (returned by the counting atomic)
-    uint2 *sort_items;     // (tile, first group slot) of every list of more than 1024 entries; count in header[4]
+    uint4 *sort_items;     // (tile, first group slot, first entry, entries) of every list of more than 1024 entries; count in header[4]
     uint2 *rank_items;     // group slots of the bucket sort: (first index | buffer flag, length | tile << 11); reserved count in header[6]
     uint32_t *items;       // backward work items: tile | segment << 20; count in header[5]
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
@@ -105,7 +105,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.point_keys = (uint64_t *)(b + L.bin_point_keys);
     g.pair_gid = (uint32_t *)(b + L.bin_pair_gid); g.pair_tile = (uint32_t *)(b + L.bin_pair_tile);
     g.pair_local = (uint32_t *)(b + L.bin_pair_local);
-    g.sort_items = (uint2 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
+    g.sort_items = (uint4 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
     return g;

@@ -163,6 +163,64 @@ def test_fused_backward(J, iso, seed):
     assert not hasattr(_RasterizeSkinnedGaussians, "last_viewspace_grad")      # the round-1 class attribute (last call wins) is gone
 
 
+def test_avatar_shaped_scene_with_long_lists_against_the_oracle():
+    """The geometry of the reference's workload, scaled down so that the oracle finishes in seconds: one narrow body far from
+    a long-focal-length camera (fx = 5000 at 512 x 896 -> 937.5 at 96 x 128, z ~ 10 m), J = 52, anisotropic Gaussians a few
+    millimetres across with high opacity.  All splats fall on a handful of tiles -- lists of several thousand entries (bucket
+    sort, depth segments, checkpoints) whose pixels saturate after a fraction of the list (live-box culling, early exit).
+    Image, and every gradient of the fused path including dL/dA and dL/dtransl, against the oracle."""
+    import math
+    from sings_amd.skinned import rasterize_skinned_gaussians
+    dev = torch.device("cuda:0")
+    N, J, Wd, Hd = 30000, 52, 96, 128
+    s = _scene(N, J, 41)
+    rs_ = np.random.RandomState(41)
+    s["xyz"] = (rs_.normal(0, 1, (N, 3)) * np.array([0.05, 0.13, 0.04])).astype(np.float32)
+    s["scales"] = np.exp(rs_.normal(-5.3, 0.3, (N, 3))).astype(np.float32)
+    s["opac"] = rs_.uniform(0.3, 0.95, (N, 1)).astype(np.float32)
+    s["A"][:, :3, 3] *= 0.2                                               # (joint offsets of centimetres: the body stays narrow)
+    s["transl"] = np.array([-0.01, 0.02, 10.0], np.float32)
+    s["cam"] = make_camera(np.eye(4, dtype=np.float32), 937.5, 937.5, Wd / 2, Hd / 2, Wd, Hd)
+    s["dL"] = rs_.normal(0, 1, (3, Hd, Wd)).astype(np.float32)
+    rs = _settings(s, dev)
+    req = lambda a: None if a is None else torch.from_numpy(a).to(dev).requires_grad_(True)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    xyz, Rc, sc, op, sh, A, tr = req(s["xyz"]), req(s["Rc"]), req(s["scales"]), req(s["opac"]), req(s["shs"]), req(s["A"]), req(s["transl"])
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    color, radii, pxyz, pq, psc = rasterize_skinned_gaussians(xyz, Rc, sc, op, sh, t(s["w"]), A, rs, smpl_scale=t(s["smpl_scale"]),
+                                                              transl=tr, return_posed=True, means2D=m2d)
+    cam = s["cam"]
+    o = ro.forward(pxyz.detach().cpu().numpy(), s["opac"], cam["world_view_transform"], cam["full_proj_transform"],
+                   cam["camera_center"], Wd, Hd, math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), s["bg"],
+                   scales=psc.cpu().numpy(), rotations=pq.detach().cpu().numpy(), shs=s["shs"], sh_degree=3)
+    tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
+    assert tl.max() > 4096, tl.max()                                      # bucket-sorted lists, > 16 depth segments
+    last = o["n_contrib"].reshape(Hd // 16, 16, Wd // 16, 16).transpose(0, 2, 1, 3).reshape(-1, 256)
+    assert (np.median(last[tl > 4096], axis=1) < 0.5 * tl[tl > 4096]).all()   # ... whose typical pixel terminates long before the end
+    assert tl.max() > 12288 and ((tl > 4096) & (tl <= 12288)).any()       # both long-list sort paths: in-LDS and multi-level
+    assert np.array_equal(o["radii"], radii.cpu().numpy())
+    strict = o["margin"] >= BORDER
+    assert strict.mean() > 0.99
+    assert np.abs(color.detach().cpu().numpy() - o["color"]).max(0)[strict].max() <= 2e-5
+    dL = s["dL"].copy(); dL[:, ~strict] = 0
+    g = ro.backward(o, dL)
+    (color * t(dL)).sum().backward()
+    (oxyz, oRc, osc, oA, otr), (pxyz_o, pq_o, psc_o, _) = _oracle_deform(s, grad=True)
+    seeds = (pxyz_o * torch.from_numpy(g["dL_dmeans3D"])).sum() + (pq_o * torch.from_numpy(g["dL_drots"])).sum() \
+        + (psc_o * torch.from_numpy(g["dL_dscales"])).sum()
+    seeds.backward()
+    # (segmented backward: the colour behind a segment comes from forward checkpoints -- a different fp32 rounding of the same
+    #  quantity, see tests/test_gpu_raster.py::test_long_tile_lists_sort_paths)
+    _close("xyz_canon", xyz.grad.cpu().numpy(), oxyz.grad.numpy(), rtol=1e-3, atol_scale=1e-5)
+    _close("scales", sc.grad.cpu().numpy(), osc.grad.numpy(), rtol=1e-3, atol_scale=1e-5)
+    _close("rotmat_canon", Rc.grad.cpu().numpy(), oRc.grad.numpy(), rtol=1e-3, atol_scale=1e-5)
+    _close("A", A.grad.cpu().numpy()[:, :3, :], oA.grad.numpy()[:, :3, :], rtol=2e-3, atol_scale=2e-4)
+    _close("transl", tr.grad.cpu().numpy(), otr.grad.numpy(), rtol=2e-3, atol_scale=2e-4)
+    _close("opacity", op.grad.cpu().numpy(), g["dL_dopacity"], rtol=1e-3, atol_scale=1e-5)
+    _close("sh", sh.grad.cpu().numpy(), g["dL_dsh"], rtol=1e-3, atol_scale=1e-5)
+    _close("viewspace", m2d.grad.cpu().numpy(), g["dL_dmean2D"], rtol=1e-3, atol_scale=1e-5)
+
+
 def test_fused_backward_deterministic_and_ext_refused():
     from sings_amd.skinned import rasterize_skinned_gaussians
     dev = torch.device("cuda:0")
