@@ -99,6 +99,18 @@ __device__ __forceinline__ float4 sg_live_box(unsigned long long live, int wave)
     return make_float4((float)(qx + c0), (float)(qx + c1), (float)(qy + r0), (float)(qy + r1));
 }
 
+// The same for a 4x4 block (lanes 0..15, lane = 4 * row + column) whose tile-relative origin is (ox, oy): the waves of a
+// workgroup that composites ONE quadrant of a long tile (sg_render_fwd_body, `split`).
+__device__ __forceinline__ float4 sg_live_box16(unsigned long long live, int ox, int oy)
+{
+    const uint32_t m = (uint32_t)live & 0xffffu;
+    if (m == 0u) return make_float4(1.0f, 0.0f, 1.0f, 0.0f);
+    const uint32_t cols = (m | (m >> 4) | (m >> 8) | (m >> 12)) & 0xfu;
+    const uint32_t rows = ((m & 0xfu) ? 1u : 0u) | ((m & 0xf0u) ? 2u : 0u) | ((m & 0xf00u) ? 4u : 0u) | ((m & 0xf000u) ? 8u : 0u);
+    const int c0 = __builtin_ctz(cols), c1 = 31 - __builtin_clz(cols), r0 = __builtin_ctz(rows), r1 = 31 - __builtin_clz(rows);
+    return make_float4((float)(ox + c0), (float)(ox + c1), (float)(oy + r0), (float)(oy + r1));
+}
+
 // box[q] = (x0, x1, y0, y1): the part of quadrant q that still matters (sg_live_box) -- the whole quadrant at first;
 // once pixels saturate (forward) / for the pixels an entry can still have contributed to (backward) only the
 // bounding box of the live pixels.  Entries that cannot reach it are dropped from that quadrant's list: this is what
@@ -151,9 +163,10 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
                       const float *__restrict__ bg, float *__restrict__ out_color,                                       \
                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,                                     \
                       const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,                 \
-                      uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count
+                      uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,            \
+                      const uint4 *__restrict__ long_items, uint32_t mask_plane
 #define SG_FWD_ARGS W, H, gx, T, nblocks, ranges, pair_keys, point_list, point_keys, recA, recB, recC, bg, out_color, final_T, \
-                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count
+                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane
 template <bool PIPE>
 __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
 {
@@ -161,21 +174,46 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     __shared__ uint32_t sM[SG_FB];
     __shared__ uint16_t sList[4][SG_FB];       // byte offsets into sR (index * 48)
     __shared__ float4 sBox[4];
-    (void)nblocks;
-    const int tile = sg_tile_of_block(blockIdx.x);
-    if (tile >= T) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // The counters the NEXT forward's preprocess counts into are consumed by now (the scan ran before this kernel): leave
     // them zeroed, so that a caller who keeps its workspace can skip the zeroing launch (SG_FLAG_WS_CLEAN).
-    if (tid == 0) { tile_count[tile] = 0u; if (blockIdx.x == 0) header[2] = 0u; }
+    if (tid == 0 && blockIdx.x == 0) header[2] = 0u;
+    // Few-tile frames (PIPE): a tile whose list is longer than 1024 entries -- an avatar's hands: thousands of small splats, no
+    // pixel saturates before entry ~3000 -- is composited by FOUR workgroups, one per quadrant, each wave owning a 4x4 block
+    // (16 active lanes).  A wave walks only the entries that reach ITS pixels, and it issues at most one instruction every ~5
+    // cycles however idle the chip is (per-tile clocks: the deepest tile alone set the kernel time, 3000 passes x 46 ns), so
+    // shorter per-wave lists on otherwise idle SIMDs are what shortens the kernel; results are bit-identical (a pixel sees the
+    // same entries in the same order).  The first `nblocks` blocks are quadrants 1..3 of the long tiles (they are the heaviest
+    // work: dispatched first), listed by the scan in `long_items`; the tile's own block takes quadrant 0.
+    int tile, part = 0;
+    bool split = false;
+    if (PIPE && (int)blockIdx.x < nblocks) {
+        const uint32_t li = blockIdx.x / 3u;
+        if (header[1] || li >= header[4]) return;
+        tile = (int)long_items[li].x; part = 1 + (int)(blockIdx.x % 3u); split = true;
+    } else {
+        tile = sg_tile_of_block((int)blockIdx.x - (PIPE ? nblocks : 0));
+        if (tile >= T) return;
+        if (tid == 0) tile_count[tile] = 0u;
+    }
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
-    const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
-    const bool inside = px < W && py < H;
-    const float pxf = (float)px, pyf = (float)py;
     const uint2 range = ranges[tile];
     // R > capacity: part of the sorted list was never written (the caller re-runs with a larger workspace) --
     // render the background instead of gathering through stale ids
     const int n = header[1] ? 0 : (int)(range.y - range.x);
+    if (PIPE && n > SG_WSORT_MAX) split = true;
+    // pixel of this lane: quadrant `wave` of the tile, or (split) block `wave` of quadrant `part`
+    const int bx0 = split ? 8 * (part & 1) + 4 * (wave & 1) : 8 * (wave & 1), by0 = split ? 8 * (part >> 1) + 4 * (wave >> 1) : 8 * (wave >> 1);
+    const int lx = split ? (lane & 3) : (lane & 7), ly = split ? ((lane >> 2) & 3) : (lane >> 3);
+    const int px = X0 + bx0 + lx, py = Y0 + by0 + ly;
+    const bool inside = px < W && py < H && (!split || lane < 16);
+    const float pxf = (float)px, pyf = (float)py;
+    // slot of this pixel in a checkpoint (the backward's layout: quadrant * 64 + 8 * row + column inside the quadrant)
+    const int ckidx = split ? part * 64 + 8 * (by0 + ly - 8 * (part >> 1)) + (bx0 + lx - 8 * (part & 1)) : tid;
+    const bool ckok = !split || lane < 16;
+    // quadrants an entry was composited in, for the backward pass: one byte per list entry; a split tile's four workgroups write
+    // one plane each (bit `part`)
+    uint8_t *__restrict__ pmask = pair_mask + (size_t)(split ? part : 0) * mask_plane;
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
@@ -205,7 +243,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     }
     for (int base = 0; base < n; base += SG_FB) {
         {   // this quadrant's pixels that are still being composited
-            const float4 bx = sg_live_box(__ballot(!done), wave);
+            const float4 bx = split ? sg_live_box16(__ballot(!done), bx0, by0) : sg_live_box(__ballot(!done), wave);
             if (lane == 0) sBox[wave] = bx;
         }
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
@@ -216,7 +254,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
             sR[tid][2].x = pc;
             const uint32_t mk = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
             sM[tid] = mk;
-            pair_mask[range.x + e] = (uint8_t)mk;          // the backward composites exactly these (entry, quadrant) pairs
+            pmask[range.x + e] = (uint8_t)(split ? (mk ? 1u << part : 0u) : mk);     // the backward composites exactly these (entry, quadrant) pairs
         }
         if (e + SG_FB < n) {
             const uint32_t gid = point_list[range.x + e + SG_FB];
@@ -225,8 +263,8 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         __syncthreads();
         if (__ballot(done) == ~0ull) continue;             // this quadrant is finished (wave-uniform)
         // state in front of entry `base`, for the backward pass of the segments behind it (SG_FB == SG_SEG)
-        if (base > 0 && cks != 0xffffffffu && cks + (uint32_t)(base / SG_SEG) < ck_cap)
-            ckpt[(size_t)(cks + (uint32_t)(base / SG_SEG)) * 256 + tid] = make_float4(Tr, C0, C1, C2);
+        if (base > 0 && ckok && cks != 0xffffffffu && cks + (uint32_t)(base / SG_SEG) < ck_cap)
+            ckpt[(size_t)(cks + (uint32_t)(base / SG_SEG)) * 256 + ckidx] = make_float4(Tr, C0, C1, C2);
         const int cnt = n - base < SG_FB ? n - base : SG_FB;
         uint16_t *list = sList[wave];
         const int nl = sg_compact_quadrant<48>(sM, cnt, wave, lane, lt, list, SG_FB);
@@ -279,7 +317,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         }
         if (lastk != 0xffffffffu) last = (uint32_t)base + lastk / 48u + 1u;
     }
-    if (cks < ck_cap) ckpt[(size_t)cks * 256 + tid] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
+    if (cks < ck_cap && ckok) ckpt[(size_t)cks * 256 + ckidx] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
     if (inside) {
         const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
         final_T[pid] = Tr;
@@ -307,16 +345,19 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    if (sg_lds_hist((size_t)T))
-        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+    if (sg_split_long((size_t)T)) {
+        const int extra = 3 * (int)sg_sort_items_cap(T, cap);         // upper bound: quadrants 1..3 of every long tile (most blocks exit at once)
+        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid), dim3(256), 0, st, c.W, c.H, c.gx, T, extra, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
-    else
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
+                           (const uint4 *)b.sort_items, sg_mask_plane(cap));
+    } else
         hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count);
+                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
+                           (const uint4 *)b.sort_items, sg_mask_plane(cap));
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -371,7 +412,8 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                      const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
                      float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap, const uint32_t *__restrict__ header,
                      const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
-                     const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask)
+                     const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
+                     int split_long)
 {
     __shared__ float4 sR[SG_BB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_BB];
@@ -441,7 +483,14 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
             // quadrants the forward composited this entry in: nothing else can carry a gradient, so neither the
             // rectangle tests nor the two record gathers are repeated for the rest
-            const uint32_t mk = e < max_contrib ? (uint32_t)pair_mask[range.x + e] : 0u;
+            // (a long tile of a few-tile frame was composited by four workgroups, one mask plane each: sg_render_fwd_body)
+            uint32_t mk = 0u;
+            if (e < max_contrib) {
+                mk = pair_mask[range.x + e];
+                if (split_long && n > SG_WSORT_MAX)
+                    mk = (mk & 1u) | (pair_mask[(size_t)mask_plane + range.x + e] & 2u) | (pair_mask[2 * (size_t)mask_plane + range.x + e] & 4u) |
+                         (pair_mask[3 * (size_t)mask_plane + range.x + e] & 8u);
+            }
             if (mk) {
                 const float4 a = recA[gid], b = recB[gid];
                 opac = b.y; cA = a.z; cB = a.w; cC = b.x;
@@ -527,6 +576,7 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     sg_prof_begin(SG_K_RENDER_BWD, st);
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
-                       grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask);
+                       grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
+                       sg_split_long((size_t)T) ? 1 : 0);
     sg_prof_end(SG_K_RENDER_BWD, st);
 }
