@@ -440,6 +440,7 @@ def main_raster(a):
         if fp is not None:
             fp.all_reduce_grads(eng.grad_flat)
     n_one = max(20, min(a.steps * k_views, 2000))
+    eng.throughput = False                                       # one view in flight from here on: the library may spend work on latency
     for _ in range(10):
         step_one_view()
     el_one = _median(timed_repeats(dist, dev, n_one, step_one_view, min_s=0.25))
@@ -1017,6 +1018,7 @@ def main_avatar(a):
         if fp is not None:
             fp.all_reduce_grads(eng.grad_flat)
     n_one = max(20, min(a.steps * k_views, 2000))
+    eng.throughput = False                                       # one frame in flight from here on (SG_FLAG_THROUGHPUT off)
     for i in range(10):
         step_one_frame(i)
     el_one = _median(timed_repeats(dist, dev, n_one, step_one_frame, min_s=0.25))

@@ -88,6 +88,12 @@ const char *sg_last_error(void);
  * The per-call zeroing launch (~7 us of a 350-us cfg3 view, launch gap included) is then skipped.  Without the flag
  * the workspace may hold anything. */
 #define SG_FLAG_WS_CLEAN 2
+/* SG_FLAG_THROUGHPUT: the caller keeps SEVERAL views in flight on the device (sings_amd.engine.ViewBatch over HIP streams).  The
+ * library then does not spend extra instructions on latency: on frames of few tiles (<= 4096: an avatar) it otherwise
+ * composites every tile of more than 1024 entries with four workgroups, one per quadrant -- 15 % off the forward composite of a
+ * frame rendered alone, ~3 % slower when other views already fill the idle SIMDs.  Must be the same in the forward and the
+ * backward call of a view (it decides the layout of the per-entry quadrant masks). */
+#define SG_FLAG_THROUGHPUT 4
 #define SG_NUM_RENDERED_LONG_LIST (-2)
 /* Workspace sizing.  capacity_pairs = upper bound on R = sum of tiles touched. */
 int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out);

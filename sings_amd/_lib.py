@@ -53,6 +53,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
 NUM_KERNELS = 8
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
+FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT
 NUM_RENDERED_LONG_LIST = -2          # SG_NUM_RENDERED_LONG_LIST
 
 

@@ -496,9 +496,19 @@ __device__ bool sg_sort_resident(const uint64_t *__restrict__ in, uint32_t n, ui
         const uint32_t s0 = bk[u] ? tab[bk[u] - 1] : 0u, e0 = tab[bk[u]];
         uint32_t rank = 0;
         uint32_t j = s0;
-        for (; j + 4 <= e0; j += 4) {                                   // four independent LDS reads in flight
-            const uint64_t k0 = sKeys[j], k1 = sKeys[j + 1], k2 = sKeys[j + 2], k3 = sKeys[j + 3];
-            rank += (uint32_t)(k0 < key) + (uint32_t)(k1 < key) + (uint32_t)(k2 < key) + (uint32_t)(k3 < key);
+        // (phase clocks on an avatar frame: the mean tile spends 2 us here, the one with the densest buckets 13 -- the loop is LDS
+        //  latency, so sixteen independent reads are in flight per round: aligned 16-byte reads of two keys each)
+        if ((j & 1u) && j < e0) { rank += sKeys[j] < key; j++; }
+        for (; j + 16 <= e0; j += 16) {
+            ulonglong2 q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = *(const ulonglong2 *)(sKeys + j + 2 * i);
+#pragma unroll
+            for (int i = 0; i < 8; i++) rank += (uint32_t)(q[i].x < key) + (uint32_t)(q[i].y < key);
+        }
+        for (; j + 4 <= e0; j += 4) {
+            const ulonglong2 q0 = *(const ulonglong2 *)(sKeys + j), q1 = *(const ulonglong2 *)(sKeys + j + 2);
+            rank += (uint32_t)(q0.x < key) + (uint32_t)(q0.y < key) + (uint32_t)(q1.x < key) + (uint32_t)(q1.y < key);
         }
         for (; j < e0; j++) rank += sKeys[j] < key;
         point_list[abs0 + s0 + rank] = (uint32_t)key;
@@ -681,7 +691,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
                        b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
                        resident > SG_PT_NB ? resident : 0u);
-    const uint32_t ggrid = sg_rank_items_cap(cap) < 1024 ? sg_rank_items_cap(cap) : 1024;     // (usually nothing to do: header[7])
+    const uint32_t ggrid = sg_rank_items_cap(cap) < 256 ? sg_rank_items_cap(cap) : 256;       // (usually nothing to do: header[7])
     hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
                        b.point_list, pk);
     sg_prof_end(SG_K_TILE_SORT, st);

@@ -41,7 +41,7 @@ static inline bool sg_lds_hist(size_t T) { return T <= SG_HIST_TILES_MAX; }
 // The same regime (few tiles, a handful of them with lists of thousands of entries) is where the forward composite ends in a few
 // deep tiles running alone: there a tile of more than 1024 entries is composited by four workgroups, one per quadrant
 // (sg_render.hip), and the per-entry quadrant masks live in four planes of mask_plane bytes.
-static inline bool sg_split_long(size_t T) { return T <= SG_HIST_TILES_MAX; }
+static inline bool sg_split_long(size_t T, int flags) { return T <= SG_HIST_TILES_MAX && !(flags & SG_FLAG_THROUGHPUT); }
 static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors

@@ -54,6 +54,7 @@ class RasterEngine:
         self._keep = []
         self._s = None
         self._chain = None                                    # (accumulate, wait-for event, done event): set by ViewBatch
+        self.throughput = False                               # SG_FLAG_THROUGHPUT: set by a ViewBatch that keeps several views in flight
 
     def set_camera(self, raster_settings, short_lists=False):
         """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 1024 entries (what the
@@ -68,7 +69,7 @@ class RasterEngine:
 
     def forward(self, means3D, shs, opacities, scales, rotations, sync_num_rendered=False):
         nr = C.c_int64(-1)
-        self._s.flags = self._hint | (_lib.FLAG_WS_CLEAN if self._clean else 0)
+        self._s.flags = self._hint | (_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0)
         self._clean = False                                  # (stays False if the call below raises)
         _lib.check(self.lib.sg_rasterize_forward(
             C.byref(self._s), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales), _ptr(rotations),
@@ -161,6 +162,7 @@ class SkinnedEngine:
         self.d_A = torch.empty((self.J, 16), **f32); self.d_transl = torch.empty(3, **f32)
         self._keep = []; self._s = None; self._k = None
         self._chain = None
+        self.throughput = False
 
     def set_camera(self, raster_settings):
         self._keep = []
@@ -176,7 +178,7 @@ class SkinnedEngine:
 
     def forward(self, shs, opacities, scales, sync_num_rendered=False):
         nr = C.c_int64(-1)
-        self._s.flags = _lib.FLAG_WS_CLEAN if self._clean else 0
+        self._s.flags = (_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0)
         self._clean = False
         _lib.check(self.lib.sg_skinned_forward(
             C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.geom),
@@ -264,6 +266,8 @@ class ViewBatch:
         self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
         self.acc = self.pipe.acc
         self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
+        for e in self.engines:                                # several views in flight: no latency-only work (SG_FLAG_THROUGHPUT)
+            e.throughput = self.n > 1
 
     def _link(self, v, e):
         # view v adds to its row iff an earlier view of the step wrote it; with one row across several streams the per-Gaussian
