@@ -548,7 +548,7 @@ sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
                          uint32_t resident_max)
 {
     __shared__ SgPartLds L;
-    extern __shared__ uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
+    extern __shared__ __attribute__((aligned(16))) uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
     const int tid = threadIdx.x;
     // (a latency chain: the work item carries the list's range itself, and the first item is requested together with the header)
     uint4 it = part_items[blockIdx.x];

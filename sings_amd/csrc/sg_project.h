@@ -304,7 +304,7 @@ __device__ __forceinline__ void sg_sum_records(SgRec grec, size_t cap, float4 re
 
 // Cooperative variant: the wave's records are ONE contiguous range (slots are reserved per wave in lane
 // order), so the wave streams them with 16-B-per-lane loads into LDS (chunks of SG_REC_CHUNK records)
-// and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*9 floats.
+// and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*12 floats.
 #define SG_REC_CHUNK 128
 __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool vis, float4 recC,
                                                     int lane, float *__restrict__ l, float a9[9])
@@ -328,7 +328,9 @@ __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool
         const float *srb = grec.b + (size_t)c0;
         // all four 16-B loads and the two 4-B loads of the chunk are issued before the first one is used (as a loop the compiler
         // emitted load -> wait -> LDS write, ONE request in flight per wave: a memory latency per KiB); indices are clamped instead
-        // of tested, so nothing branches around a load, and the surplus lanes rewrite the last element
+        // of tested, so nothing branches around a load, and the surplus lanes rewrite the last element.  In LDS a record keeps
+        // the 48-byte pitch of rounds 1-2 (two vectors + the ninth value in a third): at the 32-byte pitch of the memory layout
+        // the lanes of a wave -- ~4 records apart: 128 B -- all hit the same banks (same-box A/B: 37.6 vs 33.5 us per launch).
         {
             float4 v[SG_REC_CHUNK * 2 / 64];
             float w[SG_REC_CHUNK / 64];
@@ -345,23 +347,23 @@ __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool
             }
 #pragma unroll
             for (int i = 0; i < SG_REC_CHUNK * 2 / 64; i++) {
-                const uint32_t f = (uint32_t)lane + 64u * i;
-                ((float4 *)l)[f < last ? f : last] = v[i];
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < last ? f0 : last;
+                ((float4 *)l)[3 * (f >> 1) + (f & 1u)] = v[i];
             }
 #pragma unroll
             for (int i = 0; i < SG_REC_CHUNK / 64; i++) {
-                const uint32_t f = (uint32_t)lane + 64u * i;
-                l[SG_REC_CHUNK * 8 + (f < n - 1 ? f : n - 1)] = w[i];
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < n - 1 ? f0 : n - 1;
+                l[12 * f + 8] = w[i];
             }
         }
         __builtin_amdgcn_s_waitcnt(0);
         __builtin_amdgcn_wave_barrier();
         const uint32_t k0 = lo > c0 ? lo : c0, k1 = hi < c0 + n ? hi : c0 + n;
         for (uint32_t k = k0; k < k1; k++) {
-            const float4 *r = (const float4 *)l + 2 * (k - c0);
+            const float4 *r = (const float4 *)l + 3 * (k - c0);
             const float4 r0 = r[0], r1 = r[1];
             a9[0] += r0.x; a9[1] += r0.y; a9[2] += r0.z; a9[3] += r0.w;
-            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += l[SG_REC_CHUNK * 8 + (k - c0)];
+            a9[4] += r1.x; a9[5] += r1.y; a9[6] += r1.z; a9[7] += r1.w; a9[8] += r[2].x;
         }
         __builtin_amdgcn_wave_barrier();
     }

@@ -269,21 +269,23 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         uint16_t *list = sList[wave];
         const int nl = sg_compact_quadrant<48>(sM, cnt, wave, lane, lt, list, SG_FB);
         uint32_t lastk = 0xffffffffu;                      // record offset of the last entry blended in this batch
-        // one (entry, quadrant) pass -- straight-line, predicated: no exec-mask branches
-        auto pass = [&](const float4 ga, const float4 gb, const float gc, const uint32_t ko) {
-            const float dx = ga.x - pxf, dy = ga.y - pyf;
-            const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);
-            const float alpha = fminf(0.99f, gb.y * __builtin_amdgcn_exp2f(power));
-            const float test_T = Tr * (1.0f - alpha);
-            const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-            const bool term = valid & (test_T < 0.0001f);
-            const bool blend = valid & !term;
-            const float w = blend ? alpha * Tr : 0.0f;
-            C0 = fmaf(gb.z, w, C0); C1 = fmaf(gb.w, w, C1); C2 = fmaf(gc, w, C2);
-            Tr = blend ? test_T : Tr;
-            lastk = blend ? ko : lastk;
-            done = done | term;
-        };
+        // one (entry, quadrant) pass -- straight-line, predicated: no exec-mask branches.  (A macro, not a lambda: captured by
+        // reference, `done` lived in a byte register and every pass paid three extra vector instructions for it.)
+#define SG_FWD_PASS(ga, gb, gc, ko)                                                                        \
+        do {                                                                                               \
+            const float dx = (ga).x - pxf, dy = (ga).y - pyf;                                              \
+            const float power = sg_power2((ga).z, (ga).w, (gb).x, dx, dy);                                 \
+            const float alpha = fminf(0.99f, (gb).y * __builtin_amdgcn_exp2f(power));                      \
+            const float test_T = Tr * (1.0f - alpha);                                                      \
+            const bool valid = !done & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);                         \
+            const bool term = valid & (test_T < 0.0001f);                                                  \
+            const bool blend = valid & !term;                                                              \
+            const float w = blend ? alpha * Tr : 0.0f;                                                     \
+            C0 = fmaf((gb).z, w, C0); C1 = fmaf((gb).w, w, C1); C2 = fmaf((gc), w, C2);                    \
+            Tr = blend ? test_T : Tr;                                                                      \
+            lastk = blend ? (ko) : lastk;                                                                  \
+            done = done | term;                                                                            \
+        } while (0)
         if (PIPE) {
             // Software pipeline over the quadrant's list: the record of entry i + 1 and the list word of entry i + 2 are
             // requested BEFORE the arithmetic of entry i (two register sets, A and B, alternate: no copies).  As a plain loop
@@ -300,21 +302,24 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
                 const float cB = rec_of(kB)[2].x;
                 const uint32_t kA2 = list[i + 2 < nl ? i + 2 : nl - 1];
                 __builtin_amdgcn_sched_barrier(0);          // (hipcc otherwise sinks the requests to just in front of their use)
-                pass(aA, bA, cA, kA);
+                SG_FWD_PASS(aA, bA, cA, kA);
                 if (i + 1 >= nl) break;
                 aA = rec_of(kA2)[0]; bA = rec_of(kA2)[1]; cA = rec_of(kA2)[2].x;
                 const uint32_t kB2 = list[i + 3 < nl ? i + 3 : nl - 1];
                 __builtin_amdgcn_sched_barrier(0);
-                pass(aB, bB, cB, kB);
+                SG_FWD_PASS(aB, bB, cB, kB);
                 kA = kA2; kB = kB2;
             }
         } else {
             for (int i = 0; i < nl; i++) {
                 const uint32_t ko = list[i];
                 const float4 *rec = (const float4 *)((const char *)&sR[0][0] + ko);
-                pass(rec[0], rec[1], rec[2].x, ko);
+                const float4 ga = rec[0], gb = rec[1];
+                const float gc = rec[2].x;
+                SG_FWD_PASS(ga, gb, gc, ko);
             }
         }
+#undef SG_FWD_PASS
         if (lastk != 0xffffffffu) last = (uint32_t)base + lastk / 48u + 1u;
     }
     if (cks < ck_cap && ckok) ckpt[(size_t)cks * 256 + ckidx] = make_float4(Tr, C0, C1, C2);   // slot 0: final state
