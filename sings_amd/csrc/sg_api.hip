@@ -44,7 +44,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->geom_bytes = o;
     o = 0;
     L->bin_header = o; o = sg_align(o + 256);
-    L->bin_tile_count = o; o = sg_align(o + T * 4);
+    L->bin_tile_count = o; o = sg_align(o + sg_ctr_count((uint32_t)gx, (uint32_t)gy) * 4);
     L->bin_ranges = o; o = sg_align(o + T * 8);
     L->bin_cursor = o; o = sg_align(o + T * 4);
     L->bin_pair_keys = o; o = sg_align(o + (cap + 1) * 8);
@@ -161,7 +161,7 @@ extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const floa
     // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
     // leaves them zeroed for the next call)
     sg_arm_count(s, &c, num_rendered_host);
-    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
+    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4, st);
     sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
     SG_CHECK_LAST("preprocess_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
@@ -284,7 +284,7 @@ extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkin
     SgBin b = sg_bin_view(binning_ws, L);
     SgImg im = sg_img_view(image_ws, L);
     sg_arm_count(s, &c, num_rendered_host);
-    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + (size_t)c.gx * c.gy * 4, st);
+    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4, st);
     sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
     SG_CHECK_LAST("skin_fwd", s, st);
     sg_launch_binning(c, P, radii, g, b, cap, 0, st);

@@ -52,7 +52,7 @@ __device__ __forceinline__ void sg_publish_count(unsigned long long *signal, uin
 
 template <int SG_SCAN_BS>
 __global__ void __launch_bounds__(SG_SCAN_BS)
-sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
+sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
                     uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal)
@@ -66,7 +66,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
     uint32_t acc[NQ] = { 0, 0, 0, 0, 0 };
     for (int t = tid; t < first; t += SG_SCAN_BS) {
         uint32_t q[NQ];
-        const uint32_t v = tile_count[t];
+        const uint32_t v = tile_count[sg_ctr_of_tile((uint32_t)t, (uint32_t)gx)];
         sg_scan_derive(v, q);
 #pragma unroll
         for (int a = 0; a < NQ; a++) acc[a] += q[a];
@@ -93,7 +93,7 @@ sg_tile_scan_kernel(int T, int tpt, const uint32_t *__restrict__ tile_count,
         const int tile = first + r * SG_SCAN_BS + tid;
         const bool ok = tile < T;
         uint32_t q[NQ] = { 0, 0, 0, 0, 0 };
-        const uint32_t v = ok ? tile_count[tile] : 0u;
+        const uint32_t v = ok ? tile_count[sg_ctr_of_tile((uint32_t)tile, (uint32_t)gx)] : 0u;
         if (ok) sg_scan_derive(v, q);
         uint32_t incl[NQ];
 #pragma unroll
@@ -189,7 +189,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
 #define SG_SS_THREADS 1024
 #define SG_SS_MAX_TILES 32768
 __global__ void __launch_bounds__(SG_SS_THREADS)
-sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
+sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
                        uint32_t *__restrict__ cursor, uint32_t *__restrict__ header, uint32_t cap, uint32_t sort_cap,
                        uint32_t rank_cap, uint4 *__restrict__ plan, uint32_t *__restrict__ ck_start, uint32_t items_cap,
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
@@ -201,7 +201,7 @@ sg_scan_scatter_kernel(int T, const uint32_t *__restrict__ tile_count, uint2 *__
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
     __shared__ uint32_t wsum[NQ][SG_SS_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[t];
+    for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[sg_ctr_of_tile((uint32_t)t, (uint32_t)gx)];
     __syncthreads();
     const int tpt = (T + SG_SS_THREADS - 1) / SG_SS_THREADS;
     const int t0 = tid * tpt < T ? tid * tpt : T, t1 = t0 + tpt < T ? t0 + tpt : T;
@@ -655,7 +655,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         sg_prof_begin(SG_K_TILE_SCAN, st);
         size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
         const int grid = (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
-        hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, b.tile_count, b.ranges,
+        hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
                            b.rank_items, b.items, short_lists, c.count_signal);
@@ -664,7 +664,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         sg_prof_begin(SG_K_TILE_SCAN, st);
         const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;
         const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
-        hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, tpt, b.tile_count, b.ranges, b.cursor,
+        hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, c.gx, tpt, b.tile_count, b.ranges, b.cursor,
                            b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), short_lists, c.count_signal);
         sg_prof_end(SG_K_TILE_SCAN, st);

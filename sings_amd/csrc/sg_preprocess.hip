@@ -74,7 +74,9 @@ void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const
 }
 
 // ------------------------------------------------------------------------------------------
-template <int D>
+// ACC: add to the gradient outputs instead of writing them (a compile-time switch: as a runtime flag the untaken branches cost
+// the plain kernel 3.8 us of its 33 -- same-box A/B)
+template <int D, bool ACC>
 __global__ void __launch_bounds__(256)
 sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
@@ -83,8 +85,9 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                          size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
-                         float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D, int accumulate)
+                         float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
 {
+    constexpr bool accumulate = ACC;
     __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -215,13 +218,15 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
     (void)opacities;
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
-#define SG_PB(DD) hipLaunchKernelGGL(sg_preprocess_bwd_kernel<DD>, grid, block, 0, st, c, P, means3D, shs, \
+#define SG_PB2(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
                                      grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
-                                     dL_dopacity, dL_dscales, dL_drots, dL_dcov3D, accumulate)
+                                     dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+#define SG_PB(DD) do { if (accumulate) SG_PB2(DD, true); else SG_PB2(DD, false); } while (0)
     int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (D) { case 0: SG_PB(0); break; case 1: SG_PB(1); break; case 2: SG_PB(2); break; default: SG_PB(3); break; }
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_PB
+#undef SG_PB2
 }

@@ -158,9 +158,9 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t tx = t - ty * w;
                 tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
                 gj[u] = (uint32_t)(g0 + j);
-                // rank inside this workgroup's share of the tile (LDS) / inside the tile (global)
+                // rank inside this workgroup's share of the tile (LDS) / inside the tile (global; counters in 4x4 blocks)
                 local[u] = hist ? atomicAdd(&hist[tile[u]], 1u)
-                                : atomicAdd(&bn.tile_count[tile[u]], 1u);
+                                : atomicAdd(&bn.tile_count[sg_ctr_index((mn & 0xffffu) + tx, (mn >> 16) + ty, (uint32_t)gx)], 1u);
             }
         }
     };
@@ -206,7 +206,8 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 cnt[u] = t < T ? hist[t] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) ans[u] = cnt[u] ? atomicAdd(&bn.tile_count[t0 + u * blockDim.x], cnt[u]) : 0u;
+            for (int u = 0; u < 8; u++)
+                ans[u] = cnt[u] ? atomicAdd(&bn.tile_count[sg_ctr_of_tile((uint32_t)(t0 + u * blockDim.x), (uint32_t)gx)], cnt[u]) : 0u;
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (cnt[u]) hist[t0 + u * blockDim.x] = ans[u];

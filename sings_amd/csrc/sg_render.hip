@@ -194,7 +194,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     } else {
         tile = sg_tile_of_block((int)blockIdx.x - (PIPE ? nblocks : 0));
         if (tile >= T) return;
-        if (tid == 0) tile_count[tile] = 0u;
+        if (tid == 0) tile_count[sg_ctr_of_tile((uint32_t)tile, (uint32_t)gx)] = 0u;
     }
     const int X0 = (tile % gx) * 16, Y0 = (tile / gx) * 16;
     const uint2 range = ranges[tile];

@@ -286,15 +286,16 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
 // per workgroup: partial dL/dA [Jp x 16] (matrix cores) and dL/dtransl [3] written to a slab
 // (reduced by sg_skin_reduce_kernel -- no atomics, deterministic).
-template <int D>
+template <int D, bool ACC>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
                    const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
                    const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
-                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride, int accumulate)
+                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
 {
+    constexpr bool accumulate = ACC;                            // (compile-time: see sg_preprocess_bwd_kernel)
     __shared__ float sA[SG_JMAX * 16];
     // per wave: [weights tile | T transpose scratch, later the dT tile]; between the two uses the whole 2 x 4.3 KB is
     // the staging buffer of the record sums and of the dL/dsh rows
@@ -947,9 +948,10 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                  in->transl, nullptr, nullptr, nullptr };
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
-#define SG_SB(DD) hipLaunchKernelGGL(sg_skin_bwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
+#define SG_SB2(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
                                      grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
-                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride, accumulate)
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
+#define SG_SB(DD) do { if (accumulate) SG_SB2(DD, true); else SG_SB2(DD, false); } while (0)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
     float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;
@@ -959,6 +961,7 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
                        dL_dA, dL_dtransl);
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
+#undef SG_SB2
 }
 
 void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st)

@@ -26,7 +26,7 @@ def test_layout_is_consistent():
     L = _lib.layout(1000, 1920, 1080, 50000)
     T = 120 * 68
     assert L.geom_recB - L.geom_recA >= 1000 * 16 and L.geom_bytes >= 1000 * 56
-    assert L.bin_ranges - L.bin_tile_count >= T * 4
+    assert L.bin_ranges - L.bin_tile_count >= T * 4                   # (counters in 4x4 blocks of tiles: 120 x 68 tiles need no padding)
     assert L.bin_point_list - L.bin_pair_keys >= 50000 * 8
     assert L.img_n_contrib - L.img_final_T >= 1920 * 1080 * 4
     assert 50000 * 36 <= L.bwd_bytes < 50000 * 40
