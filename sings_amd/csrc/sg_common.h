@@ -36,14 +36,6 @@ __host__ __device__ inline uint32_t sg_ckpt_cap(size_t cap) { size_t v = 2 * (ca
 // pairs per tile in an LDS histogram first and issue ONE global atomic per (workgroup, touched tile).  (Earlier
 // schemes for that regime -- one counter per 128-B line, then 8 sub-counters per tile -- took 141 / 80 us of
 // preprocess + 22 us of scan on the avatar frame; the histogram: 43 + 7 us.)
-#define SG_HIST_TILES_MAX 4096
-static inline bool sg_lds_hist(size_t T) { return T <= SG_HIST_TILES_MAX; }
-// The same regime (few tiles, a handful of them with lists of thousands of entries) is where the forward composite ends in a few
-// deep tiles running alone: there a tile of more than 1024 entries is composited by four workgroups, one per quadrant
-// (sg_render.hip), and the per-entry quadrant masks live in four planes of mask_plane bytes.
-static inline bool sg_split_long(size_t T, int flags) { return T <= SG_HIST_TILES_MAX && !(flags & SG_FLAG_THROUGHPUT); }
-static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
-
 // Tile counters live in 4x4 BLOCKS of tiles: the 16 counters of a block share one 64-byte line.  A Gaussian's rectangle is a few
 // neighbouring tiles in x AND y, so the returning atomics of its pairs -- one per (tile, Gaussian), 780 k per cfg3 view, the
 // largest part of the preprocess -- touch one or two lines instead of one per tile row (row-major: 18.0 us for the access pattern
@@ -55,6 +47,15 @@ __host__ __device__ inline uint32_t sg_ctr_index(uint32_t tx, uint32_t ty, uint3
     return ((ty >> 2) * sg_ctr_blocks_x(gx) + (tx >> 2)) * 16u + ((ty & 3u) << 2) + (tx & 3u);
 }
 __host__ __device__ inline uint32_t sg_ctr_of_tile(uint32_t tile, uint32_t gx) { return sg_ctr_index(tile % gx, tile / gx, gx); }
+
+#define SG_HIST_TILES_MAX 4096
+// (the histogram is indexed like the counters: sg_ctr_index)
+static inline bool sg_lds_hist(int gx, int gy) { return sg_ctr_count((uint32_t)gx, (uint32_t)gy) <= SG_HIST_TILES_MAX; }
+// The same regime (few tiles, a handful of them with lists of thousands of entries) is where the forward composite ends in a few
+// deep tiles running alone: there a tile of more than 1024 entries is composited by four workgroups, one per quadrant
+// (sg_render.hip), and the per-entry quadrant masks live in four planes of mask_plane bytes.
+static inline bool sg_split_long(int gx, int gy, int flags) { return sg_lds_hist(gx, gy) && !(flags & SG_FLAG_THROUGHPUT); }
+static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)

@@ -63,7 +63,7 @@ void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const
 {
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
-    const int T = c.gx * c.gy, ht = sg_lds_hist((size_t)T) ? T : 0;
+    const int ht = sg_lds_hist(c.gx, c.gy) ? (int)sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) : 0;     // histogram words (= tile counters)
 #define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, (size_t)ht * 4, st, c, P, means3D, shs, \
                                      colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii, ht)
     int D = colors_precomp ? 0 : c.D;

@@ -138,12 +138,12 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
     // four pairs per lane per round: the four returning atomics are in flight together
-    uint32_t tile[4], local[4], gj[4];
+    uint32_t tile[4], local[4], gj[4], ctr[4];
     auto take = [&](uint32_t p0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = p0 + 64 * u + lane;
-            tile[u] = 0; local[u] = 0; gj[u] = 0;
+            tile[u] = 0; local[u] = 0; gj[u] = 0; ctr[u] = 0;
             if (p < total) {
                 int lo = 0, hi = 63;                  // smallest j with incl[j] > p
 #pragma unroll
@@ -158,9 +158,10 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t tx = t - ty * w;
                 tile[u] = ((mn >> 16) + ty) * (uint32_t)gx + (mn & 0xffffu) + tx;
                 gj[u] = (uint32_t)(g0 + j);
-                // rank inside this workgroup's share of the tile (LDS) / inside the tile (global; counters in 4x4 blocks)
-                local[u] = hist ? atomicAdd(&hist[tile[u]], 1u)
-                                : atomicAdd(&bn.tile_count[sg_ctr_index((mn & 0xffffu) + tx, (mn >> 16) + ty, (uint32_t)gx)], 1u);
+                // rank inside this workgroup's share of the tile (LDS) / inside the tile (global): counters and histogram words
+                // are indexed alike, in 4x4 blocks of tiles (sg_ctr_index)
+                ctr[u] = sg_ctr_index((mn & 0xffffu) + tx, (mn >> 16) + ty, (uint32_t)gx);
+                local[u] = hist ? atomicAdd(&hist[ctr[u]], 1u) : atomicAdd(&bn.tile_count[ctr[u]], 1u);
             }
         }
     };
@@ -178,9 +179,9 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     if (live) g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(base + incl - o.tt), __uint_as_float(rmin), __uint_as_float(rwh));
     // round 0 (all of the wave's pairs at cfg3 / most of them on an avatar) stays in registers until its ranks are final: with the
     // LDS histogram they are rebased here instead of being written, re-read and rewritten
-    uint32_t tile0[4], local0[4], gj0[4];
+    uint32_t tile0[4], local0[4], gj0[4], ctr0[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { tile0[u] = tile[u]; local0[u] = local[u]; gj0[u] = gj[u]; }
+    for (int u = 0; u < 4; u++) { tile0[u] = tile[u]; local0[u] = local[u]; gj0[u] = gj[u]; ctr0[u] = ctr[u]; }
     if (expand) {
         for (uint32_t p0 = 256; p0 < total; p0 += 256) {
             take(p0);
@@ -206,8 +207,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 cnt[u] = t < T ? hist[t] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                ans[u] = cnt[u] ? atomicAdd(&bn.tile_count[sg_ctr_of_tile((uint32_t)(t0 + u * blockDim.x), (uint32_t)gx)], cnt[u]) : 0u;
+            for (int u = 0; u < 8; u++) ans[u] = cnt[u] ? atomicAdd(&bn.tile_count[t0 + u * blockDim.x], cnt[u]) : 0u;   // (word = counter index)
 #pragma unroll
             for (int u = 0; u < 8; u++)
                 if (cnt[u]) hist[t0 + u * blockDim.x] = ans[u];
@@ -215,7 +215,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         __syncthreads();
         for (uint32_t p = 256 + lane; p < total; p += 64) {      // later rounds: a lane re-reads exactly the slots it wrote above
             const uint32_t slot = base + p;
-            if (slot < cap) bn.pair_local[slot] += hist[bn.pair_tile[slot]];
+            if (slot < cap) bn.pair_local[slot] += hist[sg_ctr_of_tile(bn.pair_tile[slot], (uint32_t)gx)];
         }
     }
     if (expand) {
@@ -225,7 +225,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             const uint32_t slot = base + p;
             if (p < total && slot < cap) {
                 bn.pair_gid[slot] = gj0[u]; bn.pair_tile[slot] = tile0[u];
-                bn.pair_local[slot] = local0[u] + (hist ? hist[tile0[u]] : 0u);
+                bn.pair_local[slot] = local0[u] + (hist ? hist[ctr0[u]] : 0u);
             }
         }
     }

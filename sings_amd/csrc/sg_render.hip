@@ -350,9 +350,9 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    if (sg_lds_hist((size_t)T)) {
+    if (sg_lds_hist(c.gx, c.gy)) {
         // upper bound: quadrants 1..3 of every long tile (most blocks exit at once); none in throughput mode
-        const int extra = sg_split_long((size_t)T, c.flags) ? 3 * (int)sg_sort_items_cap(T, cap) : 0;
+        const int extra = sg_split_long(c.gx, c.gy, c.flags) ? 3 * (int)sg_sort_items_cap(T, cap) : 0;
         hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid), dim3(256), 0, st, c.W, c.H, c.gx, T, extra, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
@@ -583,6 +583,6 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                        grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
-                       sg_split_long((size_t)T, c.flags) ? 1 : 0);
+                       sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0);
     sg_prof_end(SG_K_RENDER_BWD, st);
 }

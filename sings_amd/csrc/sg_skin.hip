@@ -925,7 +925,7 @@ void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
     SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
                  in->transl, in->ext_trans, in->ext_rot, in->ext_scale };
     dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
-    const int T = c.gx * c.gy, ht = sg_lds_hist((size_t)T) ? T : 0;
+    const int ht = sg_lds_hist(c.gx, c.gy) ? (int)sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) : 0;     // histogram words (= tile counters)
 #define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
                                      b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales, ht)
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
