@@ -1,30 +1,50 @@
 #!/bin/bash
 # Run ON THE GPU BOX (through gpurun) from the repo root: collects the rocprofv3 summaries that profiles/ keeps.
-#   /usr/local/graft/bin/gpurun --timeout 1500 -- 'bash tools/collect_profiles.sh r01d'
-# rocprofv3 gets `python3 <script>` directly after `--` (no wrappers), counters in their own passes.
+#   /usr/local/graft/bin/gpurun --timeout 2400 -- 'bash tools/collect_profiles.sh r03'
+# then, in the build container:  python tools/pmc_summary.py gpurun_out/prof_r03 r03
+#                                python tools/pmc_summary.py gpurun_out/prof_r03/avatar r03_avatar workload=avatar gaussians=150000 width=512 height=896 sh_degree=0
+# rocprofv3 gets `python3 <script>` directly after `--` (no wrappers), counters in their own passes (never together with a trace).
 # "k1" = --views-per-step 1 --streams 1: one view at a time on one stream, so a kernel's rocprof duration is its own
-# (the default bench overlaps the views of a step on two streams: kernels of different views share the GPU and every
+# (the default bench overlaps the views of a step on three streams: kernels of different views share the GPU and every
 # one of them takes longer while the step gets shorter).
 set -u
-TAG=${1:-r01d}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
-mkdir -p $OUT
+mkdir -p $OUT $OUT/avatar
 cd /tmp && export TMPDIR=/tmp
 K1="--views-per-step 1 --streams 1"
-python3 $ROOT/bench.py --steps 50 --warmup 10 > $OUT/bench_cfg3.json 2> $OUT/bench_cfg3.err
-python3 $ROOT/bench.py --steps 50 --warmup 10 $K1 --no-cpu-baseline > $OUT/bench_cfg3_k1.json 2> $OUT/bench_cfg3_k1.err
-python3 $ROOT/bench.py --workload avatar --steps 50 --warmup 10 > $OUT/bench_avatar.json 2> $OUT/bench_avatar.err
+python3 $ROOT/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 $ROOT/bench.py --steps 100 --warmup 10 $K1 --no-cpu-baseline > $OUT/bench_cfg3_k1.json 2> $OUT/bench_cfg3_k1.err
+python3 $ROOT/bench.py --workload avatar --steps 100 --warmup 10 > $OUT/bench_avatar.json 2> $OUT/bench_avatar.err
+python3 $ROOT/bench.py --workload avatar --steps 100 --warmup 10 $K1 --no-cpu-baseline > $OUT/bench_avatar_k1.json 2> $OUT/bench_avatar_k1.err
 python3 $ROOT/bench.py --workload train --steps 30 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3 -o c3 -- python3 $ROOT/bench.py --steps 30 --warmup 5 $K1 --no-cpu-baseline > $OUT/c3.log 2>&1
+python3 $ROOT/bench.py --gaussians 50000 --width 512 --height 512 --sh-degree 0 --forward-only --steps 200 --no-cpu-baseline > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
+python3 $ROOT/bench.py --gaussians 500000 --width 2048 --height 2048 --regularisers --steps 40 --no-cpu-baseline > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
+SINGS_BENCH_FORCE_DIST=1 python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err
+SINGS_BENCH_FORCE_DIST=1 SINGS_DP_ALGO=rs_ag python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_rccl_world1_rs_ag.json 2> $OUT/bench_rccl_world1_rs_ag.err
+python3 $ROOT/tools/wrapper_time.py > $OUT/wrapper_time.log 2>&1
+# kernel traces (durations + gaps)
+for w in cfg3 avatar; do
+  extra=""; [ $w = avatar ] && extra="--workload avatar"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$w -o $w -- python3 $ROOT/bench.py --steps 40 --warmup 5 $K1 --no-cpu-baseline $extra > $OUT/$w.log 2>&1
+  f=$(find $OUT/$w -name "*kernel_trace.csv" | head -1)
+  python3 $ROOT/tools/timeline.py $f $OUT/${w}_k1_timeline.csv > /dev/null 2>&1
+  find $OUT/$w -name "*kernel_stats.csv" -exec cp {} $OUT/${w}_k1_kernel_stats.csv \;
+done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3d -o c3d -- python3 $ROOT/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $OUT/c3d.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/av -o av -- python3 $ROOT/bench.py --workload avatar --steps 30 --warmup 5 --no-cpu-baseline > $OUT/av.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr -o tr -- python3 $ROOT/bench.py --workload train --steps 30 --warmup 5 > $OUT/tr.log 2>&1
+find $OUT/c3d -name "*kernel_stats.csv" -exec cp {} $OUT/cfg3_default_kernel_stats.csv \;
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr -o tr -- python3 $ROOT/bench.py --workload train --steps 30 --warmup 5 --eager > $OUT/tr.log 2>&1
+find $OUT/tr -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
+# counters: separate passes
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_$ctr.log 2>&1
+  rocprofv3 --pmc $ctr --output-format csv -d $OUT/avatar/pmc_$ctr -o c3 -- python3 $ROOT/bench.py --workload avatar --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/avatar/pmc_$ctr.log 2>&1
 done
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_SQ -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
-find $OUT -name "*.csv" | head -40
+SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES"
+rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_SQ -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
+rocprofv3 --pmc $SQ --output-format csv -d $OUT/avatar/pmc_SQ -o c3 -- python3 $ROOT/bench.py --workload avatar --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/avatar/pmc_SQ.log 2>&1
 # keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files
-find $OUT -name "*kernel_trace.csv" -size +2M -delete
+find $OUT -name "*kernel_trace.csv" -delete
+find $OUT -name "*.db" -delete
 du -sh $OUT
