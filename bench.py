@@ -581,12 +581,15 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
     if "valu" not in res:
         res["stale"] = why
     try:
-        tj = json.load(open(os.path.join(pdir, "hbm_traffic.json")))
-        st = _meta_status(tj.get("_meta"), cfg, root)
-        if st is None:
-            res["traffic"] = next((v for k, v in tj.items() if k.split("<")[0] == kernel), None)
-        else:
-            res["traffic_stale"] = st
+        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")):
+            tj = json.load(open(os.path.join(pdir, fn)))
+            st = _meta_status(tj.get("_meta"), cfg, root)
+            if st is None:
+                res["traffic"] = next((v for k, v in tj.items() if k.split("<")[0] == kernel), None)
+                res["traffic_source"] = f"profiles/{fn}"
+                res.pop("traffic_stale", None)
+                break
+            res["traffic_stale"] = f"{fn}: {st}"
     except Exception:
         pass
     return res

@@ -96,7 +96,7 @@ static inline size_t sg_align(size_t x) { return (x + 255) & ~(size_t)255; }
 // (d conic.w, d opacity, d colour r, g) as two 16-byte vectors in plane `a`, d colour b as one float in plane `b`.  (Rounds 1-2:
 // three 16-byte vectors, the last one 3/4 padding: 12 B per pair written and read for nothing, 18.7 MB per cfg3 view.)
 struct SgRec { float4 *a; float *b; };
-static inline size_t sg_rec_bytes(size_t cap) { return sg_align((cap + 1) * 32) + sg_align((cap + 1) * 4); }
+static inline size_t sg_rec_bytes(size_t cap) { return sg_align((cap + 1) * 32) + sg_align((cap + 1) * 4 + 16); }     // (+16: plane b is zeroed in 16-byte stores)
 static inline SgRec sg_rec_view(const void *bwd_ws, size_t cap)
 {
     SgRec r;

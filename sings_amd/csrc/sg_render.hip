@@ -416,6 +416,41 @@ __device__ __forceinline__ int sg_red_idx(int lane)
     return base + 4 * half;
 }
 
+// One (entry, quadrant) pass of the backward composite: `ga, gb, gc` the staged record, KPOS the entry's position in the batch
+// (compared with the pixel's contributor count inside the batch, `ncq_b`), KSLOT its row in sG.  `continue` skips entries that
+// touch no pixel of the quadrant.  Shared by sg_render_bwd_kernel and sg_render_bwd_sparse_kernel.
+#define SG_BWD_PASS(KPOS, KSLOT)                                                                                      \
+    /* straight-line, predicated (alpha_eff = 0 makes every update an exact no-op) */                                 \
+    const float dx = ga.x - pxf, dy = ga.y - pyf;                                                                     \
+    const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);   /* the forward's expression: same decisions */         \
+    const float G = __builtin_amdgcn_exp2f(power);                                                                    \
+    const float alpha = fminf(0.99f, gb.y * G);                                                                       \
+    const bool valid = ((KPOS) < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);                                 \
+    if (__ballot(valid) == 0ull) continue;          /* touches no pixel of this quadrant: the slot stays unset */     \
+    const float ae = valid ? alpha : 0.0f;                                                                            \
+    const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      /* rcp(1) == 1 exactly */                               \
+    Tr = Tr * rinv;                                  /* T in front of this entry */                                   \
+    const float dchan = ae * Tr;                                                                                      \
+    /* <colour - colour behind, dL/dpixel>, and the colour behind moves in front of this entry */                     \
+    const float e = fmaf(gc, d2, fmaf(gb.w, d1, gb.z * d0)) - Sd;                                                     \
+    Sd = fmaf(ae, e, Sd);                                                                                             \
+    const float dLa = fmaf(-tb, rinv, e * Tr);      /* + (-T_final / (1 - alpha)) <bg, dL/dpixel> */                  \
+    const float w = valid ? G * dLa : 0.0f;          /* = dL/dopacity contribution; dL/dG = o * dLa */                \
+    /* first and second moments of w over the pixels: dL/dmean is a per-entry combination of the first moments */     \
+    /* (conic . (sum w dx, sum w dy), applied once per record), and so are the factors (-o W/2, -o H/2, -o/2) */      \
+    const float wx = w * dx, wy = w * dy;                                                                             \
+    float v[9];                                                                                                       \
+    v[0] = wx; v[1] = wy;                                                                                             \
+    v[2] = wx * dx; v[3] = wx * dy; v[4] = wy * dy;                                                                   \
+    v[5] = w;                                                                                                         \
+    v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;                                                          \
+    float v8;                                                                                                         \
+    const float z = sg_reduce9(v, lane, &v8);                                                                         \
+    float *slot = &sG[wave][KSLOT][cslot];               /* lanes 0, 8, .., 56: their value's slot; lane 63: slot 8 */\
+    if ((lane & 7) == 0) *slot = z;                                                                                   \
+    if (lane == 63) *slot = v8;                                                                                       \
+    do { } while (0)
+
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
@@ -527,35 +562,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                 const uint32_t k = list[i];
                 const float4 ga = sR[k][0], gb = sR[k][1];
                 const float gc = sR[k][2].x;
-                // straight-line, predicated (alpha_eff = 0 makes every update an exact no-op)
-                const float dx = ga.x - pxf, dy = ga.y - pyf;
-                const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);   // the forward's expression: same decisions
-                const float G = __builtin_amdgcn_exp2f(power);
-                const float alpha = fminf(0.99f, gb.y * G);
-                const bool valid = (k < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);
-                if (__ballot(valid) == 0ull) continue;          // touches no pixel of this quadrant: the slot stays unset
-                const float ae = valid ? alpha : 0.0f;
-                const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      // rcp(1) == 1 exactly
-                Tr = Tr * rinv;                                  // T in front of this entry
-                const float dchan = ae * Tr;
-                // <colour - colour behind, dL/dpixel>, and the colour behind moves in front of this entry
-                const float e = fmaf(gc, d2, fmaf(gb.w, d1, gb.z * d0)) - Sd;
-                Sd = fmaf(ae, e, Sd);
-                const float dLa = fmaf(-tb, rinv, e * Tr);      // + (-T_final / (1 - alpha)) <bg, dL/dpixel>
-                const float w = valid ? G * dLa : 0.0f;          // = dL/dopacity contribution; dL/dG = o * dLa
-                // first and second moments of w over the pixels: dL/dmean is a per-entry combination of the first moments
-                // (conic . (sum w dx, sum w dy), applied once per record), and so are the factors (-o W/2, -o H/2, -o/2)
-                const float wx = w * dx, wy = w * dy;
-                float v[9];
-                v[0] = wx; v[1] = wy;
-                v[2] = wx * dx; v[3] = wx * dy; v[4] = wy * dy;
-                v[5] = w;
-                v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;
-                float v8;
-                const float z = sg_reduce9(v, lane, &v8);
-                float *slot = &sG[wave][k][cslot];               // lanes 0, 8, .., 56: their value's slot; lane 63: slot 8
-                if ((lane & 7) == 0) *slot = z;
-                if (lane == 63) *slot = v8;
+                SG_BWD_PASS(k, k);
             }
         }
         __syncthreads();
@@ -578,6 +585,163 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Backward composite for frames of FEW tiles with long lists (an avatar; the regime of sg_lds_hist).
+//
+// On such a frame the kernel above is not bound by vector issue -- PMC (profiles/r03_avatar_pmc_SQ.csv): 3.1e7 VALU instructions in
+// 118 us = 9.4 cycles per instruction on 1024 SIMDs, against 4.1 at cfg3 -- but by what surrounds the arithmetic:
+//  * 59 % of the list entries of an avatar frame lie behind saturated pixels.  Their work items still ran four batches of
+//    id -> recC gather -> zero record store, because every (tile, Gaussian) record has to exist for the per-Gaussian sums;
+//  * a live item paid the dependent chain id -> recC -> mask -> recA / recB once per 64-entry batch, with 64 of its 256 threads.
+// Here the record buffer is ZEROED first (sg_zero_records_kernel: 36 B x R, ~6 us of streaming stores) and then
+//  * an item whose segment starts behind the tile's deepest contributor returns at once (two loads per thread);
+//  * an item stages its whole segment -- 256 entries, one per thread -- in ONE round: id and mask byte first, the three record
+//    gathers only for entries the forward composited somewhere (mask != 0); entries with an empty mask are never touched again;
+//  * the four 64-entry sub-batches then run out of LDS: compaction, the passes (SG_BWD_PASS: the same arithmetic, bit for bit),
+//    the fixed-order combine and ONE record store per (tile, Gaussian) whose mask is not empty.
+// Results are identical to the kernel above (same passes in the same order; records that kernel writes as zeros stay zero).
+#define SG_BS 256         // entries staged per item (= SG_SEG)
+__global__ void __launch_bounds__(256)
+sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap)
+{
+    const uint32_t R = header[1] ? 0u : (header[0] < cap ? header[0] : cap);
+    const uint32_t n4 = 2u * R + (R + 3u) / 4u;                       // float4 stores: plane a, then plane b (16-byte aligned base)
+    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
+        if (i < 2u * R) grec_a[i] = z;
+        else ((float4 *)grec_b)[i - 2u * R] = z;
+    }
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
+sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
+                            const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
+                            const float4 *__restrict__ recB, const float4 *__restrict__ recC,
+                            const float *__restrict__ bg, const float *__restrict__ final_T,
+                            const uint32_t *__restrict__ n_contrib, const float *__restrict__ dL_dpix,
+                            float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap, const uint32_t *__restrict__ header,
+                            const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
+                            const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
+                            int split_long)
+{
+    __shared__ float4 sR[SG_BS][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
+    __shared__ uint32_t sM[SG_BS];
+    __shared__ uint16_t sList[4][SG_BB];
+    __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the sub-batch; [8] = SG_UNSET: quadrant w wrote nothing
+    __shared__ uint32_t smax[4];
+    (void)T; (void)nblocks;
+    const int nitems = header[1] ? 0 : (int)header[5];
+    const int it = sg_tile_of_block(blockIdx.x);
+    if (it >= nitems) return;
+    const uint32_t item = items[it];
+    const int tile = (int)(item & 0xfffffu), seg = (int)(item >> 20);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = tile % gx, ty = tile / gx;
+    const int X0 = tx * 16, Y0 = ty * 16;
+    const int px = X0 + 8 * (wave & 1) + (lane & 7), py = Y0 + 8 * (wave >> 1) + (lane >> 3);
+    const bool inside = px < W && py < H;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const int n = (int)(range.y - range.x);
+    const uint32_t cks = ck_start[tile];
+    const int lo = seg * SG_SEG;                                   // this item: entries [lo, hi)
+    const int hi = cks != 0xffffffffu && lo + SG_SEG < n ? lo + SG_SEG : n;
+    if (lo >= n) return;
+    const size_t pid = (size_t)py * W + px, hw = (size_t)H * W;
+    const uint32_t ncq = inside ? n_contrib[pid] : 0u;
+    uint32_t m = ncq;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
+    const int maxq = (int)__builtin_amdgcn_readfirstlane(m);          // this quadrant's deepest contributor
+    if (lane == 0) smax[wave] = m;
+    __syncthreads();
+    const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
+    if (lo >= max_contrib) return;                                     // nothing of this segment reached a pixel: its records stay zero
+    // ---- stage the segment: one entry per thread
+    const int cnt = hi - lo;                                           // <= SG_BS
+    uint32_t rslot = 0xffffffffu;
+    float opac = 0.0f, cA = 0.0f, cB = 0.0f, cC = 0.0f;
+    {
+        uint32_t mk = 0u, gid = 0u;
+        const int e = lo + tid;
+        if (tid < cnt && e < max_contrib) {
+            gid = point_list[range.x + e];
+            mk = pair_mask[range.x + e];
+            if (split_long && n > SG_WSORT_MAX)
+                mk = (mk & 1u) | (pair_mask[(size_t)mask_plane + range.x + e] & 2u) | (pair_mask[2 * (size_t)mask_plane + range.x + e] & 4u) |
+                     (pair_mask[3 * (size_t)mask_plane + range.x + e] & 8u);
+            mk &= 15u;
+        }
+        if (mk) {
+            const float4 c4 = recC[gid], a = recA[gid], b = recB[gid];
+            const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
+            const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
+            rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
+            opac = b.y; cA = a.z; cB = a.w; cC = b.x;
+            sR[tid][0] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
+            sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
+            sR[tid][2].x = c4.x;
+        }
+        sM[tid] = mk;
+    }
+    // per-pixel state (requested while the gathers above are in flight)
+    const float Tfin = inside ? final_T[pid] : 0.0f;
+    const float d0 = inside ? dL_dpix[pid] : 0.0f, d1 = inside ? dL_dpix[hw + pid] : 0.0f, d2 = inside ? dL_dpix[2 * hw + pid] : 0.0f;
+    const float tb = Tfin * (bg[0] * d0 + bg[1] * d1 + bg[2] * d2);
+    float Tr = Tfin, Sd = 0.0f;
+    if (hi < n && ncq > (uint32_t)hi && cks + (uint32_t)(hi / SG_SEG) < ck_cap) {       // (see sg_render_bwd_kernel)
+        const float4 cb = ckpt[(size_t)(cks + (uint32_t)(hi / SG_SEG)) * 256 + tid];
+        const float4 cf = ckpt[(size_t)cks * 256 + tid];
+        const float rT = 1.0f / cb.x;
+        Tr = cb.x;
+        Sd = fmaf((cf.w - cb.w) * rT, d2, fmaf((cf.z - cb.z) * rT, d1, (cf.y - cb.y) * rT * d0));
+    }
+    const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    const int cslot = lane == 63 ? 8 : sg_red_idx(lane);
+    __syncthreads();
+    // ---- the sub-batches, back to front, out of LDS
+    for (int sb = (cnt - 1) / SG_BB; sb >= 0; sb--) {
+        const int b0 = sb * SG_BB, base = lo + b0;                      // staged index / list position of the sub-batch's first entry
+        const int bc = cnt - b0 < SG_BB ? cnt - b0 : SG_BB;
+        if (tid < SG_BB) {
+#pragma unroll
+            for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
+        }
+        __syncthreads();
+        if (base < maxq) {
+            uint16_t *list = sList[wave];
+            const int lim = maxq - base < bc ? maxq - base : bc;          // entries >= maxq touch no pixel here
+            const int nl = sg_compact_quadrant<1>(sM + b0, lim, wave, lane, lt, list, SG_BB);
+            const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the sub-batch
+            for (int i = nl - 1; i >= 0; i--) {
+                const uint32_t k = list[i];
+                const float4 ga = sR[b0 + k][0], gb = sR[b0 + k][1];
+                const float gc = sR[b0 + k][2].x;
+                SG_BWD_PASS(k, k);
+            }
+        }
+        __syncthreads();
+        // ---- combine the quadrants in a fixed order and store the record (the thread that staged the entry)
+        if (tid >= b0 && tid < b0 + bc && rslot < cap) {
+            const int q0 = tid - b0;
+            float s9[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (__float_as_uint(sG[w][q0][8]) != SG_UNSET) {
+#pragma unroll
+                    for (int q = 0; q < 9; q++) s9[q] += sG[w][q0][q];
+                }
+            const float no = -opac, nh = 0.5f * no;
+            const float m0 = fmaf(cA, s9[0], cB * s9[1]), m1 = fmaf(cB, s9[0], cC * s9[1]);
+            grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s9[2], nh * s9[3]);
+            grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s9[4], s9[5], s9[6], s9[7]);
+            grec_b[rslot] = s9[8];
+        }
+        __syncthreads();
+    }
+}
+
 void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, SgRec grec, hipStream_t st)
 {
@@ -586,6 +750,15 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     const int grid = sg_render_blocks((int)sg_items_cap((size_t)T, cap));
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     sg_prof_begin(SG_K_RENDER_BWD, st);
+    if (sg_lds_hist(c.gx, c.gy)) {
+        // few tiles, long lists: zero the records, then only the entries the forward composited are touched
+        const uint32_t zg = cap32 / 1024u + 1u < 1024u ? cap32 / 1024u + 1u : 1024u;
+        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg), dim3(256), 0, st, b.header, grec.a, grec.b, cap32);
+        hipLaunchKernelGGL(sg_render_bwd_sparse_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+                           b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
+                           grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
+                           sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0);
+    } else
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                        grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),

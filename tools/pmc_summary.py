@@ -41,7 +41,7 @@ for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
     with open(out, "w") as fo:
         fo.write("kernel,Counter_Name,mean,count\n")
         for (k, c), (s, n) in sorted(acc.items()):
-            fo.write(f"{k},{c},{s / n:.1f},{n}\n")
+            fo.write(f'"{k}",{c},{s / n:.1f},{n}\n')            # (template arguments contain commas)
             means[(k, c)] = s / n
     json.dump(meta, open(out[:-4] + ".meta.json", "w"), indent=1, sort_keys=True)
     print("wrote", out, "+ .meta.json")
@@ -51,5 +51,9 @@ for (k, c) in list(means):
         traffic[k] = int((2 * means[(k, "FETCH_SIZE")] + means[(k, "WRITE_SIZE")]) * 1024)
 if traffic:
     traffic["_meta"] = meta
-    json.dump(traffic, open(os.path.join(root, "profiles", "hbm_traffic.json"), "w"), indent=1, sort_keys=True)
-    print("wrote profiles/hbm_traffic.json", {k: v for k, v in traffic.items() if k != "_meta"})
+    # the headline configuration keeps the historical name; every other configuration gets its own file (bench.py picks the
+    # one whose "_meta" matches the run)
+    default_cfg = {"workload": "raster", "gaussians": 200000, "width": 1920, "height": 1080, "sh_degree": 3}
+    name = "hbm_traffic.json" if config == default_cfg else f"{tag}_hbm_traffic.json"
+    json.dump(traffic, open(os.path.join(root, "profiles", name), "w"), indent=1, sort_keys=True)
+    print(f"wrote profiles/{name}", {k: v for k, v in traffic.items() if k != "_meta"})
