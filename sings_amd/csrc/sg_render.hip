@@ -450,6 +450,40 @@ __device__ __forceinline__ int sg_red_idx(int lane)
     if ((lane & 7) == 0) *slot = z;                                                                                   \
     if (lane == 63) *slot = v8;                                                                                       \
     do { } while (0)
+// the same with the skipped case as a block instead of `continue` (a loop that must still rotate its prefetch registers)
+#define SG_BWD_PASS_BODY(KPOS, KSLOT)                                                                                      \
+    /* straight-line, predicated (alpha_eff = 0 makes every update an exact no-op) */                                 \
+    const float dx = ga.x - pxf, dy = ga.y - pyf;                                                                     \
+    const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);   /* the forward's expression: same decisions */         \
+    const float G = __builtin_amdgcn_exp2f(power);                                                                    \
+    const float alpha = fminf(0.99f, gb.y * G);                                                                       \
+    const bool valid = ((KPOS) < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);                                 \
+    if (__ballot(valid) != 0ull) {                      /* touches no pixel of this quadrant: the slot stays unset */     \
+    const float ae = valid ? alpha : 0.0f;                                                                            \
+    const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      /* rcp(1) == 1 exactly */                               \
+    Tr = Tr * rinv;                                  /* T in front of this entry */                                   \
+    const float dchan = ae * Tr;                                                                                      \
+    /* <colour - colour behind, dL/dpixel>, and the colour behind moves in front of this entry */                     \
+    const float e = fmaf(gc, d2, fmaf(gb.w, d1, gb.z * d0)) - Sd;                                                     \
+    Sd = fmaf(ae, e, Sd);                                                                                             \
+    const float dLa = fmaf(-tb, rinv, e * Tr);      /* + (-T_final / (1 - alpha)) <bg, dL/dpixel> */                  \
+    const float w = valid ? G * dLa : 0.0f;          /* = dL/dopacity contribution; dL/dG = o * dLa */                \
+    /* first and second moments of w over the pixels: dL/dmean is a per-entry combination of the first moments */     \
+    /* (conic . (sum w dx, sum w dy), applied once per record), and so are the factors (-o W/2, -o H/2, -o/2) */      \
+    const float wx = w * dx, wy = w * dy;                                                                             \
+    float v[9];                                                                                                       \
+    v[0] = wx; v[1] = wy;                                                                                             \
+    v[2] = wx * dx; v[3] = wx * dy; v[4] = wy * dy;                                                                   \
+    v[5] = w;                                                                                                         \
+    v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;                                                          \
+    float v8;                                                                                                         \
+    const float z = sg_reduce9(v, lane, &v8);                                                                         \
+    float *slot = &sG[wave][KSLOT][cslot];               /* lanes 0, 8, .., 56: their value's slot; lane 63: slot 8 */\
+    if ((lane & 7) == 0) *slot = z;                                                                                   \
+    if (lane == 63) *slot = v8;                                                                                       \
+    }                                                                                                                 \
+    do { } while (0)
+
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
@@ -613,7 +647,7 @@ sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                             const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                             const float4 *__restrict__ recB, const float4 *__restrict__ recC,
@@ -624,7 +658,12 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
                             const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
                             int split_long)
 {
-    __shared__ float4 sR[SG_BS][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
+    // 19.8 KiB: EIGHT workgroups per CU = 2048 resident work items -- every working item of an avatar frame (~2000 of 3600; the rest
+    // are dead and gone within 2 us) starts at once.  Per-item clocks showed why that matters: a wave's pass takes ~850 cycles
+    // whatever else runs (one wave cannot issue faster), the heaviest items have ~150 passes per wave = 53 us, and with six
+    // workgroups per CU (23 KiB: a 48-byte staged record) 500 items started 10-47 us late and set the kernel time.
+    __shared__ float4 sRa[SG_BS], sRb[SG_BS];  // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1)
+    __shared__ float sRc[SG_BS];               //               colour 2
     __shared__ uint32_t sM[SG_BS];
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the sub-batch; [8] = SG_UNSET: quadrant w wrote nothing
@@ -678,9 +717,9 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
             const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
             opac = b.y; cA = a.z; cB = a.w; cC = b.x;
-            sR[tid][0] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
-            sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
-            sR[tid][2].x = c4.x;
+            sRa[tid] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
+            sRb[tid] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
+            sRc[tid] = c4.x;
         }
         sM[tid] = mk;
     }
@@ -714,11 +753,21 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
             const int lim = maxq - base < bc ? maxq - base : bc;          // entries >= maxq touch no pixel here
             const int nl = sg_compact_quadrant<1>(sM + b0, lim, wave, lane, lt, list, SG_BB);
             const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the sub-batch
+            // software pipeline (as in the forward walk): the record of the entry behind this one is requested before this
+            // entry's arithmetic -- with one wave left on the SIMD the two dependent LDS latencies were a quarter of a pass
+            uint32_t kc = nl > 0 ? list[nl - 1] : 0u, kn = nl > 1 ? list[nl - 2] : kc;     // this entry, the one behind it
+            float4 ga = sRa[b0 + kc], gb = sRb[b0 + kc];
+            float gc = sRc[b0 + kc];
             for (int i = nl - 1; i >= 0; i--) {
-                const uint32_t k = list[i];
-                const float4 ga = sR[b0 + k][0], gb = sR[b0 + k][1];
-                const float gc = sR[b0 + k][2].x;
-                SG_BWD_PASS(k, k);
+                const uint32_t k = kc;
+                const float4 na = sRa[b0 + kn], nb = sRb[b0 + kn];               // record of entry i - 1
+                const float nc = sRc[b0 + kn];
+                const uint32_t k2 = list[i > 1 ? i - 2 : 0];                      // list word of entry i - 2
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    SG_BWD_PASS_BODY(k, k);
+                }
+                ga = na; gb = nb; gc = nc; kc = kn; kn = k2;
             }
         }
         __syncthreads();
