@@ -59,6 +59,8 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_ck_start = o; o = sg_align(o + T * 4);
     L->bin_plan = o; o = sg_align(o + T * 16);
     L->bin_pair_mask = o; o = sg_align(o + 4 * (size_t)sg_mask_plane(cap));     // four planes: sg_split_long
+    L->bin_item_w = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);       // backward work-item weights
+    L->bin_item_perm = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);

@@ -158,14 +158,14 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
                        const float *__restrict__ depth, const uint32_t *__restrict__ start,
                        uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
                        uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
-                       uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap)
+                       uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap, uint32_t *__restrict__ item_w)
 {
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     for (uint32_t tile = gtid; tile < (uint32_t)T; tile += nthreads) {
         const uint4 pl = plan[tile];
         const uint32_t nseg = sg_nseg(pl.w), nit = nseg ? nseg : 1u;
         for (uint32_t sg = 0; sg < nit; sg++)
-            if (pl.x + sg < items_cap) items[pl.x + sg] = tile | (sg << 20);
+            if (pl.x + sg < items_cap) { items[pl.x + sg] = tile | (sg << 20); item_w[pl.x + sg] = 0u; }
         if (pl.w > SG_WSORT_MAX && pl.y < sort_cap) {                                              // (tile, first group slot, first entry, entries)
             const uint32_t s0 = start[tile] < cap ? start[tile] : cap, e0 = start[tile] + pl.w < cap ? start[tile] + pl.w : cap;
             sort_items[pl.y] = make_uint4(tile, pl.z, s0, e0 - s0);
@@ -195,7 +195,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items, int short_lists, unsigned long long *signal)
+                       uint32_t *__restrict__ items, uint32_t *__restrict__ item_w, int short_lists, unsigned long long *signal)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
@@ -263,7 +263,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
             ck_start[t] = q[2] ? run[2] : 0xffffffffu;
             plan[t] = make_uint4(run[1], run[3], run[4], v);
             for (uint32_t sg = 0; sg < q[1]; sg++)
-                if (run[1] + sg < items_cap) items[run[1] + sg] = (uint32_t)t | (sg << 20);
+                if (run[1] + sg < items_cap) { items[run[1] + sg] = (uint32_t)t | (sg << 20); item_w[run[1] + sg] = 0u; }
             if (q[3] && run[3] < sort_cap) sort_items[run[3]] = make_uint4((uint32_t)t, run[4], s, e - s);     // (tile, first group slot, first entry, entries)
         }
         sStart[t] = run[0];
@@ -658,7 +658,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, short_lists, c.count_signal);
+                           b.rank_items, b.items, b.item_w, short_lists, c.count_signal);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -673,7 +673,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
         hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
                            b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
-                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap));
+                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w);
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none

@@ -82,6 +82,9 @@ struct SgBin {
     uint32_t *ck_start;    // [T] first checkpoint slot of a segmented tile
     uint4 *plan;           // [T] (first backward item, first sort item, first rank item, pair count)
     uint8_t *pair_mask;    // [cap] per sorted list entry: quadrants the forward composited it in (0 if it never staged it)
+    uint32_t *item_w;      // [items_cap] weight of a backward work item: the scatter zeroes it, the few-tile forward sets it to the entries
+                           //             of the segment it composited somewhere (split tiles: the largest of the four quadrants)
+    uint32_t *item_perm;   // [items_cap]    ... and the work items by descending weight (sg_zero_records_kernel)
 };
 
 struct SgImg {
@@ -126,6 +129,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.sort_items = (uint4 *)(b + L.bin_sort_items); g.rank_items = (uint2 *)(b + L.bin_rank_items);
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
+    g.item_w = (uint32_t *)(b + L.bin_item_w); g.item_perm = (uint32_t *)(b + L.bin_item_perm);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)

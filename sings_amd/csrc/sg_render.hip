@@ -164,9 +164,10 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
                       float *__restrict__ final_T, uint32_t *__restrict__ n_contrib,                                     \
                       const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,                 \
                       uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,            \
-                      const uint4 *__restrict__ long_items, uint32_t mask_plane
+                      const uint4 *__restrict__ long_items, uint32_t mask_plane, const uint4 *__restrict__ plan,                  \
+                      uint32_t *__restrict__ item_w, uint32_t w_plane
 #define SG_FWD_ARGS W, H, gx, T, nblocks, ranges, pair_keys, point_list, point_keys, recA, recB, recC, bg, out_color, final_T, \
-                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane
+                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane, plan, item_w, w_plane
 template <bool PIPE>
 __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
 {
@@ -215,6 +216,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     // one plane each (bit `part`)
     uint8_t *__restrict__ pmask = pair_mask + (size_t)(split ? part : 0) * mask_plane;
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
+    const uint32_t first_item = PIPE ? plan[tile].x : 0u;             // first backward work item of this tile
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
     bool done = !inside;
@@ -248,18 +250,30 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         }
         if (__syncthreads_count(done) == 256) break;       // also: the previous batch is fully consumed
         const int e = base + tid;
+        bool staged = false;
         if (e < n) {
             sR[tid][0] = make_float4(pa.x, pa.y, SG_KA * pa.z, SG_KB * pa.w);
             sR[tid][1] = make_float4(SG_KA * pb.x, pb.y, pb.z, pb.w);
             sR[tid][2].x = pc;
             const uint32_t mk = sg_quad_mask(pa, pb, (float)X0, (float)Y0, sBox);
             sM[tid] = mk;
+            staged = mk != 0u;
             pmask[range.x + e] = (uint8_t)(split ? (mk ? 1u << part : 0u) : mk);     // the backward composites exactly these (entry, quadrant) pairs
         }
         if (e + SG_FB < n) {
             const uint32_t gid = point_list[range.x + e + SG_FB];
             pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
         }
+        if (PIPE) {
+            // few-tile frames: the weight of the backward work item (tile, this segment) = entries composited somewhere; the
+            // backward starts its heaviest items first (sg_zero_records_kernel sorts them)
+            const int wcount = __syncthreads_count(staged);
+            const uint32_t wi = first_item + (uint32_t)(base / SG_SEG);
+            if (tid == 0 && wi < w_plane) {
+                if (split) atomicMax(&item_w[wi], (uint32_t)wcount);    // four workgroups, one item: its latency is the slowest quadrant's
+                else item_w[wi] = (uint32_t)wcount;
+            }
+        } else
         __syncthreads();
         if (__ballot(done) == ~0ull) continue;             // this quadrant is finished (wave-uniform)
         // state in front of entry `base`, for the backward pass of the segments behind it (SG_FB == SG_SEG)
@@ -363,13 +377,13 @@ void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
-                           (const uint4 *)b.sort_items, sg_mask_plane(cap));
+                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap));
     } else
         hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
-                           (const uint4 *)b.sort_items, sg_mask_plane(cap));
+                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap));
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 
@@ -450,40 +464,6 @@ __device__ __forceinline__ int sg_red_idx(int lane)
     if ((lane & 7) == 0) *slot = z;                                                                                   \
     if (lane == 63) *slot = v8;                                                                                       \
     do { } while (0)
-// the same with the skipped case as a block instead of `continue` (a loop that must still rotate its prefetch registers)
-#define SG_BWD_PASS_BODY(KPOS, KSLOT)                                                                                      \
-    /* straight-line, predicated (alpha_eff = 0 makes every update an exact no-op) */                                 \
-    const float dx = ga.x - pxf, dy = ga.y - pyf;                                                                     \
-    const float power = sg_power2(ga.z, ga.w, gb.x, dx, dy);   /* the forward's expression: same decisions */         \
-    const float G = __builtin_amdgcn_exp2f(power);                                                                    \
-    const float alpha = fminf(0.99f, gb.y * G);                                                                       \
-    const bool valid = ((KPOS) < ncq_b) & !(power > 0.0f) & !(alpha < 1.0f / 255.0f);                                 \
-    if (__ballot(valid) != 0ull) {                      /* touches no pixel of this quadrant: the slot stays unset */     \
-    const float ae = valid ? alpha : 0.0f;                                                                            \
-    const float rinv = __builtin_amdgcn_rcpf(1.0f - ae);      /* rcp(1) == 1 exactly */                               \
-    Tr = Tr * rinv;                                  /* T in front of this entry */                                   \
-    const float dchan = ae * Tr;                                                                                      \
-    /* <colour - colour behind, dL/dpixel>, and the colour behind moves in front of this entry */                     \
-    const float e = fmaf(gc, d2, fmaf(gb.w, d1, gb.z * d0)) - Sd;                                                     \
-    Sd = fmaf(ae, e, Sd);                                                                                             \
-    const float dLa = fmaf(-tb, rinv, e * Tr);      /* + (-T_final / (1 - alpha)) <bg, dL/dpixel> */                  \
-    const float w = valid ? G * dLa : 0.0f;          /* = dL/dopacity contribution; dL/dG = o * dLa */                \
-    /* first and second moments of w over the pixels: dL/dmean is a per-entry combination of the first moments */     \
-    /* (conic . (sum w dx, sum w dy), applied once per record), and so are the factors (-o W/2, -o H/2, -o/2) */      \
-    const float wx = w * dx, wy = w * dy;                                                                             \
-    float v[9];                                                                                                       \
-    v[0] = wx; v[1] = wy;                                                                                             \
-    v[2] = wx * dx; v[3] = wx * dy; v[4] = wy * dy;                                                                   \
-    v[5] = w;                                                                                                         \
-    v[6] = dchan * d0; v[7] = dchan * d1; v[8] = dchan * d2;                                                          \
-    float v8;                                                                                                         \
-    const float z = sg_reduce9(v, lane, &v8);                                                                         \
-    float *slot = &sG[wave][KSLOT][cslot];               /* lanes 0, 8, .., 56: their value's slot; lane 63: slot 8 */\
-    if ((lane & 7) == 0) *slot = z;                                                                                   \
-    if (lane == 63) *slot = v8;                                                                                       \
-    }                                                                                                                 \
-    do { } while (0)
-
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
@@ -635,9 +615,47 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 //    the fixed-order combine and ONE record store per (tile, Gaussian) whose mask is not empty.
 // Results are identical to the kernel above (same passes in the same order; records that kernel writes as zeros stay zero).
 #define SG_BS 256         // entries staged per item (= SG_SEG)
+// Block 0 also ORDERS the backward work items, heaviest first.  Per-item clocks (round 3): a wave's pass takes ~850 cycles
+// whatever else is resident, the heaviest items have ~150 passes per wave (53 us alone), and in list order some of them were
+// dispatched 35-47 us into the kernel -- behind 1500 resident items -- and finished at 115 us while the SIMDs idled (3.1e7
+// VALU instructions in 118 us = 9.4 cycles per instruction).  Weight = entries of the segment the forward composited anywhere
+// (item_w: zeroed by the scatter, written by the forward; a split tile: the largest of its four quadrants); 33 classes,
+// counting sort.  The class of each item is kept in LDS between the two passes and the loads are issued eight at a time:
+// the block has ~4 k items to place while the other blocks stream ~6 us of zeros.
+#define SG_ITEM_CLASSES 33
+__device__ __forceinline__ uint32_t sg_item_class(uint32_t w) { return 32u - (w > 255u ? 32u : (w + 7u) / 8u); }      // 0 = heaviest
 __global__ void __launch_bounds__(256)
-sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap)
+sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap,
+                       const uint32_t *__restrict__ item_w, uint32_t *__restrict__ perm)
 {
+    if (blockIdx.x == 0) {
+        constexpr uint32_t KEEP = 8192u;
+        __shared__ uint32_t sCls[SG_ITEM_CLASSES];
+        __shared__ uint8_t sOf[KEEP];
+        const uint32_t nitems = header[1] ? 0u : header[5];
+        if (threadIdx.x < SG_ITEM_CLASSES) sCls[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t i0 = threadIdx.x; i0 < nitems; i0 += 8u * 256u) {
+            uint32_t w[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const uint32_t i = i0 + 256u * u; w[u] = i < nitems ? item_w[i] : 0u; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const uint32_t i = i0 + 256u * u;
+                if (i < nitems) { const uint32_t cl = sg_item_class(w[u]); if (i < KEEP) sOf[i] = (uint8_t)cl; atomicAdd(&sCls[cl], 1u); }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t run = 0;
+            for (int c = 0; c < SG_ITEM_CLASSES; c++) { const uint32_t v = sCls[c]; sCls[c] = run; run += v; }
+        }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nitems; i += 256u) {
+            const uint32_t cl = i < KEEP ? (uint32_t)sOf[i] : sg_item_class(item_w[i]);
+            perm[atomicAdd(&sCls[cl], 1u)] = i;
+        }
+    }
     const uint32_t R = header[1] ? 0u : (header[0] < cap ? header[0] : cap);
     const uint32_t n4 = 2u * R + (R + 3u) / 4u;                       // float4 stores: plane a, then plane b (16-byte aligned base)
     const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -647,7 +665,7 @@ sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__
     }
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
 sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                             const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                             const float4 *__restrict__ recB, const float4 *__restrict__ recC,
@@ -656,23 +674,17 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
                             float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap, const uint32_t *__restrict__ header,
                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
                             const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
-                            int split_long)
+                            int split_long, const uint32_t *__restrict__ perm)
 {
-    // 19.8 KiB: EIGHT workgroups per CU = 2048 resident work items -- every working item of an avatar frame (~2000 of 3600; the rest
-    // are dead and gone within 2 us) starts at once.  Per-item clocks showed why that matters: a wave's pass takes ~850 cycles
-    // whatever else runs (one wave cannot issue faster), the heaviest items have ~150 passes per wave = 53 us, and with six
-    // workgroups per CU (23 KiB: a 48-byte staged record) 500 items started 10-47 us late and set the kernel time.
-    __shared__ float4 sRa[SG_BS], sRb[SG_BS];  // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1)
-    __shared__ float sRc[SG_BS];               //               colour 2
+    __shared__ float4 sR[SG_BS][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_BS];
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the sub-batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
     (void)T; (void)nblocks;
     const int nitems = header[1] ? 0 : (int)header[5];
-    const int it = sg_tile_of_block(blockIdx.x);
-    if (it >= nitems) return;
-    const uint32_t item = items[it];
+    if ((int)blockIdx.x >= nitems) return;
+    const uint32_t item = items[perm[blockIdx.x]];                  // dispatch order = heaviest first
     const int tile = (int)(item & 0xfffffu), seg = (int)(item >> 20);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
@@ -717,9 +729,9 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
             const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
             opac = b.y; cA = a.z; cB = a.w; cC = b.x;
-            sRa[tid] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
-            sRb[tid] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
-            sRc[tid] = c4.x;
+            sR[tid][0] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
+            sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
+            sR[tid][2].x = c4.x;
         }
         sM[tid] = mk;
     }
@@ -753,21 +765,11 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
             const int lim = maxq - base < bc ? maxq - base : bc;          // entries >= maxq touch no pixel here
             const int nl = sg_compact_quadrant<1>(sM + b0, lim, wave, lane, lt, list, SG_BB);
             const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the sub-batch
-            // software pipeline (as in the forward walk): the record of the entry behind this one is requested before this
-            // entry's arithmetic -- with one wave left on the SIMD the two dependent LDS latencies were a quarter of a pass
-            uint32_t kc = nl > 0 ? list[nl - 1] : 0u, kn = nl > 1 ? list[nl - 2] : kc;     // this entry, the one behind it
-            float4 ga = sRa[b0 + kc], gb = sRb[b0 + kc];
-            float gc = sRc[b0 + kc];
             for (int i = nl - 1; i >= 0; i--) {
-                const uint32_t k = kc;
-                const float4 na = sRa[b0 + kn], nb = sRb[b0 + kn];               // record of entry i - 1
-                const float nc = sRc[b0 + kn];
-                const uint32_t k2 = list[i > 1 ? i - 2 : 0];                      // list word of entry i - 2
-                __builtin_amdgcn_sched_barrier(0);
-                {
-                    SG_BWD_PASS_BODY(k, k);
-                }
-                ga = na; gb = nb; gc = nc; kc = kn; kn = k2;
+                const uint32_t k = list[i];
+                const float4 ga = sR[b0 + k][0], gb = sR[b0 + k][1];
+                const float gc = sR[b0 + k][2].x;
+                SG_BWD_PASS(k, k);
             }
         }
         __syncthreads();
@@ -802,11 +804,11 @@ void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg i
     if (sg_lds_hist(c.gx, c.gy)) {
         // few tiles, long lists: zero the records, then only the entries the forward composited are touched
         const uint32_t zg = cap32 / 1024u + 1u < 1024u ? cap32 / 1024u + 1u : 1024u;
-        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg), dim3(256), 0, st, b.header, grec.a, grec.b, cap32);
+        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg), dim3(256), 0, st, b.header, grec.a, grec.b, cap32, b.item_w, b.item_perm);
         hipLaunchKernelGGL(sg_render_bwd_sparse_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                            grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
-                           sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0);
+                           sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0, b.item_perm);
     } else
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
