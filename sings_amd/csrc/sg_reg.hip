@@ -404,6 +404,15 @@ __device__ __forceinline__ void sg_knn_merge_group(float best[K])
         for (int k = 0; k < K; k++) sg_knn_insert<K>(other[k], best);
     }
 }
+#ifdef SG_KNN_ACCOUNT
+// accounting build (tools/knn_account.sh): per point (rows iterated, rows searched, cell look-ups, candidates, inserts, rings,
+// fine grid used, candidates of the busiest of its lanes)
+__device__ uint32_t *sg_knn_acct;
+extern "C" int sg_debug_knn_account(uint32_t *dev_buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(sg_knn_acct), &dev_buf, sizeof(dev_buf)); }
+#define SG_ACCT(q, n) acct[q] += (n)
+#else
+#define SG_ACCT(q, n) do { } while (0)
+#endif
 template <int K>
 __global__ void __launch_bounds__(256)
 sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__restrict__ grid_c,
@@ -416,7 +425,13 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
     // the current ring (`mine`), the lists are merged at the end of the ring into `best` (identical in the group).
     // 150k / 500k avatar points, whole k-NN: 1 lane 450 / 1 465 us, 4 lanes 353 / 1 048, 8 lanes 394 / 1 057, 16 lanes
     // 461 / 1 376.  (Dealing the CANDIDATES of a row to 8 lanes instead left the chain as long as it was: no gain.  Cell
-    // look-ups of three rows issued together + the next four candidates in flight during the inserts: 15 % slower.)
+    // look-ups of three rows issued together + the next four candidates in flight during the inserts: 15 % slower.
+    // Round 3, tools/knn_account.py: a point costs 131 distance evaluations, 21 cell look-ups and 52 inserts in 2.2 rings --
+    // 2.3 KB gathered for 128 B of neighbours -- and the busiest lane of a point evaluates 60 candidates (its share would be
+    // 33; 1 359 for the worst point).  Searching the runs of a round of four rows with ALL four lanes, candidates
+    // interleaved, evened that out (busiest lane 37 on average, 562 at worst) and was SLOWER, 366 vs 335 us at 150k and
+    // 1 204 vs 999 us at 500k: every run became its own load round-trip in every lane.  The kernel's time is the number
+    // of dependent round-trips a wave makes, not the candidates of its busiest lane.)
     const int gid = blockIdx.x * 256 + threadIdx.x, j = gid & (SG_KNN_SUB - 1);
     const int s = min(gid / SG_KNN_SUB, N - 1);                  // (the tail group repeats the last point: harmless)
     const float4 p = sorted_c[s];
@@ -431,6 +446,9 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
     }
     const float cx = (p.x - g.lo[0]) * g.inv_h, cy = (p.y - g.lo[1]) * g.inv_h, cz = (p.z - g.lo[2]) * g.inv_h;
     float best[K], mine[K];
+#ifdef SG_KNN_ACCOUNT
+    uint32_t acct[8] = { 0, 0, 0, 0, 0, 0, sorted == sorted_f ? 1u : 0u, 0 };
+#endif
 #pragma unroll
     for (int k = 0; k < K; k++) { best[k] = 3e38f; mine[k] = 3e38f; }
     const int rmax = max(max(g.dim[0], g.dim[1]), g.dim[2]);
@@ -449,7 +467,9 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
             const float ey = fmaxf(fmaxf((float)y - cy, cy - (float)(y + 1)), 0.0f);
             const float lim = fminf(best[K - 1], mine[K - 1]) * inv_h2;
             const float dyz = (ey * ey + ez * ez) * 0.999f;
+            SG_ACCT(0, 1);
             if (dyz >= lim) continue;
+            SG_ACCT(1, 1);
             const bool shell_row = (abs(z - c0[2]) == r) || (abs(y - c0[1]) == r);
             const uint32_t row = (uint32_t)((z * g.dim[1] + y) * g.dim[0]);
             if (shell_row) {
@@ -464,15 +484,16 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
                 const uint2 ca = cells[row + xa], cb = cells[row + xb];
                 uint32_t t = ca.x;
                 const uint32_t e = cb.x + cb.y;
+                SG_ACCT(2, 2); SG_ACCT(3, e - t);
                 for (; t + 4 <= e; t += 4) {
                     const float4 q0 = sorted[t], q1 = sorted[t + 1], q2 = sorted[t + 2], q3 = sorted[t + 3];
                     const float d0 = sg_d2(q0, p), d1 = sg_d2(q1, p), d2 = sg_d2(q2, p), d3 = sg_d2(q3, p);
-                    if (d0 < best[K - 1]) sg_knn_insert<K>(d0, mine);
-                    if (d1 < best[K - 1]) sg_knn_insert<K>(d1, mine);
-                    if (d2 < best[K - 1]) sg_knn_insert<K>(d2, mine);
-                    if (d3 < best[K - 1]) sg_knn_insert<K>(d3, mine);
+                    if (d0 < best[K - 1]) { SG_ACCT(4, d0 < mine[K - 1]); sg_knn_insert<K>(d0, mine); }
+                    if (d1 < best[K - 1]) { SG_ACCT(4, d1 < mine[K - 1]); sg_knn_insert<K>(d1, mine); }
+                    if (d2 < best[K - 1]) { SG_ACCT(4, d2 < mine[K - 1]); sg_knn_insert<K>(d2, mine); }
+                    if (d3 < best[K - 1]) { SG_ACCT(4, d3 < mine[K - 1]); sg_knn_insert<K>(d3, mine); }
                 }
-                for (; t < e; t++) { const float d = sg_d2(sorted[t], p); if (d < best[K - 1]) sg_knn_insert<K>(d, mine); }
+                for (; t < e; t++) { const float d = sg_d2(sorted[t], p); if (d < best[K - 1]) { SG_ACCT(4, d < mine[K - 1]); sg_knn_insert<K>(d, mine); } }
             } else {
                 // interior row: only the two end cells (if they are at distance r in x)
                 for (int side = 0; side < 2; side++) {
@@ -481,14 +502,16 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
                     const float ex = fmaxf(fmaxf((float)x - cx, cx - (float)(x + 1)), 0.0f);
                     if (dyz + ex * ex * 0.999f >= fminf(best[K - 1], mine[K - 1]) * inv_h2) continue;
                     const uint2 cc = cells[row + x];
+                    SG_ACCT(2, 1); SG_ACCT(3, cc.y);
                     for (uint32_t t = cc.x; t < cc.x + cc.y; t++) {
                         const float d = sg_d2(sorted[t], p);
-                        if (d < best[K - 1]) sg_knn_insert<K>(d, mine);
+                        if (d < best[K - 1]) { SG_ACCT(4, d < mine[K - 1]); sg_knn_insert<K>(d, mine); }
                     }
                 }
             }
         }
         // this ring's candidates: K best of the group's lists, then into the running list; the lanes' lists start empty again
+        SG_ACCT(5, j == 0);
         sg_knn_merge_group<K>(mine);
 #pragma unroll
         for (int k = 0; k < K; k++) { sg_knn_insert<K>(mine[k], best); mine[k] = 3e38f; }
@@ -509,6 +532,14 @@ sg_knn_query_kernel(int N, const float4 *__restrict__ sorted_c, const SgGrid *__
 #pragma unroll
     for (int k = 1; k < K; k++) m += sqrtf(best[k]);
     if (j == 0 && gid / SG_KNN_SUB < N) mean_edge[__float_as_uint(p.w)] = m / (float)(K - 1);
+#ifdef SG_KNN_ACCOUNT
+    if (sg_knn_acct && gid / SG_KNN_SUB < N) {
+        uint32_t *o = sg_knn_acct + 8 * (size_t)__float_as_uint(p.w);
+        for (int q = 0; q < 6; q++) atomicAdd(&o[q], acct[q]);
+        if (j == 0) o[6] = acct[6];
+        atomicMax(&o[7], acct[3]);
+    }
+#endif
 }
 
 // loss = mean((s_i - l_i)^2), dL/ds_i = 2 (s_i - l_i) / N   (edge lengths are detached in the reference)

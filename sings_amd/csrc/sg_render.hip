@@ -684,7 +684,8 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
     (void)T; (void)nblocks;
     const int nitems = header[1] ? 0 : (int)header[5];
     if ((int)blockIdx.x >= nitems) return;
-    const uint32_t item = items[perm[blockIdx.x]];                  // dispatch order = heaviest first
+    const uint32_t pit = perm[blockIdx.x];
+    const uint32_t item = items[pit];                               // dispatch order = heaviest first
     const int tile = (int)(item & 0xfffffu), seg = (int)(item >> 20);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int tx = tile % gx, ty = tile / gx;
