@@ -44,6 +44,10 @@ done
 SQ="SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_BUSY_CYCLES"
 rocprofv3 --pmc $SQ --output-format csv -d $OUT/pmc_SQ -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_SQ.log 2>&1
 rocprofv3 --pmc $SQ --output-format csv -d $OUT/avatar/pmc_SQ -o c3 -- python3 $ROOT/bench.py --workload avatar --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/avatar/pmc_SQ.log 2>&1
+# how busy the vector ALUs are (quad-cycles with a VALU instruction executing, against wave and wait cycles)
+SQ2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
+rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/pmc_SQ2 -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_SQ2.log 2>&1
+rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/avatar/pmc_SQ2 -o c3 -- python3 $ROOT/bench.py --workload avatar --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/avatar/pmc_SQ2.log 2>&1
 # keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete

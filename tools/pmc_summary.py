@@ -27,7 +27,7 @@ def short(name):
 
 
 means = {}
-for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
     f = os.path.join(src, f"pmc_{cset}", "c3_counter_collection.csv")
     if not os.path.exists(f):
         continue
