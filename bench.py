@@ -554,6 +554,12 @@ def _meta_status(meta, cfg, root=ROOT):
     return None
 
 
+# kernels behind one event bracket of the library's profiler (sg_profile_collect): few-tile frames take the deep forward and
+# zero the records + run the sparse backward inside the "sg_render_bwd_kernel" bracket
+KERNEL_VARIANTS = {"sg_render_fwd_kernel": ("sg_render_fwd_kernel", "sg_render_fwd_deep_kernel"),
+                   "sg_render_bwd_kernel": ("sg_render_bwd_kernel", "sg_render_bwd_sparse_kernel", "sg_zero_records_kernel")}
+
+
 def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
     """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of THIS configuration
     (profiles/<tag>_pmc_SQ.csv + <tag>_pmc_SQ.meta.json, profiles/hbm_traffic.json with its "_meta"; tools/pmc_summary.py writes
@@ -573,9 +579,13 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
             if st is not None:
                 why = f"profiles/{fn}: {st}"
                 continue
-            for r in csv.DictReader(open(os.path.join(pdir, fn))):
-                if r["kernel"].split("<")[0] == kernel and r["Counter_Name"] == "SQ_INSTS_VALU":
-                    res["valu"], res["valu_source"] = float(r["mean"]), f"profiles/{fn}"
+            names = KERNEL_VARIANTS.get(kernel, (kernel,))
+            got = [float(r["mean"]) for r in csv.DictReader(open(os.path.join(pdir, fn)))
+                   if r["kernel"].split("<")[0] in names and r["Counter_Name"] == "SQ_INSTS_VALU"]
+            if got:
+                res["valu"], res["valu_source"] = sum(got), f"profiles/{fn}"
+            else:
+                why = f"profiles/{fn}: no SQ_INSTS_VALU row for {kernel}"
     except Exception as e:
         why = f"{type(e).__name__}: {e}"
     if "valu" not in res:
@@ -585,7 +595,8 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
             tj = json.load(open(os.path.join(pdir, fn)))
             st = _meta_status(tj.get("_meta"), cfg, root)
             if st is None:
-                res["traffic"] = next((v for k, v in tj.items() if k.split("<")[0] == kernel), None)
+                got = [v for k, v in tj.items() if k.split("<")[0] in KERNEL_VARIANTS.get(kernel, (kernel,))]
+                res["traffic"] = sum(got) if got else None
                 res["traffic_source"] = f"profiles/{fn}"
                 res.pop("traffic_stale", None)
                 break

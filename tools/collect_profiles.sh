@@ -48,6 +48,17 @@ rocprofv3 --pmc $SQ --output-format csv -d $OUT/avatar/pmc_SQ -o c3 -- python3 $
 SQ2="SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY"
 rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/pmc_SQ2 -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_SQ2.log 2>&1
 rocprofv3 --pmc $SQ2 --output-format csv -d $OUT/avatar/pmc_SQ2 -o c3 -- python3 $ROOT/bench.py --workload avatar --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/avatar/pmc_SQ2.log 2>&1
+# the other raster configurations the bench is run on: instruction counts and HBM traffic for their rooflines
+#   python tools/pmc_summary.py gpurun_out/prof_r03/cfg2 r03_cfg2 gaussians=50000 width=512 height=512 sh_degree=0
+#   python tools/pmc_summary.py gpurun_out/prof_r03/cfg5 r03_cfg5 gaussians=500000 width=2048 height=2048
+CFG2="--gaussians 50000 --width 512 --height 512 --sh-degree 0 --forward-only"
+CFG5="--gaussians 500000 --width 2048 --height 2048"
+for ctr in FETCH_SIZE WRITE_SIZE SQ; do
+  set=$ctr; [ $ctr = SQ ] && set="$SQ"
+  mkdir -p $OUT/cfg2 $OUT/cfg5
+  rocprofv3 --pmc $set --output-format csv -d $OUT/cfg2/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG2 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg2/pmc_$ctr.log 2>&1
+  rocprofv3 --pmc $set --output-format csv -d $OUT/cfg5/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG5 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg5/pmc_$ctr.log 2>&1
+done
 # keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
