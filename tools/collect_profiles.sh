@@ -36,6 +36,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/c3d -o c3d -- pytho
 find $OUT/c3d -name "*kernel_stats.csv" -exec cp {} $OUT/cfg3_default_kernel_stats.csv \;
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr -o tr -- python3 $ROOT/bench.py --workload train --steps 30 --warmup 5 --eager > $OUT/tr.log 2>&1
 find $OUT/tr -name "*kernel_stats.csv" -exec cp {} $OUT/train_kernel_stats.csv \;
+# one graph-replayed training step as a timeline (which kernels overlap, who waits for whom)
+rocprofv3 --kernel-trace --output-format csv -d $OUT/train_trace -o tt -- python3 $ROOT/bench.py --workload train --steps 10 --warmup 3 > $OUT/train_trace.log 2>&1
+python3 $ROOT/tools/step_trace.py $(find $OUT/train_trace -name "*kernel_trace.csv" | head -1) > $OUT/train_step_trace.log 2>&1
 # counters: separate passes
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$ctr -o c3 -- python3 $ROOT/bench.py --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/pmc_$ctr.log 2>&1
