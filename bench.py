@@ -112,6 +112,9 @@ def parse_args():
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
                     help="train workload: weight-gradient kernels on the backward stream instead of a side stream")
+    ap.add_argument("--join-regularisers-early", action="store_true",
+                    help="train workload: round-2 schedule (the regularisers' stream forks after the decode and joins before the "
+                         "loss sum; default: grids early, k-NN query behind the raster forward, join in the backward pass)")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
@@ -807,7 +810,8 @@ def main_train(a):
         geo.scales[2].bias.fill_(-5.3); geo.scales[2].weight.mul_(0.1)
         geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()
     step_mod = AvatarStep(t(s["xyz_canon"]), t(s["lbs_weights"]), tri, geo, app, l2_norm=L2Norm(),
-                          gaussian_connect=GaussiansEdgeLoss(), gaussian_connect_w=1.0).to(dev)
+                          gaussian_connect=GaussiansEdgeLoss(), gaussian_connect_w=1.0,
+                          defer_regulariser_join=not a.join_regularisers_early).to(dev)
     params = [p for p in step_mod.parameters() if p.requires_grad]
     gt_rgb = torch.rand((3, H, W), device=dev)
     yy, xx = torch.meshgrid(torch.arange(H, device=dev), torch.arange(W, device=dev), indexing="ij")
@@ -836,7 +840,10 @@ def main_train(a):
         for p in params:
             p.grad = None
         loss, ld, ex = step_mod(A_static, rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
-        loss.backward()
+        if loss is None:                                            # two roots: the regularisers join where their gradient is consumed
+            step_mod.backward(ld, ex)
+        else:
+            loss.backward()
         keys = list(ld.keys())                                      # (no autograd graph kept alive across the end of a capture;
         vals = torch.stack([ld[k].detach().reshape(()) for k in keys])   # one launch for all the scalars)
         return {k: vals[i] for i, k in enumerate(keys)}

@@ -310,6 +310,13 @@ int sg_l2norm_reg(int N, const float *xyz_offsets, const float *scales, const fl
 size_t sg_knn_ws_bytes(int N);
 int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out,
                           float *loss, const float *upstream, float *d_scales, void *stream);
+/* The same in two calls on the same workspace, for callers that schedule the halves themselves: `prepare` builds the two
+ * search grids over xyz (fifteen small, latency-bound launches), `finish` runs the neighbour query -- one kernel that fills
+ * the GPU for ~0.25 ms at 150 k points -- and the loss.  Nothing else may use `ws` in between; the two calls may be on
+ * different streams if the caller orders them (event).  sg_gaussian_edge_loss == prepare + finish on one stream. */
+int sg_gaussian_edge_prepare(int N, const float *xyz, void *ws, void *stream);
+int sg_gaussian_edge_finish(int N, int K, const float *scales, void *ws, float *mean_edge_out, float *loss,
+                            const float *upstream, float *d_scales, void *stream);
 
 /* ---- attribute decode ---------------------------------------------------------------------
  * Multi-resolution tri-plane features: HexPlaneField.forward (sings/rec/models/modules/hexplane.py:46-105,163-190):

@@ -646,6 +646,22 @@ extern "C" int sg_gaussian_edge_loss(int N, int K, const float *xyz, const float
     SG_RET_LAST("sg_gaussian_edge_loss");
 }
 
+extern "C" int sg_gaussian_edge_prepare(int N, const float *xyz, void *ws, void *stream)
+{
+    if (N < 1 || !xyz || !ws) return sg_fail("sg_gaussian_edge_prepare: bad argument", hipSuccess);
+    sg_launch_knn_prepare(N, xyz, ws, (hipStream_t)stream);
+    SG_RET_LAST("sg_gaussian_edge_prepare");
+}
+
+extern "C" int sg_gaussian_edge_finish(int N, int K, const float *scales, void *ws, float *mean_edge_out, float *loss,
+                                       const float *upstream, float *d_scales, void *stream)
+{
+    if (N < K || !ws) return sg_fail("sg_gaussian_edge_finish: bad argument (need N >= K)", hipSuccess);
+    if (sg_launch_knn_finish(N, K, scales, ws, mean_edge_out, loss, upstream, d_scales, (hipStream_t)stream))
+        return sg_fail("sg_gaussian_edge_finish: K must be 5, 9 or 17", hipSuccess);
+    SG_RET_LAST("sg_gaussian_edge_finish");
+}
+
 // ---- per-kernel event timing ------------------------------------------------------------
 __global__ void __launch_bounds__(256) sg_zero_kernel(uint32_t *__restrict__ p, size_t words)
 {

@@ -222,6 +222,9 @@ void sg_launch_mesh_edge(int V, int E, const float *x, const int *row_ptr, const
                          const float *upstream, float *dL_dx, hipStream_t st);
 void sg_launch_l2norm(int N, const float *off, const float *scales, const float *opacity, const float *lambdas6, void *ws,
                       float *loss, const float *upstream, float *d_off, float *d_scales, float *d_opacity, hipStream_t st);
+void sg_launch_knn_prepare(int N, const float *xyz, void *ws, hipStream_t st);
+int sg_launch_knn_finish(int N, int K, const float *scales, void *ws, float *mean_edge_out, float *loss, const float *upstream,
+                         float *d_scales, hipStream_t st);
 int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
                        const float *upstream, float *d_scales, hipStream_t st);
 void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,

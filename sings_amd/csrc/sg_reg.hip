@@ -614,47 +614,67 @@ size_t sg_knn_ws_bytes_impl(int N)
     return sg_align((size_t)sg_nb(N) * 32) + sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4) + sg_align(n * 4) +
            sg_knn_grid_bytes(n, sg_knn_max_cells(N)) + sg_knn_grid_bytes(n, sg_knn_max_cells_fine(N));
 }
-struct SgKnnGrid { SgGrid *grid; float4 *sorted; uint2 *cells; };
-// bounding box partials -> grid -> counting sort of the points by cell
-static int sg_knn_build(int N, const float *xyz, const float *bpart, size_t mc, char *&b, SgKnnGrid *out, hipStream_t st)
+struct SgKnnGrid { SgGrid *grid; float4 *sorted; uint2 *cells; uint32_t *cell_of, *rank_in, *count, *start, *bsum; size_t mc; };
+// where one grid's arrays live in the workspace (no launches)
+static void sg_knn_grid_at(int N, size_t mc, char *&b, SgKnnGrid *g)
 {
     const size_t n = N;
-    SgGrid *grid = (SgGrid *)b; b += 256;
-    uint32_t *cell_of = (uint32_t *)b; b += sg_align(n * 4);
-    uint32_t *rank_in = (uint32_t *)b; b += sg_align(n * 4);
-    float4 *sorted = (float4 *)b; b += sg_align(n * 16);
-    uint32_t *count = (uint32_t *)b; b += sg_align(mc * 4);
-    uint32_t *start = (uint32_t *)b; b += sg_align(mc * 4);
-    uint32_t *bsum = (uint32_t *)b; b += sg_align(((mc + 1023) / 1024) * 4);
-    uint2 *cells = (uint2 *)b; b += sg_align(mc * 8);
-    const int nb = sg_nb(N), ncb = (int)((mc + 1023) / 1024);
-    hipLaunchKernelGGL(sg_grid_setup_kernel, dim3(1), dim3(256), 0, st, bpart, nb, N, (int)mc, grid);
-    sg_zero_async(count, mc * 4, st);
-    hipLaunchKernelGGL(sg_cell_count_kernel, dim3(nb), dim3(256), 0, st, N, xyz, grid, cell_of, rank_in, count);
-    hipLaunchKernelGGL(sg_cells_scan1_kernel, dim3(ncb), dim3(256), 0, st, grid, count, start, bsum);
-    hipLaunchKernelGGL(sg_cells_scan2_kernel, dim3(1), dim3(1024), 0, st, grid, bsum);
-    hipLaunchKernelGGL(sg_cell_scatter_kernel, dim3(nb), dim3(256), 0, st, N, xyz, cell_of, rank_in, start, bsum, sorted);
-    hipLaunchKernelGGL(sg_cells_finalize_kernel, dim3((unsigned)((mc + 255) / 256)), dim3(256), 0, st, grid, count, start, bsum, cells);
-    out->grid = grid; out->sorted = sorted; out->cells = cells;
-    return 0;
+    g->mc = mc;
+    g->grid = (SgGrid *)b; b += 256;
+    g->cell_of = (uint32_t *)b; b += sg_align(n * 4);
+    g->rank_in = (uint32_t *)b; b += sg_align(n * 4);
+    g->sorted = (float4 *)b; b += sg_align(n * 16);
+    g->count = (uint32_t *)b; b += sg_align(mc * 4);
+    g->start = (uint32_t *)b; b += sg_align(mc * 4);
+    g->bsum = (uint32_t *)b; b += sg_align(((mc + 1023) / 1024) * 4);
+    g->cells = (uint2 *)b; b += sg_align(mc * 8);
+}
+struct SgKnnWs { float *bpart, *partial, *medge; SgKnnGrid gc, gf; };
+static SgKnnWs sg_knn_ws_at(int N, void *ws)
+{
+    const size_t n = N;
+    SgKnnWs w;
+    char *b = (char *)ws;
+    w.bpart = (float *)b; b += sg_align((size_t)sg_nb(N) * 32);
+    w.partial = (float *)b; b += sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4);
+    w.medge = (float *)b; b += sg_align(n * 4);
+    sg_knn_grid_at(N, sg_knn_max_cells(N), b, &w.gc);
+    sg_knn_grid_at(N, sg_knn_max_cells_fine(N), b, &w.gf);
+    return w;
+}
+// bounding box partials -> grid -> counting sort of the points by cell
+static void sg_knn_build(int N, const float *xyz, const float *bpart, const SgKnnGrid &g, hipStream_t st)
+{
+    const int nb = sg_nb(N), ncb = (int)((g.mc + 1023) / 1024);
+    hipLaunchKernelGGL(sg_grid_setup_kernel, dim3(1), dim3(256), 0, st, bpart, nb, N, (int)g.mc, g.grid);
+    sg_zero_async(g.count, g.mc * 4, st);
+    hipLaunchKernelGGL(sg_cell_count_kernel, dim3(nb), dim3(256), 0, st, N, xyz, g.grid, g.cell_of, g.rank_in, g.count);
+    hipLaunchKernelGGL(sg_cells_scan1_kernel, dim3(ncb), dim3(256), 0, st, g.grid, g.count, g.start, g.bsum);
+    hipLaunchKernelGGL(sg_cells_scan2_kernel, dim3(1), dim3(1024), 0, st, g.grid, g.bsum);
+    hipLaunchKernelGGL(sg_cell_scatter_kernel, dim3(nb), dim3(256), 0, st, N, xyz, g.cell_of, g.rank_in, g.start, g.bsum, g.sorted);
+    hipLaunchKernelGGL(sg_cells_finalize_kernel, dim3((unsigned)((g.mc + 255) / 256)), dim3(256), 0, st, g.grid, g.count, g.start, g.bsum, g.cells);
 }
 
-int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
-                       const float *upstream, float *d_scales, hipStream_t st)
+// first half: the two grids over the cloud (fifteen small launches); second half: the query + the loss.  One call does both
+// (sg_gaussian_edge_loss); a caller that wants the latency-bound grid builds early and the GPU-filling query later -- beside
+// kernels with idle issue slots instead of beside a chain of small ones -- makes the two calls itself on the same workspace.
+void sg_launch_knn_prepare(int N, const float *xyz, void *ws, hipStream_t st)
+{
+    const SgKnnWs w = sg_knn_ws_at(N, ws);
+    hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(sg_nb(N)), dim3(256), 0, st, N, xyz, w.bpart);
+    sg_knn_build(N, xyz, w.bpart, w.gc, st);
+    sg_knn_build(N, xyz, w.bpart, w.gf, st);
+}
+int sg_launch_knn_finish(int N, int K, const float *scales, void *ws, float *mean_edge_out, float *loss, const float *upstream,
+                         float *d_scales, hipStream_t st)
 {
     if (K != 9 && K != 5 && K != 17) return 1;
-    const size_t n = N;
-    char *b = (char *)ws;
-    float *bpart = (float *)b; b += sg_align((size_t)sg_nb(N) * 32);
-    float *partial = (float *)b; b += sg_align((size_t)sg_nb(N) * SG_RED_MAXQ * 4);
-    float *medge = mean_edge_out ? mean_edge_out : (float *)b;
-    b += sg_align(n * 4);
+    const SgKnnWs w = sg_knn_ws_at(N, ws);
+    const SgKnnGrid &gc = w.gc, &gf = w.gf;
+    float *medge = mean_edge_out ? mean_edge_out : w.medge;
+    float *partial = w.partial;
     const int nb = sg_nb(N);
-    hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(nb), dim3(256), 0, st, N, xyz, bpart);
-    SgKnnGrid gc, gf;
     const int nbq = (int)(((size_t)N * SG_KNN_SUB + 255) / 256);
-    if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells(N), b, &gc, st)) return 2;
-    if (sg_knn_build(N, xyz, bpart, sg_knn_max_cells_fine(N), b, &gf, st)) return 2;
     if (K == 9) hipLaunchKernelGGL(sg_knn_query_kernel<9>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
     else if (K == 5) hipLaunchKernelGGL(sg_knn_query_kernel<5>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
     else hipLaunchKernelGGL(sg_knn_query_kernel<17>, dim3(nbq), dim3(256), 0, st, N, gc.sorted, gc.grid, gc.cells, gf.sorted, gf.grid, gf.cells, medge);
@@ -663,4 +683,11 @@ int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void
         if (loss) hipLaunchKernelGGL(sg_scalar_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f / (float)N, loss);
     }
     return 0;
+}
+int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
+                       const float *upstream, float *d_scales, hipStream_t st)
+{
+    if (K != 9 && K != 5 && K != 17) return 1;
+    sg_launch_knn_prepare(N, xyz, ws, st);
+    return sg_launch_knn_finish(N, K, scales, ws, mean_edge_out, loss, upstream, d_scales, st);
 }

@@ -103,7 +103,14 @@ class GaussiansEdgeLoss(torch.nn.Module):
         super().__init__()
         self._K, self._eps = K, eps
 
-    def forward(self, human_gs_out):
+    def prepare(self, human_gs_out):
+        """First half on the current stream: the two search grids over the points (small, latency-bound launches), the output
+        buffers and the autograd node.  Returns the loss tensor -- its VALUE (and the gradient the node hands back) arrives
+        with `finish()`, which runs the neighbour query and the loss on the stream that is current THEN (the caller orders
+        the two streams).  A trainer builds the grids as soon as the positions exist and holds the query -- one kernel that
+        fills the GPU -- until it can run beside kernels with idle issue slots; creating the node early keeps it BEHIND the
+        rasterizer's node in autograd's execution order, so that the backward composite is not held up by the hand-over of
+        this gradient (`sings_amd.train_step.AvatarStep`)."""
         lib = _lib.load()
         verts = human_gs_out['xyz_canon'].detach().contiguous().float()      # edge lengths are detached (:75)
         sc = human_gs_out['scales'].contiguous().float()
@@ -113,9 +120,23 @@ class GaussiansEdgeLoss(torch.nn.Module):
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         d_sc = torch.empty_like(sc)
         with torch.cuda.device(dev):
-            _lib.check(lib.sg_gaussian_edge_loss(N, self._K, _ptr(verts), _ptr(sc), _ptr(ws), None, _ptr(loss), None,
-                                                 _ptr(d_sc), _stream(dev)), "gaussian edge loss")
+            _lib.check(lib.sg_gaussian_edge_prepare(N, _ptr(verts), _ptr(ws), _stream(dev)), "gaussian edge loss (grids)")
+        self._pending = (N, verts, sc, ws, loss, d_sc)
         return _attach(loss[0], [human_gs_out['scales']], [d_sc])
+
+    def finish(self):
+        lib = _lib.load()
+        N, verts, sc, ws, loss, d_sc = self._pending
+        self._pending = None
+        dev = sc.device                              # (same stream as prepare(), or one the caller has ordered behind it AND
+        with torch.cuda.device(dev):                 #  told the allocator about: the buffers were allocated there)
+            _lib.check(lib.sg_gaussian_edge_finish(N, self._K, _ptr(sc), _ptr(ws), None, _ptr(loss), None, _ptr(d_sc),
+                                                   _stream(dev)), "gaussian edge loss (query)")
+
+    def forward(self, human_gs_out):
+        out = self.prepare(human_gs_out)
+        self.finish()
+        return out
 
 
 def knn_mean_edge(xyz, K=9):

@@ -10,9 +10,15 @@
 Everything between the parameters and the scalar loss runs in HIP kernels (library GEMMs for the decoders' forward /
 input-gradient products); torch autograd only strings the stages together.  The regularisers depend on the decoded
 attributes only, not on the render: with ``overlap_regularisers`` (default) they run on a second HIP stream next to the
-LBS + raster + photometric-loss chain -- the k-NN query (a chain of dependent look-ups per lane) and the render kernels
-(tile-imbalance tails) fill each other's holes; the streams fork after the decode and join at the loss sum, also inside a
-captured HIP graph.
+LBS + raster + photometric-loss chain, also inside a captured HIP graph.  WHERE they run decides what they cost
+(profiles/r03_train_step_trace.log): the k-NN query keeps 9 waves per SIMD resident on every CU for 0.23 ms, and beside it the
+raster forward's latency-bound chain took 2-7x as long per kernel (the long-list sort needs a nearly empty CU per workgroup:
+146 us instead of 21).  With ``defer_regulariser_join`` (round 3) the side stream builds the k-NN grids right after the decode
+(small kernels), holds the QUERY until the raster forward has finished, and is NOT joined before the loss: ``forward`` returns
+the photometric and the regulariser loss as two roots (``extras["loss_roots"]``), ``AvatarStep.backward`` hands both to one
+``torch.autograd.backward`` -- autograd runs every node on the stream its forward ran on and synchronises where the two
+gradient paths meet, at the decoders' heads -- and sums the reported loss afterwards.  The query then overlaps the photometric
+loss and the backward composite (0.23 ms of half-busy vector ALUs).
 """
 import torch
 
@@ -24,9 +30,10 @@ from .skinned import rasterize_skinned_gaussians
 class AvatarStep(torch.nn.Module):
     def __init__(self, xyz_anchor, lbs_weights, triplane, geometry_dec, appearance_dec, l1_w=0.8, ssim_w=0.2,
                  thickness_factor=1.0, scaling_multiplier=None, l2_norm=None, gaussian_connect=None, gaussian_connect_w=0.0,
-                 overlap_regularisers=True):
+                 overlap_regularisers=True, defer_regulariser_join=False):
         super().__init__()
         self.overlap_regularisers, self._side = bool(overlap_regularisers), None
+        self.defer_regulariser_join = bool(defer_regulariser_join)
         self.xyz = torch.nn.Parameter(xyz_anchor.detach().clone())
         self.register_buffer("lbs_weights", lbs_weights.detach().clone())
         self.triplane, self.geometry_dec, self.appearance_dec = triplane, geometry_dec, appearance_dec
@@ -51,19 +58,42 @@ class AvatarStep(torch.nn.Module):
                     {"xyz_canon": attrs["xyz_canon"], "scales": attrs["scales"]})
 
         has_reg = self.l2_norm is not None or (self.gaussian_connect is not None and self.gaussian_connect_w > 0)
+        has_knn = self.gaussian_connect is not None and self.gaussian_connect_w > 0
         side = None
-        if has_reg and self.overlap_regularisers and attrs["xyz_canon"].is_cuda:
+        overlap = has_reg and self.overlap_regularisers and attrs["xyz_canon"].is_cuda
+        defer = overlap and self.defer_regulariser_join and torch.is_grad_enabled()
+        if overlap:
             dev = attrs["xyz_canon"].device
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(dev)
             side, cur = self._side, torch.cuda.current_stream(dev)
             side.wait_stream(cur)                                # fork: the decoded attributes are complete
             with torch.cuda.stream(side):
-                regularisers()
+                if defer and has_knn and hasattr(self.gaussian_connect, "prepare"):
+                    # the grids and the autograd node now, the query behind the raster forward
+                    if self.l2_norm is not None:
+                        reg["l2"] = self.l2_norm({"xyz_offsets": attrs["xyz_offsets"], "scales": attrs["scales"],
+                                                  "opacity": attrs["opacity"]})
+                    edge = self.gaussian_connect.prepare({"xyz_canon": attrs["xyz_canon"], "scales": attrs["scales"]})
+                else:
+                    defer = False
+                    regularisers()
         color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
                                                    self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
                                                    transl=transl)
+        if defer:
+            side.wait_stream(cur)                                # the raster forward has the GPU to itself; then the query
+            with torch.cuda.stream(side):
+                self.gaussian_connect.finish()
+                reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
+                reg_root = torch.stack([v.reshape(()) for v in reg.values()]).sum()
         loss_dict, extras = photometric_loss(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
+        if defer:
+            # two roots, no join: the regularisers' gradients are waited for where they are consumed (AvatarStep.backward)
+            photo_root = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()
+            loss_dict.update(reg)
+            extras["loss_roots"] = (photo_root, reg_root)
+            return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
         if side is not None:
             cur.wait_stream(side)                                # join before the loss terms meet
             for v in reg.values():
@@ -74,3 +104,16 @@ class AvatarStep(torch.nn.Module):
         loss = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()      # two launches, not one addition per term
         loss_dict["loss"] = loss
         return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
+
+    def backward(self, loss_dict, extras):
+        """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and
+        ``loss_dict["loss"]`` = their sum.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
+        photo_root, reg_root = extras["loss_roots"]
+        torch.autograd.backward([photo_root, reg_root])
+        dev = photo_root.device
+        cur = torch.cuda.current_stream(dev)
+        cur.wait_stream(self._side)
+        for v in list(loss_dict.values()) + [reg_root]:
+            v.record_stream(cur)
+        loss_dict["loss"] = photo_root.detach() + reg_root.detach()
+        return loss_dict["loss"]

@@ -101,10 +101,13 @@ def test_full_step_matches_oracle_chain():
             close("plane", p.grad, q.grad)
 
 
-def test_full_step_replays_from_a_hip_graph():
+@pytest.mark.parametrize("defer_join", [False, True])
+def test_full_step_replays_from_a_hip_graph(defer_join):
     """The composed step incl. the regularisers on their side stream captured into ONE HIP graph (deferred pair-count check,
     no host round trip inside a step): replays separated by host synchronisations and by a change of the frame (joint
-    transforms updated IN PLACE) give the loss and gradients of the directly launched step."""
+    transforms updated IN PLACE) give the loss and gradients of the directly launched step.  `defer_join`: the round-3
+    schedule -- k-NN grids early, the query behind the raster forward, the regularisers joined inside the backward pass
+    (two autograd roots) -- against a reference computed with the early join."""
     from sings_amd import rasterizer as rz
     from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
     from sings_amd.rasterizer import GaussianRasterizationSettings
@@ -139,7 +142,11 @@ def test_full_step_replays_from_a_hip_graph():
         for p in params:
             p.grad = None
         loss, ld, ex = step(A_static, rset, gt, ones, bg, smpl_scale=sc, transl=tr)
-        loss.backward()
+        if loss is None:
+            assert step.defer_regulariser_join and "loss_roots" in ex
+            loss = step.backward(ld, ex)
+        else:
+            loss.backward()
         return loss.detach().clone()     # (nothing of the autograd graph may stay alive across the end of the capture:
                                          #  returning `loss` itself crashed hipStreamEndCapture in this test)
 
@@ -150,6 +157,14 @@ def test_full_step_replays_from_a_hip_graph():
             A_static.copy_(f)
             l = body(); torch.cuda.synchronize()
             ref.append((float(l), [p.grad.clone() for p in params]))
+        step.defer_regulariser_join = defer_join                  # (the references above: early join)
+        if defer_join:                                            # eager, two roots: same loss, same gradients
+            for k, f in enumerate(frames):
+                A_static.copy_(f)
+                l = body(); torch.cuda.synchronize()
+                assert abs(float(l) - ref[k][0]) <= 1e-6 * abs(ref[k][0]), (k, float(l), ref[k][0])
+                for p, r in zip(params, ref[k][1]):
+                    assert (p.grad - r).abs().max().item() <= 1e-5 * r.abs().max().item() + 1e-12, k
         rz.set_deferred_overflow_check(True, capacity_pairs=int(max(rz._capacity_hint.values()) * 1.5))
         A_static.copy_(frames[0])
         side = torch.cuda.Stream(dev); side.wait_stream(torch.cuda.current_stream(dev))
