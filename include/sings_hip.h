@@ -59,9 +59,11 @@ typedef struct SgRasterSettings {
 } SgRasterSettings;
 
 /* Byte offsets inside the opaque workspaces (exposed for tests / debugging only). */
+#define SG_GEOM_REC_BYTES 64
 typedef struct SgLayout {
-    /* geometry workspace (per Gaussian) */
-    size_t geom_recA, geom_recB, geom_recC, geom_depth, geom_flags, geom_bytes;
+    /* geometry workspace (per Gaussian).  recA / recB / recC: three 16-byte vectors INTERLEAVED in one 64-byte record per
+     * Gaussian (SG_GEOM_REC_BYTES): vector k of Gaussian i is at geom_rec{A,B,C} + 64 i */
+    size_t geom_recA, geom_recB, geom_recC, geom_depth, geom_flags, geom_slot, geom_bytes;
     /* binning workspace */
     size_t bin_header, bin_tile_count, bin_ranges, bin_cursor, bin_pair_keys, bin_point_list,
         bin_point_keys, bin_pair_gid, bin_pair_tile, bin_pair_local,

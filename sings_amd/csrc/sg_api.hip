@@ -36,11 +36,13 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     if (T >= SG_MAX_TILES) return sg_fail("sg_layout: image has 2^20 tiles or more (work items pack the tile id into 20 bits)", hipSuccess);
     const size_t Pn = P > 0 ? P : 1, hw = (size_t)width * height;
     size_t o = 0;
-    L->geom_recA = o; o = sg_align(o + Pn * 16);
-    L->geom_recB = o; o = sg_align(o + Pn * 16);
-    L->geom_recC = o; o = sg_align(o + Pn * 16);
+    // ONE 64-B line per Gaussian: (recA, recB, recC, pad) -- the composite kernels gather the three vectors of a list entry, and as
+    // three arrays that was three 64-B lines of HBM / L2 traffic per entry (3 x 780 k x 64 B = 150 of the 170 MB the backward
+    // composite moved at cfg3)
+    L->geom_recA = o; L->geom_recB = o + 16; L->geom_recC = o + 32; o = sg_align(o + Pn * SG_REC_STRIDE * 16);
     L->geom_depth = o; o = sg_align(o + Pn * 4);
     L->geom_flags = o; o = sg_align(o + Pn * 4);
+    L->geom_slot = o; o = sg_align(o + Pn * 8);
     L->geom_bytes = o;
     o = 0;
     L->bin_header = o; o = sg_align(o + 256);

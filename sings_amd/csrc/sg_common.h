@@ -57,12 +57,15 @@ static inline bool sg_lds_hist(int gx, int gy) { return sg_ctr_count((uint32_t)g
 static inline bool sg_split_long(int gx, int gy, int flags) { return sg_lds_hist(gx, gy) && !(flags & SG_FLAG_THROUGHPUT); }
 static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 
+// float4 units between the geometry records of consecutive Gaussians: recA / recB / recC interleaved + 16 B of padding = one 64-B line
+#define SG_REC_STRIDE (SG_GEOM_REC_BYTES / 16)
 struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
     float4 *recB;          // (conic.z, opacity, r, g)
     float4 *recC;          // (b, bits(goff), bits(minx | miny<<16), bits(w | h<<16))
     float *depth;          // view-space z
     uint32_t *flags;       // bits 0..2: SH colour channel clamped at 0
+    uint2 *slot;           // (first gradient-record slot, rect width | height << 16): recC.y / recC.w again, dense, for the per-Gaussian backward
 };
 
 struct SgBin {
@@ -113,7 +116,7 @@ static inline SgGeom sg_geom_view(void *ws, const SgLayout &L)
     SgGeom g;
     g.recA = (float4 *)(b + L.geom_recA); g.recB = (float4 *)(b + L.geom_recB);
     g.recC = (float4 *)(b + L.geom_recC); g.depth = (float *)(b + L.geom_depth);
-    g.flags = (uint32_t *)(b + L.geom_flags);
+    g.flags = (uint32_t *)(b + L.geom_flags); g.slot = (uint2 *)(b + L.geom_slot);
     return g;
 }
 static inline SgBin sg_bin_view(void *ws, const SgLayout &L)

@@ -116,7 +116,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 #pragma unroll
     for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
     if (vis) {
-        rc = g.recC[idx];
+        { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
         flags = g.flags[idx];
         p[0] = means3D[3 * idx]; p[1] = means3D[3 * idx + 1]; p[2] = means3D[3 * idx + 2];
         if (!cov3D_precomp) {

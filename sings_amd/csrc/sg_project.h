@@ -127,8 +127,8 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     const uint32_t rwh = (uint32_t)(o.x1 - o.x0) | ((uint32_t)(o.y1 - o.y0) << 16);
     if (live) {
         radii[idx] = o.mr;
-        g.recA[idx] = make_float4(o.pix[0], o.pix[1], o.conic[0], o.conic[1]);
-        g.recB[idx] = make_float4(o.conic[2], o.mr ? opac : 0.0f, o.rgb[0], o.rgb[1]);
+        g.recA[SG_REC_STRIDE * (size_t)idx] = make_float4(o.pix[0], o.pix[1], o.conic[0], o.conic[1]);
+        g.recB[SG_REC_STRIDE * (size_t)idx] = make_float4(o.conic[2], o.mr ? opac : 0.0f, o.rgb[0], o.rgb[1]);
         g.depth[idx] = o.depth;
         g.flags[idx] = o.clampbits;
     }
@@ -176,7 +176,11 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     __syncthreads();
     uint32_t base = sBlockBase;
     for (int w = 0; w < wave_; w++) base += sWaveTot[w];
-    if (live) g.recC[idx] = make_float4(o.rgb[2], __uint_as_float(base + incl - o.tt), __uint_as_float(rmin), __uint_as_float(rwh));
+    if (live) {
+        g.recC[SG_REC_STRIDE * (size_t)idx] = make_float4(o.rgb[2], __uint_as_float(base + incl - o.tt), __uint_as_float(rmin), __uint_as_float(rwh));
+        g.slot[idx] = make_uint2(base + incl - o.tt, rwh);       // what the per-Gaussian backward needs of it, as a dense array
+        // (writing the 16 B of padding as well, so that the whole line is dirty: no difference, 31.2 vs 31.3 us)
+    }
     // round 0 (all of the wave's pairs at cfg3 / most of them on an avatar) stays in registers until its ranks are final: with the
     // LDS histogram they are rebased here instead of being written, re-read and rewritten
     uint32_t tile0[4], local0[4], gj0[4], ctr0[4];

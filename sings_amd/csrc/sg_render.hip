@@ -237,11 +237,11 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
             const uint32_t gid = (uint32_t)key;
             point_list[range.x + i] = gid;
             if (point_keys) point_keys[range.x + i] = ((uint64_t)tile << 32) | (key >> 32);
-            if (i == tid) { pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x; }
+            if (i == tid) { pa = recA[SG_REC_STRIDE * (size_t)gid]; pb = recB[SG_REC_STRIDE * (size_t)gid]; pc = recC[SG_REC_STRIDE * (size_t)gid].x; }
         }
     } else if (tid < n) {                                   // long list: sorted by sg_tile_sort_kernel / sg_tile_rank_kernel
         const uint32_t gid = point_list[range.x + tid];
-        pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
+        pa = recA[SG_REC_STRIDE * (size_t)gid]; pb = recB[SG_REC_STRIDE * (size_t)gid]; pc = recC[SG_REC_STRIDE * (size_t)gid].x;
     }
     for (int base = 0; base < n; base += SG_FB) {
         {   // this quadrant's pixels that are still being composited
@@ -262,7 +262,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         }
         if (e + SG_FB < n) {
             const uint32_t gid = point_list[range.x + e + SG_FB];
-            pa = recA[gid]; pb = recB[gid]; pc = recC[gid].x;
+            pa = recA[SG_REC_STRIDE * (size_t)gid]; pb = recB[SG_REC_STRIDE * (size_t)gid]; pc = recC[SG_REC_STRIDE * (size_t)gid].x;
         }
         if (PIPE) {
             // few-tile frames: the weight of the backward work item (tile, this segment) = entries composited somewhere; the
@@ -538,7 +538,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
         if (tid < cnt) {
             const int e = base + tid;
             const uint32_t gid = point_list[range.x + e];
-            const float4 c4 = recC[gid];
+            const float4 c4 = recC[SG_REC_STRIDE * (size_t)gid];
             const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
             const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
@@ -553,7 +553,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
                          (pair_mask[3 * (size_t)mask_plane + range.x + e] & 8u);
             }
             if (mk) {
-                const float4 a = recA[gid], b = recB[gid];
+                const float4 a = recA[SG_REC_STRIDE * (size_t)gid], b = recB[SG_REC_STRIDE * (size_t)gid];
                 opac = b.y; cA = a.z; cB = a.w; cC = b.x;
                 sR[tid][0] = make_float4(a.x, a.y, SG_KA * a.z, SG_KB * a.w);
                 sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
@@ -725,7 +725,7 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
             mk &= 15u;
         }
         if (mk) {
-            const float4 c4 = recC[gid], a = recA[gid], b = recB[gid];
+            const float4 c4 = recC[SG_REC_STRIDE * (size_t)gid], a = recA[SG_REC_STRIDE * (size_t)gid], b = recB[SG_REC_STRIDE * (size_t)gid];
             const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
             const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
             rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));

@@ -318,7 +318,8 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     constexpr int nc = (D + 1) * (D + 1);
     // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
     const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
-    const float4 rc = vis ? g.recC[idx] : make_float4(0, 0, 0, 0);
+    float4 rc = make_float4(0, 0, 0, 0);
+    if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
     float a9[9];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();

@@ -49,10 +49,11 @@ def forward_with_state(rs, means3D, opacities, shs=None, colors_precomp=None, sc
         nbytes = n * torch.empty(0, dtype=dtype).element_size()
         return buf[off:off + nbytes].view(dtype)
 
-    recA = view(geom, L.geom_recA, P * 4, torch.float32).view(P, 4)
-    recB = view(geom, L.geom_recB, P * 4, torch.float32).view(P, 4)
-    recC = view(geom, L.geom_recC, P * 4, torch.float32).view(P, 4)
-    recCi = view(geom, L.geom_recC, P * 4, torch.int32).view(P, 4)
+    # one 64-B record per Gaussian: recA, recB, recC, padding (SG_GEOM_REC_BYTES)
+    assert L.geom_recB - L.geom_recA == 16 and L.geom_recC - L.geom_recA == 32
+    rec = view(geom, L.geom_recA, P * 16, torch.float32).view(P, 16)
+    recA, recB, recC = rec[:, 0:4], rec[:, 4:8], rec[:, 8:12]
+    recCi = view(geom, L.geom_recA, P * 16, torch.int32).view(P, 16)[:, 8:12]
     out = dict(
         color=color, radii=radii, R=R, capacity=cap, geom=geom, binning=binning, img=img, layout=L,
         xy=recA[:, :2], conic_opacity=torch.stack([recA[:, 2], recA[:, 3], recB[:, 0], recB[:, 1]], 1),

@@ -25,13 +25,13 @@ def test_layout_is_consistent():
     from sings_amd import _lib
     L = _lib.layout(1000, 1920, 1080, 50000)
     T = 120 * 68
-    assert L.geom_recB - L.geom_recA >= 1000 * 16 and L.geom_bytes >= 1000 * 56
+    assert L.geom_recB - L.geom_recA == 16 and L.geom_recC - L.geom_recA == 32 and L.geom_bytes >= 1000 * 72   # 64-B records + depth + flags
     assert L.bin_ranges - L.bin_tile_count >= T * 4                   # (counters in 4x4 blocks of tiles: 120 x 68 tiles need no padding)
     assert L.bin_point_list - L.bin_pair_keys >= 50000 * 8
     assert L.img_n_contrib - L.img_final_T >= 1920 * 1080 * 4
     assert 50000 * 36 <= L.bwd_bytes < 50000 * 40
     for f, _ in L._fields_:
-        assert getattr(L, f) % 256 == 0
+        assert getattr(L, f) % 256 == 0 or f in ("geom_recB", "geom_recC")     # (vectors 1 and 2 of the interleaved 64-B records)
     with pytest.raises(RuntimeError):
         _lib.layout(10, 0, 10, 10)
     # work items pack the tile id into 20 bits: 2^20 tiles or more are rejected, one tile less is accepted
