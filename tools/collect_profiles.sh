@@ -62,7 +62,23 @@ for ctr in FETCH_SIZE WRITE_SIZE SQ; do
   rocprofv3 --pmc $set --output-format csv -d $OUT/cfg2/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG2 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg2/pmc_$ctr.log 2>&1
   rocprofv3 --pmc $set --output-format csv -d $OUT/cfg5/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG5 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg5/pmc_$ctr.log 2>&1
 done
-# keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files
+# keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files (the three columns of the library's
+# own kernels, averaged over the dispatches: what tools/pmc_summary.py reads)
+python3 - $OUT <<'PY'
+import collections, csv, os, sys
+for d, _, fs in os.walk(sys.argv[1]):
+    for f in fs:
+        if f.endswith("counter_collection.csv"):
+            p = os.path.join(d, f)
+            acc = collections.OrderedDict()
+            for r in csv.DictReader(open(p)):
+                if r["Kernel_Name"].startswith(("sg_", "void sg_")):
+                    a = acc.setdefault((r["Kernel_Name"], r["Counter_Name"]), [0.0, 0])
+                    a[0] += float(r["Counter_Value"]); a[1] += 1
+            with open(p, "w", newline="") as fo:          # per (kernel, counter): mean over the dispatches + how many there were
+                w = csv.writer(fo); w.writerow(("Kernel_Name", "Counter_Name", "Counter_Value", "Count"))
+                w.writerows((k, c, repr(s / n), n) for (k, c), (s, n) in acc.items())
+PY
 find $OUT -name "*kernel_trace.csv" -delete
 find $OUT -name "*.db" -delete
 du -sh $OUT

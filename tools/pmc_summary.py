@@ -36,7 +36,8 @@ for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
         if not r["Kernel_Name"].startswith(("sg_", "void sg_")):
             continue
         a = acc[(short(r["Kernel_Name"]), r["Counter_Name"])]
-        a[0] += float(r["Counter_Value"]); a[1] += 1
+        n = int(r.get("Count") or 1)                       # (tools/collect_profiles.sh leaves per-(kernel, counter) means + counts)
+        a[0] += float(r["Counter_Value"]) * n; a[1] += n
     out = os.path.join(root, "profiles", f"{tag}_pmc_{cset}.csv")
     with open(out, "w") as fo:
         fo.write("kernel,Counter_Name,mean,count\n")
