@@ -59,7 +59,7 @@ static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) 
 
 // float4 units between the geometry records of consecutive Gaussians: recA / recB / recC interleaved + 16 B of padding = one 64-B line
 #define SG_REC_STRIDE (SG_GEOM_REC_BYTES / 16)
-struct SgGeom {            // per-Gaussian projected records, SoA of 16-byte vectors
+struct SgGeom {            // per-Gaussian projected records: recA / recB / recC point into ONE array of 64-B records (SG_REC_STRIDE)
     float4 *recA;          // (pix.x, pix.y, conic.x, conic.y)
     float4 *recB;          // (conic.z, opacity, r, g)
     float4 *recC;          // (b, bits(goff), bits(minx | miny<<16), bits(w | h<<16))

@@ -6,7 +6,7 @@
 // Both kernels are VALU-issue bound (not HBM): ~2e8 pixel x Gaussian evaluations per direction at
 // cfg3.  wave64 design:
 //  * One 256-thread workgroup per 16x16 tile; wave w owns the 8x8 pixel QUADRANT w (lane = pixel).
-//  * The tile's depth-sorted list is staged cooperatively through LDS (three aligned 16-B gathers per
+//  * The tile's depth-sorted list is staged cooperatively through LDS (three aligned 16-B gathers out of ONE 64-B record per
 //    entry, one entry per thread).  While staging, each thread computes for ITS entry which quadrants the
 //    alpha >= 1/255 ellipse can reach (exact ellipse-vs-rectangle test with safety margins); every wave
 //    then compacts (ballot) the entries that reach its quadrant and loops over those only: ~2.4x fewer
