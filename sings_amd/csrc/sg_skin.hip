@@ -471,7 +471,7 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 // ~10 MB of slabs are read by thousands of waves with 256-B coalesced rows (a single 53-block pass took 44 us):
 //  pass 1: grid (column blocks of 64, SG_RED_GROUPS/4); wave = row group rg sums rows rg, rg + G, ... into part[rg]
 //  pass 2: one thread per column sums the G partial rows.
-#define SG_RED_GROUPS 128
+#define SG_RED_GROUPS 64        // (32 / 64 / 128 groups: pass 1 + pass 2 = 8.5 + 4.7 / 5.6 + 4.9 / 4.9 + 6.8 us on the avatar frame)
 __global__ void __launch_bounds__(256)
 sg_skin_reduce1_kernel(const float *__restrict__ slab, int nrows, int slab_stride, float *__restrict__ part)
 {
