@@ -46,6 +46,7 @@ class _PhotoLoss(torch.autograd.Function):
         # DEVICE scalars -- nothing is read back to find out whether they are equal (a host synchronisation per step)
         ctx.save_for_backward(raw, gt_rgb, mask, bg, ws)
         ctx.args = (float(l1_w), float(ssim_w), W, H)
+        ctx.set_materialize_grads(False)       # the two report-only outputs get None, not a zero tensor each (two fill launches)
         outs = (losses[0], losses[1], losses[2], losses[3])
         if want_images:
             ctx.mark_non_differentiable(pred, gt)

@@ -27,6 +27,20 @@ from .photo_loss import photometric_loss
 from .skinned import rasterize_skinned_gaussians
 
 
+class _AddScalars(torch.autograd.Function):
+    """a + b of two 0-dim losses: ONE launch forward and none backward (torch.stack(...).sum() is a concatenation and a reduction
+    forward, and autograd's sum / stack backward each way; between the loss kernels and the first backward kernel every such
+    4-us launch sits on the step's critical path)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return a + b
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class AvatarStep(torch.nn.Module):
     def __init__(self, xyz_anchor, lbs_weights, triplane, geometry_dec, appearance_dec, l1_w=0.8, ssim_w=0.2,
                  thickness_factor=1.0, scaling_multiplier=None, l2_norm=None, gaussian_connect=None, gaussian_connect_w=0.0,
@@ -86,11 +100,13 @@ class AvatarStep(torch.nn.Module):
             with torch.cuda.stream(side):
                 self.gaussian_connect.finish()
                 reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
-                reg_root = torch.stack([v.reshape(()) for v in reg.values()]).sum()
+                vals = [v.reshape(()) for v in reg.values()]
+                reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
         loss_dict, extras = photometric_loss(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
         if defer:
             # two roots, no join: the regularisers' gradients are waited for where they are consumed (AvatarStep.backward)
-            photo_root = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()
+            vals = [v.reshape(()) for v in loss_dict.values()]
+            photo_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
             loss_dict.update(reg)
             extras["loss_roots"] = (photo_root, reg_root)
             return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
@@ -109,7 +125,10 @@ class AvatarStep(torch.nn.Module):
         """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and
         ``loss_dict["loss"]`` = their sum.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
         photo_root, reg_root = extras["loss_roots"]
-        torch.autograd.backward([photo_root, reg_root])
+        one = getattr(self, "_one", None)
+        if one is None or one.device != photo_root.device:
+            one = self._one = torch.ones((), dtype=photo_root.dtype, device=photo_root.device)     # (not a fill launch per root and step)
+        torch.autograd.backward([photo_root, reg_root], [one, one])
         dev = photo_root.device
         cur = torch.cuda.current_stream(dev)
         cur.wait_stream(self._side)
