@@ -1,6 +1,6 @@
 """Randomised HIP-vs-oracle parity sweep (GPU box): python tests/tools/fuzz_parity.py [n_cases]
 Random scene sizes / SH degrees / densities / opacity scales, plus crafted tiles whose list length sits exactly on the
-internal boundaries (256 = wave sort / depth segment, 4096 = sort chunk).  Checks per case: binning bit-exact, RGB <= 2e-5
+internal boundaries (see __main__).  FUZZ_SEED selects the random sequence.  Checks per case: binning bit-exact, RGB <= 2e-5
 off borderline pixels, gradients within tolerance.  Exit code 1 on the first failure (prints the case)."""
 import os, sys
 import numpy as np, torch
@@ -85,12 +85,19 @@ def clustered_depths(seed):
 
 if __name__ == "__main__":
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-    for n in (255, 256, 257, 511, 512, 513, 4095, 4096, 4097, 8192, 8193):
+    # 256 = depth segment / forward batch; 128 / 1024 = rank sort / in-kernel sort limits; 12 288 = keys the bucket sort keeps
+    # resident in LDS; beyond: groups of <= 1024 + sg_group_sort_kernel.  (The 64x48 image is a few-tile frame: lists of more than
+    # 1024 entries are also composited by four workgroups, and the backward is the sparse kernel.)
+    for n in (127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 8193, 12287, 12288, 12289, 20000):
         s = crafted(n, n)
         R, mx = check(s, f"crafted {n}")
         print(f"crafted list length {n}: R={R} max list {mx}  ok", flush=True)
         assert mx >= n
-    rs = np.random.RandomState(1234)
+    for seed in (1, 2, 3):
+        z = clustered_depths(seed)
+        R, mx = check(crafted(z.size, 100 + seed, depths=z), f"clustered depths {seed}")
+        print(f"clustered depths (seed {seed}): R={R} max list {mx}  ok", flush=True)
+    rs = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "1234")))
     for c in range(ncase):
         W, H = int(rs.choice([33, 64, 100, 160, 257, 400])), int(rs.choice([17, 48, 96, 144, 230]))
         N = int(rs.choice([1, 7, 300, 2000, 9000, 30000]))
