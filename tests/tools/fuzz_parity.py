@@ -107,4 +107,12 @@ if __name__ == "__main__":
         s["scales"] = (s["scales"] * rs.choice([0.3, 1.0, 4.0])).astype(np.float32)
         R, mx = check(s, f"case {c}: N={N} {W}x{H} deg={deg} seed={seed}")
         print(f"case {c}: N={N} {W}x{H} deg={deg} R={R} max list {mx}  ok", flush=True)
+    # frames of more than 4096 tiles take the other pair of composite kernels (sg_render_fwd_kernel / sg_render_bwd_kernel)
+    for c in range(int(os.environ.get("FUZZ_LARGE", "4"))):
+        W, H = int(rs.choice([1100, 1280, 1600])), int(rs.choice([1000, 1080]))
+        N = int(rs.choice([3000, 30000])); deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
+        s = synthetic_scene(N, W, H, deg, seed)
+        s["scales"] = (s["scales"] * rs.choice([1.0, 3.0])).astype(np.float32)
+        R, mx = check(s, f"large case {c}: N={N} {W}x{H} deg={deg} seed={seed}")
+        print(f"large case {c}: N={N} {W}x{H} deg={deg} R={R} max list {mx}  ok", flush=True)
     print("all cases passed")
