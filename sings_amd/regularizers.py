@@ -126,6 +126,8 @@ class GaussiansEdgeLoss(torch.nn.Module):
 
     def finish(self):
         lib = _lib.load()
+        if getattr(self, "_pending", None) is None:
+            raise RuntimeError("GaussiansEdgeLoss.finish() without a prepare() before it")
         N, verts, sc, ws, loss, d_sc = self._pending
         self._pending = None
         dev = sc.device                              # (same stream as prepare(), or one the caller has ordered behind it AND
