@@ -807,10 +807,12 @@ def test_async_overflow_check_is_opt_in_and_raises_late():
         rz.reset_overflow_state()
 
 
-@pytest.mark.parametrize("n", [128, 129, 255, 256, 257, 512, 513, 1024, 1025, 4096, 4097])
+@pytest.mark.parametrize("n", [128, 129, 255, 256, 257, 512, 513, 1024, 1025, 4096, 4097, 12288, 12289])
 def test_list_lengths_on_internal_boundaries(n):
-    """A tile whose list has exactly n entries, n on the boundaries of the rank sort (128: SG_RANKSORT_MAX), the one-wave sort /
-    depth segments (256), the in-composite sort (1024: SG_WSORT_MAX) and of the sort chunks (4096): binning bit-exact, image and gradients vs the oracle (the sweep of tests/tools/fuzz_parity.py)."""
+    """A tile whose list has at least n entries, n around the boundaries of the rank sort (128: SG_RANKSORT_MAX), the depth
+    segments (256), the in-composite sort (1024: SG_WSORT_MAX; beyond it the bucket sort, and on this few-tile image the
+    four-workgroup composite and the sparse backward) and of the LDS-resident bucket sort (12 288): binning bit-exact, image and
+    gradients vs the oracle (the sweep of tests/tools/fuzz_parity.py)."""
     import importlib.util, os
     spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
@@ -828,3 +830,32 @@ def test_bucket_sort_of_clustered_depths():
     z = fz.clustered_depths(7)
     R, mx = fz.check(fz.crafted(z.size, 7, depths=z), "clustered depths")
     assert mx >= z.size
+
+
+
+def test_throughput_flag_changes_the_schedule_not_the_result():
+    """SG_FLAG_THROUGHPUT (set by ViewBatch when several views share the GPU) turns the four-workgroup composite of long tile
+    lists off: same pixels, same entries, same order -- image, pair count and every gradient must be bit-identical, on a few-tile
+    frame whose hot tile has a list of more than 3000 entries."""
+    import importlib.util, os
+    from sings_amd.engine import RasterEngine
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    dev = _dev()
+    s = fz.crafted(3000, 21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P = s["means3D"].shape[0]
+    args = [t(s["means3D"]), t(s["shs"]), t(s["opacities"]), t(s["scales"]), t(s["rotations"])]
+    dL = t(s["dL_dimage"])
+    out = []
+    for flag in (False, True):
+        eng = RasterEngine(P, s["W"], s["H"], s["shs"].shape[1], dev, capacity_pairs=8 * P + 4096)
+        eng.set_camera(fz.settings(s))
+        eng.throughput = flag
+        R = eng.forward(*args, sync_num_rendered=True)
+        eng.backward(*args, dL)
+        torch.cuda.synchronize()
+        out.append((R, eng.color.clone(), eng.grad_flat.clone(), eng.d_means2D.clone()))
+    assert out[0][0] == out[1][0] and out[0][0] > 3000
+    for a, b in zip(out[0][1:], out[1][1:]):
+        assert torch.equal(a, b)
