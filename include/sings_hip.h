@@ -392,6 +392,10 @@ enum SgKernelId {
     SG_K_TILE_SORT = 4, SG_K_RENDER_FWD = 5, SG_K_RENDER_BWD = 6, SG_K_PREPROCESS_BWD = 7
 };
 int sg_profile_enable(int on);
+/* Measurement only: dst[0, bytes) = src[0, bytes) with a plain 16-byte-per-lane copy kernel (both 16-byte aligned, bytes a
+ * multiple of 16) -- the float4-copy bandwidth SURVEY.md 8(d) names as the denominator of the HBM roofline, measured on the box
+ * the benchmark runs on (bench.py: >= 1 GiB, best of 3).  Replaces nothing in the reference. */
+int sg_copy_probe(void *dst, const void *src, size_t bytes, void *stream);
 int sg_profile_collect(double *total_ms, int64_t *launches, int n);
 const char *sg_kernel_name(int id);
 

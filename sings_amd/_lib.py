@@ -49,7 +49,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare", "sg_gaussian_edge_finish", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
-           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate")
+           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_copy_probe")
 NUM_KERNELS = 8
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
@@ -90,6 +90,7 @@ def load():
     lib.sg_signal_free.argtypes = [vp]; lib.sg_signal_free.restype = C.c_int
     lib.sg_profile_enable.argtypes = [i32]
     lib.sg_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
+    lib.sg_copy_probe.argtypes = [vp, vp, sz, vp]; lib.sg_copy_probe.restype = C.c_int
     lib.sg_kernel_name.argtypes = [i32]
     lib.sg_kernel_name.restype = C.c_char_p
     lib.sg_skin_ws_floats.argtypes = [i32]

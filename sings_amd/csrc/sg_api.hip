@@ -4,6 +4,8 @@
 
 #include <chrono>
 #include <stdio.h>
+#include <stdlib.h>
+#include <thread>
 #include <string.h>
 #include <utility>
 #include <vector>
@@ -100,6 +102,17 @@ static void sg_arm_count(const SgRasterSettings *s, SgCam *c, const int64_t *num
 // R for the caller: from the published word once it arrives (no stream synchronisation), otherwise -- no signal word, debug
 // mode, or nothing after SG_SIGNAL_TIMEOUT_MS (a kernel that failed to launch never publishes) -- the synchronous read.
 #define SG_SIGNAL_TIMEOUT_MS 50.0
+// (SINGS_SIGNAL_TIMEOUT_MS in the environment overrides the 50 ms, read once: a caller that queues more than that in front of
+// a forward -- large scenes, a shared GPU -- would otherwise spin 50 ms and then synchronise the stream on every call)
+static double sg_signal_timeout_ms()
+{
+    static const double v = [] {
+        const char *e = getenv("SINGS_SIGNAL_TIMEOUT_MS");
+        const double x = e ? atof(e) : 0.0;
+        return x > 0.0 ? x : SG_SIGNAL_TIMEOUT_MS;
+    }();
+    return v;
+}
 static int sg_finish_count(const SgRasterSettings *s, const SgCam &c, const void *binning_ws, int64_t *num_rendered_host, void *stream)
 {
     if (!num_rendered_host) return 0;
@@ -113,9 +126,14 @@ static int sg_finish_count(const SgRasterSettings *s, const SgCam &c, const void
                 return 0;
             }
             if ((spin & 63u) == 63u) {
-                if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() > SG_SIGNAL_TIMEOUT_MS) break;
+                const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                if (waited > sg_signal_timeout_ms()) break;
+                // a queue that is more than ~0.2 ms deep in front of the binning kernel: stop burning the core, yield between looks
+                if (waited > 0.2) std::this_thread::yield();
             } else {
+#if defined(__x86_64__) || defined(__i386__)
                 __builtin_ia32_pause();
+#endif
             }
         }
     }
@@ -683,6 +701,27 @@ void sg_zero_async(void *p, size_t bytes, hipStream_t st)
     size_t blocks = (words / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
     hipLaunchKernelGGL(sg_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (uint32_t *)p, words);
+}
+
+// ---- measurement: the denominator of the HBM roofline ----------------------------------------------------------------
+// A plain 16-byte-per-lane copy (grid-stride, nothing else): what the box's HBM sustains for a read + a write stream.  bench.py
+// times it over >= 1 GiB and quotes `roofline.peak` from it ("float4-copy bandwidth measured on the same box").
+__global__ void __launch_bounds__(256) sg_copy_probe_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+extern "C" int sg_copy_probe(void *dst, const void *src, size_t bytes, void *stream)
+{
+    if (!dst || !src || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
+        return sg_fail("sg_copy_probe: 16-byte aligned buffers and a multiple of 16 bytes", hipSuccess);
+    if (!bytes) return 0;
+    const size_t n = bytes >> 4;
+    size_t blocks = (n + 255) / 256;
+    blocks = blocks > 256 * 32 ? 256 * 32 : blocks;                // 32 workgroups per CU, grid-stride
+    hipLaunchKernelGGL(sg_copy_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_copy_probe", e);
 }
 
 static bool g_prof_on = false;

@@ -23,6 +23,7 @@
 // Traffic: 12 B + 8 B written, 20 B read, 4 B written per pair -- instead of six 24-B/pair radix passes.
 // (Round 1 ran scan / scatter / sort / rank as four launches: 10 + 12 + 18 + 4 us at cfg3, all latency.)
 #include "sg_sort.h"
+#include <atomic>
 
 // Exclusive scans over the T tile counts of
 //   q0 pairs (-> ranges, cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
@@ -635,6 +636,24 @@ sg_group_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restric
     }
 }
 
+// Raising a kernel's dynamic-LDS limit is a host-side call into the runtime (a table update under a lock): asked ONCE per
+// (kernel, device) and remembered per device id -- not in a process-wide flag (a second GPU used from the same process must get
+// its own call), and a refusal is remembered too (the callers then take their fallback paths).  Round 3 asked on every forward.
+static bool sg_dyn_lds_limit(int which, const void *fn, int bytes)
+{
+    static std::atomic<signed char> state[2][64];                // 0 unknown, 1 granted, -1 refused
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess || ((void)hipGetLastError(), false);
+    signed char st = state[which][dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        st = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : -1;
+        if (st < 0) (void)hipGetLastError();
+        state[which][dev].store(st, std::memory_order_release);
+    }
+    return st > 0;
+}
+
 void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st)
 {
@@ -649,8 +668,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     // table update, no stream operation), and if the runtime refuses, the two-kernel path below does the same job.
     bool fused = T <= SG_SS_MAX_TILES;
     if (fused && (size_t)T * 4 + 1024 > 64 * 1024)
-        fused = hipFuncSetAttribute((const void *)sg_scan_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    SG_SS_MAX_TILES * 4) == hipSuccess;
+        fused = sg_dyn_lds_limit(0, (const void *)sg_scan_scatter_kernel, SG_SS_MAX_TILES * 4);
     if (fused) {
         sg_prof_begin(SG_K_TILE_SCAN, st);
         size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
@@ -685,9 +703,7 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     // allocated and every list takes the multi-level path.
     uint32_t resident = SG_PT_U * SG_PT_THREADS;
     size_t dyn = (size_t)resident * 8 + (size_t)SG_PT_FINE * 4;
-    if (hipFuncSetAttribute((const void *)sg_tile_partition_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn) != hipSuccess) {
-        (void)hipGetLastError(); resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8;
-    }
+    if (!sg_dyn_lds_limit(1, (const void *)sg_tile_partition_kernel, (int)dyn)) { resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8; }
     hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
                        b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
                        resident > SG_PT_NB ? resident : 0u);

@@ -94,7 +94,7 @@ def _tp_early(dev):
 # autograd a fresh view of the slot (AccumulateGrad adopts it without a copy when .grad is None, the precondition the training
 # step already guarantees), so `p.grad` IS a piece of `flat`.  Gradients produced elsewhere (biases, anchors) are small; the
 # caller copies those into their slots (`arena_sync`).
-_ARENA = {}                            # parameter storage address -> (flat, offset, shape)
+_ARENA = {}                            # parameter storage address -> [flat, offset, shape, weakref(parameter), weakref(last view handed out)]
 
 
 def set_gradient_arena(params, flat):
@@ -107,7 +107,7 @@ def set_gradient_arena(params, flat):
         n = p.numel()
         if not p.is_contiguous():
             raise ValueError("gradient arena: parameters must be contiguous")
-        _ARENA[p.data_ptr()] = (flat, o, tuple(p.shape))
+        _ARENA[p.data_ptr()] = [flat, o, tuple(p.shape), weakref.ref(p), None]
         views.append(flat[o:o + n].view(p.shape))
         o += n
     if o != flat.numel() or flat.dtype != torch.float32:
@@ -121,8 +121,18 @@ def _arena_out(param_like):
     hit = _ARENA.get(param_like.data_ptr())
     if hit is None or hit[2] != tuple(param_like.shape) or hit[0].device != param_like.device:
         return torch.empty_like(param_like, dtype=torch.float32)
-    flat, o, shape = hit
-    return flat[o:o + param_like.numel()].view(shape)
+    flat, o, shape, pref, last = hit
+    # The slot is the memory `p.grad` lives in once autograd has adopted the view.  Writing the NEXT gradient there is only
+    # right when nothing accumulates: p.grad must be None (zero_grad(set_to_none=False), micro-batch accumulation: the kernel
+    # would overwrite p.grad's own memory and AccumulateGrad would then add the slot to itself -- 2 x the last gradient instead of
+    # old + new), and the view of an earlier hand-out must be gone (a weight or plane used twice in ONE graph: the first use's
+    # gradient still sits in the slot, waiting to be accumulated).  Otherwise: a fresh tensor, autograd adds, arena_sync copies.
+    p = pref()
+    if p is None or p.grad is not None or (last is not None and last() is not None):
+        return torch.empty_like(param_like, dtype=torch.float32)
+    v = flat[o:o + param_like.numel()].view(shape)
+    hit[4] = weakref.ref(v)
+    return v
 
 
 def arena_sync(params, views, to_arena=True):

@@ -53,7 +53,7 @@ class RasterEngine:
         self.d_means2D = torch.empty((self.P, 3), **f32)      # densification statistic, not reduced as a weight grad
         self._keep = []
         self._s = None
-        self._chain = None                                    # (accumulate, wait-for event, done event): set by ViewBatch
+        self._chain = None                                    # inside ViewBatch.run: callable -> (accumulate, wait-for event, done event)
         self.throughput = False                               # SG_FLAG_THROUGHPUT: set by a ViewBatch that keeps several views in flight
 
     def set_camera(self, raster_settings, short_lists=False):
@@ -85,7 +85,7 @@ class RasterEngine:
         _lib.check(self.lib.sg_rasterize_backward_records(
             C.byref(self._s), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
             _ptr(dL_dcolor), self._stream()), "backward (records)")
-        accumulate, after, done = self._chain if self._chain is not None else (False, None, None)
+        accumulate, after, done = self._chain() if self._chain is not None else (False, None, None)
         if after is not None:
             torch.cuda.current_stream(self.dev).wait_event(after)
         _lib.check(self.lib.sg_rasterize_backward_gaussians(
@@ -192,7 +192,7 @@ class SkinnedEngine:
         _lib.check(self.lib.sg_rasterize_backward_records(
             C.byref(self._s), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.bwd_ws),
             _ptr(dL_dcolor), self._stream()), "skinned backward (records)")
-        accumulate, after, done = self._chain if self._chain is not None else (False, None, None)
+        accumulate, after, done = self._chain() if self._chain is not None else (False, None, None)
         if after is not None:
             torch.cuda.current_stream(self.dev).wait_event(after)
         _lib.check(self.lib.sg_skinned_backward_gaussians(
@@ -270,29 +270,47 @@ class ViewBatch:
             e.throughput = self.n > 1
 
     def _link(self, v, e):
-        # view v adds to its row iff an earlier view of the step wrote it; with one row across several streams the per-Gaussian
-        # half additionally waits for the view in front of it (events order only those last, short kernels)
-        if self.chain:
-            e._chain = (v > 0, self._events[v - 1] if v > 0 else None, self._events[v])
-        else:
-            e._chain = (v >= self.rows, None, None)
+        # Resolved when the view's backward actually RUNS (engine.backward calls it once): the view adds to its row iff a
+        # backward of this run has already written that row -- a forward-only view (fn skips the backward) therefore never makes
+        # a later view add to an unwritten buffer (round 3 decided by the view index alone); with one row across several streams
+        # the per-Gaussian half additionally waits for the last backward before it (events order only those last, short kernels).
+        def resolve():
+            row = v % self.rows
+            acc = self._written[row]
+            self._written[row] = True
+            if not self.chain:
+                return acc, None, None
+            after, self._last_event = self._last_event, self._events[v]
+            return acc, after, self._events[v]
+        e._chain = resolve
 
     def run_unreduced(self, fn):
-        """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``."""
-        if not self.streams:
-            for v, e in enumerate(self.engines):
-                self._link(v, e)
-                fn(v, e)
-            return
-        cur = torch.cuda.current_stream(self.dev)
-        for st in self.streams:
-            st.wait_stream(cur)
-        for v, e in enumerate(self.engines):
-            self._link(v, e)
-            with torch.cuda.stream(self.streams[v % self.n]):
-                fn(v, e)
-        for st in self.streams:
-            cur.wait_stream(st)
+        """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``.  ``fn(v, engine)``
+        runs view v's forward and AT MOST ONE backward; every row must be written by at least one backward before the rows are
+        folded (checked).  Outside ``run`` the engines are plain again (a later stand-alone backward writes, never adds)."""
+        self._written = [False] * self.rows
+        self._last_event = None
+        try:
+            if not self.streams:
+                for v, e in enumerate(self.engines):
+                    self._link(v, e)
+                    fn(v, e)
+            else:
+                cur = torch.cuda.current_stream(self.dev)
+                for st in self.streams:
+                    st.wait_stream(cur)
+                for v, e in enumerate(self.engines):
+                    self._link(v, e)
+                    with torch.cuda.stream(self.streams[v % self.n]):
+                        fn(v, e)
+                for st in self.streams:
+                    cur.wait_stream(st)
+        finally:
+            for e in self.engines:
+                e._chain = None
+        if any(self._written) and not all(self._written):
+            raise RuntimeError("ViewBatch: a gradient row was not written by any view of this step (every stream / row needs at "
+                               "least one view that runs its backward); the fold would read an unwritten buffer")
 
     def run(self, fn):
         self.run_unreduced(fn)

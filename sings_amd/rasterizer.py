@@ -8,7 +8,9 @@ argument order and gradient order ``(means3D, means2D, sh, colors_precomp, opaci
 rotations, cov3Ds_precomp, None)``.  The compute is the hand-written gfx950 library behind the
 C ABI of include/sings_hip.h -- there is no CPU / eager fallback.
 """
+import atexit
 import ctypes as C
+import threading
 from typing import NamedTuple
 
 import torch
@@ -62,18 +64,37 @@ _signal = {}                           # device index -> [host address, device a
 _SIGNAL_SLOTS = 64
 
 
+_signal_lock = threading.Lock()
+
+
 def _signal_slot(dev):
     """(device address, host address) of the next early-count word of ``dev`` (a ring: a "sync" forward consumes its word
-    before it returns, so slots are only shared by calls that are 64 forwards apart)."""
-    sg = _signal.get(dev.index)
-    if sg is None:
-        h, d = C.c_void_p(), C.c_void_p()
-        with torch.cuda.device(dev):
-            _lib.check(_lib.load().sg_signal_alloc(_SIGNAL_SLOTS, C.byref(h), C.byref(d)), "sg_signal_alloc")
-        sg = _signal[dev.index] = [h.value, d.value, 0]
-    k = sg[2] % _SIGNAL_SLOTS
-    sg[2] += 1
-    return sg[1] + 8 * k, sg[0] + 8 * k
+    before it returns, so slots are only shared by calls that are 64 forwards apart).  Thread-safe (a forward on the main
+    thread and one on an autograd / data-loader thread must not be handed the same word); the ring is released by
+    ``reset_overflow_state`` and at interpreter exit."""
+    with _signal_lock:
+        sg = _signal.get(dev.index)
+        if sg is None:
+            h, d = C.c_void_p(), C.c_void_p()
+            with torch.cuda.device(dev):
+                _lib.check(_lib.load().sg_signal_alloc(_SIGNAL_SLOTS, C.byref(h), C.byref(d)), "sg_signal_alloc")
+            sg = _signal[dev.index] = [h.value, d.value, 0]
+        k = sg[2] % _SIGNAL_SLOTS
+        sg[2] += 1
+        return sg[1] + 8 * k, sg[0] + 8 * k
+
+
+def _free_signal_rings(dev_index=None):
+    with _signal_lock:
+        for k in [k for k in _signal if dev_index is None or k == dev_index]:
+            sg = _signal.pop(k)
+            try:
+                _lib.load().sg_signal_free(C.c_void_p(sg[0]))
+            except Exception:
+                pass
+
+
+atexit.register(_free_signal_rings)
 
 
 def set_overflow_check(mode="sync", on_overflow=None, capacity_pairs=None, device=None):
@@ -180,6 +201,14 @@ def reset_overflow_state(device=None):
             d.clear()
         else:
             d.pop(torch.device(device).index, None)
+    if _signal and torch.cuda.is_initialized():
+        # no "sync" forward is in flight here (each consumes its word before it returns): the pinned ring can go
+        if device is None:
+            torch.cuda.synchronize()
+            _free_signal_rings()
+        else:
+            torch.cuda.synchronize(torch.device(device))
+            _free_signal_rings(torch.device(device).index)
 
 
 def check_deferred_overflow(device=None):

@@ -59,13 +59,16 @@ class _ScaledGrad(torch.autograd.Function):
         return (None, None) + tuple(torch._foreach_mul(ds, g.reshape(()))) + (None,) * ctx.n
 
 
-def _attach(loss, inputs, grads):
+def _attach(loss, inputs, grads, filled=True):
+    """``filled=False``: the kernel that writes ``loss`` has NOT run yet (GaussiansEdgeLoss.prepare): nothing may copy it now --
+    with no input that requires grad (evaluation under no_grad, detached scales) the caller gets a VIEW of the buffer the later
+    kernel fills, never a clone of uninitialised memory (round 3 cloned here: garbage in validation)."""
     keep_i, keep_g = [], []
     for t, d in zip(inputs, grads):
-        if t is not None and d is not None and t.requires_grad:
+        if t is not None and d is not None and t.requires_grad and torch.is_grad_enabled():
             keep_i.append(t); keep_g.append(d)
     if not keep_i:
-        return loss.clone()
+        return loss.clone() if filled else loss.detach()
     return _ScaledGrad.apply(loss, len(keep_i), *keep_i, *keep_g)
 
 
@@ -112,6 +115,10 @@ class GaussiansEdgeLoss(torch.nn.Module):
         rasterizer's node in autograd's execution order, so that the backward composite is not held up by the hand-over of
         this gradient (`sings_amd.train_step.AvatarStep`)."""
         lib = _lib.load()
+        if getattr(self, "_pending", None) is not None:
+            # ONE pending query per module: a second prepare() would orphan the first node -- its loss and gradient buffers
+            # would never be written and autograd would hand on whatever they held
+            raise RuntimeError("GaussiansEdgeLoss.prepare() called twice without finish(): finish() (or forward()) the first one")
         verts = human_gs_out['xyz_canon'].detach().contiguous().float()      # edge lengths are detached (:75)
         sc = human_gs_out['scales'].contiguous().float()
         _need_gpu(verts, "GaussiansEdgeLoss")
@@ -121,17 +128,23 @@ class GaussiansEdgeLoss(torch.nn.Module):
         d_sc = torch.empty_like(sc)
         with torch.cuda.device(dev):
             _lib.check(lib.sg_gaussian_edge_prepare(N, _ptr(verts), _ptr(ws), _stream(dev)), "gaussian edge loss (grids)")
-        self._pending = (N, verts, sc, ws, loss, d_sc)
-        return _attach(loss[0], [human_gs_out['scales']], [d_sc])
+        self._pending = (N, verts, sc, ws, loss, d_sc, torch.cuda.current_stream(dev))
+        return _attach(loss[0], [human_gs_out['scales']], [d_sc], filled=False)
 
     def finish(self):
         lib = _lib.load()
         if getattr(self, "_pending", None) is None:
             raise RuntimeError("GaussiansEdgeLoss.finish() without a prepare() before it")
-        N, verts, sc, ws, loss, d_sc = self._pending
-        self._pending = None
+        N, verts, sc, ws, loss, d_sc, st0 = self._pending
         dev = sc.device                              # (same stream as prepare(), or one the caller has ordered behind it AND
-        with torch.cuda.device(dev):                 #  told the allocator about: the buffers were allocated there)
+        #                                               told the allocator about: the buffers were allocated there)
+        if torch.cuda.is_current_stream_capturing() and torch.cuda.current_stream(dev) != st0:
+            # a SECOND side stream inside a HIP-graph capture: the buffers of prepare() would need record_stream across streams
+            # of the capture, and hipStreamEndCapture crashed on exactly that (round 3) -- refuse instead of dying later
+            raise RuntimeError("GaussiansEdgeLoss.finish(): inside a HIP-graph capture the query must run on the stream that ran "
+                               "prepare() (keep the whole regulariser on ONE side stream)")
+        self._pending = None
+        with torch.cuda.device(dev):
             _lib.check(lib.sg_gaussian_edge_finish(N, self._K, _ptr(sc), _ptr(ws), None, _ptr(loss), None, _ptr(d_sc),
                                                    _stream(dev)), "gaussian edge loss (query)")
 

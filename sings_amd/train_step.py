@@ -41,6 +41,59 @@ class _AddScalars(torch.autograd.Function):
         return g, g
 
 
+def _tensors_of(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
+def capture_step(fn, warmup=3, device=None):
+    """``graph, outputs = capture_step(fn)``: record ``fn()`` -- one whole step: forward, backward, whatever it launches -- into
+    a HIP graph the safe way.  On ROCm 7.2 ``hipStreamEndCapture`` SEGFAULTS (not an error code: the process dies) when
+    something ``fn`` returned still carries its autograd graph at the end of the capture (gpurun_out/crash.log, round 3): the
+    saved tensors of that graph live in the capture's private memory pool on several streams.  This wrapper therefore looks at
+    what ``fn`` returned BEFORE it ends the capture: if any returned tensor requires grad / has a grad_fn, the references are
+    dropped first, the capture is ended cleanly (the graph is discarded) and a RuntimeError says what to do -- return
+    ``loss.detach()`` (or ``.detach().clone()``) from the captured callable.  ``warmup`` eager runs on a side stream come first
+    (allocator warm-up, lazily created streams), as ``torch.cuda.graph`` requires."""
+    import gc
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("capture_step: a capture is already in progress on this stream")
+    side = torch.cuda.Stream(dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(side):
+        for _ in range(max(0, int(warmup))):
+            out = fn()
+            n_bad = sum(1 for t_ in _tensors_of(out) if t_.requires_grad or t_.grad_fn is not None)
+            del out
+            if n_bad:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                raise RuntimeError(f"capture_step: the callable returns {n_bad} tensor(s) that still carry an autograd graph; "
+                                   "return detached values (loss.detach()) -- ending a HIP-graph capture with them alive "
+                                   "crashes hipStreamEndCapture on ROCm 7.2")
+    torch.cuda.current_stream(dev).wait_stream(side)
+    torch.cuda.synchronize(dev)
+    graph = torch.cuda.CUDAGraph()
+    n_bad = 0
+    with torch.cuda.graph(graph):
+        out = fn()
+        n_bad = sum(1 for t_ in _tensors_of(out) if t_.requires_grad or t_.grad_fn is not None)
+        if n_bad:                              # (only reachable with warmup = 0) drop every reference BEFORE the capture ends
+            out = None
+            gc.collect()
+    if n_bad:
+        del graph
+        raise RuntimeError(f"capture_step: the callable returned {n_bad} tensor(s) that still carry an autograd graph; the capture "
+                           "was discarded.  Return detached values (loss.detach())")
+    return graph, out
+
+
 class AvatarStep(torch.nn.Module):
     def __init__(self, xyz_anchor, lbs_weights, triplane, geometry_dec, appearance_dec, l1_w=0.8, ssim_w=0.2,
                  thickness_factor=1.0, scaling_multiplier=None, l2_norm=None, gaussian_connect=None, gaussian_connect_w=0.0,
@@ -56,6 +109,14 @@ class AvatarStep(torch.nn.Module):
         self.l2_norm, self.gaussian_connect, self.gaussian_connect_w = l2_norm, gaussian_connect, gaussian_connect_w
 
     def forward(self, A_cano2pose, raster_settings, gt_rgb, mask, bg_color, smpl_scale=None, transl=None):
+        """-> (loss, loss_dict, extras).  With ``defer_regulariser_join`` (and gradients enabled, regularisers present) ``loss``
+        is **None**: the photometric and the regulariser terms are two autograd roots (``extras["loss_roots"]``) -- call
+        ``self.backward(loss_dict, extras)``, which runs both, joins the regularisers' side stream and fills
+        ``loss_dict["loss"]``.  Until then the regulariser entries of ``loss_dict`` live on that UNJOINED stream: do not read
+        them (``.item()``, logging) before ``backward`` -- or call ``self.join_regularisers(loss_dict)`` first.
+        Inside a HIP-graph capture: use ``sings_amd.train_step.capture_step`` (it refuses, with an error instead of a dead
+        process, a captured callable that returns tensors still carrying their autograd graph), and keep the regularisers on
+        the ONE side stream this module owns (``GaussiansEdgeLoss.finish`` refuses any other stream while capturing)."""
         attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
                                   self.scaling_multiplier)
         # anisotropic: the decoder's 6-D rotations go to the fused kernels as they are (rotation_6d_to_matrix of
@@ -120,6 +181,16 @@ class AvatarStep(torch.nn.Module):
         loss = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()      # two launches, not one addition per term
         loss_dict["loss"] = loss
         return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
+
+    def join_regularisers(self, loss_dict=None):
+        """Make the current stream wait for the regularisers' side stream (a ``defer_regulariser_join`` forward leaves it
+        unjoined), so that the regulariser losses can be read before ``backward``."""
+        if self._side is not None:
+            cur = torch.cuda.current_stream(self._side.device)
+            cur.wait_stream(self._side)
+            for v in (loss_dict or {}).values():
+                if torch.is_tensor(v) and v.is_cuda:
+                    v.record_stream(cur)
 
     def backward(self, loss_dict, extras):
         """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and

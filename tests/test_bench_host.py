@@ -49,13 +49,36 @@ def test_tampered_sidecar_drops_the_valu_roofline(tmp_path):
     try:
         kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
                 "sg_preprocess_bwd_kernel": 0.03}
-        per, _ = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
-        roof, hbm = bench.build_roofline(kern, per, CFG)
+        per, total = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
+        roof, valu = bench.build_roofline(kern, per, CFG, total, 0.25e-3, 6200.0)
     finally:
         bench._committed_pmc = old
-    assert roof["bound"] == "hbm" and roof["kernel"] == "sg_render_bwd_kernel" and "sg_render.hip" in roof["note"]
-    assert roof["traffic"] is None and abs(roof["frac"] - hbm["frac"]) < 1e-12
+    assert roof["bound"] == "hbm" and roof["dominant_kernel"] == "sg_render_bwd_kernel"
+    assert valu["frac"] is None and "sg_render.hip" in valu["note"]
+    assert roof["dominant_kernel_traffic"] is None and roof["peak"] == 6200.0
+    assert abs(roof["achieved"] - total / 0.25e-3 / 1e9) < 1e-6 and abs(roof["frac"] - roof["achieved"] / 6200.0) < 1e-12
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(roof)
+
+
+def test_roofline_is_the_whole_pass_hbm_quantity_and_valu_is_secondary(tmp_path):
+    """SURVEY.md 8(d): `roofline` = algorithmic bytes per view / seconds per view against the measured copy bandwidth;
+    the VALU-issue figure of the dominant composite kernel is `roofline_valu`; `traffic` = the PMC bytes of ALL kernels."""
+    meta = {"config": dict(CFG), "sources": bench.source_hashes()}
+    pdir = _profiles(tmp_path, meta)
+    old, oldt = bench._committed_pmc, bench.pmc_view_traffic
+    bench._committed_pmc = lambda k, c: old(k, c, pdir)
+    bench.pmc_view_traffic = lambda c: oldt(c, pdir)
+    try:
+        kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
+                "sg_preprocess_bwd_kernel": 0.03}
+        per, total = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
+        roof, valu = bench.build_roofline(kern, per, CFG, total, 0.25e-3, 6300.0)
+    finally:
+        bench._committed_pmc, bench.pmc_view_traffic = old, oldt
+    assert roof["bound"] == "hbm" and roof["scope"] == "whole_pass" and roof["traffic"] == 123456 + 777
+    assert roof["algorithmic_bytes_per_view"] == total and roof["peak_spec"] == 8000.0
+    assert valu["bound"] == "valu" and valu["kernel"] == "sg_render_bwd_kernel" and valu["valu_wave_instructions_per_launch"] == 8.0e7
+    assert abs(valu["frac"] - (8.0e7 / 0.15e-3 / 1e9) / (1024 * 2.4e9 / 2.0 / 1e9)) < 1e-9
 
 
 def test_other_configuration_or_missing_sidecar_is_not_used(tmp_path):

@@ -337,3 +337,44 @@ def test_triplane_backward_prepared_early_or_inline():
     assert torch.equal(dx0, dx1)
     for a, b in zip(dp0, dp1):
         _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="plane gradient")
+
+
+def test_gradient_arena_accumulates_like_plain_autograd():
+    """with a gradient arena registered, a SECOND backward without a reset in between (micro-batch accumulation,
+    zero_grad(set_to_none=False)) wrote the new gradient over p.grad's own memory and autograd then added the slot to itself:
+    2 x the last gradient.  The slot is now handed out only while p.grad is None and no earlier hand-out is alive; otherwise
+    autograd gets a fresh tensor and adds.  Two backwards over different inputs must give g(x1) + g(x2), bit for bit what
+    the same module computes without an arena; after `p.grad = None` the next gradient lands in the slot again."""
+    from sings_amd import decode
+    dev = _dev()
+    torch.manual_seed(5)
+    g = decode.GeometryDecoder(n_features=96, isotropic=False).to(dev)
+    params = [p for p in g.parameters() if p.requires_grad]
+    x1, x2 = torch.randn(6000, 96, device=dev), torch.randn(6000, 96, device=dev)
+
+    def run(xs):
+        for x in xs:
+            o = g(x)
+            sum((v * v).sum() for v in (o['xyz_offsets'], o['rotations'], o['scales'])).backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in params]
+
+    for p in params:
+        p.grad = None
+    ref = run([x1, x2])                                     # plain autograd accumulation, no arena
+    flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=dev)
+    views = decode.set_gradient_arena(params, flat)
+    try:
+        for p in params:
+            p.grad = None
+        got = run([x1, x2])
+        for r, t_ in zip(ref, got):
+            assert torch.equal(r, t_)
+        # a fresh step: the weight gradients are written in place again
+        for p in params:
+            p.grad = None
+        run([x1])
+        in_place = sum(p.grad.data_ptr() == v.data_ptr() for p, v in zip(params, views))
+        assert in_place >= 3, in_place                       # (every nn.Linear weight of the decoder)
+    finally:
+        decode.set_gradient_arena(None, None)

@@ -364,9 +364,44 @@ def test_segmented_backward_with_early_termination(opacity_scale):
 
 
 @pytest.mark.parametrize("N,W,H,seed", [(200000, 1920, 1080, 3), (500000, 2048, 2048, 5)])
+def test_full_size_configs_against_the_oracle(N, W, H, seed):
+    """BASELINE configs[2] ("200 k Gaussians, 1080p, SH deg 3, forward+backward, pixel-diff vs reference") and the raster part
+    of configs[4] (500 k @ 2048 x 2048) AT FULL SIZE against the CPU oracle -- the operator call being replaced is
+    gs_renderer_single.py:87-95.  The scalar C oracle needs ~4 s / ~10 s per view: the same bars as the small scenes --
+    binning bit for bit (radii, rectangles, depth bits, keys, sorted lists, ranges, R), RGB <= 1e-5 off borderline pixels with
+    the oracle's flip bound on the others, final_T / n_contrib, and EVERY gradient through the reference-facing autograd API."""
+    from sings_amd.inspect_ws import forward_with_state
+    from diff_gaussian_rasterization import GaussianRasterizer
+    dev = _dev()
+    s = synthetic_scene(N, W, H, 3, seed)
+    o = _oracle(s)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    st = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]),
+                            rotations=t(s["rotations"]), capacity=5 * N)
+    _check_forward_state(s, st, o)
+    _check_image(st["color"].cpu().numpy(), st["final_T"].cpu().numpy(), st["n_contrib"].cpu().numpy(), o)
+    del st
+    border = o["margin"] < BORDER
+    dLn = s["dL_dimage"].copy(); dLn[:, border] = 0
+    g = ro.backward(o, dLn)
+    req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+    m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+    m2 = torch.zeros_like(m, requires_grad=True)
+    color, radii = GaussianRasterizer(rs)(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rt)
+    np.testing.assert_array_equal(radii.cpu().numpy(), o["radii"])
+    assert np.abs(color.detach().cpu().numpy() - o["color"]).max(0)[~border].max() <= RGB_TOL
+    color.backward(torch.from_numpy(dLn).to(dev))
+    for name, a, b in (("means3D", m.grad, g["dL_dmeans3D"]), ("means2D", m2.grad, g["dL_dmean2D"]),
+                       ("opacity", op.grad, g["dL_dopacity"]), ("scales", sc.grad, g["dL_dscales"]),
+                       ("rotations", rt.grad, g["dL_drots"]), ("shs", sh.grad, g["dL_dsh"])):
+        _grad_close(name, a.cpu().numpy().reshape(b.shape), b)
+
+
+@pytest.mark.parametrize("N,W,H,seed", [(200000, 1920, 1080, 3), (500000, 2048, 2048, 5)])
 def test_cfg3_full_size_properties(N, W, H, seed):
     """BASELINE configs[2] and configs[4] at full size (200 k Gaussians @ 1920x1080; 500 k @ 2048x2048 = 16 384 tiles, the
-    packed-counter regime; SH degree 3) -- too big for the CPU oracle in a test, so size-independent properties: every tile range is strictly sorted by (depth bits, Gaussian id), every
+    packed-counter regime; SH degree 3) -- size-independent properties next to the oracle comparison above: every tile range is strictly sorted by (depth bits, Gaussian id), every
     Gaussian appears exactly once in each tile of its rectangle and nowhere else, R = sum of tiles touched, two runs are
     bitwise identical, and the backward pass is linear in dL/dimage."""
     from sings_amd.inspect_ws import forward_with_state

@@ -167,3 +167,27 @@ def test_cfg5_regularisers_value_and_gradient_at_500k_points():
     ld = GaussiansEdgeLoss()({'xyz_canon': xs.to(dev), 'scales': scd}); ld.backward()
     assert abs(ld.item() - lo.item()) <= 3e-6 * abs(lo.item())
     _close(scd.grad.cpu().numpy(), scs.grad.numpy())
+
+
+def test_edge_loss_without_gradients_returns_the_value_not_an_unwritten_buffer():
+    """GaussiansEdgeLoss.prepare() attached the autograd node BEFORE the query kernel had written the loss; with no
+    input that requires grad (evaluation under no_grad, detached scales) it returned a clone of the uninitialised buffer.
+    Every other test uses requires_grad=True.  The value must equal the golden loss in all three modes, and a second
+    prepare() without finish() must raise instead of orphaning the first node."""
+    from sings_amd.regularizers import GaussiansEdgeLoss
+    dev = _dev()
+    t = lambda k: torch.from_numpy(G[k]).to(dev)
+    want = float(G["edge_loss"])
+    mod = GaussiansEdgeLoss()
+    junk = torch.full((1 << 20,), 1e30, device=dev); del junk        # whatever the allocator hands out next is not zero
+    with torch.no_grad():
+        l0 = mod({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales").requires_grad_(True)})
+    l1 = mod({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales")})                   # nothing requires grad
+    l2 = mod({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales").requires_grad_(True).detach()})
+    for l in (l0, l1, l2):
+        assert not l.requires_grad and abs(l.item() - want) <= 2e-6 * abs(want), (l.item(), want)
+    out = mod.prepare({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales")})
+    with pytest.raises(RuntimeError, match="twice"):
+        mod.prepare({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales")})
+    mod.finish()
+    assert abs(out.item() - want) <= 2e-6 * abs(want)

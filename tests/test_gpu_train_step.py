@@ -185,3 +185,86 @@ def test_full_step_replays_from_a_hip_graph(defer_join):
     finally:
         rz.set_deferred_overflow_check(False)
         rz.reset_overflow_state(); rz._capacity_hint.update(hint)
+
+
+_CAPTURE_GUARD_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from sings_amd.regularizers import GaussiansEdgeLoss
+from sings_amd.train_step import capture_step
+dev = torch.device("cuda:0")
+xyz = torch.rand(4000, 3, device=dev); sc = (0.01 + 0.01 * torch.rand(4000, 3, device=dev)).requires_grad_(True)
+mod = GaussiansEdgeLoss()
+which = sys.argv[1]
+if which == "autograd_graph_alive":
+    # pattern 1 (gpurun_out/crash.log, round 3): the captured callable hands back a loss that still carries its graph
+    def body():
+        sc.grad = None
+        loss = mod({"xyz_canon": xyz, "scales": sc})
+        loss.backward(retain_graph=True)
+        return loss                                   # NOT detached
+    try:
+        capture_step(body, warmup=int(sys.argv[2]))
+    except RuntimeError as e:
+        print("RuntimeError:", str(e)[:80]); sys.exit(0)
+    print("no error"); sys.exit(3)
+if which == "second_side_stream":
+    # pattern 2: the query on another stream than the grids, inside a capture
+    other = torch.cuda.Stream(dev)
+    def body():
+        out = mod.prepare({"xyz_canon": xyz, "scales": sc})
+        cur = torch.cuda.current_stream(dev)
+        other.wait_stream(cur)
+        try:
+            with torch.cuda.stream(other):
+                mod.finish()
+        finally:
+            cur.wait_stream(other)                    # (joined again: the capture can end cleanly)
+        return out.detach()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    try:
+        with torch.cuda.graph(g):
+            body()
+    except RuntimeError as e:
+        print("RuntimeError:", str(e)[:80]); sys.exit(0 if "ONE side stream" in str(e) else 4)
+    print("no error"); sys.exit(3)
+"""
+
+
+@pytest.mark.parametrize("argv", [("autograd_graph_alive", "2"), ("autograd_graph_alive", "0"), ("second_side_stream",)])
+def test_graph_capture_misuse_is_an_error_not_a_dead_process(argv):
+    """The two recipes that SEGFAULTED hipStreamEndCapture in round 3 (gpurun_out/crash.log): a captured
+    callable that returns a tensor with its autograd graph alive, and a regulariser query moved to a second side stream inside
+    the capture.  Both are now Python-side RuntimeErrors (train_step.capture_step, GaussiansEdgeLoss.finish).  Each runs in a
+    child process: if a guard ever regresses, the child dies, not the test session."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, "-c", _CAPTURE_GUARD_SCRIPT % root, *argv], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0 and "RuntimeError:" in p.stdout, (p.returncode, p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_capture_step_returns_a_replayable_graph():
+    from sings_amd.regularizers import L2Norm
+    from sings_amd.train_step import capture_step
+    dev = torch.device("cuda:0")
+    off = (0.01 * torch.randn(5000, 3, device=dev)).requires_grad_(True)
+    sc = (0.01 + 0.01 * torch.rand(5000, 3, device=dev)).requires_grad_(True)
+    op = torch.rand(5000, 1, device=dev).requires_grad_(True)
+    mod = L2Norm()
+
+    def body():
+        off.grad = None; sc.grad = None; op.grad = None
+        loss = mod({"xyz_offsets": off, "scales": sc, "opacity": op})
+        loss.backward()
+        return {"loss": loss.detach().clone()}
+    ref = float(body()["loss"]); gref = off.grad.clone()
+    graph, out = capture_step(body)
+    with torch.no_grad():
+        off.mul_(2.0)
+    graph.replay(); torch.cuda.synchronize()
+    assert float(out["loss"]) != ref                      # the replay re-ran the kernels on the updated input
+    with torch.no_grad():
+        off.mul_(0.5)
+    graph.replay(); torch.cuda.synchronize()
+    assert abs(float(out["loss"]) - ref) <= 1e-6 * abs(ref) and torch.allclose(off.grad, gref, rtol=1e-6, atol=0)

@@ -44,9 +44,12 @@ def check(s, tag):
     for name, a, b in (("means3D", m.grad, g["dL_dmeans3D"]), ("opacity", op.grad, g["dL_dopacity"]), ("scales", sc.grad, g["dL_dscales"]),
                        ("rots", rt.grad, g["dL_drots"]), ("sh", sh.grad, g["dL_dsh"])):
         a = a.cpu().numpy().reshape(b.shape).astype(np.float64); b = b.astype(np.float64)
+        # EVERY element, like tests/test_gpu_raster.py::_grad_close (round 3 let 1e-4 of the elements miss: nothing needed it --
+        # borderline pixels carry no loss on either side); rtol / atol are those of the segmented-list tests there: the crafted
+        # lists are thousands of entries deep, and a depth segment's colour-behind comes from forward sums (~1e-6 per pixel term)
         scale = np.abs(b).max() + 1e-30
-        bad = np.abs(a - b) > 1e-3 * np.abs(b) + 1e-5 * scale
-        assert bad.mean() <= 1e-4, (tag, name, bad.sum(), np.abs(a - b).max(), scale)
+        bad = np.abs(a - b) > 1e-3 * np.abs(b) + 6e-6 * scale
+        assert not bad.any(), (tag, name, int(bad.sum()), np.abs(a - b).max(), scale)
     tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
     return int(o["R"]), int(tl.max())
 
@@ -83,12 +86,32 @@ def clustered_depths(seed):
     return z[rs.permutation(z.size)]
 
 
+CRAFTED_LENGTHS = (127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 8193, 12287, 12288, 12289, 20000)
+
+
+def random_case(rs, large=False):
+    """One random scene of the sweep from the generator state `rs` -> (scene, tag)."""
+    if large:                      # frames of more than 4096 tiles take the other pair of composite kernels
+        W, H = int(rs.choice([1100, 1280, 1600])), int(rs.choice([1000, 1080]))
+        N = int(rs.choice([3000, 30000])); deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
+        s = synthetic_scene(N, W, H, deg, seed)
+        s["scales"] = (s["scales"] * rs.choice([1.0, 3.0])).astype(np.float32)
+        return s, f"large: N={N} {W}x{H} deg={deg} seed={seed}"
+    W, H = int(rs.choice([33, 64, 100, 160, 257, 400])), int(rs.choice([17, 48, 96, 144, 230]))
+    N = int(rs.choice([1, 7, 300, 2000, 9000, 30000]))
+    deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
+    s = synthetic_scene(N, W, H, deg, seed)
+    s["opacities"] = (s["opacities"] * rs.choice([0.05, 0.3, 1.0])).astype(np.float32)
+    s["scales"] = (s["scales"] * rs.choice([0.3, 1.0, 4.0])).astype(np.float32)
+    return s, f"N={N} {W}x{H} deg={deg} seed={seed}"
+
+
 if __name__ == "__main__":
     ncase = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     # 256 = depth segment / forward batch; 128 / 1024 = rank sort / in-kernel sort limits; 12 288 = keys the bucket sort keeps
     # resident in LDS; beyond: groups of <= 1024 + sg_group_sort_kernel.  (The 64x48 image is a few-tile frame: lists of more than
     # 1024 entries are also composited by four workgroups, and the backward is the sparse kernel.)
-    for n in (127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025, 4095, 4096, 4097, 8192, 8193, 12287, 12288, 12289, 20000):
+    for n in CRAFTED_LENGTHS:
         s = crafted(n, n)
         R, mx = check(s, f"crafted {n}")
         print(f"crafted list length {n}: R={R} max list {mx}  ok", flush=True)
@@ -99,20 +122,11 @@ if __name__ == "__main__":
         print(f"clustered depths (seed {seed}): R={R} max list {mx}  ok", flush=True)
     rs = np.random.RandomState(int(os.environ.get("FUZZ_SEED", "1234")))
     for c in range(ncase):
-        W, H = int(rs.choice([33, 64, 100, 160, 257, 400])), int(rs.choice([17, 48, 96, 144, 230]))
-        N = int(rs.choice([1, 7, 300, 2000, 9000, 30000]))
-        deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
-        s = synthetic_scene(N, W, H, deg, seed)
-        s["opacities"] = (s["opacities"] * rs.choice([0.05, 0.3, 1.0])).astype(np.float32)
-        s["scales"] = (s["scales"] * rs.choice([0.3, 1.0, 4.0])).astype(np.float32)
-        R, mx = check(s, f"case {c}: N={N} {W}x{H} deg={deg} seed={seed}")
-        print(f"case {c}: N={N} {W}x{H} deg={deg} R={R} max list {mx}  ok", flush=True)
-    # frames of more than 4096 tiles take the other pair of composite kernels (sg_render_fwd_kernel / sg_render_bwd_kernel)
+        s, tag = random_case(rs)
+        R, mx = check(s, f"case {c}: {tag}")
+        print(f"case {c}: {tag} R={R} max list {mx}  ok", flush=True)
     for c in range(int(os.environ.get("FUZZ_LARGE", "4"))):
-        W, H = int(rs.choice([1100, 1280, 1600])), int(rs.choice([1000, 1080]))
-        N = int(rs.choice([3000, 30000])); deg = int(rs.randint(0, 4)); seed = int(rs.randint(1 << 30))
-        s = synthetic_scene(N, W, H, deg, seed)
-        s["scales"] = (s["scales"] * rs.choice([1.0, 3.0])).astype(np.float32)
-        R, mx = check(s, f"large case {c}: N={N} {W}x{H} deg={deg} seed={seed}")
-        print(f"large case {c}: N={N} {W}x{H} deg={deg} R={R} max list {mx}  ok", flush=True)
+        s, tag = random_case(rs, large=True)
+        R, mx = check(s, f"large case {c}: {tag}")
+        print(f"large case {c}: {tag} R={R} max list {mx}  ok", flush=True)
     print("all cases passed")
