@@ -123,6 +123,11 @@ def parse_args():
     ap.add_argument("--views-per-step", type=int, default=8,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
                          "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views")
+    ap.add_argument("--frames-per-launch", type=int, default=None,
+                    help="frames (avatar) / cameras (raster) of the same Gaussians rendered by ONE dispatch per kernel (the *_frames "
+                         "entry points: K consecutive workspaces, the per-Gaussian backward sums the K frames in registers).  A step "
+                         "of --views-per-step views is views / K such batches, dealt to the streams.  1 = one engine per view (round "
+                         "3).  Default: avatar 8, raster 1")
     ap.add_argument("--streams", type=int, default=3,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are folded on a communication stream)")
@@ -284,14 +289,15 @@ def measure_copy_peak(dev, gib=1.0):
     src = torch.zeros(n, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
     st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     best = 0.0
-    for i in range(4):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        _lib.check(lib.sg_copy_probe(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, st), "copy probe")
-        e1.record()
-        torch.cuda.synchronize(dev)
-        if i:
-            best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    for nt in (0, 1):                                  # plain / non-temporal loads + stores: the better form is the box's copy rate
+        for i in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.sg_copy_probe(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, nt, st), "copy probe")
+            e1.record()
+            torch.cuda.synchronize(dev)
+            if i:
+                best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
     del src, dst
     torch.cuda.empty_cache()
     return best
@@ -689,7 +695,7 @@ def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs):
     dom_ach = per[dom] / (kern[dom] * 1e-3) / 1e9
     view_traffic, tsrc = pmc_view_traffic(cfg)
     roof = {"bound": "hbm", "scope": "whole_pass", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
-            "peak_source": "float4 copy measured in this run (sg_copy_probe, 1 GiB, best of 3)" if copy_gbs else
+            "peak_source": "float4 copy measured in this run (sg_copy_probe, 1 GiB, best of 3, plain or non-temporal)" if copy_gbs else
                            "MI355X_MICROARCH.md (6.29 TB/s float4 copy; not measured in this run)",
             "peak_spec": HBM_PEAK_GBS, "frac_of_spec": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_view": total_bytes, "ms_per_view": s_per_view * 1e3,
@@ -1126,19 +1132,31 @@ def main_avatar(a):
     # one engine (workspaces) + loss engine per view of the batch, each writing its own row of `grads`; the views are dealt
     # round-robin to the streams; one pass sums the rows, one all-reduce per step (same scheme as the raster workload)
     k_views = max(1, a.views_per_step)
-    n_streams = max(1, min(a.streams, k_views))
+    # K frames per launch (round 4): the step's k_views frames go out as k_views / K batches, ONE dispatch per kernel and batch
+    Kf = max(1, min(a.frames_per_launch if a.frames_per_launch is not None else 8, k_views, _lib.MAX_FRAMES))
+    while k_views % Kf:
+        Kf -= 1
+    n_batches = k_views // Kf
+    n_streams = max(1, min(a.streams, n_batches))
     per_view = N * (3 + 3 + 1 + 3 * sh.shape[1])
-    from sings_amd.engine import ViewBatch
+    from sings_amd.engine import SkinnedFramesEngine, ViewBatch
     from sings_amd.photo_loss import PhotoLossEngine
-    rows = {"streams": n_streams, "views": k_views, "one": 1}[a.gradient_rows]
+    rows = {"streams": n_streams, "views": n_batches, "one": 1}[a.gradient_rows]
     grads = ViewBatch.gradient_rows(rows, per_view, dev)
     engs, losses = [], []
-    for v in range(k_views):
-        e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
+    for v in range(n_batches):
+        if Kf == 1:
+            e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
+        else:
+            e = SkinnedFramesEngine(N, J, W, H, sh.shape[1], Kf, dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
         e.set_camera(rs)
         engs.append(e)
-        losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2))          # human.loss.l1_w / ssim_w
-    eng = engs[0]
+        losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2, K=Kf))    # human.loss.l1_w / ssim_w
+    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096) if Kf > 1 else engs[0]
+    if Kf > 1:
+        eng.set_camera(rs)
+    loss1 = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2) if Kf > 1 else losses[0]
+    transl_k = transl[None].repeat(Kf, 1).contiguous()                            # (per-frame translations: here all equal)
     shard = FrameSharder(F, world, rank, seed=0)
     fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
                         force=FORCE_DIST) if dist is not None else None)
@@ -1151,22 +1169,44 @@ def main_avatar(a):
     mask = ((((xx - W / 2) / (W / 4)) ** 2 + ((yy - H / 2) / (H / 2.2)) ** 2) < 1).float().contiguous()
     bg_t = t(s["bg"])
 
-    def one_view(v, frame):
-        e = engs[v]
+    def one_view(v, frame, e=None, le=None):
+        e = engs[v] if e is None else e
         e.set_frame(xyz, None, w, A_all[frame], smpl_scale, transl)
         e.forward(sh, op, sc)
-        dLi = losses[v](e.color, gt_rgb, mask, bg_t)
+        dLi = (losses[v] if le is None else le)(e.color, gt_rgb, mask, bg_t)
+        e.backward(sh, op, sc, dLi)
+
+    frame_idx = [torch.empty(Kf, dtype=torch.long, device=dev) for _ in range(n_batches)]
+    A_batch = [torch.empty((Kf, J, 16), dtype=torch.float32, device=dev) for _ in range(n_batches)]
+    # the frame numbers of a batch reach the device through a ring of pinned host words (an asynchronous 64-byte copy: the host
+    # never waits, and runs at most a few steps ahead of the device -- the ring is 256 steps deep)
+    pins = [[torch.empty(Kf, dtype=torch.long).pin_memory() for _ in range(256)] for _ in range(n_batches)]
+    pin_at = [0] * n_batches
+
+    def one_batch(b, frames):
+        """Kf frames of the step in ONE dispatch per kernel: their joint transforms gathered into [Kf,J,16] (one small launch)."""
+        e = engs[b]
+        pin = pins[b][pin_at[b] % 256]; pin_at[b] += 1
+        pin.copy_(torch.tensor(frames, dtype=torch.long))
+        frame_idx[b].copy_(pin, non_blocking=True)
+        torch.index_select(A_all, 0, frame_idx[b], out=A_batch[b])
+        e.set_frames(xyz, None, w, A_batch[b], smpl_scale, transl_k)
+        e.forward(sh, op, sc)
+        dLi = losses[b](e.color, gt_rgb, mask, bg_t)                            # (one target image for all frames: stride 0)
         e.backward(sh, op, sc, dLi)
 
     def step(i):
-        batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
+        if Kf == 1:
+            batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
+        else:
+            batch.run(lambda b, e: one_batch(b, [shard.frame(i * k_views + b * Kf + f) for f in range(Kf)]))
 
     for i in range(a.warmup):
         step(i)
     els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i))
     el = _median(els)
     comm = allreduce_probe(fp, batch.acc)
-    assert all(e.num_rendered() <= e.cap for e in engs)
+    assert all(max(e.num_rendered()) <= e.cap if Kf > 1 else e.num_rendered() <= e.cap for e in engs)
     grad_hash = None
     if a.grad_hash:
         step(0)
@@ -1174,7 +1214,7 @@ def main_avatar(a):
         grad_hash = _grad_sha256(batch.acc)
     # the reference's unit of work: ONE frame per optimisation step on the current stream (gs_trainer.py:207-215)
     def step_one_frame(i):
-        one_view(0, shard.frame(i))
+        one_view(0, shard.frame(i), eng, loss1)
         if fp is not None:
             fp.all_reduce_grads(eng.grad_flat)
     n_one = max(20, min(a.steps * k_views, 2000))
@@ -1185,7 +1225,7 @@ def main_avatar(a):
     lib = _lib.load()
     lib.sg_profile_enable(1)
     for i in range(a.steps):
-        one_view(0, shard.frame(i))
+        one_view(0, shard.frame(i), eng, loss1)
     ms = (C.c_double * _lib.NUM_KERNELS)(); cnt = (C.c_int64 * _lib.NUM_KERNELS)()
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
     lib.sg_profile_enable(0)
@@ -1200,7 +1240,8 @@ def main_avatar(a):
                "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H} fx=fy=5000, {F} AMASS frames, SH deg 0, fused LBS+raster "
                                       f"fwd + L1/SSIM loss + bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
                           "width": W, "height": H, "max_num_rendered": Rmax, "tile_list_mean": tile_mean, "tile_list_max": tile_max,
-                          "views_per_step": k_views, "streams": n_streams, "parallelism": f"dp{world}"},
+                          "views_per_step": k_views, "frames_per_launch": Kf, "launch_batches_per_step": n_batches,
+                          "streams": n_streams, "parallelism": f"dp{world}"},
                "kernel_ms": kern}
         per, total_bytes = algorithmic_bytes_skinned(N, H, W, Rmax, 0, J)
         fps = out["value"] / world

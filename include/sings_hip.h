@@ -259,6 +259,68 @@ int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkin
                                   float *dL_dxyz_canon, float *dL_drot_canon, float *dL_dscales, float *dL_dopacity,
                                   float *dL_dsh, float *dL_dmeans2D, float *dL_dA, float *dL_dtransl, void *stream);
 
+/* ---- K frames of the SAME Gaussians per call (round 4) ------------------------------------------------------------------------
+ * The reference hands the model 16 frames per call (SinGS.forward_chunk, sings/rec/models/sings_hybrid.py:474-569, consumed one frame
+ * at a time by the render loop at sings/rec/trainer/gs_trainer.py:684-714), and a frame-parallel training step renders K frames of the
+ * same canonical Gaussians per rank.  The *_frames entry points take those K frames in ONE call and ONE dispatch per kernel: the
+ * latency-bound kernels of a frame (binning, long-list sort, loss, reductions) fill the chip with K frames' worth of workgroups, the
+ * canonical inputs are read from HBM once for the K poses / cameras, and the per-Gaussian backward sums the K frames' gradients in
+ * registers and writes the gradient row once -- in frame order, bit for bit what K single-frame calls leave behind when the first
+ * writes the gradient buffer and the others add to it (accumulate = 1).  K = 1 IS the single-frame call (same kernels).
+ *
+ * Layout of a K-frame call: every per-frame array is K consecutive single-frame arrays --
+ *   workspaces : geom_ws / binning_ws / image_ws / bwd_ws = K x sg_layout(...).{geom,bin,img,bwd}_bytes (sg_frames_layout),
+ *   out_color / dL_dout_color [K,3,H,W], radii [K,P], dL_dmeans2D [K,P,3], posed_* [K,P,.], dL_dA [K,J,16], dL_dtransl [K,3],
+ *   skin->A [K,J,16]; skin->transl [K,3] (transl_stride 3) or [3] shared (0);
+ *   cameras: camera_stride 1: s->viewmatrix [K,16], s->projmatrix [K,16], s->campos [K,3]; 0: one camera for all frames
+ *   (the shipped kit's sequences have ONE static camera).  Image size, fov, sh_degree, bg, scale_modifier are shared. */
+#define SG_MAX_FRAMES 16
+typedef struct SgFrameBatch {
+    int32_t K;               /* frames in this call, 1..SG_MAX_FRAMES */
+    int32_t camera_stride;   /* 0 | 1 */
+    int32_t transl_stride;   /* 0 | 3 (floats) */
+    int32_t reserved;        /* 0 */
+} SgFrameBatch;
+/* sizes of the K-frame workspaces (= K x the single-frame sizes, which are returned in *one); any output pointer may be NULL */
+int sg_frames_layout(int P, int width, int height, size_t capacity_pairs, int K, SgLayout *one, size_t *geom_bytes,
+                     size_t *binning_bytes, size_t *image_bytes, size_t *bwd_bytes);
+/* num_rendered_host: NULL, or [K] -- filled by one strided copy + stream synchronisation */
+int sg_rasterize_forward_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const float *means3D, const float *shs,
+                                const float *colors_precomp, const float *opacities, const float *scales, const float *rotations,
+                                const float *cov3D_precomp, void *geom_ws, void *binning_ws, size_t capacity_pairs, void *image_ws,
+                                float *out_color, int32_t *radii, int64_t *num_rendered_host, void *stream);
+int sg_skinned_forward_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const SgSkinInputs *skin, const float *shs,
+                              const float *opacities, const float *scales, void *geom_ws, void *binning_ws, size_t capacity_pairs,
+                              void *image_ws, float *out_color, int32_t *radii, float *posed_xyz, float *posed_rotq,
+                              float *posed_scales, int64_t *num_rendered_host, void *stream);
+int sg_read_num_rendered_frames(const void *binning_ws, int P, int width, int height, size_t capacity_pairs, int K,
+                                int64_t *num_rendered_host, void *stream);
+int sg_rasterize_backward_records_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const void *geom_ws,
+                                         const void *binning_ws, size_t capacity_pairs, const void *image_ws, void *bwd_ws,
+                                         const float *dL_dout_color, void *stream);
+/* accumulate != 0: the K frames' sum is ADDED to the gradient outputs (several calls of one optimisation step, one buffer) */
+int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const float *means3D,
+                                           const float *shs, const float *colors_precomp, const float *opacities,
+                                           const float *scales, const float *rotations, const float *cov3D_precomp,
+                                           const int32_t *radii, const void *geom_ws, const void *binning_ws,
+                                           size_t capacity_pairs, const void *bwd_ws, int accumulate, float *dL_dmeans3D,
+                                           float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors, float *dL_dopacity,
+                                           float *dL_dscales, float *dL_drotations, float *dL_dcov3D, void *stream);
+size_t sg_skin_ws_floats_frames(int P, int K);
+int sg_skinned_backward_gaussians_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const SgSkinInputs *skin,
+                                         const float *shs, const float *opacities, const float *scales, const int32_t *radii,
+                                         const void *geom_ws, const void *binning_ws, size_t capacity_pairs, const void *bwd_ws,
+                                         float *skin_ws, int accumulate, const float *dL_dposed_xyz_in,
+                                         const float *dL_dposed_rotq_in, float *dL_dxyz_canon, float *dL_drot_canon,
+                                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
+                                         float *dL_dtransl, void *stream);
+/* K photometric losses + gradients in three launches (HumanSceneLoss.forward of K frames, losses/loss.py:55-69): raw, dL_draw,
+ * pred_out, gt_out [K,3,H,W]; gt_rgb at + gt_stride floats per frame, mask at + mask_stride floats per frame (0: one target /
+ * mask for all frames); `ws`: K x sg_photo_loss_ws_bytes(W, H); losses [K,4]; upstream [2] (shared) or NULL */
+int sg_photo_loss_frames(int K, int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                         size_t gt_stride, const float *mask, size_t mask_stride, const float *bg, void *ws, float *pred_out,
+                         float *gt_out, float *losses, const float *upstream, float *dL_draw, void *stream);
+
 /* ---- photometric loss of one view, forward + gradient -------------------------------------------
  * Replaces, for the L1 and SSIM terms of HumanSceneLoss.forward (sings/rec/losses/loss.py:55-69):
  *   pred = clamp(raw, 0, 1)                         gs_renderer_single.py:96
@@ -393,9 +455,10 @@ enum SgKernelId {
 };
 int sg_profile_enable(int on);
 /* Measurement only: dst[0, bytes) = src[0, bytes) with a plain 16-byte-per-lane copy kernel (both 16-byte aligned, bytes a
- * multiple of 16) -- the float4-copy bandwidth SURVEY.md 8(d) names as the denominator of the HBM roofline, measured on the box
- * the benchmark runs on (bench.py: >= 1 GiB, best of 3).  Replaces nothing in the reference. */
-int sg_copy_probe(void *dst, const void *src, size_t bytes, void *stream);
+ * multiple of 16; four independent loads per lane in flight; non_temporal != 0: non-temporal loads and stores) -- the float4-copy
+ * bandwidth SURVEY.md 8(d) names as the denominator of the HBM roofline, measured on the box the benchmark runs on (bench.py:
+ * 1 GiB, best of 3 of either form).  Replaces nothing in the reference. */
+int sg_copy_probe(void *dst, const void *src, size_t bytes, int non_temporal, void *stream);
 int sg_profile_collect(double *total_ms, int64_t *launches, int n);
 const char *sg_kernel_name(int id);
 

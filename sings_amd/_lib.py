@@ -36,6 +36,13 @@ class SgSkinInputs(C.Structure):
         "xyz_canon", "rot_canon", "lbs_weights", "A", "smpl_scale", "transl", "ext_trans", "ext_rot", "ext_scale")]
 
 
+class SgFrameBatch(C.Structure):
+    _fields_ = [("K", C.c_int32), ("camera_stride", C.c_int32), ("transl_stride", C.c_int32), ("reserved", C.c_int32)]
+
+
+MAX_FRAMES = 16                      # SG_MAX_FRAMES
+
+
 class SgTriplane(C.Structure):
     _fields_ = [("n_scales", C.c_int), ("feat", C.c_int), ("res", (C.c_int * 3) * 4), ("planes", (C.c_void_p * 3) * 4),
                 ("aabb", (C.c_float * 3) * 2)]
@@ -49,7 +56,10 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare", "sg_gaussian_edge_finish", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
-           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_copy_probe")
+           "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_copy_probe",
+           "sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames",
+           "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
+           "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames")
 NUM_KERNELS = 8
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
@@ -90,7 +100,26 @@ def load():
     lib.sg_signal_free.argtypes = [vp]; lib.sg_signal_free.restype = C.c_int
     lib.sg_profile_enable.argtypes = [i32]
     lib.sg_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_int64), i32]
-    lib.sg_copy_probe.argtypes = [vp, vp, sz, vp]; lib.sg_copy_probe.restype = C.c_int
+    lib.sg_copy_probe.argtypes = [vp, vp, sz, i32, vp]; lib.sg_copy_probe.restype = C.c_int
+    # K frames per call (include/sings_hip.h, "K frames of the SAME Gaussians per call")
+    FB = C.POINTER(SgFrameBatch)
+    lib.sg_frames_layout.argtypes = [i32, i32, i32, sz, i32, C.POINTER(SgLayout)] + [C.POINTER(sz)] * 4
+    lib.sg_rasterize_forward_frames.argtypes = ([C.POINTER(SgRasterSettings), FB, i32] + [vp] * 7 +
+                                                [vp, vp, sz, vp, vp, vp, C.POINTER(C.c_int64), vp])
+    lib.sg_skinned_forward_frames.argtypes = ([C.POINTER(SgRasterSettings), FB, i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
+                                              [vp, vp, sz, vp, vp, vp, vp, vp, vp, C.POINTER(C.c_int64), vp])
+    lib.sg_read_num_rendered_frames.argtypes = [vp, i32, i32, i32, sz, i32, C.POINTER(C.c_int64), vp]
+    lib.sg_rasterize_backward_records_frames.argtypes = [C.POINTER(SgRasterSettings), FB, i32, vp, vp, sz, vp, vp, vp, vp]
+    lib.sg_rasterize_backward_gaussians_frames.argtypes = ([C.POINTER(SgRasterSettings), FB, i32] + [vp] * 7 +
+                                                           [vp, vp, vp, sz, vp, i32] + [vp] * 8 + [vp])
+    lib.sg_skin_ws_floats_frames.argtypes = [i32, i32]; lib.sg_skin_ws_floats_frames.restype = sz
+    lib.sg_skinned_backward_gaussians_frames.argtypes = ([C.POINTER(SgRasterSettings), FB, i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
+                                                         [vp, vp, vp, sz, vp, vp, i32] + [vp] * 2 + [vp] * 8 + [vp])
+    lib.sg_photo_loss_frames.argtypes = [i32, i32, i32, C.c_float, C.c_float, vp, vp, sz, vp, sz] + [vp] * 8
+    for f in ("sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames",
+              "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames",
+              "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames"):
+        getattr(lib, f).restype = C.c_int
     lib.sg_kernel_name.argtypes = [i32]
     lib.sg_kernel_name.restype = C.c_char_p
     lib.sg_skin_ws_floats.argtypes = [i32]

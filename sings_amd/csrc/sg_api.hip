@@ -158,49 +158,144 @@ extern "C" int sg_signal_free(void *host)
     return e == hipSuccess ? 0 : sg_fail("sg_signal_free", e);
 }
 
+static int sg_check_skin(const SgSkinInputs *k, int P, bool fwd)
+{
+    if (!k || k->J <= 0 || k->J > 64) return 1;
+    if (k->rot_format != SG_ROT_CANON_MATRIX && k->rot_format != SG_ROT_CANON_6D) return 1;
+    if (P > 0 && (!k->xyz_canon || !k->lbs_weights || !k->A)) return 1;
+    int e = (k->ext_trans != nullptr) + (k->ext_rot != nullptr) + (k->ext_scale != nullptr);
+    if (e != 0 && e != 3) return 1;
+    if (!fwd && e) return 1;
+    return 0;
+}
+
+// ---- K frames per call ---------------------------------------------------------------------------------------------------
+static const SgFrameBatch SG_ONE_FRAME = { 1, 0, 0, 0 };
+
+// SgFrameBatch -> the kernels' SgBatch (strides of the K consecutive workspaces: sg_layout's sizes)
+static int sg_make_batch(const SgFrameBatch *fb, int P, const SgCam &c, const SgLayout &L, size_t cap, SgBatch *bt)
+{
+    if (!fb || fb->K < 1 || fb->K > SG_MAX_FRAMES) return 1;
+    if (fb->camera_stride != 0 && fb->camera_stride != 1) return 1;
+    if (fb->transl_stride != 0 && fb->transl_stride != 3) return 1;
+    bt->K = fb->K; bt->cam_stride = fb->camera_stride; bt->transl_stride = fb->transl_stride; bt->P = P;
+    bt->geom = L.geom_bytes; bt->bin = L.bin_bytes; bt->img = L.img_bytes; bt->rec = sg_rec_bytes(cap);
+    bt->image = (size_t)3 * (size_t)c.W * (size_t)c.H;
+    return 0;
+}
+
+extern "C" int sg_frames_layout(int P, int width, int height, size_t cap, int K, SgLayout *one, size_t *geom_bytes, size_t *binning_bytes,
+                                size_t *image_bytes, size_t *bwd_bytes)
+{
+    SgLayout L;
+    if (K < 1 || K > SG_MAX_FRAMES) return sg_fail("sg_frames_layout: K must be 1..16", hipSuccess);
+    if (sg_layout(P, width, height, cap, &L)) return 1;
+    if (one) *one = L;
+    if (geom_bytes) *geom_bytes = L.geom_bytes * K;
+    if (binning_bytes) *binning_bytes = L.bin_bytes * K;
+    if (image_bytes) *image_bytes = L.img_bytes * K;
+    if (bwd_bytes) *bwd_bytes = L.bwd_bytes * K;
+    return 0;
+}
+
+// the K pair counts for the caller: one strided copy of (R, flags) of every frame's header behind the forward, then a wait
+static int sg_read_counts(const void *binning_ws, size_t bin_stride, int K, int64_t *num_rendered_host, void *stream)
+{
+    uint32_t r[2 * SG_MAX_FRAMES];
+    hipError_t e = hipMemcpy2DAsync(r, 8, binning_ws, bin_stride ? bin_stride : 8, 8, (size_t)K, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) return sg_fail("sg_read_num_rendered", e);
+    for (int f = 0; f < K; f++)
+        num_rendered_host[f] = (r[2 * f + 1] & 2u) ? (int64_t)SG_NUM_RENDERED_LONG_LIST : (int64_t)r[2 * f];
+    return 0;
+}
+
+static int sg_forward_impl(const char *who, const SgRasterSettings *s, const SgFrameBatch *fb, int P, const SgSkinInputs *skin,
+                           const float *means3D, const float *shs, const float *colors_precomp, const float *opacities,
+                           const float *scales, const float *rotations, const float *cov3D_precomp, void *geom_ws, void *binning_ws,
+                           size_t cap, void *image_ws, float *out_color, int32_t *radii, float *posed_xyz, float *posed_rotq,
+                           float *posed_scales, int write_point_keys, int64_t *num_rendered_host, void *stream)
+{
+    hipStream_t st = (hipStream_t)stream;
+    SgCam c;
+    char msg[160];
+    if (sg_make_cam(s, &c)) { snprintf(msg, sizeof msg, "%s: bad settings", who); return sg_fail(msg, hipSuccess); }
+    if (skin) {
+        if (sg_check_skin(skin, P, true)) { snprintf(msg, sizeof msg, "%s: bad skin inputs (J in 1..64, ext_tfs all or none)", who); return sg_fail(msg, hipSuccess); }
+        if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!shs || !opacities || !scales || !radii))) {
+            snprintf(msg, sizeof msg, "%s: null pointer", who); return sg_fail(msg, hipSuccess);
+        }
+        if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)) { snprintf(msg, sizeof msg, "%s: sh_coeffs smaller than (sh_degree+1)^2", who); return sg_fail(msg, hipSuccess); }
+    } else {
+        if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!means3D || !opacities || !radii))) {
+            snprintf(msg, sizeof msg, "%s: null pointer", who); return sg_fail(msg, hipSuccess);
+        }
+        if (P > 0 && ((shs != nullptr) == (colors_precomp != nullptr))) { snprintf(msg, sizeof msg, "%s: provide exactly one of shs / colors_precomp", who); return sg_fail(msg, hipSuccess); }
+        if (P > 0 && (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr))) {
+            snprintf(msg, sizeof msg, "%s: provide exactly one of (scales,rotations) / cov3D_precomp", who); return sg_fail(msg, hipSuccess);
+        }
+        if (shs && (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1))) { snprintf(msg, sizeof msg, "%s: sh_coeffs smaller than (sh_degree+1)^2", who); return sg_fail(msg, hipSuccess); }
+    }
+    SgLayout L;
+    sg_layout(P, c.W, c.H, cap, &L);
+    SgBatch bt;
+    if (sg_make_batch(fb, P, c, L, cap, &bt)) { snprintf(msg, sizeof msg, "%s: bad frame batch (K in 1..16, camera_stride 0|1, transl_stride 0|3)", who); return sg_fail(msg, hipSuccess); }
+    SgGeom g = sg_geom_view(geom_ws, L);
+    SgBin b = sg_bin_view(binning_ws, L);
+    SgImg im = sg_img_view(image_ws, L);
+    // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
+    // leaves them zeroed for the next call).  (The early pair count -- one mapped host word -- serves single-frame calls.)
+    if (bt.K == 1) sg_arm_count(s, &c, num_rendered_host);
+    if (!(c.flags & SG_FLAG_WS_CLEAN)) {
+        const size_t zb = (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4;
+        for (int f = 0; f < bt.K; f++) sg_zero_async((char *)b.header + (size_t)f * bt.bin, zb, st);
+    }
+    if (skin) sg_launch_skin_fwd(c, bt, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
+    else sg_launch_preprocess_fwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
+    SG_CHECK_LAST("preprocess_fwd", s, st);
+    sg_launch_binning(c, bt, P, radii, g, b, cap, write_point_keys, st);
+    SG_CHECK_LAST("binning", s, st);
+    sg_launch_render_fwd(c, bt, g, b, cap, im, out_color, write_point_keys, st);
+    SG_CHECK_LAST("render_fwd", s, st);
+    if (bt.K == 1) return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
+    return num_rendered_host ? sg_read_counts(binning_ws, bt.bin, bt.K, num_rendered_host, stream) : 0;
+}
+
 extern "C" int sg_rasterize_forward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
                                     const float *colors_precomp, const float *opacities, const float *scales,
                                     const float *rotations, const float *cov3D_precomp, void *geom_ws,
                                     void *binning_ws, size_t cap, void *image_ws, float *out_color,
                                     int32_t *radii, int write_point_keys, int64_t *num_rendered_host, void *stream)
 {
-    hipStream_t st = (hipStream_t)stream;
-    SgCam c;
-    if (sg_make_cam(s, &c)) return sg_fail("sg_rasterize_forward: bad settings", hipSuccess);
-    if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!means3D || !opacities || !radii)))
-        return sg_fail("sg_rasterize_forward: null pointer", hipSuccess);
-    if (P > 0 && ((shs != nullptr) == (colors_precomp != nullptr)))
-        return sg_fail("sg_rasterize_forward: provide exactly one of shs / colors_precomp", hipSuccess);
-    if (P > 0 && (((scales != nullptr) && (rotations != nullptr)) == (cov3D_precomp != nullptr)))
-        return sg_fail("sg_rasterize_forward: provide exactly one of (scales,rotations) / cov3D_precomp", hipSuccess);
-    if (shs && (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1)))
-        return sg_fail("sg_rasterize_forward: sh_coeffs smaller than (sh_degree+1)^2", hipSuccess);
-    SgLayout L;
-    sg_layout(P, c.W, c.H, cap, &L);
-    SgGeom g = sg_geom_view(geom_ws, L);
-    SgBin b = sg_bin_view(binning_ws, L);
-    SgImg im = sg_img_view(image_ws, L);
-    // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
-    // leaves them zeroed for the next call)
-    sg_arm_count(s, &c, num_rendered_host);
-    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4, st);
-    sg_launch_preprocess_fwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
-    SG_CHECK_LAST("preprocess_fwd", s, st);
-    sg_launch_binning(c, P, radii, g, b, cap, write_point_keys, st);
-    SG_CHECK_LAST("binning", s, st);
-    sg_launch_render_fwd(c, g, b, cap, im, out_color, write_point_keys, st);
-    SG_CHECK_LAST("render_fwd", s, st);
-    return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
+    return sg_forward_impl("sg_rasterize_forward", s, &SG_ONE_FRAME, P, nullptr, means3D, shs, colors_precomp, opacities, scales,
+                           rotations, cov3D_precomp, geom_ws, binning_ws, cap, image_ws, out_color, radii, nullptr, nullptr, nullptr,
+                           write_point_keys, num_rendered_host, stream);
+}
+
+extern "C" int sg_rasterize_forward_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const float *means3D,
+                                           const float *shs, const float *colors_precomp, const float *opacities,
+                                           const float *scales, const float *rotations, const float *cov3D_precomp, void *geom_ws,
+                                           void *binning_ws, size_t cap, void *image_ws, float *out_color, int32_t *radii,
+                                           int64_t *num_rendered_host, void *stream)
+{
+    return sg_forward_impl("sg_rasterize_forward_frames", s, fb, P, nullptr, means3D, shs, colors_precomp, opacities, scales,
+                           rotations, cov3D_precomp, geom_ws, binning_ws, cap, image_ws, out_color, radii, nullptr, nullptr, nullptr,
+                           0, num_rendered_host, stream);
 }
 
 extern "C" int sg_read_num_rendered(const void *binning_ws, int64_t *num_rendered_host, void *stream)
 {
-    uint32_t r[2] = { 0, 0 };                                // header words 0 (R) and 1 (bit 0: R > capacity, bit 1: long list)
-    hipError_t e = hipMemcpyAsync(r, binning_ws, 8, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
-    if (e != hipSuccess) return sg_fail("sg_read_num_rendered", e);
-    *num_rendered_host = (r[1] & 2u) ? (int64_t)SG_NUM_RENDERED_LONG_LIST : (int64_t)r[0];
-    return 0;
+    if (!binning_ws || !num_rendered_host) return sg_fail("sg_read_num_rendered: null pointer", hipSuccess);
+    return sg_read_counts(binning_ws, 0, 1, num_rendered_host, stream);      // header words 0 (R) and 1 (bit 0: R > capacity, bit 1: long list)
+}
+
+extern "C" int sg_read_num_rendered_frames(const void *binning_ws, int P, int width, int height, size_t cap, int K,
+                                           int64_t *num_rendered_host, void *stream)
+{
+    SgLayout L;
+    if (!binning_ws || !num_rendered_host || K < 1 || K > SG_MAX_FRAMES) return sg_fail("sg_read_num_rendered_frames: bad argument", hipSuccess);
+    if (sg_layout(P, width, height, cap, &L)) return 1;
+    return sg_read_counts(binning_ws, L.bin_bytes, K, num_rendered_host, stream);
 }
 
 extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
@@ -226,9 +321,9 @@ extern "C" int sg_rasterize_backward(const SgRasterSettings *s, int P, const flo
 }
 
 // first half of the backward: per-tile composite -> one gradient record per (tile, Gaussian) pair in bwd_ws
-extern "C" int sg_rasterize_backward_records(const SgRasterSettings *s, int P, const void *geom_ws, const void *binning_ws,
-                                             size_t cap, const void *image_ws, void *bwd_ws, const float *dL_dout_color,
-                                             void *stream)
+extern "C" int sg_rasterize_backward_records_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const void *geom_ws,
+                                                    const void *binning_ws, size_t cap, const void *image_ws, void *bwd_ws,
+                                                    const float *dL_dout_color, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     SgCam c;
@@ -238,22 +333,30 @@ extern "C" int sg_rasterize_backward_records(const SgRasterSettings *s, int P, c
         return sg_fail("sg_rasterize_backward_records: null pointer", hipSuccess);
     SgLayout L;
     sg_layout(P, c.W, c.H, cap, &L);
+    SgBatch bt;
+    if (sg_make_batch(fb, P, c, L, cap, &bt)) return sg_fail("sg_rasterize_backward_records: bad frame batch", hipSuccess);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
     SgImg im = sg_img_view((void *)image_ws, L);
-    sg_launch_render_bwd(c, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
+    sg_launch_render_bwd(c, bt, g, b, cap, im, dL_dout_color, sg_rec_view(bwd_ws, cap), st);
     SG_CHECK_LAST("render_bwd", s, st);
     return 0;
 }
+extern "C" int sg_rasterize_backward_records(const SgRasterSettings *s, int P, const void *geom_ws, const void *binning_ws,
+                                             size_t cap, const void *image_ws, void *bwd_ws, const float *dL_dout_color,
+                                             void *stream)
+{
+    return sg_rasterize_backward_records_frames(s, &SG_ONE_FRAME, P, geom_ws, binning_ws, cap, image_ws, bwd_ws, dL_dout_color, stream);
+}
 
 // second half: per Gaussian, the sum of its records and the chain rule; accumulate != 0: += into the gradient outputs
-extern "C" int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
-                                               const float *colors_precomp, const float *opacities, const float *scales,
-                                               const float *rotations, const float *cov3D_precomp, const int32_t *radii,
-                                               const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
-                                               int accumulate, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
-                                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
-                                               float *dL_dcov3D, void *stream)
+extern "C" int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const float *means3D,
+                                                      const float *shs, const float *colors_precomp, const float *opacities,
+                                                      const float *scales, const float *rotations, const float *cov3D_precomp,
+                                                      const int32_t *radii, const void *geom_ws, const void *binning_ws, size_t cap,
+                                                      const void *bwd_ws, int accumulate, float *dL_dmeans3D, float *dL_dmeans2D,
+                                                      float *dL_dsh, float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
+                                                      float *dL_drotations, float *dL_dcov3D, void *stream)
 {
     hipStream_t st = (hipStream_t)stream;
     SgCam c;
@@ -264,56 +367,52 @@ extern "C" int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P,
     if (shs && !dL_dsh) return sg_fail("sg_rasterize_backward_gaussians: dL_dsh missing", hipSuccess);
     SgLayout L;
     sg_layout(P, c.W, c.H, cap, &L);
+    SgBatch bt;
+    if (sg_make_batch(fb, P, c, L, cap, &bt)) return sg_fail("sg_rasterize_backward_gaussians: bad frame batch", hipSuccess);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
-    sg_launch_preprocess_bwd(c, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
+    sg_launch_preprocess_bwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
                              sg_rec_view(bwd_ws, cap), cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                              cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, accumulate, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);
     return 0;
 }
-
-static int sg_check_skin(const SgSkinInputs *k, int P, bool fwd)
+extern "C" int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P, const float *means3D, const float *shs,
+                                               const float *colors_precomp, const float *opacities, const float *scales,
+                                               const float *rotations, const float *cov3D_precomp, const int32_t *radii,
+                                               const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
+                                               int accumulate, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
+                                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales, float *dL_drotations,
+                                               float *dL_dcov3D, void *stream)
 {
-    if (!k || k->J <= 0 || k->J > 64) return 1;
-    if (k->rot_format != SG_ROT_CANON_MATRIX && k->rot_format != SG_ROT_CANON_6D) return 1;
-    if (P > 0 && (!k->xyz_canon || !k->lbs_weights || !k->A)) return 1;
-    int e = (k->ext_trans != nullptr) + (k->ext_rot != nullptr) + (k->ext_scale != nullptr);
-    if (e != 0 && e != 3) return 1;
-    if (!fwd && e) return 1;
-    return 0;
+    return sg_rasterize_backward_gaussians_frames(s, &SG_ONE_FRAME, P, means3D, shs, colors_precomp, opacities, scales, rotations,
+                                                  cov3D_precomp, radii, geom_ws, binning_ws, cap, bwd_ws, accumulate, dL_dmeans3D,
+                                                  dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D,
+                                                  stream);
 }
 
-extern "C" size_t sg_skin_ws_floats(int P) { return sg_skin_slab_floats(P > 0 ? P : 1); }
+extern "C" size_t sg_skin_ws_floats(int P) { return sg_skin_slab_floats(P > 0 ? P : 1, 1); }
+extern "C" size_t sg_skin_ws_floats_frames(int P, int K) { return sg_skin_slab_floats(P > 0 ? P : 1, K > 0 ? K : 1); }
 
 extern "C" int sg_skinned_forward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
                                   const float *opacities, const float *scales, void *geom_ws, void *binning_ws,
                                   size_t cap, void *image_ws, float *out_color, int32_t *radii, float *posed_xyz,
                                   float *posed_rotq, float *posed_scales, int64_t *num_rendered_host, void *stream)
 {
-    hipStream_t st = (hipStream_t)stream;
-    SgCam c;
-    if (sg_make_cam(s, &c)) return sg_fail("sg_skinned_forward: bad settings", hipSuccess);
-    if (sg_check_skin(skin, P, true)) return sg_fail("sg_skinned_forward: bad skin inputs (J in 1..64, ext_tfs all or none)", hipSuccess);
-    if (P < 0 || !geom_ws || !binning_ws || !image_ws || !out_color || (P > 0 && (!shs || !opacities || !scales || !radii)))
-        return sg_fail("sg_skinned_forward: null pointer", hipSuccess);
-    if (s->sh_coeffs < (s->sh_degree + 1) * (s->sh_degree + 1))
-        return sg_fail("sg_skinned_forward: sh_coeffs smaller than (sh_degree+1)^2", hipSuccess);
-    SgLayout L;
-    sg_layout(P, c.W, c.H, cap, &L);
-    SgGeom g = sg_geom_view(geom_ws, L);
-    SgBin b = sg_bin_view(binning_ws, L);
-    SgImg im = sg_img_view(image_ws, L);
-    sg_arm_count(s, &c, num_rendered_host);
-    if (!(c.flags & SG_FLAG_WS_CLEAN)) sg_zero_async(b.header, (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4, st);
-    sg_launch_skin_fwd(c, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
-    SG_CHECK_LAST("skin_fwd", s, st);
-    sg_launch_binning(c, P, radii, g, b, cap, 0, st);
-    SG_CHECK_LAST("binning", s, st);
-    sg_launch_render_fwd(c, g, b, cap, im, out_color, 0, st);
-    SG_CHECK_LAST("render_fwd", s, st);
-    return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
+    return sg_forward_impl("sg_skinned_forward", s, &SG_ONE_FRAME, P, skin, nullptr, shs, nullptr, opacities, scales, nullptr, nullptr,
+                           geom_ws, binning_ws, cap, image_ws, out_color, radii, posed_xyz, posed_rotq, posed_scales, 0,
+                           num_rendered_host, stream);
+}
+extern "C" int sg_skinned_forward_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const SgSkinInputs *skin,
+                                         const float *shs, const float *opacities, const float *scales, void *geom_ws,
+                                         void *binning_ws, size_t cap, void *image_ws, float *out_color, int32_t *radii,
+                                         float *posed_xyz, float *posed_rotq, float *posed_scales, int64_t *num_rendered_host,
+                                         void *stream)
+{
+    return sg_forward_impl("sg_skinned_forward_frames", s, fb, P, skin, nullptr, shs, nullptr, opacities, scales, nullptr, nullptr,
+                           geom_ws, binning_ws, cap, image_ws, out_color, radii, posed_xyz, posed_rotq, posed_scales, 0,
+                           num_rendered_host, stream);
 }
 
 extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
@@ -325,7 +424,6 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
                                    float *dL_dmeans2D, float *dL_dA, float *dL_dtransl, void *stream)
 {
     (void)opacities;
-    hipStream_t st = (hipStream_t)stream;
     SgCam c;
     if (sg_make_cam(s, &c)) return sg_fail("sg_skinned_backward: bad settings", hipSuccess);
     if (sg_check_skin(skin, P, false)) return sg_fail("sg_skinned_backward: bad skin inputs (ext_tfs are forward-only)", hipSuccess);
@@ -333,7 +431,6 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
     if (!shs || !scales || !radii || !geom_ws || !binning_ws || !image_ws || !bwd_ws || !skin_ws || !dL_dout_color ||
         !dL_dxyz_canon || !dL_dscales || !dL_dopacity || !dL_dsh || !dL_dmeans2D || !dL_dA)
         return sg_fail("sg_skinned_backward: null pointer", hipSuccess);
-    (void)st;
     int rc = sg_rasterize_backward_records(s, P, geom_ws, binning_ws, cap, image_ws, bwd_ws, dL_dout_color, stream);
     if (rc) return rc;
     return sg_skinned_backward_gaussians(s, P, skin, shs, opacities, scales, radii, geom_ws, binning_ws, cap, bwd_ws, skin_ws, 0,
@@ -341,13 +438,14 @@ extern "C" int sg_skinned_backward(const SgRasterSettings *s, int P, const SgSki
                                          dL_dsh, dL_dmeans2D, dL_dA, dL_dtransl, stream);
 }
 
-extern "C" int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
-                                             const float *opacities, const float *scales, const int32_t *radii,
-                                             const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
-                                             float *skin_ws, int accumulate, const float *dL_dposed_xyz_in,
-                                             const float *dL_dposed_rotq_in, float *dL_dxyz_canon, float *dL_drot_canon,
-                                             float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D,
-                                             float *dL_dA, float *dL_dtransl, void *stream)
+extern "C" int sg_skinned_backward_gaussians_frames(const SgRasterSettings *s, const SgFrameBatch *fb, int P, const SgSkinInputs *skin,
+                                                    const float *shs, const float *opacities, const float *scales,
+                                                    const int32_t *radii, const void *geom_ws, const void *binning_ws, size_t cap,
+                                                    const void *bwd_ws, float *skin_ws, int accumulate,
+                                                    const float *dL_dposed_xyz_in, const float *dL_dposed_rotq_in,
+                                                    float *dL_dxyz_canon, float *dL_drot_canon, float *dL_dscales,
+                                                    float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
+                                                    float *dL_dtransl, void *stream)
 {
     (void)opacities;
     hipStream_t st = (hipStream_t)stream;
@@ -360,13 +458,27 @@ extern "C" int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, c
         return sg_fail("sg_skinned_backward_gaussians: null pointer", hipSuccess);
     SgLayout L;
     sg_layout(P, c.W, c.H, cap, &L);
+    SgBatch bt;
+    if (sg_make_batch(fb, P, c, L, cap, &bt)) return sg_fail("sg_skinned_backward_gaussians: bad frame batch", hipSuccess);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
-    sg_launch_skin_bwd(c, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
+    sg_launch_skin_bwd(c, bt, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
                        skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
                        dL_dtransl, accumulate, st);
     SG_CHECK_LAST("skin_bwd", s, st);
     return 0;
+}
+extern "C" int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkinInputs *skin, const float *shs,
+                                             const float *opacities, const float *scales, const int32_t *radii,
+                                             const void *geom_ws, const void *binning_ws, size_t cap, const void *bwd_ws,
+                                             float *skin_ws, int accumulate, const float *dL_dposed_xyz_in,
+                                             const float *dL_dposed_rotq_in, float *dL_dxyz_canon, float *dL_drot_canon,
+                                             float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D,
+                                             float *dL_dA, float *dL_dtransl, void *stream)
+{
+    return sg_skinned_backward_gaussians_frames(s, &SG_ONE_FRAME, P, skin, shs, opacities, scales, radii, geom_ws, binning_ws, cap,
+                                                bwd_ws, skin_ws, accumulate, dL_dposed_xyz_in, dL_dposed_rotq_in, dL_dxyz_canon,
+                                                dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA, dL_dtransl, stream);
 }
 
 __global__ void sg_mark_visible_kernel(int P, const float *__restrict__ means3D, const float *__restrict__ view,
@@ -396,18 +508,25 @@ extern "C" size_t sg_photo_loss_ws_bytes(int width, int height)
     return width > 0 && height > 0 ? sg_photo_loss_ws_bytes_impl(width, height) : 0;
 }
 
+extern "C" int sg_photo_loss_frames(int K, int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                                    size_t gt_stride, const float *mask, size_t mask_stride, const float *bg, void *ws,
+                                    float *pred_out, float *gt_out, float *losses, const float *upstream, float *dL_draw, void *stream)
+{
+    if (width <= 0 || height <= 0 || K < 1 || K > SG_MAX_FRAMES) return sg_fail("sg_photo_loss: bad image size / K not in 1..16", hipSuccess);
+    if (!raw || !gt_rgb || !mask || !bg || !ws || (!losses && !dL_draw))
+        return sg_fail("sg_photo_loss: null pointer", hipSuccess);
+    sg_launch_photo_loss(K, width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, pred_out, gt_out, losses, upstream,
+                         dL_draw, gt_stride, mask_stride, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sg_fail("sg_photo_loss", e);
+    return 0;
+}
 extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                              const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
                              float *losses, const float *upstream, float *dL_draw, void *stream)
 {
-    if (width <= 0 || height <= 0) return sg_fail("sg_photo_loss: bad image size", hipSuccess);
-    if (!raw || !gt_rgb || !mask || !bg || !ws || (!losses && !dL_draw))
-        return sg_fail("sg_photo_loss: null pointer", hipSuccess);
-    sg_launch_photo_loss(width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, pred_out, gt_out, losses, upstream,
-                         dL_draw, (hipStream_t)stream);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return sg_fail("sg_photo_loss", e);
-    return 0;
+    return sg_photo_loss_frames(1, width, height, l1_w, ssim_w, raw, gt_rgb, 0, mask, 0, bg, ws, pred_out, gt_out, losses, upstream,
+                                dL_draw, stream);
 }
 
 extern "C" int sg_photo_loss_backward(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
@@ -416,7 +535,7 @@ extern "C" int sg_photo_loss_backward(int width, int height, float l1_w, float s
 {
     if (width <= 0 || height <= 0) return sg_fail("sg_photo_loss_backward: bad image size", hipSuccess);
     if (!raw || !gt_rgb || !mask || !bg || !ws || !dL_draw) return sg_fail("sg_photo_loss_backward: null pointer", hipSuccess);
-    sg_launch_photo_loss_bwd(width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, upstream, dL_draw, (hipStream_t)stream);
+    sg_launch_photo_loss_bwd(1, width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, upstream, dL_draw, 0, 0, (hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return sg_fail("sg_photo_loss_backward", e);
     return 0;
@@ -706,20 +825,38 @@ void sg_zero_async(void *p, size_t bytes, hipStream_t st)
 // ---- measurement: the denominator of the HBM roofline ----------------------------------------------------------------
 // A plain 16-byte-per-lane copy (grid-stride, nothing else): what the box's HBM sustains for a read + a write stream.  bench.py
 // times it over >= 1 GiB and quotes `roofline.peak` from it ("float4-copy bandwidth measured on the same box").
-__global__ void __launch_bounds__(256) sg_copy_probe_kernel(float4 *__restrict__ dst, const float4 *__restrict__ src, size_t n)
+// Four independent 16-byte loads per lane, all issued before the first store (a grid-stride loop of ONE load -> store per trip
+// keeps one request in flight per wave and measured 4.6 TB/s on the part the guide quotes at 6.3); NT: non-temporal loads and
+// stores (a once-touched stream need not displace L2 / Infinity Cache lines).  bench.py takes the better of the two.
+typedef float sg_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__global__ void __launch_bounds__(256) sg_copy_probe_kernel(sg_f32x4 *__restrict__ dst, const sg_f32x4 *__restrict__ src, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * 256;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+    sg_f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = base + 256 * u;
+        if (i < n) v[u] = NT ? __builtin_nontemporal_load(src + i) : src[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const size_t i = base + 256 * u;
+        if (i < n) { if (NT) __builtin_nontemporal_store(v[u], dst + i); else dst[i] = v[u]; }
+    }
 }
-extern "C" int sg_copy_probe(void *dst, const void *src, size_t bytes, void *stream)
+extern "C" int sg_copy_probe(void *dst, const void *src, size_t bytes, int non_temporal, void *stream)
 {
     if (!dst || !src || (bytes & 15) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15))
         return sg_fail("sg_copy_probe: 16-byte aligned buffers and a multiple of 16 bytes", hipSuccess);
     if (!bytes) return 0;
     const size_t n = bytes >> 4;
-    size_t blocks = (n + 255) / 256;
-    blocks = blocks > 256 * 32 ? 256 * 32 : blocks;                // 32 workgroups per CU, grid-stride
-    hipLaunchKernelGGL(sg_copy_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)dst, (const float4 *)src, n);
+    const size_t blocks = (n + 1023) / 1024;
+    if (blocks > 0x7fffffffull) return sg_fail("sg_copy_probe: more than 2^41 bytes", hipSuccess);
+    if (non_temporal)
+        hipLaunchKernelGGL(sg_copy_probe_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (sg_f32x4 *)dst, (const sg_f32x4 *)src, n);
+    else
+        hipLaunchKernelGGL(sg_copy_probe_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (sg_f32x4 *)dst, (const sg_f32x4 *)src, n);
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_copy_probe", e);
 }

@@ -56,11 +56,17 @@ __global__ void __launch_bounds__(SG_SCAN_BS)
 sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
-                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal)
+                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal, size_t bin_stride)
 {
     constexpr int NQ = SG_SCAN_NQ;
     __shared__ uint32_t wsum[NQ][SG_SCAN_BS / 64];
     __shared__ uint32_t carry[NQ];
+    {   // frame blockIdx.y of the launch: its binning workspace (K = 1: offset 0)
+        const size_t off = (size_t)blockIdx.y * bin_stride;
+        tile_count = sg_at(tile_count, off); ranges = sg_at(ranges, off); cursor = sg_at(cursor, off); header = sg_at(header, off);
+        plan = sg_at(plan, off); ck_start = sg_at(ck_start, off);
+        if (signal) signal += blockIdx.y;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int first = blockIdx.x * SG_SCAN_BS * tpt;
     // ---- 1. totals of everything in front of this workgroup's range
@@ -159,8 +165,16 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
                        const float *__restrict__ depth, const uint32_t *__restrict__ start,
                        uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
                        uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
-                       uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap, uint32_t *__restrict__ item_w)
+                       uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap, uint32_t *__restrict__ item_w,
+                       size_t bin_stride, size_t geom_stride)
 {
+    {   // frame blockIdx.y
+        const size_t off = (size_t)blockIdx.y * bin_stride;
+        header = sg_at(header, off); pair_gid = sg_at(pair_gid, off); pair_tile = sg_at(pair_tile, off); pair_local = sg_at(pair_local, off);
+        start = sg_at(start, off); pair_keys = sg_at(pair_keys, off); plan = sg_at(plan, off); sort_items = sg_at(sort_items, off);
+        rank_items = sg_at(rank_items, off); items = sg_at(items, off); item_w = sg_at(item_w, off);
+        depth = sg_at(depth, (size_t)blockIdx.y * geom_stride);
+    }
     const uint32_t gtid = blockIdx.x * blockDim.x + threadIdx.x, nthreads = gridDim.x * blockDim.x;
     for (uint32_t tile = gtid; tile < (uint32_t)T; tile += nthreads) {
         const uint4 pl = plan[tile];
@@ -196,10 +210,20 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
                        const uint32_t *__restrict__ pair_gid, const uint32_t *__restrict__ pair_tile,
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
-                       uint32_t *__restrict__ items, uint32_t *__restrict__ item_w, int short_lists, unsigned long long *signal)
+                       uint32_t *__restrict__ items, uint32_t *__restrict__ item_w, int short_lists, unsigned long long *signal,
+                       size_t bin_stride, size_t geom_stride)
 {
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
+    {   // frame blockIdx.y of the launch: its binning workspace and depth array (K = 1: offsets 0)
+        const size_t off = (size_t)blockIdx.y * bin_stride;
+        tile_count = sg_at(tile_count, off); ranges = sg_at(ranges, off); cursor = sg_at(cursor, off); header = sg_at(header, off);
+        plan = sg_at(plan, off); ck_start = sg_at(ck_start, off); pair_gid = sg_at(pair_gid, off); pair_tile = sg_at(pair_tile, off);
+        pair_local = sg_at(pair_local, off); pair_keys = sg_at(pair_keys, off); sort_items = sg_at(sort_items, off);
+        rank_items = sg_at(rank_items, off); items = sg_at(items, off); item_w = sg_at(item_w, off);
+        depth = sg_at(depth, (size_t)blockIdx.y * geom_stride);
+        if (signal) signal += blockIdx.y;
+    }
     __shared__ uint32_t wsum[NQ][SG_SS_THREADS / 64];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     for (int t = tid; t < T; t += SG_SS_THREADS) sStart[t] = tile_count[sg_ctr_of_tile((uint32_t)t, (uint32_t)gx)];
@@ -546,9 +570,14 @@ __global__ void __launch_bounds__(SG_PT_THREADS)
 sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
                          uint64_t *__restrict__ pair_keys, uint64_t *__restrict__ scratch, uint2 *__restrict__ groups,
                          uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
-                         uint32_t resident_max)
+                         uint32_t resident_max, size_t bin_stride)
 {
     __shared__ SgPartLds L;
+    {   // frame blockIdx.y
+        const size_t off = (size_t)blockIdx.y * bin_stride;
+        header = sg_at(header, off); part_items = sg_at(part_items, off); pair_keys = sg_at(pair_keys, off); scratch = sg_at(scratch, off);
+        groups = sg_at(groups, off); point_list = sg_at(point_list, off); point_keys = sg_at(point_keys, off);
+    }
     extern __shared__ __attribute__((aligned(16))) uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
     const int tid = threadIdx.x;
     // (a latency chain: the work item carries the list's range itself, and the first item is requested together with the header)
@@ -615,9 +644,15 @@ sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
 // One workgroup per group: <= 1024 keys -> sorted, as Gaussian ids into point_list (and upstream-format keys on request).
 __global__ void __launch_bounds__(256)
 sg_group_sort_kernel(const uint32_t *__restrict__ header, const uint2 *__restrict__ groups, const uint64_t *__restrict__ pair_keys,
-                     const uint64_t *__restrict__ scratch, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys)
+                     const uint64_t *__restrict__ scratch, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
+                     size_t bin_stride)
 {
     __shared__ uint64_t s[SG_WSORT_MAX + SG_RANKSORT_MAX];
+    {   // frame blockIdx.y
+        const size_t off = (size_t)blockIdx.y * bin_stride;
+        header = sg_at(header, off); groups = sg_at(groups, off); pair_keys = sg_at(pair_keys, off); scratch = sg_at(scratch, off);
+        point_list = sg_at(point_list, off); point_keys = sg_at(point_keys, off);
+    }
     const int tid = threadIdx.x;
     const uint32_t nslots = header[1] || header[7] == 0u ? 0u : header[6];    // (header[7]: groups emitted; 0 = every list was sorted in LDS)
     for (uint32_t gi = blockIdx.x; gi < nslots; gi += gridDim.x) {
@@ -654,10 +689,11 @@ static bool sg_dyn_lds_limit(int which, const void *fn, int bytes)
     return st > 0;
 }
 
-void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
+void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st)
 {
     (void)radii; (void)P;
+    const unsigned K = (unsigned)bt.K;                        // frames: blockIdx.y of every kernel below
     const int T = c.gx * c.gy;
     const uint32_t cap32 = sg_cap32(cap);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
@@ -673,25 +709,25 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
         sg_prof_begin(SG_K_TILE_SCAN, st);
         size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
         const int grid = (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
-        hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
+        hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid, K), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, b.item_w, short_lists, c.count_signal);
+                           b.rank_items, b.items, b.item_w, short_lists, c.count_signal, bt.bin, bt.geom);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
         const int tpt = (T + 65535) / 65536 > 0 ? (T + 65535) / 65536 : 1;
         const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
-        hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid), dim3(1024), 0, st, T, c.gx, tpt, b.tile_count, b.ranges, b.cursor,
+        hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid, K), dim3(1024), 0, st, T, c.gx, tpt, b.tile_count, b.ranges, b.cursor,
                            b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
-                           sg_items_cap(T, cap), short_lists, c.count_signal);
+                           sg_items_cap(T, cap), short_lists, c.count_signal, bt.bin);
         sg_prof_end(SG_K_TILE_SCAN, st);
         sg_prof_begin(SG_K_TILE_SCATTER, st);
         size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
-        hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
+        hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid, K), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
                            b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
-                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w);
+                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w, bt.bin, bt.geom);
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none
@@ -704,11 +740,11 @@ void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, Sg
     uint32_t resident = SG_PT_U * SG_PT_THREADS;
     size_t dyn = (size_t)resident * 8 + (size_t)SG_PT_FINE * 4;
     if (!sg_dyn_lds_limit(1, (const void *)sg_tile_partition_kernel, (int)dyn)) { resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8; }
-    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
+    hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid, K), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
                        b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
-                       resident > SG_PT_NB ? resident : 0u);
+                       resident > SG_PT_NB ? resident : 0u, bt.bin);
     const uint32_t ggrid = sg_rank_items_cap(cap) < 256 ? sg_rank_items_cap(cap) : 256;       // (usually nothing to do: header[7])
-    hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
-                       b.point_list, pk);
+    hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid, K), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
+                       b.point_list, pk, bt.bin);
     sg_prof_end(SG_K_TILE_SORT, st);
 }

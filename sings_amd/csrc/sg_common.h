@@ -144,6 +144,62 @@ static inline SgImg sg_img_view(void *ws, const SgLayout &L)
     return g;
 }
 
+// ---- K frames per launch (round 4) -------------------------------------------------------------------------------------------
+// The frames (poses / cameras) of one optimisation step render the SAME canonical Gaussians: sings_hybrid.py:474-569 hands the model
+// 16 frames per call, and the frame-parallel step renders K frames per rank.  Every kernel of the path takes a frame index --
+// blockIdx.y (composite / binning / loss kernels), a decoded linear block id (per-Gaussian forward: the K blocks of one Gaussian
+// block run back to back on ONE XCD, so the canonical inputs come from HBM once and from that XCD's L2 K - 1 times), or an in-kernel
+// loop (per-Gaussian backward: the K frames' gradients are summed in registers, the gradient row is written ONCE) -- and finds the
+// frame's workspaces at base + frame * stride: K consecutive workspaces of sg_layout's sizes in one allocation.  K = 1 with zero
+// strides is the single-frame call: the same kernels, bit for bit.
+#ifndef SG_MAX_FRAMES
+#define SG_MAX_FRAMES 16
+#endif
+struct SgBatch {
+    int K;                         // frames in this launch
+    int cam_stride;                // 0: one camera for all frames; 1: frame f reads view + 16 f, proj + 16 f, campos + 3 f
+    int transl_stride;             // floats between the frames' translations (0 or 3)
+    int P;                         // Gaussians (radii / means2D of frame f at + f P)
+    size_t geom, bin, img, rec;    // bytes between consecutive frames' workspaces
+    size_t image;                  // floats of one [3,H,W] image (out_color / dL_dout_color of frame f at + f image)
+};
+static inline SgBatch sg_batch_one(int P) { SgBatch b; b.K = 1; b.cam_stride = 0; b.transl_stride = 0; b.P = P; b.geom = b.bin = b.img = b.rec = 0; b.image = 0; return b; }
+// Linear workgroup id -> (Gaussian block, frame) for the per-Gaussian FORWARD kernels.  Workgroups are dealt round-robin to the 8
+// XCDs (id % 8); inside an XCD the K frames of one Gaussian block take consecutive slots, so the block's canonical inputs (means,
+// scales, SH rows, 4 J bytes of skinning weights per Gaussian) are fetched from HBM by the first of them and served by that XCD's
+// L2 to the others.  K = 1: the identity.  Grid: sg_frame_grid(nblocks, K) workgroups; false = surplus workgroup.
+__device__ __forceinline__ bool sg_block_frame(int id, int K, int nblocks, int &gblock, int &frame)
+{
+    const int xcd = id & 7, slot = id >> 3;
+    frame = slot % K;
+    gblock = (slot / K) * 8 + xcd;
+    return gblock < nblocks;
+}
+static inline unsigned sg_frame_grid(int nblocks, int K) { return (unsigned)(((nblocks + 7) / 8) * 8 * K); }
+template <class T> __host__ __device__ __forceinline__ T *sg_at(T *p, size_t bytes) { return p ? (T *)((char *)p + bytes) : p; }
+__host__ __device__ __forceinline__ SgGeom sg_frame(SgGeom g, size_t off)
+{
+    g.recA = sg_at(g.recA, off); g.recB = sg_at(g.recB, off); g.recC = sg_at(g.recC, off);
+    g.depth = sg_at(g.depth, off); g.flags = sg_at(g.flags, off); g.slot = sg_at(g.slot, off);
+    return g;
+}
+__host__ __device__ __forceinline__ SgBin sg_frame(SgBin b, size_t off)
+{
+    b.header = sg_at(b.header, off); b.tile_count = sg_at(b.tile_count, off); b.ranges = sg_at(b.ranges, off);
+    b.cursor = sg_at(b.cursor, off); b.pair_keys = sg_at(b.pair_keys, off); b.point_list = sg_at(b.point_list, off);
+    b.point_keys = sg_at(b.point_keys, off); b.pair_gid = sg_at(b.pair_gid, off); b.pair_tile = sg_at(b.pair_tile, off);
+    b.pair_local = sg_at(b.pair_local, off); b.sort_items = sg_at(b.sort_items, off); b.rank_items = sg_at(b.rank_items, off);
+    b.items = sg_at(b.items, off); b.ck_start = sg_at(b.ck_start, off); b.plan = sg_at(b.plan, off);
+    b.pair_mask = sg_at(b.pair_mask, off); b.item_w = sg_at(b.item_w, off); b.item_perm = sg_at(b.item_perm, off);
+    return b;
+}
+__host__ __device__ __forceinline__ SgImg sg_frame(SgImg i, size_t off)
+{
+    i.final_T = sg_at(i.final_T, off); i.n_contrib = sg_at(i.n_contrib, off); i.ckpt = sg_at(i.ckpt, off);
+    return i;
+}
+__host__ __device__ __forceinline__ SgRec sg_frame(SgRec r, size_t off) { r.a = sg_at(r.a, off); r.b = sg_at(r.b, off); return r; }
+
 // Kernel parameter block for per-Gaussian kernels
 struct SgCam {
     int W, H, gx, gy, flags;
@@ -152,20 +208,27 @@ struct SgCam {
     const float *view, *proj, *campos, *bg;
     unsigned long long *count_signal;      // mapped host word the tile scan publishes (valid bit | flags << 32 | R) to, or null
 };
+__host__ __device__ __forceinline__ SgCam sg_frame(SgCam c, int frame, int cam_stride)
+{
+    const size_t f = (size_t)frame * (size_t)cam_stride;
+    c.view += 16 * f; c.proj += 16 * f; c.campos += 3 * f;
+    if (c.count_signal) c.count_signal += frame;
+    return c;
+}
 
 // launchers (defined in the .hip files)
-void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
+void sg_launch_preprocess_fwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, SgGeom g, SgBin b,
                               size_t cap, int32_t *radii, hipStream_t st);
-void sg_launch_binning(const SgCam &c, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
+void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *radii, SgGeom g, SgBin b, size_t cap,
                        int write_keys, hipStream_t st);
 static inline uint32_t sg_cap32(size_t cap) { return cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap; }
-void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
+void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           int write_keys, hipStream_t st);
-void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
+void sg_launch_render_bwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, SgRec grec, hipStream_t st);
-void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
+void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
                               const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
@@ -190,10 +253,10 @@ void sg_prof_begin(int id, hipStream_t st);
 void sg_prof_end(int id, hipStream_t st);
 
 // LBS-fused per-Gaussian kernels (sg_skin.hip)
-void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
+void sg_launch_skin_fwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
                         float *posed_rotq, float *posed_scales, hipStream_t st);
-size_t sg_skin_slab_floats(int P);
+size_t sg_skin_slab_floats(int P, int K);
 size_t sg_photo_loss_ws_bytes_impl(int W, int H);
 int sg_tp_check(const SgTriplane *tp);
 size_t sg_triplane_ws_bytes_impl(const SgTriplane *tp);
@@ -230,13 +293,13 @@ int sg_launch_knn_finish(int N, int K, const float *scales, void *ws, float *mea
                          float *d_scales, hipStream_t st);
 int sg_launch_knn_edge(int N, int K, const float *xyz, const float *scales, void *ws, float *mean_edge_out, float *loss,
                        const float *upstream, float *d_scales, hipStream_t st);
-void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+void sg_launch_photo_loss(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                           const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
-                          float *losses, const float *upstream, float *dL_draw, hipStream_t st);
-void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                          float *losses, const float *upstream, float *dL_draw, size_t gt_stride, size_t mask_stride, hipStream_t st);
+void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
-                              hipStream_t st);
-void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
+                              size_t gt_stride, size_t mask_stride, hipStream_t st);
+void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const float *dposed_xyz_in,
                         const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,

@@ -25,6 +25,10 @@ struct SgLossArgs {
     int W, H;
     float l1_w, ssim_w;
     float w[11];                  // the reference's fp32 window: exp(-(x-5)^2 / (2 * 1.5^2)), normalised
+    // K frames per launch (round 4): blockIdx.z = 3 frame + channel.  Frame f: raw / gradient / optional images at + 3 H W f,
+    // target at + gt_stride f, mask at + mask_stride f (floats; 0 = one target / mask for all frames), workspace at + ws_stride f
+    // bytes, losses at + 4 f
+    size_t gt_stride, mask_stride, ws_stride;
 };
 
 __device__ __forceinline__ float sg_clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
@@ -42,8 +46,16 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
     float acc_l1 = 0.0f, acc_ssim = 0.0f, acc_mask = 0.0f;
+    const int frame = blockIdx.z / 3;
+    {
+        const size_t fi = (size_t)frame * 3 * hw;
+        raw += fi; gt_rgb += (size_t)frame * a.gt_stride; mask += (size_t)frame * a.mask_stride;
+        maps = sg_at(maps, (size_t)frame * a.ws_stride); partial = sg_at(partial, (size_t)frame * a.ws_stride);
+        if (pred_out) pred_out += fi;
+        if (gt_out) gt_out += fi;
+    }
     {   // one (tile, channel) per workgroup: a 512x896 frame is only 448 tiles, fewer than two per CU
-        const int ch = blockIdx.z;
+        const int ch = blockIdx.z - 3 * frame;
         const float bgc = bg[ch];
         for (int i = tid; i < SG_LH * SG_LH; i += 256) {
             const int r = i / SG_LH, c = i - r * SG_LH;
@@ -139,7 +151,7 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
     if (tid == 0) {
         float t0 = 0, t1 = 0, t2 = 0;
         for (int w = 0; w < 4; w++) { t0 += sRed[w][0]; t1 += sRed[w][1]; t2 += sRed[w][2]; }
-        partial[(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float4(t0, t1, t2, 0.0f);
+        partial[((blockIdx.z - 3 * frame) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float4(t0, t1, t2, 0.0f);
     }
 }
 
@@ -149,6 +161,8 @@ sg_loss_reduce_kernel(SgLossArgs a, const float4 *__restrict__ partial, int nblo
                       float *__restrict__ losses)
 {
     __shared__ double sR[256][3];
+    partial = sg_at(partial, (size_t)blockIdx.x * a.ws_stride); scalars = sg_at(scalars, (size_t)blockIdx.x * a.ws_stride);   // frame blockIdx.x
+    if (losses) losses += 4 * blockIdx.x;
     double t0 = 0, t1 = 0, t2 = 0;
     for (int i = threadIdx.x; i < nblocks; i += 256) { const float4 p = partial[i]; t0 += p.x; t1 += p.y; t2 += p.z; }
     sR[threadIdx.x][0] = t0; sR[threadIdx.x][1] = t1; sR[threadIdx.x][2] = t2;
@@ -181,11 +195,17 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
     const int tid = threadIdx.x;
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
-    // upstream = (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL
+    const int frame = blockIdx.z / 3;
+    {
+        const size_t fi = (size_t)frame * 3 * hw;
+        raw += fi; gt_rgb += (size_t)frame * a.gt_stride; mask += (size_t)frame * a.mask_stride; dL_draw += fi;
+        maps = sg_at(maps, (size_t)frame * a.ws_stride); scalars = sg_at(scalars, (size_t)frame * a.ws_stride);
+    }
+    // upstream = (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL (the same for all frames)
     const float u_l1 = upstream ? upstream[0] : 1.0f, u_ss = upstream ? upstream[1] : 1.0f;
     const float c_l1 = scalars[4] * u_l1, c_ss = scalars[5] * u_ss;
     {
-        const int ch = blockIdx.z;
+        const int ch = blockIdx.z - 3 * frame;
         for (int i = tid; i < SG_LH * SG_LH; i += 256) {
             const int r = i / SG_LH, c = i - r * SG_LH;
             const int x = X0 - 5 + c, y = Y0 - 5 + r;
@@ -256,10 +276,11 @@ size_t sg_photo_loss_ws_bytes_impl(int W, int H)
     return sg_align(9 * hw * 4) + sg_align(nb * 16) + 256;
 }
 
-static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w)
+static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt_stride = 0, size_t mask_stride = 0)
 {
     SgLossArgs a;
     a.W = W; a.H = H; a.l1_w = l1_w; a.ssim_w = ssim_w;
+    a.gt_stride = gt_stride; a.mask_stride = mask_stride; a.ws_stride = sg_photo_loss_ws_bytes_impl(W, H);
     {   // losses/utils.py:28-30 in fp32, like torch.Tensor([...]) / sum()
         float g[11], s = 0.0f;
         for (int x = 0; x < 11; x++) { g[x] = (float)exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5)); }
@@ -270,14 +291,14 @@ static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w)
 }
 
 // gradient pass alone over the workspace of an earlier forward-only call (window statistics + scalars)
-void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
-                              hipStream_t st)
+                              size_t gt_stride, size_t mask_stride, hipStream_t st)
 {
-    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w);
+    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride);
     const size_t hw = (size_t)W * H;
-    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3), block(256);
-    const int nb = (int)(grid.x * grid.y * grid.z);
+    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3 * K), block(256);
+    const int nb = (int)(grid.x * grid.y * 3);
     const char *b = (const char *)ws;
     const float *maps = (const float *)b;
     const float *scalars = (const float *)(b + sg_align(9 * hw * 4) + sg_align((size_t)nb * 16));
@@ -286,21 +307,22 @@ void sg_launch_photo_loss_bwd(int W, int H, float l1_w, float ssim_w, const floa
     sg_prof_end(SG_K_PHOTO_LOSS, st);
 }
 
-void sg_launch_photo_loss(int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+// K frames per launch: three launches for the K losses and gradients (frame = blockIdx.z / 3), K = 1: the single-frame call
+void sg_launch_photo_loss(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                           const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
-                          float *losses, const float *upstream, float *dL_draw, hipStream_t st)
+                          float *losses, const float *upstream, float *dL_draw, size_t gt_stride, size_t mask_stride, hipStream_t st)
 {
-    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w);
+    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride);
     const size_t hw = (size_t)W * H;
-    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3), block(256);
-    const int nb = (int)(grid.x * grid.y * grid.z);
+    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3 * K), block(256);
+    const int nb = (int)(grid.x * grid.y * 3);
     char *b = (char *)ws;
     float *maps = (float *)b;
     float4 *partial = (float4 *)(b + sg_align(9 * hw * 4));
     float *scalars = (float *)(b + sg_align(9 * hw * 4) + sg_align((size_t)nb * 16));
     sg_prof_begin(SG_K_PHOTO_LOSS, st);
     hipLaunchKernelGGL(sg_ssim_stats_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, pred_out, gt_out, partial);
-    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(1), dim3(256), 0, st, a, partial, nb, scalars, losses);
+    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(K), dim3(256), 0, st, a, partial, nb, scalars, losses);
     if (dL_draw)
         hipLaunchKernelGGL(sg_ssim_grad_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, scalars, upstream, dL_draw);
     sg_prof_end(SG_K_PHOTO_LOSS, st);

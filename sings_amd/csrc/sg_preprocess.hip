@@ -9,15 +9,20 @@
 
 template <int D>
 __global__ void __launch_bounds__(256)
-sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
+sg_preprocess_fwd_kernel(SgCam c, SgBatch bt, int P, const float *__restrict__ means3D,
                          const float *__restrict__ shs, const float *__restrict__ colors_precomp,
                          const float *__restrict__ opacities, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii, int hist_tiles)
+                         SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii, int hist_tiles, int nblocks)
 {
     extern __shared__ uint32_t sg_hist_lds[];               // hist_tiles words (0: per-pair global atomics)
     __shared__ uint32_t scratch_all[4][192];
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    // (Gaussian block, camera) of this workgroup: the K cameras of one block run back to back on ONE XCD (sg_block_frame)
+    int gblock, frame;
+    if (!sg_block_frame((int)blockIdx.x, bt.K, nblocks, gblock, frame)) return;
+    c = sg_frame(c, frame, bt.cam_stride); g = sg_frame(g, (size_t)frame * bt.geom); bn = sg_frame(bn, (size_t)frame * bt.bin);
+    radii += (size_t)frame * bt.P;
+    const int idx = gblock * 256 + (int)threadIdx.x;
     const int wave = threadIdx.x >> 6;
     const bool live = idx < P;
     constexpr int nc = (D + 1) * (D + 1);
@@ -56,16 +61,17 @@ sg_preprocess_fwd_kernel(SgCam c, int P, const float *__restrict__ means3D,
     sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave], hist_tiles ? sg_hist_lds : nullptr, hist_tiles);
 }
 
-void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const float *shs,
+void sg_launch_preprocess_fwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp, SgGeom g, SgBin b,
                               size_t cap, int32_t *radii, hipStream_t st)
 {
     if (P <= 0) return;
-    dim3 grid((P + 255) / 256), block(256);
+    const int nblocks = (P + 255) / 256;
+    dim3 grid(sg_frame_grid(nblocks, bt.K)), block(256);
     const int ht = sg_lds_hist(c.gx, c.gy) ? (int)sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) : 0;     // histogram words (= tile counters)
-#define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, (size_t)ht * 4, st, c, P, means3D, shs, \
-                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii, ht)
+#define SG_PP(DD) hipLaunchKernelGGL(sg_preprocess_fwd_kernel<DD>, grid, block, (size_t)ht * 4, st, c, bt, P, means3D, shs, \
+                                     colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, sg_cap32(cap), radii, ht, nblocks)
     int D = colors_precomp ? 0 : c.D;
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (D) { case 0: SG_PP(0); break; case 1: SG_PP(1); break; case 2: SG_PP(2); break; default: SG_PP(3); break; }
@@ -76,13 +82,19 @@ void sg_launch_preprocess_fwd(const SgCam &c, int P, const float *means3D, const
 // ------------------------------------------------------------------------------------------
 // ACC: add to the gradient outputs instead of writing them (a compile-time switch: as a runtime flag the untaken branches cost
 // the plain kernel 3.8 us of its 33 -- same-box A/B)
-template <int D, bool ACC>
+// K cameras (bt.K frames) of the SAME Gaussians: the kernel walks the frames -- records of frame f, chain rule with camera f -- and
+// sums the K gradients of a Gaussian in registers, in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K
+// single-camera calls leave behind when the first writes the gradient buffer and the others run with accumulate = 1), then writes
+// the 248-byte gradient row ONCE: K - 1 read-modify-write passes over the buffer less (at cfg3 2 x 47 MB per view), and the
+// Gaussian's inputs (236 B) are read once for the K cameras.  dL_dmeans2D (the densifier's per-view statistic) is per frame.
+// ONE: bt.K == 1 known at compile time (the single-camera entry points): no loop, the round-3 kernel.
+template <int D, bool ACC, bool ONE>
 __global__ void __launch_bounds__(256)
-sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
+sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         const int32_t *__restrict__ radii, SgGeom g, SgRec grec,
-                         size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0,
+                         size_t cap, const uint32_t *__restrict__ header0, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
@@ -90,34 +102,29 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
     constexpr bool accumulate = ACC;
     __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g0 = idx - lane;
+    const int lane_all = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
+    const int g0 = idx - lane_all;
     if (g0 >= P) return;                                    // whole wave out of range
-    float *L = lds_all[wave];
     const bool live = idx < P;
-    SgGaussGrad G;
-#pragma unroll
-    for (int k = 0; k < 3; k++) { G.dmean[k] = 0; G.dcol[k] = 0; G.dsc[k] = 0; }
-#pragma unroll
-    for (int k = 0; k < 4; k++) G.drot[k] = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) G.g6[k] = 0;
-    G.g2[0] = G.g2[1] = 0; G.dop = 0;
-    // after a forward that overflowed (header[1] != 0) the backward composite wrote no records: every gradient is ZERO, the
-    // stale contents of the record buffer are never summed (asynchronous overflow check: rasterizer.py)
-    const bool vis = live && radii[idx] > 0 && header[1] == 0u;
-    const int Mrows = c.M;
+    const int Mrows = c0.M;
+    const int nframes = ONE ? 1 : bt.K;
     constexpr int nc = (D + 1) * (D + 1);
     const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
-    // 0. issue every load that does not depend on another one up front (one memory round trip, not four)
-    float4 rc = make_float4(0, 0, 0, 0);
+    // the Gaussian's inputs: read ONCE for all frames (a Gaussian that no frame sees loads nothing)
     float p[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 }, sh[nc * 3], dsh[nc * 3];
-    uint32_t flags = 0;
 #pragma unroll
     for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
-    if (vis) {
-        { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
-        flags = g.flags[idx];
+    bool any_vis = false;
+#pragma unroll 1
+    for (int f = 0; f < nframes; f++)
+        any_vis |= live && radii0[(size_t)f * bt.P + idx] > 0 && sg_at(header0, (size_t)f * bt.bin)[1] == 0u;
+    // frame f + 1's (visible, record slot, clamp flags) are requested while frame f is worked on; frame 0's go out together with
+    // the Gaussian's inputs: two dependent memory round trips in front of the first record sum, as in the single-frame kernel
+    bool vis_n = live && radii0[idx] > 0 && header0[1] == 0u;
+    uint2 sl_n = make_uint2(0u, 0u);
+    uint32_t fl_n = 0u;
+    if (vis_n) { sl_n = g0_.slot[idx]; fl_n = g0_.flags[idx]; }
+    if (any_vis) {
         p[0] = means3D[3 * idx]; p[1] = means3D[3 * idx + 1]; p[2] = means3D[3 * idx + 2];
         if (!cov3D_precomp) {
             s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
@@ -137,13 +144,71 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
             }
         }
     }
-    // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
-    float a9[9];
-    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
-    // 2. the chain rule
-    if (vis)
-        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
-                          dL_dsh != nullptr, dsh, G);
+    const int idx_all = idx;
+    SgGaussGrad A;                                          // the sum over the frames
+#pragma unroll
+    for (int k = 0; k < 3; k++) { A.dmean[k] = 0; A.dcol[k] = 0; A.dsc[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) A.drot[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) A.g6[k] = 0;
+    A.g2[0] = A.g2[1] = 0; A.dop = 0;
+#pragma unroll 1
+    for (int f = 0; f < nframes; f++) {
+        // (opaque per trip: keeps hipcc from hoisting what depends on them only -- LDS addresses, shuffle indices, the per-frame
+        //  arrays' addresses -- in front of the loop, where it would stay live across it: see sg_skin_bwd_kernel)
+        int idx = idx_all, lane = lane_all, wave = wave_all;
+        if (!ONE) asm volatile("" : "+v"(idx), "+v"(lane), "+v"(wave));
+        float *L = lds_all[wave];
+        const SgCam c = sg_frame(c0, f, bt.cam_stride);
+        const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
+        SgGaussGrad G;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { G.dmean[k] = 0; G.dcol[k] = 0; G.dsc[k] = 0; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) G.drot[k] = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) G.g6[k] = 0;
+        G.g2[0] = G.g2[1] = 0; G.dop = 0;
+        // after a forward that overflowed (header[1] != 0) the backward composite wrote no records: every gradient is ZERO, the
+        // stale contents of the record buffer are never summed (asynchronous overflow check: rasterizer.py)
+        const bool vis = vis_n;
+        float4 rc = make_float4(0, 0, 0, 0);
+        rc.y = __uint_as_float(sl_n.x); rc.w = __uint_as_float(sl_n.y);
+        const uint32_t flags = fl_n;
+        if (f + 1 < nframes) {
+            const SgGeom gn = sg_frame(g0_, (size_t)(f + 1) * bt.geom);
+            vis_n = live && radii0[(size_t)(f + 1) * bt.P + idx] > 0 && sg_at(header0, (size_t)(f + 1) * bt.bin)[1] == 0u;
+            sl_n = make_uint2(0u, 0u); fl_n = 0u;
+            if (vis_n) { sl_n = gn.slot[idx]; fl_n = gn.flags[idx]; }
+        }
+        // 1. this Gaussian's gradient records of frame f (wave-cooperative, coalesced)
+        float a9[9];
+        sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+        // 2. the chain rule; dL/dsh rows: frame 0 assigns, later frames add (`first`)
+        if (vis)
+            sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
+                              dL_dsh != nullptr, dsh, G, f == 0);
+        // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
+        if (live) {
+            float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
+            m2[0] = G.g2[0]; m2[1] = G.g2[1]; m2[2] = 0.0f;
+        }
+        if (f == 0) {
+            A = G;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { A.dmean[k] += G.dmean[k]; A.dcol[k] += G.dcol[k]; A.dsc[k] += G.dsc[k]; }
+#pragma unroll
+            for (int k = 0; k < 4; k++) A.drot[k] += G.drot[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) A.g6[k] += G.g6[k];
+            A.dop += G.dop;
+        }
+    }
+    SgGaussGrad &G = A;
+    const int lane = lane_all;
+    float *L = lds_all[wave_all];
     // 3. dL/dsh rows out (every one of the M rows is written; coalesced through LDS when staged)
     if (dL_dsh) {
         if (staged) {
@@ -173,11 +238,9 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
         }
     }
     if (!live) return;
-    // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
-    dL_dmeans2D[3 * idx] = G.g2[0]; dL_dmeans2D[3 * idx + 1] = G.g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     if (accumulate) {
-        // the views of one optimisation step share ONE gradient buffer: this view adds to what the views in front of it in the
-        // step's chain left there (the old values are requested together, here: one more memory round trip per wave)
+        // the batches of one optimisation step share ONE gradient buffer: this batch adds to what the batches in front of it in
+        // the step's chain left there (the old values are requested together, here: one more memory round trip per wave)
         float o3[3], os[3], orr[4], oc[3], og[6], oo;
 #pragma unroll
         for (int k = 0; k < 3; k++) o3[k] = dL_dmeans3D[3 * idx + k];
@@ -207,7 +270,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
     }
 }
 
-void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const float *shs,
+void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
                               const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
@@ -218,10 +281,11 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
     (void)opacities;
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
-#define SG_PB2(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, means3D, shs, \
+#define SG_PB3(DD, AA, OO) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA, OO>), grid, block, 0, st, c, bt, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
                                      grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+#define SG_PB2(DD, AA) do { if (bt.K == 1) SG_PB3(DD, AA, true); else SG_PB3(DD, AA, false); } while (0)
 #define SG_PB(DD) do { if (accumulate) SG_PB2(DD, true); else SG_PB2(DD, false); } while (0)
     int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
@@ -229,4 +293,5 @@ void sg_launch_preprocess_bwd(const SgCam &c, int P, const float *means3D, const
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_PB
 #undef SG_PB2
+#undef SG_PB3
 }

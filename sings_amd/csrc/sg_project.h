@@ -376,12 +376,13 @@ __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool
 
 // Backward of sg_project_fwd for one VISIBLE Gaussian.  a9 = summed record
 // (mean2D.x, mean2D.y, conic.x, conic.y, conic.w, opacity, colour r,g,b).
-// dsh_out: (D+1)^2 x 3 gradient rows of this Gaussian (written iff want_sh; pass a local array).
+// dsh_out: (D+1)^2 x 3 gradient rows of this Gaussian (written iff want_sh; pass a local array); `first` false: ADDED to what the
+// array holds (the frames of one step summed in registers).
 template <int D>
 __device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3], const float s3[3], const float q[4],
                                                const float *__restrict__ c6pre, const float *__restrict__ sh,
                                                uint32_t clampbits, const float a9[9], bool want_sh,
-                                               float *__restrict__ dsh_out, SgGaussGrad &G)
+                                               float *__restrict__ dsh_out, SgGaussGrad &G, bool first = true)
 {
     float *dmean = G.dmean, *g2 = G.g2, *dcol = G.dcol, *dsc = G.dsc, *drot = G.drot, *g6 = G.g6;
     g2[0] = a9[0]; g2[1] = a9[1];
@@ -497,7 +498,8 @@ __device__ __forceinline__ void sg_project_bwd(const SgCam &c, const float p[3],
         for (int k = 0; k < nc; k++)
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-                dsh_out[3 * k + ch] = bas[k] * dRGB[ch];
+                // frames of one step (sg_preprocess_bwd_kernel / sg_skin_bwd_kernel): frame 0 assigns, later frames add
+                dsh_out[3 * k + ch] = first ? bas[k] * dRGB[ch] : dsh_out[3 * k + ch] + bas[k] * dRGB[ch];
                 if (k > 0) {
                     float sv = sh[3 * k + ch] * dRGB[ch];
                     ddir[0] += db[3 * k] * sv; ddir[1] += db[3 * k + 1] * sv; ddir[2] += db[3 * k + 2] * sv;

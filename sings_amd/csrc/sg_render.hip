@@ -353,33 +353,49 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     }
 }
 
+// Frame blockIdx.y of a launch of K frames (sg_common.h, SgBatch): the frame's workspaces at base + frame x stride, its image at
+// + frame x 3 H W, its camera-independent inputs unchanged.  K = 1: every offset is 0 -- the single-frame kernel, bit for bit.
+// (gridDim.x is a multiple of 8, so blockIdx.x % 8 is the XCD of a workgroup in every frame: sg_tile_of_block.)
+#define SG_FWD_FRAME_OFFSETS                                                                                            \
+    {                                                                                                                   \
+        const size_t fb = (size_t)blockIdx.y * bt.bin, fg = (size_t)blockIdx.y * bt.geom, fi = (size_t)blockIdx.y * bt.img; \
+        ranges = sg_at(ranges, fb); pair_keys = sg_at(pair_keys, fb); point_list = sg_at(point_list, fb);                \
+        point_keys = sg_at(point_keys, fb); ck_start = sg_at(ck_start, fb); header = sg_at(header, fb);                  \
+        pair_mask = sg_at(pair_mask, fb); tile_count = sg_at(tile_count, fb); long_items = sg_at(long_items, fb);        \
+        plan = sg_at(plan, fb); item_w = sg_at(item_w, fb);                                                              \
+        recA = sg_at(recA, fg); recB = sg_at(recB, fg); recC = sg_at(recC, fg);                                          \
+        final_T = sg_at(final_T, fi); n_contrib = sg_at(n_contrib, fi); ckpt = sg_at(ckpt, fi);                          \
+        out_color += (size_t)blockIdx.y * bt.image;                                                                      \
+    }
 // The plain loop at eight waves per SIMD: frames of many tiles (cfg3: 8 160 tiles, lists of ~100 entries, every SIMD busy).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-sg_render_fwd_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<false>(SG_FWD_ARGS); }
+sg_render_fwd_kernel(SgBatch bt, SG_FWD_PARAMS) { SG_FWD_FRAME_OFFSETS; sg_render_fwd_body<false>(SG_FWD_ARGS); }
 // The pipelined loop: frames of few tiles with lists of thousands of entries (an avatar in front of a background: T <= 4096, the
 // regime of the LDS histogram in the preprocess), where the kernel ends in a handful of deep tiles, one wave per SIMD.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
-sg_render_fwd_deep_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<true>(SG_FWD_ARGS); }
+sg_render_fwd_deep_kernel(SgBatch bt, SG_FWD_PARAMS) { SG_FWD_FRAME_OFFSETS; sg_render_fwd_body<true>(SG_FWD_ARGS); }
 
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
 
-void sg_launch_render_fwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
+void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, size_t cap, SgImg im, float *out_color,
                           int write_keys, hipStream_t st)
 {
     static_assert(SG_FB == SG_SEG, "forward batches are the checkpoint granularity");
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
+    const unsigned K = (unsigned)bt.K;
     sg_prof_begin(SG_K_RENDER_FWD, st);
     if (sg_lds_hist(c.gx, c.gy)) {
-        // upper bound: quadrants 1..3 of every long tile (most blocks exit at once); none in throughput mode
-        const int extra = sg_split_long(c.gx, c.gy, c.flags) ? 3 * (int)sg_sort_items_cap(T, cap) : 0;
-        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid), dim3(256), 0, st, c.W, c.H, c.gx, T, extra, b.ranges,
+        // upper bound: quadrants 1..3 of every long tile (most blocks exit at once); none in throughput mode.  (Rounded up to a
+        // multiple of 24: whole tiles, and gridDim.x stays a multiple of 8 -- the XCD of a block is blockIdx.x % 8 in every frame.)
+        const int extra = sg_split_long(c.gx, c.gy, c.flags) ? ((3 * (int)sg_sort_items_cap(T, cap) + 23) / 24) * 24 : 0;
+        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, extra, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
                            (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap));
     } else
-        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
@@ -465,8 +481,20 @@ __device__ __forceinline__ int sg_red_idx(int lane)
     if (lane == 63) *slot = v8;                                                                                       \
     do { } while (0)
 
+// frame blockIdx.y of a launch of K frames (see SG_FWD_FRAME_OFFSETS)
+#define SG_BWD_FRAME_OFFSETS                                                                                            \
+    {                                                                                                                   \
+        const size_t fb = (size_t)blockIdx.y * bt.bin, fg = (size_t)blockIdx.y * bt.geom, fi = (size_t)blockIdx.y * bt.img, \
+                     fr = (size_t)blockIdx.y * bt.rec;                                                                   \
+        ranges = sg_at(ranges, fb); point_list = sg_at(point_list, fb); header = sg_at(header, fb); items = sg_at(items, fb); \
+        ck_start = sg_at(ck_start, fb); pair_mask = sg_at(pair_mask, fb);                                                \
+        recA = sg_at(recA, fg); recB = sg_at(recB, fg); recC = sg_at(recC, fg);                                          \
+        final_T = sg_at(final_T, fi); n_contrib = sg_at(n_contrib, fi); ckpt = sg_at(ckpt, fi);                          \
+        grec_a = sg_at(grec_a, fr); grec_b = sg_at(grec_b, fr);                                                          \
+        dL_dpix += (size_t)blockIdx.y * bt.image;                                                                        \
+    }
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
+sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                      const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                      const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -481,6 +509,7 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
+    SG_BWD_FRAME_OFFSETS;
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
     (void)T; (void)nblocks;
@@ -625,9 +654,14 @@ sg_render_bwd_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__re
 #define SG_ITEM_CLASSES 33
 __device__ __forceinline__ uint32_t sg_item_class(uint32_t w) { return 32u - (w > 255u ? 32u : (w + 7u) / 8u); }      // 0 = heaviest
 __global__ void __launch_bounds__(256)
-sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap,
+sg_zero_records_kernel(SgBatch bt, const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap,
                        const uint32_t *__restrict__ item_w, uint32_t *__restrict__ perm)
 {
+    {   // frame blockIdx.y
+        const size_t fb = (size_t)blockIdx.y * bt.bin, fr = (size_t)blockIdx.y * bt.rec;
+        header = sg_at(header, fb); item_w = sg_at(item_w, fb); perm = sg_at(perm, fb);
+        grec_a = sg_at(grec_a, fr); grec_b = sg_at(grec_b, fr);
+    }
     if (blockIdx.x == 0) {
         constexpr uint32_t KEEP = 8192u;
         __shared__ uint32_t sCls[SG_ITEM_CLASSES];
@@ -666,7 +700,7 @@ sg_zero_records_kernel(const uint32_t *__restrict__ header, float4 *__restrict__
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
-sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
+sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                             const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
                             const float4 *__restrict__ recB, const float4 *__restrict__ recC,
                             const float *__restrict__ bg, const float *__restrict__ final_T,
@@ -682,6 +716,8 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the sub-batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
     (void)T; (void)nblocks;
+    SG_BWD_FRAME_OFFSETS;
+    perm = sg_at(perm, (size_t)blockIdx.y * bt.bin);
     const int nitems = header[1] ? 0 : (int)header[5];
     if ((int)blockIdx.x >= nitems) return;
     const uint32_t pit = perm[blockIdx.x];
@@ -794,24 +830,25 @@ sg_render_bwd_sparse_kernel(int W, int H, int gx, int T, int nblocks, const uint
     }
 }
 
-void sg_launch_render_bwd(const SgCam &c, SgGeom g, SgBin b, size_t cap, SgImg im,
+void sg_launch_render_bwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, SgRec grec, hipStream_t st)
 {
     static_assert(SG_SEG % SG_BB == 0, "segments are whole backward batches");
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks((int)sg_items_cap((size_t)T, cap));
+    const unsigned K = (unsigned)bt.K;
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     sg_prof_begin(SG_K_RENDER_BWD, st);
     if (sg_lds_hist(c.gx, c.gy)) {
         // few tiles, long lists: zero the records, then only the entries the forward composited are touched
         const uint32_t zg = cap32 / 1024u + 1u < 1024u ? cap32 / 1024u + 1u : 1024u;
-        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg), dim3(256), 0, st, b.header, grec.a, grec.b, cap32, b.item_w, b.item_perm);
-        hipLaunchKernelGGL(sg_render_bwd_sparse_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg, K), dim3(256), 0, st, bt, b.header, grec.a, grec.b, cap32, b.item_w, b.item_perm);
+        hipLaunchKernelGGL(sg_render_bwd_sparse_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                            grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
                            sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0, b.item_perm);
     } else
-    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid), dim3(256), 0, st, c.W, c.H, c.gx, T, grid, b.ranges,
+    hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                        grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
                        sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0);

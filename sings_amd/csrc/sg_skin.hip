@@ -243,19 +243,37 @@ __device__ __forceinline__ void sg_load_A(const SgSkin &k, float *__restrict__ s
     for (int i = threadIdx.x; i < Jp * 16; i += blockDim.x) sA[i] = i < k.J * 16 ? k.A[i] : 0.0f;
 }
 
+// frame f of a launch of bt.K frames: joint transforms A + 16 J f, translation + transl_stride f (sg_frame for the rest)
+__device__ __forceinline__ SgSkin sg_skin_frame(SgSkin k, int frame, const SgBatch &bt)
+{
+    k.A += (size_t)frame * k.J * 16;
+    if (k.transl) k.transl += (size_t)frame * bt.transl_stride;
+    return k;
+}
+
 template <int D>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
-sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ opacities,
+sg_skin_fwd_kernel(SgCam c, SgBatch bt, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ opacities,
                    const float *__restrict__ scales, SgGeom g, SgBin bn, uint32_t cap,
                    int32_t *__restrict__ radii, float *__restrict__ posed_xyz, float *__restrict__ posed_rotq,
-                   float *__restrict__ posed_scales, int hist_tiles)
+                   float *__restrict__ posed_scales, int hist_tiles, int nblocks)
 {
     __shared__ float sA[SG_JMAX * 16];
     __shared__ float sW[SG_SKIN_WAVES][64 * SG_WSTRIDE];
     __shared__ float sT[SG_SKIN_WAVES][64 * 13];
     static_assert(SG_SKIN_WAVES * 64 * SG_WSTRIDE >= SG_HIST_TILES_MAX, "the weight tiles double as the per-tile histogram");
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
+    // (Gaussian block, frame): the K poses of one block of 256 Gaussians run back to back on one XCD -- its skinning weights
+    // (4 J bytes per Gaussian: the largest input), means, scales and SH rows come from HBM once and from that L2 K - 1 times
+    int gblock, frame;
+    if (!sg_block_frame((int)blockIdx.x, bt.K, nblocks, gblock, frame)) return;
+    c = sg_frame(c, frame, bt.cam_stride); k = sg_skin_frame(k, frame, bt);
+    g = sg_frame(g, (size_t)frame * bt.geom); bn = sg_frame(bn, (size_t)frame * bt.bin);
+    radii += (size_t)frame * bt.P;
+    if (posed_xyz) posed_xyz += 3 * (size_t)frame * bt.P;
+    if (posed_rotq) posed_rotq += 4 * (size_t)frame * bt.P;
+    if (posed_scales) posed_scales += 3 * (size_t)frame * bt.P;
+    const int g0 = (gblock * SG_SKIN_WAVES + wave) * 64;
     const int idx = g0 + lane;
     sg_load_A(k, sA);
     __syncthreads();
@@ -286,14 +304,21 @@ sg_skin_fwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
 // per workgroup: partial dL/dA [Jp x 16] (matrix cores) and dL/dtransl [3] written to a slab
 // (reduced by sg_skin_reduce_kernel -- no atomics, deterministic).
-template <int D, bool ACC>
+// bt.K frames of the SAME canonical Gaussians (round 4): the wave walks the frames -- blend T with frame f's joint transforms, sum
+// frame f's gradient records, chain rule, dA partials of frame f into frame f's slab row -- and sums the canonical-Gaussian
+// gradients of the K frames in registers, in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K single-frame calls
+// leave behind when the first writes the gradient buffer and the others run with accumulate = 1).  The gradient row -- 55 floats per
+// Gaussian on the avatar, 48 of them the SH block -- is written ONCE per K frames instead of being read and rewritten by every
+// frame, and the canonical inputs are read once.  dL_dmeans2D, dL_dA, dL_dtransl are per frame.
+// ONE: bt.K == 1 known at compile time (the single-frame entry points): no loop, no per-trip recomputation.
+template <int D, bool ACC, bool ONE>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
-sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
-                   const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
-                   const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restrict__ shs, const float *__restrict__ scales,
+                   const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0, size_t cap,
+                   const uint32_t *__restrict__ header0, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
-                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
+                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride, size_t slab_frame)
 {
     constexpr bool accumulate = ACC;                            // (compile-time: see sg_preprocess_bwd_kernel)
     __shared__ float sA[SG_JMAX * 16];
@@ -301,79 +326,164 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     // the staging buffer of the record sums and of the dL/dsh rows
     __shared__ float sWT[SG_SKIN_WAVES][2 * 64 * SG_WSTRIDE];
     static_assert(2 * 64 * SG_WSTRIDE >= SG_REC_CHUNK * 12 && 2 * 64 * SG_WSTRIDE >= 32 * SG_ROW_LDS, "staging buffer size");
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *const sWw = sWT[wave], *const sTw = sWT[wave] + 64 * SG_WSTRIDE;
-    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
-    const int idx = g0 + lane;
-    sg_load_A(k, sA);
-    __syncthreads();
-    float T[12];
-    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sWw, sTw, T);
-    const bool live = idx < P;
-    float dT[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) dT[i] = 0.0f;
-    float dtr[3] = { 0, 0, 0 };
-    const int Mrows = c.M;
+    const int wave_all = threadIdx.x >> 6, lane_all = threadIdx.x & 63;
+    const int g0_all = (blockIdx.x * SG_SKIN_WAVES + wave_all) * 64;
+    const int idx_all = g0_all + lane_all;
+    const bool live = idx_all < P;
+    const int Mrows = c0.M;
     constexpr int nc = (D + 1) * (D + 1);
-    // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
-    const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
-    float4 rc = make_float4(0, 0, 0, 0);
-    if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
-    float a9[9];
-    __builtin_amdgcn_s_waitcnt(0xC07F);
-    __builtin_amdgcn_wave_barrier();
-    sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
+    const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
+    // sums over the frames
+    float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0;
     float dsh[nc * 3];
 #pragma unroll
     for (int i = 0; i < nc * 3; i++) dsh[i] = 0.0f;
-    if (live) {
-        float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0, g2[2] = { 0, 0 };
-        const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
-        if (vis || have_in) {
-            SgPosed ps;
-            sg_pose_gaussian(k, idx, T, scales, ps);
-            SgGaussGrad G;
+    const int nchunk = (k0.J + 15) >> 4;
+    const bool vec = (k0.J & 3) == 0;
+    const int nframes = ONE ? 1 : bt.K;
+#pragma unroll 1
+    for (int f = 0; f < nframes; f++) {
+        // Gaussian index, lane and wave are made opaque per trip: hipcc otherwise hoists everything of the loop body that depends
+        // on them only -- 16 weight-row indices and their bounds masks, ~25 LDS addresses, the shuffle lane indices, the canonical
+        // inputs' addresses -- in front of the loop and keeps it live across it: 327 VGPRs instead of the single-frame kernel's
+        // 192, one wave per SIMD instead of two (248 with this; the recomputation is a few dozen integer operations per frame).
+        int g0 = g0_all, idx = idx_all, lane = lane_all, wave = wave_all;
+        if (!ONE) asm volatile("" : "+v"(g0), "+v"(idx), "+v"(lane), "+v"(wave));
+        float *const sWw = sWT[wave], *const sTw = sWT[wave] + 64 * SG_WSTRIDE;
+        const SgCam c = sg_frame(c0, f, bt.cam_stride);
+        const SgSkin k = sg_skin_frame(k0, f, bt);
+        const SgGeom g = sg_frame(g0_, (size_t)f * bt.geom);
+        const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
+        const uint32_t *header = sg_at(header0, (size_t)f * bt.bin);
+        const int32_t *radii = radii0 + (size_t)f * bt.P;
+        if (f > 0) __syncthreads();                              // every wave is done with the previous frame's sA
+        sg_load_A(k, sA);
+        __syncthreads();
+        float T[12];
+        sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sWw, sTw, T);
+        float dT[12];
 #pragma unroll
-            for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
+        for (int i = 0; i < 12; i++) dT[i] = 0.0f;
+        float dtr[3] = { 0, 0, 0 };
+        // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
+        const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
+        float4 rc = make_float4(0, 0, 0, 0);
+        if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
+        float a9[9];
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
+        float g2[2] = { 0, 0 };
+        if (live) {
+            float fxc[3] = { 0, 0, 0 }, fRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, fsc[3] = { 0, 0, 0 }, fop = 0;
+            if (vis || have_in) {
+                SgPosed ps;
+                sg_pose_gaussian(k, idx, T, scales, ps);
+                SgGaussGrad G;
 #pragma unroll
-            for (int i = 0; i < 4; i++) G.drot[i] = 0;
-            G.g2[0] = G.g2[1] = 0; G.dop = 0;
-            if (vis)
-                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh, G);
-            if (dposed_xyz_in) {
+                for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
 #pragma unroll
-                for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * idx + i];
-            }
-            if (dposed_rotq_in) {
+                for (int i = 0; i < 4; i++) G.drot[i] = 0;
+                G.g2[0] = G.g2[1] = 0; G.dop = 0;
+                if (vis)
+                    sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh, G, f == 0);
+                if (dposed_xyz_in) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * idx + i];
-            }
-            g2[0] = G.g2[0]; g2[1] = G.g2[1]; dop = G.dop;
-            // scales_posed = scales * s ; p = (T33 x + t) * s + transl
+                    for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * ((size_t)f * bt.P + idx) + i];
+                }
+                if (dposed_rotq_in) {
 #pragma unroll
-            for (int i = 0; i < 3; i++) { dsc[i] = G.dsc[i] * ps.sc; dtr[i] = G.dmean[i]; }
-            float dps[3] = { G.dmean[0] * ps.sc, G.dmean[1] * ps.sc, G.dmean[2] * ps.sc };
-            float dRd[9];
-            sg_m2q_bwd(ps.q, ps.best, ps.qab, G.drot, dRd);
+                    for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * ((size_t)f * bt.P + idx) + i];
+                }
+                g2[0] = G.g2[0]; g2[1] = G.g2[1]; fop = G.dop;
+                // scales_posed = scales * s ; p = (T33 x + t) * s + transl
 #pragma unroll
-            for (int i = 0; i < 3; i++) {
+                for (int i = 0; i < 3; i++) { fsc[i] = G.dsc[i] * ps.sc; dtr[i] = G.dmean[i]; }
+                float dps[3] = { G.dmean[0] * ps.sc, G.dmean[1] * ps.sc, G.dmean[2] * ps.sc };
+                float dRd[9];
+                sg_m2q_bwd(ps.q, ps.best, ps.qab, G.drot, dRd);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++) {
+                        // dT33 = dp x^T + dRdef Rc^T
+                        dT[4 * i + kx] = dps[i] * ps.x[kx] + dRd[3 * i] * ps.Rc[3 * kx] + dRd[3 * i + 1] * ps.Rc[3 * kx + 1] + dRd[3 * i + 2] * ps.Rc[3 * kx + 2];
+                    }
+                    dT[4 * i + 3] = dps[i];
+                }
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    // dT33 = dp x^T + dRdef Rc^T
-                    dT[4 * i + kx] = dps[i] * ps.x[kx] + dRd[3 * i] * ps.Rc[3 * kx] + dRd[3 * i + 1] * ps.Rc[3 * kx + 1] + dRd[3 * i + 2] * ps.Rc[3 * kx + 2];
+                    fxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
+#pragma unroll
+                    for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
+                        fRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
                 }
-                dT[4 * i + 3] = dps[i];
             }
+            // frame 0 assigns, later frames add: the order of K single-frame calls sharing one gradient buffer
+            if (f == 0) {
 #pragma unroll
-            for (int kx = 0; kx < 3; kx++) {
-                dxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
+                for (int i = 0; i < 3; i++) { dxc[i] = fxc[i]; dsc[i] = fsc[i]; }
 #pragma unroll
-                for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
-                    dRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
+                for (int i = 0; i < 9; i++) dRc[i] = fRc[i];
+                dop = fop;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { dxc[i] += fxc[i]; dsc[i] += fsc[i]; }
+#pragma unroll
+                for (int i = 0; i < 9; i++) dRc[i] += fRc[i];
+                dop += fop;
             }
+            float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
+            m2[0] = g2[0]; m2[1] = g2[1]; m2[2] = 0.0f;
         }
-        // accumulate: the frames of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
+        // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
+        float *sdT = sTw;
+#pragma unroll
+        for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
+#pragma unroll
+        for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
+        // every wave owns one slab row per frame (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
+        float *out = slab + (size_t)f * slab_frame + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
+        float4 wv[4];
+        if (vec) sg_w_fetch(k.lbs_w, k.J, P, g0, 0, lane, wv);
+        for (int cch = 0; cch < nchunk; cch++) {
+            if (vec) {
+                sg_w_stash(wv, lane, sWw);
+                if (cch + 1 < nchunk) sg_w_fetch(k.lbs_w, k.J, P, g0, cch + 1, lane, wv);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+            } else {
+                sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sWw);
+                __builtin_amdgcn_s_waitcnt(0);
+            }
+            __builtin_amdgcn_wave_barrier();
+            f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+            for (int kk = 0; kk < 16; kk++) {
+                float av = sWw[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
+                float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+            __builtin_amdgcn_wave_barrier();
+        }
+        // dtransl: wave sum
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float v = dtr[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) out[SG_JMAX * 16 + i] = v;
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+    }
+    // ---- the canonical-Gaussian gradients, once for the K frames
+    const int g0 = g0_all, idx = idx_all, lane = lane_all, wave = wave_all;
+    float *const sWw = sWT[wave];
+    if (live) {
+        // accumulate: the batches of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
         if (accumulate) {
 #pragma unroll
             for (int i = 0; i < 3; i++) { dxc[i] += dL_dxyz_canon[3 * idx + i]; dsc[i] += dL_dscales[3 * idx + i]; }
@@ -381,10 +491,10 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         }
         dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
         if (dL_drot_canon) {
-            if (k.rot6d) {
+            if (k0.rot6d) {
                 float d6[6], dd[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) d6[i] = k.rot_canon[6 * (size_t)idx + i];
+                for (int i = 0; i < 6; i++) d6[i] = k0.rot_canon[6 * (size_t)idx + i];
                 sg_r6d2m_bwd(d6, dRc, dd);
 #pragma unroll
                 for (int i = 0; i < 6; i++) dL_drot_canon[6 * (size_t)idx + i] = dd[i] + (accumulate ? dL_drot_canon[6 * (size_t)idx + i] : 0.0f);
@@ -395,7 +505,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         }
         dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
         dL_dopacity[idx] = dop;
-        dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     }
     // dL/dsh rows (every one of the M rows is written): through LDS as 16-B-per-lane coalesced stores when M == 16
     if (Mrows == 16) {
@@ -423,48 +532,6 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
             for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
         }
     }
-    // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
-    float *sdT = sTw;
-#pragma unroll
-    for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
-#pragma unroll
-    for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
-    const int nchunk = (k.J + 15) >> 4;
-    // every wave owns one slab row (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
-    float *out = slab + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
-    const bool vec = (k.J & 3) == 0;
-    float4 wv[4];
-    if (vec) sg_w_fetch(k.lbs_w, k.J, P, g0, 0, lane, wv);
-    for (int cch = 0; cch < nchunk; cch++) {
-        if (vec) {
-            sg_w_stash(wv, lane, sWw);
-            if (cch + 1 < nchunk) sg_w_fetch(k.lbs_w, k.J, P, g0, cch + 1, lane, wv);
-            __builtin_amdgcn_s_waitcnt(0xC07F);
-        } else {
-            sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sWw);
-            __builtin_amdgcn_s_waitcnt(0);
-        }
-        __builtin_amdgcn_wave_barrier();
-        f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-        for (int kk = 0; kk < 16; kk++) {
-            float av = sWw[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
-            float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-        }
-        // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
-#pragma unroll
-        for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
-        __builtin_amdgcn_wave_barrier();
-    }
-    // dtransl: wave sum
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        float v = dtr[i];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (lane == 0) out[SG_JMAX * 16 + i] = v;
-    }
 }
 
 // sums the per-wave slab rows in a fixed order: dL_dA [J,16] and dL_dtransl [3].  Two passes so that the
@@ -473,8 +540,10 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
 //  pass 2: one thread per column sums the G partial rows.
 #define SG_RED_GROUPS 64        // (32 / 64 / 128 groups: pass 1 + pass 2 = 8.5 + 4.7 / 5.6 + 4.9 / 4.9 + 6.8 us on the avatar frame)
 __global__ void __launch_bounds__(256)
-sg_skin_reduce1_kernel(const float *__restrict__ slab, int nrows, int slab_stride, float *__restrict__ part)
+sg_skin_reduce1_kernel(const float *__restrict__ slab, int nrows, int slab_stride, float *__restrict__ part, size_t slab_frame)
 {
+    slab += (size_t)blockIdx.z * slab_frame;                   // frame blockIdx.z: its slab rows -> its SG_RED_GROUPS partial rows
+    part += (size_t)blockIdx.z * SG_RED_GROUPS * slab_stride;
     const int col = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rg = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (col >= slab_stride) return;
@@ -494,6 +563,9 @@ __global__ void __launch_bounds__(64)
 sg_skin_reduce2_kernel(const float *__restrict__ part, int slab_stride, int J, float *__restrict__ dL_dA,
                        float *__restrict__ dL_dtransl)
 {
+    part += (size_t)blockIdx.z * SG_RED_GROUPS * slab_stride;  // frame blockIdx.z -> dL_dA [K,J,16], dL_dtransl [K,3]
+    dL_dA += (size_t)blockIdx.z * J * 16;
+    if (dL_dtransl) dL_dtransl += 3 * (size_t)blockIdx.z;
     const int i = blockIdx.x * 64 + threadIdx.x;
     const int nA = J * 16;
     if (i >= nA + 3) return;
@@ -918,27 +990,29 @@ void sg_launch_joint_transforms(int B, int J, const float *pose, const float *jo
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-void sg_launch_skin_fwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
+void sg_launch_skin_fwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *opacities,
                         const float *scales, SgGeom g, SgBin b, size_t cap, int32_t *radii, float *posed_xyz,
                         float *posed_rotq, float *posed_scales, hipStream_t st)
 {
     if (P <= 0) return;
     SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
                  in->transl, in->ext_trans, in->ext_rot, in->ext_scale };
-    dim3 grid((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS), block(SG_SKIN_THREADS);
+    const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS;
+    dim3 grid(sg_frame_grid(nblocks, bt.K)), block(SG_SKIN_THREADS);
     const int ht = sg_lds_hist(c.gx, c.gy) ? (int)sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) : 0;     // histogram words (= tile counters)
-#define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, P, k, shs, opacities, scales, g, \
-                                     b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales, ht)
+#define SG_SF(DD) hipLaunchKernelGGL(sg_skin_fwd_kernel<DD>, grid, block, 0, st, c, bt, P, k, shs, opacities, scales, g, \
+                                     b, sg_cap32(cap), radii, posed_xyz, posed_rotq, posed_scales, ht, nblocks)
     sg_prof_begin(SG_K_PREPROCESS_FWD, st);
     switch (c.D) { case 0: SG_SF(0); break; case 1: SG_SF(1); break; case 2: SG_SF(2); break; default: SG_SF(3); break; }
     sg_prof_end(SG_K_PREPROCESS_FWD, st);
 #undef SG_SF
 }
 
-// per-wave slabs followed by the SG_RED_GROUPS partial rows of the reduction
-size_t sg_skin_slab_floats(int P) { return ((size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES + SG_RED_GROUPS) * (SG_JMAX * 16 + 4); }
+// per frame: the per-wave slabs, followed (after the slabs of ALL frames) by the SG_RED_GROUPS partial rows of every frame
+static size_t sg_skin_slab_rows(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES; }
+size_t sg_skin_slab_floats(int P, int K) { return (sg_skin_slab_rows(P) + SG_RED_GROUPS) * (size_t)(K > 0 ? K : 1) * (SG_JMAX * 16 + 4); }
 
-void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const float *shs, const float *scales,
+void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
                         const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
@@ -948,21 +1022,24 @@ void sg_launch_skin_bwd(const SgCam &c, int P, const SgSkinInputs *in, const flo
     SgSkin k = { in->J, in->rot_format == SG_ROT_CANON_6D, in->xyz_canon, in->rot_canon, in->lbs_weights, in->A, in->smpl_scale,
                  in->transl, nullptr, nullptr, nullptr };
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
+    const size_t slab_frame = sg_skin_slab_rows(P) * stride;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
-#define SG_SB2(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
+#define SG_SB3(DD, AA, OO) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA, OO>), grid, block, 0, st, c, bt, P, k, shs, scales, radii, g,       \
                                      grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
-                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride, slab_frame)
+#define SG_SB2(DD, AA) do { if (bt.K == 1) SG_SB3(DD, AA, true); else SG_SB3(DD, AA, false); } while (0)
 #define SG_SB(DD) do { if (accumulate) SG_SB2(DD, true); else SG_SB2(DD, false); } while (0)
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
-    float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;
-    hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4), dim3(256), 0, st, slab,
-                       nblocks * SG_SKIN_WAVES, stride, part);
-    hipLaunchKernelGGL(sg_skin_reduce2_kernel, dim3((in->J * 16 + 3 + 63) / 64), dim3(64), 0, st, part, stride, in->J,
+    float *part = slab + slab_frame * bt.K;
+    hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4, bt.K), dim3(256), 0, st, slab,
+                       nblocks * SG_SKIN_WAVES, stride, part, slab_frame);
+    hipLaunchKernelGGL(sg_skin_reduce2_kernel, dim3((in->J * 16 + 3 + 63) / 64, 1, bt.K), dim3(64), 0, st, part, stride, in->J,
                        dL_dA, dL_dtransl);
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
 #undef SG_SB2
+#undef SG_SB3
 }
 
 void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st)
@@ -979,6 +1056,6 @@ void sg_launch_lbs_bwd(int P, int J, const float *W, const float *A, const float
     hipLaunchKernelGGL(sg_lbs_bwd_kernel, dim3(nblocks), dim3(SG_SKIN_THREADS), 0, st, P, J, W, A, v, dT, dverts, dv, slab, stride);
     float *part = slab + (size_t)nblocks * SG_SKIN_WAVES * stride;
     hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4), dim3(256), 0, st, slab,
-                       nblocks * SG_SKIN_WAVES, stride, part);
+                       nblocks * SG_SKIN_WAVES, stride, part, (size_t)0);
     hipLaunchKernelGGL(sg_skin_reduce2_kernel, dim3((J * 16 + 3 + 63) / 64), dim3(64), 0, st, part, stride, J, dA, (float *)nullptr);
 }

@@ -267,7 +267,7 @@ class ViewBatch:
         self.acc = self.pipe.acc
         self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
         for e in self.engines:                                # several views in flight: no latency-only work (SG_FLAG_THROUGHPUT)
-            e.throughput = self.n > 1
+            e.throughput = self.n > 1 or getattr(e, "K", 1) > 1
 
     def _link(self, v, e):
         # Resolved when the view's backward actually RUNS (engine.backward calls it once): the view adds to its row iff a
@@ -315,3 +315,212 @@ class ViewBatch:
     def run(self, fn):
         self.run_unreduced(fn)
         return self.pipe.reduce()
+
+
+def _frame_batch(K, camera_stride, transl_stride):
+    fb = _lib.SgFrameBatch()
+    fb.K, fb.camera_stride, fb.transl_stride, fb.reserved = int(K), int(camera_stride), int(transl_stride), 0
+    return fb
+
+
+class _FramesBase:
+    """K frames (poses and / or cameras) of the SAME Gaussians per call: ONE dispatch per kernel for the K frames (the ``*_frames``
+    entry points of include/sings_hip.h).  The reference hands its model 16 frames per call (``SinGS.forward_chunk``,
+    sings_hybrid.py:474-569) and then renders them one by one (gs_trainer.py:684-714); a frame-parallel step renders K frames of the
+    same canonical Gaussians per rank.  Workspaces are K consecutive single-frame workspaces in one allocation each; the
+    per-Gaussian backward sums the K frames' gradients in registers and writes the gradient row once, in frame order -- bit
+    for bit what K single-frame calls leave behind when the first writes the buffer and the others add (``accumulate=1``)."""
+
+    def _alloc(self, P, W, H, K, cap):
+        self.lib = _lib.load()
+        if not 1 <= K <= _lib.MAX_FRAMES:
+            raise ValueError(f"K must be 1..{_lib.MAX_FRAMES}")
+        self.P, self.W, self.H, self.K, self.cap = int(P), int(W), int(H), int(K), int(cap)
+        L = _lib.SgLayout()
+        sizes = [C.c_size_t() for _ in range(4)]
+        _lib.check(self.lib.sg_frames_layout(self.P, self.W, self.H, self.cap, self.K, C.byref(L), *[C.byref(x) for x in sizes]),
+                   "sg_frames_layout")
+        self.L = L
+        u8 = dict(dtype=torch.uint8, device=self.dev)
+        self.geom = torch.empty(sizes[0].value, **u8)
+        self.binning = torch.empty(sizes[1].value, **u8)
+        self.binning.view(self.K, L.bin_bytes)[:, :L.bin_ranges].zero_()     # counters zeroed ONCE (SG_FLAG_WS_CLEAN afterwards)
+        self._clean = True
+        self.img = torch.empty(sizes[2].value, **u8)
+        self.bwd_ws = torch.empty(sizes[3].value, **u8)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.color = torch.empty((self.K, 3, self.H, self.W), **f32)
+        self.radii = torch.empty((self.K, self.P), dtype=torch.int32, device=self.dev)
+        self.d_means2D = torch.empty((self.K, self.P, 3), **f32)
+        self._keep, self._s, self._fb = [], None, None
+        self.throughput = True            # K frames share the chip: no latency-only work (SG_FLAG_THROUGHPUT), as in ViewBatch
+        self._chain = None                # inside ViewBatch.run (a batch of frames is one "view" of the ViewBatch): see RasterEngine
+
+    def _chain_state(self, accumulate):
+        """(accumulate, done event) for this backward: inside a ViewBatch the batch adds to its gradient row iff an earlier batch
+        of the step wrote it (and, with one row across streams, waits for that batch's per-Gaussian half first)."""
+        acc, after, done = self._chain() if self._chain is not None else (False, None, None)
+        if after is not None:
+            torch.cuda.current_stream(self.dev).wait_event(after)
+        return bool(accumulate) or bool(acc), done
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def set_camera(self, raster_settings):
+        """One camera for all K frames ([4,4] matrices) or one per frame (``viewmatrix`` / ``projmatrix`` [K,4,4], ``campos``
+        [K,3]: the other fields are shared)."""
+        self._keep = []
+        vm = raster_settings.viewmatrix
+        per_frame = vm.dim() == 3
+        if per_frame and (vm.shape[0] != self.K or raster_settings.projmatrix.shape[0] != self.K or raster_settings.campos.shape[0] != self.K):
+            raise ValueError(f"per-frame cameras must be stacked [{self.K},4,4] / [{self.K},3]")
+        self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+        self._cam_stride = 1 if per_frame else 0
+
+    def num_rendered(self):
+        nr = (C.c_int64 * self.K)()
+        _lib.check(self.lib.sg_read_num_rendered_frames(_ptr(self.binning), self.P, self.W, self.H, self.cap, self.K, nr,
+                                                        self._stream()), "read R")
+        return [int(v) for v in nr]
+
+    def _flags(self):
+        f = (_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0)
+        return f
+
+
+class SkinnedFramesEngine(_FramesBase):
+    """LBS-fused path, K posed frames of the same canonical Gaussians per call.  Flat gradient layout as ``SkinnedEngine``
+    (xyz_canon 3P, scales 3P, opacity P, sh 3MP, [rot_canon]); per frame: ``color`` [K,3,H,W], ``radii`` [K,P], ``d_means2D``
+    [K,P,3], ``d_A`` [K,J,16], ``d_transl`` [K,3]."""
+
+    def __init__(self, P, J, W, H, sh_coeffs, K, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9):
+        self.dev = torch.device(device)
+        self.J, self.M = int(J), int(sh_coeffs)
+        self._alloc(P, W, H, K, capacity_pairs)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.skin_ws = torch.empty(int(self.lib.sg_skin_ws_floats_frames(self.P, self.K)), **f32)
+        rot_width = int(rot_width)
+        per = 3 + 3 + 1 + 3 * self.M + (rot_width if with_rot else 0)
+        if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
+                                      or not grad_flat.is_contiguous() or grad_flat.device != self.dev):
+            raise ValueError(f"grad_flat must be a contiguous fp32 tensor of {self.P * per} elements on {self.dev}")
+        self.grad_flat = torch.empty(self.P * per, **f32) if grad_flat is None else grad_flat.view(-1)
+        o = 0
+
+        def carve(n, *shape):
+            nonlocal o
+            v = self.grad_flat[o:o + n].view(*shape); o += n
+            return v
+        self.d_xyz = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
+        self.d_opacity = carve(self.P, self.P, 1); self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
+        self.d_rot = carve(self.P * rot_width, self.P, rot_width) if with_rot else None
+        self.d_A = torch.empty((self.K, self.J, 16), **f32); self.d_transl = torch.empty((self.K, 3), **f32)
+        self._k = None
+
+    def set_frames(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl):
+        """``A``: [K,J,4,4] / [K,J,16] joint transforms of the K frames; ``transl``: [K,3] (one per frame), [3] (shared) or None."""
+        from .skinned import _skin_struct
+        A = A.reshape(self.K, -1, 16)
+        if A.shape[1] != self.J:
+            raise ValueError(f"A must be [{self.K},{self.J},16]")
+        self._kkeep = []
+        tstride = 0
+        if transl is not None:
+            transl = transl.contiguous().float()
+            if transl.numel() == 3:
+                tstride = 0
+            elif transl.numel() == 3 * self.K:
+                tstride = 3
+            else:
+                raise ValueError(f"transl must be [{self.K},3] or [3]")
+        # (_skin_struct reads J from A's row count: hand it frame 0, the pointer is the base of the K stacked frames)
+        self._k = _skin_struct(self.dev, xyz_canon, rotmat_canon, lbs_weights, A[0], smpl_scale,
+                               None if transl is None else transl.reshape(-1)[:3], None, self._kkeep)
+        A = A.contiguous()
+        self._kkeep += [A, transl]
+        self._k.A = A.data_ptr()
+        self._k.transl = None if transl is None else transl.data_ptr()
+        self._fb = _frame_batch(self.K, self._cam_stride, tstride)
+
+    def forward(self, shs, opacities, scales, sync_num_rendered=False):
+        nr = (C.c_int64 * self.K)()
+        self._fb.camera_stride = self._cam_stride
+        self._s.flags = self._flags()
+        self._clean = False
+        _lib.check(self.lib.sg_skinned_forward_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales),
+            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
+            nr if sync_num_rendered else None, self._stream()), "skinned forward (frames)")
+        self._clean = True
+        return [int(v) for v in nr] if sync_num_rendered else None
+
+    def backward(self, shs, opacities, scales, dL_dcolor, accumulate=False):
+        """``dL_dcolor`` [K,3,H,W].  ``accumulate``: the K frames' sum is ADDED to the gradient buffer (a later batch of the step)."""
+        _lib.check(self.lib.sg_rasterize_backward_records_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img),
+            _ptr(self.bwd_ws), _ptr(dL_dcolor), self._stream()), "skinned backward (records, frames)")
+        accumulate, done = self._chain_state(accumulate)
+        _lib.check(self.lib.sg_skinned_backward_gaussians_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales),
+            _ptr(self.radii), _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.bwd_ws), _ptr(self.skin_ws),
+            int(bool(accumulate)), None, None, _ptr(self.d_xyz), _ptr(self.d_rot), _ptr(self.d_scales), _ptr(self.d_opacity),
+            _ptr(self.d_sh), _ptr(self.d_means2D), _ptr(self.d_A), _ptr(self.d_transl), self._stream()),
+            "skinned backward (gaussians, frames)")
+        if done is not None:
+            done.record(torch.cuda.current_stream(self.dev))
+
+
+class RasterFramesEngine(_FramesBase):
+    """Un-skinned path: K cameras of the same Gaussians per call (``sg_rasterize_*_frames``).  Flat gradient layout as
+    ``RasterEngine``; ``color`` [K,3,H,W], ``radii`` [K,P], ``d_means2D`` [K,P,3]."""
+
+    def __init__(self, P, W, H, sh_coeffs, K, device, capacity_pairs, grad_flat=None):
+        self.dev = torch.device(device)
+        self.M = int(sh_coeffs)
+        self._alloc(P, W, H, K, capacity_pairs)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        per = 3 + 3 + 4 + 1 + 3 * self.M
+        if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
+                                      or not grad_flat.is_contiguous() or grad_flat.device != self.dev):
+            raise ValueError(f"grad_flat must be a contiguous fp32 tensor of {self.P * per} elements on {self.dev}")
+        self.grad_flat = torch.empty(self.P * per, **f32) if grad_flat is None else grad_flat.view(-1)
+        o = 0
+
+        def carve(n, *shape):
+            nonlocal o
+            v = self.grad_flat[o:o + n].view(*shape); o += n
+            return v
+        self.d_means3D = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
+        self.d_rots = carve(self.P * 4, self.P, 4); self.d_opacity = carve(self.P, self.P, 1)
+        self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3) if self.M else None
+        self._hint = 0
+
+    def set_camera(self, raster_settings, short_lists=False):
+        super().set_camera(raster_settings)
+        self._hint = _lib.FLAG_SHORT_LISTS if short_lists else 0
+        self._fb = _frame_batch(self.K, self._cam_stride, 0)
+
+    def forward(self, means3D, shs, opacities, scales, rotations, sync_num_rendered=False):
+        nr = (C.c_int64 * self.K)()
+        self._s.flags = self._hint | self._flags()
+        self._clean = False
+        _lib.check(self.lib.sg_rasterize_forward_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales),
+            _ptr(rotations), None, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color),
+            _ptr(self.radii), nr if sync_num_rendered else None, self._stream()), "forward (frames)")
+        self._clean = True
+        return [int(v) for v in nr] if sync_num_rendered else None
+
+    def backward(self, means3D, shs, opacities, scales, rotations, dL_dcolor, accumulate=False):
+        _lib.check(self.lib.sg_rasterize_backward_records_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img),
+            _ptr(self.bwd_ws), _ptr(dL_dcolor), self._stream()), "backward (records, frames)")
+        accumulate, done = self._chain_state(accumulate)
+        _lib.check(self.lib.sg_rasterize_backward_gaussians_frames(
+            C.byref(self._s), C.byref(self._fb), self.P, _ptr(means3D), _ptr(shs), None, _ptr(opacities), _ptr(scales),
+            _ptr(rotations), None, _ptr(self.radii), _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.bwd_ws),
+            int(bool(accumulate)), _ptr(self.d_means3D), _ptr(self.d_means2D), _ptr(self.d_sh), None, _ptr(self.d_opacity),
+            _ptr(self.d_scales), _ptr(self.d_rots), None, self._stream()), "backward (gaussians, frames)")
+        if done is not None:
+            done.record(torch.cuda.current_stream(self.dev))

@@ -89,19 +89,25 @@ def photometric_loss(raw_image, gt_rgb, mask, bg_color, l1_w=0.8, ssim_w=0.2, re
 
 
 class PhotoLossEngine:
-    """Pre-allocated variant for training loops / bench.py: no allocation, no synchronisation per call."""
+    """Pre-allocated variant for training loops / bench.py: no allocation, no synchronisation per call.  ``K`` > 1: the losses
+    and gradients of K frames in three launches (``sg_photo_loss_frames``): ``raw`` [K,3,H,W]; ``gt_rgb`` [K,3,H,W] or one
+    [3,H,W] target for all frames, ``mask`` likewise; ``losses`` [K,4], ``grad`` [K,3,H,W]."""
 
-    def __init__(self, W, H, device, l1_w=0.8, ssim_w=0.2):
+    def __init__(self, W, H, device, l1_w=0.8, ssim_w=0.2, K=1):
         self.lib = _lib.load()
-        self.W, self.H, self.l1_w, self.ssim_w = int(W), int(H), float(l1_w), float(ssim_w)
+        self.W, self.H, self.l1_w, self.ssim_w, self.K = int(W), int(H), float(l1_w), float(ssim_w), int(K)
         self.dev = torch.device(device)
-        self.ws = torch.empty(int(self.lib.sg_photo_loss_ws_bytes(self.W, self.H)), dtype=torch.uint8, device=self.dev)
-        self.losses = torch.zeros(4, dtype=torch.float32, device=self.dev)
-        self.grad = torch.empty((3, self.H, self.W), dtype=torch.float32, device=self.dev)
+        self.ws = torch.empty(self.K * int(self.lib.sg_photo_loss_ws_bytes(self.W, self.H)), dtype=torch.uint8, device=self.dev)
+        shape = (lambda *s: s) if self.K == 1 else (lambda *s: (self.K,) + s)
+        self.losses = torch.zeros(shape(4), dtype=torch.float32, device=self.dev)
+        self.grad = torch.empty(shape(3, self.H, self.W), dtype=torch.float32, device=self.dev)
 
     def __call__(self, raw, gt_rgb, mask, bg):
         stream = C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
-        _lib.check(self.lib.sg_photo_loss(self.W, self.H, self.l1_w, self.ssim_w, _ptr(raw), _ptr(gt_rgb), _ptr(mask),
-                                          _ptr(bg), _ptr(self.ws), None, None, _ptr(self.losses), None, _ptr(self.grad),
-                                          stream), "photo loss")
+        hw = self.H * self.W
+        gt_stride = 3 * hw if gt_rgb.numel() == self.K * 3 * hw and self.K > 1 else 0
+        mask_stride = hw if mask.numel() == self.K * hw and self.K > 1 else 0
+        _lib.check(self.lib.sg_photo_loss_frames(self.K, self.W, self.H, self.l1_w, self.ssim_w, _ptr(raw), _ptr(gt_rgb), gt_stride,
+                                                 _ptr(mask), mask_stride, _ptr(bg), _ptr(self.ws), None, None, _ptr(self.losses),
+                                                 None, _ptr(self.grad), stream), "photo loss")
         return self.grad

@@ -1,0 +1,202 @@
+"""K frames of the same Gaussians per call (the ``*_frames`` entry points, include/sings_hip.h; reference shape: SinGS.forward_chunk,
+sings/rec/models/sings_hybrid.py:474-569, 16 frames per call, rendered one by one at gs_trainer.py:684-714).
+
+The bar is BIT-IDENTITY with K single-frame calls: every per-frame output (image, radii, screen-space gradient, dL/dA, dL/dtransl)
+equals the single-frame call's, and the summed canonical-Gaussian gradient equals what K single-frame calls leave in ONE gradient
+buffer when frame 0 writes it and frames 1.. add to it in frame order (``accumulate=1``).  The single-frame path is the one the
+oracle tests pin (tests/test_gpu_skinned.py, test_gpu_raster.py), so parity with the oracle carries over to the K-frame calls.
+"""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def _avatar(N, J, W, H, seed, K, per_frame_camera, with_rot):
+    from sings_amd.body import joint_transforms
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import avatar_scene
+    dev = _dev()
+    s = avatar_scene(N=N, J=J, W=W, H=H, seed=seed, isotropic=not with_rot)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = np.random.RandomState(seed)
+    jr = t(s["joints_rest"])
+    A = torch.stack([joint_transforms(t(rs.normal(0, 0.2, J * 3).astype(np.float32)), jr, tuple(s["parents"])).reshape(J, 16)
+                     for _ in range(K)]).contiguous()
+    transl = t((s["transl"][None] + rs.normal(0, 0.03, (K, 3))).astype(np.float32))
+    cam = s["cam"]
+    view = np.repeat(cam["world_view_transform"][None], K, 0).copy()
+    if per_frame_camera:
+        view[:, 3, 0] += 0.02 * np.arange(K)                       # every frame its own camera (shifted along x)
+    P_T = np.linalg.inv(cam["world_view_transform"]) @ cam["full_proj_transform"]
+    proj = np.stack([(v @ P_T).astype(np.float32) for v in view])
+    campos = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in view])
+
+    def settings(vm, pm, cp):
+        return GaussianRasterizationSettings(
+            image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+            scale_modifier=1.0, viewmatrix=vm, projmatrix=pm, sh_degree=0, campos=cp, prefiltered=False, debug=False)
+    one = [settings(t(view[f]), t(proj[f]), t(campos[f])) for f in range(K)]
+    stacked = settings(t(view), t(proj), t(campos)) if per_frame_camera else one[0]
+    rot = t(rs.normal(size=(N, 6)).astype(np.float32)) if with_rot else None
+    ins = dict(xyz=t(s["xyz_canon"]), w=t(s["lbs_weights"]), sc=t(s["scales"]), op=t(s["opacities"]), sh=t(s["shs"]), rot=rot,
+               smpl_scale=t(s["smpl_scale"]))
+    dL = t(rs.normal(0, 1, (K, 3, H, W)).astype(np.float32))
+    return s, ins, A, transl, one, stacked, dL
+
+
+@pytest.mark.parametrize("K,per_frame_camera,with_rot", [(1, False, False), (3, False, False), (8, False, False), (4, True, True),
+                                                         (16, False, True)])
+def test_skinned_frames_equal_single_frame_calls_bit_for_bit(K, per_frame_camera, with_rot):
+    from sings_amd.engine import SkinnedEngine, SkinnedFramesEngine
+    dev = _dev()
+    N, J, W, H = 20000, 52, 160, 288
+    s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 3, K, per_frame_camera, with_rot)
+    cap = 24 * N
+    # ---- reference: K single-frame calls into ONE gradient buffer, frame 0 writes, the others add, in frame order
+    ref = SkinnedEngine(N, J, W, H, 16, dev, cap, with_rot=with_rot, rot_width=6)
+    ref.throughput = True                                           # (the K-frame calls never split long tiles: same mask layout)
+    per_frame = []
+    for f in range(K):
+        ref.set_camera(one[f])
+        ref.set_frame(ins["xyz"], ins["rot"], ins["w"], A[f], ins["smpl_scale"], transl[f])
+        R = ref.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+        assert 0 < R <= cap
+        ref._chain = (lambda f=f: (f > 0, None, None))
+        ref.backward(ins["sh"], ins["op"], ins["sc"], dL[f])
+        torch.cuda.synchronize()
+        per_frame.append([x.clone() for x in (ref.color, ref.radii, ref.d_means2D, ref.d_A, ref.d_transl)] + [R])
+    ref_grad = ref.grad_flat.clone()
+    # ---- K frames per call
+    eng = SkinnedFramesEngine(N, J, W, H, 16, K, dev, cap, with_rot=with_rot, rot_width=6)
+    eng.set_camera(stacked)
+    eng.set_frames(ins["xyz"], ins["rot"], ins["w"], A, ins["smpl_scale"], transl)
+    for rep in range(2):                                            # twice: the workspaces are reused (SG_FLAG_WS_CLEAN)
+        Rs = eng.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+        eng.backward(ins["sh"], ins["op"], ins["sc"], dL)
+        torch.cuda.synchronize()
+        assert Rs == [p[5] for p in per_frame] and eng.num_rendered() == Rs
+        for f in range(K):
+            c, r, m2, dA, dt, _ = per_frame[f]
+            assert torch.equal(eng.color[f], c), f"image of frame {f}"
+            assert torch.equal(eng.radii[f], r) and torch.equal(eng.d_means2D[f], m2), f"radii / means2D of frame {f}"
+            assert torch.equal(eng.d_A[f], dA) and torch.equal(eng.d_transl[f], dt), f"dL/dA, dL/dtransl of frame {f}"
+        assert torch.equal(eng.grad_flat, ref_grad), "summed canonical-Gaussian gradient"
+    assert float(ref_grad.abs().max()) > 0 and float((per_frame[0][0] - per_frame[-1][0]).abs().max()) > (0 if K == 1 else 1e-3)
+
+
+def test_two_batches_of_a_step_share_one_gradient_buffer():
+    """accumulate=1 on the K-frame call: a step of 6 frames as batches of 4 + 2 into one buffer == 6 single-frame calls."""
+    from sings_amd.engine import SkinnedEngine, SkinnedFramesEngine
+    dev = _dev()
+    N, J, W, H, K = 12000, 24, 128, 224, 6
+    s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 5, K, False, False)
+    cap = 24 * N
+    ref = SkinnedEngine(N, J, W, H, 16, dev, cap); ref.throughput = True
+    ref.set_camera(one[0])
+    for f in range(K):
+        ref.set_frame(ins["xyz"], None, ins["w"], A[f], ins["smpl_scale"], transl[f])
+        ref.forward(ins["sh"], ins["op"], ins["sc"])
+        ref._chain = (lambda f=f: (f > 0, None, None))
+        ref.backward(ins["sh"], ins["op"], ins["sc"], dL[f])
+    torch.cuda.synchronize()
+    flat = torch.empty_like(ref.grad_flat)
+    a = SkinnedFramesEngine(N, J, W, H, 16, 4, dev, cap, grad_flat=flat)
+    b = SkinnedFramesEngine(N, J, W, H, 16, 2, dev, cap, grad_flat=flat)
+    for e, lo, hi, acc in ((a, 0, 4, False), (b, 4, 6, True)):
+        e.set_camera(one[0])
+        e.set_frames(ins["xyz"], None, ins["w"], A[lo:hi].contiguous(), ins["smpl_scale"], transl[lo:hi].contiguous())
+        e.forward(ins["sh"], ins["op"], ins["sc"])
+        e.backward(ins["sh"], ins["op"], ins["sc"], dL[lo:hi].contiguous(), accumulate=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, ref.grad_flat)
+
+
+@pytest.mark.parametrize("K,deg,W,H", [(1, 3, 640, 368), (4, 3, 640, 368), (8, 1, 1600, 1056), (3, 0, 160, 96)])
+def test_raster_frames_equal_single_camera_calls_bit_for_bit(K, deg, W, H):
+    """Un-skinned path: K cameras of the same Gaussians in one call -- many tiles (the dense composite kernels) and few tiles (the
+    deep / sparse pair) -- against K RasterEngine calls that share one gradient buffer."""
+    from sings_amd.engine import RasterEngine, RasterFramesEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    N = 30000
+    s = synthetic_scene(N, W, H, deg, 7)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    views = np.repeat(s["viewmatrix"][None], K, 0).copy(); views[:, 3, 0] = 0.05 * np.arange(K)
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+
+    def settings(vm, pm, cp):
+        return GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                             scale_modifier=1.0, viewmatrix=vm, projmatrix=pm, sh_degree=deg, campos=cp,
+                                             prefiltered=False, debug=False)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    rs = np.random.RandomState(1)
+    dL = t(rs.normal(0, 1, (K, 3, H, W)).astype(np.float32))
+    cap = 12 * N
+    ref = RasterEngine(N, W, H, 16, dev, cap); ref.throughput = True
+    per = []
+    for f in range(K):
+        ref.set_camera(settings(t(views[f]), t(projs[f]), t(cps[f])))
+        R = ref.forward(*ins, sync_num_rendered=True)
+        ref._chain = (lambda f=f: (f > 0, None, None))
+        ref.backward(*ins, dL[f])
+        torch.cuda.synchronize()
+        per.append((ref.color.clone(), ref.radii.clone(), ref.d_means2D.clone(), R))
+    eng = RasterFramesEngine(N, W, H, 16, K, dev, cap)
+    eng.set_camera(settings(t(views), t(projs), t(cps)))
+    for rep in range(2):
+        Rs = eng.forward(*ins, sync_num_rendered=True)
+        eng.backward(*ins, dL)
+        torch.cuda.synchronize()
+        assert Rs == [p[3] for p in per]
+        for f in range(K):
+            assert torch.equal(eng.color[f], per[f][0]) and torch.equal(eng.radii[f], per[f][1]) and torch.equal(eng.d_means2D[f], per[f][2]), f
+        assert torch.equal(eng.grad_flat, ref.grad_flat)
+
+
+def test_photo_loss_frames_equal_single_calls():
+    from sings_amd.photo_loss import PhotoLossEngine
+    dev = _dev()
+    K, W, H = 5, 200, 136
+    g = torch.Generator(device="cpu").manual_seed(3)
+    raw = (torch.rand(K, 3, H, W, generator=g) * 1.4 - 0.2).to(dev)
+    gt = torch.rand(K, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(K, H, W, generator=g) > 0.3).float().to(dev)
+    bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
+    one = PhotoLossEngine(W, H, dev)
+    many = PhotoLossEngine(W, H, dev, K=K)
+    grad = many(raw, gt, mask, bg)
+    torch.cuda.synchronize()
+    for f in range(K):
+        gf = one(raw[f], gt[f], mask[f], bg)
+        torch.cuda.synchronize()
+        assert torch.equal(grad[f], gf) and torch.equal(many.losses[f], one.losses), f
+    # one target / one mask for all frames
+    shared = PhotoLossEngine(W, H, dev, K=K)
+    g2 = shared(raw, gt[0], mask[0], bg)
+    torch.cuda.synchronize()
+    for f in range(K):
+        gf = one(raw[f], gt[0], mask[0], bg)
+        torch.cuda.synchronize()
+        assert torch.equal(g2[f], gf) and torch.equal(shared.losses[f], one.losses), f
+
+
+def test_frames_api_rejects_bad_batches():
+    from sings_amd.engine import SkinnedFramesEngine
+    dev = _dev()
+    with pytest.raises(ValueError):
+        SkinnedFramesEngine(100, 24, 64, 64, 16, 17, dev, 4096)
+    with pytest.raises(ValueError):
+        SkinnedFramesEngine(100, 24, 64, 64, 16, 0, dev, 4096)
