@@ -120,15 +120,16 @@ def parse_args():
                     help="train workload: round-2 schedule (the regularisers' stream forks after the decode and joins before the "
                          "loss sum; default: grids early, k-NN query behind the raster forward, join in the backward pass)")
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
-    ap.add_argument("--views-per-step", type=int, default=8,
+    ap.add_argument("--views-per-step", type=int, default=None,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
-                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views")
+                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views.  Default: raster 8; "
+                         "avatar 16 (the reference's chunk: SinGS.forward_chunk hands the model 16 frames per call)")
     ap.add_argument("--frames-per-launch", type=int, default=None,
                     help="frames (avatar) / cameras (raster) of the same Gaussians rendered by ONE dispatch per kernel (the *_frames "
                          "entry points: K consecutive workspaces, the per-Gaussian backward sums the K frames in registers).  A step "
                          "of --views-per-step views is views / K such batches, dealt to the streams.  1 = one engine per view (round "
                          "3).  Default: avatar 8, raster 1")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=None,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are folded on a communication stream)")
     ap.add_argument("--reduce-chunks", type=int, default=4,
@@ -150,7 +151,14 @@ def parse_args():
     ap.add_argument("--workload", choices=("raster", "avatar", "train"), default="raster",
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    # per-workload defaults (measured on one MI355X: tools/r04_combos.sh): raster 8 views on 3 streams; avatar 16 frames as two
+    # launches of 8 frames on 2 streams (5 260 frames/s; 8 frames: one launch of 8 4 750, two of 4 on 2 streams 5 040)
+    if a.views_per_step is None:
+        a.views_per_step = 16 if a.workload == "avatar" else 8
+    if a.streams is None:
+        a.streams = 2 if a.workload == "avatar" else 3
+    return a
 
 
 def spawn_ranks(a):

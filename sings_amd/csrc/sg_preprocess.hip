@@ -153,6 +153,25 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 6; k++) A.g6[k] = 0;
     A.g2[0] = A.g2[1] = 0; A.dop = 0;
+    // K > 1 and accumulate: the sums START from what the gradient buffer holds (read once, here), so that the K frames are added
+    // in the order K single-camera calls with accumulate = 1 would add them: ((old + g0) + g1) + ...
+    constexpr bool preload = ACC && !ONE;
+    if (preload && live) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) A.dmean[k] = dL_dmeans3D[3 * idx + k];
+        A.dop = dL_dopacity[idx];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { A.dcol[k] = dL_dcolors ? dL_dcolors[3 * idx + k] : 0.0f; A.dsc[k] = dL_dscales ? dL_dscales[3 * idx + k] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) A.drot[k] = dL_drots ? dL_drots[4 * idx + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) A.g6[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
+        if (dL_dsh) {
+            const float *row = dL_dsh + (size_t)idx * Mrows * 3;
+#pragma unroll
+            for (int k = 0; k < nc * 3; k++) dsh[k] = row[k];
+        }
+    }
 #pragma unroll 1
     for (int f = 0; f < nframes; f++) {
         // (opaque per trip: keeps hipcc from hoisting what depends on them only -- LDS addresses, shuffle indices, the per-frame
@@ -188,22 +207,23 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
         // 2. the chain rule; dL/dsh rows: frame 0 assigns, later frames add (`first`)
         if (vis)
             sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
-                              dL_dsh != nullptr, dsh, G, f == 0);
+                              dL_dsh != nullptr, dsh, G, !preload && f == 0);
         // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
         if (live) {
             float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
             m2[0] = G.g2[0]; m2[1] = G.g2[1]; m2[2] = 0.0f;
         }
-        if (f == 0) {
+        if (!preload && f == 0) {
             A = G;
         } else {
+            // (operand order of the single-camera accumulate: new + old)
 #pragma unroll
-            for (int k = 0; k < 3; k++) { A.dmean[k] += G.dmean[k]; A.dcol[k] += G.dcol[k]; A.dsc[k] += G.dsc[k]; }
+            for (int k = 0; k < 3; k++) { A.dmean[k] = G.dmean[k] + A.dmean[k]; A.dcol[k] = G.dcol[k] + A.dcol[k]; A.dsc[k] = G.dsc[k] + A.dsc[k]; }
 #pragma unroll
-            for (int k = 0; k < 4; k++) A.drot[k] += G.drot[k];
+            for (int k = 0; k < 4; k++) A.drot[k] = G.drot[k] + A.drot[k];
 #pragma unroll
-            for (int k = 0; k < 6; k++) A.g6[k] += G.g6[k];
-            A.dop += G.dop;
+            for (int k = 0; k < 6; k++) A.g6[k] = G.g6[k] + A.g6[k];
+            A.dop = G.dop + A.dop;
         }
     }
     SgGaussGrad &G = A;
@@ -221,15 +241,18 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
-                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, accumulate != 0);
+                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, accumulate && ONE);     // (K > 1: dsh already holds old + frames)
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (live) {
             float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
-            if (accumulate) {
+            if (accumulate && ONE) {
 #pragma unroll
                 for (int k = 0; k < nc * 3; k++) dsh_row[k] += dsh[k];
+            } else if (accumulate) {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
             } else {
 #pragma unroll
                 for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
@@ -238,7 +261,7 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
         }
     }
     if (!live) return;
-    if (accumulate) {
+    if (accumulate && ONE) {
         // the batches of one optimisation step share ONE gradient buffer: this batch adds to what the batches in front of it in
         // the step's chain left there (the old values are requested together, here: one more memory round trip per wave)
         float o3[3], os[3], orr[4], oc[3], og[6], oo;

@@ -216,7 +216,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     // one plane each (bit `part`)
     uint8_t *__restrict__ pmask = pair_mask + (size_t)(split ? part : 0) * mask_plane;
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
-    const uint32_t first_item = PIPE ? plan[tile].x : 0u;             // first backward work item of this tile
+    const uint32_t first_item = (PIPE || w_plane) ? plan[tile].x : 0u;             // first backward work item of this tile
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
     bool done = !inside;
@@ -264,7 +264,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
             const uint32_t gid = point_list[range.x + e + SG_FB];
             pa = recA[SG_REC_STRIDE * (size_t)gid]; pb = recB[SG_REC_STRIDE * (size_t)gid]; pc = recC[SG_REC_STRIDE * (size_t)gid].x;
         }
-        if (PIPE) {
+        if (PIPE || w_plane) {
             // few-tile frames: the weight of the backward work item (tile, this segment) = entries composited somewhere; the
             // backward starts its heaviest items first (sg_zero_records_kernel sorts them)
             const int wcount = __syncthreads_count(staged);
@@ -385,7 +385,12 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
     const int grid = sg_render_blocks(T);
     const unsigned K = (unsigned)bt.K;
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    if (sg_lds_hist(c.gx, c.gy)) {
+    // Few-tile frames (an avatar), two regimes.  One frame alone: the deep kernel -- pipelined list walk, long tiles split over four
+    // workgroups -- because the kernel then ENDS in a few deep tiles walked by single waves.  Several frames sharing the chip
+    // (SG_FLAG_THROUGHPUT: K frames per launch, or views on several streams): every SIMD has other waves to run, the pipelined walk's
+    // extra vector instructions only cost issue slots -- the plain loop at eight waves per SIMD is 7 % faster there (344 -> 319 us for
+    // the 8 frames of an avatar step, same box; it also leaves the backward's work-item weights: w_plane != 0).
+    if (sg_lds_hist(c.gx, c.gy) && !(c.flags & SG_FLAG_THROUGHPUT)) {
         // upper bound: quadrants 1..3 of every long tile (most blocks exit at once); none in throughput mode.  (Rounded up to a
         // multiple of 24: whole tiles, and gridDim.x stays a multiple of 8 -- the XCD of a block is blockIdx.x % 8 in every frame.)
         const int extra = sg_split_long(c.gx, c.gy, c.flags) ? ((3 * (int)sg_sort_items_cap(T, cap) + 23) / 24) * 24 : 0;
@@ -399,7 +404,8 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
                            b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
                            c.bg, out_color, im.final_T, im.n_contrib,
                            b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
-                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap));
+                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w,
+                           sg_lds_hist(c.gx, c.gy) ? sg_items_cap((size_t)T, cap) : 0u);     // (item weights: few-tile frames only)
     sg_prof_end(SG_K_RENDER_FWD, st);
 }
 

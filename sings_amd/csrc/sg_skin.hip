@@ -304,21 +304,14 @@ sg_skin_fwd_kernel(SgCam c, SgBatch bt, int P, SgSkin k, const float *__restrict
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;
 // per workgroup: partial dL/dA [Jp x 16] (matrix cores) and dL/dtransl [3] written to a slab
 // (reduced by sg_skin_reduce_kernel -- no atomics, deterministic).
-// bt.K frames of the SAME canonical Gaussians (round 4): the wave walks the frames -- blend T with frame f's joint transforms, sum
-// frame f's gradient records, chain rule, dA partials of frame f into frame f's slab row -- and sums the canonical-Gaussian
-// gradients of the K frames in registers, in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K single-frame calls
-// leave behind when the first writes the gradient buffer and the others run with accumulate = 1).  The gradient row -- 55 floats per
-// Gaussian on the avatar, 48 of them the SH block -- is written ONCE per K frames instead of being read and rewritten by every
-// frame, and the canonical inputs are read once.  dL_dmeans2D, dL_dA, dL_dtransl are per frame.
-// ONE: bt.K == 1 known at compile time (the single-frame entry points): no loop, no per-trip recomputation.
-template <int D, bool ACC, bool ONE>
+template <int D, bool ACC>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
-sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restrict__ shs, const float *__restrict__ scales,
-                   const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0, size_t cap,
-                   const uint32_t *__restrict__ header0, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
+                   const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
+                   const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
-                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride, size_t slab_frame)
+                   float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
 {
     constexpr bool accumulate = ACC;                            // (compile-time: see sg_preprocess_bwd_kernel)
     __shared__ float sA[SG_JMAX * 16];
@@ -326,164 +319,79 @@ sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restri
     // the staging buffer of the record sums and of the dL/dsh rows
     __shared__ float sWT[SG_SKIN_WAVES][2 * 64 * SG_WSTRIDE];
     static_assert(2 * 64 * SG_WSTRIDE >= SG_REC_CHUNK * 12 && 2 * 64 * SG_WSTRIDE >= 32 * SG_ROW_LDS, "staging buffer size");
-    const int wave_all = threadIdx.x >> 6, lane_all = threadIdx.x & 63;
-    const int g0_all = (blockIdx.x * SG_SKIN_WAVES + wave_all) * 64;
-    const int idx_all = g0_all + lane_all;
-    const bool live = idx_all < P;
-    const int Mrows = c0.M;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *const sWw = sWT[wave], *const sTw = sWT[wave] + 64 * SG_WSTRIDE;
+    const int g0 = (blockIdx.x * SG_SKIN_WAVES + wave) * 64;
+    const int idx = g0 + lane;
+    sg_load_A(k, sA);
+    __syncthreads();
+    float T[12];
+    sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sWw, sTw, T);
+    const bool live = idx < P;
+    float dT[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++) dT[i] = 0.0f;
+    float dtr[3] = { 0, 0, 0 };
+    const int Mrows = c.M;
     constexpr int nc = (D + 1) * (D + 1);
-    const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
-    // sums over the frames
-    float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0;
+    // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
+    const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
+    float4 rc = make_float4(0, 0, 0, 0);
+    if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
+    float a9[9];
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+    sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
     float dsh[nc * 3];
 #pragma unroll
     for (int i = 0; i < nc * 3; i++) dsh[i] = 0.0f;
-    const int nchunk = (k0.J + 15) >> 4;
-    const bool vec = (k0.J & 3) == 0;
-    const int nframes = ONE ? 1 : bt.K;
-#pragma unroll 1
-    for (int f = 0; f < nframes; f++) {
-        // Gaussian index, lane and wave are made opaque per trip: hipcc otherwise hoists everything of the loop body that depends
-        // on them only -- 16 weight-row indices and their bounds masks, ~25 LDS addresses, the shuffle lane indices, the canonical
-        // inputs' addresses -- in front of the loop and keeps it live across it: 327 VGPRs instead of the single-frame kernel's
-        // 192, one wave per SIMD instead of two (248 with this; the recomputation is a few dozen integer operations per frame).
-        int g0 = g0_all, idx = idx_all, lane = lane_all, wave = wave_all;
-        if (!ONE) asm volatile("" : "+v"(g0), "+v"(idx), "+v"(lane), "+v"(wave));
-        float *const sWw = sWT[wave], *const sTw = sWT[wave] + 64 * SG_WSTRIDE;
-        const SgCam c = sg_frame(c0, f, bt.cam_stride);
-        const SgSkin k = sg_skin_frame(k0, f, bt);
-        const SgGeom g = sg_frame(g0_, (size_t)f * bt.geom);
-        const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
-        const uint32_t *header = sg_at(header0, (size_t)f * bt.bin);
-        const int32_t *radii = radii0 + (size_t)f * bt.P;
-        if (f > 0) __syncthreads();                              // every wave is done with the previous frame's sA
-        sg_load_A(k, sA);
-        __syncthreads();
-        float T[12];
-        sg_skin_T(k.lbs_w, k.J, P, g0, lane, sA, sWw, sTw, T);
-        float dT[12];
+    if (live) {
+        float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0, g2[2] = { 0, 0 };
+        const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
+        if (vis || have_in) {
+            SgPosed ps;
+            sg_pose_gaussian(k, idx, T, scales, ps);
+            SgGaussGrad G;
 #pragma unroll
-        for (int i = 0; i < 12; i++) dT[i] = 0.0f;
-        float dtr[3] = { 0, 0, 0 };
-        // this Gaussian's gradient records: wave-cooperative, coalesced (as in sg_preprocess_bwd_kernel)
-        const bool vis = live && radii[idx] > 0 && header[1] == 0u;     // forward overflowed: zero gradients (see sg_preprocess.hip)
-        float4 rc = make_float4(0, 0, 0, 0);
-        if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
-        float a9[9];
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-        sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
-        float g2[2] = { 0, 0 };
-        if (live) {
-            float fxc[3] = { 0, 0, 0 }, fRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, fsc[3] = { 0, 0, 0 }, fop = 0;
-            if (vis || have_in) {
-                SgPosed ps;
-                sg_pose_gaussian(k, idx, T, scales, ps);
-                SgGaussGrad G;
+            for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
 #pragma unroll
-                for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
+            for (int i = 0; i < 4; i++) G.drot[i] = 0;
+            G.g2[0] = G.g2[1] = 0; G.dop = 0;
+            if (vis)
+                sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh, G);
+            if (dposed_xyz_in) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) G.drot[i] = 0;
-                G.g2[0] = G.g2[1] = 0; G.dop = 0;
-                if (vis)
-                    sg_project_bwd<D>(c, ps.p, ps.s3, ps.q, nullptr, shs + (size_t)idx * Mrows * 3, g.flags[idx], a9, true, dsh, G, f == 0);
-                if (dposed_xyz_in) {
+                for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * idx + i];
+            }
+            if (dposed_rotq_in) {
 #pragma unroll
-                    for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * ((size_t)f * bt.P + idx) + i];
-                }
-                if (dposed_rotq_in) {
+                for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * idx + i];
+            }
+            g2[0] = G.g2[0]; g2[1] = G.g2[1]; dop = G.dop;
+            // scales_posed = scales * s ; p = (T33 x + t) * s + transl
 #pragma unroll
-                    for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * ((size_t)f * bt.P + idx) + i];
-                }
-                g2[0] = G.g2[0]; g2[1] = G.g2[1]; fop = G.dop;
-                // scales_posed = scales * s ; p = (T33 x + t) * s + transl
+            for (int i = 0; i < 3; i++) { dsc[i] = G.dsc[i] * ps.sc; dtr[i] = G.dmean[i]; }
+            float dps[3] = { G.dmean[0] * ps.sc, G.dmean[1] * ps.sc, G.dmean[2] * ps.sc };
+            float dRd[9];
+            sg_m2q_bwd(ps.q, ps.best, ps.qab, G.drot, dRd);
 #pragma unroll
-                for (int i = 0; i < 3; i++) { fsc[i] = G.dsc[i] * ps.sc; dtr[i] = G.dmean[i]; }
-                float dps[3] = { G.dmean[0] * ps.sc, G.dmean[1] * ps.sc, G.dmean[2] * ps.sc };
-                float dRd[9];
-                sg_m2q_bwd(ps.q, ps.best, ps.qab, G.drot, dRd);
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-#pragma unroll
-                    for (int kx = 0; kx < 3; kx++) {
-                        // dT33 = dp x^T + dRdef Rc^T
-                        dT[4 * i + kx] = dps[i] * ps.x[kx] + dRd[3 * i] * ps.Rc[3 * kx] + dRd[3 * i + 1] * ps.Rc[3 * kx + 1] + dRd[3 * i + 2] * ps.Rc[3 * kx + 2];
-                    }
-                    dT[4 * i + 3] = dps[i];
-                }
+            for (int i = 0; i < 3; i++) {
 #pragma unroll
                 for (int kx = 0; kx < 3; kx++) {
-                    fxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
-#pragma unroll
-                    for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
-                        fRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
+                    // dT33 = dp x^T + dRdef Rc^T
+                    dT[4 * i + kx] = dps[i] * ps.x[kx] + dRd[3 * i] * ps.Rc[3 * kx] + dRd[3 * i + 1] * ps.Rc[3 * kx + 1] + dRd[3 * i + 2] * ps.Rc[3 * kx + 2];
                 }
+                dT[4 * i + 3] = dps[i];
             }
-            // frame 0 assigns, later frames add: the order of K single-frame calls sharing one gradient buffer
-            if (f == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; i++) { dxc[i] = fxc[i]; dsc[i] = fsc[i]; }
+            for (int kx = 0; kx < 3; kx++) {
+                dxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
 #pragma unroll
-                for (int i = 0; i < 9; i++) dRc[i] = fRc[i];
-                dop = fop;
-            } else {
-#pragma unroll
-                for (int i = 0; i < 3; i++) { dxc[i] += fxc[i]; dsc[i] += fsc[i]; }
-#pragma unroll
-                for (int i = 0; i < 9; i++) dRc[i] += fRc[i];
-                dop += fop;
+                for (int j = 0; j < 3; j++)      // dRc = T33^T dRdef
+                    dRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
             }
-            float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
-            m2[0] = g2[0]; m2[1] = g2[1]; m2[2] = 0.0f;
         }
-        // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
-        float *sdT = sTw;
-#pragma unroll
-        for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
-#pragma unroll
-        for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
-        // every wave owns one slab row per frame (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
-        float *out = slab + (size_t)f * slab_frame + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
-        float4 wv[4];
-        if (vec) sg_w_fetch(k.lbs_w, k.J, P, g0, 0, lane, wv);
-        for (int cch = 0; cch < nchunk; cch++) {
-            if (vec) {
-                sg_w_stash(wv, lane, sWw);
-                if (cch + 1 < nchunk) sg_w_fetch(k.lbs_w, k.J, P, g0, cch + 1, lane, wv);
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-            } else {
-                sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sWw);
-                __builtin_amdgcn_s_waitcnt(0);
-            }
-            __builtin_amdgcn_wave_barrier();
-            f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
-#pragma unroll
-            for (int kk = 0; kk < 16; kk++) {
-                float av = sWw[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
-                float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
-                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
-            }
-            // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
-#pragma unroll
-            for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
-            __builtin_amdgcn_wave_barrier();
-        }
-        // dtransl: wave sum
-#pragma unroll
-        for (int i = 0; i < 3; i++) {
-            float v = dtr[i];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if (lane == 0) out[SG_JMAX * 16 + i] = v;
-        }
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        __builtin_amdgcn_wave_barrier();
-    }
-    // ---- the canonical-Gaussian gradients, once for the K frames
-    const int g0 = g0_all, idx = idx_all, lane = lane_all, wave = wave_all;
-    float *const sWw = sWT[wave];
-    if (live) {
-        // accumulate: the batches of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
+        // accumulate: the frames of one optimisation step share ONE canonical-gradient buffer (sg_skinned_backward_gaussians)
         if (accumulate) {
 #pragma unroll
             for (int i = 0; i < 3; i++) { dxc[i] += dL_dxyz_canon[3 * idx + i]; dsc[i] += dL_dscales[3 * idx + i]; }
@@ -491,10 +399,10 @@ sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restri
         }
         dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
         if (dL_drot_canon) {
-            if (k0.rot6d) {
+            if (k.rot6d) {
                 float d6[6], dd[6];
 #pragma unroll
-                for (int i = 0; i < 6; i++) d6[i] = k0.rot_canon[6 * (size_t)idx + i];
+                for (int i = 0; i < 6; i++) d6[i] = k.rot_canon[6 * (size_t)idx + i];
                 sg_r6d2m_bwd(d6, dRc, dd);
 #pragma unroll
                 for (int i = 0; i < 6; i++) dL_drot_canon[6 * (size_t)idx + i] = dd[i] + (accumulate ? dL_drot_canon[6 * (size_t)idx + i] : 0.0f);
@@ -505,6 +413,7 @@ sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restri
         }
         dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
         dL_dopacity[idx] = dop;
+        dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     }
     // dL/dsh rows (every one of the M rows is written): through LDS as 16-B-per-lane coalesced stores when M == 16
     if (Mrows == 16) {
@@ -531,6 +440,431 @@ sg_skin_bwd_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restri
             for (int i = 0; i < nc * 3; i++) dsh_row[i] = dsh[i];
             for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
         }
+    }
+    // ---- dA[J x 16] += W^T[J x 64] . dT[64 x 16] on the matrix cores
+    float *sdT = sTw;
+#pragma unroll
+    for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
+#pragma unroll
+    for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
+    const int nchunk = (k.J + 15) >> 4;
+    // every wave owns one slab row (no cross-wave stage): [Jp x 16] dA partials + 3 dtransl partials
+    float *out = slab + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
+    const bool vec = (k.J & 3) == 0;
+    float4 wv[4];
+    if (vec) sg_w_fetch(k.lbs_w, k.J, P, g0, 0, lane, wv);
+    for (int cch = 0; cch < nchunk; cch++) {
+        if (vec) {
+            sg_w_stash(wv, lane, sWw);
+            if (cch + 1 < nchunk) sg_w_fetch(k.lbs_w, k.J, P, g0, cch + 1, lane, wv);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        } else {
+            sg_stage_w_chunk(k.lbs_w, k.J, P, g0, cch, lane, sWw);
+            __builtin_amdgcn_s_waitcnt(0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) {
+            float av = sWw[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];     // W^T[joint lane&15][gaussian]
+            float bv = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane&15]
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+        }
+        // acc[r] = dA[joint 16c + 4(lane>>4) + r][entry lane&15]
+#pragma unroll
+        for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        __builtin_amdgcn_wave_barrier();
+    }
+    // dtransl: wave sum
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        float v = dtr[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        if (lane == 0) out[SG_JMAX * 16 + i] = v;
+    }
+}
+
+// ---- K frames per launch (round 4) -----------------------------------------------------------------------------------------
+// bt.K frames of the SAME canonical Gaussians: the wave walks the frames -- blend T with frame f's joint transforms, sum frame f's
+// gradient records, chain rule, dA partials of frame f into frame f's slab row -- and sums the canonical-Gaussian gradients of the
+// K frames in registers, in frame order: frame 0 assigns (ACC: adds to what the gradient buffer holds, read ONCE in front of the
+// loop), frame f > 0 adds -- bit for bit what K single-frame calls leave behind when they share one gradient buffer (first call
+// accumulate = 0 resp. 1, the others 1).  The gradient row -- 55 floats per Gaussian on the avatar, 48 of them the SH block -- is
+// written ONCE per K frames instead of being read and rewritten by every frame.  dL_dmeans2D, dL_dA, dL_dtransl are per frame.
+//
+// What a frame costs here is dependent memory round trips, not arithmetic (6.3e6 VALU instructions per frame = 9 us of issue; the
+// single-frame kernel takes 43 us, the first version of this loop 38 us per frame: A_f -> LDS, 4 weight chunks for T, slot / flags,
+// 3 record chunks, the canonical inputs, 4 weight chunks again for W^T dT).  So, per wave:
+//  * the skinning-weight tile (64 x J floats, the largest input: 4 J bytes per Gaussian) is read from HBM ONCE and stays in LDS
+//    for all K frames and both contractions (row pitch J + 1: conflict-free for the [gaussian][joint] reads of W.A and the
+//    [joint][gaussian] reads of W^T.dT alike);
+//  * the canonical inputs (mean, scales, SH rows in use, 6-D rotation) are read once, in front of the loop;
+//  * frame f + 1's joint transforms and (visible, record slot, clamp flags) are requested while frame f is worked on.
+// LDS: 4 waves x (64 (J + 1) + 64 x 17) floats + 4 KB of joint transforms = 76 KB at J = 52: two workgroups per CU, as many
+// waves per SIMD as the kernel's ~250 registers allow anyway.
+// T rows 0..2 of this lane's Gaussian from the wave's RESIDENT weight tile sW [64][WP] (WP = J + 1) and the frame's sA.
+// The same k-ordered fp32 MFMA chain as sg_skin_T (joints in ascending order, zero weights for the padding joints of the last
+// chunk): the same T, bit for bit.
+__device__ __forceinline__ void sg_skin_T_resident(const float *__restrict__ sW, int WP, int J, int lane, const float *__restrict__ sA,
+                                                   float *__restrict__ sT, float T[12])
+{
+    f32x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; b++) acc[b] = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+    // k-steps of 4 joints; a step whose joints are all padding (J % 16 != 0: the tail of the last chunk) is skipped -- its weights are
+    // zero and A is finite, so acc + 0 x b = acc exactly: the same T as sg_skin_T, bit for bit; the operands of a step are
+    // requested together, in front of its four MFMAs (one LDS latency per step, not one per MFMA)
+    const int nsteps = (J + 3) >> 2;
+    for (int st = 0; st < nsteps; st++) {
+        const int col = 4 * st + (lane >> 4);
+        const float bv = sA[col * 16 + (lane & 15)];
+        float av[4];
+#pragma unroll
+        for (int b = 0; b < 4; b++) av[b] = sW[(16 * b + (lane & 15)) * WP + (col < J ? col : 0)];
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(col < J ? av[b] : 0.0f, bv, acc[b], 0, 0, 0);
+    }
+    if ((lane & 15) < 12) {
+#pragma unroll
+        for (int b = 0; b < 4; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sT[(16 * b + 4 * (lane >> 4) + r) * 13 + (lane & 15)] = acc[b][r];
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int i = 0; i < 12; i++) T[i] = sT[lane * 13 + i];
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Record sums of ALL frames as a kernel of their own (grid: Gaussian blocks x K): a9 [K][P][12] (9 sums + padding: three 16-byte
+// vectors per Gaussian).  Inside the frame loop below the sums were the largest item -- five dependent round trips (load -> LDS ->
+// sum) per wave and frame, 98 of the loop kernel's 320 us at K = 8 (timing-only ablation builds, tools/ablate.py) -- because that
+// kernel runs two waves per SIMD and nothing hides a round trip; here the same coalesced chunk loop runs at full occupancy (40
+// registers) next to thousands of other waves, and the loop kernel reads 48 contiguous bytes per Gaussian and frame instead.  The
+// order of the additions per Gaussian is sg_sum_records_coop's: the same sums, bit for bit.
+__global__ void __launch_bounds__(256)
+sg_record_sums_kernel(SgBatch bt, int P, const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0, size_t cap,
+                      const uint32_t *__restrict__ header0, float4 *__restrict__ a9out)
+{
+    __shared__ float lds_all[4][SG_REC_CHUNK * 12];
+    const int f = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (idx - lane >= P) return;
+    const bool live = idx < P;
+    const SgGeom g = sg_frame(g0_, (size_t)f * bt.geom);
+    const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
+    const bool vis = live && radii0[(size_t)f * bt.P + idx] > 0 && sg_at(header0, (size_t)f * bt.bin)[1] == 0u;
+    float4 rc = make_float4(0, 0, 0, 0);
+    if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
+    float a9[9];
+    sg_sum_records_coop(grec, cap, vis, rc, lane, lds_all[wave], a9);
+    if (live) {
+        float4 *o = a9out + 3 * ((size_t)f * bt.P + idx);
+        o[0] = make_float4(a9[0], a9[1], a9[2], a9[3]); o[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
+        o[2] = make_float4(a9[8], 0.0f, 0.0f, 0.0f);
+    }
+}
+
+template <int D, bool ACC>
+__global__ void __launch_bounds__(SG_SKIN_THREADS) __attribute__((amdgpu_waves_per_eu(D <= 1 ? 2 : 1, 2)))   // (D = 0: 255 VGPRs, no spills)
+sg_skin_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restrict__ shs, const float *__restrict__ scales,
+                          const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0, size_t cap,
+                          const uint32_t *__restrict__ header0, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+                          float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
+                          float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
+                          float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride, size_t slab_frame,
+                          const float4 *__restrict__ a9in)
+{
+    constexpr bool accumulate = ACC;
+    extern __shared__ float sg_skin_lds[];                      // [sA 64 x 16][per wave: W tile 64 x WP | scratch 64 x 17]
+    const int J = k0.J, WP = J + 1;
+    const int wave_size = 64 * WP + 64 * SG_WSTRIDE;
+    float *const sA = sg_skin_lds;
+    const int wave_all = threadIdx.x >> 6, lane_all = threadIdx.x & 63;
+    const int g0_all = (blockIdx.x * SG_SKIN_WAVES + wave_all) * 64;
+    const int idx_all = g0_all + lane_all;
+    const bool live = idx_all < P;
+    const int Mrows = c0.M;
+    constexpr int nc = (D + 1) * (D + 1);
+    const bool have_in = dposed_xyz_in != nullptr || dposed_rotq_in != nullptr;
+    const int nchunk = (J + 15) >> 4;
+    // ---- once per K frames: the wave's weight tile into LDS (coalesced: the tile's 64 rows are one contiguous range)
+    {
+        float *const sW = sg_skin_lds + SG_JMAX * 16 + wave_all * wave_size;
+        const int rows = P - g0_all < 64 ? (P - g0_all > 0 ? P - g0_all : 0) : 64;
+        const int total = rows * J;
+        const float *src = k0.lbs_w + (size_t)g0_all * J;
+        if (((J & 3) == 0)) {
+            // every load of the tile is issued before the first LDS write: ONE memory round trip (64 x 64 floats = 16 float4 per lane)
+            float4 v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = 4 * (64 * u + lane_all);
+                v[u] = e < total ? *(const float4 *)(src + e) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int e = 4 * (64 * u + lane_all);
+                if (e < total) {
+                    const int r = e / J, cc = e - r * J;              // (J % 4 == 0: the four values share a row)
+                    float *d = sW + r * WP + cc;
+                    d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+                }
+            }
+        } else {
+            for (int e = lane_all; e < total; e += 64) { const int r = e / J; sW[r * WP + (e - r * J)] = src[e]; }
+        }
+        for (int e = total + lane_all; e < 64 * J; e += 64) { const int r = e / J; sW[r * WP + (e - r * J)] = 0.0f; }   // rows beyond P
+    }
+    // ---- once per K frames: the canonical inputs of this lane's Gaussian
+    float cx[3] = { 0, 0, 0 }, cs[3] = { 0, 0, 0 }, cRc[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, d6[6] = { 0, 0, 0, 0, 0, 0 };
+    if (live) {
+        cx[0] = k0.xyz_canon[3 * idx_all]; cx[1] = k0.xyz_canon[3 * idx_all + 1]; cx[2] = k0.xyz_canon[3 * idx_all + 2];
+        cs[0] = scales[3 * idx_all]; cs[1] = scales[3 * idx_all + 1]; cs[2] = scales[3 * idx_all + 2];
+        if (k0.rot_canon) {
+            if (k0.rot6d) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) d6[i] = k0.rot_canon[6 * (size_t)idx_all + i];
+                sg_r6d2m(d6, cRc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 9; i++) cRc[i] = k0.rot_canon[9 * (size_t)idx_all + i];
+            }
+        }
+    }
+    const float csc = k0.smpl_scale ? k0.smpl_scale[0] : 1.0f;
+    // ---- sums over the frames; ACC: they start from what the gradient buffer holds
+    float dxc[3] = { 0, 0, 0 }, dRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, dsc[3] = { 0, 0, 0 }, dop = 0;
+    float dsh[nc * 3];
+#pragma unroll
+    for (int i = 0; i < nc * 3; i++) dsh[i] = 0.0f;
+    if (accumulate && live) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { dxc[i] = dL_dxyz_canon[3 * idx_all + i]; dsc[i] = dL_dscales[3 * idx_all + i]; }
+        dop = dL_dopacity[idx_all];
+        if (dL_drot_canon) {
+            const int rw = k0.rot6d ? 6 : 9;
+            for (int i = 0; i < rw; i++) dRc[i] = dL_drot_canon[(size_t)rw * idx_all + i];
+        }
+#pragma unroll
+        for (int i = 0; i < nc * 3; i++) dsh[i] = dL_dsh[(size_t)idx_all * Mrows * 3 + i];
+    }
+    // frame 0's joint transforms; (visible, slot, flags) of frame 0
+    for (int i = threadIdx.x; i < SG_JMAX * 16; i += SG_SKIN_THREADS) sA[i] = i < J * 16 ? k0.A[i] : 0.0f;
+    bool vis_n = live && radii0[idx_all] > 0 && header0[1] == 0u;
+    uint32_t fl_n = 0u;
+    if (vis_n) fl_n = g0_.flags[idx_all];
+    __syncthreads();
+#pragma unroll 1
+    for (int f = 0; f < bt.K; f++) {
+        // lane / wave / Gaussian index are made opaque per trip: hipcc otherwise hoists everything of the loop body that depends on
+        // them only (LDS addresses, shuffle lane indices, per-frame array addresses) in front of the loop and keeps it live across
+        // it -- 330 VGPRs instead of ~250, one wave per SIMD instead of two
+        int idx = idx_all, lane = lane_all, wave = wave_all;
+        asm volatile("" : "+v"(idx), "+v"(lane), "+v"(wave));
+        float *const sW = sg_skin_lds + SG_JMAX * 16 + wave * wave_size, *const sTw = sW + 64 * WP;
+        const SgCam c = sg_frame(c0, f, bt.cam_stride);
+        const float *transl = k0.transl ? k0.transl + (size_t)f * bt.transl_stride : nullptr;
+        // next frame's joint transforms: requested now, written to LDS when every wave is done with this frame's
+        float4 an = make_float4(0, 0, 0, 0);
+        const bool more = f + 1 < bt.K;
+        if (more) {
+            const int i4 = 4 * (int)threadIdx.x;                  // SG_JMAX * 16 = 1024 floats = one float4 per thread
+            if (i4 < J * 16) an = *(const float4 *)(k0.A + (size_t)(f + 1) * J * 16 + i4);
+        }
+        float T[12];
+        sg_skin_T_resident(sW, WP, J, lane, sA, sTw, T);
+        const bool vis = vis_n;
+        const uint32_t flags = fl_n;
+        if (more) {
+            const SgGeom gn = sg_frame(g0_, (size_t)(f + 1) * bt.geom);
+            vis_n = live && radii0[(size_t)(f + 1) * bt.P + idx] > 0 && sg_at(header0, (size_t)(f + 1) * bt.bin)[1] == 0u;
+            fl_n = 0u;
+            if (vis_n) fl_n = gn.flags[idx];
+        }
+        // this frame's record sums (sg_record_sums_kernel): 48 contiguous bytes per Gaussian
+        float a9[9];
+        {
+            const float4 *src = a9in + 3 * ((size_t)f * bt.P + idx);
+            float4 r0 = make_float4(0, 0, 0, 0), r1 = r0, r2 = r0;
+            if (vis) { r0 = src[0]; r1 = src[1]; r2 = src[2]; }
+            a9[0] = r0.x; a9[1] = r0.y; a9[2] = r0.z; a9[3] = r0.w; a9[4] = r1.x; a9[5] = r1.y; a9[6] = r1.z; a9[7] = r1.w; a9[8] = r2.x;
+        }
+        float dT[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) dT[i] = 0.0f;
+        float dtr[3] = { 0, 0, 0 };
+        if (live) {
+            float fxc[3] = { 0, 0, 0 }, fRc[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 }, fsc[3] = { 0, 0, 0 }, fop = 0, g2[2] = { 0, 0 };
+            if (vis || have_in) {
+                // sings_hybrid.py:400-419 for this Gaussian (sg_pose_gaussian without the loads and without ext_tfs)
+                float pp[3], s3[3], Rdef[9], q[4];
+#pragma unroll
+                for (int i = 0; i < 3; i++) pp[i] = T[4 * i] * cx[0] + T[4 * i + 1] * cx[1] + T[4 * i + 2] * cx[2] + T[4 * i + 3];
+                s3[0] = cs[0]; s3[1] = cs[1]; s3[2] = cs[2];
+                if (k0.smpl_scale) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) { pp[i] = pp[i] * csc; s3[i] = s3[i] * csc; }
+                }
+                if (transl) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) pp[i] = pp[i] + transl[i];
+                }
+                if (k0.rot_canon) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++)
+                            Rdef[3 * i + j] = T[4 * i] * cRc[j] + T[4 * i + 1] * cRc[3 + j] + T[4 * i + 2] * cRc[6 + j];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 3; i++)
+#pragma unroll
+                        for (int j = 0; j < 3; j++) Rdef[3 * i + j] = T[4 * i + j];
+                }
+                int best; float qab;
+                sg_m2q(Rdef, q, best, qab);
+                SgGaussGrad G;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { G.dmean[i] = 0; G.dsc[i] = 0; G.dcol[i] = 0; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) G.drot[i] = 0;
+                G.g2[0] = G.g2[1] = 0; G.dop = 0;
+                if (vis)
+                    sg_project_bwd<D>(c, pp, s3, q, nullptr, shs + (size_t)idx * Mrows * 3, flags, a9, true, dsh, G, !accumulate && f == 0);
+                if (dposed_xyz_in) {
+#pragma unroll
+                    for (int i = 0; i < 3; i++) G.dmean[i] += dposed_xyz_in[3 * ((size_t)f * bt.P + idx) + i];
+                }
+                if (dposed_rotq_in) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) G.drot[i] += dposed_rotq_in[4 * ((size_t)f * bt.P + idx) + i];
+                }
+                g2[0] = G.g2[0]; g2[1] = G.g2[1]; fop = G.dop;
+#pragma unroll
+                for (int i = 0; i < 3; i++) { fsc[i] = G.dsc[i] * csc; dtr[i] = G.dmean[i]; }
+                float dps[3] = { G.dmean[0] * csc, G.dmean[1] * csc, G.dmean[2] * csc };
+                float dRd[9];
+                sg_m2q_bwd(q, best, qab, G.drot, dRd);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; kx++)
+                        dT[4 * i + kx] = dps[i] * cx[kx] + dRd[3 * i] * cRc[3 * kx] + dRd[3 * i + 1] * cRc[3 * kx + 1] + dRd[3 * i + 2] * cRc[3 * kx + 2];
+                    dT[4 * i + 3] = dps[i];
+                }
+#pragma unroll
+                for (int kx = 0; kx < 3; kx++) {
+                    fxc[kx] = T[kx] * dps[0] + T[4 + kx] * dps[1] + T[8 + kx] * dps[2];
+#pragma unroll
+                    for (int j = 0; j < 3; j++) fRc[3 * kx + j] = T[kx] * dRd[j] + T[4 + kx] * dRd[3 + j] + T[8 + kx] * dRd[6 + j];
+                }
+            }
+            // the decoder's 6-D rotations: every frame's dL/dR_canon goes through the Gram-Schmidt backward on its own, as in a
+            // single-frame call (the map is linear in dR, but J (a + b) and J a + J b differ in the last bit)
+            if (dL_drot_canon && k0.rot6d) {
+                float dd[6];
+                sg_r6d2m_bwd(d6, fRc, dd);
+#pragma unroll
+                for (int i = 0; i < 6; i++) fRc[i] = dd[i];
+            }
+            if (!accumulate && f == 0) {
+#pragma unroll
+                for (int i = 0; i < 3; i++) { dxc[i] = fxc[i]; dsc[i] = fsc[i]; }
+#pragma unroll
+                for (int i = 0; i < 9; i++) dRc[i] = fRc[i];
+                dop = fop;
+            } else {
+                // (operand order of the single-frame accumulate: new + old)
+#pragma unroll
+                for (int i = 0; i < 3; i++) { dxc[i] = fxc[i] + dxc[i]; dsc[i] = fsc[i] + dsc[i]; }
+#pragma unroll
+                for (int i = 0; i < 9; i++) dRc[i] = fRc[i] + dRc[i];
+                dop = fop + dop;
+            }
+            float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
+            m2[0] = g2[0]; m2[1] = g2[1]; m2[2] = 0.0f;
+        }
+        // ---- dA[J x 16] = W^T[J x 64] . dT[64 x 16] on the matrix cores, W from the resident tile
+        float *sdT = sTw;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 12; i++) sdT[lane * SG_WSTRIDE + i] = dT[i];
+#pragma unroll
+        for (int i = 12; i < 16; i++) sdT[lane * SG_WSTRIDE + i] = 0.0f;
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_wave_barrier();
+        float *out = slab + (size_t)f * slab_frame + ((size_t)blockIdx.x * SG_SKIN_WAVES + wave) * slab_stride;
+        for (int cch = 0; cch < nchunk; cch++) {
+            f32x4 acc = (f32x4){ 0.0f, 0.0f, 0.0f, 0.0f };
+            // (joints >= J of the last chunk: the column index is clamped -- those rows of dA are written with whatever comes out
+            //  and never read: sg_skin_reduce2_kernel sums J x 16 columns)
+            const int col = 16 * cch + (lane & 15) < J ? 16 * cch + (lane & 15) : J - 1;
+#pragma unroll
+            for (int k4 = 0; k4 < 4; k4++) {
+                float av[4], bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int kk = 4 * k4 + u;
+                    av[u] = sW[(4 * kk + (lane >> 4)) * WP + col];                          // W^T[joint][gaussian 4 kk + (lane >> 4)]
+                    bv[u] = sdT[(4 * kk + (lane >> 4)) * SG_WSTRIDE + (lane & 15)];          // dT[gaussian][entry lane & 15]
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u], bv[u], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) out[(16 * cch + 4 * (lane >> 4) + r) * 16 + (lane & 15)] = acc[r];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            float v = dtr[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if (lane == 0) out[SG_JMAX * 16 + i] = v;
+        }
+        if (more) {
+            __syncthreads();                                     // every wave is done with this frame's joint transforms
+            *(float4 *)(sA + 4 * (int)threadIdx.x) = an;
+            __syncthreads();
+        }
+    }
+    // ---- the canonical-Gaussian gradients, once for the K frames (ACC: the sums already include what the buffer held)
+    const int idx = idx_all, lane = lane_all, g0 = g0_all;
+    float *const sWw = sg_skin_lds + SG_JMAX * 16 + wave_all * wave_size;      // (the weight tile is dead: staging for the SH rows)
+    if (live) {
+        dL_dxyz_canon[3 * idx] = dxc[0]; dL_dxyz_canon[3 * idx + 1] = dxc[1]; dL_dxyz_canon[3 * idx + 2] = dxc[2];
+        if (dL_drot_canon) {
+            const int rw = k0.rot6d ? 6 : 9;
+            for (int i = 0; i < rw; i++) dL_drot_canon[(size_t)rw * idx + i] = dRc[i];
+        }
+        dL_dscales[3 * idx] = dsc[0]; dL_dscales[3 * idx + 1] = dsc[1]; dL_dscales[3 * idx + 2] = dsc[2];
+        dL_dopacity[idx] = dop;
+    }
+    // dL/dsh rows: every one of the M rows is written (through LDS as 16-B-per-lane coalesced stores when M == 16); ACC: only the
+    // (D+1)^2 rows in use are rewritten -- the others keep what the step's first call wrote
+    if (Mrows == 16 && (!accumulate || nc == 16) && 64 * WP >= 32 * SG_ROW_LDS) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            if ((lane >> 5) == h) {
+                float *row = sWw + (lane & 31) * SG_ROW_LDS;
+#pragma unroll
+                for (int i = 0; i < 48; i++) row[i] = i < nc * 3 ? dsh[i < nc * 3 ? i : 0] : 0.0f;
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+            sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, sWw, 32, false);
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (live) {
+        float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+#pragma unroll
+        for (int i = 0; i < nc * 3; i++) dsh_row[i] = dsh[i];
+        if (!accumulate)
+            for (int i = nc * 3; i < Mrows * 3; i++) dsh_row[i] = 0.0f;
     }
 }
 
@@ -1008,9 +1342,20 @@ void sg_launch_skin_fwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
 #undef SG_SF
 }
 
+// dynamic LDS above 64 KB needs the kernel's limit raised (once per kernel and process; J = 64: 88 KB)
+static void sg_skin_frames_lds(const void *fn, size_t bytes)
+{
+    if (bytes > 64 * 1024) (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 // per frame: the per-wave slabs, followed (after the slabs of ALL frames) by the SG_RED_GROUPS partial rows of every frame
 static size_t sg_skin_slab_rows(int P) { return (size_t)((P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS) * SG_SKIN_WAVES; }
-size_t sg_skin_slab_floats(int P, int K) { return (sg_skin_slab_rows(P) + SG_RED_GROUPS) * (size_t)(K > 0 ? K : 1) * (SG_JMAX * 16 + 4); }
+size_t sg_skin_slab_floats(int P, int K)
+{
+    const size_t k = (size_t)(K > 0 ? K : 1);
+    // (+ the record sums of the K-frame backward: 12 floats per frame and Gaussian, 16-byte aligned behind the partial rows)
+    return (sg_skin_slab_rows(P) + SG_RED_GROUPS) * k * (SG_JMAX * 16 + 4) + (k > 1 ? k * 12 * (size_t)P + 4 : 0);
+}
 
 void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
@@ -1024,12 +1369,22 @@ void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
     const int nblocks = (P + SG_SKIN_THREADS - 1) / SG_SKIN_THREADS, stride = SG_JMAX * 16 + 4;
     const size_t slab_frame = sg_skin_slab_rows(P) * stride;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
-#define SG_SB3(DD, AA, OO) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA, OO>), grid, block, 0, st, c, bt, P, k, shs, scales, radii, g,       \
+#define SG_SB1(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
                                      grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
-                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride, slab_frame)
-#define SG_SB2(DD, AA) do { if (bt.K == 1) SG_SB3(DD, AA, true); else SG_SB3(DD, AA, false); } while (0)
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
+#define SG_SBK(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_frames_kernel<DD, AA>), grid, block, dyn, st, c, bt, P, k, shs, scales, radii, g,       \
+                                     grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
+                                     dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride, slab_frame, a9buf)
+#define SG_SB2(DD, AA) do { if (bt.K == 1) SG_SB1(DD, AA); else { sg_skin_frames_lds((const void *)sg_skin_bwd_frames_kernel<DD, AA>, dyn); SG_SBK(DD, AA); } } while (0)
 #define SG_SB(DD) do { if (accumulate) SG_SB2(DD, true); else SG_SB2(DD, false); } while (0)
+    // the frames kernel: sA + 4 waves x (resident weight tile 64 x (J + 1) + scratch 64 x 17) floats of dynamic LDS
+    const size_t dyn = ((size_t)SG_JMAX * 16 + (size_t)SG_SKIN_WAVES * (64 * (in->J + 1) + 64 * SG_WSTRIDE)) * sizeof(float);
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
+    // K > 1: the record sums of all frames first, as a kernel of their own (a9 [K][P][12] behind the slabs and partial rows)
+    const float4 *a9buf = (const float4 *)(slab + (slab_frame + (size_t)SG_RED_GROUPS * stride) * bt.K);
+    if (bt.K > 1)
+        hipLaunchKernelGGL(sg_record_sums_kernel, dim3((P + 255) / 256, bt.K), dim3(256), 0, st, bt, P, radii, g, grec, cap, header,
+                           (float4 *)a9buf);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
     float *part = slab + slab_frame * bt.K;
     hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4, bt.K), dim3(256), 0, st, slab,
@@ -1039,7 +1394,8 @@ void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_SB
 #undef SG_SB2
-#undef SG_SB3
+#undef SG_SB1
+#undef SG_SBK
 }
 
 void sg_launch_lbs_fwd(int P, int J, const float *W, const float *A, const float *v, float *T_out, float *verts, hipStream_t st)
