@@ -129,6 +129,12 @@ def parse_args():
                          "entry points: K consecutive workspaces, the per-Gaussian backward sums the K frames in registers).  A step "
                          "of --views-per-step views is views / K such batches, dealt to the streams.  1 = one engine per view (round "
                          "3).  Default: avatar 8, raster 1")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="avatar workload: instead of one batch of frames per stream, schedule by KIND of kernel on two streams -- the "
+                         "composite kernels of all batches on one, everything else beside them on a high-priority one "
+                         "(sings_amd.engine.FramePipeline).  Measured and NOT the default: beside a composite kernel the light "
+                         "kernels take 3-4x as long (the composites already use 70-77 % of the vector issue slots): 4 970 vs 5 380 "
+                         "frames/s (LAB.md)")
     ap.add_argument("--streams", type=int, default=None,
                     help="raster workload: HIP streams the views of one step are spread over (each stream has its own "
                          "workspaces; the per-view gradients are folded on a communication stream)")
@@ -311,6 +317,27 @@ def measure_copy_peak(dev, gib=1.0):
     return best
 
 
+def scaling_model(bytes_, t_step_ms, t_one_ms, exposed_ms=None, world=8):
+    """A clearly labelled MODEL of the 8-GPU frame-parallel step (no multi-GPU box is available to this build: the driver's SCALE
+    run is the measurement this is to be compared with).  Per step every rank adds ONE collective over `bytes_` of gradient:
+      rs_ag      : reduce-scatter + all-gather, every rank exchanging 1/W of the buffer with each peer over its own xGMI link:
+                   2 (W-1)/W S / ((W-1) 153 GB/s) = 2 S / (W 153 GB/s)
+      all_reduce : one ring: 2 (W-1)/W S / 153 GB/s  (per-link bound of RCCL's default schedule on a point-to-point mesh)
+    and cannot hide it (every gradient element depends on the last backward kernel; the optimiser needs the sum), so
+      predicted_scale_W = W t_step / (t_step + max(exposed_measured_world1, t_collective))
+    at the batched step and at the reference's one frame per step."""
+    S = float(bytes_)
+    link = XGMI_LINK_GBS * 1e9
+    coll = {"rs_ag": 2.0 * S / (world * link) * 1e3, "all_reduce": 2.0 * (world - 1) / world * S / link * 1e3}
+    floor = exposed_ms or 0.0
+    pred = {}
+    for label, t in (("batched", t_step_ms), ("one_view_per_step", t_one_ms)):
+        pred[label] = {k: world * t / (t + max(floor, v)) for k, v in coll.items()}
+    return {"label": "MODEL of the 8-GPU step, not a measurement (SCALE runs are the driver's)", "world": world, "collective_bytes": int(S),
+            "xgmi_link_GBs": XGMI_LINK_GBS, "collective_ms": coll, "exposed_ms_measured_world1": exposed_ms,
+            "t_step_ms": {"batched": t_step_ms, "one_view_per_step": t_one_ms}, "predicted_scale_8": pred}
+
+
 def allreduce_probe(fp, buf, iters=10):
     """Stand-alone collective on the step's gradient buffer: ms per call (device events; MAX over ranks is implied by the
     collective itself), bytes, and the xGMI per-link lower bound 2 (S/W) / 153 GB/s of a reduce-scatter + all-gather that
@@ -396,7 +423,12 @@ def main_raster(a):
         fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
                            force=FORCE_DIST)
 
-    n_streams = max(1, min(a.streams, k_views))
+    # K cameras per launch (round 4, sings_amd.engine.RasterFramesEngine): the step's k_views views go out as k_views / K batches
+    Kf = 1 if a.graph else max(1, min(a.frames_per_launch if a.frames_per_launch is not None else 1, k_views, _lib.MAX_FRAMES))
+    while k_views % Kf:
+        Kf -= 1
+    n_batches = k_views // Kf
+    n_streams = max(1, min(a.streams, n_batches))
     per_view = N * (3 + 3 + 4 + 1 + 3 * shs.shape[1])
     # the k views of a step: each has its own engine (= workspaces, so that views in flight at the same time on different
     # streams share no state) writing its gradients into its own row of `grads`; ViewBatch deals them to the streams and
@@ -404,17 +436,30 @@ def main_raster(a):
     # round 3: one gradient row per STREAM -- the first view of a stream writes it, the later ones add to it (accumulate mode of
     # the per-Gaussian backward), so the fold after the join reads `streams` rows, not `views` rows.  --gradient-rows views: the
     # round-2 scheme; one: a single buffer, the views' last kernels ordered across the streams by events.
-    rows = {"streams": n_streams, "views": k_views, "one": 1}[a.gradient_rows]
+    rows = {"streams": n_streams, "views": n_batches, "one": 1}[a.gradient_rows]
     grads = ViewBatch.gradient_rows(rows, per_view, dev)
     engs = []
-    for v in range(k_views):
-        e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
+    short = tile_max * 1.5 <= 1024
+    for v in range(n_batches):
         # the sizing pass knows the longest tile list (135 at cfg3): with 1.5x margin for the other cameras of the batch no
         # list can need the long-list sort kernels (lists <= 1024 are sorted by the compositing workgroups; checked on the device, a
         # violation surfaces in num_rendered() below)
-        e.set_camera(camera(rank * k_views + v)[3], short_lists=tile_max * 1.5 <= 1024)
+        if Kf == 1:
+            e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
+            e.set_camera(camera(rank * k_views + v)[3], short_lists=short)
+        else:
+            from sings_amd.engine import RasterFramesEngine
+            e = RasterFramesEngine(N, W, H, shs.shape[1], Kf, dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
+            cams = [camera(rank * k_views + v * Kf + f) for f in range(Kf)]
+            e.set_camera(cams[0][3]._replace(viewmatrix=t(np.stack([c_[0] for c_ in cams])), projmatrix=t(np.stack([c_[1] for c_ in cams])),
+                                             campos=t(np.stack([c_[2] for c_ in cams]))), short_lists=short)
         engs.append(e)
-    eng = engs[0]
+    if Kf == 1:
+        eng = engs[0]
+    else:                                                        # the one-view-per-step leg and the parity views: a plain engine
+        eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096)
+        eng.set_camera(camera(rank * k_views)[3], short_lists=short)
+    dL_k = dL if Kf == 1 else dL[None].expand(Kf, -1, -1, -1).contiguous()
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
 
     graph = eng.capture(means3D, shs, opac, scales, rots, None if a.forward_only else dL) if a.graph else None
@@ -422,7 +467,7 @@ def main_raster(a):
     def one_view(v, e):
         e.forward(means3D, shs, opac, scales, rots)
         if not a.forward_only:
-            e.backward(means3D, shs, opac, scales, rots, dL)
+            e.backward(means3D, shs, opac, scales, rots, dL if getattr(e, "K", 1) == 1 else dL_k)
 
     reg = None
     if a.regularisers:
@@ -469,7 +514,8 @@ def main_raster(a):
     els = timed_repeats(dist, dev, a.steps, step)
     el = _median(els)
     _log(f"{el / a.steps * 1e3:.3f} ms per step (median of {len(els)} regions); one view per step")
-    assert all(0 <= e.num_rendered() <= e.cap for e in engs), "pair capacity / short-list hint violated"
+    assert all(0 <= r_ <= e.cap for e in engs for r_ in (e.num_rendered() if getattr(e, "K", 1) > 1 else [e.num_rendered()])), \
+        "pair capacity / short-list hint violated"
     ms_per_step = el / a.steps * 1e3
     views_s = world * a.steps * k_views / el
     grad_hash = None
@@ -544,7 +590,8 @@ def main_raster(a):
                                f"{'forward only' if a.forward_only else 'fwd+bwd'}, "
                                f"R={R} (tile,Gaussian) pairs, frame-parallel dp{world}",
                    "gaussians": N, "width": W, "height": H, "sh_degree": deg, "num_rendered": R, "tile_list_mean": tile_mean,
-                   "tile_list_max": tile_max, "views_per_step": k_views, "streams": n_streams, "regularisers": bool(a.regularisers),
+                   "tile_list_max": tile_max, "views_per_step": k_views, "frames_per_launch": Kf, "launch_batches_per_step": n_batches,
+                   "streams": n_streams, "regularisers": bool(a.regularisers),
                    "forward_only": bool(a.forward_only), "hip_graph": bool(a.graph),
                    "reduction": "one_shot" if a.one_shot_reduce or graph is not None else
                                 f"fold of {rows} gradient row(s) for {k_views} views + collective in {len(batch.pipe.bounds)} chunk(s)",
@@ -562,6 +609,8 @@ def main_raster(a):
     out.update({k: None for k in COMM_KEYS})
     if comm is not None:
         out.update(comm)
+    out["scaling_model"] = scaling_model(batch.acc.numel() * 4, ms_per_step, el_one / n_one * 1e3,
+                                         comm.get("allreduce_exposed_ms") if comm else None)
     if grad_hash is not None:
         out["grad_sha256"] = grad_hash
     if world == 1 and not a.no_cpu_baseline:
@@ -1149,18 +1198,24 @@ def main_avatar(a):
     per_view = N * (3 + 3 + 1 + 3 * sh.shape[1])
     from sings_amd.engine import SkinnedFramesEngine, ViewBatch
     from sings_amd.photo_loss import PhotoLossEngine
-    rows = {"streams": n_streams, "views": n_batches, "one": 1}[a.gradient_rows]
-    grads = ViewBatch.gradient_rows(rows, per_view, dev)
+    pipelined = Kf > 1 and n_batches > 1 and a.pipeline
+    rows = 1 if pipelined else {"streams": n_streams, "views": n_batches, "one": 1}[a.gradient_rows]
+    # SH gradients coefficient-major (SG_FLAG_SH_PLANAR): the reference allocates 16 SH rows and trains at degree 0 -- 45 of the 55
+    # gradient floats per Gaussian are structural zeros.  Only the prefix that carries gradient (10 floats per Gaussian) is
+    # written, folded and all-reduced; the rest of the buffer is zeroed once, here
+    grads = torch.zeros((rows, per_view), dtype=torch.float32, device=dev)
     engs, losses = [], []
     for v in range(n_batches):
         if Kf == 1:
-            e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
+            e = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows], sh_planar=True)
         else:
-            e = SkinnedFramesEngine(N, J, W, H, sh.shape[1], Kf, dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows])
+            e = SkinnedFramesEngine(N, J, W, H, sh.shape[1], Kf, dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows],
+                                    sh_planar=True)
         e.set_camera(rs)
         engs.append(e)
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2, K=Kf))    # human.loss.l1_w / ssim_w
-    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096) if Kf > 1 else engs[0]
+    eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, sh_planar=True) if Kf > 1 else engs[0]
+    active = eng.active_floats(0)                                    # N * 10 of the N * 55 floats
     if Kf > 1:
         eng.set_camera(rs)
     loss1 = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2) if Kf > 1 else losses[0]
@@ -1168,7 +1223,7 @@ def main_avatar(a):
     shard = FrameSharder(F, world, rank, seed=0)
     fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
                         force=FORCE_DIST) if dist is not None else None)
-    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
+    batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks, active=active)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
     # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
     torch.manual_seed(0)                                             # (the target image: the same in every process)
@@ -1203,9 +1258,26 @@ def main_avatar(a):
         dLi = losses[b](e.color, gt_rgb, mask, bg_t)                            # (one target image for all frames: stride 0)
         e.backward(sh, op, sc, dLi)
 
+    if pipelined:
+        # ONE gradient buffer for the step (rows = 1): the batches' per-Gaussian halves run in batch order on one stream
+        from sings_amd.engine import FramePipeline
+        pipe2 = FramePipeline(engs, dev)
+
+        def set_frames(b, frames):
+            pin = pins[b][pin_at[b] % 256]; pin_at[b] += 1
+            pin.copy_(torch.tensor(frames, dtype=torch.long))
+            frame_idx[b].copy_(pin, non_blocking=True)
+            torch.index_select(A_all, 0, frame_idx[b], out=A_batch[b])
+            engs[b].set_frames(xyz, None, w, A_batch[b], smpl_scale, transl_k)
+
     def step(i):
         if Kf == 1:
             batch.run(lambda v, e: one_view(v, shard.frame(i * k_views + v)))
+        elif pipelined:
+            pipe2.run(prepare=lambda b, e: set_frames(b, [shard.frame(i * k_views + b * Kf + f) for f in range(Kf)]),
+                      forward_args=(sh, op, sc),
+                      loss=lambda b, e: losses[b](e.color, gt_rgb, mask, bg_t))
+            batch.pipe.reduce()                                  # (one row: no fold; with several ranks the all-reduce)
         else:
             batch.run(lambda b, e: one_batch(b, [shard.frame(i * k_views + b * Kf + f) for f in range(Kf)]))
 
@@ -1213,7 +1285,7 @@ def main_avatar(a):
         step(i)
     els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i))
     el = _median(els)
-    comm = allreduce_probe(fp, batch.acc)
+    comm = allreduce_probe(fp, batch.acc[:active])
     assert all(max(e.num_rendered()) <= e.cap if Kf > 1 else e.num_rendered() <= e.cap for e in engs)
     grad_hash = None
     if a.grad_hash:
@@ -1224,7 +1296,7 @@ def main_avatar(a):
     def step_one_frame(i):
         one_view(0, shard.frame(i), eng, loss1)
         if fp is not None:
-            fp.all_reduce_grads(eng.grad_flat)
+            fp.all_reduce_grads(eng.grad_flat[:active])
     n_one = max(20, min(a.steps * k_views, 2000))
     eng.throughput = False                                       # one frame in flight from here on (SG_FLAG_THROUGHPUT off)
     for i in range(10):
@@ -1249,7 +1321,11 @@ def main_avatar(a):
                                       f"fwd + L1/SSIM loss + bwd, R<={Rmax}, frame-parallel dp{world}", "gaussians": N, "joints": J,
                           "width": W, "height": H, "max_num_rendered": Rmax, "tile_list_mean": tile_mean, "tile_list_max": tile_max,
                           "views_per_step": k_views, "frames_per_launch": Kf, "launch_batches_per_step": n_batches,
-                          "streams": n_streams, "parallelism": f"dp{world}"},
+                          "streams": 2 if pipelined else n_streams,
+                          "schedule": "pipeline: composite kernels on one stream, binning / loss / per-Gaussian backward of the "
+                                      "other batches beside them on a high-priority stream" if pipelined else
+                                      "every batch runs its whole chain on one of the streams",
+                          "parallelism": f"dp{world}"},
                "kernel_ms": kern}
         per, total_bytes = algorithmic_bytes_skinned(N, H, W, Rmax, 0, J)
         fps = out["value"] / world
@@ -1264,6 +1340,11 @@ def main_avatar(a):
         out.update({k: None for k in COMM_KEYS})
         if comm is not None:
             out.update(comm)
+        out["scaling_model"] = scaling_model(active * 4, el / a.steps * 1e3, el_one / n_one * 1e3,
+                                             comm.get("allreduce_exposed_ms") if comm else None)
+        out["gradient_floats_per_gaussian"] = {"buffer": per_view // N, "carrying_gradient": active // N,
+                                               "note": "SH gradients coefficient-major (SG_FLAG_SH_PLANAR): only the (sh_degree+1)^2 "
+                                                       "planes in use are written, folded and all-reduced"}
         if grad_hash is not None:
             out["grad_sha256"] = grad_hash
         if world == 1 and not a.no_cpu_baseline:

@@ -96,6 +96,21 @@ const char *sg_last_error(void);
  * frame rendered alone, ~3 % slower when other views already fill the idle SIMDs.  Must be the same in the forward and the
  * backward call of a view (it decides the layout of the per-entry quadrant masks). */
 #define SG_FLAG_THROUGHPUT 4
+/* The forward in two calls on the SAME workspaces, for callers that schedule the halves on different streams (ordered by their own
+ * events): SG_FLAG_FORWARD_BINNING runs the per-Gaussian kernel and the tile binning only (latency-bound, light on the vector ALUs),
+ * SG_FLAG_FORWARD_COMPOSITE the per-tile composite only (VALU-bound).  bench.py's avatar step runs the composite kernels of one
+ * batch of frames on one stream while the binning / loss / per-Gaussian backward of the next batch run beside them on another.
+ * Neither flag: the whole forward.  num_rendered_host is honoured by the call that runs the binning. */
+#define SG_FLAG_FORWARD_BINNING 8
+#define SG_FLAG_FORWARD_COMPOSITE 16
+/* SG_FLAG_SH_PLANAR (backward calls): dL_dsh is COEFFICIENT-major, [M][P][3] instead of the reference's [P][M][3], and only the
+ * (sh_degree + 1)^2 coefficient planes in use are written (or, with accumulate, added to); the others are never touched -- zero them
+ * once.  The reference always allocates M = 16 rows (sings/rec/models/modules/decoders.py:34) and trains at sh_degree 0
+ * (human_complex.yaml:34): in the [P][16][3] layout 45 of the 55 gradient floats per Gaussian are structural zeros that every
+ * frame writes, every fold reads and every all-reduce carries.  With the planes in use at the head of the SH block the
+ * canonical-Gaussian gradient of a step is ONE contiguous prefix of the flat buffer (sings_amd.engine: 10 floats per Gaussian on
+ * the avatar) and the frame-parallel collective moves 6 MB instead of 33. */
+#define SG_FLAG_SH_PLANAR 32
 #define SG_NUM_RENDERED_LONG_LIST (-2)
 /* Workspace sizing.  capacity_pairs = upper bound on R = sum of tiles touched. */
 int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out);

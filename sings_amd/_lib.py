@@ -64,6 +64,9 @@ NUM_KERNELS = 8
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT
+FLAG_FORWARD_BINNING = 8             # SG_FLAG_FORWARD_BINNING
+FLAG_FORWARD_COMPOSITE = 16          # SG_FLAG_FORWARD_COMPOSITE
+FLAG_SH_PLANAR = 32                  # SG_FLAG_SH_PLANAR
 NUM_RENDERED_LONG_LIST = -2          # SG_NUM_RENDERED_LONG_LIST
 
 

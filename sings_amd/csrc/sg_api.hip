@@ -245,18 +245,25 @@ static int sg_forward_impl(const char *who, const SgRasterSettings *s, const SgF
     SgImg im = sg_img_view(image_ws, L);
     // header + tile counters: zeroed here unless the caller vouches for them (SG_FLAG_WS_CLEAN; the forward composite
     // leaves them zeroed for the next call).  (The early pair count -- one mapped host word -- serves single-frame calls.)
-    if (bt.K == 1) sg_arm_count(s, &c, num_rendered_host);
-    if (!(c.flags & SG_FLAG_WS_CLEAN)) {
-        const size_t zb = (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4;
-        for (int f = 0; f < bt.K; f++) sg_zero_async((char *)b.header + (size_t)f * bt.bin, zb, st);
+    const bool do_bin = !(c.flags & SG_FLAG_FORWARD_COMPOSITE), do_comp = !(c.flags & SG_FLAG_FORWARD_BINNING);
+    if (!do_bin && !do_comp) { snprintf(msg, sizeof msg, "%s: SG_FLAG_FORWARD_BINNING and SG_FLAG_FORWARD_COMPOSITE exclude each other", who); return sg_fail(msg, hipSuccess); }
+    if (do_bin) {
+        if (bt.K == 1) sg_arm_count(s, &c, num_rendered_host);
+        if (!(c.flags & SG_FLAG_WS_CLEAN)) {
+            const size_t zb = (L.bin_tile_count - L.bin_header) + sg_ctr_count((uint32_t)c.gx, (uint32_t)c.gy) * 4;
+            for (int f = 0; f < bt.K; f++) sg_zero_async((char *)b.header + (size_t)f * bt.bin, zb, st);
+        }
+        if (skin) sg_launch_skin_fwd(c, bt, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
+        else sg_launch_preprocess_fwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
+        SG_CHECK_LAST("preprocess_fwd", s, st);
+        sg_launch_binning(c, bt, P, radii, g, b, cap, write_point_keys, st);
+        SG_CHECK_LAST("binning", s, st);
     }
-    if (skin) sg_launch_skin_fwd(c, bt, P, skin, shs, opacities, scales, g, b, cap, radii, posed_xyz, posed_rotq, posed_scales, st);
-    else sg_launch_preprocess_fwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, g, b, cap, radii, st);
-    SG_CHECK_LAST("preprocess_fwd", s, st);
-    sg_launch_binning(c, bt, P, radii, g, b, cap, write_point_keys, st);
-    SG_CHECK_LAST("binning", s, st);
-    sg_launch_render_fwd(c, bt, g, b, cap, im, out_color, write_point_keys, st);
-    SG_CHECK_LAST("render_fwd", s, st);
+    if (do_comp) {
+        sg_launch_render_fwd(c, bt, g, b, cap, im, out_color, write_point_keys, st);
+        SG_CHECK_LAST("render_fwd", s, st);
+    }
+    if (!do_bin) return 0;
     if (bt.K == 1) return sg_finish_count(s, c, binning_ws, num_rendered_host, stream);
     return num_rendered_host ? sg_read_counts(binning_ws, bt.bin, bt.K, num_rendered_host, stream) : 0;
 }

@@ -168,8 +168,9 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
         for (int k = 0; k < 6; k++) A.g6[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
         if (dL_dsh) {
             const float *row = dL_dsh + (size_t)idx * Mrows * 3;
+            const bool planar = c0.flags & SG_FLAG_SH_PLANAR;
 #pragma unroll
-            for (int k = 0; k < nc * 3; k++) dsh[k] = row[k];
+            for (int k = 0; k < nc * 3; k++) dsh[k] = planar ? dL_dsh[((size_t)(k / 3) * P + idx) * 3 + k % 3] : row[k];
         }
     }
 #pragma unroll 1
@@ -229,8 +230,19 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
     SgGaussGrad &G = A;
     const int lane = lane_all;
     float *L = lds_all[wave_all];
-    // 3. dL/dsh rows out (every one of the M rows is written; coalesced through LDS when staged)
-    if (dL_dsh) {
+    // 3. dL/dsh out: coefficient-major planes [M][P][3], only the (D+1)^2 in use (SG_FLAG_SH_PLANAR); or the reference's rows
+    //    (every one of the M rows is written; coalesced through LDS when staged)
+    if (dL_dsh && (c0.flags & SG_FLAG_SH_PLANAR)) {
+        if (live) {
+#pragma unroll
+            for (int kq = 0; kq < nc; kq++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float *d = dL_dsh + ((size_t)kq * P + idx) * 3 + ch;
+                    *d = (accumulate && ONE) ? dsh[3 * kq + ch] + *d : dsh[3 * kq + ch];
+                }
+        }
+    } else if (dL_dsh) {
         if (staged) {
 #pragma unroll
             for (int h = 0; h < 2; h++) {                    // 32 rows at a time (keeps LDS at 6.5 KiB per wave)

@@ -415,8 +415,20 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
         dL_dopacity[idx] = dop;
         dL_dmeans2D[3 * idx] = g2[0]; dL_dmeans2D[3 * idx + 1] = g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
     }
-    // dL/dsh rows (every one of the M rows is written): through LDS as 16-B-per-lane coalesced stores when M == 16
-    if (Mrows == 16) {
+    // dL/dsh: coefficient-major planes [M][P][3], only the (D+1)^2 in use (SG_FLAG_SH_PLANAR: 12-byte stores, coalesced across
+    // the lanes); or the reference's rows (every one of the M rows is written): through LDS as 16-B-per-lane coalesced stores when
+    // M == 16
+    if (c.flags & SG_FLAG_SH_PLANAR) {
+        if (live) {
+#pragma unroll
+            for (int kq = 0; kq < nc; kq++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float *d = dL_dsh + ((size_t)kq * P + idx) * 3 + ch;
+                    *d = accumulate ? dsh[3 * kq + ch] + *d : dsh[3 * kq + ch];
+                }
+        }
+    } else if (Mrows == 16) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             if ((lane >> 5) == h) {
@@ -648,8 +660,10 @@ sg_skin_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *_
             const int rw = k0.rot6d ? 6 : 9;
             for (int i = 0; i < rw; i++) dRc[i] = dL_drot_canon[(size_t)rw * idx_all + i];
         }
+        const bool planar = c0.flags & SG_FLAG_SH_PLANAR;
 #pragma unroll
-        for (int i = 0; i < nc * 3; i++) dsh[i] = dL_dsh[(size_t)idx_all * Mrows * 3 + i];
+        for (int i = 0; i < nc * 3; i++)
+            dsh[i] = planar ? dL_dsh[((size_t)(i / 3) * P + idx_all) * 3 + i % 3] : dL_dsh[(size_t)idx_all * Mrows * 3 + i];
     }
     // frame 0's joint transforms; (visible, slot, flags) of frame 0
     for (int i = threadIdx.x; i < SG_JMAX * 16; i += SG_SKIN_THREADS) sA[i] = i < J * 16 ? k0.A[i] : 0.0f;
@@ -844,7 +858,14 @@ sg_skin_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *_
     }
     // dL/dsh rows: every one of the M rows is written (through LDS as 16-B-per-lane coalesced stores when M == 16); ACC: only the
     // (D+1)^2 rows in use are rewritten -- the others keep what the step's first call wrote
-    if (Mrows == 16 && (!accumulate || nc == 16) && 64 * WP >= 32 * SG_ROW_LDS) {
+    if (c0.flags & SG_FLAG_SH_PLANAR) {                          // coefficient-major planes, only those in use (see sg_skin_bwd_kernel)
+        if (live) {
+#pragma unroll
+            for (int kq = 0; kq < nc; kq++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) dL_dsh[((size_t)kq * P + idx) * 3 + ch] = dsh[3 * kq + ch];
+        }
+    } else if (Mrows == 16 && (!accumulate || nc == 16) && 64 * WP >= 32 * SG_ROW_LDS) {
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int h = 0; h < 2; h++) {

@@ -152,14 +152,19 @@ class GradientPipeline:
     streams onto four hardware queues, so the communication stream shares a queue with a rendering stream and its
     event waits stall that stream's kernels.  Works on CPU tensors too (gloo tests)."""
 
-    def __init__(self, rows, frame_parallel=None, chunks=4):
+    def __init__(self, rows, frame_parallel=None, chunks=4, active=None):
+        """``active``: only ``rows[:, :active]`` carries gradient (engines with ``sh_planar``: the SH planes not in use stay zero
+        behind it) -- only that prefix is folded and all-reduced; ``acc[active:]`` is zero."""
         if rows.dim() != 2:
             raise ValueError("rows must be [views, floats_per_view]")
         self.rows, self.fp = rows, frame_parallel
-        self.k, self.n = rows.shape
+        self.k, self.n_full = rows.shape
+        self.n = self.n_full if active is None else int(active)
+        if not 0 < self.n <= self.n_full:
+            raise ValueError("active must be in (0, floats_per_view]")
         self.cuda = rows.is_cuda
         # one view per step: the row IS the sum (no fold, no copy)
-        self.acc = rows[0] if self.k == 1 else torch.empty(self.n, dtype=rows.dtype, device=rows.device)
+        self.acc = rows[0] if self.k == 1 else torch.zeros(self.n_full, dtype=rows.dtype, device=rows.device)
         world = 1 if frame_parallel is None else frame_parallel.world
         c = max(1, int(chunks)) if frame_parallel is not None and frame_parallel.active else 1
         step = -(-self.n // c)
@@ -186,7 +191,7 @@ class GradientPipeline:
         if self.fp is not None and self.cuda:
             self.fp.wait(works, None)
             if self.fp.average and self.fp.world > 1:
-                self.acc.div_(self.fp.world)
+                self.acc[:self.n].div_(self.fp.world)
         if self.cuda and self._timed:
             self._t[1].record(torch.cuda.current_stream(self.rows.device))
         return self.acc
@@ -199,9 +204,9 @@ class GradientPipeline:
         ranks, where chunking changes which rank adds first: there both schedules are deterministic per configuration, and
         equal only to rounding."""
         if self.k > 1:
-            torch.sum(self.rows, dim=0, out=self.acc)
+            torch.sum(self.rows[:, :self.n], dim=0, out=self.acc[:self.n])
         if self.fp is not None:
-            self.fp.all_reduce_grads(self.acc)
+            self.fp.all_reduce_grads(self.acc[:self.n])
         return self.acc
 
     # -- measurement --------------------------------------------------------------------------------------------------

@@ -123,14 +123,41 @@ class RasterEngine:
         return g
 
 
+def _carve_skinned(self, carve, with_rot, rot_width, own):
+    """Gradient views of the LBS-fused engines.  Default (the reference's tensor shapes): xyz 3P, scales 3P, opacity P, sh [P,M,3],
+    [rot].  ``sh_planar``: xyz, scales, opacity, [rot], then the SH gradient COEFFICIENT-major, [M,P,3] (SG_FLAG_SH_PLANAR) -- the
+    kernels write only the (sh_degree + 1)^2 planes in use, so the step's gradient is the PREFIX ``grad_flat[:active_floats(deg)]``
+    (10 floats per Gaussian at degree 0 instead of 55): that prefix is what is folded and all-reduced; the rest stays zero (zeroed
+    here, once, when the engine owns the buffer -- a caller-owned buffer must come zeroed)."""
+    P, M = self.P, self.M
+    self.d_xyz = carve(P * 3, P, 3); self.d_scales = carve(P * 3, P, 3); self.d_opacity = carve(P, P, 1)
+    if self.sh_planar:
+        self.d_rot = carve(P * rot_width, P, rot_width) if with_rot else None
+        self.d_sh = carve(P * 3 * M, M, P, 3)
+        if own:
+            self.d_sh.zero_()
+    else:
+        self.d_sh = carve(P * 3 * M, P, M, 3)
+        self.d_rot = carve(P * rot_width, P, rot_width) if with_rot else None
+    self._head = P * 7 + (P * rot_width if with_rot else 0)
+
+
+def _active_floats(self, sh_degree):
+    """Length of the prefix of ``grad_flat`` that carries the step's gradient (everything, unless ``sh_planar``)."""
+    if not self.sh_planar:
+        return self.grad_flat.numel()
+    return self._head + (int(sh_degree) + 1) ** 2 * self.P * 3
+
+
 class SkinnedEngine:
     """Same idea for the LBS-fused path (sg_skinned_forward / backward): canonical Gaussians + per-frame joint
     transforms in, image + flat canonical-Gaussian gradient buffer out.  Flat layout (floats): xyz_canon 3P,
     scales 3P, opacity P, sh 3MP, [rot_canon 9P].  dL/dA [J,16] and dL/dtransl [3] are per-frame (not all-reduced)."""
 
-    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9):
+    def __init__(self, P, J, W, H, sh_coeffs, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9, sh_planar=False):
         self.lib = _lib.load()
         self.P, self.J, self.W, self.H, self.M = int(P), int(J), int(W), int(H), int(sh_coeffs)
+        self.sh_planar = bool(sh_planar)
         self.dev = torch.device(device)
         self.cap = int(capacity_pairs)
         L = _lib.layout(self.P, self.W, self.H, self.cap)
@@ -155,9 +182,7 @@ class SkinnedEngine:
             nonlocal o
             v = self.grad_flat[o:o + n].view(*shape); o += n
             return v
-        self.d_xyz = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
-        self.d_opacity = carve(self.P, self.P, 1); self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
-        self.d_rot = carve(self.P * rot_width, self.P, rot_width) if with_rot else None
+        _carve_skinned(self, carve, with_rot, rot_width, grad_flat is None)
         self.d_means2D = torch.empty((self.P, 3), **f32)
         self.d_A = torch.empty((self.J, 16), **f32); self.d_transl = torch.empty(3, **f32)
         self._keep = []; self._s = None; self._k = None
@@ -167,6 +192,8 @@ class SkinnedEngine:
     def set_camera(self, raster_settings):
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+
+    active_floats = _active_floats
 
     def set_frame(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl, ext_tfs=None):
         from .skinned import _skin_struct
@@ -178,7 +205,8 @@ class SkinnedEngine:
 
     def forward(self, shs, opacities, scales, sync_num_rendered=False):
         nr = C.c_int64(-1)
-        self._s.flags = (_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0)
+        self._s.flags = ((_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0) |
+                         (_lib.FLAG_SH_PLANAR if self.sh_planar else 0))
         self._clean = False
         _lib.check(self.lib.sg_skinned_forward(
             C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.geom),
@@ -245,7 +273,7 @@ class ViewBatch:
     def gradient_rows(views, per_view, device):
         return torch.empty((int(views), int(per_view)), dtype=torch.float32, device=device)
 
-    def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4):
+    def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4, active=None):
         from .dp import GradientPipeline
         self.engines = list(engines)
         if grads.dim() == 1:
@@ -263,7 +291,7 @@ class ViewBatch:
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)] if self.n > 1 else []
         # the rows are folded (one row: nothing to fold) and the sum is all-reduced chunk by chunk on the caller's stream once
         # the views have joined it: sings_amd.dp.GradientPipeline
-        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks)
+        self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks, active=active)
         self.acc = self.pipe.acc
         self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
         for e in self.engines:                                # several views in flight: no latency-only work (SG_FLAG_THROUGHPUT)
@@ -385,8 +413,11 @@ class _FramesBase:
         return [int(v) for v in nr]
 
     def _flags(self):
-        f = (_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0)
+        f = ((_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0) |
+             (_lib.FLAG_SH_PLANAR if getattr(self, "sh_planar", False) else 0))
         return f
+
+    active_floats = _active_floats
 
 
 class SkinnedFramesEngine(_FramesBase):
@@ -394,9 +425,10 @@ class SkinnedFramesEngine(_FramesBase):
     (xyz_canon 3P, scales 3P, opacity P, sh 3MP, [rot_canon]); per frame: ``color`` [K,3,H,W], ``radii`` [K,P], ``d_means2D``
     [K,P,3], ``d_A`` [K,J,16], ``d_transl`` [K,3]."""
 
-    def __init__(self, P, J, W, H, sh_coeffs, K, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9):
+    def __init__(self, P, J, W, H, sh_coeffs, K, device, capacity_pairs, with_rot=False, grad_flat=None, rot_width=9, sh_planar=False):
         self.dev = torch.device(device)
         self.J, self.M = int(J), int(sh_coeffs)
+        self.sh_planar = bool(sh_planar)
         self._alloc(P, W, H, K, capacity_pairs)
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.skin_ws = torch.empty(int(self.lib.sg_skin_ws_floats_frames(self.P, self.K)), **f32)
@@ -412,11 +444,23 @@ class SkinnedFramesEngine(_FramesBase):
             nonlocal o
             v = self.grad_flat[o:o + n].view(*shape); o += n
             return v
-        self.d_xyz = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
-        self.d_opacity = carve(self.P, self.P, 1); self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
-        self.d_rot = carve(self.P * rot_width, self.P, rot_width) if with_rot else None
+        _carve_skinned(self, carve, with_rot, rot_width, grad_flat is None)
         self.d_A = torch.empty((self.K, self.J, 16), **f32); self.d_transl = torch.empty((self.K, 3), **f32)
         self._k = None
+
+    def rebind_gradients(self, grad_flat):
+        """Point the gradient views at another flat buffer (several engines of one step sharing ONE buffer: FramePipeline)."""
+        if grad_flat.numel() != self.grad_flat.numel() or grad_flat.dtype != torch.float32 or not grad_flat.is_contiguous():
+            raise ValueError("rebind_gradients: a contiguous fp32 buffer of the same size")
+        with_rot, rw = self.d_rot is not None, (self.d_rot.shape[1] if self.d_rot is not None else 0)
+        self.grad_flat = grad_flat.view(-1)
+        o = 0
+
+        def carve(n, *shape):
+            nonlocal o
+            v = self.grad_flat[o:o + n].view(*shape); o += n
+            return v
+        _carve_skinned(self, carve, with_rot, rw, False)
 
     def set_frames(self, xyz_canon, rotmat_canon, lbs_weights, A, smpl_scale, transl):
         """``A``: [K,J,4,4] / [K,J,16] joint transforms of the K frames; ``transl``: [K,3] (one per frame), [3] (shared) or None."""
@@ -443,23 +487,35 @@ class SkinnedFramesEngine(_FramesBase):
         self._k.transl = None if transl is None else transl.data_ptr()
         self._fb = _frame_batch(self.K, self._cam_stride, tstride)
 
-    def forward(self, shs, opacities, scales, sync_num_rendered=False):
+    def forward(self, shs, opacities, scales, sync_num_rendered=False, phase=None):
+        """``phase``: None = the whole forward; "binning" / "composite" = its two halves as separate calls on the same workspaces
+        (SG_FLAG_FORWARD_BINNING / _COMPOSITE), for a caller that runs them on different streams and orders them with events."""
         nr = (C.c_int64 * self.K)()
         self._fb.camera_stride = self._cam_stride
-        self._s.flags = self._flags()
+        self._s.flags = self._flags() | {None: 0, "binning": _lib.FLAG_FORWARD_BINNING, "composite": _lib.FLAG_FORWARD_COMPOSITE}[phase]
+        if phase == "composite":
+            self._s.flags &= ~_lib.FLAG_WS_CLEAN
         self._clean = False
         _lib.check(self.lib.sg_skinned_forward_frames(
             C.byref(self._s), C.byref(self._fb), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales),
             _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
-            nr if sync_num_rendered else None, self._stream()), "skinned forward (frames)")
-        self._clean = True
-        return [int(v) for v in nr] if sync_num_rendered else None
+            nr if sync_num_rendered and phase != "composite" else None, self._stream()), "skinned forward (frames)")
+        self._clean = phase != "binning"                      # (the COMPOSITE leaves the counters zeroed for the next forward)
+        return [int(v) for v in nr] if sync_num_rendered and phase != "composite" else None
 
     def backward(self, shs, opacities, scales, dL_dcolor, accumulate=False):
         """``dL_dcolor`` [K,3,H,W].  ``accumulate``: the K frames' sum is ADDED to the gradient buffer (a later batch of the step)."""
+        self.backward_records(dL_dcolor)
+        self.backward_gaussians(shs, opacities, scales, accumulate)
+
+    def backward_records(self, dL_dcolor):
+        """First half of ``backward``: the per-tile composite backward of the K frames (VALU-bound)."""
         _lib.check(self.lib.sg_rasterize_backward_records_frames(
             C.byref(self._s), C.byref(self._fb), self.P, _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img),
             _ptr(self.bwd_ws), _ptr(dL_dcolor), self._stream()), "skinned backward (records, frames)")
+
+    def backward_gaussians(self, shs, opacities, scales, accumulate=False):
+        """Second half: record sums + the per-Gaussian chain rule summed over the K frames (latency-bound)."""
         accumulate, done = self._chain_state(accumulate)
         _lib.check(self.lib.sg_skinned_backward_gaussians_frames(
             C.byref(self._s), C.byref(self._fb), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales),
@@ -524,3 +580,63 @@ class RasterFramesEngine(_FramesBase):
             _ptr(self.d_scales), _ptr(self.d_rots), None, self._stream()), "backward (gaussians, frames)")
         if done is not None:
             done.record(torch.cuda.current_stream(self.dev))
+
+
+class FramePipeline:
+    """The batches of frames of ONE optimisation step on TWO streams, by kind of kernel instead of by batch.
+
+    A frame's chain alternates between kernels that keep the vector ALUs busy (the two composite kernels: half of an avatar frame)
+    and kernels that wait -- binning, long-list sort, loss, record sums, per-Gaussian backward: a handful of waves per SIMD in
+    dependent chains, a fifth of the chip's issue slots.  Batch-per-stream scheduling (``ViewBatch``) overlaps them only by
+    accident.  Here stream A runs nothing but the composite kernels of all batches, back to back; stream B (high priority, so that
+    its short kernels get wave slots as soon as they are ready) runs everything else, issued in an order that always has the
+    other batch's light work ready beside the running composite:
+
+        B:  bin 0 | bin 1 | .. | loss 0 | loss 1 | .. | per-Gaussian 0 | per-Gaussian 1 | ..
+        A:          fwd 0 | fwd 1 | ..   | records 0 | records 1 | ..
+
+    (events order a batch's own phases across the streams).  The per-Gaussian halves run in batch order on B and share ONE gradient
+    buffer -- batch 0 writes, the others add: bit for bit the sum that the same batches give one after the other on one stream.
+    Engines: ``SkinnedFramesEngine`` objects bound to the same ``grad_flat`` (``rebind_gradients``)."""
+
+    def __init__(self, engines, device):
+        self.engines = list(engines)
+        self.dev = torch.device(device)
+        self.A = torch.cuda.Stream(self.dev)
+        self.B = torch.cuda.Stream(self.dev, priority=-1)
+        self.ev = [[torch.cuda.Event() for _ in range(4)] for _ in self.engines]
+        for e in self.engines:
+            e.throughput = True
+            if e.grad_flat.data_ptr() != self.engines[0].grad_flat.data_ptr():
+                raise ValueError("FramePipeline: every engine must be bound to the same gradient buffer (rebind_gradients)")
+
+    def run(self, prepare, forward_args, loss):
+        """``prepare(b, engine)``: set the batch's frames (runs on B); ``forward_args`` = (shs, opacities, scales);
+        ``loss(b, engine)`` -> dL_dcolor [K,3,H,W] (runs on B, after the batch's composite)."""
+        cur = torch.cuda.current_stream(self.dev)
+        A, B, ev = self.A, self.B, self.ev
+        A.wait_stream(cur); B.wait_stream(cur)
+        for b, e in enumerate(self.engines):
+            with torch.cuda.stream(B):
+                prepare(b, e)
+                e.forward(*forward_args, phase="binning")
+                ev[b][0].record(B)
+            with torch.cuda.stream(A):
+                A.wait_event(ev[b][0])
+                e.forward(*forward_args, phase="composite")
+                ev[b][1].record(A)
+        grads = []
+        for b, e in enumerate(self.engines):
+            with torch.cuda.stream(B):
+                B.wait_event(ev[b][1])
+                grads.append(loss(b, e))
+                ev[b][2].record(B)
+            with torch.cuda.stream(A):
+                A.wait_event(ev[b][2])
+                e.backward_records(grads[b])
+                ev[b][3].record(A)
+        for b, e in enumerate(self.engines):
+            with torch.cuda.stream(B):
+                B.wait_event(ev[b][3])
+                e.backward_gaussians(*forward_args, accumulate=b > 0)
+        cur.wait_stream(A); cur.wait_stream(B)

@@ -191,3 +191,56 @@ def test_forced_one_rank_group_issues_every_collective():
     assert p.exitcode == 0
     assert res == {"all_reduce": (True, True, True), "rs_ag": (True, True, True)}
     assert calls["all_reduce"] >= 6 and calls["reduce_scatter_tensor"] >= 5 and calls["all_gather_into_tensor"] >= 5
+
+
+def _packed_worker(rank, world, port, algorithm, out):
+    """The frame-parallel collective over the PREFIX of the gradient rows that carries gradient (engines with sh_planar: the SH
+    planes not in use stay zero behind it) against the same sum over the full rows in the reference's [P,16,3] layout."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, M, deg, k = 517, 16, 0, 3
+        nc = (deg + 1) ** 2
+        g = torch.Generator().manual_seed(7 + rank)
+        head = torch.randn((k, P * 7), generator=g) * torch.logspace(-3, 3, P * 7)       # xyz 3, scales 3, opacity 1
+        sh_used = torch.randn((k, nc, P, 3), generator=g)                                 # the planes in use
+        # reference layout: [head | sh as [P, M, 3]] -- 45 of the 55 floats per Gaussian are zero
+        sh_rows = torch.zeros((k, P, M, 3)); sh_rows[:, :, :nc, :] = sh_used.permute(0, 2, 1, 3)
+        full = torch.cat([head, sh_rows.reshape(k, -1)], 1).contiguous()
+        # planar layout: [head | sh as [M, P, 3]]: the gradient is the prefix
+        sh_planes = torch.zeros((k, M, P, 3)); sh_planes[:, :nc] = sh_used
+        packed = torch.cat([head, sh_planes.reshape(k, -1)], 1).contiguous()
+        active = P * 7 + nc * P * 3
+        fp = FrameParallel(algorithm=algorithm)
+        ref = GradientPipeline(full, fp, chunks=4).reduce().clone()
+        pipe = GradientPipeline(packed, fp, chunks=4, active=active)
+        got = pipe.reduce().clone()
+        out.put((rank, ref.numpy(), got.numpy(), active, P, M, nc))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_packed_gradient_prefix_equals_the_full_row_sum_world2():
+    """only the floats that carry gradient are folded and all-reduced (avatar: 10 of 55 per Gaussian).  World
+    size 2 over gloo, both schedules: the reduced prefix equals, bit for bit, the corresponding elements of the full-row sum in
+    the reference's layout, and everything behind the prefix is zero."""
+    for algorithm in ("all_reduce", "rs_ag"):
+        world = 2
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_packed_worker, args=(r, world, port, algorithm, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(60)
+            assert p.exitcode == 0
+        for rank, ref, got, active, P, M, nc in res:
+            assert active == P * 10 and got.shape == ref.shape
+            assert np.array_equal(got[:P * 7], ref[:P * 7])
+            ref_sh = ref[P * 7:].reshape(P, M, 3)
+            got_sh = got[P * 7:].reshape(M, P, 3)
+            assert np.array_equal(got_sh[:nc].transpose(1, 0, 2), ref_sh[:, :nc])
+            assert not got[active:].any() and not ref_sh[:, nc:].any()
+        assert np.array_equal(res[0][2], res[1][2])

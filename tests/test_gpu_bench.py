@@ -96,7 +96,11 @@ def test_rccl_branches_run_with_one_rank_avatar_and_train():
     ref = _line(_bench("--workload", "avatar", "--grad-hash", *small))
     j = _line(_bench("--workload", "avatar", "--grad-hash", *small, env=env))
     assert j["dist_backend"] == "nccl" and j["rccl_world"] == 1 and j["allreduce_ms"] > 0
-    assert j["allreduce_bytes"] == 20000 * 55 * 4 and j["grad_sha256"] == ref["grad_sha256"]
+    # SH gradients coefficient-major: of the 55 gradient floats per Gaussian the 10 that carry gradient at sh_degree 0 are all-reduced
+    assert j["allreduce_bytes"] == 20000 * 10 * 4 and j["grad_sha256"] == ref["grad_sha256"]
+    assert j["gradient_floats_per_gaussian"] == dict(j["gradient_floats_per_gaussian"], buffer=55, carrying_gradient=10)
+    m = j["scaling_model"]
+    assert m["collective_bytes"] == 20000 * 10 * 4 and "MODEL" in m["label"] and 0 < m["predicted_scale_8"]["one_view_per_step"]["rs_ag"] <= 8
     assert j["repeats"] >= 2 and j["roofline"]["dominant_kernel"].startswith("sg_") and j["train_step_ms_one_view"] > 0
     ref = _line(_bench("--workload", "train", *small))
     assert ref["allreduce_ms"] is None and ref["rccl_world"] is None

@@ -202,3 +202,46 @@ def test_frames_api_rejects_bad_batches():
         SkinnedFramesEngine(100, 24, 64, 64, 16, 17, dev, 4096)
     with pytest.raises(ValueError):
         SkinnedFramesEngine(100, 24, 64, 64, 16, 0, dev, 4096)
+
+
+@pytest.mark.parametrize("K", [1, 4])
+def test_planar_sh_gradients_are_the_reference_layout_transposed(K):
+    """SG_FLAG_SH_PLANAR (``sh_planar=True``): dL/dsh coefficient-major [M,P,3], only the (sh_degree+1)^2 planes in use written --
+    the gradient of a step is the prefix ``grad_flat[:active_floats(deg)]`` (10 of 55 floats per Gaussian at degree 0).  Every
+    gradient equals the default layout's, bit for bit (the planes in use = the rows in use transposed; the rest of the SH block
+    is never touched), for the single-frame kernel, the K-frame kernel and their accumulate variants."""
+    from sings_amd.engine import SkinnedEngine, SkinnedFramesEngine
+    dev = _dev()
+    N, J, W, H = 9000, 24, 128, 224
+    s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 9, K, False, False)
+    cap = 24 * N
+
+    def run(planar, accumulate):
+        if K == 1:
+            e = SkinnedEngine(N, J, W, H, 16, dev, cap, sh_planar=planar); e.throughput = True
+            e.set_camera(one[0]); e.set_frame(ins["xyz"], None, ins["w"], A[0], ins["smpl_scale"], transl[0])
+            e.grad_flat.fill_(0.25 if accumulate else 0.0)
+            if planar and accumulate:
+                e.d_sh[1:].zero_()                                   # (planes not in use: never written, must come zeroed)
+            e.forward(ins["sh"], ins["op"], ins["sc"])
+            e._chain = lambda: (accumulate, None, None)
+            e.backward(ins["sh"], ins["op"], ins["sc"], dL[0])
+        else:
+            e = SkinnedFramesEngine(N, J, W, H, 16, K, dev, cap, sh_planar=planar)
+            e.set_camera(one[0]); e.set_frames(ins["xyz"], None, ins["w"], A, ins["smpl_scale"], transl)
+            e.grad_flat.fill_(0.25 if accumulate else 0.0)
+            if planar and accumulate:
+                e.d_sh[1:].zero_()
+            e.forward(ins["sh"], ins["op"], ins["sc"])
+            e.backward(ins["sh"], ins["op"], ins["sc"], dL, accumulate=accumulate)
+        torch.cuda.synchronize()
+        return e
+
+    for accumulate in (False, True):
+        a, b = run(False, accumulate), run(True, accumulate)
+        assert b.active_floats(0) == N * 10 and a.active_floats(0) == N * 55
+        assert torch.equal(a.d_xyz, b.d_xyz) and torch.equal(a.d_scales, b.d_scales) and torch.equal(a.d_opacity, b.d_opacity)
+        assert torch.equal(a.d_sh[:, 0, :], b.d_sh[0]) and float(b.d_sh[0].abs().max()) > 0
+        assert not bool(b.d_sh[1:].any())                            # never touched
+        assert torch.equal(b.grad_flat[:N * 7], a.grad_flat[:N * 7])
+        assert not bool(b.grad_flat[b.active_floats(0):].any())
