@@ -82,15 +82,157 @@ void sg_launch_preprocess_fwd(const SgCam &c, const SgBatch &bt, int P, const fl
 // ------------------------------------------------------------------------------------------
 // ACC: add to the gradient outputs instead of writing them (a compile-time switch: as a runtime flag the untaken branches cost
 // the plain kernel 3.8 us of its 33 -- same-box A/B)
+template <int D, bool ACC>
+__global__ void __launch_bounds__(256)
+sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
+                         const float *__restrict__ colors_precomp, const float *__restrict__ scales,
+                         const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
+                         const int32_t *__restrict__ radii, SgGeom g, SgRec grec,
+                         size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
+                         float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
+                         float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
+{
+    constexpr bool accumulate = ACC;
+    __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g0 = idx - lane;
+    if (g0 >= P) return;                                    // whole wave out of range
+    float *L = lds_all[wave];
+    const bool live = idx < P;
+    SgGaussGrad G;
+#pragma unroll
+    for (int k = 0; k < 3; k++) { G.dmean[k] = 0; G.dcol[k] = 0; G.dsc[k] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) G.drot[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) G.g6[k] = 0;
+    G.g2[0] = G.g2[1] = 0; G.dop = 0;
+    // after a forward that overflowed (header[1] != 0) the backward composite wrote no records: every gradient is ZERO, the
+    // stale contents of the record buffer are never summed (asynchronous overflow check: rasterizer.py)
+    const bool vis = live && radii[idx] > 0 && header[1] == 0u;
+    const int Mrows = c.M;
+    constexpr int nc = (D + 1) * (D + 1);
+    const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
+    // 0. issue every load that does not depend on another one up front (one memory round trip, not four)
+    float4 rc = make_float4(0, 0, 0, 0);
+    float p[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 }, sh[nc * 3], dsh[nc * 3];
+    uint32_t flags = 0;
+#pragma unroll
+    for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
+    if (vis) {
+        { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
+        flags = g.flags[idx];
+        p[0] = means3D[3 * idx]; p[1] = means3D[3 * idx + 1]; p[2] = means3D[3 * idx + 2];
+        if (!cov3D_precomp) {
+            s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
+            q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
+        }
+        if (shs) {
+            const float *src = shs + (size_t)idx * Mrows * 3;
+            if (staged) {
+#pragma unroll
+                for (int k = 0; k < nc * 3 / 4; k++) {
+                    float4 v = ((const float4 *)src)[k];
+                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+            }
+        }
+    }
+    // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
+    float a9[9];
+    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+    // 2. the chain rule
+    if (vis)
+        sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
+                          dL_dsh != nullptr, dsh, G);
+    // 3. dL/dsh out: coefficient-major planes [M][P][3], only the (D+1)^2 in use (SG_FLAG_SH_PLANAR); or the reference's rows
+    //    (every one of the M rows is written; coalesced through LDS when staged)
+    if (dL_dsh && (c.flags & SG_FLAG_SH_PLANAR)) {
+        if (live) {
+#pragma unroll
+            for (int kq = 0; kq < nc; kq++)
+#pragma unroll
+                for (int ch = 0; ch < 3; ch++) {
+                    float *d = dL_dsh + ((size_t)kq * P + idx) * 3 + ch;
+                    *d = accumulate ? dsh[3 * kq + ch] + *d : dsh[3 * kq + ch];
+                }
+        }
+    } else if (dL_dsh) {
+        if (staged) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                    // 32 rows at a time (keeps LDS at 6.5 KiB per wave)
+                if ((lane >> 5) == h) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++)
+                        *(float4 *)(L + (lane & 31) * SG_ROW_LDS + 4 * k) = make_float4(dsh[4 * k], dsh[4 * k + 1], dsh[4 * k + 2], dsh[4 * k + 3]);
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, accumulate != 0);
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else if (live) {
+            float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
+            if (accumulate) {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) dsh_row[k] += dsh[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
+                for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
+            }
+        }
+    }
+    if (!live) return;
+    // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
+    dL_dmeans2D[3 * idx] = G.g2[0]; dL_dmeans2D[3 * idx + 1] = G.g2[1]; dL_dmeans2D[3 * idx + 2] = 0.0f;
+    if (accumulate) {
+        // the views of one optimisation step share ONE gradient buffer: this view adds to what the views in front of it in the
+        // step's chain left there (the old values are requested together, here: one more memory round trip per wave)
+        float o3[3], os[3], orr[4], oc[3], og[6], oo;
+#pragma unroll
+        for (int k = 0; k < 3; k++) o3[k] = dL_dmeans3D[3 * idx + k];
+        oo = dL_dopacity[idx];
+#pragma unroll
+        for (int k = 0; k < 3; k++) { oc[k] = dL_dcolors ? dL_dcolors[3 * idx + k] : 0.0f; os[k] = dL_dscales ? dL_dscales[3 * idx + k] : 0.0f; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) orr[k] = dL_drots ? dL_drots[4 * idx + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; k++) og[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { G.dmean[k] += o3[k]; G.dcol[k] += oc[k]; G.dsc[k] += os[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; k++) G.drot[k] += orr[k];
+#pragma unroll
+        for (int k = 0; k < 6; k++) G.g6[k] += og[k];
+        G.dop += oo;
+    }
+    dL_dmeans3D[3 * idx] = G.dmean[0]; dL_dmeans3D[3 * idx + 1] = G.dmean[1]; dL_dmeans3D[3 * idx + 2] = G.dmean[2];
+    dL_dopacity[idx] = G.dop;
+    if (dL_dcolors) { dL_dcolors[3 * idx] = G.dcol[0]; dL_dcolors[3 * idx + 1] = G.dcol[1]; dL_dcolors[3 * idx + 2] = G.dcol[2]; }
+    if (dL_dscales) { dL_dscales[3 * idx] = G.dsc[0]; dL_dscales[3 * idx + 1] = G.dsc[1]; dL_dscales[3 * idx + 2] = G.dsc[2]; }
+    if (dL_drots) { dL_drots[4 * idx] = G.drot[0]; dL_drots[4 * idx + 1] = G.drot[1]; dL_drots[4 * idx + 2] = G.drot[2]; dL_drots[4 * idx + 3] = G.drot[3]; }
+    if (dL_dcov3D) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) dL_dcov3D[6 * idx + k] = G.g6[k];
+    }
+}
+
+// ---- K cameras per launch (round 4) -------------------------------------------------------------------------------------------
 // K cameras (bt.K frames) of the SAME Gaussians: the kernel walks the frames -- records of frame f, chain rule with camera f -- and
 // sums the K gradients of a Gaussian in registers, in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K
 // single-camera calls leave behind when the first writes the gradient buffer and the others run with accumulate = 1), then writes
 // the 248-byte gradient row ONCE: K - 1 read-modify-write passes over the buffer less (at cfg3 2 x 47 MB per view), and the
 // Gaussian's inputs (236 B) are read once for the K cameras.  dL_dmeans2D (the densifier's per-view statistic) is per frame.
-// ONE: bt.K == 1 known at compile time (the single-camera entry points): no loop, the round-3 kernel.
-template <int D, bool ACC, bool ONE>
+template <int D, bool ACC>
 __global__ void __launch_bounds__(256)
-sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
+sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                          const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0,
@@ -107,7 +249,7 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
     if (g0 >= P) return;                                    // whole wave out of range
     const bool live = idx < P;
     const int Mrows = c0.M;
-    const int nframes = ONE ? 1 : bt.K;
+    const int nframes = bt.K;
     constexpr int nc = (D + 1) * (D + 1);
     const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
     // the Gaussian's inputs: read ONCE for all frames (a Gaussian that no frame sees loads nothing)
@@ -155,7 +297,7 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
     A.g2[0] = A.g2[1] = 0; A.dop = 0;
     // K > 1 and accumulate: the sums START from what the gradient buffer holds (read once, here), so that the K frames are added
     // in the order K single-camera calls with accumulate = 1 would add them: ((old + g0) + g1) + ...
-    constexpr bool preload = ACC && !ONE;
+    constexpr bool preload = ACC;
     if (preload && live) {
 #pragma unroll
         for (int k = 0; k < 3; k++) A.dmean[k] = dL_dmeans3D[3 * idx + k];
@@ -178,7 +320,7 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
         // (opaque per trip: keeps hipcc from hoisting what depends on them only -- LDS addresses, shuffle indices, the per-frame
         //  arrays' addresses -- in front of the loop, where it would stay live across it: see sg_skin_bwd_kernel)
         int idx = idx_all, lane = lane_all, wave = wave_all;
-        if (!ONE) asm volatile("" : "+v"(idx), "+v"(lane), "+v"(wave));
+        asm volatile("" : "+v"(idx), "+v"(lane), "+v"(wave));
         float *L = lds_all[wave];
         const SgCam c = sg_frame(c0, f, bt.cam_stride);
         const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
@@ -239,7 +381,7 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
 #pragma unroll
                 for (int ch = 0; ch < 3; ch++) {
                     float *d = dL_dsh + ((size_t)kq * P + idx) * 3 + ch;
-                    *d = (accumulate && ONE) ? dsh[3 * kq + ch] + *d : dsh[3 * kq + ch];
+                    *d = dsh[3 * kq + ch];               // (accumulate: dsh already holds old + frames)
                 }
         }
     } else if (dL_dsh) {
@@ -253,16 +395,13 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
-                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, accumulate && ONE);     // (K > 1: dsh already holds old + frames)
+                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, false);     // (accumulate: dsh already holds old + frames)
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (live) {
             float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
-            if (accumulate && ONE) {
-#pragma unroll
-                for (int k = 0; k < nc * 3; k++) dsh_row[k] += dsh[k];
-            } else if (accumulate) {
+            if (accumulate) {
 #pragma unroll
                 for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
             } else {
@@ -273,27 +412,6 @@ sg_preprocess_bwd_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ 
         }
     }
     if (!live) return;
-    if (accumulate && ONE) {
-        // the batches of one optimisation step share ONE gradient buffer: this batch adds to what the batches in front of it in
-        // the step's chain left there (the old values are requested together, here: one more memory round trip per wave)
-        float o3[3], os[3], orr[4], oc[3], og[6], oo;
-#pragma unroll
-        for (int k = 0; k < 3; k++) o3[k] = dL_dmeans3D[3 * idx + k];
-        oo = dL_dopacity[idx];
-#pragma unroll
-        for (int k = 0; k < 3; k++) { oc[k] = dL_dcolors ? dL_dcolors[3 * idx + k] : 0.0f; os[k] = dL_dscales ? dL_dscales[3 * idx + k] : 0.0f; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) orr[k] = dL_drots ? dL_drots[4 * idx + k] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 6; k++) og[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
-#pragma unroll
-        for (int k = 0; k < 3; k++) { G.dmean[k] += o3[k]; G.dcol[k] += oc[k]; G.dsc[k] += os[k]; }
-#pragma unroll
-        for (int k = 0; k < 4; k++) G.drot[k] += orr[k];
-#pragma unroll
-        for (int k = 0; k < 6; k++) G.g6[k] += og[k];
-        G.dop += oo;
-    }
     dL_dmeans3D[3 * idx] = G.dmean[0]; dL_dmeans3D[3 * idx + 1] = G.dmean[1]; dL_dmeans3D[3 * idx + 2] = G.dmean[2];
     dL_dopacity[idx] = G.dop;
     if (dL_dcolors) { dL_dcolors[3 * idx] = G.dcol[0]; dL_dcolors[3 * idx + 1] = G.dcol[1]; dL_dcolors[3 * idx + 2] = G.dcol[2]; }
@@ -316,11 +434,15 @@ void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const fl
     (void)opacities;
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
-#define SG_PB3(DD, AA, OO) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA, OO>), grid, block, 0, st, c, bt, P, means3D, shs, \
+#define SG_PB1(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
                                      grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
-#define SG_PB2(DD, AA) do { if (bt.K == 1) SG_PB3(DD, AA, true); else SG_PB3(DD, AA, false); } while (0)
+#define SG_PBK(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_frames_kernel<DD, AA>), grid, block, 0, st, c, bt, P, means3D, shs, \
+                                     colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
+                                     grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
+#define SG_PB2(DD, AA) do { if (bt.K == 1) SG_PB1(DD, AA); else SG_PBK(DD, AA); } while (0)      // (K = 1: the round-3 kernel, untouched)
 #define SG_PB(DD) do { if (accumulate) SG_PB2(DD, true); else SG_PB2(DD, false); } while (0)
     int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
@@ -328,5 +450,6 @@ void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const fl
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_PB
 #undef SG_PB2
-#undef SG_PB3
+#undef SG_PB1
+#undef SG_PBK
 }

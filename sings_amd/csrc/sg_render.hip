@@ -168,7 +168,8 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
                       uint32_t *__restrict__ item_w, uint32_t w_plane
 #define SG_FWD_ARGS W, H, gx, T, nblocks, ranges, pair_keys, point_list, point_keys, recA, recB, recC, bg, out_color, final_T, \
                     n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane, plan, item_w, w_plane
-template <bool PIPE>
+// WEIGHTS: leave the backward's work-item weights (few-tile frames: item_w, first_item); always with PIPE
+template <bool PIPE, bool WEIGHTS>
 __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
 {
     __shared__ float4 sR[SG_FB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
@@ -216,7 +217,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     // one plane each (bit `part`)
     uint8_t *__restrict__ pmask = pair_mask + (size_t)(split ? part : 0) * mask_plane;
     const uint32_t cks = n > SG_SEG ? ck_start[tile] : 0xffffffffu;   // segmented list: checkpoint slots cks + segment
-    const uint32_t first_item = (PIPE || w_plane) ? plan[tile].x : 0u;             // first backward work item of this tile
+    const uint32_t first_item = (PIPE || WEIGHTS) ? plan[tile].x : 0u;   // first backward work item of this tile
     float Tr = 1.0f, C0 = 0.0f, C1 = 0.0f, C2 = 0.0f;
     uint32_t last = 0;
     bool done = !inside;
@@ -264,7 +265,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
             const uint32_t gid = point_list[range.x + e + SG_FB];
             pa = recA[SG_REC_STRIDE * (size_t)gid]; pb = recB[SG_REC_STRIDE * (size_t)gid]; pc = recC[SG_REC_STRIDE * (size_t)gid].x;
         }
-        if (PIPE || w_plane) {
+        if (PIPE || WEIGHTS) {
             // few-tile frames: the weight of the backward work item (tile, this segment) = entries composited somewhere; the
             // backward starts its heaviest items first (sg_zero_records_kernel sorts them)
             const int wcount = __syncthreads_count(staged);
@@ -353,27 +354,33 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
     }
 }
 
-// Frame blockIdx.y of a launch of K frames (sg_common.h, SgBatch): the frame's workspaces at base + frame x stride, its image at
-// + frame x 3 H W, its camera-independent inputs unchanged.  K = 1: every offset is 0 -- the single-frame kernel, bit for bit.
-// (gridDim.x is a multiple of 8, so blockIdx.x % 8 is the XCD of a workgroup in every frame: sg_tile_of_block.)
-#define SG_FWD_FRAME_OFFSETS                                                                                            \
-    {                                                                                                                   \
-        const size_t fb = (size_t)blockIdx.y * bt.bin, fg = (size_t)blockIdx.y * bt.geom, fi = (size_t)blockIdx.y * bt.img; \
-        ranges = sg_at(ranges, fb); pair_keys = sg_at(pair_keys, fb); point_list = sg_at(point_list, fb);                \
-        point_keys = sg_at(point_keys, fb); ck_start = sg_at(ck_start, fb); header = sg_at(header, fb);                  \
-        pair_mask = sg_at(pair_mask, fb); tile_count = sg_at(tile_count, fb); long_items = sg_at(long_items, fb);        \
-        plan = sg_at(plan, fb); item_w = sg_at(item_w, fb);                                                              \
-        recA = sg_at(recA, fg); recB = sg_at(recB, fg); recC = sg_at(recC, fg);                                          \
-        final_T = sg_at(final_T, fi); n_contrib = sg_at(n_contrib, fi); ckpt = sg_at(ckpt, fi);                          \
-        out_color += (size_t)blockIdx.y * bt.image;                                                                      \
-    }
 // The plain loop at eight waves per SIMD: frames of many tiles (cfg3: 8 160 tiles, lists of ~100 entries, every SIMD busy).
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
-sg_render_fwd_kernel(SgBatch bt, SG_FWD_PARAMS) { SG_FWD_FRAME_OFFSETS; sg_render_fwd_body<false>(SG_FWD_ARGS); }
-// The pipelined loop: frames of few tiles with lists of thousands of entries (an avatar in front of a background: T <= 4096, the
+sg_render_fwd_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<false, false>(SG_FWD_ARGS); }
+// The pipelined loop: ONE frame of few tiles with lists of thousands of entries (an avatar in front of a background: T <= 4096, the
 // regime of the LDS histogram in the preprocess), where the kernel ends in a handful of deep tiles, one wave per SIMD.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 7)))
-sg_render_fwd_deep_kernel(SgBatch bt, SG_FWD_PARAMS) { SG_FWD_FRAME_OFFSETS; sg_render_fwd_body<true>(SG_FWD_ARGS); }
+sg_render_fwd_deep_kernel(SG_FWD_PARAMS) { sg_render_fwd_body<true, true>(SG_FWD_ARGS); }
+// Frame blockIdx.y of a launch of K frames (sg_common.h, SgBatch): the frame's workspaces at base + frame x stride, its image at
+// + frame x 3 H W.  Also the kernel of few-tile frames that share the chip with other views (SG_FLAG_THROUGHPUT), K = 1 included:
+// every SIMD has other waves to run there, the pipelined walk's extra vector instructions only cost issue slots (344 -> 319 us for
+// the 8 frames of an avatar step, same box).  The single-frame kernels above are the round-3 kernels, untouched: the offsets'
+// scalar registers and the weight branch cost the cfg3 forward 1.9 of its 71 us (same-box A/B against the round-3 tree).
+// (gridDim.x is a multiple of 8, so blockIdx.x % 8 is the XCD of a workgroup in every frame: sg_tile_of_block.)
+template <bool WEIGHTS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
+sg_render_fwd_frames_kernel(SgBatch bt, SG_FWD_PARAMS)
+{
+    const size_t fb = (size_t)blockIdx.y * bt.bin, fg = (size_t)blockIdx.y * bt.geom, fi = (size_t)blockIdx.y * bt.img;
+    ranges = sg_at(ranges, fb); pair_keys = sg_at(pair_keys, fb); point_list = sg_at(point_list, fb);
+    point_keys = sg_at(point_keys, fb); ck_start = sg_at(ck_start, fb); header = sg_at(header, fb);
+    pair_mask = sg_at(pair_mask, fb); tile_count = sg_at(tile_count, fb); long_items = sg_at(long_items, fb);
+    plan = sg_at(plan, fb); item_w = sg_at(item_w, fb);
+    recA = sg_at(recA, fg); recB = sg_at(recB, fg); recC = sg_at(recC, fg);
+    final_T = sg_at(final_T, fi); n_contrib = sg_at(n_contrib, fi); ckpt = sg_at(ckpt, fi);
+    out_color += (size_t)blockIdx.y * bt.image;
+    sg_render_fwd_body<false, WEIGHTS>(SG_FWD_ARGS);
+}
 
 static inline int sg_render_blocks(int T) { return ((T + 8 * SG_XCD_RUN - 1) / (8 * SG_XCD_RUN)) * (8 * SG_XCD_RUN); }
 
@@ -384,29 +391,25 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
     const int T = c.gx * c.gy;
     const int grid = sg_render_blocks(T);
     const unsigned K = (unsigned)bt.K;
+    const bool few = sg_lds_hist(c.gx, c.gy);
+    uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
+#define SG_RF_ARGS(NB) c.W, c.H, c.gx, T, NB, b.ranges, b.pair_keys, b.point_list, pk, g.recA, g.recB, g.recC, c.bg, out_color,     \
+                       im.final_T, im.n_contrib, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,       \
+                       (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap)
     sg_prof_begin(SG_K_RENDER_FWD, st);
-    // Few-tile frames (an avatar), two regimes.  One frame alone: the deep kernel -- pipelined list walk, long tiles split over four
-    // workgroups -- because the kernel then ENDS in a few deep tiles walked by single waves.  Several frames sharing the chip
-    // (SG_FLAG_THROUGHPUT: K frames per launch, or views on several streams): every SIMD has other waves to run, the pipelined walk's
-    // extra vector instructions only cost issue slots -- the plain loop at eight waves per SIMD is 7 % faster there (344 -> 319 us for
-    // the 8 frames of an avatar step, same box; it also leaves the backward's work-item weights: w_plane != 0).
-    if (sg_lds_hist(c.gx, c.gy) && !(c.flags & SG_FLAG_THROUGHPUT)) {
-        // upper bound: quadrants 1..3 of every long tile (most blocks exit at once); none in throughput mode.  (Rounded up to a
-        // multiple of 24: whole tiles, and gridDim.x stays a multiple of 8 -- the XCD of a block is blockIdx.x % 8 in every frame.)
-        const int extra = sg_split_long(c.gx, c.gy, c.flags) ? ((3 * (int)sg_sort_items_cap(T, cap) + 23) / 24) * 24 : 0;
-        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, extra, b.ranges,
-                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
-                           c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
-                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap));
+    if (K > 1 || (few && (c.flags & SG_FLAG_THROUGHPUT))) {
+        // K frames per launch, or a few-tile frame that shares the chip with other views: the plain loop (see the kernel)
+        if (few) hipLaunchKernelGGL(sg_render_fwd_frames_kernel<true>, dim3(grid, K), dim3(256), 0, st, bt, SG_RF_ARGS(grid));
+        else hipLaunchKernelGGL(sg_render_fwd_frames_kernel<false>, dim3(grid, K), dim3(256), 0, st, bt, SG_RF_ARGS(grid));
+    } else if (few) {
+        // ONE few-tile frame alone on the chip: the deep kernel.  Upper bound of its extra blocks: quadrants 1..3 of every long
+        // tile (most exit at once)
+        const int extra = sg_split_long(c.gx, c.gy, c.flags) ? 3 * (int)sg_sort_items_cap(T, cap) : 0;
+        hipLaunchKernelGGL(sg_render_fwd_deep_kernel, dim3(extra + grid), dim3(256), 0, st, SG_RF_ARGS(extra));
     } else
-        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
-                           b.pair_keys, b.point_list, write_keys ? b.point_keys : (uint64_t *)nullptr, g.recA, g.recB, g.recC,
-                           c.bg, out_color, im.final_T, im.n_contrib,
-                           b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,
-                           (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w,
-                           sg_lds_hist(c.gx, c.gy) ? sg_items_cap((size_t)T, cap) : 0u);     // (item weights: few-tile frames only)
+        hipLaunchKernelGGL(sg_render_fwd_kernel, dim3(grid), dim3(256), 0, st, SG_RF_ARGS(grid));
     sg_prof_end(SG_K_RENDER_FWD, st);
+#undef SG_RF_ARGS
 }
 
 // ------------------------------------------------------------------------------------------
