@@ -673,7 +673,7 @@ def _meta_status(meta, cfg, root=ROOT):
 # kernels behind one event bracket of the library's profiler (sg_profile_collect): few-tile frames take the deep forward and
 # zero the records + run the sparse backward inside the "sg_render_bwd_kernel" bracket
 KERNEL_VARIANTS = {"sg_render_fwd_kernel": ("sg_render_fwd_kernel", "sg_render_fwd_deep_kernel"),
-                   "sg_render_bwd_kernel": ("sg_render_bwd_kernel", "sg_render_bwd_sparse_kernel", "sg_zero_records_kernel")}
+                   "sg_render_bwd_kernel": ("sg_render_bwd_kernel", "sg_render_bwd_sparse_kernel", "sg_order_items_kernel")}
 
 
 def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):

@@ -68,7 +68,9 @@ typedef struct SgLayout {
     size_t bin_header, bin_tile_count, bin_ranges, bin_cursor, bin_pair_keys, bin_point_list,
         bin_point_keys, bin_pair_gid, bin_pair_tile, bin_pair_local,
         bin_sort_items, bin_rank_items, bin_items,      /* work lists: long-list sort chunks, chunk merges, backward segments */
-        bin_ck_start, bin_plan, bin_pair_mask, bin_item_w, bin_item_perm, bin_bytes;
+        bin_ck_start, bin_plan, bin_pair_mask, bin_item_w, bin_item_perm,
+        bin_rec_valid,          /* [cap] one byte per gradient record (Gaussian-major pair slot): written by the sparse backward */
+        bin_bytes;
     /* image workspace */
     size_t img_final_T, img_n_contrib, img_ckpt, img_bytes;
     /* backward workspace */

@@ -65,6 +65,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_pair_mask = o; o = sg_align(o + 4 * (size_t)sg_mask_plane(cap));     // four planes: sg_split_long
     L->bin_item_w = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);       // backward work-item weights
     L->bin_item_perm = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
+    L->bin_rec_valid = o; o = sg_align(o + cap + 16);                                // one byte per gradient record (few-tile frames)
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);
@@ -379,7 +380,7 @@ extern "C" int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s,
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
     sg_launch_preprocess_bwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
-                             sg_rec_view(bwd_ws, cap), cap, b.header, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
+                             sg_rec_view(bwd_ws, cap), cap, b.header, sg_lds_hist(c.gx, c.gy) ? b.rec_valid : nullptr, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                              cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, accumulate, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);
@@ -469,7 +470,8 @@ extern "C" int sg_skinned_backward_gaussians_frames(const SgRasterSettings *s, c
     if (sg_make_batch(fb, P, c, L, cap, &bt)) return sg_fail("sg_skinned_backward_gaussians: bad frame batch", hipSuccess);
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
-    sg_launch_skin_bwd(c, bt, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, dL_dposed_xyz_in, dL_dposed_rotq_in,
+    sg_launch_skin_bwd(c, bt, P, skin, shs, scales, radii, g, sg_rec_view(bwd_ws, cap), cap, b.header, sg_lds_hist(c.gx, c.gy) ? b.rec_valid : nullptr,
+                       dL_dposed_xyz_in, dL_dposed_rotq_in,
                        skin_ws, dL_dxyz_canon, dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, dL_dA,
                        dL_dtransl, accumulate, st);
     SG_CHECK_LAST("skin_bwd", s, st);

@@ -166,8 +166,9 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
                        uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
                        uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
                        uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap, uint32_t *__restrict__ item_w,
-                       size_t bin_stride, size_t geom_stride)
+                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid)
 {
+    rec_valid = sg_at(rec_valid, (size_t)blockIdx.y * bin_stride);
     {   // frame blockIdx.y
         const size_t off = (size_t)blockIdx.y * bin_stride;
         header = sg_at(header, off); pair_gid = sg_at(pair_gid, off); pair_tile = sg_at(pair_tile, off); pair_local = sg_at(pair_local, off);
@@ -191,6 +192,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
         uint32_t gid = pair_gid[i];
         uint32_t slot = start[pair_tile[i]] + pair_local[i];
         if (slot < cap) pair_keys[slot] = ((uint64_t)__float_as_uint(depth[gid]) << 32) | gid;
+        if (rec_valid) rec_valid[i] = 0;                    // pair i IS gradient-record slot i (Gaussian-major): nothing written yet
     }
 }
 
@@ -211,8 +213,9 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
                        uint32_t *__restrict__ items, uint32_t *__restrict__ item_w, int short_lists, unsigned long long *signal,
-                       size_t bin_stride, size_t geom_stride)
+                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid)
 {
+    rec_valid = sg_at(rec_valid, (size_t)blockIdx.y * bin_stride);
     constexpr int NQ = SG_SCAN_NQ;
     extern __shared__ uint32_t sStart[];                     // [T] counts, then exclusive pair prefix
     {   // frame blockIdx.y of the launch: its binning workspace and depth array (K = 1: offsets 0)
@@ -314,6 +317,10 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
         const uint32_t gid = pair_gid[i];
         const uint32_t slot = sStart[pair_tile[i]] + pair_local[i];
         if (slot < cap) pair_keys[slot] = ((uint64_t)__float_as_uint(depth[gid]) << 32) | gid;
+        // pair i IS gradient-record slot i (the preprocess reserves both Gaussian-major): few-tile frames mark the records the
+        // sparse backward composite writes; here, one lane per pair anyway, every mark is cleared -- instead of a kernel that
+        // streams 36 B of zeros per pair in front of every backward (round 3: 27 MB, 10 us per avatar frame)
+        if (rec_valid) rec_valid[i] = 0;
     }
 }
 
@@ -712,7 +719,8 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid, K), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
-                           b.rank_items, b.items, b.item_w, short_lists, c.count_signal, bt.bin, bt.geom);
+                           b.rank_items, b.items, b.item_w, short_lists, c.count_signal, bt.bin, bt.geom,
+                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -727,7 +735,8 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
         hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid, K), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
                            b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
-                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w, bt.bin, bt.geom);
+                           sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w, bt.bin, bt.geom,
+                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr);
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none

@@ -87,7 +87,10 @@ struct SgBin {
     uint8_t *pair_mask;    // [cap] per sorted list entry: quadrants the forward composited it in (0 if it never staged it)
     uint32_t *item_w;      // [items_cap] weight of a backward work item: the scatter zeroes it, the few-tile forward sets it to the entries
                            //             of the segment it composited somewhere (split tiles: the largest of the four quadrants)
-    uint32_t *item_perm;   // [items_cap]    ... and the work items by descending weight (sg_zero_records_kernel)
+    uint32_t *item_perm;   // [items_cap]    ... and the work items by descending weight (sg_order_items_kernel)
+    uint8_t *rec_valid;    // [cap] few-tile frames: 1 = the sparse backward composite wrote the gradient record of this Gaussian-major
+                           //       pair slot; zeroed by the forward's scatter (one lane per pair anyway).  Readers skip the others:
+                           //       the 36-B records themselves are never zeroed (round 3 streamed 27 MB of zeros per avatar frame)
 };
 
 struct SgImg {
@@ -133,6 +136,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
     g.item_w = (uint32_t *)(b + L.bin_item_w); g.item_perm = (uint32_t *)(b + L.bin_item_perm);
+    g.rec_valid = (uint8_t *)(b + L.bin_rec_valid);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
@@ -191,6 +195,7 @@ __host__ __device__ __forceinline__ SgBin sg_frame(SgBin b, size_t off)
     b.pair_local = sg_at(b.pair_local, off); b.sort_items = sg_at(b.sort_items, off); b.rank_items = sg_at(b.rank_items, off);
     b.items = sg_at(b.items, off); b.ck_start = sg_at(b.ck_start, off); b.plan = sg_at(b.plan, off);
     b.pair_mask = sg_at(b.pair_mask, off); b.item_w = sg_at(b.item_w, off); b.item_perm = sg_at(b.item_perm, off);
+    b.rec_valid = sg_at(b.rec_valid, off);
     return b;
 }
 __host__ __device__ __forceinline__ SgImg sg_frame(SgImg i, size_t off)
@@ -231,7 +236,7 @@ void sg_launch_render_bwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
 void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
+                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st);
@@ -300,7 +305,7 @@ void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, con
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
                               size_t gt_stride, size_t mask_stride, hipStream_t st);
 void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const float *dposed_xyz_in,
-                        const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
+                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
+                        const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, int accumulate, hipStream_t st);

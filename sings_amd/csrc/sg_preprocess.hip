@@ -88,7 +88,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                          const int32_t *__restrict__ radii, SgGeom g, SgRec grec,
-                         size_t cap, const uint32_t *__restrict__ header, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         size_t cap, const uint32_t *__restrict__ header, const uint8_t *__restrict__ rec_valid, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
@@ -145,7 +145,7 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
     }
     // 1. this Gaussian's gradient records (wave-cooperative, coalesced)
     float a9[9];
-    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+    sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9, rec_valid);
     // 2. the chain rule
     if (vis)
         sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
@@ -236,7 +236,7 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
                          const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0,
-                         size_t cap, const uint32_t *__restrict__ header0, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         size_t cap, const uint32_t *__restrict__ header0, const uint8_t *__restrict__ rec_valid, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
@@ -346,7 +346,7 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
         }
         // 1. this Gaussian's gradient records of frame f (wave-cooperative, coalesced)
         float a9[9];
-        sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9);
+        sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9, sg_at(rec_valid, (size_t)f * bt.bin));
         // 2. the chain rule; dL/dsh rows: frame 0 assigns, later frames add (`first`)
         if (vis)
             sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
@@ -426,7 +426,7 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
 void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
-                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
+                              const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
                               float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st)
@@ -436,11 +436,11 @@ void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const fl
     dim3 grid((P + 255) / 256), block(256);
 #define SG_PB1(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
-                                     grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     grec, cap, header, rec_valid, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
 #define SG_PBK(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_frames_kernel<DD, AA>), grid, block, 0, st, c, bt, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
-                                     grec, cap, header, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     grec, cap, header, rec_valid, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
 #define SG_PB2(DD, AA) do { if (bt.K == 1) SG_PB1(DD, AA); else SG_PBK(DD, AA); } while (0)      // (K = 1: the round-3 kernel, untouched)
 #define SG_PB(DD) do { if (accumulate) SG_PB2(DD, true); else SG_PB2(DD, false); } while (0)

@@ -311,8 +311,23 @@ __device__ __forceinline__ void sg_sum_records(SgRec grec, size_t cap, float4 re
 // order), so the wave streams them with 16-B-per-lane loads into LDS (chunks of SG_REC_CHUNK records)
 // and every lane then sums its own records from LDS in the same fixed order.  `l` >= SG_REC_CHUNK*12 floats.
 #define SG_REC_CHUNK 128
+// `valid` (few-tile frames; nullptr = every record was written): one byte per record, 1 = the sparse backward composite wrote it.
+// Records whose byte is 0 are NOT loaded -- they enter the sums as the zeros the round-3 kernel stored there (still added: x + 0
+// keeps the bits of every x the sums can hold, so the result is the one of the zero-filled buffer).  Lane L holds the bytes of
+// records L and L + 64 of the chunk as two bits; the bits of the NEXT chunk are fetched beside the records of this one.
+__device__ __forceinline__ uint32_t sg_valid_bits(const uint8_t *__restrict__ valid, uint32_t c0, uint32_t whi, int lane)
+{
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const uint32_t r = c0 + (uint32_t)lane + 64u * i;
+        if (r < whi) m |= (uint32_t)valid[r] << i;
+    }
+    return m;
+}
 __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool vis, float4 recC,
-                                                    int lane, float *__restrict__ l, float a9[9])
+                                                    int lane, float *__restrict__ l, float a9[9],
+                                                    const uint8_t *__restrict__ valid = nullptr)
 {
     const uint32_t goff = __float_as_uint(recC.y), wh = __float_as_uint(recC.w);
     const uint32_t tt = vis ? (wh & 0xffffu) * (wh >> 16) : 0u;
@@ -327,10 +342,44 @@ __device__ __forceinline__ void sg_sum_records_coop(SgRec grec, size_t cap, bool
     for (int i = 0; i < 9; i++) a9[i] = 0.0f;
     if (whi <= wlo) return;                               // wave-uniform: nothing visible
     if ((size_t)whi > cap) whi = (uint32_t)cap;
+    static_assert(SG_REC_CHUNK == 128, "sg_valid_bits holds two records per lane");
+    uint32_t vnext = valid ? sg_valid_bits(valid, wlo, whi, lane) : 3u;
     for (uint32_t c0 = wlo; c0 < whi; c0 += SG_REC_CHUNK) {
         const uint32_t n = whi - c0 < SG_REC_CHUNK ? whi - c0 : SG_REC_CHUNK;
         const float4 *src = grec.a + 2 * (size_t)c0;
         const float *srb = grec.b + (size_t)c0;
+        if (valid) {                                      // (wave-uniform)
+            const uint32_t vcur = vnext;
+            if (c0 + SG_REC_CHUNK < whi) vnext = sg_valid_bits(valid, c0 + SG_REC_CHUNK, whi, lane);
+            const float4 z4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 v[SG_REC_CHUNK * 2 / 64];
+            float w[SG_REC_CHUNK / 64];
+            const uint32_t last = 2 * n - 1;
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK * 2 / 64; i++) {
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < last ? f0 : last, r = f >> 1;
+                const uint32_t ok = ((uint32_t)__shfl((int)vcur, (int)(r & 63u), 64) >> (r >> 6)) & 1u;
+                v[i] = z4;
+                if (ok) v[i] = src[f];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK / 64; i++) {
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < n - 1 ? f0 : n - 1;
+                const uint32_t ok = ((uint32_t)__shfl((int)vcur, (int)(f & 63u), 64) >> (f >> 6)) & 1u;
+                w[i] = 0.0f;
+                if (ok) w[i] = srb[f];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK * 2 / 64; i++) {
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < last ? f0 : last;
+                ((float4 *)l)[3 * (f >> 1) + (f & 1u)] = v[i];
+            }
+#pragma unroll
+            for (int i = 0; i < SG_REC_CHUNK / 64; i++) {
+                const uint32_t f0 = (uint32_t)lane + 64u * i, f = f0 < n - 1 ? f0 : n - 1;
+                l[12 * f + 8] = w[i];
+            }
+        } else
         // all four 16-B loads and the two 4-B loads of the chunk are issued before the first one is used (as a loop the compiler
         // emitted load -> wait -> LDS write, ONE request in flight per wave: a memory latency per KiB); indices are clamped instead
         // of tested, so nothing branches around a load, and the surplus lanes rewrite the last element.  In LDS a record keeps

@@ -267,7 +267,7 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         }
         if (PIPE || WEIGHTS) {
             // few-tile frames: the weight of the backward work item (tile, this segment) = entries composited somewhere; the
-            // backward starts its heaviest items first (sg_zero_records_kernel sorts them)
+            // backward starts its heaviest items first (sg_order_items_kernel sorts them)
             const int wcount = __syncthreads_count(staged);
             const uint32_t wi = first_item + (uint32_t)(base / SG_SEG);
             if (tid == 0 && wi < w_plane) {
@@ -645,33 +645,33 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
 //  * 59 % of the list entries of an avatar frame lie behind saturated pixels.  Their work items still ran four batches of
 //    id -> recC gather -> zero record store, because every (tile, Gaussian) record has to exist for the per-Gaussian sums;
 //  * a live item paid the dependent chain id -> recC -> mask -> recA / recB once per 64-entry batch, with 64 of its 256 threads.
-// Here the record buffer is ZEROED first (sg_zero_records_kernel: 36 B x R, ~6 us of streaming stores) and then
+// Here every record starts INVALID (rec_valid: one byte per record, cleared by the forward's scatter -- rounds 3 streamed 36 B of
+// zeros per record in front of every backward instead: 27 MB, 6-10 us per avatar frame) and then
 //  * an item whose segment starts behind the tile's deepest contributor returns at once (two loads per thread);
 //  * an item stages its whole segment -- 256 entries, one per thread -- in ONE round: id and mask byte first, the three record
 //    gathers only for entries the forward composited somewhere (mask != 0); entries with an empty mask are never touched again;
 //  * the four 64-entry sub-batches then run out of LDS: compaction, the passes (SG_BWD_PASS: the same arithmetic, bit for bit),
-//    the fixed-order combine and ONE record store per (tile, Gaussian) whose mask is not empty.
-// Results are identical to the kernel above (same passes in the same order; records that kernel writes as zeros stay zero).
+//    the fixed-order combine and ONE record store per (tile, Gaussian) whose mask is not empty, marked valid.
+// Results are identical to the kernel above (same passes in the same order; records that kernel writes as zeros are the
+// invalid ones, which the per-Gaussian sums take as zeros without loading them: sg_sum_records_coop).
 #define SG_BS 256         // entries staged per item (= SG_SEG)
-// Block 0 also ORDERS the backward work items, heaviest first.  Per-item clocks (round 3): a wave's pass takes ~850 cycles
+// One workgroup per frame ORDERS the backward work items, heaviest first.  Per-item clocks (round 3): a wave's pass takes ~850 cycles
 // whatever else is resident, the heaviest items have ~150 passes per wave (53 us alone), and in list order some of them were
 // dispatched 35-47 us into the kernel -- behind 1500 resident items -- and finished at 115 us while the SIMDs idled (3.1e7
 // VALU instructions in 118 us = 9.4 cycles per instruction).  Weight = entries of the segment the forward composited anywhere
 // (item_w: zeroed by the scatter, written by the forward; a split tile: the largest of its four quadrants); 33 classes,
 // counting sort.  The class of each item is kept in LDS between the two passes and the loads are issued eight at a time:
-// the block has ~4 k items to place while the other blocks stream ~6 us of zeros.
+// the block has ~4 k items to place.
 #define SG_ITEM_CLASSES 33
 __device__ __forceinline__ uint32_t sg_item_class(uint32_t w) { return 32u - (w > 255u ? 32u : (w + 7u) / 8u); }      // 0 = heaviest
 __global__ void __launch_bounds__(256)
-sg_zero_records_kernel(SgBatch bt, const uint32_t *__restrict__ header, float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap,
-                       const uint32_t *__restrict__ item_w, uint32_t *__restrict__ perm)
+sg_order_items_kernel(SgBatch bt, const uint32_t *__restrict__ header, const uint32_t *__restrict__ item_w, uint32_t *__restrict__ perm)
 {
-    {   // frame blockIdx.y
-        const size_t fb = (size_t)blockIdx.y * bt.bin, fr = (size_t)blockIdx.y * bt.rec;
+    {   // frame blockIdx.y (one workgroup per frame)
+        const size_t fb = (size_t)blockIdx.y * bt.bin;
         header = sg_at(header, fb); item_w = sg_at(item_w, fb); perm = sg_at(perm, fb);
-        grec_a = sg_at(grec_a, fr); grec_b = sg_at(grec_b, fr);
     }
-    if (blockIdx.x == 0) {
+    {
         constexpr uint32_t KEEP = 8192u;
         __shared__ uint32_t sCls[SG_ITEM_CLASSES];
         __shared__ uint8_t sOf[KEEP];
@@ -699,13 +699,6 @@ sg_zero_records_kernel(SgBatch bt, const uint32_t *__restrict__ header, float4 *
             perm[atomicAdd(&sCls[cl], 1u)] = i;
         }
     }
-    const uint32_t R = header[1] ? 0u : (header[0] < cap ? header[0] : cap);
-    const uint32_t n4 = 2u * R + (R + 3u) / 4u;                       // float4 stores: plane a, then plane b (16-byte aligned base)
-    const float4 z = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n4; i += gridDim.x * 256u) {
-        if (i < 2u * R) grec_a[i] = z;
-        else ((float4 *)grec_b)[i - 2u * R] = z;
-    }
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6)))
@@ -717,7 +710,7 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
                             float4 *__restrict__ grec_a, float *__restrict__ grec_b, uint32_t cap, const uint32_t *__restrict__ header,
                             const uint32_t *__restrict__ items, const uint32_t *__restrict__ ck_start,
                             const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
-                            int split_long, const uint32_t *__restrict__ perm)
+                            int split_long, const uint32_t *__restrict__ perm, uint8_t *__restrict__ rec_valid)
 {
     __shared__ float4 sR[SG_BS][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
     __shared__ uint32_t sM[SG_BS];
@@ -726,7 +719,7 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
     __shared__ uint32_t smax[4];
     (void)T; (void)nblocks;
     SG_BWD_FRAME_OFFSETS;
-    perm = sg_at(perm, (size_t)blockIdx.y * bt.bin);
+    perm = sg_at(perm, (size_t)blockIdx.y * bt.bin); rec_valid = sg_at(rec_valid, (size_t)blockIdx.y * bt.bin);
     const int nitems = header[1] ? 0 : (int)header[5];
     if ((int)blockIdx.x >= nitems) return;
     const uint32_t pit = perm[blockIdx.x];
@@ -834,6 +827,7 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
             grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s9[2], nh * s9[3]);
             grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s9[4], s9[5], s9[6], s9[7]);
             grec_b[rslot] = s9[8];
+            rec_valid[rslot] = 1;                                  // (every other record of the frame is never read: sg_sum_records_coop)
         }
         __syncthreads();
     }
@@ -849,13 +843,13 @@ void sg_launch_render_bwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
     uint32_t cap32 = cap > 0xffffffffull ? 0xffffffffu : (uint32_t)cap;
     sg_prof_begin(SG_K_RENDER_BWD, st);
     if (sg_lds_hist(c.gx, c.gy)) {
-        // few tiles, long lists: zero the records, then only the entries the forward composited are touched
-        const uint32_t zg = cap32 / 1024u + 1u < 1024u ? cap32 / 1024u + 1u : 1024u;
-        hipLaunchKernelGGL(sg_zero_records_kernel, dim3(zg, K), dim3(256), 0, st, bt, b.header, grec.a, grec.b, cap32, b.item_w, b.item_perm);
+        // few tiles, long lists: order the work items (heaviest first), then only the entries the forward composited are touched --
+        // and only their records are marked valid (rec_valid: cleared by the forward's scatter) and ever read
+        hipLaunchKernelGGL(sg_order_items_kernel, dim3(1, K), dim3(256), 0, st, bt, b.header, b.item_w, b.item_perm);
         hipLaunchKernelGGL(sg_render_bwd_sparse_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
                            b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,
                            grec.a, grec.b, cap32, b.header, b.items, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.pair_mask, sg_mask_plane(cap),
-                           sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0, b.item_perm);
+                           sg_split_long(c.gx, c.gy, c.flags) ? 1 : 0, b.item_perm, b.rec_valid);
     } else
     hipLaunchKernelGGL(sg_render_bwd_kernel, dim3(grid, K), dim3(256), 0, st, bt, c.W, c.H, c.gx, T, grid, b.ranges,
                        b.point_list, g.recA, g.recB, g.recC, c.bg, im.final_T, im.n_contrib, dL_dpix,

@@ -308,7 +308,7 @@ template <int D, bool ACC>
 __global__ void __launch_bounds__(SG_SKIN_THREADS)
 sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
                    const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
-                   const uint32_t *__restrict__ header, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
+                   const uint32_t *__restrict__ header, const uint8_t *__restrict__ rec_valid, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
                    float *__restrict__ dL_dxyz_canon, float *__restrict__ dL_drot_canon,
                    float *__restrict__ dL_dscales, float *__restrict__ dL_dopacity, float *__restrict__ dL_dsh,
                    float *__restrict__ dL_dmeans2D, float *__restrict__ slab, int slab_stride)
@@ -341,7 +341,7 @@ sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, cons
     float a9[9];
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
-    sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9);
+    sg_sum_records_coop(grec, cap, vis, rc, lane, sWw, a9, rec_valid);
     float dsh[nc * 3];
 #pragma unroll
     for (int i = 0; i < nc * 3; i++) dsh[i] = 0.0f;
@@ -558,7 +558,7 @@ __device__ __forceinline__ void sg_skin_T_resident(const float *__restrict__ sW,
 // order of the additions per Gaussian is sg_sum_records_coop's: the same sums, bit for bit.
 __global__ void __launch_bounds__(256)
 sg_record_sums_kernel(SgBatch bt, int P, const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0, size_t cap,
-                      const uint32_t *__restrict__ header0, float4 *__restrict__ a9out)
+                      const uint32_t *__restrict__ header0, const uint8_t *__restrict__ rec_valid, float4 *__restrict__ a9out)
 {
     __shared__ float lds_all[4][SG_REC_CHUNK * 12];
     const int f = blockIdx.y;
@@ -571,7 +571,7 @@ sg_record_sums_kernel(SgBatch bt, int P, const int32_t *__restrict__ radii0, SgG
     float4 rc = make_float4(0, 0, 0, 0);
     if (vis) { const uint2 sl = g.slot[idx]; rc.y = __uint_as_float(sl.x); rc.w = __uint_as_float(sl.y); }
     float a9[9];
-    sg_sum_records_coop(grec, cap, vis, rc, lane, lds_all[wave], a9);
+    sg_sum_records_coop(grec, cap, vis, rc, lane, lds_all[wave], a9, sg_at(rec_valid, (size_t)f * bt.bin));
     if (live) {
         float4 *o = a9out + 3 * ((size_t)f * bt.P + idx);
         o[0] = make_float4(a9[0], a9[1], a9[2], a9[3]); o[1] = make_float4(a9[4], a9[5], a9[6], a9[7]);
@@ -1379,7 +1379,7 @@ size_t sg_skin_slab_floats(int P, int K)
 }
 
 void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
-                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
+                        const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
                         const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,
                         float *dL_dscales, float *dL_dopacity, float *dL_dsh, float *dL_dmeans2D, float *dL_dA,
                         float *dL_dtransl, int accumulate, hipStream_t st)
@@ -1391,7 +1391,7 @@ void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
     const size_t slab_frame = sg_skin_slab_rows(P) * stride;
     dim3 grid(nblocks), block(SG_SKIN_THREADS);
 #define SG_SB1(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, k, shs, scales, radii, g,       \
-                                     grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
+                                     grec, cap, header, rec_valid, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
                                      dL_drot_canon, dL_dscales, dL_dopacity, dL_dsh, dL_dmeans2D, slab, stride)
 #define SG_SBK(DD, AA) hipLaunchKernelGGL((sg_skin_bwd_frames_kernel<DD, AA>), grid, block, dyn, st, c, bt, P, k, shs, scales, radii, g,       \
                                      grec, cap, header, dposed_xyz_in, dposed_rotq_in, dL_dxyz_canon,  \
@@ -1405,7 +1405,7 @@ void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
     const float4 *a9buf = (const float4 *)(slab + (slab_frame + (size_t)SG_RED_GROUPS * stride) * bt.K);
     if (bt.K > 1)
         hipLaunchKernelGGL(sg_record_sums_kernel, dim3((P + 255) / 256, bt.K), dim3(256), 0, st, bt, P, radii, g, grec, cap, header,
-                           (float4 *)a9buf);
+                           rec_valid, (float4 *)a9buf);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
     float *part = slab + slab_frame * bt.K;
     hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4, bt.K), dim3(256), 0, st, slab,
