@@ -20,6 +20,7 @@
 #define SG_LT 32                  // output tile edge
 #define SG_LH (SG_LT + 10)        // with the 5-pixel halo of the 11-tap window
 #define SG_LP (SG_LH + 1)         // LDS row pitch (bank-conflict padding)
+#define SG_LOADS ((SG_LH * SG_LH + 255) / 256)     // halo pixels per thread
 
 struct SgLossArgs {
     int W, H;
@@ -33,6 +34,22 @@ struct SgLossArgs {
 
 __device__ __forceinline__ float sg_clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
+// true for all threads iff every thread's `same` holds and (v0, v1, v2) have the same bits in all 256 threads; contains the
+// workgroup barrier that also publishes the tile the caller has just stored to LDS.
+__device__ __forceinline__ bool sg_tile_is_flat(bool same, float v0, float v1, float v2, uint32_t (*sFlat)[4], int lane, int wave)
+{
+    const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1), b2 = __float_as_uint(v2);
+    const uint32_t f0 = __builtin_amdgcn_readfirstlane(b0), f1 = __builtin_amdgcn_readfirstlane(b1), f2 = __builtin_amdgcn_readfirstlane(b2);
+    const bool w = __all(same && b0 == f0 && b1 == f1 && b2 == f2);
+    if (lane == 0) { sFlat[wave][0] = w ? 1u : 0u; sFlat[wave][1] = f0; sFlat[wave][2] = f1; sFlat[wave][3] = f2; }
+    __syncthreads();
+    bool flat = true;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        flat = flat && sFlat[k][0] != 0u && sFlat[k][1] == sFlat[0][1] && sFlat[k][2] == sFlat[0][2] && sFlat[k][3] == sFlat[0][3];
+    return flat;
+}
+
 // block partial layout: [block][4] = (sum |pred - gt|, sum ssim, sum mask, unused)
 __global__ void __launch_bounds__(256)
 sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__restrict__ gt_rgb,
@@ -42,6 +59,7 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
     __shared__ float sX[SG_LH][SG_LP], sY[SG_LH][SG_LP];
     __shared__ float sH[SG_LH][SG_LT + 1];
     __shared__ float sRed[4][3];
+    __shared__ uint32_t sFlat[4][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
@@ -57,19 +75,34 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
     {   // one (tile, channel) per workgroup: a 512x896 frame is only 448 tiles, fewer than two per CU
         const int ch = blockIdx.z - 3 * frame;
         const float bgc = bg[ch];
-        for (int i = tid; i < SG_LH * SG_LH; i += 256) {
-            const int r = i / SG_LH, c = i - r * SG_LH;
-            const int x = X0 - 5 + c, y = Y0 - 5 + r;
-            float xv = 0.0f, yv = 0.0f;
-            if (x >= 0 && x < a.W && y >= 0 && y < a.H) {
-                const size_t p = (size_t)y * a.W + x;
-                const float m = mask[p];
-                xv = sg_clamp01(raw[ch * hw + p]);
-                yv = gt_rgb[ch * hw + p] * m + bgc * (1.0f - m);
+        // the halo tile: all 3 x SG_LOADS loads of a thread are in flight together (as a rolled loop hipcc emitted load, load, load,
+        // s_waitcnt vmcnt(0) per trip -- seven dependent memory round trips in front of the first barrier of a workgroup whose
+        // arithmetic is ~800 instructions per wave).  Addresses are clamped into the image instead of branched around.
+        bool same = true;
+        float x0 = 0.0f, y0 = 0.0f;
+        {
+            float lx[SG_LOADS], ly[SG_LOADS], lm[SG_LOADS];
+#pragma unroll
+            for (int u = 0; u < SG_LOADS; u++) {
+                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
+                const int x = X0 - 5 + c, y = Y0 - 5 + r;
+                const int xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1), yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1);
+                const size_t p = (size_t)yc * a.W + xc;
+                lm[u] = mask[p]; lx[u] = raw[ch * hw + p]; ly[u] = gt_rgb[ch * hw + p];
             }
-            sX[r][c] = xv; sY[r][c] = yv;
+#pragma unroll
+            for (int u = 0; u < SG_LOADS; u++) {
+                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
+                const int x = X0 - 5 + c, y = Y0 - 5 + r;
+                const bool in = x >= 0 && x < a.W && y >= 0 && y < a.H;
+                const float m = lm[u];
+                const float xv = in ? sg_clamp01(lx[u]) : 0.0f, yv = in ? ly[u] * m + bgc * (1.0f - m) : 0.0f;
+                if (i < SG_LH * SG_LH) { sX[r][c] = xv; sY[r][c] = yv; }
+                if (u == 0) { x0 = xv; y0 = yv; }
+                else if (i < SG_LH * SG_LH) same = same && __float_as_uint(xv) == __float_as_uint(x0) && __float_as_uint(yv) == __float_as_uint(y0);
+            }
         }
-        __syncthreads();
+        const bool flat = sg_tile_is_flat(same, x0, y0, 0.0f, sFlat, lane, wave);        // (holds the barrier behind the LDS stores)
         // Separable window, one quantity at a time through ONE LDS plane (20 KB per workgroup instead of 42 KB: the
         // kernel is latency-bound, resident workgroups are what hides it).  Horizontal pass: an item = 8 consecutive
         // output columns of one halo row, its 18 samples of x and y stay in registers for all five quantities;
@@ -77,12 +110,28 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
         const bool hthread = tid < SG_LH * 4;
         const int hr = tid >> 2, hc0 = (tid & 3) * 8;
         float xs[18], ys[18];
-        if (hthread) {
+        if (hthread && !flat) {
 #pragma unroll
             for (int k = 0; k < 18; k++) { xs[k] = sX[hr][hc0 + k]; ys[k] = sY[hr][hc0 + k]; }
         }
         const int c = tid & 31, r0 = (tid >> 5) * 4;
         float vq[5][4];
+        if (flat) {
+            // every sample of the halo tile has the same bits (background behind the avatar: render = bg, target = bg; or the zero
+            // padding outside the image): each of the 8 x 11 and 4 x 11 FMA chains below would run on the same operands in the same
+            // order, so ONE chain per quantity IS the value of all of them -- no LDS traffic, no barriers, identical bits
+#pragma unroll
+            for (int q = 0; q < 5; q++) {
+                const float v = q == 0 ? x0 : q == 1 ? y0 : q == 2 ? x0 * x0 : q == 3 ? y0 * y0 : x0 * y0;
+                float h = 0.0f, t = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v, h);
+#pragma unroll
+                for (int k = 0; k < 11; k++) t = fmaf(a.w[k], h, t);
+#pragma unroll
+                for (int j = 0; j < 4; j++) vq[q][j] = t;
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 5; q++) {
             if (hthread) {
@@ -111,6 +160,14 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
             }
             __syncthreads();
         }
+        float mk[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // (channel 0 also sums the mask: its four loads go out together)
+        if (ch == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int x = X0 + c, y = Y0 + r0 + j;
+                mk[j] = mask[(size_t)(y < a.H ? y : a.H - 1) * a.W + (x < a.W ? x : a.W - 1)];       // (clamped, not branched: used in-image only)
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int r = r0 + j;
@@ -135,7 +192,7 @@ sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *_
                 const float xv = sX[r + 5][c + 5], yv = sY[r + 5][c + 5];
                 acc_ssim += m;
                 acc_l1 += fabsf(xv - yv);
-                if (ch == 0) acc_mask += mask[p];
+                if (ch == 0) acc_mask += mk[j];
                 if (pred_out) pred_out[ch * hw + p] = xv;
                 if (gt_out) gt_out[ch * hw + p] = yv;
             }
@@ -192,6 +249,7 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
 {
     __shared__ float sM[3][SG_LH][SG_LP];
     __shared__ float sH[SG_LH][SG_LT + 1];
+    __shared__ uint32_t sFlat[4][4];
     const int tid = threadIdx.x;
     const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
     const size_t hw = (size_t)a.W * a.H;
@@ -206,23 +264,51 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
     const float c_l1 = scalars[4] * u_l1, c_ss = scalars[5] * u_ss;
     {
         const int ch = blockIdx.z - 3 * frame;
-        for (int i = tid; i < SG_LH * SG_LH; i += 256) {
-            const int r = i / SG_LH, c = i - r * SG_LH;
-            const int x = X0 - 5 + c, y = Y0 - 5 + r;
-            float m0 = 0.0f, m1 = 0.0f, m2 = 0.0f;
-            if (x >= 0 && x < a.W && y >= 0 && y < a.H) {
-                const size_t p = (size_t)y * a.W + x;
-                m0 = maps[(size_t)(ch * 3 + 0) * hw + p]; m1 = maps[(size_t)(ch * 3 + 1) * hw + p];
-                m2 = maps[(size_t)(ch * 3 + 2) * hw + p];
+        bool same = true;
+        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
+        {   // (all loads of the halo tile in flight together: see sg_ssim_stats_kernel)
+            float l0[SG_LOADS], l1[SG_LOADS], l2[SG_LOADS];
+#pragma unroll
+            for (int u = 0; u < SG_LOADS; u++) {
+                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
+                const int x = X0 - 5 + c, y = Y0 - 5 + r;
+                const int xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1), yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1);
+                const size_t p = (size_t)yc * a.W + xc;
+                l0[u] = maps[(size_t)(ch * 3 + 0) * hw + p]; l1[u] = maps[(size_t)(ch * 3 + 1) * hw + p];
+                l2[u] = maps[(size_t)(ch * 3 + 2) * hw + p];
             }
-            sM[0][r][c] = m0; sM[1][r][c] = m1; sM[2][r][c] = m2;
+#pragma unroll
+            for (int u = 0; u < SG_LOADS; u++) {
+                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
+                const int x = X0 - 5 + c, y = Y0 - 5 + r;
+                const bool in = x >= 0 && x < a.W && y >= 0 && y < a.H;
+                const float m0 = in ? l0[u] : 0.0f, m1 = in ? l1[u] : 0.0f, m2 = in ? l2[u] : 0.0f;
+                if (i < SG_LH * SG_LH) { sM[0][r][c] = m0; sM[1][r][c] = m1; sM[2][r][c] = m2; }
+                if (u == 0) { f0 = m0; f1 = m1; f2 = m2; }
+                else if (i < SG_LH * SG_LH)
+                    same = same && __float_as_uint(m0) == __float_as_uint(f0) && __float_as_uint(m1) == __float_as_uint(f1)
+                           && __float_as_uint(m2) == __float_as_uint(f2);
+            }
         }
-        __syncthreads();
+        const bool flat = sg_tile_is_flat(same, f0, f1, f2, sFlat, tid & 63, tid >> 6);
         const bool hthread = tid < SG_LH * 4;
         const int hr = tid >> 2, hc0 = (tid & 3) * 8;
         const int c = tid & 31, r0 = (tid >> 5) * 4;
         const float bgc = bg[ch];
         float gq[3][4];
+        if (flat) {                                         // (one chain per map: see sg_ssim_stats_kernel)
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                const float v = q == 0 ? f0 : q == 1 ? f1 : f2;
+                float h = 0.0f, t = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v, h);
+#pragma unroll
+                for (int k = 0; k < 11; k++) t = fmaf(a.w[k], h, t);
+#pragma unroll
+                for (int j = 0; j < 4; j++) gq[q][j] = t;
+            }
+        } else
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             if (hthread) {
@@ -250,6 +336,14 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
             }
             __syncthreads();
         }
+        float trv[4], tm[4], tgt[4];                        // the rendered / mask / target pixels of the four rows: twelve loads, one round trip
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int x = X0 + c, y = Y0 + r0 + j;
+            const int xc = x < a.W ? x : a.W - 1, yc = y < a.H ? y : a.H - 1;
+            const size_t p = (size_t)yc * a.W + xc;
+            trv[j] = raw[ch * hw + p]; tm[j] = mask[p]; tgt[j] = gt_rgb[ch * hw + p];
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++) {
             const int r = r0 + j;
@@ -257,8 +351,8 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
             const float g0 = gq[0][j], g1 = gq[1][j], g2 = gq[2][j];
             if (x < a.W && y < a.H) {
                 const size_t p = (size_t)y * a.W + x;
-                const float rv = raw[ch * hw + p], m = mask[p];
-                const float xv = sg_clamp01(rv), yv = gt_rgb[ch * hw + p] * m + bgc * (1.0f - m);
+                const float rv = trv[j], m = tm[j];
+                const float xv = sg_clamp01(rv), yv = tgt[j] * m + bgc * (1.0f - m);
                 const float d = xv - yv;
                 const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
                 float g = c_ss * (g0 + 2.0f * xv * g1 + yv * g2) + c_l1 * sgn;

@@ -85,3 +85,49 @@ def test_full_hd_deterministic_and_flat_image_properties():
     torch.cuda.synchronize()
     assert abs(eng.losses[3].item() - 1.0) <= 1e-6 and eng.losses[2].item() == 0.0
     assert ga.abs().max().item() <= 1e-9
+
+
+def test_flat_tiles_take_the_short_path_with_the_same_bits():
+    """An avatar frame: the body covers part of the image, the rest is background on both sides (render = bg, mask = 0).  Workgroups
+    whose whole 42 x 42 halo tile holds ONE value evaluate one 11-tap chain per quantity instead of the tile's (sg_tile_is_flat).
+    (i) the result agrees with the oracle like any other image; (ii) a pixel's gradient depends on its 21 x 21 neighbourhood only
+    (two 11-tap windows), so every pixel with a flat neighbourhood -- whether its tile went the short way (far from the body) or
+    the long way (tiles that also hold part of the body, tiles at the image border) -- must carry the SAME gradient bits."""
+    from sings_amd.photo_loss import photometric_loss
+    dev = _dev()
+    W, H = 352, 288
+    rs = np.random.RandomState(11)
+    bg = np.array([0.25, 0.5, 0.75], np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    body = ((xx - 201) ** 2 / 60.0 ** 2 + (yy - 150) ** 2 / 95.0 ** 2) < 1.0
+    mask = body.astype(np.float32)
+    gt = rs.uniform(0, 1, (3, H, W)).astype(np.float32)                       # (noise outside the mask too: it is multiplied by 0)
+    raw = np.where(body[None], rs.uniform(-0.2, 1.2, (3, H, W)), bg[:, None, None]).astype(np.float32)
+    r_cpu = torch.from_numpy(raw).requires_grad_(True)
+    o = plo.photometric_loss(r_cpu, torch.from_numpy(gt), torch.from_numpy(mask), torch.from_numpy(bg), 0.8, 0.2)
+    (o["l1"] + o["ssim"]).backward()
+    r_gpu = torch.from_numpy(raw).to(dev).requires_grad_(True)
+    ld, _ = photometric_loss(r_gpu, torch.from_numpy(gt).to(dev), torch.from_numpy(mask).to(dev)[None], torch.from_numpy(bg).to(dev), 0.8, 0.2)
+    (ld["l1"] + ld["ssim"]).backward()
+    assert abs(ld["l1"].item() - o["l1"].item()) <= 2e-6 * abs(o["l1"].item()) + 1e-7
+    assert abs(ld["ssim"].item() - o["ssim"].item()) <= 2e-6
+    g = r_gpu.grad.cpu().numpy()
+    _close_grad(g, r_cpu.grad.numpy())
+    # pixels at least 10 px from the body and from the image border: flat 21 x 21 neighbourhood
+    from scipy.ndimage import binary_dilation
+    near = binary_dilation(body, structure=np.ones((21, 21), bool))
+    inner = np.zeros((H, W), bool); inner[10:H - 10, 10:W - 10] = True
+    sel = inner & ~near
+    ty, tx = yy // 32, xx // 32
+    tile_has_body = np.zeros((H // 32 + 1, W // 32 + 1), bool)
+    for t_y in range(H // 32 + (H % 32 > 0)):
+        for t_x in range(W // 32 + (W % 32 > 0)):
+            y0, y1, x0, x1 = max(t_y * 32 - 5, 0), min(t_y * 32 + 37, H), max(t_x * 32 - 5, 0), min(t_x * 32 + 37, W)
+            edge = t_y * 32 - 5 < 0 or t_x * 32 - 5 < 0 or t_y * 32 + 37 > H or t_x * 32 + 37 > W
+            tile_has_body[t_y, t_x] = body[y0:y1, x0:x1].any() or edge
+    long_way = sel & tile_has_body[ty, tx]
+    short_way = sel & ~tile_has_body[ty, tx]
+    assert long_way.sum() > 2000 and short_way.sum() > 10000, (long_way.sum(), short_way.sum())
+    for ch in range(3):
+        bits = g[ch].view(np.uint32)
+        assert np.unique(bits[sel]).size == 1, (ch, np.unique(bits[sel]).size)
