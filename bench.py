@@ -122,13 +122,13 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=None,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
-                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views.  Default: raster 8; "
-                         "avatar 16 (the reference's chunk: SinGS.forward_chunk hands the model 16 frames per call)")
+                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views.  Default: 16 (the "
+                         "reference's chunk: SinGS.forward_chunk hands the model 16 frames per call)")
     ap.add_argument("--frames-per-launch", type=int, default=None,
                     help="frames (avatar) / cameras (raster) of the same Gaussians rendered by ONE dispatch per kernel (the *_frames "
                          "entry points: K consecutive workspaces, the per-Gaussian backward sums the K frames in registers).  A step "
                          "of --views-per-step views is views / K such batches, dealt to the streams.  1 = one engine per view (round "
-                         "3).  Default: avatar 8, raster 1")
+                         "3).  Default: 8")
     ap.add_argument("--pipeline", action="store_true",
                     help="avatar workload: instead of one batch of frames per stream, schedule by KIND of kernel on two streams -- the "
                          "composite kernels of all batches on one, everything else beside them on a high-priority one "
@@ -158,12 +158,14 @@ def parse_args():
                     help="raster = BASELINE configs[2] (the metric's config, default); avatar = configs[3]: ~150k canonical "
                          "Gaussians, J=52, AMASS frames, 512x896, LBS-fused kernels (reported as an extra workload)")
     a = ap.parse_args()
-    # per-workload defaults (measured on one MI355X: tools/r04_combos.sh): raster 8 views on 3 streams; avatar 16 frames as two
-    # launches of 8 frames on 2 streams (5 260 frames/s; 8 frames: one launch of 8 4 750, two of 4 on 2 streams 5 040)
+    # per-workload defaults (measured on one MI355X: tools/r04_combos.sh, r04_raster_combos.sh; LAB.md): 16 views per step as two
+    # launches of 8 frames / cameras on 2 streams.  raster: 4 245 views/s (8 views, one camera per launch, 3 streams -- the round-3
+    # schedule, --views-per-step 8 --frames-per-launch 1 --streams 3 --: 3 874; one launch of 8: 4 080); avatar: 5 820 frames/s
+    # (one launch of 8: 4 940; 24 frames on 3 streams: 5 930-6 005)
     if a.views_per_step is None:
-        a.views_per_step = 16 if a.workload == "avatar" else 8
+        a.views_per_step = 16
     if a.streams is None:
-        a.streams = 2 if a.workload == "avatar" else 3
+        a.streams = 2
     return a
 
 
@@ -424,7 +426,7 @@ def main_raster(a):
                            force=FORCE_DIST)
 
     # K cameras per launch (round 4, sings_amd.engine.RasterFramesEngine): the step's k_views views go out as k_views / K batches
-    Kf = 1 if a.graph else max(1, min(a.frames_per_launch if a.frames_per_launch is not None else 1, k_views, _lib.MAX_FRAMES))
+    Kf = 1 if a.graph else max(1, min(a.frames_per_launch if a.frames_per_launch is not None else 8, k_views, _lib.MAX_FRAMES))
     while k_views % Kf:
         Kf -= 1
     n_batches = k_views // Kf

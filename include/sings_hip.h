@@ -286,7 +286,8 @@ int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkin
  * writes the gradient buffer and the others add to it (accumulate = 1).  K = 1 IS the single-frame call (same kernels).
  *
  * Layout of a K-frame call: every per-frame array is K consecutive single-frame arrays --
- *   workspaces : geom_ws / binning_ws / image_ws / bwd_ws = K x sg_layout(...).{geom,bin,img,bwd}_bytes (sg_frames_layout),
+ *   workspaces : geom_ws / binning_ws / image_ws / bwd_ws = K x sg_layout(...).{geom,bin,img,bwd}_bytes (sg_frames_layout;
+ *                bwd_ws, K > 1: + K x P x 48 bytes behind the K record buffers, scratch of sg_rasterize_backward_gaussians_frames),
  *   out_color / dL_dout_color [K,3,H,W], radii [K,P], dL_dmeans2D [K,P,3], posed_* [K,P,.], dL_dA [K,J,16], dL_dtransl [K,3],
  *   skin->A [K,J,16]; skin->transl [K,3] (transl_stride 3) or [3] shared (0);
  *   cameras: camera_stride 1: s->viewmatrix [K,16], s->projmatrix [K,16], s->campos [K,3]; 0: one camera for all frames
@@ -298,7 +299,8 @@ typedef struct SgFrameBatch {
     int32_t transl_stride;   /* 0 | 3 (floats) */
     int32_t reserved;        /* 0 */
 } SgFrameBatch;
-/* sizes of the K-frame workspaces (= K x the single-frame sizes, which are returned in *one); any output pointer may be NULL */
+/* sizes of the K-frame workspaces (K x the single-frame sizes, which are returned in *one; bwd: see above); any output pointer may
+ * be NULL */
 int sg_frames_layout(int P, int width, int height, size_t capacity_pairs, int K, SgLayout *one, size_t *geom_bytes,
                      size_t *binning_bytes, size_t *image_bytes, size_t *bwd_bytes);
 /* num_rendered_host: NULL, or [K] -- filled by one strided copy + stream synchronisation */

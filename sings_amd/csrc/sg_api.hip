@@ -195,7 +195,7 @@ extern "C" int sg_frames_layout(int P, int width, int height, size_t cap, int K,
     if (geom_bytes) *geom_bytes = L.geom_bytes * K;
     if (binning_bytes) *binning_bytes = L.bin_bytes * K;
     if (image_bytes) *image_bytes = L.img_bytes * K;
-    if (bwd_bytes) *bwd_bytes = L.bwd_bytes * K;
+    if (bwd_bytes) *bwd_bytes = L.bwd_bytes * K + sg_a9_bytes(P, K);      // (+ the record sums [K][P][12] of the K-camera backward)
     return 0;
 }
 
@@ -380,7 +380,9 @@ extern "C" int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s,
     SgGeom g = sg_geom_view((void *)geom_ws, L);
     SgBin b = sg_bin_view((void *)binning_ws, L);
     sg_launch_preprocess_bwd(c, bt, P, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, radii, g,
-                             sg_rec_view(bwd_ws, cap), cap, b.header, sg_lds_hist(c.gx, c.gy) ? b.rec_valid : nullptr, dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
+                             sg_rec_view(bwd_ws, cap), cap, b.header, sg_lds_hist(c.gx, c.gy) ? b.rec_valid : nullptr,
+                             bt.K > 1 ? (float4 *)((char *)bwd_ws + (size_t)bt.K * L.bwd_bytes) : nullptr,     // (sg_frames_layout: the a9 block)
+                             dL_dmeans3D, dL_dmeans2D, shs ? dL_dsh : nullptr,
                              dL_dcolors, dL_dopacity, cov3D_precomp ? nullptr : dL_dscales,
                              cov3D_precomp ? nullptr : dL_drotations, dL_dcov3D, accumulate, st);
     SG_CHECK_LAST("preprocess_bwd", s, st);

@@ -233,11 +233,17 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
                           int write_keys, hipStream_t st);
 void sg_launch_render_bwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, size_t cap, SgImg im,
                           const float *dL_dpix, SgRec grec, hipStream_t st);
+// a9out [K][P][12]: the per-Gaussian sums of frame f's gradient records (sg_skin.hip::sg_record_sums_kernel), for the K-frame
+// per-Gaussian backward kernels
+void sg_launch_record_sums(const SgBatch &bt, int P, const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
+                           const uint8_t *rec_valid, float4 *a9out, hipStream_t st);
+// bytes behind the K record buffers of a K-frame backward workspace: the a9 block of the K-camera per-Gaussian backward (K > 1)
+static inline size_t sg_a9_bytes(int P, int K) { return K > 1 ? sg_align((size_t)K * (size_t)P * 48 + 256) : 0; }
 void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
                               const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
-                              float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
+                              float4 *a9buf, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st);
 

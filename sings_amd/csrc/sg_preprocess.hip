@@ -225,68 +225,63 @@ sg_preprocess_bwd_kernel(SgCam c, int P, const float *__restrict__ means3D, cons
 }
 
 // ---- K cameras per launch (round 4) -------------------------------------------------------------------------------------------
-// K cameras (bt.K frames) of the SAME Gaussians: the kernel walks the frames -- records of frame f, chain rule with camera f -- and
-// sums the K gradients of a Gaussian in registers, in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K
-// single-camera calls leave behind when the first writes the gradient buffer and the others run with accumulate = 1), then writes
-// the 248-byte gradient row ONCE: K - 1 read-modify-write passes over the buffer less (at cfg3 2 x 47 MB per view), and the
-// Gaussian's inputs (236 B) are read once for the K cameras.  dL_dmeans2D (the densifier's per-view statistic) is per frame.
+// K cameras (bt.K frames) of the SAME Gaussians: the kernel walks the frames -- chain rule with camera f on the record sums of frame
+// f -- and sums the K gradients of a Gaussian in frame order (frame 0 assigns, frame f > 0 adds: bit for bit what K single-camera
+// calls leave behind when the first writes the gradient buffer and the others run with accumulate = 1), then writes the 248-byte
+// gradient row ONCE: K - 1 read-modify-write passes over the buffer less (at cfg3 2 x 47 MB per view), and the Gaussian's position,
+// scale and rotation are read once for the K cameras.  dL_dmeans2D (the densifier's per-view statistic) is per frame.
+//
+// What a frame needs is kept OUT of the loop-carried registers (the first form of this kernel held 48 SH coefficients, 48 dL/dsh
+// sums and the record-chunk staging across the loop: 316 registers at degree 3, one wave per SIMD, 45.8 us per view against the
+// single-camera kernel's 30):
+//  * the record sums of all frames come from sg_record_sums_kernel (a9 [K][P][12]: a kernel of ~40 registers at full occupancy
+//    does the dependent chunk loop); the loop reads 48 contiguous bytes per Gaussian and frame, requested one frame ahead;
+//  * the dL/dsh sums live in LDS ([coefficient][thread], pitch 257: conflict-free for the sums and for the transposed read of the
+//    row store) -- 48 KiB per workgroup at degree 3: three workgroups per CU, which is what 168 registers allow anyway;
+//  * the SH coefficients are re-read per frame (192 B per Gaussian out of L2: frame 0 brought them in).
+#define SG_ACC_PITCH 257
 template <int D, bool ACC>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, D >= 2 ? 2 : 3)))
 sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__restrict__ means3D, const float *__restrict__ shs,
                          const float *__restrict__ colors_precomp, const float *__restrict__ scales,
                          const float *__restrict__ rotations, const float *__restrict__ cov3D_precomp,
-                         const int32_t *__restrict__ radii0, SgGeom g0_, SgRec grec0,
-                         size_t cap, const uint32_t *__restrict__ header0, const uint8_t *__restrict__ rec_valid, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
+                         const int32_t *__restrict__ radii0, SgGeom g0_, const uint32_t *__restrict__ header0,
+                         const float4 *__restrict__ a9in, float *__restrict__ dL_dmeans3D, float *__restrict__ dL_dmeans2D,
                          float *__restrict__ dL_dsh, float *__restrict__ dL_dcolors,
                          float *__restrict__ dL_dopacity, float *__restrict__ dL_dscales,
                          float *__restrict__ dL_drots, float *__restrict__ dL_dcov3D)
 {
     constexpr bool accumulate = ACC;
-    __shared__ float lds_all[4][32 * SG_ROW_LDS];         // 6.5 KiB per wave: record chunks, then dL/dsh rows out
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ float sAcc[];                         // dL/dsh sums [nc * 3][SG_ACC_PITCH]; afterwards the staging rows of the store
+    const int idx_all = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane_all = threadIdx.x & 63, wave_all = threadIdx.x >> 6;
-    const int g0 = idx - lane_all;
-    if (g0 >= P) return;                                    // whole wave out of range
-    const bool live = idx < P;
+    const int g0 = idx_all - lane_all;
+    const bool live = idx_all < P;
     const int Mrows = c0.M;
     const int nframes = bt.K;
     constexpr int nc = (D + 1) * (D + 1);
-    const bool staged = D == 3 && Mrows == 16 && shs != nullptr && dL_dsh != nullptr;
-    // the Gaussian's inputs: read ONCE for all frames (a Gaussian that no frame sees loads nothing)
-    float p[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 }, sh[nc * 3], dsh[nc * 3];
-#pragma unroll
-    for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dsh[k] = 0.0f; }
-    bool any_vis = false;
-#pragma unroll 1
-    for (int f = 0; f < nframes; f++)
-        any_vis |= live && radii0[(size_t)f * bt.P + idx] > 0 && sg_at(header0, (size_t)f * bt.bin)[1] == 0u;
-    // frame f + 1's (visible, record slot, clamp flags) are requested while frame f is worked on; frame 0's go out together with
-    // the Gaussian's inputs: two dependent memory round trips in front of the first record sum, as in the single-frame kernel
-    bool vis_n = live && radii0[idx] > 0 && header0[1] == 0u;
-    uint2 sl_n = make_uint2(0u, 0u);
+    const bool want_sh = dL_dsh != nullptr;
+    const bool planar = c0.flags & SG_FLAG_SH_PLANAR;
+    const bool vec_rows = D == 3 && Mrows == 16 && shs != nullptr;            // 16-byte loads of the coefficient row
+    const bool staged = vec_rows && want_sh && !planar;
+    // the Gaussian's position / scale / rotation: read ONCE for all frames
+    float p[3] = { 0, 0, 0 }, s3[3] = { 0, 0, 0 }, q[4] = { 0, 0, 0, 0 };
+    // frame f + 1's (visible, clamp flags, record sums) are requested while frame f is worked on; frame 0's go out with the inputs
+    bool vis_n = live && radii0[idx_all] > 0 && header0[1] == 0u;
     uint32_t fl_n = 0u;
-    if (vis_n) { sl_n = g0_.slot[idx]; fl_n = g0_.flags[idx]; }
-    if (any_vis) {
-        p[0] = means3D[3 * idx]; p[1] = means3D[3 * idx + 1]; p[2] = means3D[3 * idx + 2];
+    float4 n0 = make_float4(0, 0, 0, 0), n1 = n0, n2 = n0;
+    if (vis_n) {
+        fl_n = g0_.flags[idx_all];
+        const float4 *src = a9in + 3 * (size_t)idx_all;
+        n0 = src[0]; n1 = src[1]; n2 = src[2];
+    }
+    if (live) {
+        p[0] = means3D[3 * idx_all]; p[1] = means3D[3 * idx_all + 1]; p[2] = means3D[3 * idx_all + 2];
         if (!cov3D_precomp) {
-            s3[0] = scales[3 * idx]; s3[1] = scales[3 * idx + 1]; s3[2] = scales[3 * idx + 2];
-            q[0] = rotations[4 * idx]; q[1] = rotations[4 * idx + 1]; q[2] = rotations[4 * idx + 2]; q[3] = rotations[4 * idx + 3];
-        }
-        if (shs) {
-            const float *src = shs + (size_t)idx * Mrows * 3;
-            if (staged) {
-#pragma unroll
-                for (int k = 0; k < nc * 3 / 4; k++) {
-                    float4 v = ((const float4 *)src)[k];
-                    sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
-            }
+            s3[0] = scales[3 * idx_all]; s3[1] = scales[3 * idx_all + 1]; s3[2] = scales[3 * idx_all + 2];
+            q[0] = rotations[4 * idx_all]; q[1] = rotations[4 * idx_all + 1]; q[2] = rotations[4 * idx_all + 2]; q[3] = rotations[4 * idx_all + 3];
         }
     }
-    const int idx_all = idx;
     SgGaussGrad A;                                          // the sum over the frames
 #pragma unroll
     for (int k = 0; k < 3; k++) { A.dmean[k] = 0; A.dcol[k] = 0; A.dsc[k] = 0; }
@@ -300,30 +295,33 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
     constexpr bool preload = ACC;
     if (preload && live) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) A.dmean[k] = dL_dmeans3D[3 * idx + k];
-        A.dop = dL_dopacity[idx];
+        for (int k = 0; k < 3; k++) A.dmean[k] = dL_dmeans3D[3 * idx_all + k];
+        A.dop = dL_dopacity[idx_all];
 #pragma unroll
-        for (int k = 0; k < 3; k++) { A.dcol[k] = dL_dcolors ? dL_dcolors[3 * idx + k] : 0.0f; A.dsc[k] = dL_dscales ? dL_dscales[3 * idx + k] : 0.0f; }
+        for (int k = 0; k < 3; k++) { A.dcol[k] = dL_dcolors ? dL_dcolors[3 * idx_all + k] : 0.0f; A.dsc[k] = dL_dscales ? dL_dscales[3 * idx_all + k] : 0.0f; }
 #pragma unroll
-        for (int k = 0; k < 4; k++) A.drot[k] = dL_drots ? dL_drots[4 * idx + k] : 0.0f;
+        for (int k = 0; k < 4; k++) A.drot[k] = dL_drots ? dL_drots[4 * idx_all + k] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 6; k++) A.g6[k] = dL_dcov3D ? dL_dcov3D[6 * idx + k] : 0.0f;
-        if (dL_dsh) {
-            const float *row = dL_dsh + (size_t)idx * Mrows * 3;
-            const bool planar = c0.flags & SG_FLAG_SH_PLANAR;
+        for (int k = 0; k < 6; k++) A.g6[k] = dL_dcov3D ? dL_dcov3D[6 * idx_all + k] : 0.0f;
+    }
+    if (want_sh) {
+        float *acc = sAcc + threadIdx.x;
+        if (preload && live) {
+            const float *row = dL_dsh + (size_t)idx_all * Mrows * 3;
 #pragma unroll
-            for (int k = 0; k < nc * 3; k++) dsh[k] = planar ? dL_dsh[((size_t)(k / 3) * P + idx) * 3 + k % 3] : row[k];
+            for (int k = 0; k < nc * 3; k++) acc[k * SG_ACC_PITCH] = planar ? dL_dsh[((size_t)(k / 3) * P + idx_all) * 3 + k % 3] : row[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < nc * 3; k++) acc[k * SG_ACC_PITCH] = 0.0f;
         }
     }
 #pragma unroll 1
     for (int f = 0; f < nframes; f++) {
-        // (opaque per trip: keeps hipcc from hoisting what depends on them only -- LDS addresses, shuffle indices, the per-frame
-        //  arrays' addresses -- in front of the loop, where it would stay live across it: see sg_skin_bwd_kernel)
-        int idx = idx_all, lane = lane_all, wave = wave_all;
-        asm volatile("" : "+v"(idx), "+v"(lane), "+v"(wave));
-        float *L = lds_all[wave];
+        // (opaque per trip: keeps hipcc from hoisting what depends on the thread's index only -- the SH row, LDS addresses, the
+        //  per-frame arrays' addresses -- in front of the loop, where it would stay live across it: see sg_skin_bwd_frames_kernel)
+        int idx = idx_all, tid = (int)threadIdx.x;
+        asm volatile("" : "+v"(idx), "+v"(tid));
         const SgCam c = sg_frame(c0, f, bt.cam_stride);
-        const SgRec grec = sg_frame(grec0, (size_t)f * bt.rec);
         SgGaussGrad G;
 #pragma unroll
         for (int k = 0; k < 3; k++) { G.dmean[k] = 0; G.dcol[k] = 0; G.dsc[k] = 0; }
@@ -335,22 +333,49 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
         // after a forward that overflowed (header[1] != 0) the backward composite wrote no records: every gradient is ZERO, the
         // stale contents of the record buffer are never summed (asynchronous overflow check: rasterizer.py)
         const bool vis = vis_n;
-        float4 rc = make_float4(0, 0, 0, 0);
-        rc.y = __uint_as_float(sl_n.x); rc.w = __uint_as_float(sl_n.y);
         const uint32_t flags = fl_n;
+        const float a9[9] = { n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, n1.z, n1.w, n2.x };
         if (f + 1 < nframes) {
             const SgGeom gn = sg_frame(g0_, (size_t)(f + 1) * bt.geom);
             vis_n = live && radii0[(size_t)(f + 1) * bt.P + idx] > 0 && sg_at(header0, (size_t)(f + 1) * bt.bin)[1] == 0u;
-            sl_n = make_uint2(0u, 0u); fl_n = 0u;
-            if (vis_n) { sl_n = gn.slot[idx]; fl_n = gn.flags[idx]; }
+            fl_n = 0u;
+            if (vis_n) {
+                fl_n = gn.flags[idx];
+                const float4 *src = a9in + 3 * ((size_t)(f + 1) * bt.P + idx);
+                n0 = src[0]; n1 = src[1]; n2 = src[2];
+            }
         }
-        // 1. this Gaussian's gradient records of frame f (wave-cooperative, coalesced)
-        float a9[9];
-        sg_sum_records_coop(grec, cap, vis, rc, lane, L, a9, sg_at(rec_valid, (size_t)f * bt.bin));
-        // 2. the chain rule; dL/dsh rows: frame 0 assigns, later frames add (`first`)
-        if (vis)
+        // the chain rule; dL/dsh rows: frame 0 assigns, later frames add
+        if (vis) {
+            float sh[nc * 3], dshf[nc * 3];
+#pragma unroll
+            for (int k = 0; k < nc * 3; k++) { sh[k] = 0.0f; dshf[k] = 0.0f; }
+            if (shs) {
+                const float *src = shs + (size_t)idx * Mrows * 3;
+                if (vec_rows) {
+#pragma unroll
+                    for (int k = 0; k < nc * 3 / 4; k++) {
+                        float4 v = ((const float4 *)src)[k];
+                        sh[4 * k] = v.x; sh[4 * k + 1] = v.y; sh[4 * k + 2] = v.z; sh[4 * k + 3] = v.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < nc * 3; k++) sh[k] = src[k];
+                }
+            }
             sg_project_bwd<D>(c, p, s3, q, cov3D_precomp ? cov3D_precomp + 6 * (size_t)idx : nullptr, sh, flags, a9,
-                              dL_dsh != nullptr, dsh, G, !preload && f == 0);
+                              want_sh, dshf, G);
+            if (want_sh) {
+                float *acc = sAcc + tid;
+                if (!preload && f == 0) {
+#pragma unroll
+                    for (int k = 0; k < nc * 3; k++) acc[k * SG_ACC_PITCH] = dshf[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < nc * 3; k++) acc[k * SG_ACC_PITCH] = acc[k * SG_ACC_PITCH] + dshf[k];
+                }
+            }
+        }
         // the screen-space gradient is per VIEW (the densifier's statistic): never accumulated
         if (live) {
             float *m2 = dL_dmeans2D + 3 * ((size_t)f * bt.P + idx);
@@ -370,24 +395,28 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
         }
     }
     SgGaussGrad &G = A;
-    const int lane = lane_all;
-    float *L = lds_all[wave_all];
-    // 3. dL/dsh out: coefficient-major planes [M][P][3], only the (D+1)^2 in use (SG_FLAG_SH_PLANAR); or the reference's rows
-    //    (every one of the M rows is written; coalesced through LDS when staged)
-    if (dL_dsh && (c0.flags & SG_FLAG_SH_PLANAR)) {
+    const int idx = idx_all, lane = lane_all;
+    // dL/dsh out: coefficient-major planes [M][P][3], only the (D+1)^2 in use (SG_FLAG_SH_PLANAR); or the reference's rows
+    // (every one of the M rows is written; coalesced through LDS when staged).  (accumulate: the sums already hold old + frames)
+    if (want_sh && planar) {
         if (live) {
+            const float *acc = sAcc + threadIdx.x;
 #pragma unroll
-            for (int kq = 0; kq < nc; kq++)
-#pragma unroll
-                for (int ch = 0; ch < 3; ch++) {
-                    float *d = dL_dsh + ((size_t)kq * P + idx) * 3 + ch;
-                    *d = dsh[3 * kq + ch];               // (accumulate: dsh already holds old + frames)
-                }
+            for (int k = 0; k < nc * 3; k++) dL_dsh[((size_t)(k / 3) * P + idx) * 3 + k % 3] = acc[k * SG_ACC_PITCH];
         }
-    } else if (dL_dsh) {
-        if (staged) {
+    } else if (want_sh) {
+        float dsh[nc * 3];
+        {
+            const float *acc = sAcc + threadIdx.x;
 #pragma unroll
-            for (int h = 0; h < 2; h++) {                    // 32 rows at a time (keeps LDS at 6.5 KiB per wave)
+            for (int k = 0; k < nc * 3; k++) dsh[k] = acc[k * SG_ACC_PITCH];
+        }
+        if (staged) {
+            __syncthreads();                                 // every thread holds its sums: the LDS is free for the staging rows
+            float *L = sAcc + wave_all * (32 * SG_ROW_LDS);
+            static_assert(4 * 32 * SG_ROW_LDS <= 48 * SG_ACC_PITCH, "staging rows fit the accumulator block");
+#pragma unroll
+            for (int h = 0; h < 2; h++) {                    // 32 rows at a time
                 if ((lane >> 5) == h) {
 #pragma unroll
                     for (int k = 0; k < 12; k++)
@@ -395,20 +424,16 @@ sg_preprocess_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, const float *__rest
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
-                sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, false);     // (accumulate: dsh already holds old + frames)
+                if (g0 < P) sg_rows48_store(dL_dsh, g0 + 32 * h, P, lane, L, 32, false);
                 __builtin_amdgcn_s_waitcnt(0xC07F);
                 __builtin_amdgcn_wave_barrier();
             }
         } else if (live) {
             float *dsh_row = dL_dsh + (size_t)idx * Mrows * 3;
-            if (accumulate) {
 #pragma unroll
-                for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
+            for (int k = 0; k < nc * 3; k++) dsh_row[k] = dsh[k];
+            if (!accumulate)
                 for (int k = nc * 3; k < Mrows * 3; k++) dsh_row[k] = 0.0f;
-            }
         }
     }
     if (!live) return;
@@ -427,25 +452,29 @@ void sg_launch_preprocess_bwd(const SgCam &c, const SgBatch &bt, int P, const fl
                               const float *colors_precomp, const float *opacities, const float *scales,
                               const float *rotations, const float *cov3D_precomp,
                               const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
-                              float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
+                              float4 *a9buf, float *dL_dmeans3D, float *dL_dmeans2D, float *dL_dsh,
                               float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                               float *dL_drots, float *dL_dcov3D, int accumulate, hipStream_t st)
 {
     (void)opacities;
     if (P <= 0) return;
     dim3 grid((P + 255) / 256), block(256);
+    int D = shs ? c.D : 0;
+    // K > 1: dL/dsh sums in LDS ([coefficient][thread]); the staged row store reuses the block
+    const size_t dyn = dL_dsh ? (size_t)(D + 1) * (D + 1) * 3 * SG_ACC_PITCH * sizeof(float) : 0;
 #define SG_PB1(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_kernel<DD, AA>), grid, block, 0, st, c, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
                                      grec, cap, header, rec_valid, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
-#define SG_PBK(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_frames_kernel<DD, AA>), grid, block, 0, st, c, bt, P, means3D, shs, \
+#define SG_PBK(DD, AA) hipLaunchKernelGGL((sg_preprocess_bwd_frames_kernel<DD, AA>), grid, block, dyn, st, c, bt, P, means3D, shs, \
                                      colors_precomp, scales, rotations, cov3D_precomp, radii, g,            \
-                                     grec, cap, header, rec_valid, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
+                                     header, a9buf, dL_dmeans3D, dL_dmeans2D, dL_dsh, dL_dcolors, \
                                      dL_dopacity, dL_dscales, dL_drots, dL_dcov3D)
 #define SG_PB2(DD, AA) do { if (bt.K == 1) SG_PB1(DD, AA); else SG_PBK(DD, AA); } while (0)      // (K = 1: the round-3 kernel, untouched)
 #define SG_PB(DD) do { if (accumulate) SG_PB2(DD, true); else SG_PB2(DD, false); } while (0)
-    int D = shs ? c.D : 0;
     sg_prof_begin(SG_K_PREPROCESS_BWD, st);
+    // K > 1: the record sums of all frames first, as a kernel of their own (a9 [K][P][12] behind the K record buffers)
+    if (bt.K > 1) sg_launch_record_sums(bt, P, radii, g, grec, cap, header, rec_valid, a9buf, st);
     switch (D) { case 0: SG_PB(0); break; case 1: SG_PB(1); break; case 2: SG_PB(2); break; default: SG_PB(3); break; }
     sg_prof_end(SG_K_PREPROCESS_BWD, st);
 #undef SG_PB

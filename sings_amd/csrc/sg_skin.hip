@@ -579,6 +579,14 @@ sg_record_sums_kernel(SgBatch bt, int P, const int32_t *__restrict__ radii0, SgG
     }
 }
 
+void sg_launch_record_sums(const SgBatch &bt, int P, const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header,
+                           const uint8_t *rec_valid, float4 *a9out, hipStream_t st)
+{
+    if (P <= 0) return;
+    hipLaunchKernelGGL(sg_record_sums_kernel, dim3((P + 255) / 256, bt.K), dim3(256), 0, st, bt, P, radii, g, grec, cap, header,
+                       rec_valid, a9out);
+}
+
 template <int D, bool ACC>
 __global__ void __launch_bounds__(SG_SKIN_THREADS) __attribute__((amdgpu_waves_per_eu(D <= 1 ? 2 : 1, 2)))   // (D = 0: 255 VGPRs, no spills)
 sg_skin_bwd_frames_kernel(SgCam c0, SgBatch bt, int P, SgSkin k0, const float *__restrict__ shs, const float *__restrict__ scales,
@@ -1404,8 +1412,7 @@ void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinIn
     // K > 1: the record sums of all frames first, as a kernel of their own (a9 [K][P][12] behind the slabs and partial rows)
     const float4 *a9buf = (const float4 *)(slab + (slab_frame + (size_t)SG_RED_GROUPS * stride) * bt.K);
     if (bt.K > 1)
-        hipLaunchKernelGGL(sg_record_sums_kernel, dim3((P + 255) / 256, bt.K), dim3(256), 0, st, bt, P, radii, g, grec, cap, header,
-                           rec_valid, (float4 *)a9buf);
+        sg_launch_record_sums(bt, P, radii, g, grec, cap, header, rec_valid, (float4 *)a9buf, st);
     switch (c.D) { case 0: SG_SB(0); break; case 1: SG_SB(1); break; case 2: SG_SB(2); break; default: SG_SB(3); break; }
     float *part = slab + slab_frame * bt.K;
     hipLaunchKernelGGL(sg_skin_reduce1_kernel, dim3((stride + 63) / 64, SG_RED_GROUPS / 4, bt.K), dim3(256), 0, st, slab,

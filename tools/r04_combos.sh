@@ -2,7 +2,7 @@
 # avatar step: frames per launch x streams x views per step (same box)
 for cfg in "$@"; do
   IFS=, read V K S <<< "$cfg"
-  timeout 600 python bench.py --workload avatar --no-cpu-baseline --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S \
+  timeout 150 python bench.py --workload avatar --no-cpu-baseline --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S \
       > gpurun_out/r04c_avatar_V${V}_K${K}_S${S}.json 2> gpurun_out/r04c_avatar_V${V}_K${K}_S${S}.err
   python - $V $K $S <<'PY'
 import json,sys

@@ -2,7 +2,7 @@
 # cfg3 raster step: cameras per launch x streams (same box).  args: V,K,S ...
 for cfg in "$@"; do
   IFS=, read V K S <<< "$cfg"
-  timeout 600 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S \
+  timeout 150 python bench.py --no-cpu-baseline --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S \
       > gpurun_out/r04d_raster_V${V}_K${K}_S${S}.json 2> gpurun_out/r04d_raster_V${V}_K${K}_S${S}.err
   python - $V $K $S <<'PY'
 import json,sys
