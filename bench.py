@@ -578,7 +578,7 @@ def main_raster(a):
     _log("float4-copy probe (the roofline's denominator)")
     copy_gbs = measure_copy_peak(dev)
     roofline, roofline_valu = build_roofline(kern, per, {"workload": "raster", "gaussians": N, "width": W, "height": H, "sh_degree": deg},
-                                             total_bytes, world / views_s, copy_gbs)
+                                             total_bytes, world / views_s, copy_gbs, frames=Kf)
     out = {
         "metric": "rendered views/sec fwd+bwd, 200k Gaussians @1080p" if not a.forward_only and (N, W, H) == (200000, 1920, 1080)
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
@@ -724,20 +724,30 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
     return res
 
 
-def pmc_view_traffic(cfg, pdir=None, root=ROOT):
-    """Sum over ALL kernels of the committed HBM-traffic pass of this configuration and tree (bytes per view), or None."""
+def pmc_view_traffic(cfg, pdir=None, root=ROOT, frames=1):
+    """Sum over ALL kernels of the committed HBM-traffic pass of this configuration and tree (bytes per VIEW), or None.  A pass
+    is taken with ONE view per launch or with K frames / cameras per launch (sidecar key `frames_per_launch`; the per-launch
+    counts are divided by K by tools/pmc_summary.py): the pass of the run's own K is preferred, the one-view pass is the fallback.
+    -> (bytes, source, frames per launch of the pass)."""
     pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
+    best = None
     try:
         for fn in sorted((f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")), reverse=True):
             tj = json.load(open(os.path.join(pdir, fn)))
-            if _meta_status(tj.get("_meta"), cfg, root) is None:
-                return sum(v for k, v in tj.items() if not k.startswith("_") and isinstance(v, (int, float))), f"profiles/{fn}"
+            meta = tj.get("_meta")
+            if _meta_status(meta, cfg, root) is None:
+                k = int(meta["config"].get("frames_per_launch", 1))
+                tot = sum(v for kk, v in tj.items() if not kk.startswith("_") and isinstance(v, (int, float)))
+                if k == frames:
+                    return tot, f"profiles/{fn}", k
+                if k == 1 and best is None:
+                    best = (tot, f"profiles/{fn}", 1)
     except Exception:
         pass
-    return None, None
+    return best if best else (None, None, None)
 
 
-def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs):
+def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs, frames=1):
     """-> (roofline, roofline_valu).
 
     roofline (SURVEY.md 8(d) "Which roofline" / "Algorithmic bytes per view"): bound "hbm", scope the WHOLE pass of one view --
@@ -752,13 +762,13 @@ def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs):
     peak = copy_gbs if copy_gbs else HBM_COPY_GBS
     ach = total_bytes / s_per_view / 1e9
     dom_ach = per[dom] / (kern[dom] * 1e-3) / 1e9
-    view_traffic, tsrc = pmc_view_traffic(cfg)
+    view_traffic, tsrc, tframes = pmc_view_traffic(cfg, frames=frames)
     roof = {"bound": "hbm", "scope": "whole_pass", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
             "peak_source": "float4 copy measured in this run (sg_copy_probe, 1 GiB, best of 3, plain or non-temporal)" if copy_gbs else
                            "MI355X_MICROARCH.md (6.29 TB/s float4 copy; not measured in this run)",
             "peak_spec": HBM_PEAK_GBS, "frac_of_spec": ach / HBM_PEAK_GBS,
             "algorithmic_bytes_per_view": total_bytes, "ms_per_view": s_per_view * 1e3,
-            "traffic": view_traffic, "traffic_source": tsrc,
+            "traffic": view_traffic, "traffic_source": tsrc, "traffic_frames_per_launch": tframes,
             "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_algorithmic_bytes": per[dom],
             "dominant_kernel_achieved": dom_ach, "dominant_kernel_frac": dom_ach / peak,
             "dominant_kernel_frac_of_spec": dom_ach / HBM_PEAK_GBS, "dominant_kernel_traffic": pmc.get("traffic")}
@@ -1334,7 +1344,7 @@ def main_avatar(a):
         copy_gbs = measure_copy_peak(dev)
         out["roofline"], out["roofline_valu"] = build_roofline(
             kern, per, {"workload": "avatar", "gaussians": N, "width": W, "height": H, "sh_degree": 0}, total_bytes, 1.0 / fps,
-            copy_gbs)
+            copy_gbs, frames=Kf)
         out["roofline"]["note"] = ("raster + fused LBS bytes at the largest R of the sequence; the L1 + SSIM loss inside the timed "
                                    "step (HW 40 B algorithmic) is not counted")
         out["hbm_copy_GBs_measured"] = copy_gbs

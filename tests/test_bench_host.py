@@ -67,7 +67,7 @@ def test_roofline_is_the_whole_pass_hbm_quantity_and_valu_is_secondary(tmp_path)
     pdir = _profiles(tmp_path, meta)
     old, oldt = bench._committed_pmc, bench.pmc_view_traffic
     bench._committed_pmc = lambda k, c: old(k, c, pdir)
-    bench.pmc_view_traffic = lambda c: oldt(c, pdir)
+    bench.pmc_view_traffic = lambda c, frames=1: oldt(c, pdir, frames=frames)
     try:
         kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
                 "sg_preprocess_bwd_kernel": 0.03}
@@ -76,6 +76,7 @@ def test_roofline_is_the_whole_pass_hbm_quantity_and_valu_is_secondary(tmp_path)
     finally:
         bench._committed_pmc, bench.pmc_view_traffic = old, oldt
     assert roof["bound"] == "hbm" and roof["scope"] == "whole_pass" and roof["traffic"] == 123456 + 777
+    assert roof["traffic_frames_per_launch"] == 1
     assert roof["algorithmic_bytes_per_view"] == total and roof["peak_spec"] == 8000.0
     assert valu["bound"] == "valu" and valu["kernel"] == "sg_render_bwd_kernel" and valu["valu_wave_instructions_per_launch"] == 8.0e7
     assert abs(valu["frac"] - (8.0e7 / 0.15e-3 / 1e9) / (1024 * 2.4e9 / 2.0 / 1e9)) < 1e-9

@@ -16,8 +16,12 @@ config = {"workload": "raster", "gaussians": 200000, "width": 1920, "height": 10
 for kv in sys.argv[3:]:
     k, v = kv.split("=")
     config[k] = v if k == "workload" else int(v)
+# frames_per_launch=K: the passes ran `--views-per-step K --frames-per-launch K --streams 1` (K frames / cameras per dispatch; the
+# GPU-side reducer of tools/collect_profiles.sh keeps the K-frame dispatches only): the means are divided by K -> per VIEW
+frames = int(config.get("frames_per_launch", 1))
+sched = f"--views-per-step {frames} --frames-per-launch {frames} --streams 1" if frames > 1 else "--views-per-step 1 --streams 1"
 meta = {"config": config, "sources": bench.source_hashes(root),
-        "command": "rocprofv3 --pmc <set> -- python3 bench.py --steps 5 --warmup 2 --views-per-step 1 --streams 1 --no-cpu-baseline"
+        "command": f"rocprofv3 --pmc <set> -- python3 bench.py --steps 5 --warmup 2 {sched} --no-cpu-baseline"
                    + ("" if config["workload"] == "raster" else f" --workload {config['workload']}")}
 
 
@@ -37,7 +41,7 @@ for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
             continue
         a = acc[(short(r["Kernel_Name"]), r["Counter_Name"])]
         n = int(r.get("Count") or 1)                       # (tools/collect_profiles.sh leaves per-(kernel, counter) means + counts)
-        a[0] += float(r["Counter_Value"]) * n; a[1] += n
+        a[0] += float(r["Counter_Value"]) * n / frames; a[1] += n
     out = os.path.join(root, "profiles", f"{tag}_pmc_{cset}.csv")
     with open(out, "w") as fo:
         fo.write("kernel,Counter_Name,mean,count\n")
@@ -55,6 +59,6 @@ if traffic:
     # the headline configuration keeps the historical name; every other configuration gets its own file (bench.py picks the
     # one whose "_meta" matches the run)
     default_cfg = {"workload": "raster", "gaussians": 200000, "width": 1920, "height": 1080, "sh_degree": 3}
-    name = "hbm_traffic.json" if config == default_cfg else f"{tag}_hbm_traffic.json"
+    name = "hbm_traffic.json" if config == default_cfg else f"{tag}_hbm_traffic.json"      # (K-frame passes: tag them, e.g. r04_k8)
     json.dump(traffic, open(os.path.join(root, "profiles", name), "w"), indent=1, sort_keys=True)
     print(f"wrote profiles/{name}", {k: v for k, v in traffic.items() if k != "_meta"})
