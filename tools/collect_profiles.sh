@@ -42,7 +42,7 @@ for w in cfg3 avatar; do
   extra=""; [ $w = avatar ] && extra="--workload avatar"
   $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${w}_k8t -o $w -- python3 $ROOT/bench.py --steps 20 --warmup 5 $K8 --no-cpu-baseline $extra > $OUT/${w}_k8.log 2>&1
   f=$(find $OUT/${w}_k8t -name "*kernel_trace.csv" | head -1)
-  python3 $ROOT/tools/timeline.py $f $OUT/${w}_k8_timeline.csv > /dev/null 2>&1
+  python3 $ROOT/tools/timeline.py $f $OUT/${w}_k8_timeline.csv must=sg_record_sums_kernel > /dev/null 2>&1
   find $OUT/${w}_k8t -name "*kernel_stats.csv" -exec cp {} $OUT/${w}_k8_kernel_stats.csv \;
 done
 $TO rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/avd -o avd -- python3 $ROOT/bench.py --workload avatar --steps 30 --warmup 5 --no-cpu-baseline > $OUT/avd.log 2>&1

@@ -36,8 +36,18 @@ for cset in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
     if not os.path.exists(f):
         continue
     acc = defaultdict(lambda: [0.0, 0])
-    for r in csv.DictReader(open(f)):
-        if not r["Kernel_Name"].startswith(("sg_", "void sg_")):
+    rows = [r for r in csv.DictReader(open(f)) if r["Kernel_Name"].startswith(("sg_", "void sg_"))]
+    names = {short(r["Kernel_Name"]).split("<")[0] for r in rows}
+    # not part of a view: the bandwidth probe of the bench line; and, in a K-frame run, the kernels only its one-view-per-step leg
+    # launches (their K-frame forms have their own names)
+    skip = {"sg_copy_probe_kernel"}
+    if frames > 1:
+        for k1, kk in (("sg_render_fwd_kernel", "sg_render_fwd_frames_kernel"), ("sg_render_fwd_deep_kernel", "sg_render_fwd_frames_kernel"),
+                       ("sg_preprocess_bwd_kernel", "sg_preprocess_bwd_frames_kernel"), ("sg_skin_bwd_kernel", "sg_skin_bwd_frames_kernel")):
+            if kk in names:
+                skip.add(k1)
+    for r in rows:
+        if short(r["Kernel_Name"]).split("<")[0] in skip:
             continue
         a = acc[(short(r["Kernel_Name"]), r["Counter_Name"])]
         n = int(r.get("Count") or 1)                       # (tools/collect_profiles.sh leaves per-(kernel, counter) means + counts)

@@ -1,7 +1,9 @@
 """Per-view kernel timeline from a rocprofv3 --kernel-trace CSV of `bench.py --views-per-step 1 --streams 1`:
 for every kernel of a view (in launch order) its mean duration and the mean GAP between the end of the kernel before it
 and its own start -- kernel boundaries are a tenth of a 350-us view, invisible in `--stats`.
-    python tools/timeline.py <..._kernel_trace.csv> [out.csv]"""
+    python tools/timeline.py <..._kernel_trace.csv> [out.csv] [must=<kernel name prefix>]
+must=...: only steps that contain such a kernel (a K-frame run -- `--frames-per-launch 8 --streams 1` -- also holds the one-view
+steps of the bench's second leg: must=sg_record_sums_kernel picks the K-frame steps; durations are then per K frames)."""
 import csv, re, sys
 from collections import defaultdict
 
@@ -24,6 +26,9 @@ if cur:
 shape = defaultdict(int)
 for v in views:
     shape[tuple(k[2] for k in v)] += 1
+must = [a[5:] for a in sys.argv[3:] if a.startswith("must=")]
+if must:
+    shape = {k: n for k, n in shape.items() if any(x.startswith(must[0]) for x in k)}
 best = max(shape, key=shape.get)
 sel = [v for v in views if tuple(k[2] for k in v) == best][5:]
 out = []
