@@ -75,7 +75,7 @@ def _log(msg):
 
 
 def algorithmic_bytes(N, H, W, R, deg):
-    """SURVEY.md 8(d) per-unit figures, split per kernel."""
+    """SURVEY.md 8(d) per-unit figures, split per kernel (DESIGN.md sections 4-5)."""
     inb = 44 + 12 * (deg + 1) ** 2
     rec, gout, hw = 75, 248, H * W
     per = {

@@ -8,7 +8,7 @@
 
 #define SG_WAVE 64
 // (The compile-time experiment switches of rounds 1-2 -- SG_EXP bits that compiled phases of a kernel out for timing -- are no
-// longer in the product sources; the measurements they produced are in DESIGN.md section 4, the variants in the git history.)
+// longer in the product sources; the measurements they produced are in LAB.md, the variants in the git history.)
 #ifdef SG_EXP
 #error "SG_EXP experiment variants were removed from the product sources"
 #endif

@@ -53,7 +53,7 @@ __device__ __forceinline__ int sg_tile_of_block(int block)
     // without the skew a CU always gets the same position of the run -- the same image column when the image is 32
     // tiles wide -- and the CUs that own an avatar's body columns carry 2.6x the mean load.  (slot / 32) * 7 walks the
     // position through the run from one visit of a CU to the next (max/mean load 1.6).  The avatar forward itself is
-    // bound by its longest tile (39 serial batches), not by this; see DESIGN.md.
+    // bound by its longest tile (39 serial batches), not by this; see LAB.md.
     const int within = (slot + 7 * (slot >> 5)) & (SG_XCD_RUN - 1);
     return ((slot / SG_XCD_RUN) * 8 + xcd) * SG_XCD_RUN + within;
 }
