@@ -168,6 +168,48 @@ def test_raster_frames_equal_single_camera_calls_bit_for_bit(K, deg, W, H):
         assert torch.equal(eng.grad_flat, ref.grad_flat)
 
 
+@pytest.mark.parametrize("deg,W,H", [(3, 640, 368), (2, 320, 192), (0, 160, 96)])
+def test_raster_two_batches_of_a_step_share_one_gradient_buffer(deg, W, H):
+    """accumulate=1 on the K-camera call (the per-Gaussian backward preloads the buffer, then adds its frames in order; dL/dsh sums
+    in LDS): 5 cameras as batches of 3 + 2 into one buffer == 5 single-camera calls chained with accumulate."""
+    from sings_amd.engine import RasterEngine, RasterFramesEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    N, K = 20000, 5
+    s = synthetic_scene(N, W, H, deg, 11)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    views = np.repeat(s["viewmatrix"][None], K, 0).copy(); views[:, 3, 0] = 0.04 * np.arange(K)
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+
+    def settings(vm, pm, cp):
+        return GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                             scale_modifier=1.0, viewmatrix=vm, projmatrix=pm, sh_degree=deg, campos=cp,
+                                             prefiltered=False, debug=False)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(np.random.RandomState(2).normal(0, 1, (K, 3, H, W)).astype(np.float32))
+    cap = 12 * N
+    ref = RasterEngine(N, W, H, 16, dev, cap); ref.throughput = True
+    for f in range(K):
+        ref.set_camera(settings(t(views[f]), t(projs[f]), t(cps[f])))
+        ref.forward(*ins)
+        ref._chain = (lambda f=f: (f > 0, None, None))
+        ref.backward(*ins, dL[f])
+    torch.cuda.synchronize()
+    flat = torch.full_like(ref.grad_flat, float("nan"))
+    a = RasterFramesEngine(N, W, H, 16, 3, dev, cap, grad_flat=flat)
+    b = RasterFramesEngine(N, W, H, 16, 2, dev, cap, grad_flat=flat)
+    for e, lo, hi, acc in ((a, 0, 3, False), (b, 3, 5, True)):
+        e.set_camera(settings(t(views[lo:hi]), t(projs[lo:hi]), t(cps[lo:hi])))
+        e.forward(*ins)
+        e.backward(*ins, dL[lo:hi].contiguous(), accumulate=acc)
+    torch.cuda.synchronize()
+    assert torch.equal(flat, ref.grad_flat)
+    assert float(flat.abs().max()) > 0
+
+
 def test_photo_loss_frames_equal_single_calls():
     from sings_amd.photo_loss import PhotoLossEngine
     dev = _dev()
