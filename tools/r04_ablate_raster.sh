@@ -1,11 +1,11 @@
 #!/bin/bash
-# per-variant duration of one kernel in the K-frame avatar step:  bash tools/r04_ablate_run.sh <kernel substring> <variant> ...
+# per-variant duration of one kernel in the K-frame raster step:  bash tools/r04_ablate_run.sh <kernel substring> <variant> ...
 KERN=$1; shift
 ROOT=$(pwd); cd /tmp && export TMPDIR=/tmp
 for v in base "$@"; do
   OUT=$ROOT/gpurun_out/abl_$v; rm -rf $OUT; mkdir -p $OUT
   if [ $v = base ]; then unset SINGS_HIP_LIB; else export SINGS_HIP_LIB=$ROOT/build/exp/lib_$v.so; fi
-  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 $ROOT/bench.py --workload avatar --steps 10 --warmup 3 --views-per-step 8 --frames-per-launch 8 --streams 1 --no-cpu-baseline > $OUT/log 2>&1
+  timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 $ROOT/bench.py --steps 10 --warmup 3 --views-per-step 8 --frames-per-launch 8 --streams 1 --no-cpu-baseline > $OUT/log 2>&1
   python3 - $OUT $KERN $v <<'PY'
 import csv, sys, glob
 f = glob.glob(sys.argv[1] + "/t/**/*kernel_trace.csv", recursive=True)[0]
