@@ -96,6 +96,58 @@ def test_skinned_frames_equal_single_frame_calls_bit_for_bit(K, per_frame_camera
         assert float((per_frame[0][0] - per_frame[-1][0]).abs().max()) > 1e-3
 
 
+def test_a_frame_that_overflows_its_workspace_is_background_with_zero_gradient_and_harms_no_other_frame():
+    """The pair capacity lies between the smallest and the largest R of the batch: frames that fit render and differentiate as
+    ever, frames that do not render the background, report their (too large) R, and contribute ZERO to the summed gradient --
+    poisoned workspaces prove that nothing stale is followed (the single-frame contract,
+    test_capacity_overflow_is_reported_and_harmless, frame by frame inside one K-frame call)."""
+    from sings_amd.engine import SkinnedFramesEngine
+    dev = _dev()
+    N, J, W, H, K = 20000, 52, 160, 288, 6
+    s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 9, K, False, False)
+    # frames of different weight: the body comes closer to the camera frame by frame
+    transl = transl.clone(); transl[:, 2] -= torch.linspace(0.0, 0.6 * float(transl[0, 2].abs()), K, device=dev) * torch.sign(transl[:, 2])
+    big = SkinnedFramesEngine(N, J, W, H, 16, K, dev, 64 * N)
+    big.set_camera(one[0]); big.set_frames(ins["xyz"], None, ins["w"], A, ins["smpl_scale"], transl)
+    R = big.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+    assert min(R) * 1.05 < max(R), R
+    cap = (sorted(R)[K // 2 - 1] + sorted(R)[K // 2]) // 2           # half of the frames fit
+    fits = [r <= cap for r in R]
+    assert any(fits) and not all(fits)
+    # reference: the fitting frames alone, as one batch each, accumulated in frame order
+    flat_ref = torch.zeros_like(big.grad_flat)
+    first = True
+    imgs = {}
+    for f in range(K):
+        if not fits[f]:
+            continue
+        e1 = SkinnedFramesEngine(N, J, W, H, 16, 1, dev, cap, grad_flat=flat_ref)
+        e1.set_camera(one[0]); e1.set_frames(ins["xyz"], None, ins["w"], A[f:f + 1].contiguous(), ins["smpl_scale"], transl[f:f + 1].contiguous())
+        assert e1.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True) == [R[f]]
+        e1.backward(ins["sh"], ins["op"], ins["sc"], dL[f:f + 1].contiguous(), accumulate=not first)
+        first = False
+        torch.cuda.synchronize()
+        imgs[f] = e1.color[0].clone()
+    eng = SkinnedFramesEngine(N, J, W, H, 16, K, dev, cap)
+    for buf in (eng.geom, eng.img, eng.bwd_ws):
+        buf.fill_(0xA5)                                               # stale contents must never be followed
+    eng.binning.view(K, -1)[:, eng.L.bin_ranges:].fill_(0xA5)
+    eng.set_camera(one[0]); eng.set_frames(ins["xyz"], None, ins["w"], A, ins["smpl_scale"], transl)
+    Rs = eng.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+    eng.backward(ins["sh"], ins["op"], ins["sc"], dL)
+    torch.cuda.synchronize()
+    assert Rs == R                                                  # every frame reports its true pair count
+    bg = torch.from_numpy(np.ascontiguousarray(s["bg"])).to(dev)
+    for f in range(K):
+        if fits[f]:
+            assert torch.equal(eng.color[f], imgs[f]), f
+        else:
+            assert torch.equal(eng.color[f], bg[:, None, None].expand(3, H, W)), f
+            assert float(eng.d_means2D[f].abs().max()) == 0.0 and float(eng.d_A[f].abs().max()) == 0.0, f
+    assert torch.isfinite(eng.grad_flat).all()
+    assert torch.equal(eng.grad_flat, flat_ref)
+
+
 def test_two_batches_of_a_step_share_one_gradient_buffer():
     """accumulate=1 on the K-frame call: a step of 6 frames as batches of 4 + 2 into one buffer == 6 single-frame calls."""
     from sings_amd.engine import SkinnedEngine, SkinnedFramesEngine
