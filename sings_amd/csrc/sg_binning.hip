@@ -709,7 +709,11 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
     // kernel needs its limit raised -- per DEVICE and not remembered in a process-wide flag (a second GPU used from the same
     // process, or a failed call, must not leave the launch below without it): asked for whenever it is needed (a host-side
     // table update, no stream operation), and if the runtime refuses, the two-kernel path below does the same job.
-    bool fused = T <= SG_SS_MAX_TILES;
+    // K > 1 frames of MANY tiles take the two-kernel path as well: in the fused kernel every workgroup repeats the scan of the T tile
+    // counts in front of its share of the scatter -- the price of saving a launch when ONE frame's 211 workgroups are all the GPU
+    // has; with K x 211 workgroups queued a 10-us scan kernel (one workgroup row per frame) + a plain scatter are faster (cfg3, 8
+    // cameras: 10.4 + 78.0 against 110.9 us; few-tile frames: 75.6 against 77.0, left fused)
+    bool fused = T <= SG_SS_MAX_TILES && (K == 1 || sg_lds_hist(c.gx, c.gy));
     if (fused && (size_t)T * 4 + 1024 > 64 * 1024)
         fused = sg_dyn_lds_limit(0, (const void *)sg_scan_scatter_kernel, SG_SS_MAX_TILES * 4);
     if (fused) {
