@@ -380,7 +380,7 @@ class _FramesBase:
         self.color = torch.empty((self.K, 3, self.H, self.W), **f32)
         self.radii = torch.empty((self.K, self.P), dtype=torch.int32, device=self.dev)
         self.d_means2D = torch.empty((self.K, self.P, 3), **f32)
-        self._keep, self._s, self._fb = [], None, None
+        self._keep, self._s, self._fb, self._cam_stride = [], None, None, 0
         self.throughput = True            # K frames share the chip: no latency-only work (SG_FLAG_THROUGHPUT), as in ViewBatch
         self._chain = None                # inside ViewBatch.run (a batch of frames is one "view" of the ViewBatch): see RasterEngine
 
@@ -490,6 +490,8 @@ class SkinnedFramesEngine(_FramesBase):
     def forward(self, shs, opacities, scales, sync_num_rendered=False, phase=None):
         """``phase``: None = the whole forward; "binning" / "composite" = its two halves as separate calls on the same workspaces
         (SG_FLAG_FORWARD_BINNING / _COMPOSITE), for a caller that runs them on different streams and orders them with events."""
+        if self._s is None or self._fb is None or self._k is None:
+            raise RuntimeError("SkinnedFramesEngine: set_camera() and set_frames() first")
         nr = (C.c_int64 * self.K)()
         self._fb.camera_stride = self._cam_stride
         self._s.flags = self._flags() | {None: 0, "binning": _lib.FLAG_FORWARD_BINNING, "composite": _lib.FLAG_FORWARD_COMPOSITE}[phase]
@@ -558,6 +560,8 @@ class RasterFramesEngine(_FramesBase):
         self._fb = _frame_batch(self.K, self._cam_stride, 0)
 
     def forward(self, means3D, shs, opacities, scales, rotations, sync_num_rendered=False):
+        if self._s is None or self._fb is None:
+            raise RuntimeError("RasterFramesEngine: set_camera() first")
         nr = (C.c_int64 * self.K)()
         self._s.flags = self._hint | self._flags()
         self._clean = False
