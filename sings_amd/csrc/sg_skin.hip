@@ -305,7 +305,10 @@ sg_skin_fwd_kernel(SgCam c, SgBatch bt, int P, SgSkin k, const float *__restrict
 // per workgroup: partial dL/dA [Jp x 16] (matrix cores) and dL/dtransl [3] written to a slab
 // (reduced by sg_skin_reduce_kernel -- no atomics, deterministic).
 template <int D, bool ACC>
-__global__ void __launch_bounds__(SG_SKIN_THREADS)
+// D = 0 (what SinGS trains at): three waves per SIMD.  Unconstrained hipcc takes 196 registers = two waves per SIMD = 2 048 resident
+// waves, and an avatar of 150 k Gaussians is 2 344 waves: a second, 14 %-full round (the kernel is latency-bound: a round costs what
+// a wave costs).  With the hint it fits 168 registers without scratch.  D >= 1 would spill (36-52 B at D = 1): left alone.
+__global__ void __launch_bounds__(SG_SKIN_THREADS) __attribute__((amdgpu_waves_per_eu(D == 0 ? 3 : 1, D == 0 ? 3 : 10)))
 sg_skin_bwd_kernel(SgCam c, int P, SgSkin k, const float *__restrict__ shs, const float *__restrict__ scales,
                    const int32_t *__restrict__ radii, SgGeom g, SgRec grec, size_t cap,
                    const uint32_t *__restrict__ header, const uint8_t *__restrict__ rec_valid, const float *__restrict__ dposed_xyz_in, const float *__restrict__ dposed_rotq_in,
