@@ -122,7 +122,7 @@ def parse_args():
     ap.add_argument("--graph", action="store_true", help="raster workload: replay the step from a captured HIP graph")
     ap.add_argument("--views-per-step", type=int, default=None,
                     help="raster workload: views each rank renders (gradients summed locally) per step and all-reduce; 1 = the "
-                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views.  Default: 16 (the "
+                         "reference's one frame per step.  k > 1 amortises the 47 MB all-reduce over k views.  Default: raster 16, avatar 24 (16 is the "
                          "reference's chunk: SinGS.forward_chunk hands the model 16 frames per call)")
     ap.add_argument("--frames-per-launch", type=int, default=None,
                     help="frames (avatar) / cameras (raster) of the same Gaussians rendered by ONE dispatch per kernel (the *_frames "
@@ -162,10 +162,13 @@ def parse_args():
     # launches of 8 frames / cameras on 2 streams.  raster: 4 088-4 131 views/s (8 views, one camera per launch, 3 streams -- the round-3
     # schedule, --views-per-step 8 --frames-per-launch 1 --streams 3 --: 3 887; one launch of 8: 4 085); avatar: 5 820-5 845 frames/s
     # (one launch of 8: 4 940; 24 frames on 3 streams: 5 930-6 005)
+    # avatar: 24 frames = three launches of 8 on three streams -- 5 930-6 010 against 5 770-5 940 frames/s for 16 / 2: the latency-bound
+    # per-Gaussian kernels of an avatar end in partly filled rounds (2 344 waves on 2 048 slots) which a third stream fills; the
+    # raster step gains nothing from a third stream (its composites saturate the vector issue on their own)
     if a.views_per_step is None:
-        a.views_per_step = 16
+        a.views_per_step = 24 if a.workload == "avatar" else 16
     if a.streams is None:
-        a.streams = 2
+        a.streams = 3 if a.workload == "avatar" else 2
     return a
 
 
