@@ -10,17 +10,19 @@ exits non-zero if any rank failed.  Under `python -m torch.distributed.run --npr
 ranks are already there; either way every rank checks `world == --gpus` and the line carries what the collective layer
 saw (`rccl_world`, `dist_backend`).
 
-One "step" = one pass of the hot path over one BATCH of views per rank (default 8 views, `--views-per-step`): for
-every view the rasterizer forward (preprocess -> tile binning -> alpha composite) + backward (composite bwd ->
-per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated, nothing synchronises inside
-the timed region; the views of a batch are dealt round-robin to `--streams` HIP streams (default 3: the latency-bound
-binning kernels and the tile-imbalance tails of one view overlap the composite of the others) and their gradient rows
-are folded in one pass once the views have joined (sings_amd.dp.GradientPipeline).
+One "step" = one pass of the hot path over one BATCH of views per rank (default 16 views, `--views-per-step`; every view of a
+step carries the same work: cameras a few centimetres apart): the rasterizer forward (preprocess -> tile binning -> alpha
+composite) + backward (composite bwd -> per-Gaussian bwd) through the C ABI, inputs resident in HBM, workspaces pre-allocated,
+nothing synchronises inside the timed region.  The views go out as launches of `--frames-per-launch` cameras of the same
+Gaussians (default 8: ONE dispatch per kernel for the 8 cameras -- the *_frames entry points), the launches are dealt to
+`--streams` HIP streams (default 2) and their gradient rows are folded in one pass once they have joined
+(sings_amd.dp.GradientPipeline).  `--views-per-step 8 --frames-per-launch 1 --streams 3` is the round-3 schedule (one engine per
+view).
 `--views-per-step 1 --streams 1` is the reference's one frame per step (gs_trainer.py:207-215); the default run times
 that too, after the batched region, and reports it as `train_step_ms_one_view`.  With N > 1 every (rank, view) pair
 renders a DIFFERENT camera of the same Gaussians (frame-parallel) and the ranks sum the canonical-Gaussian gradients of
 the batch with ONE RCCL all-reduce per step (in chunks, each behind its part of the fold), i.e. the 47 MB all-reduce is paid
-once per 8 views ("scaling": "weak": the batch per rank is fixed).
+once per step of 16 views ("scaling": "weak": the batch per rank is fixed).
 
 Prints ONE JSON line (rank 0).  Besides the driver's contract it carries
   roofline      - SURVEY.md 8(d): bound "hbm", the WHOLE pass of a view -- algorithmic bytes per view / seconds per view against
