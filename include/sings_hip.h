@@ -322,7 +322,8 @@ int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s, const SgFr
                                            const float *shs, const float *colors_precomp, const float *opacities,
                                            const float *scales, const float *rotations, const float *cov3D_precomp,
                                            const int32_t *radii, const void *geom_ws, const void *binning_ws,
-                                           size_t capacity_pairs, const void *bwd_ws, int accumulate, float *dL_dmeans3D,
+                                           size_t capacity_pairs, void *bwd_ws /* records in; K > 1: its tail is scratch */,
+                                           int accumulate, float *dL_dmeans3D,
                                            float *dL_dmeans2D, float *dL_dsh, float *dL_dcolors, float *dL_dopacity,
                                            float *dL_dscales, float *dL_drotations, float *dL_dcov3D, void *stream);
 size_t sg_skin_ws_floats_frames(int P, int K);

@@ -362,7 +362,7 @@ extern "C" int sg_rasterize_backward_gaussians_frames(const SgRasterSettings *s,
                                                       const float *shs, const float *colors_precomp, const float *opacities,
                                                       const float *scales, const float *rotations, const float *cov3D_precomp,
                                                       const int32_t *radii, const void *geom_ws, const void *binning_ws, size_t cap,
-                                                      const void *bwd_ws, int accumulate, float *dL_dmeans3D, float *dL_dmeans2D,
+                                                      void *bwd_ws, int accumulate, float *dL_dmeans3D, float *dL_dmeans2D,
                                                       float *dL_dsh, float *dL_dcolors, float *dL_dopacity, float *dL_dscales,
                                                       float *dL_drotations, float *dL_dcov3D, void *stream)
 {
@@ -397,7 +397,7 @@ extern "C" int sg_rasterize_backward_gaussians(const SgRasterSettings *s, int P,
                                                float *dL_dcov3D, void *stream)
 {
     return sg_rasterize_backward_gaussians_frames(s, &SG_ONE_FRAME, P, means3D, shs, colors_precomp, opacities, scales, rotations,
-                                                  cov3D_precomp, radii, geom_ws, binning_ws, cap, bwd_ws, accumulate, dL_dmeans3D,
+                                                  cov3D_precomp, radii, geom_ws, binning_ws, cap, (void *)bwd_ws /* K = 1: read only */, accumulate, dL_dmeans3D,
                                                   dL_dmeans2D, dL_dsh, dL_dcolors, dL_dopacity, dL_dscales, dL_drotations, dL_dcov3D,
                                                   stream);
 }
