@@ -262,6 +262,68 @@ def test_raster_two_batches_of_a_step_share_one_gradient_buffer(deg, W, H):
     assert float(flat.abs().max()) > 0
 
 
+def test_a_step_of_four_launches_on_two_streams_sums_like_twelve_single_views():
+    """What bench.py does with more launches than streams: ViewBatch deals 4 launches of 3 cameras to 2 streams, one gradient row per
+    stream -- the second launch of a stream ADDS to its row (accumulate, decided at backward time) -- and the fold sums the rows.
+    The result must be the sum of the 12 views' gradients: rows are compared bit for bit with single-camera chains in the same
+    order, the folded sum with their fold."""
+    from sings_amd.engine import RasterEngine, RasterFramesEngine, ViewBatch
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    N, W, H, deg, K, B, S = 15000, 320, 192, 3, 3, 4, 2
+    s = synthetic_scene(N, W, H, deg, 5)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    V = K * B
+    views = np.repeat(s["viewmatrix"][None], V, 0).copy(); views[:, 3, 0] = 0.01 * np.arange(V)
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+
+    def settings(vm, pm, cp):
+        return GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                             scale_modifier=1.0, viewmatrix=vm, projmatrix=pm, sh_degree=deg, campos=cp,
+                                             prefiltered=False, debug=False)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(np.random.RandomState(3).normal(0, 1, (V, 3, H, W)).astype(np.float32))
+    cap = 12 * N
+    per_view = N * (3 + 3 + 4 + 1 + 3 * 16)
+    grads = ViewBatch.gradient_rows(S, per_view, dev)
+    grads.fill_(float("nan"))
+    engs = []
+    for b in range(B):
+        e = RasterFramesEngine(N, W, H, 16, K, dev, cap, grad_flat=grads[b % S])
+        lo = b * K
+        e.set_camera(settings(t(views[lo:lo + K]), t(projs[lo:lo + K]), t(cps[lo:lo + K])))
+        engs.append(e)
+    batch = ViewBatch(engs, grads, S)
+
+    def one(b, e):
+        e.forward(*ins)
+        e.backward(*ins, dL[b * K:(b + 1) * K].contiguous())
+    for rep in range(2):                                            # twice: nothing of the first step may leak into the second
+        acc = batch.run(one).clone()
+        torch.cuda.synchronize()
+    # reference: per stream row, the views of its launches in launch order, chained with accumulate
+    ref_rows = []
+    for r in range(S):
+        ref = RasterEngine(N, W, H, 16, dev, cap); ref.throughput = True
+        first = True
+        for b in range(r, B, S):
+            for f in range(K):
+                v = b * K + f
+                ref.set_camera(settings(t(views[v]), t(projs[v]), t(cps[v])))
+                ref.forward(*ins)
+                ref._chain = (lambda first=first: (not first, None, None))
+                ref.backward(*ins, dL[v])
+                first = False
+        torch.cuda.synchronize()
+        ref_rows.append(ref.grad_flat.clone())
+        assert torch.equal(grads[r], ref_rows[r]), f"row {r}"
+    assert torch.equal(acc, ref_rows[0] + ref_rows[1])
+    assert torch.isfinite(acc).all() and float(acc.abs().max()) > 0
+
+
 def test_photo_loss_frames_equal_single_calls():
     from sings_amd.photo_loss import PhotoLossEngine
     dev = _dev()
