@@ -324,6 +324,78 @@ def test_a_step_of_four_launches_on_two_streams_sums_like_twelve_single_views():
     assert torch.isfinite(acc).all() and float(acc.abs().max()) > 0
 
 
+def test_frames_through_the_c_abi_with_precomputed_colours_and_covariances():
+    """colors_precomp + cov3D_precomp (the op surface's two optional inputs) through the K-frame entry points
+    themselves -- no engine class wraps these: 3 cameras in one call against three K = 1 calls chained with accumulate, bit for
+    bit, gradients of the colours and the covariances included."""
+    import ctypes as C
+    from oracle import raster_oracle as ro
+    from sings_amd import _lib
+    from sings_amd.engine import _frame_batch
+    from sings_amd.rasterizer import GaussianRasterizationSettings, _ptr, _settings_struct
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    lib = _lib.load()
+    N, W, H, K = 6000, 256, 160, 3
+    s = synthetic_scene(N, W, H, 0, 21)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    colors = np.random.RandomState(1).uniform(0, 1, (N, 3)).astype(np.float32)
+    o = ro.forward(s["means3D"], s["opacities"], s["viewmatrix"], s["projmatrix"], s["campos"], W, H, s["tanfovx"], s["tanfovy"], s["bg"],
+                   colors_precomp=colors, scales=s["scales"], rotations=s["rotations"])
+    means, op, col, cov = t(s["means3D"]), t(s["opacities"]), t(colors), t(o["cov3D"])
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    views = np.repeat(s["viewmatrix"][None], K, 0).copy(); views[:, 3, 0] = 0.03 * np.arange(K)
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+    dL = t(np.random.RandomState(2).normal(0, 1, (K, 3, H, W)).astype(np.float32))
+    cap = 16 * N
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+    def run(k, lo, grads, accumulate):
+        """cameras lo .. lo + k of the batch in ONE call; returns (images, radii, dL_dmeans2D)"""
+        keep = []
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                           scale_modifier=1.0, viewmatrix=t(views[lo:lo + k]), projmatrix=t(projs[lo:lo + k]),
+                                           sh_degree=0, campos=t(cps[lo:lo + k]), prefiltered=False, debug=False)
+        st = _settings_struct(rs, dev, 0, keep)
+        fb = _frame_batch(k, 1, 0)
+        L = _lib.SgLayout(); sizes = [C.c_size_t() for _ in range(4)]
+        _lib.check(lib.sg_frames_layout(N, W, H, cap, k, C.byref(L), *[C.byref(x) for x in sizes]), "layout")
+        u8 = dict(dtype=torch.uint8, device=dev)
+        geom, binning, img, bwd = (torch.zeros(x.value, **u8) for x in sizes)
+        color = torch.empty((k, 3, H, W), device=dev); radii = torch.empty((k, N), dtype=torch.int32, device=dev)
+        m2 = torch.empty((k, N, 3), device=dev)
+        nr = (C.c_int64 * k)()
+        _lib.check(lib.sg_rasterize_forward_frames(C.byref(st), C.byref(fb), N, _ptr(means), None, _ptr(col), _ptr(op), None, None, _ptr(cov),
+                                                   _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii), nr, stream), "fwd")
+        assert all(0 < int(v) <= cap for v in nr)
+        _lib.check(lib.sg_rasterize_backward_records_frames(C.byref(st), C.byref(fb), N, _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(bwd),
+                                                            _ptr(dL[lo:lo + k].contiguous()), stream), "bwd records")
+        _lib.check(lib.sg_rasterize_backward_gaussians_frames(
+            C.byref(st), C.byref(fb), N, _ptr(means), None, _ptr(col), _ptr(op), None, None, _ptr(cov), _ptr(radii), _ptr(geom),
+            _ptr(binning), cap, _ptr(bwd), int(accumulate), _ptr(grads["means"]), _ptr(m2), None, _ptr(grads["col"]), _ptr(grads["op"]),
+            None, None, _ptr(grads["cov"]), stream), "bwd gaussians")
+        torch.cuda.synchronize()
+        return color, radii, m2
+
+    def buffers():
+        nan = float("nan")
+        return dict(means=torch.full((N, 3), nan, device=dev), col=torch.full((N, 3), nan, device=dev),
+                    op=torch.full((N, 1), nan, device=dev), cov=torch.full((N, 6), nan, device=dev))
+    ref = buffers()
+    singles = [run(1, f, ref, f > 0) for f in range(K)]
+    got = buffers()
+    color, radii, m2 = run(K, 0, got, False)
+    for f in range(K):
+        assert torch.equal(color[f], singles[f][0][0]) and torch.equal(radii[f], singles[f][1][0]) and torch.equal(m2[f], singles[f][2][0]), f
+    for k in ref:
+        assert torch.isfinite(got[k]).all() and torch.equal(got[k], ref[k]), k
+    assert float(got["cov"].abs().max()) > 0 and float(got["col"].abs().max()) > 0
+    # and the single camera 0 agrees with the oracle's image (the precomputed inputs really are what was rendered)
+    border = o["margin"] < 2e-5 if "margin" in o else np.zeros((H, W), bool)
+    assert np.abs(singles[0][0][0].cpu().numpy() - o["color"]).max(0)[~border].max() <= 1e-5
+
+
 def test_photo_loss_frames_equal_single_calls():
     from sings_amd.photo_loss import PhotoLossEngine
     dev = _dev()
