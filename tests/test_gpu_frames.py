@@ -324,6 +324,39 @@ def test_a_step_of_four_launches_on_two_streams_sums_like_twelve_single_views():
     assert torch.isfinite(acc).all() and float(acc.abs().max()) > 0
 
 
+def test_posed_side_outputs_of_a_k_frame_forward():
+    """posed_xyz / posed_rotq / posed_scales [K,P,.] of sg_skinned_forward_frames (what the unfused callers of row a8 read back:
+    sings_hybrid.py:400-419) equal the single-frame call's, frame by frame, for isotropic and 6-D-rotation avatars."""
+    import ctypes as C
+    from sings_amd import _lib
+    from sings_amd.engine import SkinnedFramesEngine
+    from sings_amd.rasterizer import _ptr
+    dev = _dev()
+    lib = _lib.load()
+    N, J, W, H, K = 9000, 52, 128, 224, 4
+    for with_rot in (False, True):
+        s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 13, K, False, with_rot)
+        cap = 24 * N
+
+        def posed(k, lo):
+            e = SkinnedFramesEngine(N, J, W, H, 16, k, dev, cap, with_rot=with_rot, rot_width=6)
+            e.set_camera(one[0]); e.set_frames(ins["xyz"], ins["rot"], ins["w"], A[lo:lo + k].contiguous(), ins["smpl_scale"], transl[lo:lo + k].contiguous())
+            px = torch.full((k, N, 3), float("nan"), device=dev); pq = torch.full((k, N, 4), float("nan"), device=dev)
+            ps = torch.full((k, N, 3), float("nan"), device=dev)
+            e._s.flags = e._flags()
+            _lib.check(lib.sg_skinned_forward_frames(C.byref(e._s), C.byref(e._fb), N, C.byref(e._k), _ptr(ins["sh"]), _ptr(ins["op"]), _ptr(ins["sc"]),
+                                                     _ptr(e.geom), _ptr(e.binning), cap, _ptr(e.img), _ptr(e.color), _ptr(e.radii), _ptr(px), _ptr(pq),
+                                                     _ptr(ps), None, e._stream()), "forward with posed outputs")
+            torch.cuda.synchronize()
+            return px, pq, ps
+        px, pq, ps = posed(K, 0)
+        assert torch.isfinite(px).all() and torch.isfinite(pq).all() and torch.isfinite(ps).all()
+        for f in range(K):
+            x1, q1, s1 = posed(1, f)
+            assert torch.equal(px[f], x1[0]) and torch.equal(pq[f], q1[0]) and torch.equal(ps[f], s1[0]), (with_rot, f)
+        assert float((px[0] - px[K - 1]).abs().max()) > 1e-3
+
+
 def test_frames_through_the_c_abi_with_precomputed_colours_and_covariances():
     """colors_precomp + cov3D_precomp (the op surface's two optional inputs) through the K-frame entry points
     themselves -- no engine class wraps these: 3 cameras in one call against three K = 1 calls chained with accumulate, bit for
