@@ -533,10 +533,11 @@ class RasterFramesEngine(_FramesBase):
     """Un-skinned path: K cameras of the same Gaussians per call (``sg_rasterize_*_frames``).  Flat gradient layout as
     ``RasterEngine``; ``color`` [K,3,H,W], ``radii`` [K,P], ``d_means2D`` [K,P,3]."""
 
-    def __init__(self, P, W, H, sh_coeffs, K, device, capacity_pairs, grad_flat=None):
+    def __init__(self, P, W, H, sh_coeffs, K, device, capacity_pairs, grad_flat=None, sh_planar=False):
         self.dev = torch.device(device)
         self.M = int(sh_coeffs)
-        self._alloc(P, W, H, K, capacity_pairs)
+        self.sh_planar = bool(sh_planar)        # dL/dsh coefficient-major [M,P,3] (the SH block is LAST in this layout: the planes in
+        self._alloc(P, W, H, K, capacity_pairs)  # use are a prefix of it, active_floats(deg) floats of grad_flat carry gradient)
         f32 = dict(dtype=torch.float32, device=self.dev)
         per = 3 + 3 + 4 + 1 + 3 * self.M
         if grad_flat is not None and (grad_flat.numel() != self.P * per or grad_flat.dtype != torch.float32
@@ -551,7 +552,13 @@ class RasterFramesEngine(_FramesBase):
             return v
         self.d_means3D = carve(self.P * 3, self.P, 3); self.d_scales = carve(self.P * 3, self.P, 3)
         self.d_rots = carve(self.P * 4, self.P, 4); self.d_opacity = carve(self.P, self.P, 1)
-        self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3) if self.M else None
+        self._head = o
+        if not self.M:
+            self.d_sh = None
+        elif self.sh_planar:
+            self.d_sh = carve(self.P * 3 * self.M, self.M, self.P, 3)
+        else:
+            self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
         self._hint = 0
 
     def set_camera(self, raster_settings, short_lists=False):

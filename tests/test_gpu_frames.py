@@ -456,6 +456,46 @@ def test_photo_loss_frames_equal_single_calls():
         assert torch.equal(g2[f], gf) and torch.equal(shared.losses[f], one.losses), f
 
 
+@pytest.mark.parametrize("deg", [2, 3])
+def test_planar_sh_gradients_of_the_k_camera_raster_call(deg):
+    """The same flag on the un-skinned K-camera call (``RasterFramesEngine(sh_planar=True)``): (deg+1)^2 planes written, equal to the
+    default layout's rows transposed, with and without accumulate (the planar preload of the per-Gaussian backward)."""
+    from sings_amd.engine import RasterFramesEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    N, W, H, K = 12000, 320, 192, 3
+    s = synthetic_scene(N, W, H, deg, 17)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    views = np.repeat(s["viewmatrix"][None], K, 0).copy(); views[:, 3, 0] = 0.02 * np.arange(K)
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                       scale_modifier=1.0, viewmatrix=t(views), projmatrix=t(projs), sh_degree=deg, campos=t(cps),
+                                       prefiltered=False, debug=False)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(np.random.RandomState(4).normal(0, 1, (K, 3, H, W)).astype(np.float32))
+    nc = (deg + 1) ** 2
+
+    def run(planar, accumulate):
+        e = RasterFramesEngine(N, W, H, 16, K, dev, 12 * N, sh_planar=planar)
+        e.set_camera(rs)
+        e.grad_flat.fill_(0.5 if accumulate else float("nan"))
+        e.forward(*ins)
+        e.backward(*ins, dL, accumulate=accumulate)
+        torch.cuda.synchronize()
+        return e
+    for accumulate in (False, True):
+        a, b = run(False, accumulate), run(True, accumulate)
+        assert b.active_floats(deg) == N * (11 + 3 * nc) and a.active_floats(deg) == N * 59
+        for x, y in ((a.d_means3D, b.d_means3D), (a.d_scales, b.d_scales), (a.d_rots, b.d_rots), (a.d_opacity, b.d_opacity)):
+            assert torch.equal(x, y)
+        assert torch.equal(a.d_sh[:, :nc, :].permute(1, 0, 2), b.d_sh[:nc]) and float(b.d_sh[:nc].abs().max()) > 0
+        rest = b.d_sh[nc:]
+        assert bool((rest == 0.5).all()) if accumulate else bool(torch.isnan(rest).all())       # planes not in use: never touched
+
+
 def test_frames_api_rejects_bad_batches():
     from sings_amd.engine import SkinnedFramesEngine
     dev = _dev()
