@@ -3,7 +3,7 @@
 K=${1:-8}; S=${2:-1}; V=${3:-8}
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/prof_r04_avatar_K${K}_S${S}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 $ROOT/bench.py --workload avatar --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S --no-cpu-baseline > $OUT/log 2>&1
+timeout 180 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t -o t -- python3 $ROOT/bench.py --workload avatar $EXTRA --steps 20 --warmup 5 --views-per-step $V --frames-per-launch $K --streams $S --no-cpu-baseline > $OUT/log 2>&1
 find $OUT -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 f=$(find $OUT/t -name "*kernel_trace.csv" | head -1)
 python3 - $f $OUT/timeline.txt <<'PY'
