@@ -10,6 +10,8 @@
    ``streams > 1`` renders that many frames at a time on separate HIP streams through pre-allocated engines
    (``FrameAnimator``): an avatar frame is a chain of short, latency-bound kernels and a few very long tile lists, so
    frames in flight together fill the GPU (150k-Gaussian avatar, 120 frames: 3 100 -> 8 550 frames/s with 4 streams).
+   ``frames_per_launch = K`` (round 4): K consecutive frames of the chunk per DISPATCH through ``SkinnedFramesEngine`` -- what
+   ``SinGS.forward_chunk`` + the render loop of gs_trainer.py:684-714 do for a chunk of 16 frames, in one pass over the kernels.
 """
 import numpy as np
 import torch
@@ -213,17 +215,121 @@ class FrameAnimator:
             yield pop()
 
 
+    # ---- K frames of the same Gaussians per dispatch (round 4: sings_amd.engine.SkinnedFramesEngine) -------------------------
+    def _frame_engines(self, J, W, H, K, cap):
+        from .engine import SkinnedFramesEngine
+        c = self.canon
+        P, M = int(c['xyz_canon'].shape[0]), int(c['shs'].shape[1])
+        rot = c.get('rotmat_canon')
+        key = (P, J, W, H, M, K, None if rot is None else int(rot.reshape(P, -1).shape[1]))
+        if getattr(self, "_fshape", None) != key or cap > getattr(self, "_fcap", 0):
+            self._fengs = []
+            self._fengs = [SkinnedFramesEngine(P, J, W, H, M, K, self.dev, capacity_pairs=cap, with_rot=rot is not None,
+                                               rot_width=9 if rot is None else key[6]) for _ in range(self.n)]
+            self._fshape, self._fcap = key, cap
+        return self._fengs
+
+    def render_frames_batched(self, jobs, bg_color, frames_per_launch=8, scaling_modifier=1.0):
+        """``render_frames`` with K = ``frames_per_launch`` consecutive frames per DISPATCH: the reference's chunk
+        (``SinGS.forward_chunk``, sings_hybrid.py:474-569, rendered one frame at a time at gs_trainer.py:684-714) goes through
+        every kernel of the forward once -- canonical inputs read once for the K poses, K frames' worth of workgroups for the
+        latency-bound kernels.  One launch per stream in flight.  Jobs as in ``render_round`` but WITHOUT ``ext_tfs`` (the K-frame
+        entry points take none) and with one ``smpl_scale`` for the batch; the cameras of a batch may differ.  Yields
+        (index, clamped image) in order; images are bit-identical to the per-frame path's."""
+        from collections import deque
+        c = self.canon
+        K = max(1, min(int(frames_per_launch), 16))
+        cur = torch.cuda.current_stream(self.dev)
+        P = int(c['xyz_canon'].shape[0])
+        q = deque()
+        state = dict(b=0)
+
+        def launch(i0, batch, e, st):
+            k = len(batch)
+            cams = [j[0] for j in batch]
+            A = torch.stack([j[1].reshape(-1, 16) for j in batch] + [batch[-1][1].reshape(-1, 16)] * (K - k)).contiguous()
+            tr = None
+            if batch[0][2] is not None:
+                tr = torch.stack([j[2].reshape(3) for j in batch] + [batch[-1][2].reshape(3)] * (K - k)).contiguous()
+            st.wait_stream(cur)                                  # the jobs' tensors were produced on the caller's stream
+            with torch.cuda.stream(st):
+                rs = _settings(cams[0], bg_color, scaling_modifier, c['active_sh_degree'])
+                if any(cm is not cams[0] for cm in cams):        # per-frame cameras: stacked [K,4,4] / [K,3]
+                    pad = cams + [cams[-1]] * (K - k)
+                    rs = rs._replace(viewmatrix=torch.stack([cm['world_view_transform'] for cm in pad]).contiguous(),
+                                     projmatrix=torch.stack([cm['full_proj_transform'] for cm in pad]).contiguous(),
+                                     campos=torch.stack([cm['camera_center'] for cm in pad]).contiguous())
+                e.set_camera(rs)
+                e.set_frames(c['xyz_canon'], c.get('rotmat_canon'), c['lbs_weights'], A, batch[0][3], tr)
+                e.forward(c['shs'], c['opacity'], c['scales'])
+                img = torch.clamp(e.color, 0.0, 1.0)             # [K,3,H,W]: a new tensor, the engine's image buffer is reused
+                ev = torch.cuda.Event(); ev.record(st)
+            img.record_stream(cur)
+            return img, ev
+
+        def submit(i0, batch):
+            for j in batch:
+                if j[4] is not None:
+                    raise ValueError("render_frames_batched: ext_tfs are not supported by the K-frame entry points "
+                                     "(use render_frames)")
+                if j[3] is not batch[0][3] and not (j[3] is not None and batch[0][3] is not None and torch.equal(j[3], batch[0][3])):
+                    raise ValueError("render_frames_batched: one smpl_scale per batch of frames")
+            J = int(batch[0][1].reshape(-1, 16).shape[0])
+            W, H = int(batch[0][0]['image_width']), int(batch[0][0]['image_height'])
+            cap = max(getattr(self, "_fcap", 0), 8 * P + ((W + 15) // 16) * ((H + 15) // 16), 1 << 16)
+            engs = self._frame_engines(J, W, H, K, cap)
+            e, st = engs[state['b'] % self.n], self.streams[state['b'] % self.n]
+            state['b'] += 1
+            img, ev = launch(i0, batch, e, st)
+            q.append((i0, batch, img, ev, e, st))
+
+        def pop():
+            i0, batch, img, ev, e, st = q.popleft()
+            ev.synchronize()
+            with torch.cuda.stream(st):
+                Rs = e.num_rendered()                            # (this engine has nothing else queued: one launch per engine)
+            if max(Rs[:len(batch)]) > e.cap:                     # rare: grow the workspaces, render this batch again
+                torch.cuda.synchronize(self.dev)
+                need = max(Rs[:len(batch)])
+                J, W, H = self._fshape[1], self._fshape[2], self._fshape[3]
+                e2 = self._frame_engines(J, W, H, K, need + need // 4 + 1024)[0]
+                img, ev = launch(i0, batch, e2, self.streams[0])
+                torch.cuda.synchronize(self.dev)
+            for k in range(len(batch)):
+                yield i0 + k, img[k]
+
+        batch, i0, i = [], 0, 0
+        for i, job in enumerate(jobs):
+            if not batch:
+                i0 = i
+            batch.append(job)
+            if len(batch) == K:
+                while len(q) >= self.n:
+                    yield from pop()
+                submit(i0, batch)
+                batch = []
+        if batch:
+            while len(q) >= self.n:
+                yield from pop()
+            submit(i0, batch)
+        while q:
+            yield from pop()
+
+
 @torch.no_grad()
 def animate_chunk(canon, poses, joints_rest, A_t2cano, cameras, bg_color, transl=None, smpl_scale=None, ext_tfs=None,
-                  parents=SMPL_PARENTS, chunk_size=16, streams=1, animator=None):
+                  parents=SMPL_PARENTS, chunk_size=16, streams=1, animator=None, frames_per_launch=1):
     """Renders frames ``poses[f]`` with camera dict ``cameras[f]`` (or one shared dict); yields (f, image[3,H,W]).
 
     canon: dict(xyz_canon, rotmat_canon|None, scales, opacity, shs, lbs_weights, active_sh_degree);
     transl [F,3] or None; ext_tfs: per-frame tuple (trans[F,3], rotmat[F,3,3], scale[F,1]) or None.
-    streams > 1 (or an existing ``animator``): that many frames in flight (FrameAnimator); same images."""
+    streams > 1 (or an existing ``animator``): that many frames in flight (FrameAnimator); same images.
+    frames_per_launch = K > 1 (without ext_tfs): K consecutive frames per DISPATCH (FrameAnimator.render_frames_batched), one such
+    launch per stream in flight; same images."""
     F = poses.shape[0]
     inv_cano = torch.inverse(A_t2cano)
-    if animator is None and streams > 1:
+    batched = int(frames_per_launch) > 1 and ext_tfs is None
+    if animator is None and (streams > 1 or batched):
         animator = FrameAnimator(canon, streams)
     if animator is not None:
         # ONE pipelined pass over all chunks: the joint transforms of chunk k + 1 are computed (on the caller's stream) while
@@ -239,7 +345,10 @@ def animate_chunk(canon, poses, joints_rest, A_t2cano, cameras, bg_color, transl
                     yield (cameras[f] if isinstance(cameras, (list, tuple)) else cameras, A[i],
                            None if transl is None else transl[f], smpl_scale,
                            None if ext_tfs is None else (ext_tfs[0][f], ext_tfs[1][f], ext_tfs[2][f]))
-        yield from animator.render_frames(jobs(), bg_color)
+        if batched:
+            yield from animator.render_frames_batched(jobs(), bg_color, frames_per_launch=int(frames_per_launch))
+        else:
+            yield from animator.render_frames(jobs(), bg_color)
         return
     for c0 in range(0, F, chunk_size):
         A = joint_transforms_batch(poses[c0:c0 + chunk_size], joints_rest, parents) @ inv_cano[None]

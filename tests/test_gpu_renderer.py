@@ -128,6 +128,27 @@ def test_animate_chunk_matches_per_frame_fused_calls():
     assert sorted(imgs3) == [0, 1, 2, 3, 4]
     for f in range(5):
         assert torch.equal(imgs3[f], imgs[f])
+    # K consecutive frames per DISPATCH (SkinnedFramesEngine): batches of 2 + 2 + 1 (padded) on two streams, one padded batch of 8
+    for K, streams in ((2, 2), (8, 1), (3, 3)):
+        imgsK = dict(animate_chunk(canon, poses, jr, A_cano, data, bg, transl=transl, parents=tuple(s["parents"]), chunk_size=4,
+                                   streams=streams, frames_per_launch=K))
+        assert sorted(imgsK) == [0, 1, 2, 3, 4]
+        for f in range(5):
+            assert torch.equal(imgsK[f], imgs[f]), (K, streams, f)
+    # every frame its own camera (list of camera dicts): stacked cameras inside a launch
+    cams = []
+    for f in range(5):
+        V = np.eye(4, dtype=np.float32); V[3, 0] = 0.02 * f
+        cm = make_camera(V, 1250.0, 1250.0, 64, 112, 128, 224)
+        cams.append(dict(fovx=cm["fovx"], fovy=cm["fovy"], image_height=224, image_width=128,
+                         world_view_transform=t(cm["world_view_transform"]), full_proj_transform=t(cm["full_proj_transform"]),
+                         camera_center=t(cm["camera_center"])))
+    ref_c = dict(animate_chunk(canon, poses, jr, A_cano, cams, bg, transl=transl, parents=tuple(s["parents"]), chunk_size=4))
+    got_c = dict(animate_chunk(canon, poses, jr, A_cano, cams, bg, transl=transl, parents=tuple(s["parents"]), chunk_size=4,
+                               streams=2, frames_per_launch=4))
+    for f in range(5):
+        assert torch.equal(got_c[f], ref_c[f]), f
+    assert not torch.equal(ref_c[0], ref_c[4])
 
 
 def test_render_then_fused_photometric_loss_matches_torch_chain():

@@ -23,13 +23,15 @@ canon = dict(xyz_canon=t(s["xyz_canon"]), rotmat_canon=None, scales=t(s["scales"
 A_cano = joint_transforms(torch.zeros(J * 3, device=dev), jr, tuple(s["parents"]))
 transl = t(np.tile(s["transl"], (F, 1)))
 bg = t(s["bg"])
-for streams, chunk in ((1, 16), (2, 16), (3, 16), (4, 16), (6, 16), (8, 16)):
-    anim = FrameAnimator(canon, streams) if streams > 1 else None
-    for rep in range(2):
+scale = t(s["smpl_scale"])
+for streams, chunk, K in ((1, 16, 1), (2, 16, 1), (3, 16, 1), (4, 16, 1), (6, 16, 1), (8, 16, 1),
+                         (1, 16, 8), (2, 16, 8), (3, 16, 8), (1, 16, 16), (2, 16, 16), (3, 16, 16)):
+    anim = FrameAnimator(canon, streams) if streams > 1 or K > 1 else None
+    for rep in range(3):
         torch.cuda.synchronize(); t0 = time.perf_counter()
         n = 0
-        for f, img in animate_chunk(canon, poses, jr, A_cano, data, bg, transl=transl, smpl_scale=t(s["smpl_scale"]),
-                                    parents=tuple(s["parents"]), chunk_size=chunk, animator=anim):
+        for f, img in animate_chunk(canon, poses, jr, A_cano, data, bg, transl=transl, smpl_scale=scale,
+                                    parents=tuple(s["parents"]), chunk_size=chunk, animator=anim, frames_per_launch=K):
             n += 1
         torch.cuda.synchronize(); el = time.perf_counter() - t0
-    print(f"streams={streams} chunk={chunk}: {n / el:8.1f} frames/s ({el / n * 1e3:.3f} ms per frame, {n} frames, joint transforms included)")
+    print(f"streams={streams} chunk={chunk} frames per launch={K}: {n / el:8.1f} frames/s ({el / n * 1e3:.3f} ms per frame, {n} frames, joint transforms included)")
