@@ -91,3 +91,33 @@ def get_render_pkg_fused(data, canon, A_cano2pose, bg_color, smpl_scale=None, tr
     if return_posed:
         pkg.update(xyz=out[2], rotq=out[3], scales=out[4])
     return pkg
+
+
+def get_render_pkgs_fused(data, canon, A_cano2pose, bg_color, smpl_scale=None, transl=None, scaling_modifier=1.0):
+    """The chunk form of ``get_render_pkg_fused``: K posed frames of the same canonical Gaussians in ONE fused call (K <= 16).
+
+    ``data``: one camera dict for all frames or a list of K dicts (same image size and field of view); ``A_cano2pose`` [K,J,4,4];
+    ``transl`` [K,3] / [3] / None.  Returns the keys of ``get_render_pkg`` with a leading frame axis: 'render' [K,3,H,W],
+    'radii' [K,N], 'visibility_filter' [K,N], 'viewspace_points' [K,N,3] (its ``.grad`` receives every frame's screen-space
+    gradient: the densifier's statistics stay per frame)."""
+    from .skinned import rasterize_skinned_frames
+    datas = list(data) if isinstance(data, (list, tuple)) else None
+    d0 = datas[0] if datas is not None else data
+    rs = _settings(d0, bg_color, scaling_modifier, canon['active_sh_degree'])
+    K = int(A_cano2pose.shape[0])
+    if datas is not None:
+        if len(datas) != K:
+            raise ValueError(f"{len(datas)} camera dicts for {K} frames")
+        rs = rs._replace(viewmatrix=torch.stack([d['world_view_transform'] for d in datas]).contiguous(),
+                         projmatrix=torch.stack([d['full_proj_transform'] for d in datas]).contiguous(),
+                         campos=torch.stack([d['camera_center'] for d in datas]).contiguous())
+    xyz = canon['xyz_canon']
+    screenspace_points = None
+    if torch.is_grad_enabled():
+        screenspace_points = torch.zeros((K,) + tuple(xyz.shape), dtype=xyz.dtype, device=xyz.device, requires_grad=True) + 0
+        screenspace_points.retain_grad()
+    color, radii = rasterize_skinned_frames(xyz, canon.get('rotmat_canon'), canon['scales'], canon['opacity'], canon['shs'],
+                                            canon['lbs_weights'], A_cano2pose, rs, smpl_scale=smpl_scale, transl=transl,
+                                            means2D=screenspace_points)
+    return {"render": torch.clamp(color, 0.0, 1.0), "render_raw": color, "viewspace_points": screenspace_points,
+            "visibility_filter": radii > 0, "radii": radii, "human_visibility_filter": radii > 0, "human_radii": radii}

@@ -158,3 +158,142 @@ def rasterize_skinned_gaussians(xyz_canon, rotmat_canon, scales, opacities, shs,
     """
     return _RasterizeSkinnedGaussians.apply(xyz_canon, rotmat_canon, scales, opacities, shs, A_cano2pose, transl,
                                             lbs_weights, smpl_scale, ext_tfs, raster_settings, return_posed, means2D)
+
+
+class _RasterizeSkinnedFrames(torch.autograd.Function):
+    """K posed frames of the SAME canonical Gaussians in ONE call per direction (the ``*_frames`` entry points of
+    include/sings_hip.h): what ``SinGS.forward_chunk`` (sings_hybrid.py:474-569) + the render loop of gs_trainer.py:684-714 do for
+    a chunk, as one differentiable operator.  The gradients of the canonical Gaussians are the SUM over the K frames (formed inside
+    the per-Gaussian backward kernel, in frame order); dL/dA and dL/dtransl are per frame.  The pair counts of the K frames are read
+    before the call returns (one strided copy + stream synchronisation): a frame that would overflow is never returned, the
+    workspaces grow and the call is repeated."""
+
+    @staticmethod
+    def forward(ctx, xyz_canon, rotmat_canon, scales, opacities, shs, A, transl, lbs_weights, smpl_scale, raster_settings,
+                means2D=None):
+        from .engine import _frame_batch
+        lib = _lib.load()
+        dev = xyz_canon.device
+        if dev.type != "cuda":
+            raise RuntimeError("sings_amd fused LBS+raster runs on the MI355X only; there is no CPU fallback")
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("rasterize_skinned_frames reads the pair counts on the host: not capturable (use SkinnedFramesEngine)")
+        rs = raster_settings
+        xyz_canon = _f32(xyz_canon, "xyz_canon", dev)
+        rot_shape = None if rotmat_canon is None else tuple(rotmat_canon.shape)
+        if rotmat_canon is not None:
+            rotmat_canon = _f32(rotmat_canon, "rotmat_canon", dev)
+            if rotmat_canon.shape[-2:] == (3, 3):
+                rotmat_canon = rotmat_canon.reshape(-1, 9)
+            elif rotmat_canon.dim() != 2 or rotmat_canon.shape[1] not in (6, 9):
+                raise RuntimeError(f"rotmat_canon must be [N,3,3], [N,9] or [N,6] (6-D form), got {tuple(rotmat_canon.shape)}")
+        scales = _f32(scales, "scales", dev); opacities = _f32(opacities, "opacities", dev); shs = _f32(shs, "shs", dev)
+        A = _f32(A, "A", dev)
+        K = int(A.shape[0])
+        if A.dim() < 3 or not 1 <= K <= _lib.MAX_FRAMES:
+            raise RuntimeError(f"A must be [K,J,4,4] / [K,J,16] with K in 1..{_lib.MAX_FRAMES}, got {tuple(A.shape)}")
+        A16 = A.reshape(K, -1, 16)
+        tstride = 0
+        if transl is not None:
+            transl = _f32(transl, "transl", dev)
+            if transl.numel() == 3 * K and K > 1:
+                tstride = 3
+            elif transl.numel() != 3:
+                raise RuntimeError(f"transl must be [{K},3] or [3], got {tuple(transl.shape)}")
+        vm = rs.viewmatrix
+        cam_stride = 1 if vm.dim() == 3 else 0
+        if cam_stride and (vm.shape[0] != K or rs.projmatrix.shape[0] != K or rs.campos.shape[0] != K):
+            raise RuntimeError(f"per-frame cameras must be stacked [{K},4,4] / [{K},3]")
+        P = int(xyz_canon.shape[0]); H, W = int(rs.image_height), int(rs.image_width); M = int(shs.shape[1])
+        keep = []
+        s = _settings_struct(rs, dev, M, keep)
+        s.flags = _lib.FLAG_THROUGHPUT
+        k = _skin_struct(dev, xyz_canon, rotmat_canon, lbs_weights, A16[0], smpl_scale,
+                         None if transl is None else transl.reshape(-1)[:3], None, keep)
+        k.A = A16.data_ptr()
+        k.transl = None if transl is None else transl.data_ptr()
+        fb = _frame_batch(K, cam_stride, tstride)
+        color = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev)
+        radii = torch.empty((K, P), dtype=torch.int32, device=dev)
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        cap = max(_rz._capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            while True:
+                L = _lib.SgLayout(); sizes = [C.c_size_t() for _ in range(4)]
+                _lib.check(lib.sg_frames_layout(P, W, H, cap, K, C.byref(L), *[C.byref(x) for x in sizes]), "sg_frames_layout")
+                geom = torch.empty(sizes[0].value, dtype=torch.uint8, device=dev)
+                binning = torch.empty(sizes[1].value, dtype=torch.uint8, device=dev)
+                img = torch.empty(sizes[2].value, dtype=torch.uint8, device=dev)
+                nr = (C.c_int64 * K)()
+                _lib.check(lib.sg_skinned_forward_frames(C.byref(s), C.byref(fb), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales),
+                                                         _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii), None, None,
+                                                         None, nr, stream), "skinned forward (frames)")
+                R = max(int(v) for v in nr)
+                if R <= cap:
+                    break
+                cap = int(R * _rz._HEADROOM) + 1024
+            _rz._grow(dev.index, R)
+        ctx.rs, ctx.cap, ctx.M, ctx.K, ctx.fb = rs, cap, M, K, (cam_stride, tstride)
+        ctx.num_rendered = [int(v) for v in nr]
+        ctx.has_rot = rotmat_canon is not None
+        ctx.rot_shape = rot_shape
+        ctx.has_m2d = means2D is not None
+        ctx.aux = (lbs_weights, smpl_scale, A.shape, None if transl is None else transl.shape, sizes[3].value)
+        z = torch.empty(0, device=dev)
+        ctx.save_for_backward(xyz_canon, rotmat_canon if ctx.has_rot else z, scales, opacities, shs, A16,
+                              transl if transl is not None else z, radii, geom, binning, img)
+        ctx.mark_non_differentiable(radii)
+        return color, radii
+
+    @staticmethod
+    def backward(ctx, g_color, _g_radii=None):
+        from .engine import _frame_batch
+        lib = _lib.load()
+        xyz_canon, rotmat_canon, scales, opacities, shs, A16, transl, radii, geom, binning, img = ctx.saved_tensors
+        lbs_weights, smpl_scale, A_shape, transl_shape, bwd_bytes = ctx.aux
+        dev = xyz_canon.device
+        rs, K = ctx.rs, ctx.K
+        P = int(xyz_canon.shape[0]); H, W = int(rs.image_height), int(rs.image_width)
+        keep = []
+        s = _settings_struct(rs, dev, ctx.M, keep)
+        s.flags = _lib.FLAG_THROUGHPUT
+        k = _skin_struct(dev, xyz_canon, rotmat_canon if ctx.has_rot else None, lbs_weights, A16[0], smpl_scale,
+                         transl.reshape(-1)[:3] if transl_shape is not None else None, None, keep)
+        k.A = A16.data_ptr()
+        k.transl = transl.data_ptr() if transl_shape is not None else None
+        fb = _frame_batch(K, *ctx.fb)
+        e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+        d_xyz, d_scales, d_op, d_sh, d_m2d = e(P, 3), e(P, 3), e(P, 1), e(P, ctx.M, 3), e(K, P, 3)
+        d_rot = e(P, int(rotmat_canon.shape[1])) if ctx.has_rot else None
+        d_A = e(K, k.J, 16); d_tr = e(K, 3)
+        g_color = _f32(g_color, "grad_out_color", dev)
+        with torch.cuda.device(dev):
+            bwd_ws = torch.empty(bwd_bytes, dtype=torch.uint8, device=dev)
+            skin_ws = e(int(lib.sg_skin_ws_floats_frames(P, K)))
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_rasterize_backward_records_frames(C.byref(s), C.byref(fb), P, _ptr(geom), _ptr(binning), ctx.cap, _ptr(img),
+                                                                _ptr(bwd_ws), _ptr(g_color), stream), "skinned backward (records, frames)")
+            _lib.check(lib.sg_skinned_backward_gaussians_frames(
+                C.byref(s), C.byref(fb), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(radii), _ptr(geom), _ptr(binning),
+                ctx.cap, _ptr(bwd_ws), _ptr(skin_ws), 0, None, None, _ptr(d_xyz), _ptr(d_rot), _ptr(d_scales), _ptr(d_op), _ptr(d_sh),
+                _ptr(d_m2d), _ptr(d_A), _ptr(d_tr), stream), "skinned backward (gaussians, frames)")
+        if transl_shape is None:
+            g_tr = None
+        elif ctx.fb[1] == 3:
+            g_tr = d_tr.view(transl_shape)
+        else:
+            g_tr = d_tr.sum(0).view(transl_shape)                 # one translation shared by the K frames
+        return (d_xyz, None if d_rot is None else d_rot.view(ctx.rot_shape), d_scales, d_op.view_as(opacities), d_sh,
+                d_A.view(A_shape), g_tr, None, None, None, d_m2d if ctx.has_m2d else None)
+
+
+def rasterize_skinned_frames(xyz_canon, rotmat_canon, scales, opacities, shs, lbs_weights, A_cano2pose, raster_settings,
+                             smpl_scale=None, transl=None, means2D=None):
+    """color [K,3,H,W], radii [K,P] = fused LBS + rasterization of K posed frames of the same canonical Gaussians in one call.
+
+    ``A_cano2pose`` [K,J,4,4]; ``transl`` [K,3] (per frame), [3] (shared) or None; ``raster_settings``: one camera, or
+    ``viewmatrix`` / ``projmatrix`` [K,4,4] and ``campos`` [K,3] for a camera per frame.  ``means2D``: optional [K,N,3] holder
+    (``requires_grad``) of the per-frame screen-space gradients.  Backward: canonical-Gaussian gradients summed over the K frames."""
+    return _RasterizeSkinnedFrames.apply(xyz_canon, rotmat_canon, scales, opacities, shs, A_cano2pose, transl, lbs_weights,
+                                         smpl_scale, raster_settings, means2D)

@@ -239,3 +239,66 @@ def test_render_glue_against_the_references_own_render():
     assert torch.allclose(outs[1]["xyz"], t(s["means3D"][cut:]) + t(G["multi_trans"][1])[None])     # translated in place (:25-27)
     with pytest.raises(ValueError):
         get_render_pkgs(data, outs, [t(G["multi_trans"][0])] * 2, [None, None], t(G["bg"]), render_mode="single-person")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rot,shared_transl,per_frame_cameras", [(False, False, False), (True, True, True)])
+def test_fused_chunk_render_pkg_equals_per_frame_fused_calls(with_rot, shared_transl, per_frame_cameras):
+    """get_render_pkgs_fused (K frames, one differentiable call) against K get_render_pkg_fused calls: images, radii, per-frame
+    screen-space gradients, dL/dA bit for bit; the canonical-Gaussian gradients (summed over the frames inside the kernel, in frame
+    order; autograd adds the per-frame calls' in its own order) to 1e-6 of their scale."""
+    from sings_amd.body import joint_transforms
+    from sings_amd.renderer import get_render_pkg_fused, get_render_pkgs_fused
+    from sings_amd.scene import avatar_scene
+    dev = torch.device("cuda:0")
+    K, N, J = 5, 9000, 24
+    s = avatar_scene(N=N, J=J, W=128, H=224, seed=7, isotropic=not with_rot)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs = np.random.RandomState(3)
+    cams = []
+    for f in range(K):
+        V = np.eye(4, dtype=np.float32); V[3, 0] = 0.02 * f if per_frame_cameras else 0.0
+        cm = make_camera(V, 1250.0, 1250.0, 64, 112, 128, 224)
+        cams.append(dict(fovx=cm["fovx"], fovy=cm["fovy"], image_height=224, image_width=128,
+                         world_view_transform=t(cm["world_view_transform"]), full_proj_transform=t(cm["full_proj_transform"]),
+                         camera_center=t(cm["camera_center"])))
+    jr = t(s["joints_rest"])
+    A0 = torch.stack([joint_transforms(t(rs.normal(0, 0.2, J * 3).astype(np.float32)), jr, tuple(s["parents"])) for _ in range(K)])
+    tr0 = t(s["transl"]) if shared_transl else t(np.tile(s["transl"], (K, 1)) + rs.normal(0, 0.02, (K, 3)).astype(np.float32))
+    w = t(rs.normal(0, 1, (K, 3, 224, 128)).astype(np.float32))
+    bg = torch.tensor([0.2, 0.4, 0.6], device=dev)
+
+    def leaves():
+        c = dict(xyz_canon=t(s["xyz_canon"]).requires_grad_(True),
+                 rotmat_canon=t(rs2.normal(size=(N, 6)).astype(np.float32)).requires_grad_(True) if with_rot else None,
+                 scales=t(s["scales"]).requires_grad_(True), opacity=t(s["opacities"]).requires_grad_(True),
+                 shs=t(s["shs"]).requires_grad_(True), lbs_weights=t(s["lbs_weights"]), active_sh_degree=0)
+        return c, A0.clone().requires_grad_(True), tr0.clone().requires_grad_(True)
+    rs2 = np.random.RandomState(9)
+    c1, A1, tr1 = leaves()
+    rs2 = np.random.RandomState(9)
+    c2, A2, tr2 = leaves()
+    # K single-frame fused calls
+    imgs, radii, vsp = [], [], []
+    loss = 0
+    for f in range(K):
+        pkg = get_render_pkg_fused(cams[f] if per_frame_cameras else cams[0], c1, A1[f], bg, transl=tr1 if shared_transl else tr1[f])
+        imgs.append(pkg["render_raw"]); radii.append(pkg["radii"]); vsp.append(pkg["viewspace_points"])
+        loss = loss + (pkg["render_raw"] * w[f]).sum()
+    loss.backward()
+    # one K-frame call
+    pk = get_render_pkgs_fused(cams if per_frame_cameras else cams[0], c2, A2, bg, transl=tr2)
+    (pk["render_raw"] * w).sum().backward()
+    for f in range(K):
+        assert torch.equal(pk["render_raw"][f], imgs[f]) and torch.equal(pk["radii"][f], radii[f]), f
+        assert torch.equal(pk["viewspace_points"].grad[f], vsp[f].grad), f
+    assert torch.equal(pk["visibility_filter"], pk["radii"] > 0)
+    assert torch.equal(A2.grad, A1.grad)
+    close = lambda a, b: float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
+    if shared_transl:
+        assert close(tr2.grad, tr1.grad)
+    else:
+        assert torch.equal(tr2.grad, tr1.grad)
+    for key in ("xyz_canon", "scales", "opacity", "shs") + (("rotmat_canon",) if with_rot else ()):
+        assert close(c2[key].grad, c1[key].grad), key
+        assert float(c1[key].grad.abs().max()) > 0
