@@ -340,6 +340,12 @@ int sg_skinned_backward_gaussians_frames(const SgRasterSettings *s, const SgFram
 int sg_photo_loss_frames(int K, int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                          size_t gt_stride, const float *mask, size_t mask_stride, const float *bg, void *ws, float *pred_out,
                          float *gt_out, float *losses, const float *upstream, float *dL_draw, void *stream);
+/* The gradients alone, K frames in one launch, over the workspace a forward-only sg_photo_loss_frames call left behind (the K-frame
+ * form of sg_photo_loss_backward below): `upstream` NULL = (1, 1) for every frame, upstream_stride 0 = one pair [2] for all
+ * frames, 2 = a pair per frame [K,2] (device memory) */
+int sg_photo_loss_backward_frames(int K, int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                                  size_t gt_stride, const float *mask, size_t mask_stride, const float *bg, const void *ws,
+                                  const float *upstream, int upstream_stride, float *dL_draw, void *stream);
 
 /* ---- photometric loss of one view, forward + gradient -------------------------------------------
  * Replaces, for the L1 and SSIM terms of HumanSceneLoss.forward (sings/rec/losses/loss.py:55-69):

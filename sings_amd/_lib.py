@@ -57,7 +57,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare", "sg_gaussian_edge_finish", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_copy_probe",
-           "sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames",
+           "sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames", "sg_photo_loss_backward_frames",
            "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
            "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames")
 NUM_KERNELS = 8
@@ -119,6 +119,7 @@ def load():
     lib.sg_skinned_backward_gaussians_frames.argtypes = ([C.POINTER(SgRasterSettings), FB, i32, C.POINTER(SgSkinInputs)] + [vp] * 3 +
                                                          [vp, vp, vp, sz, vp, vp, i32] + [vp] * 2 + [vp] * 8 + [vp])
     lib.sg_photo_loss_frames.argtypes = [i32, i32, i32, C.c_float, C.c_float, vp, vp, sz, vp, sz] + [vp] * 8
+    lib.sg_photo_loss_backward_frames.argtypes = [i32, i32, i32, C.c_float, C.c_float, vp, vp, sz, vp, sz, vp, vp, vp, i32, vp, vp]
     for f in ("sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames",
               "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames",
               "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames"):

@@ -540,6 +540,18 @@ extern "C" int sg_photo_loss(int width, int height, float l1_w, float ssim_w, co
                                 dL_draw, stream);
 }
 
+extern "C" int sg_photo_loss_backward_frames(int K, int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
+                                             size_t gt_stride, const float *mask, size_t mask_stride, const float *bg, const void *ws,
+                                             const float *upstream, int upstream_stride, float *dL_draw, void *stream)
+{
+    if (K < 1 || K > SG_MAX_FRAMES || width <= 0 || height <= 0 || !raw || !gt_rgb || !mask || !bg || !ws || !dL_draw)
+        return sg_fail("sg_photo_loss_backward_frames: bad arguments (K in 1..16, no null pointers)", hipSuccess);
+    if (upstream_stride != 0 && upstream_stride != 2) return sg_fail("sg_photo_loss_backward_frames: upstream_stride must be 0 or 2", hipSuccess);
+    sg_launch_photo_loss_bwd(K, width, height, l1_w, ssim_w, raw, gt_rgb, mask, bg, ws, upstream, dL_draw, gt_stride, mask_stride,
+                             (hipStream_t)stream, upstream ? upstream_stride : 0);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_photo_loss_backward_frames", e);
+}
 extern "C" int sg_photo_loss_backward(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                                       const float *mask, const float *bg, const void *ws, const float *upstream,
                                       float *dL_draw, void *stream)

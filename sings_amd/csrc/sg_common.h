@@ -309,7 +309,7 @@ void sg_launch_photo_loss(int K, int W, int H, float l1_w, float ssim_w, const f
                           float *losses, const float *upstream, float *dL_draw, size_t gt_stride, size_t mask_stride, hipStream_t st);
 void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
-                              size_t gt_stride, size_t mask_stride, hipStream_t st);
+                              size_t gt_stride, size_t mask_stride, hipStream_t st, int up_stride = 0);
 void sg_launch_skin_bwd(const SgCam &c, const SgBatch &bt, int P, const SgSkinInputs *in, const float *shs, const float *scales,
                         const int32_t *radii, SgGeom g, SgRec grec, size_t cap, const uint32_t *header, const uint8_t *rec_valid,
                         const float *dposed_xyz_in, const float *dposed_rotq_in, float *slab, float *dL_dxyz_canon, float *dL_drot_canon,

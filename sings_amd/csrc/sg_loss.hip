@@ -30,6 +30,7 @@ struct SgLossArgs {
     // target at + gt_stride f, mask at + mask_stride f (floats; 0 = one target / mask for all frames), workspace at + ws_stride f
     // bytes, losses at + 4 f
     size_t gt_stride, mask_stride, ws_stride;
+    int up_stride;                // floats between the upstream weight pairs of consecutive frames: 0 (shared) | 2
 };
 
 __device__ __forceinline__ float sg_clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
@@ -260,7 +261,8 @@ sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
         maps = sg_at(maps, (size_t)frame * a.ws_stride); scalars = sg_at(scalars, (size_t)frame * a.ws_stride);
     }
     // upstream = (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL (the same for all frames)
-    const float u_l1 = upstream ? upstream[0] : 1.0f, u_ss = upstream ? upstream[1] : 1.0f;
+    const float *up = upstream ? upstream + (size_t)frame * a.up_stride : nullptr;     // (up_stride 2: a pair of weights per frame)
+    const float u_l1 = up ? up[0] : 1.0f, u_ss = up ? up[1] : 1.0f;
     const float c_l1 = scalars[4] * u_l1, c_ss = scalars[5] * u_ss;
     {
         const int ch = blockIdx.z - 3 * frame;
@@ -370,10 +372,10 @@ size_t sg_photo_loss_ws_bytes_impl(int W, int H)
     return sg_align(9 * hw * 4) + sg_align(nb * 16) + 256;
 }
 
-static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt_stride = 0, size_t mask_stride = 0)
+static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt_stride = 0, size_t mask_stride = 0, int up_stride = 0)
 {
     SgLossArgs a;
-    a.W = W; a.H = H; a.l1_w = l1_w; a.ssim_w = ssim_w;
+    a.W = W; a.H = H; a.l1_w = l1_w; a.ssim_w = ssim_w; a.up_stride = up_stride;
     a.gt_stride = gt_stride; a.mask_stride = mask_stride; a.ws_stride = sg_photo_loss_ws_bytes_impl(W, H);
     {   // losses/utils.py:28-30 in fp32, like torch.Tensor([...]) / sum()
         float g[11], s = 0.0f;
@@ -387,9 +389,9 @@ static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt
 // gradient pass alone over the workspace of an earlier forward-only call (window statistics + scalars)
 void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
-                              size_t gt_stride, size_t mask_stride, hipStream_t st)
+                              size_t gt_stride, size_t mask_stride, hipStream_t st, int up_stride)
 {
-    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride);
+    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride, up_stride);
     const size_t hw = (size_t)W * H;
     dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3 * K), block(256);
     const int nb = (int)(grid.x * grid.y * 3);

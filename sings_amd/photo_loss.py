@@ -88,6 +88,69 @@ def photometric_loss(raw_image, gt_rgb, mask, bg_color, l1_w=0.8, ssim_w=0.2, re
     return loss_dict, extras
 
 
+class _PhotoLossFrames(torch.autograd.Function):
+    """K frames at once: ``raw`` [K,3,H,W]; ``gt_rgb`` [K,3,H,W] or [3,H,W]; ``mask`` [K,H,W] / [K,1,H,W] or [H,W].  Returns the four
+    loss scalars per frame as [K] tensors; backward takes a pair of upstream weights PER FRAME (sg_photo_loss_backward_frames)."""
+
+    @staticmethod
+    def forward(ctx, raw, gt_rgb, mask, bg, l1_w, ssim_w):
+        if not raw.is_cuda:
+            raise RuntimeError("sings_amd.photo_loss: tensors must live on the GPU (no CPU fallback)")
+        lib = _lib.load()
+        raw = raw.contiguous().float(); gt_rgb = gt_rgb.contiguous().float()
+        mask = mask.contiguous().float(); bg = bg.contiguous().float()
+        if raw.dim() != 4 or raw.shape[1] != 3 or not 1 <= raw.shape[0] <= _lib.MAX_FRAMES:
+            raise ValueError(f"photometric_loss_frames: raw must be [K,3,H,W] with K in 1..{_lib.MAX_FRAMES}")
+        K, H, W = int(raw.shape[0]), int(raw.shape[2]), int(raw.shape[3])
+        hw = H * W
+        if gt_rgb.numel() not in (3 * hw, K * 3 * hw) or mask.numel() not in (hw, K * hw):
+            raise ValueError("photometric_loss_frames: gt_rgb must be [K,3,H,W] or [3,H,W], mask [K,H,W] or [H,W]")
+        gt_stride = 3 * hw if gt_rgb.numel() == K * 3 * hw and K > 1 else 0
+        mask_stride = hw if mask.numel() == K * hw and K > 1 else 0
+        dev = raw.device
+        ws = torch.empty(K * int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
+        losses = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_photo_loss_frames(K, W, H, float(l1_w), float(ssim_w), _ptr(raw), _ptr(gt_rgb), gt_stride, _ptr(mask),
+                                                mask_stride, _ptr(bg), _ptr(ws), None, None, _ptr(losses), None, None, stream),
+                       "photo loss (frames)")
+        ctx.save_for_backward(raw, gt_rgb, mask, bg, ws)
+        ctx.args = (float(l1_w), float(ssim_w), K, W, H, gt_stride, mask_stride)
+        ctx.set_materialize_grads(False)
+        return losses[:, 0], losses[:, 1], losses[:, 2], losses[:, 3]
+
+    @staticmethod
+    def backward(ctx, g_l1, g_ssim, g_raw_l1=None, g_ssim_mean=None):
+        raw, gt_rgb, mask, bg, ws = ctx.saved_tensors
+        l1_w, ssim_w, K, W, H, gt_stride, mask_stride = ctx.args
+        lib = _lib.load()
+        dev = raw.device
+        zero = torch.zeros(K, dtype=torch.float32, device=dev)
+        up = torch.stack([zero if g_l1 is None else g_l1.reshape(K).float(), zero if g_ssim is None else g_ssim.reshape(K).float()], 1)
+        up = up.contiguous()                                                   # [K,2]: a pair of weights per frame, device memory
+        out = torch.empty_like(raw)
+        with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(lib.sg_photo_loss_backward_frames(K, W, H, l1_w, ssim_w, _ptr(raw), _ptr(gt_rgb), gt_stride, _ptr(mask), mask_stride,
+                                                         _ptr(bg), _ptr(ws), _ptr(up), 2, _ptr(out), stream), "photo loss backward (frames)")
+        return out, None, None, None, None, None
+
+
+def photometric_loss_frames(raw_images, gt_rgb, mask, bg_color, l1_w=0.8, ssim_w=0.2):
+    """The K-frame form of ``photometric_loss`` (three launches forward, one backward for the K frames): ``raw_images`` [K,3,H,W]
+    (e.g. ``get_render_pkgs_fused(...)['render_raw']``), ``gt_rgb`` [K,3,H,W] or one [3,H,W] target, ``mask`` likewise.
+    -> (loss_dict, extras_dict): 'l1' / 'ssim' are [K] tensors (weighted, differentiable; ``sum()`` them for the step's loss),
+    'l1_raw' / 'ssim_mean' [K] detached."""
+    out = _PhotoLossFrames.apply(raw_images, gt_rgb, mask, bg_color, l1_w, ssim_w)
+    loss_dict = {}
+    if l1_w > 0.0:
+        loss_dict["l1"] = out[0]
+    if ssim_w > 0.0:
+        loss_dict["ssim"] = out[1]
+    return loss_dict, {"l1_raw": out[2].detach(), "ssim_mean": out[3].detach()}
+
+
 class PhotoLossEngine:
     """Pre-allocated variant for training loops / bench.py: no allocation, no synchronisation per call.  ``K`` > 1: the losses
     and gradients of K frames in three launches (``sg_photo_loss_frames``): ``raw`` [K,3,H,W]; ``gt_rgb`` [K,3,H,W] or one

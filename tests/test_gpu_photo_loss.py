@@ -131,3 +131,42 @@ def test_flat_tiles_take_the_short_path_with_the_same_bits():
     for ch in range(3):
         bits = g[ch].view(np.uint32)
         assert np.unique(bits[sel]).size == 1, (ch, np.unique(bits[sel]).size)
+
+
+def test_k_frame_autograd_loss_equals_k_single_losses():
+    """photometric_loss_frames ([K,3,H,W], one backward launch with a pair of upstream weights PER FRAME) against K
+    photometric_loss calls: values and gradients bit for bit, with different weights on every frame's two terms."""
+    from sings_amd.photo_loss import photometric_loss, photometric_loss_frames
+    dev = _dev()
+    K, W, H = 4, 200, 136
+    g = torch.Generator(device="cpu").manual_seed(8)
+    raw = (torch.rand(K, 3, H, W, generator=g) * 1.4 - 0.2).to(dev)
+    gt = torch.rand(K, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(K, H, W, generator=g) > 0.3).float().to(dev)
+    bg = torch.tensor([1.0, 0.5, 0.25], device=dev)
+    a = torch.tensor([1.0, 0.7, -0.3, 2.0], device=dev); b = torch.tensor([1.0, -1.1, 0.4, 0.0], device=dev)
+    r1 = raw.clone().requires_grad_(True)
+    tot = 0
+    singles = []
+    for f in range(K):
+        ld, ex = photometric_loss(r1[f], gt[f], mask[f], bg, 0.8, 0.2)
+        singles.append((ld["l1"].detach().clone(), ld["ssim"].detach().clone(), ex["l1_raw"].clone(), ex["ssim_mean"].clone()))
+        tot = tot + a[f] * ld["l1"] + b[f] * ld["ssim"]
+    tot.backward()
+    r2 = raw.clone().requires_grad_(True)
+    ld, ex = photometric_loss_frames(r2, gt, mask, bg, 0.8, 0.2)
+    ((a * ld["l1"]).sum() + (b * ld["ssim"]).sum()).backward()
+    for f in range(K):
+        assert torch.equal(ld["l1"][f], singles[f][0]) and torch.equal(ld["ssim"][f], singles[f][1])
+        assert torch.equal(ex["l1_raw"][f], singles[f][2]) and torch.equal(ex["ssim_mean"][f], singles[f][3])
+        assert torch.equal(r2.grad[f], r1.grad[f]), f
+    # one target / one mask for all frames; only the L1 term used
+    r3 = raw.clone().requires_grad_(True)
+    ld3, _ = photometric_loss_frames(r3, gt[0], mask[0], bg, 0.8, 0.2)
+    ld3["l1"].sum().backward()
+    r4 = raw.clone().requires_grad_(True)
+    t4 = 0
+    for f in range(K):
+        t4 = t4 + photometric_loss(r4[f], gt[0], mask[0], bg, 0.8, 0.2)[0]["l1"]
+    t4.backward()
+    assert torch.equal(r3.grad, r4.grad)
