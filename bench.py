@@ -168,7 +168,7 @@ def parse_args():
     # per-Gaussian kernels of an avatar end in partly filled rounds (2 344 waves on 2 048 slots) which a third stream fills; the
     # raster step gains nothing from a third stream (its composites saturate the vector issue on their own)
     if a.views_per_step is None:
-        a.views_per_step = 24 if a.workload == "avatar" else 16
+        a.views_per_step = 24 if a.workload == "avatar" else 1 if a.workload == "train" else 16     # (train: the reference's one frame per step)
     if a.streams is None:
         a.streams = 3 if a.workload == "avatar" else 2
     return a
@@ -1064,7 +1064,10 @@ def main_train(a):
     # No host synchronisation inside a step: synchronous steps size the pair capacity, then the rasterizer's pair-count
     # check is deferred (sings_amd.rasterizer.set_deferred_overflow_check) and polled once after the timed region.
     from sings_amd import rasterizer as _rz
-    A_static = A_all[0].clone()
+    # --views-per-step K > 1: a CHUNK of K frames per optimisation step (AvatarStep with A [K,J,4,4]): one decode, K frames rendered,
+    # compared and differentiated in one call per direction; the default 1 is the reference's step
+    Kt = max(1, min(int(a.views_per_step), 16))
+    A_static = A_all[0].clone() if Kt == 1 else A_all[:Kt].clone()
 
     def step_body():
         for p in params:
@@ -1081,7 +1084,7 @@ def main_train(a):
     cap_pairs = 0
     _rz.set_overflow_check("sync")                               # every sizing step reads its pair count before it returns, so
     for f in range(0, F, 8):                                     # _capacity_hint (2 x the largest count) has seen them all
-        A_static.copy_(A_all[f])
+        A_static.copy_(A_all[f] if Kt == 1 else A_all[torch.arange(f, f + Kt, device=dev) % F])
         step_body()
         cap_pairs = max(cap_pairs, _rz._capacity_hint[dev.index])
     torch.cuda.synchronize()
@@ -1112,8 +1115,17 @@ def main_train(a):
         from sings_amd.train_step import capture_step
         graph, ld_static = capture_step(step_body, warmup=3, device=dev)
 
+    frame_ix = torch.empty(Kt, dtype=torch.long, device=dev)
+    pins = [torch.empty(Kt, dtype=torch.long).pin_memory() for _ in range(64)]
+
     def step(i):
-        A_static.copy_(A_all[shard.frame(i)])
+        if Kt == 1:
+            A_static.copy_(A_all[shard.frame(i)])
+        else:                                                    # the step's K frames: gathered on the device (no host wait)
+            pin = pins[i % 64]
+            pin.copy_(torch.tensor([shard.frame(i * Kt + k) for k in range(Kt)], dtype=torch.long))
+            frame_ix.copy_(pin, non_blocking=True)
+            torch.index_select(A_all, 0, frame_ix, out=A_static)
         if graph is not None:
             graph.replay()
             ld = ld_static
@@ -1142,14 +1154,14 @@ def main_train(a):
         nparam = sum(p.numel() for p in params)
         out = ({
             "metric": "full train-step views/sec (decode + LBS-fused raster + L1/SSIM + regularisers, fwd+bwd), avatar ~150k Gaussians",
-            "value": world * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": el / a.steps * 1e3, "timed_region_s": sum(els), "repeats": len(els),
+            "value": world * Kt * a.steps / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": el / a.steps * 1e3, "ms_per_view": el / a.steps / Kt * 1e3, "timed_region_s": sum(els), "repeats": len(els),
             "ms_per_step_min": min(els) / a.steps * 1e3, "ms_per_step_max": max(els) / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"avatar_scene(N={N}, J={J}) {W}x{H}, tri-plane 32 x (64,128,256)^2 x 3, decoders 96-128-128 / "
                                    f"96-64-64, SH deg 0, {F} AMASS frames, no optimiser step, frame-parallel dp{world}",
-                       "gaussians": N, "trainable_parameters": nparam, "num_rendered_last": R_last, "hip_graph": not a.eager,
+                       "gaussians": N, "frames_per_step": Kt, "trainable_parameters": nparam, "num_rendered_last": R_last, "hip_graph": not a.eager,
                        "gradient_bytes_written_in_place": inplace,
                        "parallelism": f"dp{world}"},
             "losses": {k: float(v.detach()) for k, v in ld.items()}})

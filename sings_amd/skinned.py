@@ -166,7 +166,9 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
     a chunk, as one differentiable operator.  The gradients of the canonical Gaussians are the SUM over the K frames (formed inside
     the per-Gaussian backward kernel, in frame order); dL/dA and dL/dtransl are per frame.  The pair counts of the K frames are read
     before the call returns (one strided copy + stream synchronisation): a frame that would overflow is never returned, the
-    workspaces grow and the call is repeated."""
+    workspaces grow and the call is repeated.  With ``set_overflow_check("deferred")`` or inside a HIP-graph capture nothing is
+    read on the host: the largest (pair count, overflow flag) of the K frames is folded into the device-side accumulator that
+    ``check_deferred_overflow()`` polls, exactly as the single-frame operator does."""
 
     @staticmethod
     def forward(ctx, xyz_canon, rotmat_canon, scales, opacities, shs, A, transl, lbs_weights, smpl_scale, raster_settings,
@@ -176,8 +178,6 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
         dev = xyz_canon.device
         if dev.type != "cuda":
             raise RuntimeError("sings_amd fused LBS+raster runs on the MI355X only; there is no CPU fallback")
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("rasterize_skinned_frames reads the pair counts on the host: not capturable (use SkinnedFramesEngine)")
         rs = raster_settings
         xyz_canon = _f32(xyz_canon, "xyz_canon", dev)
         rot_shape = None if rotmat_canon is None else tuple(rotmat_canon.shape)
@@ -217,6 +217,7 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
         radii = torch.empty((K, P), dtype=torch.int32, device=dev)
         T = ((W + 15) // 16) * ((H + 15) // 16)
         cap = max(_rz._capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
+        sync = not (torch.cuda.is_current_stream_capturing() or _rz._mode["mode"] == "deferred")
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             while True:
@@ -228,12 +229,20 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
                 nr = (C.c_int64 * K)()
                 _lib.check(lib.sg_skinned_forward_frames(C.byref(s), C.byref(fb), P, C.byref(k), _ptr(shs), _ptr(opacities), _ptr(scales),
                                                          _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color), _ptr(radii), None, None,
-                                                         None, nr, stream), "skinned forward (frames)")
+                                                         None, nr if sync else None, stream), "skinned forward (frames)")
+                if not sync:
+                    break
                 R = max(int(v) for v in nr)
                 if R <= cap:
                     break
                 cap = int(R * _rz._HEADROOM) + 1024
-            _rz._grow(dev.index, R)
+            if sync:
+                _rz._grow(dev.index, R)
+            else:
+                # (pair count, overflow flag) of the worst frame -> the device-side accumulator of the deferred check
+                hdr = binning.view(K, L.bin_bytes)[:, :8].view(torch.int32).amax(0).contiguous()
+                _rz._after_forward(dev, hdr.view(torch.uint8), cap)
+                nr = [0] * K
         ctx.rs, ctx.cap, ctx.M, ctx.K, ctx.fb = rs, cap, M, K, (cam_stride, tstride)
         ctx.num_rendered = [int(v) for v in nr]
         ctx.has_rot = rotmat_canon is not None

@@ -23,8 +23,8 @@ loss and the backward composite (0.23 ms of half-busy vector ALUs).
 import torch
 
 from .decode import decode_attributes
-from .photo_loss import photometric_loss
-from .skinned import rasterize_skinned_gaussians
+from .photo_loss import photometric_loss, photometric_loss_frames
+from .skinned import rasterize_skinned_frames, rasterize_skinned_gaussians
 
 
 class _AddScalars(torch.autograd.Function):
@@ -109,7 +109,10 @@ class AvatarStep(torch.nn.Module):
         self.l2_norm, self.gaussian_connect, self.gaussian_connect_w = l2_norm, gaussian_connect, gaussian_connect_w
 
     def forward(self, A_cano2pose, raster_settings, gt_rgb, mask, bg_color, smpl_scale=None, transl=None):
-        """-> (loss, loss_dict, extras).  With ``defer_regulariser_join`` (and gradients enabled, regularisers present) ``loss``
+        """-> (loss, loss_dict, extras).  ``A_cano2pose`` [J,4,4]: one frame per step (the reference's step); [K,J,4,4]: a chunk
+        of K <= 16 frames of the step's Gaussians -- ONE attribute decode, the K frames rendered, compared (``gt_rgb`` / ``mask``
+        [K,...] or one for all) and differentiated in one call per direction, the photometric terms summed over the frames,
+        the regularisers once (``transl`` [K,3] / [3]; cameras: one, or stacked [K,4,4] / [K,3] in ``raster_settings``).  With ``defer_regulariser_join`` (and gradients enabled, regularisers present) ``loss``
         is **None**: the photometric and the regulariser terms are two autograd roots (``extras["loss_roots"]``) -- call
         ``self.backward(loss_dict, extras)``, which runs both, joins the regularisers' side stream and fills
         ``loss_dict["loss"]``.  Until then the regulariser entries of ``loss_dict`` live on that UNJOINED stream: do not read
@@ -153,9 +156,17 @@ class AvatarStep(torch.nn.Module):
                 else:
                     defer = False
                     regularisers()
-        color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
-                                                   self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                   transl=transl)
+        frames = A_cano2pose.dim() == 4                          # [K,J,4,4]: a CHUNK of K frames of this step's Gaussians (round 4)
+        if frames:
+            # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
+            # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
+            color, radii = rasterize_skinned_frames(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
+                                                    self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                    transl=transl)
+        else:
+            color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
+                                                       self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                       transl=transl)
         if defer:
             side.wait_stream(cur)                                # the raster forward has the GPU to itself; then the query
             with torch.cuda.stream(side):
@@ -163,7 +174,12 @@ class AvatarStep(torch.nn.Module):
                 reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
                 vals = [v.reshape(()) for v in reg.values()]
                 reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
-        loss_dict, extras = photometric_loss(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
+        if frames:
+            per_frame, extras = photometric_loss_frames(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
+            loss_dict = {k: v.sum() for k, v in per_frame.items()}          # the step's photometric terms: summed over its frames
+            extras = dict(extras, per_frame=per_frame)
+        else:
+            loss_dict, extras = photometric_loss(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
         if defer:
             # two roots, no join: the regularisers' gradients are waited for where they are consumed (AvatarStep.backward)
             vals = [v.reshape(()) for v in loss_dict.values()]

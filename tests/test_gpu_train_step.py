@@ -268,3 +268,72 @@ def test_capture_step_returns_a_replayable_graph():
         off.mul_(0.5)
     graph.replay(); torch.cuda.synchronize()
     assert abs(float(out["loss"]) - ref) <= 1e-6 * abs(ref) and torch.allclose(off.grad, gref, rtol=1e-6, atol=0)
+
+
+def test_a_step_over_a_chunk_of_frames_equals_the_sum_of_one_frame_steps():
+    """AvatarStep with A [K,J,4,4]: ONE decode, K frames rendered / compared / differentiated in one call per direction.  With the
+    regularisers off its loss is the sum of K one-frame steps' losses (bit for bit per frame) and its parameter gradients their sum
+    (to 2e-5 of each gradient's scale: autograd adds the K one-frame gradients in another order; tri-plane scatter uses float
+    atomics); with regularisers on, they enter once per step."""
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.regularizers import L2Norm
+    from sings_amd.train_step import AvatarStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    rs = np.random.RandomState(5)
+    N, J, W, H, K = 4000, 24, 160, 144, 4
+    xyz = (rs.normal(0, 0.3, (N, 3)) * np.array([0.5, 1.0, 0.3])).astype(np.float32)
+    A = np.tile(np.eye(4, dtype=np.float32), (K, J, 1, 1))
+    for f in range(K):
+        for j in range(J):
+            A[f, j, :3, :3] = lo.batch_rodrigues(torch.from_numpy(rs.normal(0, 0.25, (1, 3)).astype(np.float32))).numpy()[0]
+            A[f, j, :3, 3] = rs.normal(0, 0.04, 3)
+    w = rs.rand(N, J).astype(np.float32) ** 6
+    w[np.arange(N), rs.randint(0, J, N)] += 0.3
+    w = (w / w.sum(1, keepdims=True)).astype(np.float32)
+    cam = make_camera(np.eye(4, dtype=np.float32), 900.0, 900.0, W / 2, H / 2, W, H)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    transl = t(np.array([0.02, -0.05, 4.0], np.float32)[None] + rs.normal(0, 0.02, (K, 3)).astype(np.float32))
+    smpl_scale = t(np.array([1.05], np.float32)); bg = t(np.array([0.3, 0.5, 0.2], np.float32))
+    gt = t(rs.uniform(0, 1, (K, 3, H, W)).astype(np.float32))
+    yy, xx = np.mgrid[0:H, 0:W]
+    mask = t(((((xx - W / 2) / (W / 3)) ** 2 + ((yy - H / 2) / (H / 2.4)) ** 2) < 1).astype(np.float32))
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [16, 16, 16], 'multires': [1, 2]}
+    tri = HexPlaneField(cfg, device=dev); geo = GeometryDecoder(64).to(dev); app = AppearanceDecoder(64).to(dev)
+    with torch.no_grad():
+        geo.scales[2].bias.fill_(-3.6); geo.xyz_offsets.weight.mul_(0.05); geo.xyz_offsets.bias.mul_(0.05)
+    rset = GaussianRasterizationSettings(
+        image_height=H, image_width=W, tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=bg,
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    step = AvatarStep(t(xyz), t(w), tri, geo, app).to(dev)               # no regularisers
+    params = [p for p in step.parameters() if p.requires_grad]
+    A_t = t(A)
+    # K one-frame steps, gradients accumulated by autograd
+    for p in params:
+        p.grad = None
+    per = []
+    for f in range(K):
+        loss, ld, ex = step(A_t[f], rset, gt[f], mask, bg, smpl_scale=smpl_scale, transl=transl[f])
+        loss.backward()
+        per.append((ld["l1"].detach().clone(), ld["ssim"].detach().clone(), ex["render_raw"].detach().clone()))
+    ref = [p.grad.clone() for p in params]
+    # one step over the chunk
+    for p in params:
+        p.grad = None
+    loss, ld, ex = step(A_t, rset, gt, mask, bg, smpl_scale=smpl_scale, transl=transl)
+    loss.backward()
+    for f in range(K):
+        assert torch.equal(ex["render_raw"][f], per[f][2]), f
+        assert torch.equal(ex["per_frame"]["l1"][f], per[f][0]) and torch.equal(ex["per_frame"]["ssim"][f], per[f][1]), f
+    assert abs(float(loss.detach()) - sum(float(a + b) for a, b, _ in per)) <= 1e-5 * abs(float(loss.detach()))
+    for p, r in zip(params, ref):
+        scale = float(r.abs().max())
+        assert scale > 0 or float(p.grad.abs().max()) == 0
+        assert float((p.grad - r).abs().max()) <= 2e-5 * scale + 1e-12, (tuple(p.shape), float((p.grad - r).abs().max()), scale)
+    # regularisers: once per step
+    step2 = AvatarStep(t(xyz), t(w), tri, geo, app, l2_norm=L2Norm()).to(dev)
+    lossK, ldK, _ = step2(A_t, rset, gt, mask, bg, smpl_scale=smpl_scale, transl=transl)
+    loss1, ld1, _ = step2(A_t[0], rset, gt[0], mask, bg, smpl_scale=smpl_scale, transl=transl[0])
+    assert torch.allclose(ldK["l2"], ld1["l2"]) and abs(float(ldK["l1"]) - sum(float(a) for a, _, _ in per)) <= 1e-5 * float(ldK["l1"])
