@@ -24,6 +24,7 @@ $TO python3 $ROOT/bench.py --steps 100 --warmup 10 $K1 --no-cpu-baseline > $OUT/
 $TO python3 $ROOT/bench.py --workload avatar --steps 100 --warmup 10 > $OUT/bench_avatar.json 2> $OUT/bench_avatar.err
 $TO python3 $ROOT/bench.py --workload avatar --steps 100 --warmup 10 $K1 --no-cpu-baseline > $OUT/bench_avatar_k1.json 2> $OUT/bench_avatar_k1.err
 $TO python3 $ROOT/bench.py --workload train --steps 30 --warmup 5 > $OUT/bench_train.json 2> $OUT/bench_train.err
+$TO python3 $ROOT/bench.py --workload train --views-per-step 16 --steps 30 --warmup 5 --no-cpu-baseline > $OUT/bench_train_k16.json 2> $OUT/bench_train_k16.err
 $TO python3 $ROOT/bench.py --gaussians 50000 --width 512 --height 512 --sh-degree 0 --forward-only --steps 200 --no-cpu-baseline > $OUT/bench_cfg2.json 2> $OUT/bench_cfg2.err
 $TO python3 $ROOT/bench.py --gaussians 500000 --width 2048 --height 2048 --regularisers --steps 40 --no-cpu-baseline > $OUT/bench_cfg5.json 2> $OUT/bench_cfg5.err
 SINGS_BENCH_FORCE_DIST=1 $TO python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_rccl_world1.json 2> $OUT/bench_rccl_world1.err

@@ -9,6 +9,6 @@ python tools/pmc_summary.py $P/k8 ${TAG}_k8 frames_per_launch=8 | tail -1 | cut 
 python tools/pmc_summary.py $P/avatar_k8 ${TAG}_avatar_k8 $AV frames_per_launch=8 | tail -1 | cut -c1-100
 python tools/pmc_summary.py $P/cfg2 ${TAG}_cfg2 gaussians=50000 width=512 height=512 sh_degree=0 | tail -1 | cut -c1-100
 python tools/pmc_summary.py $P/cfg5 ${TAG}_cfg5 gaussians=500000 width=2048 height=2048 | tail -1 | cut -c1-100
-for f in bench_default bench_cfg3_k1 bench_avatar bench_avatar_k1 bench_train bench_cfg2 bench_cfg5 bench_rccl_world1 bench_rccl_world1_rs_ag; do cp $P/$f.json profiles/${TAG}_$f.json; done
+for f in bench_default bench_cfg3_k1 bench_avatar bench_avatar_k1 bench_train bench_train_k16 bench_cfg2 bench_cfg5 bench_rccl_world1 bench_rccl_world1_rs_ag; do cp $P/$f.json profiles/${TAG}_$f.json; done
 for f in cfg3_k1_kernel_stats cfg3_k1_timeline cfg3_k8_kernel_stats cfg3_k8_timeline cfg3_default_kernel_stats avatar_k1_kernel_stats avatar_k1_timeline avatar_k8_kernel_stats avatar_k8_timeline avatar_default_kernel_stats train_kernel_stats; do cp $P/$f.csv profiles/${TAG}_$f.csv; done
 cp $P/train_step_trace.log profiles/${TAG}_train_step_trace.log; cp $P/wrapper_time.log profiles/${TAG}_wrapper_time.log
