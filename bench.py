@@ -404,8 +404,9 @@ def main_raster(a):
         # (R within 0.1 % of camera 0's).  Rounds 1-3 shifted by 0.05 x index: from index ~4 on the scene slides out of the frustum
         # (camera 7: R - 3.7 %, camera 15: - 13 %, camera 63: - 64 %), i.e. a larger batch rendered LIGHTER views (LAB.md 4.7)
         view = s["viewmatrix"].copy()
-        view[3, 0] = 0.012 * (index % 8)
+        view[3, 0] += 0.012 * (index % 8)
         view[3, 1] += 0.012 * ((index // 8) % 8)
+        view[3, 0] += 0.0015 * (index // 64)                      # beyond 64 cameras (ranks >= 4 at 16 views): still distinct
         proj = (view @ P_T).astype(np.float32)
         campos = np.linalg.inv(view)[3, :3].astype(np.float32)
         return view, proj, campos, GaussianRasterizationSettings(

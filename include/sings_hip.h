@@ -77,6 +77,13 @@ typedef struct SgLayout {
     size_t bwd_bytes;
 } SgLayout;
 
+/* SG_ABI_VERSION changes whenever a struct of this header changes layout or an entry point changes its signature or the meaning of
+ * a workspace size (round 4 inserted SgLayout.bin_rec_valid and enlarged the K-frame bwd_ws without a signal: ADVICE r4).  A C
+ * caller checks `sg_abi_version() == SG_ABI_VERSION` once after dlopen; the Python host does (sings_amd/_lib.py).  New SgLayout
+ * fields are appended from now on.  Workspaces are sized ONLY through sg_layout (one frame) / sg_frames_layout (K frames) -- never
+ * as a multiple computed by the caller. */
+#define SG_ABI_VERSION 5
+int sg_abi_version(void);
 const char *sg_version(void);
 const char *sg_last_error(void);
 
@@ -287,7 +294,8 @@ int sg_skinned_backward_gaussians(const SgRasterSettings *s, int P, const SgSkin
  *
  * Layout of a K-frame call: every per-frame array is K consecutive single-frame arrays --
  *   workspaces : geom_ws / binning_ws / image_ws / bwd_ws = K x sg_layout(...).{geom,bin,img,bwd}_bytes (sg_frames_layout;
- *                bwd_ws, K > 1: + K x P x 48 bytes behind the K record buffers, scratch of sg_rasterize_backward_gaussians_frames),
+ *                bwd_ws, K > 1: the K record buffers + the aligned record-sum scratch of sg_rasterize_backward_gaussians_frames
+ *                behind them: take the size from sg_frames_layout, it is NOT K x bwd_bytes),
  *   out_color / dL_dout_color [K,3,H,W], radii [K,P], dL_dmeans2D [K,P,3], posed_* [K,P,.], dL_dA [K,J,16], dL_dtransl [K,3],
  *   skin->A [K,J,16]; skin->transl [K,3] (transl_stride 3) or [3] shared (0);
  *   cameras: camera_stride 1: s->viewmatrix [K,16], s->projmatrix [K,16], s->campos [K,3]; 0: one camera for all frames

@@ -221,6 +221,9 @@ void FN(sgo_preprocess)(int P, int D, int M,
         REAL l1 = mid + sq, l2 = mid - sq;
         REAL lm = l1 > l2 ? l1 : l2;
         REAL my_radius = CEIL((REAL)3 * SQRT(lm));
+        /* non-finite / non-positive / unrepresentable radius (NaN or Inf covariance): culled.  Upstream's (int)NaN is 0 on its
+         * hardware: radii = 0, no keys emitted -- nothing rendered; (int) of such a value is undefined in C, so it is decided here */
+        if (!(my_radius > (REAL)0 && my_radius < (REAL)1073741824.0)) continue;
         REAL pix[2] = { ((pp[0] + (REAL)1) * (REAL)W - (REAL)1) * (REAL)0.5,
                         ((pp[1] + (REAL)1) * (REAL)H - (REAL)1) * (REAL)0.5 };
         int mr = (int)my_radius;

@@ -49,7 +49,7 @@ class SgTriplane(C.Structure):
 
 
 # every symbol include/sings_hip.h declares
-EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
+EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "sg_rasterize_backward",
            "sg_rasterize_backward_records", "sg_rasterize_backward_gaussians", "sg_skinned_backward_gaussians",
            "sg_mark_visible", "sg_read_num_rendered", "sg_signal_alloc", "sg_signal_free", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
@@ -61,6 +61,7 @@ EXPORTS = ("sg_version", "sg_last_error", "sg_layout", "sg_rasterize_forward", "
            "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
            "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames")
 NUM_KERNELS = 8
+ABI_VERSION = 5                      # SG_ABI_VERSION
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT
@@ -84,6 +85,10 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
     lib.sg_version.restype = C.c_char_p
+    lib.sg_abi_version.restype = C.c_int
+    if lib.sg_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"sings_amd: {LIB_PATH} speaks ABI {lib.sg_abi_version()}, this host code ABI {ABI_VERSION} "
+                           "(include/sings_hip.h SG_ABI_VERSION): rebuild with `make -C sings_amd/csrc`")
     lib.sg_last_error.restype = C.c_char_p
     lib.sg_layout.argtypes = [i32, i32, i32, sz, C.POINTER(SgLayout)]
     lib.sg_rasterize_forward.argtypes = ([C.POINTER(SgRasterSettings), i32] + [vp] * 7 +

@@ -67,6 +67,10 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
     float l1 = mid + sq, l2 = mid - sq;
     float lm = l1 > l2 ? l1 : l2;
     float my_radius = ceilf(3.0f * sqrtf(lm));
+    // A radius that is not a positive number below 2^30 pixels (NaN / Inf covariance: non-finite scales or rotations): culled.
+    // Upstream converts it with (int) -- 0 for NaN on its hardware --, stores radii = 0 and emits no keys for it: nothing is
+    // rendered there either; here the Gaussian also takes no pair slot and a zero gradient (tests/test_gpu_degenerate.py).
+    if (!(my_radius > 0.0f && my_radius < 1073741824.0f)) return;
     float pix0 = ((ppx + 1.0f) * (float)c.W - 1.0f) * 0.5f;
     float pix1 = ((ppy + 1.0f) * (float)c.H - 1.0f) * 0.5f;
     int r = (int)my_radius, x0, y0, x1, y1;

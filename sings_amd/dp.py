@@ -165,14 +165,31 @@ class GradientPipeline:
         self.cuda = rows.is_cuda
         # one view per step: the row IS the sum (no fold, no copy)
         self.acc = rows[0] if self.k == 1 else torch.zeros(self.n_full, dtype=rows.dtype, device=rows.device)
-        world = 1 if frame_parallel is None else frame_parallel.world
-        c = max(1, int(chunks)) if frame_parallel is not None and frame_parallel.active else 1
-        step = -(-self.n // c)
-        step = -(-step // (world * 64)) * (world * 64)           # chunk boundaries the rs_ag schedule divides, 256-B aligned
-        self.bounds = [(lo, min(lo + step, self.n)) for lo in range(0, self.n, step)]
+        self._chunks = chunks
+        self._set_bounds()
         if self.cuda:
             self._t = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         self._timed = False
+
+    def _set_bounds(self):
+        fp = self.fp
+        world = 1 if fp is None else fp.world
+        c = max(1, int(self._chunks)) if fp is not None and fp.active else 1
+        step = -(-self.n // c)
+        step = -(-step // (world * 64)) * (world * 64)           # chunk boundaries the rs_ag schedule divides, 256-B aligned
+        self.bounds = [(lo, min(lo + step, self.n)) for lo in range(0, self.n, step)]
+
+    def set_active(self, active):
+        """Change the prefix that is folded and reduced (``oneupSHdegree``, gs_trainer.py:436-438: more SH planes carry gradient
+        from now on).  Growing is always safe -- the planes behind the old prefix were zero; every rank must call it at the same
+        step (the chunk boundaries of the collective follow)."""
+        active = self.n_full if active is None else int(active)
+        if not 0 < active <= self.n_full:
+            raise ValueError("active must be in (0, floats_per_view]")
+        if active < self.n and self.k > 1:
+            self.acc[active:self.n].zero_()                      # (what the wider fold left there)
+        self.n = active
+        self._set_bounds()
 
     def reduce(self):
         """Call on the stream the views were joined into.  Returns ``acc`` (ready on that stream)."""

@@ -270,8 +270,12 @@ class ViewBatch:
     """
 
     @staticmethod
-    def gradient_rows(views, per_view, device):
-        return torch.empty((int(views), int(per_view)), dtype=torch.float32, device=device)
+    def gradient_rows(views, per_view, device, zero=True):
+        """``zero`` (default): ``sh_planar`` engines write only the SH planes in use, and with one row the row IS the
+        accumulator -- an uninitialised tail would reach the optimiser.  ``zero=False`` for engines that write every
+        float of their row (the reference layout) and callers that want to skip the one-off fill."""
+        alloc = torch.zeros if zero else torch.empty
+        return alloc((int(views), int(per_view)), dtype=torch.float32, device=device)
 
     def __init__(self, engines, grads, streams=3, frame_parallel=None, chunks=4, active=None):
         from .dp import GradientPipeline
@@ -293,6 +297,7 @@ class ViewBatch:
         # the views have joined it: sings_amd.dp.GradientPipeline
         self.pipe = GradientPipeline(grads, frame_parallel, chunks=chunks, active=active)
         self.acc = self.pipe.acc
+        self._active_given = active is not None
         self._events = [torch.cuda.Event() for _ in self.engines] if self.chain else None
         for e in self.engines:                                # several views in flight: no latency-only work (SG_FLAG_THROUGHPUT)
             e.throughput = self.n > 1 or getattr(e, "K", 1) > 1
@@ -312,10 +317,28 @@ class ViewBatch:
             return acc, after, self._events[v]
         e._chain = resolve
 
+    def set_active(self, sh_degree):
+        """The engines' SH degree changed (``oneupSHdegree``): widen (or narrow) the prefix of the gradient rows that is folded and
+        all-reduced to ``engine.active_floats(sh_degree)``.  Every rank calls it at the same step."""
+        self.pipe.set_active(self.engines[0].active_floats(sh_degree))
+        self._active_given = True
+
+    def _check_active(self):
+        """An ``sh_planar`` engine whose camera asks for more SH planes than the configured prefix covers would have its extra
+        planes silently dropped by the fold and the collective: refuse (call ``set_active(sh_degree)``)."""
+        if not self._active_given:
+            return
+        for e in self.engines:
+            st = getattr(e, "_s", None)
+            if getattr(e, "sh_planar", False) and st is not None and e.active_floats(int(st.sh_degree)) > self.pipe.n:
+                raise RuntimeError(f"ViewBatch: an engine renders at SH degree {int(st.sh_degree)} but only the first {self.pipe.n} "
+                                   f"floats of a gradient row are folded / all-reduced: call set_active({int(st.sh_degree)})")
+
     def run_unreduced(self, fn):
         """Render the views only (rows left unfolded): the caller reduces them itself, e.g. ``pipe.one_shot()``.  ``fn(v, engine)``
         runs view v's forward and AT MOST ONE backward; every row must be written by at least one backward before the rows are
         folded (checked).  Outside ``run`` the engines are plain again (a later stand-alone backward writes, never adds)."""
+        self._check_active()
         self._written = [False] * self.rows
         self._last_event = None
         try:
@@ -487,11 +510,18 @@ class SkinnedFramesEngine(_FramesBase):
         self._k.transl = None if transl is None else transl.data_ptr()
         self._fb = _frame_batch(self.K, self._cam_stride, tstride)
 
-    def forward(self, shs, opacities, scales, sync_num_rendered=False, phase=None):
+    def forward(self, shs, opacities, scales, sync_num_rendered=False, phase=None, posed_out=None):
         """``phase``: None = the whole forward; "binning" / "composite" = its two halves as separate calls on the same workspaces
-        (SG_FLAG_FORWARD_BINNING / _COMPOSITE), for a caller that runs them on different streams and orders them with events."""
+        (SG_FLAG_FORWARD_BINNING / _COMPOSITE), for a caller that runs them on different streams and orders them with events.
+        ``posed_out``: optional (xyz [K,P,3], quaternions [K,P,4], scales [K,P,3]) fp32 tensors the posed values of the K frames are
+        also written to (what forward_chunk returns, sings_hybrid.py:512-553; the render itself never reads them back)."""
         if self._s is None or self._fb is None or self._k is None:
             raise RuntimeError("SkinnedFramesEngine: set_camera() and set_frames() first")
+        if posed_out is not None:
+            for x, wdt in zip(posed_out, (3, 4, 3)):
+                if (tuple(x.shape) != (self.K, self.P, wdt) or x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.dev):
+                    raise ValueError(f"posed_out: contiguous fp32 [{self.K},{self.P},3|4|3] tensors on {self.dev}")
+        pxyz, pq, psc = posed_out if posed_out is not None else (None, None, None)
         nr = (C.c_int64 * self.K)()
         self._fb.camera_stride = self._cam_stride
         self._s.flags = self._flags() | {None: 0, "binning": _lib.FLAG_FORWARD_BINNING, "composite": _lib.FLAG_FORWARD_COMPOSITE}[phase]
@@ -500,8 +530,8 @@ class SkinnedFramesEngine(_FramesBase):
         self._clean = False
         _lib.check(self.lib.sg_skinned_forward_frames(
             C.byref(self._s), C.byref(self._fb), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales),
-            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
-            nr if sync_num_rendered and phase != "composite" else None, self._stream()), "skinned forward (frames)")
+            _ptr(self.geom), _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), _ptr(pxyz), _ptr(pq),
+            _ptr(psc), nr if sync_num_rendered and phase != "composite" else None, self._stream()), "skinned forward (frames)")
         self._clean = phase != "binning"                      # (the COMPOSITE leaves the counters zeroed for the next forward)
         return [int(v) for v in nr] if sync_num_rendered and phase != "composite" else None
 

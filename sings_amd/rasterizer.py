@@ -70,8 +70,8 @@ _signal_lock = threading.Lock()
 def _signal_slot(dev):
     """(device address, host address) of the next early-count word of ``dev`` (a ring: a "sync" forward consumes its word
     before it returns, so slots are only shared by calls that are 64 forwards apart).  Thread-safe (a forward on the main
-    thread and one on an autograd / data-loader thread must not be handed the same word); the ring is released by
-    ``reset_overflow_state`` and at interpreter exit."""
+    thread and one on an autograd / data-loader thread must not be handed the same word); the ring is released at
+    interpreter exit only (``reset_overflow_state`` rewinds its cursor: another thread may hold a slot)."""
     with _signal_lock:
         sg = _signal.get(dev.index)
         if sg is None:
@@ -94,7 +94,17 @@ def _free_signal_rings(dev_index=None):
                 pass
 
 
-atexit.register(_free_signal_rings)
+def _free_signal_rings_at_exit():
+    # kernels of a forward still in flight write their slot: drain the devices before the pinned words go
+    try:
+        if torch.cuda.is_initialized():
+            torch.cuda.synchronize()
+    except Exception:
+        return                                        # (the process is exiting: leaking 512 pinned bytes is harmless)
+    _free_signal_rings()
+
+
+atexit.register(_free_signal_rings_at_exit)
 
 
 def set_overflow_check(mode="sync", on_overflow=None, capacity_pairs=None, device=None):
@@ -189,6 +199,18 @@ def _forward_plan(dev, P, W, H):
     return cap, sync, sig
 
 
+_flag_bit_cache = {}
+
+
+def _flag_bits(dev):
+    """[1, 2, 4, ... 2^15] on ``dev``: OR-reduction of header flag words over the frames of a K-frame call = sum over the bits
+    of the per-bit maxima (torch has no bitwise-or reduction)."""
+    t = _flag_bit_cache.get(dev.index)
+    if t is None:
+        t = _flag_bit_cache[dev.index] = (2 ** torch.arange(16, dtype=torch.int32)).to(dev)
+    return t
+
+
 def _forward_done_sync(dev, R, sig):
     _seen[dev.index].add(sig)
     _grow(dev.index, R)
@@ -201,14 +223,12 @@ def reset_overflow_state(device=None):
             d.clear()
         else:
             d.pop(torch.device(device).index, None)
-    if _signal and torch.cuda.is_initialized():
-        # no "sync" forward is in flight here (each consumes its word before it returns): the pinned ring can go
-        if device is None:
-            torch.cuda.synchronize()
-            _free_signal_rings()
-        else:
-            torch.cuda.synchronize(torch.device(device))
-            _free_signal_rings(torch.device(device).index)
+    # The pinned early-count ring is NOT freed here: a forward on another thread may already hold a slot address the
+    # scan kernel will write and the host will spin on; only its cursor is rewound.  The ring lives until interpreter exit.
+    with _signal_lock:
+        for k, sg in _signal.items():
+            if device is None or k == torch.device(device).index:
+                sg[2] = 0
 
 
 def check_deferred_overflow(device=None):

@@ -141,6 +141,7 @@ class GaussiansEdgeLoss(torch.nn.Module):
         if torch.cuda.is_current_stream_capturing() and torch.cuda.current_stream(dev) != st0:
             # a SECOND side stream inside a HIP-graph capture: the buffers of prepare() would need record_stream across streams
             # of the capture, and hipStreamEndCapture crashed on exactly that (round 3) -- refuse instead of dying later
+            self._pending = None                     # (the query is dropped: the module stays usable after the error)
             raise RuntimeError("GaussiansEdgeLoss.finish(): inside a HIP-graph capture the query must run on the stream that ran "
                                "prepare() (keep the whole regulariser on ONE side stream)")
         self._pending = None
@@ -148,9 +149,19 @@ class GaussiansEdgeLoss(torch.nn.Module):
             _lib.check(lib.sg_gaussian_edge_finish(N, self._K, _ptr(sc), _ptr(ws), None, _ptr(loss), None, _ptr(d_sc),
                                                    _stream(dev)), "gaussian edge loss (query)")
 
+    def abort(self):
+        """Drop a prepared query that will never be finished (the step between prepare() and finish() raised -- an overflow with
+        on_overflow='raise', an allocation failure, bad input): the loss tensor prepare() returned must not be used; the module is
+        ready for the next prepare().  No-op when nothing is pending."""
+        self._pending = None
+
     def forward(self, human_gs_out):
         out = self.prepare(human_gs_out)
-        self.finish()
+        try:
+            self.finish()
+        except BaseException:
+            self.abort()
+            raise
         return out
 
 

@@ -216,8 +216,10 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
         color = torch.empty((K, 3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((K, P), dtype=torch.int32, device=dev)
         T = ((W + 15) // 16) * ((H + 15) // 16)
-        cap = max(_rz._capacity_hint.get(dev.index, 0), 4 * P + T, 1 << 16)
-        sync = not (torch.cuda.is_current_stream_capturing() or _rz._mode["mode"] == "deferred")
+        # the same plan as the single-frame op (rasterizer.set_overflow_check): "sync" reads the K pair counts before returning,
+        # "async" does so for the first call of a shape only and afterwards copies the K headers' (worst R, OR of the flags) to the
+        # pinned ring without waiting, "deferred" / a graph capture folds them into the device-side accumulator
+        cap, sync, sig = _rz._forward_plan(dev, P, W, H)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             while True:
@@ -237,10 +239,13 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
                     break
                 cap = int(R * _rz._HEADROOM) + 1024
             if sync:
-                _rz._grow(dev.index, R)
+                _rz._forward_done_sync(dev, R, sig)
             else:
-                # (pair count, overflow flag) of the worst frame -> the device-side accumulator of the deferred check
-                hdr = binning.view(K, L.bin_bytes)[:, :8].view(torch.int32).amax(0).contiguous()
+                # largest pair count and the OR of the K frames' flag words (a frame's "long list" bit must not hide another
+                # frame's "overflow" bit: ADVICE r4) -> the asynchronous / deferred check of the single-frame op
+                h = binning.view(K, L.bin_bytes)[:, :8].view(torch.int32)
+                flags = (h[:, 1:2] & _rz._flag_bits(dev)).amax(0).sum().to(torch.int32)
+                hdr = torch.stack([h[:, 0].amax(), flags]).contiguous()
                 _rz._after_forward(dev, hdr.view(torch.uint8), cap)
                 nr = [0] * K
         ctx.rs, ctx.cap, ctx.M, ctx.K, ctx.fb = rs, cap, M, K, (cam_stride, tstride)

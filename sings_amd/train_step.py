@@ -157,20 +157,32 @@ class AvatarStep(torch.nn.Module):
                     defer = False
                     regularisers()
         frames = A_cano2pose.dim() == 4                          # [K,J,4,4]: a CHUNK of K frames of this step's Gaussians (round 4)
-        if frames:
-            # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
-            # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
-            color, radii = rasterize_skinned_frames(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
-                                                    self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                    transl=transl)
-        else:
-            color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
-                                                       self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                       transl=transl)
+        try:
+            if frames:
+                # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
+                # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
+                color, radii = rasterize_skinned_frames(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
+                                                        self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                        transl=transl)
+            else:
+                color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
+                                                           self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                           transl=transl)
+        except BaseException:
+            # a raster forward that raises (pair-capacity overflow with on_overflow='raise', out of memory, bad input) sits between
+            # the edge loss's prepare() and finish(): drop the prepared query, or every later step would fail with "prepare() called
+            # twice"  -- the step that raised is lost, the module is not
+            if defer:
+                self.gaussian_connect.abort()
+            raise
         if defer:
             side.wait_stream(cur)                                # the raster forward has the GPU to itself; then the query
             with torch.cuda.stream(side):
-                self.gaussian_connect.finish()
+                try:
+                    self.gaussian_connect.finish()
+                except BaseException:
+                    self.gaussian_connect.abort()
+                    raise
                 reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
                 vals = [v.reshape(()) for v in reg.values()]
                 reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()

@@ -244,3 +244,23 @@ def test_packed_gradient_prefix_equals_the_full_row_sum_world2():
             assert np.array_equal(got_sh[:nc].transpose(1, 0, 2), ref_sh[:, :nc])
             assert not got[active:].any() and not ref_sh[:, nc:].any()
         assert np.array_equal(res[0][2], res[1][2])
+
+
+def test_pipeline_active_prefix_follows_the_sh_degree():
+    """GradientPipeline.set_active: the folded / reduced prefix of the gradient rows can grow when the SH degree is raised
+    (oneupSHdegree, gs_trainer.py:436-438) -- planes behind the old prefix are no longer dropped -- and shrink again (the tail of
+    the accumulator is zeroed, not left with the wider fold's sums)."""
+    rows = torch.arange(3 * 40, dtype=torch.float32).view(3, 40)
+    pipe = GradientPipeline(rows, None, active=10)
+    acc = pipe.reduce()
+    assert torch.equal(acc[:10], rows[:, :10].sum(0)) and float(acc[10:].abs().max()) == 0
+    pipe.set_active(25)
+    acc = pipe.reduce()
+    assert torch.equal(acc[:25], rows[:, :25].sum(0)) and float(acc[25:].abs().max()) == 0
+    assert pipe.bounds[-1][1] == 25
+    pipe.set_active(10)
+    acc = pipe.reduce()
+    assert torch.equal(acc[:10], rows[:, :10].sum(0)) and float(acc[10:].abs().max()) == 0
+    import pytest
+    with pytest.raises(ValueError):
+        pipe.set_active(41)

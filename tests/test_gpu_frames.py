@@ -546,3 +546,69 @@ def test_planar_sh_gradients_are_the_reference_layout_transposed(K):
         assert not bool(b.d_sh[1:].any())                            # never touched
         assert torch.equal(b.grad_flat[:N * 7], a.grad_flat[:N * 7])
         assert not bool(b.grad_flat[b.active_floats(0):].any())
+
+
+def test_cfg3_eight_cameras_in_one_launch_against_the_oracle():
+    """ONE K = 8 launch per kernel of BASELINE configs[2] at FULL size (200 k Gaussians, 1080p, SH degree 3: the launch the
+    headline bench line times, sg_rasterize_forward_frames / *_backward_*_frames with bench.py's cameras) compared with the CPU
+    oracle DIRECTLY, not through "K-camera call == K single-camera calls == oracle": every camera's pair count and radii bit for
+    bit; cameras 0 and 7: sorted lists and ranges bit for bit, image (<= 1e-5 off borderline pixels, those within the oracle's
+    flip bound), the screen-space gradient; and the gradient row the launch leaves behind = the SUM of the oracle's gradients
+    over the eight cameras (means, scales, rotations, opacity, SH).  ~35 s of scalar oracle."""
+    from oracle import raster_oracle as ro
+    from sings_amd.engine import RasterFramesEngine
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import synthetic_scene
+    dev = _dev()
+    N, W, H, deg, K = 200000, 1920, 1080, 3, 8
+    s = synthetic_scene(N, W, H, deg, 3)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
+    views = np.repeat(s["viewmatrix"][None], K, 0).copy(); views[:, 3, 0] = 0.012 * np.arange(K)       # bench.py's cameras 0..7
+    projs = np.stack([(v @ P_T).astype(np.float32) for v in views])
+    cps = np.stack([np.linalg.inv(v)[3, :3].astype(np.float32) for v in views])
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                       scale_modifier=1.0, viewmatrix=t(views), projmatrix=t(projs), sh_degree=deg, campos=t(cps),
+                                       prefiltered=False, debug=False)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    eng = RasterFramesEngine(N, W, H, 16, K, dev, 5 * N)
+    eng.set_camera(rs)
+    Rs = eng.forward(*ins, sync_num_rendered=True)
+    assert max(Rs) <= eng.cap
+    color = eng.color.cpu().numpy(); radii = eng.radii.cpu().numpy()
+    L, Tn = eng.L, ((W + 15) // 16) * ((H + 15) // 16)
+    bins = eng.binning.view(K, -1)
+    dL_n = np.random.RandomState(12).normal(0, 1, (K, 3, H, W)).astype(np.float32)
+    sums = {k: 0.0 for k in ("dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dopacity", "dL_dsh")}
+    keep = {}
+    BORDER = 2e-5
+    for f in range(K):
+        o = ro.forward(s["means3D"], s["opacities"], views[f], projs[f], cps[f], W, H, s["tanfovx"], s["tanfovy"], s["bg"],
+                       scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=deg)
+        assert Rs[f] == o["R"] and np.array_equal(radii[f], o["radii"]), (f, Rs[f], o["R"])
+        border = o["margin"] < BORDER
+        dL_n[f][:, border] = 0
+        g = ro.backward(o, dL_n[f])
+        for k in sums:
+            sums[k] = sums[k] + g[k].astype(np.float64)
+        if f in (0, K - 1):
+            ranges = bins[f, L.bin_ranges:L.bin_ranges + 8 * Tn].view(torch.int32).view(Tn, 2).cpu().numpy()
+            plist = bins[f, L.bin_point_list:L.bin_point_list + 4 * Rs[f]].view(torch.int32).cpu().numpy()
+            assert np.array_equal(ranges.astype(np.uint32), o["ranges"]) and np.array_equal(plist.astype(np.uint32), o["point_list"]), f
+            diff = np.abs(color[f] - o["color"]).max(0)
+            assert diff[~border].max() <= 1e-5, (f, diff[~border].max())
+            assert border.sum() == 0 or (diff[border] - (1e-5 + 1.001 * o["flip"][border])).max() <= 0, f
+            keep[f] = g["dL_dmean2D"]
+    eng.backward(*ins, t(dL_n))
+    torch.cuda.synchronize()
+
+    def close(name, a, b, rtol=2e-4, atol=2e-6):
+        a = np.asarray(a, np.float64).reshape(b.shape); b = np.asarray(b, np.float64)
+        scale = np.abs(b).max() + 1e-30
+        bad = np.abs(a - b) > rtol * np.abs(b) + atol * scale
+        assert not bad.any(), f"{name}: {bad.sum()} of {bad.size} off; worst {np.abs(a - b).max():.3e} (scale {scale:.3e})"
+    for f, g2 in keep.items():
+        close(f"means2D[{f}]", eng.d_means2D[f].cpu().numpy(), g2)
+    for name, ten, key in (("means3D", eng.d_means3D, "dL_dmeans3D"), ("scales", eng.d_scales, "dL_dscales"),
+                           ("rotations", eng.d_rots, "dL_drots"), ("opacity", eng.d_opacity, "dL_dopacity"), ("sh", eng.d_sh, "dL_dsh")):
+        close("sum " + name, ten.cpu().numpy(), sums[key])

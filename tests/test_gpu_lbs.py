@@ -151,3 +151,48 @@ def test_joint_transforms_kernel_vs_torch_chain(J, B):
                                rtol=2e-5, atol=2e-5)
     with pytest.raises(ValueError):
         body.joint_transforms_hip(torch.zeros(1, 9, device=dev), torch.zeros(3, 3, device=dev), (-1, 2, 0))
+
+
+def test_joint_transforms_and_template_skinning_against_golden_g2():
+    """SURVEY.md 8 row a10 on the HIP path, against the REFERENCE's numbers: golden G2 holds the outputs of the reference's own
+    batch_rodrigues + batch_rigid_transform + lbs (sings/rec/utils/body_model/smpl.py:274-513) for the seeded SMPL-shaped model
+    (V = 6 890, J = 24) at three poses (zero, the 'da' pose, one AMASS frame).
+     * sg_joint_transforms (one launch for the three poses) vs G["g2_A_i"], and the posed joints A [j;1] + ... vs G["g2_J_i"];
+     * sg_lbs_forward on the 6 890-vertex shaped template with those A (BASELINE configs[0]'s shape) vs G["g2_verts_i"];
+     * sg_joint_transforms_backward (dpose, djoints) vs the fp64 autograd of oracle/lbs_oracle.py's restatement of the chain."""
+    from sings_amd import body
+    from sings_amd.lbs import lbs_extra
+    dev = _dev()
+    bm = lo.synthetic_body_model(seed=0)
+    parents = tuple(int(p) for p in bm["parents"])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    # shaped template and rest joints: the blend-shape / regressor einsums of smpl.py:371-412, once per shape, on the host
+    v_shaped = T(bm["v_template"]) + torch.einsum("l,mkl->mk", T(G["g2_betas"][0]), T(bm["shapedirs"]))
+    J_rest = torch.einsum("ik,ji->jk", v_shaped, T(bm["J_regressor"]))
+    poses = T(G["g2_poses"])                                                   # [3, 72]
+    pose_d = poses.to(dev).requires_grad_(True); jr_d = J_rest.to(dev).requires_grad_(True)
+    A = body.joint_transforms_hip(pose_d, jr_d, parents)                        # [3, 24, 4, 4], ONE launch
+    for i in range(3):
+        np.testing.assert_allclose(A[i].detach().cpu().numpy(), G[f"g2_A_{i}"][0], rtol=0, atol=3e-6)
+        # posed joints: G_j's translation = A_j [j_rest; 1]
+        Ai = A[i].detach().cpu()
+        posed = torch.einsum("jab,jb->ja", Ai[:, :3, :3], J_rest) + Ai[:, :3, 3]
+        np.testing.assert_allclose(posed.numpy(), G[f"g2_J_{i}"][0], rtol=0, atol=3e-6)
+        verts, _, Tm, _, _ = lbs_extra(A[i:i + 1].detach(), v_shaped[None].to(dev), None, T(bm["lbs_weights"]).to(dev), None,
+                                       disable_posedirs=True)
+        assert verts.shape == (1, 6890, 3)
+        np.testing.assert_allclose(verts[0].cpu().numpy(), G[f"g2_verts_{i}"][0], rtol=0, atol=5e-6)
+    assert np.abs(A[0].detach().cpu().numpy() - np.eye(4)).max() < 1e-5         # zero pose: identities (the 1e-8 of batch_rodrigues)
+    # backward against the oracle's chain in fp64
+    g_n = np.random.RandomState(2).randn(3, 24, 4, 4).astype(np.float32)
+    (A * torch.from_numpy(g_n).to(dev)).sum().backward()
+    p64 = poses.double().requires_grad_(True); j64 = J_rest.double().requires_grad_(True)
+    R64 = lo.batch_rodrigues(p64.view(-1, 3)).view(3, 24, 3, 3)
+    _, A64 = lo.batch_rigid_transform(R64, j64[None].expand(3, -1, -1), list(parents))
+    np.testing.assert_allclose(A.detach().cpu().numpy(), A64.detach().numpy(), rtol=0, atol=3e-6)
+    (A64 * torch.from_numpy(g_n).double()).sum().backward()
+
+    def close(a, b, what):
+        a = a.detach().cpu().numpy().astype(np.float64); b = b.detach().numpy()
+        assert (np.abs(a - b) <= 3e-5 * np.abs(b) + 3e-6 * np.abs(b).max()).all(), (what, np.abs(a - b).max())
+    close(pose_d.grad, p64.grad, "dpose"); close(jr_d.grad, j64.grad, "djoints_rest")

@@ -894,3 +894,48 @@ def test_throughput_flag_changes_the_schedule_not_the_result():
     assert out[0][0] == out[1][0] and out[0][0] > 3000
     for a, b in zip(out[0][1:], out[1][1:]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colour_against_the_reference_spherical_harmonics(deg):
+    """Golden G9 on the HIP path: the colour sg_preprocess_fwd_kernel<D> stores for a Gaussian (record words r, g, b; SH clamp
+    bits) against the REFERENCE's eval_sh (sings/rec/utils/visualize/spherical_harmonics.py:54-113, executed in the build
+    container by tests/golden/gen_sh_golden.py) + 0.5, clamped at 0 -- 512 directions, every octant, degrees 0..3; and
+    dL/dsh of a full backward = reference basis value x the oracle's dL/dcolour."""
+    import sh_case
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sings_amd.inspect_ws import forward_with_state
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    seen = 0
+    for g in sh_case.groups():
+        rs = GaussianRasterizationSettings(image_height=sh_case.H, image_width=sh_case.W, tanfovx=sh_case.TANFOV, tanfovy=sh_case.TANFOV,
+                                           bg=torch.zeros(3, device=dev), scale_modifier=1.0, viewmatrix=t(g["viewmatrix"]),
+                                           projmatrix=t(g["projmatrix"]), sh_degree=deg, campos=t(g["campos"]), prefiltered=False,
+                                           debug=False)
+        st = forward_with_state(rs, t(g["means3D"]), t(g["opacities"]), shs=t(g["shs"]), scales=t(g["scales"]), rotations=t(g["rotations"]))
+        assert bool((st["radii"] > 0).all())
+        rgb, clamped = sh_case.expected_rgb(deg, g["idx"])
+        got = st["rgb"].cpu().numpy()
+        assert np.abs(got - rgb).max() <= 2e-6, np.abs(got - rgb).max()
+        sure = np.abs(sh_case.G9[f"eval_deg{deg}"][g["idx"]] + 0.5) > 1e-5
+        bits = st["clamp_bits"].cpu().numpy()
+        got_clamped = np.stack([(bits >> c) & 1 for c in range(3)], 1).astype(bool)
+        assert np.array_equal(got_clamped[sure], clamped[sure])
+        seen += g["idx"].size
+        if deg == 3:
+            o = ro.forward(g["means3D"], g["opacities"], g["viewmatrix"], g["projmatrix"], g["campos"], sh_case.W, sh_case.H,
+                           sh_case.TANFOV, sh_case.TANFOV, np.zeros(3, np.float32), scales=g["scales"], rotations=g["rotations"],
+                           shs=g["shs"], sh_degree=deg)
+            dL = np.random.RandomState(1).normal(0, 1, (3, sh_case.H, sh_case.W)).astype(np.float32)
+            dL[:, o["margin"] < BORDER] = 0
+            gr = ro.backward(o, dL)
+            dcol = np.where(o["clamped"].astype(bool), 0.0, gr["dL_dcolor"])
+            want = sh_case.G9["basis_deg3"][g["idx"]][:, :, None] * dcol[:, None, :]
+            sh = t(g["shs"]).requires_grad_(True)
+            m = t(g["means3D"])
+            color, _ = GaussianRasterizer(rs)(means3D=m, means2D=torch.zeros_like(m), opacities=t(g["opacities"]), shs=sh,
+                                              scales=t(g["scales"]), rotations=t(g["rotations"]))
+            color.backward(t(dL))
+            _grad_close("dL/dsh vs reference basis", sh.grad.cpu().numpy(), want, rtol=2e-4, atol=2e-6)
+    assert seen == 512

@@ -246,9 +246,9 @@ def test_fused_backward_deterministic_and_ext_refused():
 
 def test_cfg4_full_size_properties():
     """BASELINE configs[3] at full size (150 k canonical Gaussians, J = 52, 512x896, AMASS frame; longest tile list ~10^4:
-    chunked sort + rank merge, depth-segmented backward): too big for the CPU oracle in a test, so size-independent
-    properties -- two runs bitwise identical (image, radii, every gradient incl. dL/dA), the backward linear in dL/dimage, the
-    pair count within the capacity and equal to the sum of the tile rectangles of the visible Gaussians."""
+    bucket sort, depth-segmented backward) through the pre-allocated engine: size-independent properties -- two runs bitwise
+    identical (image, radii, every gradient incl. dL/dA), the backward linear in dL/dimage, the pair count within the capacity.
+    (The same scene against the composed oracle: test_cfg4_full_size_against_the_oracle below.)"""
     import math, os
     from sings_amd.body import joint_transforms
     from sings_amd.engine import SkinnedEngine
@@ -291,6 +291,172 @@ def test_cfg4_full_size_properties():
         err = (c_.double() - ref).abs().max().item(); scale = ref.abs().max().item()
         assert err <= 5e-5 * scale, (name, err, scale)
 
+
+def _cfg4(dev, frame=17):
+    """BASELINE configs[3] as bench.py --workload avatar builds it: avatar_scene(N = 150 000, J = 52), 512 x 896, fx = fy = 5000,
+    AMASS frame `frame` of the committed 120 (global orientation zeroed: the body faces the camera)."""
+    import math, os
+    from sings_amd.body import joint_transforms
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.scene import avatar_scene
+    s = avatar_scene(N=150000, J=52)
+    J = s["J"]
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cam = s["cam"]
+    rs = GaussianRasterizationSettings(
+        image_height=s["H"], image_width=s["W"], tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5),
+        bg=t(s["bg"]), scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]),
+        sh_degree=0, campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    poses72 = np.load(os.path.join(os.path.dirname(__file__), "golden", "lbs_golden.npz"))["amass_poses_72"]
+
+    def A_of(f):
+        pose = np.zeros(J * 3, np.float32); pose[:72] = poses72[f]; pose[:3] = 0
+        return joint_transforms(t(pose), t(s["joints_rest"]), tuple(s["parents"])).reshape(J, 4, 4).contiguous()
+    return s, rs, A_of
+
+
+def _oracle_view(s, cam_args, pxyz, pq, psc, deg=0):
+    import math
+    cam = s["cam"]
+    return ro.forward(pxyz, s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], s["W"], s["H"],
+                      math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), s["bg"], scales=psc, rotations=pq, shs=s["shs"],
+                      sh_degree=deg)
+
+
+def _posed_ulps(pxyz, pq, psc, oxyz, oq, osc):
+    mag = np.abs(oxyz).max(1, keepdims=True)
+    u_xyz = (np.abs(pxyz.astype(np.float64) - oxyz) / np.spacing(mag.astype(np.float32))).max()
+    u_q = (np.abs(pq.astype(np.float64) - oq) / np.spacing(np.float32(1.0))).max()
+    u_sc = (np.abs(psc.astype(np.float64) - osc) / np.spacing(np.abs(osc))).max()
+    return float(u_xyz), float(u_q), float(u_sc)
+
+
+def _oracle_lbs_gradients(s, A, g):
+    """dL/d(canonical means, scales, A, transl) by autograd through oracle/lbs_oracle.py (pinned by the reference-generated
+    lbs_golden.npz), seeded with the raster oracle's gradients w.r.t. the posed means / quaternions / scales."""
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
+    xyz, sc, A_, tr = T(s["xyz_canon"]), T(s["scales"]), T(A), T(s["transl"])
+    eye = torch.eye(3)[None].repeat(s["N"], 1, 1)
+    pxyz_o, pq_o, psc_o, _ = lo.deform_gaussians(xyz, eye, sc, torch.from_numpy(s["lbs_weights"]), A_,
+                                                 smpl_scale=torch.from_numpy(s["smpl_scale"]), transl=tr)
+    ((pxyz_o * torch.from_numpy(g["dL_dmeans3D"])).sum() + (pq_o * torch.from_numpy(g["dL_drots"])).sum()
+     + (psc_o * torch.from_numpy(g["dL_dscales"])).sum()).backward()
+    return xyz.grad.numpy(), sc.grad.numpy(), A_.grad.numpy(), tr.grad.numpy(), (pxyz_o.detach().numpy(), pq_o.detach().numpy(),
+                                                                               psc_o.detach().numpy())
+
+
+def test_cfg4_full_size_against_the_oracle():
+    """BASELINE configs[3] AT FULL SIZE against the composed oracle (the CPU side needs ~4 s): the workload SinGS trains
+    (human_complex.yaml:34-35, 95-96; the calls replaced are sings_hybrid.py:398-428 + gs_renderer_single.py:87-95).
+     * posed means / quaternions / scales of the fused kernel vs oracle/lbs_oracle.py, in ulps (the seam between the two oracles);
+     * the raster oracle on the kernel's own posed values: R, radii, rectangles, depth bits, upstream-format keys, the sorted
+       lists (bucket-sorted: the longest has ~10^4 entries), ranges -- bit for bit; RGB <= 1e-5 off borderline pixels (those
+       within the oracle's flip bound), final_T, n_contrib;
+     * EVERY gradient of the fused op -- canonical means, scales, opacity, SH, the screen-space statistic, dL/dA and dL/dtransl --
+       vs the raster oracle's explicit backward chained through the LBS oracle's autograd (four-workgroup composite of lists
+       > 1024, sparse backward, record-valid bytes, segmented checkpoints: all at their production sizes)."""
+    import test_gpu_raster as TR
+    from sings_amd.inspect_ws import forward_with_state
+    from sings_amd.skinned import rasterize_skinned_gaussians
+    dev = torch.device("cuda:0")
+    s, rs, A_of = _cfg4(dev)
+    N = s["N"]
+    A = A_of(17)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    req = lambda a: t(a).requires_grad_(True)
+    xyz, sc, op, sh, tr = req(s["xyz_canon"]), req(s["scales"]), req(s["opacities"]), req(s["shs"]), req(s["transl"])
+    A_g = A.clone().requires_grad_(True)
+    m2d = torch.zeros(N, 3, device=dev, requires_grad=True)
+    color, radii, pxyz, pq, psc = rasterize_skinned_gaussians(xyz, None, sc, op, sh, t(s["lbs_weights"]), A_g, rs,
+                                                              smpl_scale=t(s["smpl_scale"]), transl=tr, return_posed=True, means2D=m2d)
+    c = lambda x: x.detach().cpu().numpy()
+    o = _oracle_view(s, None, c(pxyz), c(pq), c(psc))
+    tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
+    assert o["R"] > 5e5 and tl.max() > 8192, (o["R"], tl.max())
+    # the plain path on the kernel's posed outputs exposes the workspaces: every integer of the binning, bit for bit
+    st = forward_with_state(rs, pxyz.detach(), op.detach(), shs=sh.detach(), scales=psc.detach(), rotations=pq.detach(), capacity=8 * N)
+    s_r = dict(s, H=s["H"], W=s["W"])
+    TR._check_forward_state(s_r, st, o)
+    assert torch.equal(st["color"], color.detach()) and torch.equal(st["radii"], radii)        # fused == plain, bit for bit
+    TR._check_image(c(color), c(st["final_T"]), c(st["n_contrib"]), o)
+    del st
+    border = o["margin"] < BORDER
+    dL = s["dL_dimage"].copy(); dL[:, border] = 0
+    g = ro.backward(o, dL)
+    (color * t(dL)).sum().backward()
+    gx, gs, gA, gt, (oxyz, oq, osc) = _oracle_lbs_gradients(s, c(A), g)
+    u = _posed_ulps(c(pxyz), c(pq), c(psc), oxyz, oq, osc)
+    assert u[0] <= 2.0 and u[1] <= 8.0 and u[2] <= 1.0, u
+    # (segmented backward: the colour behind a segment comes from forward checkpoints -- a different fp32 rounding of the same
+    #  quantity; same tolerances as the scaled-down avatar scene above)
+    _close("xyz_canon", c(xyz.grad), gx, rtol=1e-3, atol_scale=1e-5)
+    _close("scales", c(sc.grad), gs, rtol=1e-3, atol_scale=1e-5)
+    _close("A", c(A_g.grad)[:, :3, :], gA[:, :3, :], rtol=2e-3, atol_scale=2e-4)
+    _close("transl", c(tr.grad), gt, rtol=2e-3, atol_scale=2e-4)
+    _close("opacity", c(op.grad), g["dL_dopacity"], rtol=1e-3, atol_scale=1e-5)
+    _close("sh", c(sh.grad), g["dL_dsh"], rtol=1e-3, atol_scale=1e-5)
+    _close("viewspace", c(m2d.grad), g["dL_dmean2D"], rtol=1e-3, atol_scale=1e-5)
+
+
+def test_cfg4_eight_frames_in_one_launch_against_the_oracle():
+    """ONE K = 8 launch per kernel of the full-size avatar (sg_skinned_forward_frames / *_backward_*_frames: what bench.py
+    --workload avatar and the chunked training step run) compared with the oracle DIRECTLY -- not through the chain "K-frame
+    call == K single-frame calls == oracle" of tests/test_gpu_frames.py.  Every frame: posed values vs the LBS oracle in ulps,
+    pair count and radii vs the raster oracle (bit for bit, on the launch's own posed outputs); frames 0 and 7: the image, dL/dA,
+    dL/dtransl and the screen-space statistic; and the canonical-Gaussian gradient the launch leaves behind = the SUM over its
+    eight frames of the oracle's gradients (raster oracle's explicit backward chained through the LBS oracle's autograd)."""
+    from sings_amd.engine import SkinnedFramesEngine
+    dev = torch.device("cuda:0")
+    s, rs, A_of = _cfg4(dev)
+    N, J, W, H, K = s["N"], s["J"], s["W"], s["H"], 8
+    frames = [3, 17, 29, 41, 56, 70, 88, 101]
+    A = torch.stack([A_of(f) for f in frames]).reshape(K, J, 16).contiguous()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rs_ = np.random.RandomState(8)
+    transl_n = (s["transl"][None] + rs_.normal(0, 0.02, (K, 3))).astype(np.float32)
+    dL_n = rs_.normal(0, 1, (K, 3, H, W)).astype(np.float32)
+    xyz, w, sc, op, sh = t(s["xyz_canon"]), t(s["lbs_weights"]), t(s["scales"]), t(s["opacities"]), t(s["shs"])
+    eng = SkinnedFramesEngine(N, J, W, H, sh.shape[1], K, dev, 16 * N)
+    eng.set_camera(rs)
+    eng.set_frames(xyz, None, w, A, t(s["smpl_scale"]), t(transl_n))
+    e = lambda *shp: torch.empty(shp, dtype=torch.float32, device=dev)
+    posed = (e(K, N, 3), e(K, N, 4), e(K, N, 3))
+    Rs = eng.forward(sh, op, sc, sync_num_rendered=True, posed_out=posed)
+    assert max(Rs) <= eng.cap
+    color = eng.color.cpu().numpy(); radii = eng.radii.cpu().numpy()
+    pxyz, pq, psc = (x.cpu().numpy() for x in posed)
+    sums = dict(xyz=0.0, sc=0.0, op=0.0, sh=0.0)
+    per_frame = {}
+    A_n = A.cpu().numpy().reshape(K, J, 4, 4)
+    for f in range(K):
+        sf = dict(s, transl=transl_n[f])
+        o = _oracle_view(sf, None, pxyz[f], pq[f], psc[f])
+        assert Rs[f] == o["R"] and np.array_equal(radii[f], o["radii"]), (f, Rs[f], o["R"])
+        border = o["margin"] < BORDER
+        dL_n[f][:, border] = 0
+        g = ro.backward(o, dL_n[f])
+        gx, gs, gA, gt, (oxyz, oq, osc) = _oracle_lbs_gradients(sf, A_n[f], g)
+        u = _posed_ulps(pxyz[f], pq[f], psc[f], oxyz, oq, osc)
+        assert u[0] <= 2.0 and u[1] <= 8.0 and u[2] <= 1.0, (f, u)
+        sums["xyz"] = sums["xyz"] + gx.astype(np.float64); sums["sc"] = sums["sc"] + gs.astype(np.float64)
+        sums["op"] = sums["op"] + g["dL_dopacity"].astype(np.float64); sums["sh"] = sums["sh"] + g["dL_dsh"].astype(np.float64)
+        if f in (0, K - 1):
+            per_frame[f] = (o, border, g, gA, gt)
+    assert len(set(Rs)) > 1                                          # (the frames really differ)
+    eng.backward(sh, op, sc, t(dL_n))
+    torch.cuda.synchronize()
+    for f, (o, border, g, gA, gt) in per_frame.items():
+        diff = np.abs(color[f] - o["color"]).max(0)
+        assert diff[~border].max() <= 1e-5, (f, diff[~border].max())
+        over = diff[border] - (1e-5 + 1.001 * o["flip"][border])
+        assert border.sum() == 0 or over.max() <= 0, (f, over.max())
+        _close(f"A[{f}]", eng.d_A[f].cpu().numpy().reshape(J, 4, 4)[:, :3, :], gA[:, :3, :], rtol=2e-3, atol_scale=2e-4)
+        _close(f"transl[{f}]", eng.d_transl[f].cpu().numpy(), gt, rtol=2e-3, atol_scale=2e-4)
+        _close(f"viewspace[{f}]", eng.d_means2D[f].cpu().numpy(), g["dL_dmean2D"], rtol=1e-3, atol_scale=1e-5)
+    _close("sum xyz_canon", eng.d_xyz.cpu().numpy(), sums["xyz"], rtol=1e-3, atol_scale=1e-5)
+    _close("sum scales", eng.d_scales.cpu().numpy(), sums["sc"], rtol=1e-3, atol_scale=1e-5)
+    _close("sum opacity", eng.d_opacity.cpu().numpy(), sums["op"], rtol=1e-3, atol_scale=1e-5)
+    _close("sum sh", eng.d_sh.cpu().numpy(), sums["sh"], rtol=1e-3, atol_scale=1e-5)
 
 def _avatar_shaped(N=30000, J=52, Wd=96, Hd=128, seed=41):
     """The scaled-down geometry of the reference's workload used by test_avatar_shaped_scene_with_long_lists_against_the_oracle."""

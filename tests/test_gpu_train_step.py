@@ -337,3 +337,56 @@ def test_a_step_over_a_chunk_of_frames_equals_the_sum_of_one_frame_steps():
     lossK, ldK, _ = step2(A_t, rset, gt, mask, bg, smpl_scale=smpl_scale, transl=transl)
     loss1, ld1, _ = step2(A_t[0], rset, gt[0], mask, bg, smpl_scale=smpl_scale, transl=transl[0])
     assert torch.allclose(ldK["l2"], ld1["l2"]) and abs(float(ldK["l1"]) - sum(float(a) for a, _, _ in per)) <= 1e-5 * float(ldK["l1"])
+
+
+def test_a_step_that_raises_between_prepare_and_finish_leaves_the_module_usable():
+    """ADVICE r4: with `defer_regulariser_join` the edge loss's prepare() runs before the raster forward and its finish() after it;
+    a forward that RAISES in between (here: a camera tensor left on the host, refused by the op) used to leave the prepared query
+    pending, and every later step failed with "prepare() called twice".  Now the query is dropped with the step."""
+    from sings_amd.body import joint_transforms
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm
+    from sings_amd.scene import avatar_scene
+    from sings_amd.train_step import AvatarStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(6)
+    s = avatar_scene(N=4000, J=24, W=96, H=160, seed=6)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [16, 16, 16], 'multires': [1, 2]}
+    tri = HexPlaneField(cfg, bounds=1.2, device=dev); geo = GeometryDecoder(64).to(dev); app = AppearanceDecoder(64).to(dev)
+    with torch.no_grad():
+        geo.scales[2].bias.fill_(-4.5); geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()
+    edge = GaussiansEdgeLoss()
+    step = AvatarStep(t(s["xyz_canon"]), t(s["lbs_weights"]), tri, geo, app, l2_norm=L2Norm(), gaussian_connect=edge,
+                      gaussian_connect_w=1.0, defer_regulariser_join=True).to(dev)
+    cam = s["cam"]
+    good = GaussianRasterizationSettings(
+        image_height=s["H"], image_width=s["W"], tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    bad = good._replace(viewmatrix=torch.from_numpy(cam["world_view_transform"]))          # a host tensor: the op raises
+    A = joint_transforms(t(np.zeros(72, np.float32)), t(s["joints_rest"]), tuple(s["parents"]))
+    gt = torch.rand(3, s["H"], s["W"], device=dev); ones = torch.ones(s["H"], s["W"], device=dev)
+    args = (gt, ones, t(s["bg"]))
+    kw = dict(smpl_scale=t(s["smpl_scale"]), transl=t(s["transl"]))
+
+    def run(rset):
+        for p in step.parameters():
+            p.grad = None
+        loss, ld, ex = step(A, rset, *args, **kw)
+        assert loss is None                                          # (deferred join: two autograd roots)
+        return float(step.backward(ld, ex))
+    ref = run(good)
+    for _ in range(2):
+        with pytest.raises(RuntimeError):
+            run(bad)
+        assert getattr(edge, "_pending", None) is None
+        assert abs(run(good) - ref) <= 1e-6 * abs(ref)
+    # the module-level contract: abort() drops a prepared query; prepare() twice without it is still an error
+    edge.prepare({"xyz_canon": t(s["xyz_canon"]), "scales": torch.rand(4000, 3, device=dev)})
+    with pytest.raises(RuntimeError, match="twice"):
+        edge.prepare({"xyz_canon": t(s["xyz_canon"]), "scales": torch.rand(4000, 3, device=dev)})
+    edge.abort()
+    torch.cuda.synchronize()
+    assert abs(run(good) - ref) <= 1e-6 * abs(ref)

@@ -191,3 +191,32 @@ def test_oracle_reproduces_frozen_vectors():
         for k in ("dL_dmeans3D", "dL_dscales", "dL_drots", "dL_dopacity", "dL_dsh"):
             ref = G[f"{tag}_{k}"]
             np.testing.assert_allclose(g[k], ref, rtol=1e-5, atol=1e-6 * np.abs(ref).max(), err_msg=f"{tag} {k}")
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_colour_against_the_reference_spherical_harmonics(deg):
+    """Golden G9: the ONE piece of the rasterizer's preprocess with an in-tree reference statement -- the SH polynomial,
+    sings/rec/utils/visualize/spherical_harmonics.py:54-113 -- executed in the build container (tests/golden/gen_sh_golden.py) at
+    512 seeded directions.  The oracle's per-Gaussian colour (eval + 0.5, clamp at 0, clamp flags) must reproduce it for every
+    degree, and its backward's dL/dsh must be basis value x dL/dcolour (the basis by autograd through the reference function).
+    The raster oracle as a whole stays PARITY UNPINNED; this pins its SH part."""
+    import sh_case
+    seen = 0
+    for g in sh_case.groups():
+        o = ro.forward(g["means3D"], g["opacities"], g["viewmatrix"], g["projmatrix"], g["campos"], sh_case.W, sh_case.H,
+                       sh_case.TANFOV, sh_case.TANFOV, np.zeros(3, np.float32), scales=g["scales"], rotations=g["rotations"],
+                       shs=g["shs"], sh_degree=deg)
+        assert (o["radii"] > 0).all()                                   # every direction of the group is on screen
+        rgb, clamped = sh_case.expected_rgb(deg, g["idx"])
+        assert np.abs(o["rgb"] - rgb).max() <= 2e-6, np.abs(o["rgb"] - rgb).max()
+        sure = np.abs(sh_case.G9[f"eval_deg{deg}"][g["idx"]] + 0.5) > 1e-5
+        assert np.array_equal(o["clamped"].astype(bool)[sure], clamped[sure])
+        seen += g["idx"].size
+        if deg == 3:
+            dL = np.random.RandomState(1).normal(0, 1, (3, sh_case.H, sh_case.W)).astype(np.float32)
+            gr = ro.backward(o, dL)
+            dcol = np.where(o["clamped"].astype(bool), 0.0, gr["dL_dcolor"])                 # [n,3]
+            want = sh_case.G9["basis_deg3"][g["idx"]][:, :, None] * dcol[:, None, :]        # [n,16,3]
+            assert np.abs(dcol).max() > 0
+            assert np.abs(gr["dL_dsh"] - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    assert seen == 512
