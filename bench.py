@@ -67,6 +67,7 @@ FORCE_DIST = bool(os.environ.get("SINGS_BENCH_FORCE_DIST"))
 # one schema for every N: the collective keys are present (null) when no collective ran
 COMM_KEYS = ("allreduce_ms", "allreduce_bytes", "allreduce_algorithm", "allreduce_per_link_bound_ms", "allreduce_exposed_ms")
 MIN_TIMED_S = 0.5              # the timed region is repeated (whole regions of exactly --steps steps) until it adds up to this
+LIGHT_TIMED_S = 0.3            # ... of a secondary leg (--light)
 MAX_REPEATS = 5000
 
 
@@ -114,6 +115,13 @@ def parse_args():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="default single-GPU run only: skip the `secondary` block (the other BASELINE configurations, each a timed "
+                         "region of >= 0.3 s in this same process: cfg2 forward, cfg4 avatar, cfg5 + regularisers, the full training "
+                         "step at K = 1 and K = 16, the drop-in autograd surface)")
+    ap.add_argument("--light", action="store_true",
+                    help="a secondary leg's settings: timed regions of >= 0.3 s, one parity view, no LBS + project CPU sweep, no "
+                         "collective probe")
     ap.add_argument("--morton", action="store_true", help="avatar / train workloads: store the canonical Gaussians in Morton order")
     ap.add_argument("--forward-only", action="store_true", help="raster workload: time the forward pass only (BASELINE configs[1])")
     ap.add_argument("--no-wgrad-overlap", action="store_true",
@@ -248,9 +256,55 @@ def dist_setup(a):
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         if dist.get_world_size() != a.gpus:
             raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
+        # one rank per GPU, or the run is not the measurement it claims to be: every rank reports its device, all must differ
+        # (single-GPU test boxes are knowingly oversubscribed: gloo, `ranks_per_device` > 1, said in the line)
+        mine = torch.tensor([local_rank % ndev], dtype=torch.int64, device="cpu" if oversub else dev)
+        got = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(got, mine)
+        devices = [int(g.item()) for g in got]
+        if not oversub and not FORCE_DIST and len(set(devices)) != world:
+            raise SystemExit(f"bench.py: --gpus {a.gpus} but the ranks sit on devices {devices}: one rank per GPU")
         info = {"rccl_world": None if oversub else dist.get_world_size(), "dist_backend": dist.get_backend(),
-                "dist_world": dist.get_world_size(), "ranks_per_device": -(-world // ndev)}
+                "dist_world": dist.get_world_size(), "ranks_per_device": -(-world // ndev), "rank_devices": devices}
     return rank, world, dev, dist, info
+
+
+def make_frame_parallel(ctx, nfloats):
+    """The collective layer of a leg + which algorithm it runs.  SINGS_DP_ALGO=all_reduce|rs_ag forces one; otherwise, with several
+    real ranks, BOTH are timed stand-alone on a scratch buffer of the step's gradient size (10 calls each after 3 warm-ups, device
+    events, MAX over ranks so that every rank reaches the same verdict) and the faster one runs the step -- the first real
+    multi-GPU run therefore measures the better schedule AND reports both (`allreduce_ms_by_algorithm`).  -> (fp or None, info)."""
+    import torch
+    rank, world, dev, dist, dinfo = ctx
+    if dist is None:
+        return None, {}
+    from sings_amd.dp import FrameParallel
+    staged = dist.get_backend() != "nccl"
+    mk = lambda algo: FrameParallel(algorithm=algo, host_staged=staged, force=FORCE_DIST)
+    forced = os.environ.get("SINGS_DP_ALGO")
+    if forced:
+        return mk(forced), {"allreduce_algorithm_chosen_by": "SINGS_DP_ALGO"}
+    if world == 1:
+        return mk("all_reduce"), {"allreduce_algorithm_chosen_by": "default (one rank)"}
+    scratch = torch.zeros(int(nfloats), dtype=torch.float32, device=dev)
+    times = {}
+    for algo in ("all_reduce", "rs_ag"):
+        f = mk(algo)
+        for _ in range(3):
+            f.all_reduce_grads(scratch)
+        torch.cuda.synchronize(); dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            f.all_reduce_grads(scratch)
+        e1.record()
+        torch.cuda.synchronize()
+        tt = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device="cpu" if staged else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        times[algo] = float(tt.item())
+    del scratch
+    best = min(times, key=times.get)
+    return mk(best), {"allreduce_ms_by_algorithm": times, "allreduce_algorithm_chosen_by": "measured in this run (the faster of the two, stand-alone)"}
 
 
 def timed_region(dist, dev, steps, step):
@@ -375,17 +429,41 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a)
-    if a.workload == "avatar":
-        return main_avatar(a)
-    if a.workload == "train":
-        return main_train(a)
-    return main_raster(a)
+    ctx = dist_setup(a)
+    out = LEGS[a.workload](a, ctx)                               # rank 0: the line (a dict); other ranks: None
+    if out is not None and wants_secondary(a, ctx):
+        out["secondary"] = secondary_legs(a, ctx, out)
+    if ctx[3] is not None:
+        ctx[3].destroy_process_group()
+    if out is not None:
+        _log("done")
+        _emit(out)
 
 
-def main_raster(a):
+def _release():
+    """Between legs of one process: drop what the finished leg allocated (its locals are gone) and reset the library's global modes."""
+    import gc
+    import torch
+    from sings_amd import rasterizer as _rz
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    _rz.set_overflow_check("sync")
+    _rz.reset_overflow_state()
+
+
+def wants_secondary(a, ctx):
+    """The default single-GPU headline run (what the driver launches) also measures every other BASELINE configuration."""
+    return (ctx[1] == 1 and not a.no_secondary and not a.light and a.workload == "raster" and not a.forward_only and not a.graph
+            and (a.gaussians, a.width, a.height, a.sh_degree) == (200000, 1920, 1080, 3) and not a.regularisers)
+
+
+def leg_raster(a, ctx):
+    """BASELINE configs[2] (default), configs[1] (--forward-only, 50 k @ 512^2, degree 0), the raster part of configs[4].
+    -> the JSON line as a dict on rank 0, None on the other ranks."""
     import numpy as np
     import torch
-    rank, world, dev, dist, dinfo = dist_setup(a)
+    rank, world, dev, dist, dinfo = ctx
 
     from sings_amd import _lib
     from sings_amd.engine import RasterEngine, ViewBatch
@@ -429,11 +507,7 @@ def main_raster(a):
     del eng
     torch.cuda.empty_cache()
 
-    fp = None
-    if dist is not None:
-        from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
-                           force=FORCE_DIST)
+    fp, algo_info = make_frame_parallel(ctx, N * (3 + 3 + 4 + 1 + 3 * shs.shape[1]))
 
     # K cameras per launch (round 4, sings_amd.engine.RasterFramesEngine): the step's k_views views go out as k_views / K batches
     Kf = 1 if a.graph else max(1, min(a.frames_per_launch if a.frames_per_launch is not None else 8, k_views, _lib.MAX_FRAMES))
@@ -523,7 +597,7 @@ def main_raster(a):
             t2 = _t.perf_counter()
             _log(f"host submission {1e3 * (t1 - t0):.3f} ms, step complete after {1e3 * (t2 - t0):.3f} ms")
     _log(f"timed region ({a.steps} steps, repeated until {MIN_TIMED_S} s)")
-    els = timed_repeats(dist, dev, a.steps, step)
+    els = timed_repeats(dist, dev, a.steps, step, min_s=LIGHT_TIMED_S if a.light else None)
     el = _median(els)
     _log(f"{el / a.steps * 1e3:.3f} ms per step (median of {len(els)} regions); one view per step")
     assert all(0 <= r_ <= e.cap for e in engs for r_ in (e.num_rendered() if getattr(e, "K", 1) > 1 else [e.num_rendered()])), \
@@ -547,6 +621,24 @@ def main_raster(a):
     for _ in range(10):
         step_one_view()
     el_one = _median(timed_repeats(dist, dev, n_one, step_one_view, min_s=0.25))
+    # SURVEY.md 8(d) "Timing": train-step ms = forward + L1(-SSIM)-to-random-target loss + backward (+ the all-reduce): the same
+    # one-view step with the photometric loss of the reference (clamp, 0.8 L1 + 0.2 SSIM: loss.py:55-69) computed from the rendered
+    # image and ITS gradient fed to the backward, instead of a fixed dL/dimage
+    el_loss = None
+    if not a.forward_only:
+        from sings_amd.photo_loss import PhotoLossEngine
+        loss1 = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2)
+        torch.manual_seed(0)
+        gt_rgb = torch.rand((3, H, W), device=dev); ones = torch.ones((H, W), device=dev)
+
+        def step_one_view_loss(_i=0):
+            eng.forward(means3D, shs, opac, scales, rots)
+            eng.backward(means3D, shs, opac, scales, rots, loss1(eng.color, gt_rgb, ones, bg_t))
+            if fp is not None:
+                fp.all_reduce_grads(eng.grad_flat)
+        for _ in range(10):
+            step_one_view_loss()
+        el_loss = _median(timed_repeats(dist, dev, n_one, step_one_view_loss, min_s=0.25))
 
     # collective: stand-alone time and the part of it the batched step cannot hide
     _log("collective probe / per-kernel event pass")
@@ -577,16 +669,22 @@ def main_raster(a):
     lib.sg_profile_enable(0)
     kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
 
+    dp_check = None
+    if dist is not None and not a.graph:
+        dp_check = dp_self_check(ctx, lambda: (step(), batch.acc)[1],
+                                 lambda v: _raster_view(eng, camera, v, (means3D, shs, opac, scales, rots), s["dL_dimage"], t, host=False)["flat"],
+                                 world * k_views)
+        dp_check.update(algo_info)
+        if comm is not None and not a.one_shot_reduce and world > 1:
+            dp_check["allreduce_exposed_ms_by_algorithm"] = exposed_by_algorithm(ctx, batch.pipe, step)
     if rank != 0:
-        if dist is not None:
-            dist.destroy_process_group()
-        return
+        return None
 
     per, total_bytes = algorithmic_bytes(N, H, W, R, deg)
     if a.forward_only:                                          # B_f = N (in + 4 + 2 rec) + HW 12 + R 16
         total_bytes = N * (44 + 12 * (deg + 1) ** 2 + 4 + 2 * 75) + H * W * 12 + R * 16
     _log("float4-copy probe (the roofline's denominator)")
-    copy_gbs = measure_copy_peak(dev)
+    copy_gbs = a.copy_gbs if getattr(a, "copy_gbs", None) else measure_copy_peak(dev)
     roofline, roofline_valu = build_roofline(kern, per, {"workload": "raster", "gaussians": N, "width": W, "height": H, "sh_degree": deg},
                                              total_bytes, world / views_s, copy_gbs, frames=Kf)
     out = {
@@ -594,7 +692,11 @@ def main_raster(a):
                   else f"rendered views/sec {'forward only' if a.forward_only else 'fwd+bwd'}, {N} Gaussians @{W}x{H}",
         "value": views_s, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_per_step, "ms_per_view": ms_per_step / k_views,
-        "train_step_ms_one_view": el_one / n_one * 1e3, "views_per_s_one_view_per_step": world * n_one / el_one,
+        "train_step_ms_one_view": (el_loss if el_loss is not None else el_one) / n_one * 1e3,
+        "train_step_ms_one_view_note": "one view per step: forward + clamp / 0.8 L1 + 0.2 SSIM loss against a random target + backward "
+                                       "(+ the all-reduce with several ranks): SURVEY.md 8(d) Timing" if el_loss is not None else
+                                       "forward only (no loss, no backward)",
+        "raster_fwd_bwd_ms_one_view": el_one / n_one * 1e3, "views_per_s_one_view_per_step": world * n_one / el_one,
         "timed_region_s": sum(els), "repeats": len(els), "ms_per_step_min": min(els) / a.steps * 1e3,
         "ms_per_step_max": max(els) / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -626,31 +728,43 @@ def main_raster(a):
                                          comm.get("allreduce_exposed_ms") if comm else None)
     if grad_hash is not None:
         out["grad_sha256"] = grad_hash
+    if dp_check is not None:
+        out.update(dp_check)
     if world == 1 and not a.no_cpu_baseline:
         _log("CPU baseline (child process, bounded) + parity of the full-size views against the oracle")
-        L = eng.L
-        Tn = ((W + 15) // 16) * ((H + 15) // 16)
+        ins = (means3D, shs, opac, scales, rots)
+        out["cpu_baseline"], out["parity"] = cpu_baseline(
+            s, camera, deg, W, H, lambda v, dLn: _raster_view(eng, camera, v, ins, dLn, t, backward=not a.forward_only),
+            n_views=1 if a.light else 3, lbs_project=not a.light, backward=not a.forward_only)
+    return out
 
-        def gpu_view(v, dLn):
-            """View v of this run's batch through the engine (forward + backward, its own gradient row), on the host."""
-            eng.set_camera(camera(v)[3])
-            eng._chain = None
-            Rv = eng.forward(means3D, shs, opac, scales, rots, sync_num_rendered=True)
-            if not 0 <= Rv <= eng.cap:
-                return {"error": f"view {v}: R = {Rv} exceeds the engine's pair capacity {eng.cap}"}
-            eng.backward(means3D, shs, opac, scales, rots, t(dLn))
-            torch.cuda.synchronize()
-            c = lambda x: x.detach().cpu().numpy()
-            return {"R": Rv, "radii": c(eng.radii), "color": c(eng.color),
-                    "ranges": c(eng.binning[L.bin_ranges:L.bin_ranges + 8 * Tn].view(torch.int32).view(Tn, 2)),
-                    "point_list": c(eng.binning[L.bin_point_list:L.bin_point_list + 4 * Rv].view(torch.int32)),
-                    "grads": {"means3D": c(eng.d_means3D), "means2D": c(eng.d_means2D), "opacity": c(eng.d_opacity),
-                              "scales": c(eng.d_scales), "rotations": c(eng.d_rots), "sh": c(eng.d_sh)}}
-        out["cpu_baseline"], out["parity"] = cpu_baseline(s, camera, deg, W, H, None if a.forward_only else gpu_view)
-    _log("done")
-    if dist is not None:
-        dist.destroy_process_group()
-    _emit(out)
+
+def _raster_view(eng, camera, v, ins, dLn, t, backward=True, host=True):
+    """View v of the run's camera set through the one-view engine (forward + backward into its own gradient buffer), on the host:
+    what the parity block and the frame-parallel self-check compare with the oracle / with the reduced sum."""
+    import torch
+    W, H, L = eng.W, eng.H, eng.L
+    Tn = ((W + 15) // 16) * ((H + 15) // 16)
+    eng.set_camera(camera(v)[3])
+    eng._chain = None
+    Rv = eng.forward(*ins, sync_num_rendered=True)
+    if not 0 <= Rv <= eng.cap:
+        if not host:
+            raise SystemExit(f"bench.py: view {v}: R = {Rv} exceeds the engine's pair capacity {eng.cap}")
+        return {"error": f"view {v}: R = {Rv} exceeds the engine's pair capacity {eng.cap}"}
+    if backward:
+        eng.backward(*ins, t(dLn))
+    if not host:
+        return {"R": Rv, "flat": eng.grad_flat}
+    torch.cuda.synchronize()
+    c = lambda x: x.detach().cpu().numpy()
+    d = {"R": Rv, "radii": c(eng.radii), "color": c(eng.color),
+         "ranges": c(eng.binning[L.bin_ranges:L.bin_ranges + 8 * Tn].view(torch.int32).view(Tn, 2)),
+         "point_list": c(eng.binning[L.bin_point_list:L.bin_point_list + 4 * Rv].view(torch.int32))}
+    if backward:
+        d["grads"] = {"means3D": c(eng.d_means3D), "means2D": c(eng.d_means2D), "opacity": c(eng.d_opacity),
+                      "scales": c(eng.d_scales), "rotations": c(eng.d_rots), "sh": c(eng.d_sh)}
+    return d
 
 
 PMC_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
@@ -832,29 +946,47 @@ def usable_cores():
 
 def cpu_lbs_project_worker(argv):
     """Child process of the cpu_baseline leg (never touches the GPU): PyTorch-CPU "LBS + project" with `threads` threads,
-    median of 10 runs at N = 6 890 / 50 k / 200 k; prints one JSON line.  Runs in a child so that the parent can bound it
-    with a timeout (an over-subscribed OpenMP team can take minutes per call)."""
+    median of 10 runs at N = 6 890 / 50 k / 200 k (+ the workload's own N); prints one JSON line.  Runs in a child so that the
+    parent can bound it with a timeout (an over-subscribed OpenMP team can take minutes per call).  `kind`: "raster" -- the first
+    N Gaussians of the benchmark scene with seeded sparse J = 52 skinning weights and near-identity joint transforms (the
+    arithmetic does not depend on their values); "avatar" -- the avatar scene's own canonical points, weights and an AMASS pose."""
+    import math
     import numpy as np
     import torch
     from oracle import lbs_project_torch as lp
-    from sings_amd.scene import synthetic_scene
-    threads, Ntot, W, H, deg = (int(v) for v in argv[:5])
+    threads, kind, Ntot, W, H, deg = int(argv[0]), argv[1], *(int(v) for v in argv[2:6])
     torch.set_num_threads(threads)
-    s = synthetic_scene(Ntot, W, H, deg, 3)
     T = torch.from_numpy
     J = 52
-    rsd = np.random.RandomState(11)
-    w = np.zeros((Ntot, J), np.float32)
-    ja, jb = rsd.randint(0, J, Ntot), rsd.randint(0, J, Ntot)
-    u = rsd.rand(Ntot).astype(np.float32)
-    w[np.arange(Ntot), ja] = u; w[np.arange(Ntot), jb] += 1 - u
-    A = np.tile(np.eye(4, dtype=np.float32), (J, 1, 1)); A[:, :3, 3] = rsd.normal(0, 1e-3, (J, 3))
+    if kind == "avatar":
+        from oracle import lbs_oracle as lo
+        from sings_amd.scene import avatar_scene
+        s = avatar_scene(N=Ntot, J=J)
+        cam = s["cam"]
+        poses72 = np.load(os.path.join(ROOT, "tests", "golden", "lbs_golden.npz"))["amass_poses_72"]
+        pose = np.zeros(J * 3, np.float32); pose[:72] = poses72[0]; pose[:3] = 0
+        R = lo.batch_rodrigues(T(pose).view(-1, 3)).view(1, J, 3, 3)
+        A = lo.batch_rigid_transform(R, T(s["joints_rest"])[None], list(s["parents"]))[1][0]
+        base = (s["xyz_canon"], s["scales"], s["opacities"], s["shs"], s["lbs_weights"])
+        tail = (A, T(s["smpl_scale"]), T(s["transl"]), T(cam["world_view_transform"]), T(cam["full_proj_transform"]),
+                T(cam["camera_center"]), s["W"], s["H"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5))
+    else:
+        from sings_amd.scene import synthetic_scene
+        s = synthetic_scene(Ntot, W, H, deg, 3)
+        rsd = np.random.RandomState(11)
+        w = np.zeros((Ntot, J), np.float32)
+        ja, jb = rsd.randint(0, J, Ntot), rsd.randint(0, J, Ntot)
+        u = rsd.rand(Ntot).astype(np.float32)
+        w[np.arange(Ntot), ja] = u; w[np.arange(Ntot), jb] += 1 - u
+        A = np.tile(np.eye(4, dtype=np.float32), (J, 1, 1)); A[:, :3, 3] = rsd.normal(0, 1e-3, (J, 3))
+        base = (s["means3D"], s["scales"], s["opacities"], s["shs"], w)
+        tail = (T(A), torch.ones(1), torch.zeros(3), T(s["viewmatrix"]), T(s["projmatrix"]), T(s["campos"]), W, H, s["tanfovx"],
+                s["tanfovy"])
     sweep = {}
-    for n in (6890, 50000, 200000):
+    for n in dict.fromkeys((6890, 50000, 200000, Ntot)):
         idx = np.arange(n) % Ntot
-        args = (T(s["means3D"][idx]), torch.eye(3)[None].repeat(n, 1, 1), T(s["scales"][idx]), T(s["opacities"][idx]),
-                T(s["shs"][idx]), deg, T(w[idx]), T(A), torch.ones(1), torch.zeros(3), T(s["viewmatrix"]), T(s["projmatrix"]),
-                T(s["campos"]), W, H, s["tanfovx"], s["tanfovy"])
+        xyz, sc, op, sh, w_ = (T(np.ascontiguousarray(x[idx])) for x in base)
+        args = (xyz, torch.eye(3)[None].repeat(n, 1, 1), sc, op, sh, deg, w_) + tail
         lp.lbs_project(*args)                                   # (first call: thread pool start-up)
         ts = []
         for _ in range(10):
@@ -863,29 +995,23 @@ def cpu_lbs_project_worker(argv):
     print(json.dumps({"threads": threads, "median_ms_by_points": sweep, "torch": torch.__version__}), flush=True)
 
 
-def cpu_baseline(s, camera, deg, W, H, gpu_view=None):
+def cpu_lbs_project(kind, Ntot, W, H, deg):
     """SURVEY.md 8(d) / BASELINE.md section 3: PyTorch-CPU "LBS + project" -- skinning (W.A, T[v;1]), rotation compose,
     matrix_to_quaternion, then cull / project / cov3D / cov2D / radius / SH -- on the host cores this process may use
-    (`usable_cores`, stated), median of 10 runs at N = 6 890, 50 k and 200 k Gaussians of the benchmark scene (its first N
-    Gaussians and its camera; J = 52 seeded sparse skinning weights and near-identity joint transforms stand in for the
-    pose, the arithmetic does not depend on their values).  Measured in a child process under a timeout; if the full team
-    does not finish (over-subscription) the 16-thread figure is reported and the line says so.  The scalar C restatement
-    of the whole rasterizer (1 core, full views fwd+bwd) rides along as an extra key -- and its images and gradients are
-    compared with the engine's for the same cameras (`gpu_view(v, dL) -> dict`): returns (cpu_baseline, parity)."""
-    from oracle import raster_oracle as ro
-    Ntot = s["means3D"].shape[0]
+    (`usable_cores`, stated), in a child process under a timeout; if the full team does not finish (over-subscription) the
+    16-thread figure is reported and the line says so.  ONE implementation for every workload.  -> the cpu_baseline dict."""
     cores = usable_cores()
     tried, res = [], None
     for threads in dict.fromkeys((cores, min(cores, 16))):
         try:
-            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--_cpu-worker", str(threads), str(Ntot), str(W), str(H),
-                                str(deg)], capture_output=True, text=True, timeout=150)
+            p = subprocess.run([sys.executable, os.path.abspath(__file__), "--_cpu-worker", str(threads), kind, str(Ntot), str(W),
+                                str(H), str(deg)], capture_output=True, text=True, timeout=150)
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if p.returncode == 0 and line:
                 res = json.loads(line[-1])
                 tried.append({"threads": threads, "ok": True})
                 break
-            tried.append({"threads": threads, "ok": False, "rc": p.returncode})
+            tried.append({"threads": threads, "ok": False, "rc": p.returncode, "stderr": p.stderr[-300:]})
         except subprocess.TimeoutExpired:
             tried.append({"threads": threads, "ok": False, "timeout_s": 150})
     cpu_model = ""
@@ -893,33 +1019,47 @@ def cpu_baseline(s, camera, deg, W, H, gpu_view=None):
         cpu_model = next(ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name"))
     except Exception:
         pass
-    n_cpu = 3                                                    # bounded sample: the first 3 cameras of the batch (~12 s)
+    if res is None:
+        return {"value": None, "unit": "frames/s", "cores": cores, "kind": "port", "sample": "PyTorch-CPU LBS + project did not finish",
+                "attempts": tried, "host_cpus": os.cpu_count(), "usable_cores": cores}
+    ms = res["median_ms_by_points"][str(Ntot)] if str(Ntot) in res["median_ms_by_points"] else res["median_ms_by_points"]["200000"]
+    n_at = Ntot if str(Ntot) in res["median_ms_by_points"] else 200000
+    return {"value": 1e3 / ms, "unit": "frames/s (PyTorch-CPU LBS + project only: no binning, no composite, no backward)",
+            "cores": res["threads"], "kind": "port",
+            "sample": f"oracle/lbs_project_torch.py on the {kind} scene, J=52, SH deg {deg}, median of 10 runs per size, N={n_at}: {ms} ms",
+            "median_ms_by_points": res["median_ms_by_points"], "cpu_model": cpu_model, "torch": res["torch"],
+            "host_cpus": os.cpu_count(), "usable_cores": cores, "attempts": tried}
+
+
+def cpu_baseline(s, camera, deg, W, H, gpu_view=None, n_views=3, lbs_project=True, backward=True):
+    """The raster workloads' cpu_baseline + parity: `cpu_lbs_project` (the reported baseline), and the scalar C restatement of the
+    whole rasterizer (1 core, `n_views` full views fwd+bwd of this run's cameras: a bounded sample) riding along as an extra key --
+    its images and gradients are COMPARED with the engine's for the same cameras (`gpu_view(v, dL) -> dict`).
+    -> (cpu_baseline, parity)."""
+    from oracle import raster_oracle as ro
+    Ntot = s["means3D"].shape[0]
     tc = 0.0
     par = _ParityLog()
-    for v in range(n_cpu):
+    for v in range(n_views):
         v_, p_, c_, _ = camera(v)
         t0 = time.perf_counter()
         o = ro.forward(s["means3D"], s["opacities"], v_, p_, c_, W, H, s["tanfovx"], s["tanfovy"], s["bg"],
                        scales=s["scales"], rotations=s["rotations"], shs=s["shs"], sh_degree=deg, want_margin=True)
         # pixels whose hard-threshold decisions are borderline in the oracle carry no loss, on both sides (tests/test_gpu_raster.py)
         dLn = s["dL_dimage"].copy(); dLn[:, o["margin"] < PARITY_BORDER] = 0
-        g = ro.backward(o, dLn)
+        g = ro.backward(o, dLn) if backward else None
         tc += time.perf_counter() - t0
         if gpu_view is not None:                                 # the checker's result is USED: the engine's view v against it
             par.add(o, g, gpu_view(v, dLn))
-    raster = {"value": n_cpu / tc, "unit": "views/s", "cores": 1, "kind": "port",
-              "sample": f"{n_cpu} full views fwd+bwd of the same scene with the scalar C oracle ({tc:.1f} s; the forward also "
-                        f"computes the per-pixel threshold margins the parity block needs)"}
+    raster = {"value": n_views / tc, "unit": "views/s", "cores": 1, "kind": "port",
+              "sample": f"{n_views} full view(s) {'fwd+bwd' if backward else 'forward'} of the same scene with the scalar C oracle "
+                        f"({tc:.1f} s; the forward also computes the per-pixel threshold margins the parity block needs)"}
     parity = par.result() if gpu_view is not None else None
-    if res is None:
-        return dict(raster, lbs_project="PyTorch-CPU LBS + project did not finish", attempts=tried, host_cpus=os.cpu_count(),
-                    usable_cores=cores), parity
-    ms200 = res["median_ms_by_points"]["200000"]
-    return {"value": 1e3 / ms200, "unit": "frames/s (PyTorch-CPU LBS + project only: no binning, no composite, no backward)",
-            "cores": res["threads"], "kind": "port",
-            "sample": f"oracle/lbs_project_torch.py, J=52, SH deg {deg}, median of 10 runs per size, N=200000: {ms200} ms",
-            "median_ms_by_points": res["median_ms_by_points"], "cpu_model": cpu_model, "torch": res["torch"],
-            "host_cpus": os.cpu_count(), "usable_cores": cores, "attempts": tried, "raster_oracle_1core": raster}, parity
+    if not lbs_project:
+        return raster, parity
+    cb = cpu_lbs_project("raster", Ntot, W, H, deg)
+    cb["raster_oracle_1core"] = raster
+    return cb, parity
 
 
 PARITY_BORDER = 2e-5          # tests/test_gpu_raster.py::BORDER
@@ -941,6 +1081,7 @@ class _ParityLog:
         self.border_beyond_flip = 0
         self.grad_max_rel = 0.0
         self.grad_violations = 0
+        self.grads_compared = 0
         self.failed = []
 
     def add(self, o, g, d):
@@ -960,13 +1101,20 @@ class _ParityLog:
         if border.any():
             self.border_beyond_tol += int((diff[border] > PARITY_RGB_TOL).sum())
             self.border_beyond_flip += int((diff[border] > PARITY_RGB_TOL + 1.001 * o["flip"][border]).sum())
+        if g is None:
+            return
         for name, key in (("means3D", "dL_dmeans3D"), ("means2D", "dL_dmean2D"), ("opacity", "dL_dopacity"), ("scales", "dL_dscales"),
                           ("rotations", "dL_drots"), ("sh", "dL_dsh")):
-            b = g[key].astype(np.float64); a = d["grads"][name].astype(np.float64).reshape(b.shape)
-            scale = np.abs(b).max() + 1e-30
-            err = np.abs(a - b)
-            self.grad_max_rel = max(self.grad_max_rel, float(err.max() / scale))
-            self.grad_violations += int((err > 2e-4 * np.abs(b) + 2e-6 * scale).sum())
+            self.add_grad(d["grads"][name], g[key])
+
+    def add_grad(self, a, b, rtol=2e-4, atol=2e-6):
+        import numpy as np
+        b = np.asarray(b, np.float64); a = np.asarray(a, np.float64).reshape(b.shape)
+        scale = np.abs(b).max() + 1e-30
+        err = np.abs(a - b)
+        self.grads_compared += 1
+        self.grad_max_rel = max(self.grad_max_rel, float(err.max() / scale))
+        self.grad_violations += int((err > rtol * np.abs(b) + atol * scale).sum())
 
     def result(self):
         ok = (self.binning_exact and self.rgb_linf <= PARITY_RGB_TOL and self.border_beyond_flip == 0 and self.grad_violations == 0
@@ -974,7 +1122,7 @@ class _ParityLog:
         return {"views": self.views, "ok": bool(ok), "binning_exact": bool(self.binning_exact), "rgb_linf": self.rgb_linf,
                 "rgb_tol": PARITY_RGB_TOL, "borderline_px": self.border_px, "borderline_px_beyond_1e-5": self.border_beyond_tol,
                 "borderline_px_beyond_flip_bound": self.border_beyond_flip, "grad_max_rel": self.grad_max_rel,
-                "grad_violations": self.grad_violations, "grad_tol": "rtol 2e-4 + 2e-6 x max|g| per array (tests/test_gpu_raster.py)",
+                "grad_violations": self.grad_violations, "gradient_arrays_compared": self.grads_compared, "grad_tol": "rtol 2e-4 + 2e-6 x max|g| per array (tests/test_gpu_raster.py)",
                 "errors": self.failed,
                 "against": "oracle/raster_oracle (scalar C restatement, fp32; PARITY UNPINNED: DESIGN.md section 2), full-size views "
                            "of this run's cameras 0..views-1, R / radii / ranges / point_list compared bit for bit"}
@@ -1001,14 +1149,14 @@ def _emit(obj):
     print(json.dumps(obj), flush=True)
 
 
-def main_train(a):
+def leg_train(a, ctx):
     """Extra workload: ONE COMPLETE training step of an avatar through autograd -- tri-plane + decoder decode of all
     Gaussians, fused LBS + raster forward, clamp + L1 + SSIM, L2Norm + Gaussian edge regularisers, backward through all
     of it to the planes / decoder weights / anchors (SURVEY.md 3.1 without optimiser and densification)."""
     import math
     import numpy as np
     import torch
-    rank, world, dev, dist, dinfo = dist_setup(a)
+    rank, world, dev, dist, dinfo = ctx
     from sings_amd.body import joint_transforms
     from sings_amd.decode import (AppearanceDecoder, GeometryDecoder, HexPlaneField, arena_sync, overlap_weight_grads,
                                   prepare_triplane_backward_early, set_gradient_arena)
@@ -1054,8 +1202,7 @@ def main_train(a):
     fp = None
     if dist is not None:
         from sings_amd.dp import FrameParallel
-        fp = FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
-                           force=FORCE_DIST)
+        fp, algo_info = make_frame_parallel(ctx, sum(p.numel() for p in params))
         # parameter-level gradients live in ONE flat buffer: the kernels that produce the large ones (tri-plane scatter, weight
         # gradients) write straight into it (sings_amd.decode.set_gradient_arena), so p.grad is a view of `flat` and the
         # collective needs no gather / scatter passes; what torch's own backward produced (biases, anchors: < 1 %) is copied
@@ -1144,7 +1291,7 @@ def main_train(a):
 
     def timed_step(i):
         last["ld"] = step(a.warmup + i)
-    els = timed_repeats(dist, dev, a.steps, timed_step)
+    els = timed_repeats(dist, dev, a.steps, timed_step, min_s=LIGHT_TIMED_S if a.light else None)
     el = _median(els)
     ld = last["ld"]
     comm = allreduce_probe(fp, flat) if fp is not None else None
@@ -1170,18 +1317,83 @@ def main_train(a):
         out.update({k: None for k in COMM_KEYS})
         if comm is not None:
             out.update(comm)
-    if dist is not None:
-        dist.destroy_process_group()
-    if rank == 0:
-        _emit(out)
+        if fp is not None:
+            out.update(algo_info)
+        out["schedule_note"] = ("one optimisation step per timed step: at frames_per_step = 1 this is the reference's batch-1 schedule "
+                                "(config.py:27, gs_trainer.py:209-254); at K > 1 ONE optimiser step consumes a chunk of K frames -- "
+                                "K times fewer parameter updates per frame, a different optimisation trajectory, quoted per frame "
+                                "for throughput only")
+        if world == 1 and not a.no_cpu_baseline:
+            _log("train: parity of one step's decode / image / loss against the oracle chain")
+            out["parity"] = train_parity(s, step_mod, (tri, geo, app), rs, A_all[0], gt_rgb, mask, bg_t, smpl_scale, transl)
+    _rz.set_overflow_check("sync")
+    return out if rank == 0 else None
 
 
-def main_avatar(a):
+def train_parity(s, step_mod, mods, rs, A, gt_rgb, mask, bg_t, smpl_scale, transl):
+    """ONE forward of the complete training step against the chain of CPU oracles (the forward half of
+    tests/test_gpu_train_step.py::test_full_step_matches_oracle_chain, at the benchmark's full size): decoded attributes vs
+    oracle/decode_oracle.py (pinned by the reference-generated decode_golden.npz), the image vs lbs_oracle -> raster_oracle on
+    those attributes, the L1 / SSIM loss values vs oracle/photo_loss_oracle.py (pinned by photo_loss_golden.npz)."""
+    import math
+    import numpy as np
+    import torch
+    from oracle import decode_oracle as do
+    from oracle import lbs_oracle as lo
+    from oracle import photo_loss_oracle as plo
+    from oracle import raster_oracle as ro
+    tri, geo, app = mods
+    with torch.no_grad():
+        loss, ld, ex = step_mod(A, rs, gt_rgb, mask, bg_t, smpl_scale=smpl_scale, transl=transl)
+    torch.cuda.synchronize()
+    c = lambda x: x.detach().float().cpu()
+    N = int(step_mod.xyz.shape[0])
+    with torch.no_grad():
+        grids = [[c(p_) for p_ in gp] for gp in tri.grids]
+        feats = do.triplane_features(c(step_mod.xyz), grids, c(tri.aabb))
+        og = do.geometry_decoder(feats, {k: c(v) for k, v in geo.named_parameters()})
+        oa = do.appearance_decoder(feats, {k: c(v) for k, v in app.named_parameters()})
+        want = {"xyz_canon": c(step_mod.xyz) + og["xyz_offsets"], "scales": og["scales"], "opacity": oa["opacity"], "shs": oa["shs"]}
+    at = ex["attrs"]
+    dec_rel, dec_bad = 0.0, 0
+    for k, b in want.items():
+        a_ = c(at[k]).numpy().astype(np.float64).reshape(b.shape); b = b.numpy().astype(np.float64)
+        scale = np.abs(b).max() + 1e-30
+        err = np.abs(a_ - b)
+        dec_rel = max(dec_rel, float(err.max() / scale))
+        dec_bad += int((err > 1e-4 * np.abs(b) + 1e-5 * scale).sum())
+    # raster + loss on the GPU's OWN decoded attributes (the seam to the decode oracle is the comparison above)
+    cam = s["cam"]
+    A_n = c(A).reshape(-1, 4, 4)
+    pxyz, pq, psc, _ = lo.deform_gaussians(c(at["xyz_canon"]), torch.eye(3)[None].repeat(N, 1, 1), c(at["scales"]),
+                                           torch.from_numpy(s["lbs_weights"]), A_n, smpl_scale=c(smpl_scale), transl=c(transl))
+    o = ro.forward(pxyz.numpy(), c(at["opacity"]).numpy(), cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"],
+                   s["W"], s["H"], math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), s["bg"], scales=psc.numpy(),
+                   rotations=pq.numpy(), shs=c(at["shs"]).numpy(), sh_degree=0)
+    img = c(ex["render_raw"]).numpy()
+    diff = np.abs(img - o["color"]).max(0)
+    border = o["margin"] < PARITY_BORDER
+    # (posed by the LBS ORACLE here, not by the kernel: a last-ulp difference of a posed quaternion may move a splat's rectangle --
+    #  such pixels are counted, not excused)
+    pl = plo.photometric_loss(torch.from_numpy(o["color"]), c(gt_rgb), c(mask), c(bg_t), 0.8, 0.2)
+    l1_rel = abs(float(ld["l1"]) - float(pl["l1"])) / max(abs(float(pl["l1"])), 1e-30)
+    ssim_rel = abs(float(ld["ssim"]) - float(pl["ssim"])) / max(abs(float(pl["ssim"])), 1e-30)
+    over = int((diff[~border] > PARITY_RGB_TOL).sum())
+    ok = dec_bad == 0 and over <= 1e-5 * diff.size and l1_rel <= 2e-5 and ssim_rel <= 2e-5
+    return {"ok": bool(ok), "decode_max_rel": dec_rel, "decode_violations": dec_bad,
+            "decode_tol": "rtol 1e-4 + 1e-5 x max|x| per attribute (tests/test_gpu_decode.py)", "num_rendered_oracle": int(o["R"]),
+            "rgb_linf_median_px": float(np.median(diff)), "rgb_px_beyond_1e-5": over, "borderline_px": int(border.sum()),
+            "l1_rel_err": l1_rel, "ssim_rel_err": ssim_rel, "loss_tol": 2e-5,
+            "against": "oracle/decode_oracle -> lbs_oracle -> raster_oracle (PARITY UNPINNED) -> photo_loss_oracle, one full-size "
+                       "forward of this run's step (frame 0); gradients of the composed step: tests/test_gpu_train_step.py"}
+
+
+def leg_avatar(a, ctx):
     """BASELINE configs[3]: frame-parallel training step of an avatar through the LBS-fused kernels."""
     import math
     import numpy as np
     import torch
-    rank, world, dev, dist, dinfo = dist_setup(a)
+    rank, world, dev, dist, dinfo = ctx
     from sings_amd import _lib
     from sings_amd.body import joint_transforms
     from sings_amd.dp import FrameParallel, FrameSharder
@@ -1256,8 +1468,7 @@ def main_avatar(a):
     loss1 = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2) if Kf > 1 else losses[0]
     transl_k = transl[None].repeat(Kf, 1).contiguous()                            # (per-frame translations: here all equal)
     shard = FrameSharder(F, world, rank, seed=0)
-    fp = (FrameParallel(algorithm=os.environ.get("SINGS_DP_ALGO", "all_reduce"), host_staged=dist.get_backend() != "nccl",
-                        force=FORCE_DIST) if dist is not None else None)
+    fp, algo_info = make_frame_parallel(ctx, active)
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks, active=active)
     # train step = fused LBS+raster forward -> clamp + L1 + SSIM loss against a (random) target with a body-shaped
     # mask, forward and gradient -> backward (SURVEY.md 8d "Timing")
@@ -1318,7 +1529,7 @@ def main_avatar(a):
 
     for i in range(a.warmup):
         step(i)
-    els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i))
+    els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i), min_s=LIGHT_TIMED_S if a.light else None)
     el = _median(els)
     comm = allreduce_probe(fp, batch.acc[:active])
     assert all(max(e.num_rendered()) <= e.cap if Kf > 1 else e.num_rendered() <= e.cap for e in engs)
@@ -1345,6 +1556,15 @@ def main_avatar(a):
     _lib.check(lib.sg_profile_collect(ms, cnt, _lib.NUM_KERNELS), "profile")
     lib.sg_profile_enable(0)
     kern = {lib.sg_kernel_name(k).decode(): (ms[k] / max(cnt[k], 1)) for k in range(_lib.NUM_KERNELS)}
+    dp_check = None
+    if dist is not None and not pipelined:
+        def render_flat(v):
+            r_, j_ = divmod(v, k_views)                              # view j of rank r at step 0
+            one_view(0, FrameSharder(F, world, r_, seed=0).frame(j_), eng, loss1)
+            return eng.grad_flat[:active]
+        dp_check = dp_self_check(ctx, lambda: (step(0), batch.acc[:active])[1], render_flat, world * k_views)
+        dp_check.update(algo_info)
+        dp_check.update(densification_stats_check(ctx, fp, engs))
     if rank == 0:
         out = {"metric": "train-step views/sec (LBS-fused fwd + L1/SSIM loss + bwd), avatar ~150k Gaussians x 120 AMASS frames",
                "value": world * a.steps * k_views / el, "unit": "views/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -1364,7 +1584,7 @@ def main_avatar(a):
                "kernel_ms": kern}
         per, total_bytes = algorithmic_bytes_skinned(N, H, W, Rmax, 0, J)
         fps = out["value"] / world
-        copy_gbs = measure_copy_peak(dev)
+        copy_gbs = a.copy_gbs if getattr(a, "copy_gbs", None) else measure_copy_peak(dev)
         out["roofline"], out["roofline_valu"] = build_roofline(
             kern, per, {"workload": "avatar", "gaussians": N, "width": W, "height": H, "sh_degree": 0}, total_bytes, 1.0 / fps,
             copy_gbs, frames=Kf)
@@ -1383,36 +1603,267 @@ def main_avatar(a):
         if grad_hash is not None:
             out["grad_sha256"] = grad_hash
         if world == 1 and not a.no_cpu_baseline:
-            from oracle import lbs_project_torch as lp
-            T = torch.from_numpy
-            nthr = min(os.cpu_count(), 16)          # tiny batched matmuls: more threads only add OpenMP overhead
-            torch.set_num_threads(nthr)
-            args = (T(s["xyz_canon"]), torch.eye(3)[None].repeat(N, 1, 1), T(s["scales"]), T(s["opacities"]), T(s["shs"]), 0,
-                    T(s["lbs_weights"]), A_all[0].cpu().view(J, 4, 4), T(s["smpl_scale"]), T(s["transl"]),
-                    T(cam["world_view_transform"]), T(cam["full_proj_transform"]), T(cam["camera_center"]), W, H,
-                    math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5))
-            def median_ms(argv, reps):
-                lp.lbs_project(*argv)                                    # (first call: thread pool start-up)
-                ts = []
-                for _ in range(reps):
-                    t1 = time.perf_counter(); lp.lbs_project(*argv); ts.append(time.perf_counter() - t1)
-                return sorted(ts)[len(ts) // 2] * 1e3
-            tm = median_ms(args, 5) * 1e-3
-            # median of 10 runs at N = 6 890 (the SMPL template), 50 k and 200 k points (the first N of the
-            # avatar cloud, tiled past 150 k)
-            sweep = {}
-            for n in (6890, 50000, 200000):
-                idx = torch.arange(n) % N
-                sub = tuple(x[idx] if torch.is_tensor(x) and x.dim() > 0 and x.shape[0] == N else x for x in args)
-                sweep[str(n)] = round(median_ms(sub, 10), 3)
-            out["cpu_baseline"] = {"value": 1.0 / tm, "unit": "frames/s (LBS + project only, no raster)", "cores": nthr,
-                                   "kind": "port", "sample": f"PyTorch-CPU LBS+project (BASELINE.md section 3), N={N}, J={J}, "
-                                   f"median of 5 ({tm * 1e3:.1f} ms), torch {torch.__version__}",
-                                   "median_ms_by_points": sweep, "host_cpus": os.cpu_count()}
-    if dist is not None:
-        dist.destroy_process_group()
+            _log("avatar: parity of one full-size frame against the composed oracle" + ("" if a.light else " + CPU baseline"))
+            out["parity"] = avatar_parity(s, eng, rs, A_all[shard.frame(0)], (xyz, w, sc, op, sh, smpl_scale, transl), t)
+            if not a.light:
+                out["cpu_baseline"] = cpu_lbs_project("avatar", N, W, H, 0)
+        if dp_check is not None:
+            out.update(dp_check)
+    return out if rank == 0 else None
+
+
+def avatar_parity(s, eng, rs, A, ins, t):
+    """ONE full-size frame of the avatar workload against the composed oracle (the bars of tests/test_gpu_skinned.py::
+    test_cfg4_full_size_against_the_oracle): posed values vs oracle/lbs_oracle.py in ulps, the raster oracle on the kernel's own
+    posed values (R, radii, ranges, sorted lists bit for bit; RGB <= 1e-5 off borderline pixels), and the gradients w.r.t. the
+    canonical means / scales / opacity / SH, dL/dA, dL/dtransl and the screen-space statistic vs the raster oracle's explicit
+    backward chained through the LBS oracle's autograd.  Outside every timed region; the oracle is the checker only."""
+    import math
+    import numpy as np
+    import torch
+    from oracle import lbs_oracle as lo
+    from oracle import raster_oracle as ro
+    xyz, w, sc, op, sh, smpl_scale, transl = ins
+    N, J, W, H, dev = eng.P, eng.J, eng.W, eng.H, eng.dev
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    posed = (e(N, 3), e(N, 4), e(N, 3))
+    eng.set_camera(rs)
+    eng.set_frame(xyz, None, w, A, smpl_scale, transl)
+    eng._chain = None
+    Rv = eng.forward(sh, op, sc, sync_num_rendered=True, posed_out=posed)
+    torch.cuda.synchronize()
+    c = lambda x: x.detach().cpu().numpy()
+    pxyz, pq, psc = (c(x) for x in posed)
+    cam = s["cam"]
+    o = ro.forward(pxyz, s["opacities"], cam["world_view_transform"], cam["full_proj_transform"], cam["camera_center"], W, H,
+                   math.tan(cam["fovx"] * 0.5), math.tan(cam["fovy"] * 0.5), s["bg"], scales=psc, rotations=pq, shs=s["shs"], sh_degree=0)
+    dLn = s["dL_dimage"].copy(); dLn[:, o["margin"] < PARITY_BORDER] = 0
+    g = ro.backward(o, dLn)
+    eng.backward(sh, op, sc, t(dLn))
+    torch.cuda.synchronize()
+    L, Tn = eng.L, ((W + 15) // 16) * ((H + 15) // 16)
+    par = _ParityLog()
+    par.add(o, None, {"R": Rv, "radii": c(eng.radii), "color": c(eng.color),
+                      "ranges": c(eng.binning[L.bin_ranges:L.bin_ranges + 8 * Tn].view(torch.int32).view(Tn, 2)),
+                      "point_list": c(eng.binning[L.bin_point_list:L.bin_point_list + 4 * max(Rv, 0)].view(torch.int32))})
+    # LBS^T by the oracle's autograd, seeded with the raster oracle's posed-space gradients
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).clone().requires_grad_(True)
+    xo, so, Ao, to = T(s["xyz_canon"]), T(s["scales"]), T(c(A).reshape(J, 4, 4)), T(s["transl"])
+    px, pqo, pso, _ = lo.deform_gaussians(xo, torch.eye(3)[None].repeat(N, 1, 1), so, torch.from_numpy(s["lbs_weights"]), Ao,
+                                          smpl_scale=torch.from_numpy(s["smpl_scale"]), transl=to)
+    ((px * torch.from_numpy(g["dL_dmeans3D"])).sum() + (pqo * torch.from_numpy(g["dL_drots"])).sum()
+     + (pso * torch.from_numpy(g["dL_dscales"])).sum()).backward()
+    mag = np.abs(px.detach().numpy()).max(1, keepdims=True)
+    ulps = {"means": float((np.abs(pxyz.astype(np.float64) - px.detach().numpy()) / np.spacing(mag.astype(np.float32))).max()),
+            "quaternions_of_1": float((np.abs(pq.astype(np.float64) - pqo.detach().numpy()) / np.spacing(np.float32(1))).max()),
+            "scales": float((np.abs(psc.astype(np.float64) - pso.detach().numpy()) / np.spacing(np.abs(pso.detach().numpy()))).max())}
+    # (segmented backward of long lists: the tolerances of the full-size test)
+    dsh = c(eng.d_sh)
+    dsh = dsh.transpose(1, 0, 2) if eng.sh_planar else dsh                   # [M,P,3] -> [P,M,3]
+    for a_, b_, rt, at in ((c(eng.d_xyz), xo.grad.numpy(), 1e-3, 1e-5), (c(eng.d_scales), so.grad.numpy(), 1e-3, 1e-5),
+                           (c(eng.d_opacity), g["dL_dopacity"], 1e-3, 1e-5), (dsh[:, :1], g["dL_dsh"][:, :1], 1e-3, 1e-5),
+                           (c(eng.d_means2D), g["dL_dmean2D"], 1e-3, 1e-5),
+                           (c(eng.d_A).reshape(J, 4, 4)[:, :3], Ao.grad.numpy()[:, :3], 2e-3, 2e-4), (c(eng.d_transl), to.grad.numpy(), 2e-3, 2e-4)):
+        par.add_grad(a_, b_, rtol=rt, atol=at)
+    res = par.result()
+    res["posed_ulps_vs_lbs_oracle"] = ulps
+    res["ok"] = bool(res["ok"] and ulps["means"] <= 2 and ulps["quaternions_of_1"] <= 8 and ulps["scales"] <= 1)
+    res["grad_tol"] = "rtol 1e-3 + 1e-5 x max|g| (dL/dA, dL/dtransl: 2e-3 + 2e-4): tests/test_gpu_skinned.py, full-size avatar"
+    res["against"] = ("oracle/lbs_oracle (pinned by the reference-generated lbs_golden.npz) composed with oracle/raster_oracle (PARITY "
+                      "UNPINNED) on ONE full-size frame of this run: posed values in ulps, R / radii / ranges / point_list bit for "
+                      "bit, image, 7 gradient arrays incl. dL/dA and dL/dtransl")
+    return res
+
+
+def densification_stats_check(ctx, fp, engs):
+    """Frame-parallel densification statistics (sings_hybrid.py:1013-1015, gs_trainer.py:486-492): every rank accumulates
+    |viewspace gradient| (sum), the visibility count (sum) and the largest screen radius (max) of ITS frames; the three are reduced
+    so that all ranks take identical densify / prune decisions.  Reduced here from the last step's engines, then compared across
+    ranks by hash.  -> keys for the line (the same on every rank)."""
+    import hashlib
+    import torch
+    rank, world, dev, dist, _ = ctx
+    e0 = engs[0]
+    P = e0.P
+    acc = torch.zeros(P, device=dev); den = torch.zeros(P, device=dev); rad = torch.zeros(P, dtype=torch.int32, device=dev)
+    for e in engs:
+        m2 = e.d_means2D.view(-1, P, 3); r = e.radii.view(-1, P)
+        vis = r > 0
+        acc += (m2[..., :2].norm(dim=-1) * vis).sum(0); den += vis.sum(0).float(); rad = torch.maximum(rad, r.max(0).values)
+    fp.reduce_densification_stats(acc, den, rad)
+    h = hashlib.sha256(acc.cpu().numpy().tobytes() + den.cpu().numpy().tobytes() + rad.cpu().numpy().tobytes()).digest()
+    return {"densification_stats": {"reduced": True, "ranks_agree": _ranks_agree(ctx, h), "visible_sum": float(den.sum()),
+                                    "max_radius": int(rad.max())}}
+
+
+def _ranks_agree(ctx, digest):
+    """all_gather of a 32-byte digest: True iff every rank holds the same bytes."""
+    import torch
+    rank, world, dev, dist, _ = ctx
+    on_dev = dist.get_backend() == "nccl"
+    mine = torch.tensor(list(digest), dtype=torch.uint8, device=dev if on_dev else "cpu")
+    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(got, mine)
+    return all(bool(torch.equal(g, got[0])) for g in got)
+
+
+def leg_dropin(a, ctx):
+    """The drop-in autograd surface an UNMODIFIED gs_renderer_single.render() calls (GaussianRasterizer.forward / backward through
+    torch autograd, default overflow mode: the pair count is checked before the call returns), cfg3, fwd + bwd per view --
+    workspaces and gradient tensors allocated per call as torch does for any op.  -> {"ms_per_view", ...}."""
+    import numpy as np
+    import torch
+    from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+    from sings_amd.scene import synthetic_scene
+    rank, world, dev, dist, dinfo = ctx
+    N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
+    s = synthetic_scene(N, W, H, deg, 3)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=s["tanfovx"], tanfovy=s["tanfovy"], bg=t(s["bg"]),
+                                       scale_modifier=1.0, viewmatrix=t(s["viewmatrix"]), projmatrix=t(s["projmatrix"]), sh_degree=deg,
+                                       campos=t(s["campos"]), prefiltered=False, debug=False)
+    req = lambda x: t(x).requires_grad_(True)
+    m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
+    dL = t(s["dL_dimage"])
+    rast = GaussianRasterizer(rs)
+
+    def step(_i=0):
+        for x in (m, op, sh, sc, rt):
+            x.grad = None
+        m2 = torch.zeros_like(m, requires_grad=True)               # gs_renderer_single.py:50-56
+        color, radii = rast(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rt)
+        color.backward(dL)
+    for _ in range(10):
+        step()
+    n = 100
+    els = timed_repeats(None, dev, n, step, min_s=LIGHT_TIMED_S)
+    return {"ms_per_view": _median(els) / n * 1e3, "timed_region_s": sum(els), "overflow_check": "sync (default)",
+            "workload": f"S({N},{W},{H},deg={deg},seed=3) through diff_gaussian_rasterization.GaussianRasterizer + torch autograd, one view per call"}
+
+
+LEGS = {"raster": leg_raster, "avatar": leg_avatar, "train": leg_train}
+
+
+def _compact(j):
+    """What a secondary leg contributes to the headline line."""
+    keep = {k: j.get(k) for k in ("metric", "value", "unit", "ms_per_step", "ms_per_view", "train_step_ms_one_view", "timed_region_s",
+                                  "repeats", "parity", "losses", "schedule_note") if k in j}
+    cfg = j.get("config", {})
+    keep["config"] = {k: cfg[k] for k in ("workload", "gaussians", "width", "height", "num_rendered", "max_num_rendered", "tile_list_mean",
+                                          "tile_list_max", "views_per_step", "frames_per_launch", "streams", "frames_per_step",
+                                          "regularisers", "forward_only", "hip_graph") if k in cfg}
+    r = j.get("roofline")
+    if r:
+        keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_spec", "algorithmic_bytes_per_view",
+                                                  "traffic", "dominant_kernel", "dominant_kernel_ms", "dominant_kernel_frac")}
+    if "raster_oracle_1core" in (j.get("cpu_baseline") or {}):
+        keep["cpu_oracle_views_per_s_1core"] = j["cpu_baseline"]["raster_oracle_1core"]["value"]
+    elif (j.get("cpu_baseline") or {}).get("unit") == "views/s":
+        keep["cpu_oracle_views_per_s_1core"] = j["cpu_baseline"]["value"]
+    return keep
+
+
+def secondary_legs(a, ctx, head):
+    """The other BASELINE configurations, in this process, after the headline measurement (`--no-secondary` skips them): each a
+    timed region of >= 0.3 s with its own algorithmic bytes against the copy rate measured in THIS run, R / tile-list statistics
+    and a parity block from one full-size oracle view."""
+    import copy
+    t0 = time.perf_counter()
+    base = copy.copy(a)
+    base.light, base.no_secondary, base.copy_gbs = True, True, head.get("hbm_copy_GBs_measured")
+    base.grad_hash = False
+
+    def variant(**kw):
+        v = copy.copy(base)
+        for k, val in kw.items():
+            setattr(v, k, val)
+        return v
+    plan = [
+        ("cfg2_forward", "raster", variant(gaussians=50000, width=512, height=512, sh_degree=0, forward_only=True, steps=max(a.steps, 50))),
+        ("cfg4_avatar", "avatar", variant(workload="avatar", views_per_step=24, streams=3, frames_per_launch=None, steps=max(a.steps // 2, 10))),
+        ("cfg5_regularisers", "raster", variant(gaussians=500000, width=2048, height=2048, regularisers=True, steps=max(a.steps // 4, 5))),
+        ("train_step_K1", "train", variant(workload="train", views_per_step=1, steps=max(a.steps, 20), warmup=5)),
+        ("train_step_K16", "train", variant(workload="train", views_per_step=16, steps=max(a.steps // 2, 10), warmup=3, no_cpu_baseline=True)),
+    ]
+    sec = {}
+    for name, leg, args in plan:
+        _release()
+        _log(f"secondary leg {name}")
+        try:
+            sec[name] = _compact(LEGS[leg](args, ctx))
+        except Exception as e:                                       # a failing extra must not cost the headline line
+            sec[name] = {"error": f"{type(e).__name__}: {e}"}
+    _release()
+    _log("secondary leg dropin_autograd")
+    try:
+        sec["dropin_autograd"] = leg_dropin(base, ctx)
+        sec["dropin_autograd_ms_per_view"] = sec["dropin_autograd"]["ms_per_view"]
+    except Exception as e:
+        sec["dropin_autograd"] = {"error": f"{type(e).__name__}: {e}"}
+    if "train_step_ms_one_view" in sec.get("cfg4_avatar", {}):
+        sec["cfg4_avatar"]["frames_per_s_one_frame_per_step"] = 1e3 / sec["cfg4_avatar"]["train_step_ms_one_view"]
+    _release()
+    sec["wall_s"] = time.perf_counter() - t0
+    return sec
+
+
+def dp_self_check(ctx, step0, render_flat, n_views_world):
+    """N > 1 (or a forced one-rank group), outside every timed region -- what makes the first real multi-GPU run decisive:
+      ranks_agree   all ranks all_gather the sha256 of their reduced gradient buffer: the collective must leave the SAME bytes
+                    everywhere;
+      dp_parity     rank 0 re-renders ALL `n_views_world` views of the step locally (one-view engine, the cameras / frames the
+                    ranks used: `render_flat(v)` -> that view's gradient in the buffer's layout), sums them in fp64 on the device
+                    and compares with the reduced sum (rtol 2e-4 + 2e-6 max|g|).
+    `step0()` runs one step on every rank and returns the reduced buffer.  Oversubscribed single-GPU test boxes (gloo, host-staged)
+    run the same code."""
+    import hashlib
+    import torch
+    rank, world, dev, dist, dinfo = ctx
+    acc = step0()
+    torch.cuda.synchronize()
+    agree = _ranks_agree(ctx, hashlib.sha256(acc.detach().cpu().numpy().tobytes()).digest())
+    res = {"ranks_agree": bool(agree), "dp_parity": None}
     if rank == 0:
-        _emit(out)
+        got = acc.detach().double().clone()
+        ref = torch.zeros_like(got)
+        for v in range(n_views_world):
+            ref += render_flat(v).detach().double()
+        scale = float(ref.abs().max()) + 1e-30
+        err = (got - ref).abs()
+        bad = int((err > 2e-4 * ref.abs() + 2e-6 * scale).sum())
+        res["dp_parity"] = {"ok": bad == 0, "views": n_views_world, "max_rel": float(err.max()) / scale, "violations": bad,
+                            "tol": "rtol 2e-4 + 2e-6 x max|g|",
+                            "note": "reduced sum of one step vs rank 0 rendering every rank's views itself (fp64 sum of the per-view gradients)"}
+        del got, ref, err
+    torch.cuda.synchronize()
+    dist.barrier()
+    return res
+
+
+def exposed_by_algorithm(ctx, pipe, step):
+    """The part of the collective the batched step cannot hide, for BOTH algorithms in the same run (median of 10 synchronised
+    steps each; MAX over ranks): the chunked fold + collective of sings_amd.dp.GradientPipeline with its FrameParallel swapped."""
+    import torch
+    rank, world, dev, dist, dinfo = ctx
+    from sings_amd.dp import FrameParallel
+    staged = dist.get_backend() != "nccl"
+    keep = pipe.fp
+    out = {}
+    pipe.enable_timing(True)
+    for algo in ("all_reduce", "rs_ag"):
+        pipe.fp = FrameParallel(algorithm=algo, host_staged=staged, force=FORCE_DIST)
+        ex = []
+        for _ in range(10):
+            torch.cuda.synchronize(); dist.barrier()
+            step()
+            torch.cuda.synchronize()
+            ex.append(pipe.exposed_ms())
+        tt = torch.tensor([sorted(ex)[len(ex) // 2]], dtype=torch.float64, device="cpu" if staged else dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        out[algo] = float(tt.item())
+    pipe.enable_timing(False)
+    pipe.fp = keep
+    return out
 
 
 if __name__ == "__main__":

@@ -116,9 +116,13 @@ class FrameParallel:
         """sum / sum / max over ranks, in place (identical topology decisions on every rank)."""
         if not self.active:
             return
-        dist.all_reduce(xyz_gradient_accum, op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(denom, op=dist.ReduceOp.SUM, group=self.group)
-        dist.all_reduce(max_radii2D, op=dist.ReduceOp.MAX, group=self.group)
+        for t, op in ((xyz_gradient_accum, dist.ReduceOp.SUM), (denom, dist.ReduceOp.SUM), (max_radii2D, dist.ReduceOp.MAX)):
+            if self.host_staged and t.is_cuda:                    # (gloo group over device tensors: single-GPU test boxes only)
+                h = t.detach().cpu()
+                dist.all_reduce(h, op=op, group=self.group)
+                t.copy_(h)
+            else:
+                dist.all_reduce(t, op=op, group=self.group)
 
     def broadcast_(self, tensors, src=0):
         for t in tensors:

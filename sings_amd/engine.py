@@ -203,14 +203,17 @@ class SkinnedEngine:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def forward(self, shs, opacities, scales, sync_num_rendered=False):
+    def forward(self, shs, opacities, scales, sync_num_rendered=False, posed_out=None):
+        """``posed_out``: optional (xyz [P,3], quaternions [P,4], scales [P,3]) fp32 tensors that also receive the posed values
+        (what SinGS.forward returns: sings_hybrid.py:400-419); the render itself never reads them back."""
         nr = C.c_int64(-1)
         self._s.flags = ((_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0) |
                          (_lib.FLAG_SH_PLANAR if self.sh_planar else 0))
         self._clean = False
+        pxyz, pq, psc = posed_out if posed_out is not None else (None, None, None)
         _lib.check(self.lib.sg_skinned_forward(
             C.byref(self._s), self.P, C.byref(self._k), _ptr(shs), _ptr(opacities), _ptr(scales), _ptr(self.geom),
-            _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), None, None, None,
+            _ptr(self.binning), self.cap, _ptr(self.img), _ptr(self.color), _ptr(self.radii), _ptr(pxyz), _ptr(pq), _ptr(psc),
             C.byref(nr) if sync_num_rendered else None, self._stream()), "skinned forward")
         self._clean = True
         return int(nr.value)

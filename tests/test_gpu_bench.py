@@ -128,6 +128,62 @@ def test_gpus_2_starts_two_ranks_and_the_collective_layer_sees_them():
         assert j["rccl_world"] is None and j["dist_backend"] == "gloo" and j["ranks_per_device"] == 2
     assert j["allreduce_bytes"] == 20000 * 59 * 4 and j["allreduce_ms"] > 0 and j["allreduce_exposed_ms"] > 0
     assert j["value"] > 0
+    # what makes a real N > 1 run decisive, exercised here at world 2:
+    #  (a) every rank holds the same reduced bytes; rank 0 re-rendered all 2 x 16 views itself and found the same sum
+    assert j["ranks_agree"] is True
+    assert j["dp_parity"]["ok"] and j["dp_parity"]["views"] == 2 * j["config"]["views_per_step"] and j["dp_parity"]["violations"] == 0
+    #  (b) both collectives timed stand-alone and exposed in the SAME run, the faster one ran the step
+    by = j["allreduce_ms_by_algorithm"]
+    assert set(by) == {"all_reduce", "rs_ag"} and min(by.values()) > 0
+    assert j["allreduce_algorithm"] == min(by, key=by.get) and "measured" in j["allreduce_algorithm_chosen_by"]
+    assert set(j["allreduce_exposed_ms_by_algorithm"]) == {"all_reduce", "rs_ag"}
+    #  (c) one device per rank, or the line says that the box is oversubscribed
+    assert len(j["rank_devices"]) == 2
+    assert (len(set(j["rank_devices"])) == 2) == (torch.cuda.device_count() >= 2)
+
+
+@pytest.mark.gpu
+def test_gpus_2_avatar_reduces_the_densification_statistics_and_the_ranks_agree():
+    """The avatar workload at world 2: gradient sum checked as above, and the densification statistics (sum of |viewspace gradient|,
+    visibility count, max radius: sings_hybrid.py:1013-1015, gs_trainer.py:486-492) reduced and equal on both ranks."""
+    j = _line(_bench("--gpus", "2", "--workload", "avatar", "--gaussians", "20000", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+                     "--views-per-step", "8", "--frames-per-launch", "4"))
+    assert j["n_gpus"] == 2 and j["dist_world"] == 2 and j["ranks_agree"] is True
+    assert j["dp_parity"]["ok"] and j["dp_parity"]["views"] == 16
+    d = j["densification_stats"]
+    assert d["reduced"] and d["ranks_agree"] and d["visible_sum"] > 0 and d["max_radius"] > 0
+    assert j["allreduce_bytes"] == 20000 * 10 * 4
+
+
+@pytest.mark.gpu
+def test_default_line_carries_every_baseline_configuration():
+    """`python bench.py --gpus 1 --steps 20 --warmup 5` (the driver's command): cfg3 stays `value`; `secondary` holds the other
+    BASELINE configurations, each from a timed region of >= 0.3 s in the same process, with its own roofline against the copy rate
+    of the run and a parity block from a full-size oracle view."""
+    j = _line(_bench("--gpus", "1", "--steps", "20", "--warmup", "5", timeout=1500))
+    assert j["config"]["gaussians"] == 200000 and j["parity"]["ok"] and j["parity"]["views"] == 3
+    assert j["train_step_ms_one_view"] > j["raster_fwd_bwd_ms_one_view"] > 0            # (the loss is inside the one-view train step)
+    sec = j["secondary"]
+    for k in ("cfg2_forward", "cfg4_avatar", "cfg5_regularisers", "train_step_K1", "train_step_K16", "dropin_autograd"):
+        assert k in sec and "error" not in sec[k], (k, sec.get(k))
+    for k in ("cfg2_forward", "cfg4_avatar", "cfg5_regularisers"):
+        e = sec[k]
+        assert e["value"] > 0 and e["timed_region_s"] >= 0.3 and e["repeats"] >= 2
+        r = e["roofline"]
+        assert r["bound"] == "hbm" and r["peak"] == j["hbm_copy_GBs_measured"] and 0 < r["frac"] < 1
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["algorithmic_bytes_per_view"] > 0
+        assert e["parity"]["ok"], (k, e["parity"])
+    assert sec["cfg2_forward"]["config"]["forward_only"] and sec["cfg2_forward"]["config"]["gaussians"] == 50000
+    assert sec["cfg5_regularisers"]["config"]["regularisers"] and sec["cfg5_regularisers"]["config"]["gaussians"] == 500000
+    av = sec["cfg4_avatar"]
+    assert av["config"]["gaussians"] == 150000 and av["train_step_ms_one_view"] > 0 and av["frames_per_s_one_frame_per_step"] > 0
+    assert av["parity"]["binning_exact"] and av["parity"]["gradient_arrays_compared"] == 7
+    for k, K in (("train_step_K1", 1), ("train_step_K16", 16)):
+        e = sec[k]
+        assert e["config"]["frames_per_step"] == K and e["value"] > 0 and e["timed_region_s"] >= 0.3 and "trajectory" in e["schedule_note"]
+    assert sec["train_step_K1"]["parity"]["ok"], sec["train_step_K1"]["parity"]
+    assert sec["dropin_autograd_ms_per_view"] == sec["dropin_autograd"]["ms_per_view"] > 0
+    assert sec["wall_s"] < 240
 
 
 @pytest.mark.gpu
