@@ -293,6 +293,15 @@ def _arm_early_count(s, dev):
     s.count_signal, s.count_signal_host = _signal_slot(dev)
 
 
+def _backward_buffers(dev, P, M, bwd_bytes, has_sh, has_col, has_scale, has_cov):
+    """The gradient tensors and the record workspace of one backward call (every element is written by the kernels)."""
+    def e(*shape):
+        return torch.empty(shape, dtype=torch.float32, device=dev)
+    return (e(P, 3), e(P, 3), e(P, 1), e(P, M, 3) if has_sh else None, e(P, 3) if has_col else None,
+            e(P, 3) if has_scale else None, e(P, 4) if has_scale else None, e(P, 6) if has_cov else None,
+            torch.empty(int(bwd_bytes), dtype=torch.uint8, device=dev))
+
+
 def _empty_to_none(t):
     return None if t is None or t.numel() == 0 else t
 
@@ -323,6 +332,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         cap, sync, sig = _forward_plan(dev, P, W, H)
+        need_bwd = any(ctx.needs_input_grad[:8])
         with torch.cuda.device(dev):
             if sync and not rs.debug:
                 _arm_early_count(s, dev)
@@ -331,6 +341,15 @@ class _RasterizeGaussians(torch.autograd.Function):
                 geom = torch.empty(L.geom_bytes, dtype=torch.uint8, device=dev)
                 binning = torch.empty(L.bin_bytes, dtype=torch.uint8, device=dev)
                 img = torch.empty(L.img_bytes, dtype=torch.uint8, device=dev)
+                # The backward's buffers are allocated HERE, in front of the forward's launch + wait for the pair count: the host
+                # work of a "sync" forward ends when the scan kernel has published R, and from there to the backward's first
+                # launch the GPU has only the forward composite (~70 us at cfg3) to run -- autograd's thread hop plus eight
+                # allocations, a layout call and a settings struct on the far side of that wait left it idle for ~50 us per view
+                # (drop-in surface 0.358 ms against 0.293 for the pre-allocated engine; now the allocations hide under the previous
+                # view's backward).  Only when a gradient is wanted; handed out once (a second backward through a retained graph
+                # allocates afresh: autograd may have adopted the first set as .grad).
+                bufs = _backward_buffers(dev, P, M, L.bwd_bytes, sh is not None, colors_precomp is not None, scales is not None,
+                                         cov3Ds_precomp is not None) if need_bwd else None
                 nr = C.c_int64(0)
                 _lib.check(lib.sg_rasterize_forward(
                     C.byref(s), P, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
@@ -348,6 +367,9 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = R
         ctx.capacity = cap
         ctx.sh_coeffs = M
+        ctx.bwd_bufs = bufs
+        ctx.bwd_bytes = int(L.bwd_bytes)
+        ctx.settings_struct = (s, keep)                     # the backward passes the same struct (same camera, same flags)
         ctx.flags = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
         z = torch.empty(0, device=dev)
         ctx.save_for_backward(means3D, sh if sh is not None else z,
@@ -369,22 +391,14 @@ class _RasterizeGaussians(torch.autograd.Function):
         dev = means3D.device
         P = int(means3D.shape[0])
         H, W = int(rs.image_height), int(rs.image_width)
-        keep = []
-        s = _settings_struct(rs, dev, ctx.sh_coeffs, keep)
+        s, keep = ctx.settings_struct
+        s.count_signal = None; s.count_signal_host = None
         g = _f32(grad_out_color, "grad_out_color", dev)
-
-        def e(*shape):
-            return torch.empty(shape, dtype=torch.float32, device=dev)
-
-        dmeans3D, dmeans2D, dopac = e(P, 3), e(P, 3), e(P, 1)
-        dsh = e(P, ctx.sh_coeffs, 3) if has_sh else None
-        dcol = e(P, 3) if has_col else None
-        dscales = e(P, 3) if has_scale else None
-        drots = e(P, 4) if has_scale else None
-        dcov = e(P, 6) if has_cov else None
+        bufs, ctx.bwd_bufs = ctx.bwd_bufs, None
+        if bufs is None:
+            bufs = _backward_buffers(dev, P, ctx.sh_coeffs, ctx.bwd_bytes, has_sh, has_col, has_scale, has_cov)
+        dmeans3D, dmeans2D, dopac, dsh, dcol, dscales, drots, dcov, bwd_ws = bufs
         with torch.cuda.device(dev):
-            L = _lib.layout(P, W, H, ctx.capacity)
-            bwd_ws = torch.empty(L.bwd_bytes, dtype=torch.uint8, device=dev)
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.sg_rasterize_backward(
                 C.byref(s), P, _ptr(means3D), _ptr(sh) if has_sh else None,

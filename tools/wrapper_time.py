@@ -1,7 +1,8 @@
-"""Drop-in autograd surface vs the pre-allocated engine (GPU box): python tools/wrapper_time.py -- cfg3, fwd+bwd per view."""
+"""Drop-in autograd surface (GaussianRasterizer through torch autograd, cfg3, fwd+bwd per view) in its overflow-check modes, each twice
+(GPU box): python tools/wrapper_time.py  -- per view: wall time and the host's submission time."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, "/root/repo")
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from sings_amd import rasterizer as rz
 from sings_amd.scene import synthetic_scene
@@ -15,30 +16,18 @@ req = lambda a: t(a).requires_grad_(True)
 m, op, sh, sc, rt = req(s["means3D"]), req(s["opacities"]), req(s["shs"]), req(s["scales"]), req(s["rotations"])
 dL = t(s["dL_dimage"])
 rast = GaussianRasterizer(rs)
-
-
 def step():
     for x in (m, op, sh, sc, rt): x.grad = None
     m2 = torch.zeros_like(m, requires_grad=True)
     color, radii = rast(means3D=m, means2D=m2, opacities=op, shs=sh, scales=sc, rotations=rt)
     color.backward(dL)
-
-
 def timeit(n=50):
     for _ in range(5): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): step()
-    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-
-
-print(f"autograd surface, default 'sync' (early pair count through a mapped host word):   {timeit():.3f} ms per view")
-# the round-1 / round-2 synchronous check for comparison: debug = False, but no early-count word -> stream synchronisation
-_arm = rz._arm_early_count
-rz._arm_early_count = lambda s, dev: None
-print(f"autograd surface, 'sync' by stream synchronisation (round-1 behaviour):             {timeit():.3f} ms per view")
-rz._arm_early_count = _arm
-rz.set_overflow_check("async")
-print(f"autograd surface, 'async' (pair count looked at one call later; opt-in):            {timeit():.3f} ms per view")
-rz.set_overflow_check("deferred")
-print(f"autograd surface, 'deferred' (device-side accumulator, polled; opt-in):             {timeit():.3f} ms per view")
-rz.set_overflow_check("sync")
+    t1 = time.perf_counter()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3, (t1 - t0) / n * 1e3
+for mode in ("sync", "async", "async", "deferred", "deferred", "sync"):
+    rz.set_overflow_check(mode)
+    a, b = timeit()
+    print(f"{mode:9s} {a:.3f} ms per view (host submission {b:.3f} ms)  reserved {torch.cuda.memory_reserved()/2**30:.2f} GiB")
