@@ -454,8 +454,8 @@ def _release():
 
 def wants_secondary(a, ctx):
     """The default single-GPU headline run (what the driver launches) also measures every other BASELINE configuration."""
-    return (ctx[1] == 1 and not a.no_secondary and not a.light and a.workload == "raster" and not a.forward_only and not a.graph
-            and (a.gaussians, a.width, a.height, a.sh_degree) == (200000, 1920, 1080, 3) and not a.regularisers)
+    return (ctx[1] == 1 and not a.no_secondary and not a.no_cpu_baseline and not a.light and a.workload == "raster" and not a.forward_only
+            and not a.graph and (a.gaussians, a.width, a.height, a.sh_degree) == (200000, 1920, 1080, 3) and not a.regularisers)
 
 
 def leg_raster(a, ctx):

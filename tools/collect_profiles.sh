@@ -11,7 +11,7 @@
 # (the default bench overlaps the views of a step on three streams: kernels of different views share the GPU and every
 # one of them takes longer while the step gets shorter).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT $OUT/avatar $OUT/k8 $OUT/avatar_k8

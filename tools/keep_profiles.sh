@@ -1,7 +1,7 @@
 #!/bin/bash
 # in the build container, after `gpurun -- 'bash tools/collect_profiles.sh <tag>'`, in the tree the passes ran from:
 #   bash tools/keep_profiles.sh <tag>     -> PMC summaries + sidecars and the campaign's files copied into profiles/<tag>_*
-TAG=${1:-r04}; P=gpurun_out/prof_$TAG
+TAG=${1:-r05}; P=gpurun_out/prof_$TAG
 AV="workload=avatar gaussians=150000 width=512 height=896 sh_degree=0"
 python tools/pmc_summary.py $P $TAG | tail -1 | cut -c1-100
 python tools/pmc_summary.py $P/avatar ${TAG}_avatar $AV | tail -1 | cut -c1-100
