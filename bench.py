@@ -48,61 +48,17 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-HBM_COPY_GBS = 6290.0
-XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU
-SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
-VALU_CYCLES_GUIDE = 2.0        # MI355X_MICROARCH.md constants table: one wave64 v_fma_f32 issues in 2 cycles
-VALU_CYCLES_MIX = 3.6          # issue cost of the backward composite's instruction mix, from tools/valu_probe.hip's per-kind costs: per
-                               # pass 6 lane swaps x 8.2 + 13 DPP x 4.2 + exp2, rcp x 8.2 + 6 cmp / select x 3.9 + ~45 plain x 2.6 cycles over 72
-                               # instructions (round 1's 95-instruction pass: 2.9 -- the instructions removed since were the cheap ones)
-
-
-_T0 = time.perf_counter()
-# SINGS_BENCH_FORCE_DIST=1: initialise the process group and ISSUE every collective even with one rank (RCCL accepts a one-rank
-# communicator), so that the nccl branches -- init_process_group("nccl", device_id), async all-reduce / in-place reduce-scatter +
-# all-gather on device views, work handles, the device-side MAX of the timed region -- run on a single-GPU box
-# (tests/test_gpu_bench.py); the line then carries rccl_world = 1 and the allreduce_* keys.
-FORCE_DIST = bool(os.environ.get("SINGS_BENCH_FORCE_DIST"))
-# one schema for every N: the collective keys are present (null) when no collective ran
-COMM_KEYS = ("allreduce_ms", "allreduce_bytes", "allreduce_algorithm", "allreduce_per_link_bound_ms", "allreduce_exposed_ms")
-MIN_TIMED_S = 0.5              # the timed region is repeated (whole regions of exactly --steps steps) until it adds up to this
-LIGHT_TIMED_S = 0.3            # ... of a secondary leg (--light)
-MAX_REPEATS = 5000
-
-
-def _log(msg):
-    """Progress on stderr (stdout carries only the JSON line): where a run is, should it ever stall."""
-    if os.environ.get("RANK", "0") == "0":
-        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
-
-
-def algorithmic_bytes(N, H, W, R, deg):
-    """SURVEY.md 8(d) per-unit figures, split per kernel (DESIGN.md sections 4-5)."""
-    inb = 44 + 12 * (deg + 1) ** 2
-    rec, gout, hw = 75, 248, H * W
-    per = {
-        "sg_preprocess_fwd_kernel": N * (inb + 4 + rec),
-        "binning": R * 12,
-        "sg_render_fwd_kernel": N * rec + hw * (12 + 8) + R * 4,
-        "sg_render_bwd_kernel": hw * (12 + 8) + R * 4,
-        "sg_preprocess_bwd_kernel": N * (inb + gout),
-    }
-    total = N * (2 * inb + gout + 4 + 2 * rec) + hw * 40 + R * 20
-    return per, total
-
-
-def algorithmic_bytes_skinned(N, H, W, R, deg, J, has_rot=False):
-    """The same for the LBS-fused path (last sentences): + N (12 + [36] + 4 J) read forward and again backward
-    (xyz_canon, [R_canon], skinning weights), + N (12 [+ 36]) written backward (dL/dxyz_canon [, dL/dR_canon]); posed means /
-    quaternions are never materialised: - N 28 read per pass, - N 28 of gradient writes."""
-    per, total = algorithmic_bytes(N, H, W, R, deg)
-    extra_in = N * (12 + (36 if has_rot else 0) + 4 * J) - N * 28
-    extra_out = N * (12 + (36 if has_rot else 0)) - N * 28
-    per = dict(per)
-    per["sg_preprocess_fwd_kernel"] += extra_in
-    per["sg_preprocess_bwd_kernel"] += extra_in + extra_out
-    return per, total + 2 * extra_in + extra_out
+# rooflines / PMC sidecars and the process-group / timing / self-check plumbing live in benchkit/ (no oracle, no workload there);
+# the names stay reachable as bench.<name> (tests/test_bench_host.py, tools/)
+from benchkit import distrib as _distrib                                     # noqa: E402
+from benchkit import roofline as _roofline                                   # noqa: E402
+from benchkit.distrib import (COMM_KEYS, FORCE_DIST, LIGHT_TIMED_S, MAX_REPEATS, MIN_TIMED_S, _grad_sha256, _log, _median,   # noqa: E402,F401
+                              _ranks_agree, allreduce_probe, densification_stats_check, dist_setup, dp_self_check,
+                              exposed_by_algorithm, make_frame_parallel, spawn_ranks, timed_region, timed_repeats, usable_cores)
+from benchkit.roofline import (CLOCK_HZ, HBM_COPY_GBS, HBM_PEAK_GBS, KERNEL_VARIANTS, PMC_SOURCES, SIMDS, VALU_CYCLES_GUIDE,   # noqa: E402,F401
+                               VALU_CYCLES_MIX, XGMI_LINK_GBS, _committed_pmc, _meta_status, algorithmic_bytes,
+                               algorithmic_bytes_skinned, build_roofline, git_blob_sha1, measure_copy_peak, pmc_view_traffic,
+                               scaling_model, source_hashes)
 
 
 def parse_args():
@@ -182,245 +138,6 @@ def parse_args():
     return a
 
 
-def spawn_ranks(a):
-    """`python bench.py --gpus N` (N > 1, not under a launcher): start N rank processes and relay rank 0's line.
-
-    Runs BEFORE anything in this process has initialised the GPU (no HIP call, no torch.cuda.is_available(); torch is not
-    even imported yet), and never exec()s: the ranks are ordinary children.  Ranks share a device only when the box has
-    fewer GPUs than ranks (single-GPU test boxes); RCCL refuses two ranks on one device, so that oversubscribed mode uses
-    host-staged gloo collectives and says so in the JSON line."""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    procs = []
-    import tempfile
-    out0 = tempfile.TemporaryFile()
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), LOCAL_WORLD_SIZE=str(a.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
-    # wait for all ranks; if one dies, the others would sit in a collective until its timeout: stop exactly those PIDs
-    rcs = [None] * a.gpus
-    while any(rc is None for rc in rcs):
-        for r, p in enumerate(procs):
-            if rcs[r] is None:
-                rcs[r] = p.poll()
-        if any(rc not in (None, 0) for rc in rcs):
-            for r, p in enumerate(procs):
-                if rcs[r] is None:
-                    p.terminate()
-            for r, p in enumerate(procs):
-                if rcs[r] is None:
-                    try:
-                        rcs[r] = p.wait(timeout=20)
-                    except subprocess.TimeoutExpired:
-                        p.kill(); rcs[r] = p.wait()
-            break
-        time.sleep(0.05)
-    out0.seek(0)
-    text = out0.read().decode(errors="replace")
-    lines = [ln for ln in text.splitlines() if ln.strip()]
-    if any(rcs):
-        print(text, file=sys.stderr)
-        raise SystemExit(f"bench.py: rank exit codes {rcs}")
-    if not lines or not lines[-1].lstrip().startswith("{"):
-        raise SystemExit("bench.py: rank 0 printed no JSON line")
-    for ln in lines[:-1]:
-        print(ln)
-    print(lines[-1], flush=True)
-
-
-def dist_setup(a):
-    """One process per GPU.  Returns (rank, world, device, dist module or None, info dict for the JSON line)."""
-    import torch
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != a.gpus:
-        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
-                         f"(python bench.py --gpus N starts them itself)")
-    ndev = torch.cuda.device_count()
-    if ndev == 0 or not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU path")
-    oversub = world > ndev
-    torch.cuda.set_device(local_rank % ndev)
-    dev = torch.device("cuda", local_rank % ndev)
-    dist, info = None, {"rccl_world": None, "dist_backend": None, "dist_world": 1, "ranks_per_device": 1}
-    if world > 1 or FORCE_DIST:                                    # the env knob exercises the RCCL path with one rank
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if oversub:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        if dist.get_world_size() != a.gpus:
-            raise SystemExit(f"bench.py: the process group has {dist.get_world_size()} ranks, --gpus {a.gpus}")
-        # one rank per GPU, or the run is not the measurement it claims to be: every rank reports its device, all must differ
-        # (single-GPU test boxes are knowingly oversubscribed: gloo, `ranks_per_device` > 1, said in the line)
-        mine = torch.tensor([local_rank % ndev], dtype=torch.int64, device="cpu" if oversub else dev)
-        got = [torch.empty_like(mine) for _ in range(world)]
-        dist.all_gather(got, mine)
-        devices = [int(g.item()) for g in got]
-        if not oversub and not FORCE_DIST and len(set(devices)) != world:
-            raise SystemExit(f"bench.py: --gpus {a.gpus} but the ranks sit on devices {devices}: one rank per GPU")
-        info = {"rccl_world": None if oversub else dist.get_world_size(), "dist_backend": dist.get_backend(),
-                "dist_world": dist.get_world_size(), "ranks_per_device": -(-world // ndev), "rank_devices": devices}
-    return rank, world, dev, dist, info
-
-
-def make_frame_parallel(ctx, nfloats):
-    """The collective layer of a leg + which algorithm it runs.  SINGS_DP_ALGO=all_reduce|rs_ag forces one; otherwise, with several
-    real ranks, BOTH are timed stand-alone on a scratch buffer of the step's gradient size (10 calls each after 3 warm-ups, device
-    events, MAX over ranks so that every rank reaches the same verdict) and the faster one runs the step -- the first real
-    multi-GPU run therefore measures the better schedule AND reports both (`allreduce_ms_by_algorithm`).  -> (fp or None, info)."""
-    import torch
-    rank, world, dev, dist, dinfo = ctx
-    if dist is None:
-        return None, {}
-    from sings_amd.dp import FrameParallel
-    staged = dist.get_backend() != "nccl"
-    mk = lambda algo: FrameParallel(algorithm=algo, host_staged=staged, force=FORCE_DIST)
-    forced = os.environ.get("SINGS_DP_ALGO")
-    if forced:
-        return mk(forced), {"allreduce_algorithm_chosen_by": "SINGS_DP_ALGO"}
-    if world == 1:
-        return mk("all_reduce"), {"allreduce_algorithm_chosen_by": "default (one rank)"}
-    scratch = torch.zeros(int(nfloats), dtype=torch.float32, device=dev)
-    times = {}
-    for algo in ("all_reduce", "rs_ag"):
-        f = mk(algo)
-        for _ in range(3):
-            f.all_reduce_grads(scratch)
-        torch.cuda.synchronize(); dist.barrier()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            f.all_reduce_grads(scratch)
-        e1.record()
-        torch.cuda.synchronize()
-        tt = torch.tensor([e0.elapsed_time(e1) / 10], dtype=torch.float64, device="cpu" if staged else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        times[algo] = float(tt.item())
-    del scratch
-    best = min(times, key=times.get)
-    return mk(best), {"allreduce_ms_by_algorithm": times, "allreduce_algorithm_chosen_by": "measured in this run (the faster of the two, stand-alone)"}
-
-
-def timed_region(dist, dev, steps, step):
-    """EXACTLY `steps` steps bracketed by barrier + synchronize on both sides; MAX over ranks (seconds)."""
-    import torch
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        el = float(tt.item())
-    return el
-
-
-def timed_repeats(dist, dev, steps, step, min_s=None):
-    """The timed region, repeated: whole regions of EXACTLY `steps` steps (each bracketed by barrier + synchronize, MAX over
-    ranks) until they add up to MIN_TIMED_S seconds and there are at least two.  The driver's `--steps 20` is 42 ms of work
-    for a 2-ms step -- one region of that length moves by +-1.5 % with the box; the line reports the MEDIAN region (and min /
-    max).  Every rank sees the same (reduced) durations, so all ranks take the same number of repetitions."""
-    min_s = MIN_TIMED_S if min_s is None else min_s
-    els = []
-    while True:
-        els.append(timed_region(dist, dev, steps, step))
-        if (len(els) >= 2 and sum(els) >= min_s) or len(els) >= MAX_REPEATS:
-            return els
-
-
-def _median(v):
-    v = sorted(v)
-    return v[len(v) // 2] if len(v) % 2 else 0.5 * (v[len(v) // 2 - 1] + v[len(v) // 2])
-
-
-def _grad_sha256(t):
-    """sha256 of a device buffer's bytes (tests: the forced one-rank RCCL run must reproduce the no-dist gradients bit for bit)."""
-    import hashlib
-    return hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()
-
-
-def measure_copy_peak(dev, gib=1.0):
-    """float4-copy bandwidth of THIS box in GB/s: sg_copy_probe (a plain 16-byte-per-lane copy kernel) over `gib` GiB, HIP events
-    on the launch stream, best of 3 after one warm-up; bytes = read + written.  SURVEY.md 8(d) / BASELINE.md section 2: the
-    denominator of the HBM roofline is measured, not quoted (the guide's figure for this part is 6.29 TB/s)."""
-    import torch
-    from sings_amd import _lib
-    lib = _lib.load()
-    n = int(gib * (1 << 30)) & ~255
-    src = torch.zeros(n, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
-    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    best = 0.0
-    for nt in (0, 1):                                  # plain / non-temporal loads + stores: the better form is the box's copy rate
-        for i in range(4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            _lib.check(lib.sg_copy_probe(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, nt, st), "copy probe")
-            e1.record()
-            torch.cuda.synchronize(dev)
-            if i:
-                best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-    del src, dst
-    torch.cuda.empty_cache()
-    return best
-
-
-def scaling_model(bytes_, t_step_ms, t_one_ms, exposed_ms=None, world=8):
-    """A clearly labelled MODEL of the 8-GPU frame-parallel step (no multi-GPU box is available to this build: the driver's SCALE
-    run is the measurement this is to be compared with).  Per step every rank adds ONE collective over `bytes_` of gradient:
-      rs_ag      : reduce-scatter + all-gather, every rank exchanging 1/W of the buffer with each peer over its own xGMI link:
-                   2 (W-1)/W S / ((W-1) 153 GB/s) = 2 S / (W 153 GB/s)
-      all_reduce : one ring: 2 (W-1)/W S / 153 GB/s  (per-link bound of RCCL's default schedule on a point-to-point mesh)
-    and cannot hide it (every gradient element depends on the last backward kernel; the optimiser needs the sum), so
-      predicted_scale_W = W t_step / (t_step + max(exposed_measured_world1, t_collective))
-    at the batched step and at the reference's one frame per step."""
-    S = float(bytes_)
-    link = XGMI_LINK_GBS * 1e9
-    coll = {"rs_ag": 2.0 * S / (world * link) * 1e3, "all_reduce": 2.0 * (world - 1) / world * S / link * 1e3}
-    floor = exposed_ms or 0.0
-    pred = {}
-    for label, t in (("batched", t_step_ms), ("one_view_per_step", t_one_ms)):
-        pred[label] = {k: world * t / (t + max(floor, v)) for k, v in coll.items()}
-    return {"label": "MODEL of the 8-GPU step, not a measurement (SCALE runs are the driver's)", "world": world, "collective_bytes": int(S),
-            "xgmi_link_GBs": XGMI_LINK_GBS, "collective_ms": coll, "exposed_ms_measured_world1": exposed_ms,
-            "t_step_ms": {"batched": t_step_ms, "one_view_per_step": t_one_ms}, "predicted_scale_8": pred}
-
-
-def allreduce_probe(fp, buf, iters=10):
-    """Stand-alone collective on the step's gradient buffer: ms per call (device events; MAX over ranks is implied by the
-    collective itself), bytes, and the xGMI per-link lower bound 2 (S/W) / 153 GB/s of a reduce-scatter + all-gather that
-    uses every link of the fully connected mesh."""
-    import torch
-    if fp is None or not fp.active:
-        return None
-    scratch = buf.clone()
-    for _ in range(3):
-        fp.all_reduce_grads(scratch)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        fp.all_reduce_grads(scratch)
-    e1.record()
-    torch.cuda.synchronize()
-    S = buf.numel() * buf.element_size()
-    return {"allreduce_ms": e0.elapsed_time(e1) / iters, "allreduce_bytes": S, "allreduce_algorithm": fp.algorithm,
-            "allreduce_per_link_bound_ms": 2.0 * (S / fp.world) / (XGMI_LINK_GBS * 1e9) * 1e3}
-
-
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--_cpu-worker":
         return cpu_lbs_project_worker(sys.argv[2:])
@@ -428,7 +145,7 @@ def main():
     if a.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        return spawn_ranks(a)
+        return spawn_ranks(a, os.path.abspath(__file__))
     ctx = dist_setup(a)
     out = LEGS[a.workload](a, ctx)                               # rank 0: the line (a dict); other ranks: None
     if out is not None and wants_secondary(a, ctx):
@@ -765,183 +482,6 @@ def _raster_view(eng, camera, v, ins, dLn, t, backward=True, host=True):
         d["grads"] = {"means3D": c(eng.d_means3D), "means2D": c(eng.d_means2D), "opacity": c(eng.d_opacity),
                       "scales": c(eng.d_scales), "rotations": c(eng.d_rots), "sh": c(eng.d_sh)}
     return d
-
-
-PMC_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
-               "sings_amd/csrc/sg_project.h", "sings_amd/csrc/sg_preprocess.hip", "sings_amd/csrc/sg_skin.hip",
-               "sings_amd/csrc/sg_common.h", "sings_amd/csrc/sg_math.h")
-
-
-def git_blob_sha1(path):
-    """The hash `git hash-object` gives the file (no git needed on the GPU box)."""
-    import hashlib
-    data = open(path, "rb").read()
-    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
-
-
-def source_hashes(root=ROOT):
-    return {rel: git_blob_sha1(os.path.join(root, rel)) for rel in PMC_SOURCES}
-
-
-def _meta_status(meta, cfg, root=ROOT):
-    """None if the PMC pass described by `meta` (sidecar written by tools/pmc_summary.py: configuration it ran + git blob
-    hashes of the kernel sources it profiled) is a pass of THIS configuration over THIS tree; otherwise the reason."""
-    if not isinstance(meta, dict) or "sources" not in meta or "config" not in meta:
-        return "no sidecar (configuration and kernel-source hashes of the PMC pass unknown)"
-    if any(meta["config"].get(k) != v for k, v in cfg.items()):
-        return f"PMC pass of another configuration ({meta['config']})"
-    cur = source_hashes(root)
-    changed = sorted(rel for rel, h in meta["sources"].items() if cur.get(rel) != h)
-    if changed:
-        return "kernel sources changed since the PMC pass: " + ", ".join(os.path.basename(c) for c in changed)
-    return None
-
-
-# kernels behind one event bracket of the library's profiler (sg_profile_collect): few-tile frames take the deep forward and
-# zero the records + run the sparse backward inside the "sg_render_bwd_kernel" bracket
-KERNEL_VARIANTS = {"sg_render_fwd_kernel": ("sg_render_fwd_kernel", "sg_render_fwd_deep_kernel"),
-                   "sg_render_bwd_kernel": ("sg_render_bwd_kernel", "sg_render_bwd_sparse_kernel", "sg_order_items_kernel")}
-
-
-def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
-    """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of THIS configuration
-    (profiles/<tag>_pmc_SQ.csv + <tag>_pmc_SQ.meta.json, profiles/hbm_traffic.json with its "_meta"; tools/pmc_summary.py writes
-    them).  A pass whose sidecar names another configuration, or whose recorded source hashes differ from the tree, is NOT
-    used: the counts describe other kernels -- the caller then falls back to the HBM roofline and says why (`stale`)."""
-    import csv
-    res = {"stale": None}
-    pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
-    why = "no committed *_pmc_SQ.csv"
-    try:
-        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv")):
-            try:
-                meta = json.load(open(os.path.join(pdir, fn[:-4] + ".meta.json")))
-            except Exception:
-                meta = None
-            st = _meta_status(meta, cfg, root)
-            if st is not None:
-                why = f"profiles/{fn}: {st}"
-                continue
-            names = KERNEL_VARIANTS.get(kernel, (kernel,))
-            got = [float(r["mean"]) for r in csv.DictReader(open(os.path.join(pdir, fn)))
-                   if r["kernel"].split("<")[0] in names and r["Counter_Name"] == "SQ_INSTS_VALU"]
-            if got:
-                res["valu"], res["valu_source"] = sum(got), f"profiles/{fn}"
-            else:
-                why = f"profiles/{fn}: no SQ_INSTS_VALU row for {kernel}"
-    except Exception as e:
-        why = f"{type(e).__name__}: {e}"
-    if "valu" not in res:
-        res["stale"] = why
-    try:
-        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")):
-            tj = json.load(open(os.path.join(pdir, fn)))
-            st = _meta_status(tj.get("_meta"), cfg, root)
-            if st is None:
-                got = [v for k, v in tj.items() if k.split("<")[0] in KERNEL_VARIANTS.get(kernel, (kernel,))]
-                res["traffic"] = sum(got) if got else None
-                res["traffic_source"] = f"profiles/{fn}"
-                res.pop("traffic_stale", None)
-                break
-            res["traffic_stale"] = f"{fn}: {st}"
-    except Exception:
-        pass
-    return res
-
-
-def pmc_view_traffic(cfg, pdir=None, root=ROOT, frames=1):
-    """Sum over ALL kernels of the committed HBM-traffic pass of this configuration and tree (bytes per VIEW), or None.  A pass
-    is taken with ONE view per launch or with K frames / cameras per launch (sidecar key `frames_per_launch`; the per-launch
-    counts are divided by K by tools/pmc_summary.py): the pass of the run's own K is preferred, the one-view pass is the fallback.
-    -> (bytes, source, frames per launch of the pass)."""
-    pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
-    best = None
-    try:
-        for fn in sorted((f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")), reverse=True):
-            tj = json.load(open(os.path.join(pdir, fn)))
-            meta = tj.get("_meta")
-            if _meta_status(meta, cfg, root) is None:
-                k = int(meta["config"].get("frames_per_launch", 1))
-                tot = sum(v for kk, v in tj.items() if not kk.startswith("_") and isinstance(v, (int, float)))
-                if k == frames:
-                    return tot, f"profiles/{fn}", k
-                if k == 1 and best is None:
-                    best = (tot, f"profiles/{fn}", 1)
-    except Exception:
-        pass
-    return best if best else (None, None, None)
-
-
-def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs, frames=1):
-    """-> (roofline, roofline_valu).
-
-    roofline (SURVEY.md 8(d) "Which roofline" / "Algorithmic bytes per view"): bound "hbm", scope the WHOLE pass of one view --
-    `achieved` = algorithmic bytes per view / seconds per view of the timed region, `peak` = the float4-copy bandwidth measured in
-    this run (`peak_spec` = the 8 TB/s of the data sheet, `frac_of_spec` against it), `traffic` = HBM bytes per view summed over
-    the kernels of the committed PMC pass of this configuration and tree (null if none matches).  The dominant kernel rides
-    along: its own algorithmic bytes / its live HIP-event duration (`dominant_kernel_frac`, same peak).
-    roofline_valu: the secondary bound SURVEY.md 8(d) names -- VALU issue of the dominant composite kernel (instructions per
-    launch from the committed PMC pass x the guide's 2 cycles / (duration x 2.4 GHz x 1024 SIMDs)); null without a matching pass."""
-    dom = max((k for k in per if k in kern), key=lambda k: kern[k])
-    pmc = _committed_pmc(dom, cfg)
-    peak = copy_gbs if copy_gbs else HBM_COPY_GBS
-    ach = total_bytes / s_per_view / 1e9
-    dom_ach = per[dom] / (kern[dom] * 1e-3) / 1e9
-    view_traffic, tsrc, tframes = pmc_view_traffic(cfg, frames=frames)
-    roof = {"bound": "hbm", "scope": "whole_pass", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
-            "peak_source": "float4 copy measured in this run (sg_copy_probe, 1 GiB, best of 3, plain or non-temporal)" if copy_gbs else
-                           "MI355X_MICROARCH.md (6.29 TB/s float4 copy; not measured in this run)",
-            "peak_spec": HBM_PEAK_GBS, "frac_of_spec": ach / HBM_PEAK_GBS,
-            "algorithmic_bytes_per_view": total_bytes, "ms_per_view": s_per_view * 1e3,
-            "traffic": view_traffic, "traffic_source": tsrc, "traffic_frames_per_launch": tframes,
-            "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_algorithmic_bytes": per[dom],
-            "dominant_kernel_achieved": dom_ach, "dominant_kernel_frac": dom_ach / peak,
-            "dominant_kernel_frac_of_spec": dom_ach / HBM_PEAK_GBS, "dominant_kernel_traffic": pmc.get("traffic")}
-    if pmc.get("traffic_stale"):
-        roof["traffic_note"] = "profiles/hbm_traffic.json not used: " + pmc["traffic_stale"]
-    if dom not in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
-        return roof, None
-    if not pmc.get("valu"):
-        return roof, {"bound": "valu", "kernel": dom, "frac": None,
-                      "note": "the composite kernels are VALU-issue bound (DESIGN.md section 4); omitted because no PMC pass "
-                              "matches this run -- " + str(pmc["stale"])}
-    instr = pmc["valu"]
-    rate = instr / (kern[dom] * 1e-3) / 1e9                                     # G wave-instructions / s
-    vpeak = SIMDS * CLOCK_HZ / VALU_CYCLES_GUIDE / 1e9
-    cpi = kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr
-    return roof, {"bound": "valu", "kernel": dom, "achieved": rate, "peak": vpeak, "unit": "G wave64-instr/s",
-                  "frac": rate / vpeak, "traffic": pmc.get("traffic"), "kernel_ms": kern[dom],
-                  "valu_wave_instructions_per_launch": instr, "source": pmc.get("valu_source"),
-                  "cycles_per_instruction": cpi, "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
-                  "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / cpi,
-                  "note": "secondary bound (SURVEY.md 8(d)): peak = guide's 2 cycles per wave64 VALU instruction; "
-                          "frac_vs_measured_mix_cost uses the cycles per instruction that tools/valu_probe.hip's per-kind costs "
-                          "give for this kernel's instruction mix"}
-
-
-def usable_cores():
-    """Host cores this process may actually run on: the affinity mask and the cgroup CPU quota, not just os.cpu_count()
-    (a container can see 256 CPUs and be allowed a fraction of them; an OpenMP team of 256 threads on a 16-CPU quota spends
-    its time in barriers)."""
-    n = os.cpu_count() or 1
-    try:
-        n = min(n, len(os.sched_getaffinity(0)))
-    except Exception:
-        pass
-    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
-        try:
-            txt = open(path).read().split()
-            if path.endswith("cpu.max"):
-                if txt[0] != "max":
-                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
-            else:
-                q = int(txt[0])
-                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
-                if q > 0:
-                    n = min(n, max(1, q // per))
-        except Exception:
-            pass
-    return max(1, n)
 
 
 def cpu_lbs_project_worker(argv):
@@ -1675,38 +1215,6 @@ def avatar_parity(s, eng, rs, A, ins, t):
     return res
 
 
-def densification_stats_check(ctx, fp, engs):
-    """Frame-parallel densification statistics (sings_hybrid.py:1013-1015, gs_trainer.py:486-492): every rank accumulates
-    |viewspace gradient| (sum), the visibility count (sum) and the largest screen radius (max) of ITS frames; the three are reduced
-    so that all ranks take identical densify / prune decisions.  Reduced here from the last step's engines, then compared across
-    ranks by hash.  -> keys for the line (the same on every rank)."""
-    import hashlib
-    import torch
-    rank, world, dev, dist, _ = ctx
-    e0 = engs[0]
-    P = e0.P
-    acc = torch.zeros(P, device=dev); den = torch.zeros(P, device=dev); rad = torch.zeros(P, dtype=torch.int32, device=dev)
-    for e in engs:
-        m2 = e.d_means2D.view(-1, P, 3); r = e.radii.view(-1, P)
-        vis = r > 0
-        acc += (m2[..., :2].norm(dim=-1) * vis).sum(0); den += vis.sum(0).float(); rad = torch.maximum(rad, r.max(0).values)
-    fp.reduce_densification_stats(acc, den, rad)
-    h = hashlib.sha256(acc.cpu().numpy().tobytes() + den.cpu().numpy().tobytes() + rad.cpu().numpy().tobytes()).digest()
-    return {"densification_stats": {"reduced": True, "ranks_agree": _ranks_agree(ctx, h), "visible_sum": float(den.sum()),
-                                    "max_radius": int(rad.max())}}
-
-
-def _ranks_agree(ctx, digest):
-    """all_gather of a 32-byte digest: True iff every rank holds the same bytes."""
-    import torch
-    rank, world, dev, dist, _ = ctx
-    on_dev = dist.get_backend() == "nccl"
-    mine = torch.tensor(list(digest), dtype=torch.uint8, device=dev if on_dev else "cpu")
-    got = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
-    dist.all_gather(got, mine)
-    return all(bool(torch.equal(g, got[0])) for g in got)
-
-
 def leg_dropin(a, ctx):
     """The drop-in autograd surface an UNMODIFIED gs_renderer_single.render() calls (GaussianRasterizer.forward / backward through
     torch autograd, default overflow mode: the pair count is checked before the call returns), cfg3, fwd + bwd per view --
@@ -1805,65 +1313,6 @@ def secondary_legs(a, ctx, head):
     _release()
     sec["wall_s"] = time.perf_counter() - t0
     return sec
-
-
-def dp_self_check(ctx, step0, render_flat, n_views_world):
-    """N > 1 (or a forced one-rank group), outside every timed region -- what makes the first real multi-GPU run decisive:
-      ranks_agree   all ranks all_gather the sha256 of their reduced gradient buffer: the collective must leave the SAME bytes
-                    everywhere;
-      dp_parity     rank 0 re-renders ALL `n_views_world` views of the step locally (one-view engine, the cameras / frames the
-                    ranks used: `render_flat(v)` -> that view's gradient in the buffer's layout), sums them in fp64 on the device
-                    and compares with the reduced sum (rtol 2e-4 + 2e-6 max|g|).
-    `step0()` runs one step on every rank and returns the reduced buffer.  Oversubscribed single-GPU test boxes (gloo, host-staged)
-    run the same code."""
-    import hashlib
-    import torch
-    rank, world, dev, dist, dinfo = ctx
-    acc = step0()
-    torch.cuda.synchronize()
-    agree = _ranks_agree(ctx, hashlib.sha256(acc.detach().cpu().numpy().tobytes()).digest())
-    res = {"ranks_agree": bool(agree), "dp_parity": None}
-    if rank == 0:
-        got = acc.detach().double().clone()
-        ref = torch.zeros_like(got)
-        for v in range(n_views_world):
-            ref += render_flat(v).detach().double()
-        scale = float(ref.abs().max()) + 1e-30
-        err = (got - ref).abs()
-        bad = int((err > 2e-4 * ref.abs() + 2e-6 * scale).sum())
-        res["dp_parity"] = {"ok": bad == 0, "views": n_views_world, "max_rel": float(err.max()) / scale, "violations": bad,
-                            "tol": "rtol 2e-4 + 2e-6 x max|g|",
-                            "note": "reduced sum of one step vs rank 0 rendering every rank's views itself (fp64 sum of the per-view gradients)"}
-        del got, ref, err
-    torch.cuda.synchronize()
-    dist.barrier()
-    return res
-
-
-def exposed_by_algorithm(ctx, pipe, step):
-    """The part of the collective the batched step cannot hide, for BOTH algorithms in the same run (median of 10 synchronised
-    steps each; MAX over ranks): the chunked fold + collective of sings_amd.dp.GradientPipeline with its FrameParallel swapped."""
-    import torch
-    rank, world, dev, dist, dinfo = ctx
-    from sings_amd.dp import FrameParallel
-    staged = dist.get_backend() != "nccl"
-    keep = pipe.fp
-    out = {}
-    pipe.enable_timing(True)
-    for algo in ("all_reduce", "rs_ag"):
-        pipe.fp = FrameParallel(algorithm=algo, host_staged=staged, force=FORCE_DIST)
-        ex = []
-        for _ in range(10):
-            torch.cuda.synchronize(); dist.barrier()
-            step()
-            torch.cuda.synchronize()
-            ex.append(pipe.exposed_ms())
-        tt = torch.tensor([sorted(ex)[len(ex) // 2]], dtype=torch.float64, device="cpu" if staged else dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        out[algo] = float(tt.item())
-    pipe.enable_timing(False)
-    pipe.fp = keep
-    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,243 @@
+"""Rooflines of the bench line: SURVEY.md 8(d) algorithmic bytes, the measured copy peak, the committed PMC passes with their sidecars
+(a pass is used only if it profiled THIS configuration and THIS tree), the 8-GPU scaling MODEL.  No oracle, no workload."""
+import ctypes as C
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+HBM_COPY_GBS = 6290.0
+XGMI_LINK_GBS = 153.0          # per direction and link; 7 links per GPU
+SIMDS, CLOCK_HZ = 1024, 2.4e9  # 256 CUs x 4 SIMDs
+VALU_CYCLES_GUIDE = 2.0        # MI355X_MICROARCH.md constants table: one wave64 v_fma_f32 issues in 2 cycles
+VALU_CYCLES_MIX = 3.6          # issue cost of the backward composite's instruction mix, from tools/valu_probe.hip's per-kind costs: per
+                               # pass 6 lane swaps x 8.2 + 13 DPP x 4.2 + exp2, rcp x 8.2 + 6 cmp / select x 3.9 + ~45 plain x 2.6 cycles over 72
+                               # instructions (round 1's 95-instruction pass: 2.9 -- the instructions removed since were the cheap ones)
+
+
+def algorithmic_bytes(N, H, W, R, deg):
+    """SURVEY.md 8(d) per-unit figures, split per kernel (DESIGN.md sections 4-5)."""
+    inb = 44 + 12 * (deg + 1) ** 2
+    rec, gout, hw = 75, 248, H * W
+    per = {
+        "sg_preprocess_fwd_kernel": N * (inb + 4 + rec),
+        "binning": R * 12,
+        "sg_render_fwd_kernel": N * rec + hw * (12 + 8) + R * 4,
+        "sg_render_bwd_kernel": hw * (12 + 8) + R * 4,
+        "sg_preprocess_bwd_kernel": N * (inb + gout),
+    }
+    total = N * (2 * inb + gout + 4 + 2 * rec) + hw * 40 + R * 20
+    return per, total
+
+
+def algorithmic_bytes_skinned(N, H, W, R, deg, J, has_rot=False):
+    """The same for the LBS-fused path (last sentences): + N (12 + [36] + 4 J) read forward and again backward
+    (xyz_canon, [R_canon], skinning weights), + N (12 [+ 36]) written backward (dL/dxyz_canon [, dL/dR_canon]); posed means /
+    quaternions are never materialised: - N 28 read per pass, - N 28 of gradient writes."""
+    per, total = algorithmic_bytes(N, H, W, R, deg)
+    extra_in = N * (12 + (36 if has_rot else 0) + 4 * J) - N * 28
+    extra_out = N * (12 + (36 if has_rot else 0)) - N * 28
+    per = dict(per)
+    per["sg_preprocess_fwd_kernel"] += extra_in
+    per["sg_preprocess_bwd_kernel"] += extra_in + extra_out
+    return per, total + 2 * extra_in + extra_out
+
+
+def measure_copy_peak(dev, gib=1.0):
+    """float4-copy bandwidth of THIS box in GB/s: sg_copy_probe (a plain 16-byte-per-lane copy kernel) over `gib` GiB, HIP events
+    on the launch stream, best of 3 after one warm-up; bytes = read + written.  SURVEY.md 8(d) / BASELINE.md section 2: the
+    denominator of the HBM roofline is measured, not quoted (the guide's figure for this part is 6.29 TB/s)."""
+    import torch
+    from sings_amd import _lib
+    lib = _lib.load()
+    n = int(gib * (1 << 30)) & ~255
+    src = torch.zeros(n, dtype=torch.uint8, device=dev); dst = torch.empty_like(src)
+    st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    best = 0.0
+    for nt in (0, 1):                                  # plain / non-temporal loads + stores: the better form is the box's copy rate
+        for i in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _lib.check(lib.sg_copy_probe(C.c_void_p(dst.data_ptr()), C.c_void_p(src.data_ptr()), n, nt, st), "copy probe")
+            e1.record()
+            torch.cuda.synchronize(dev)
+            if i:
+                best = max(best, 2.0 * n / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+    del src, dst
+    torch.cuda.empty_cache()
+    return best
+
+
+def scaling_model(bytes_, t_step_ms, t_one_ms, exposed_ms=None, world=8):
+    """A clearly labelled MODEL of the 8-GPU frame-parallel step (no multi-GPU box is available to this build: the driver's SCALE
+    run is the measurement this is to be compared with).  Per step every rank adds ONE collective over `bytes_` of gradient:
+      rs_ag      : reduce-scatter + all-gather, every rank exchanging 1/W of the buffer with each peer over its own xGMI link:
+                   2 (W-1)/W S / ((W-1) 153 GB/s) = 2 S / (W 153 GB/s)
+      all_reduce : one ring: 2 (W-1)/W S / 153 GB/s  (per-link bound of RCCL's default schedule on a point-to-point mesh)
+    and cannot hide it (every gradient element depends on the last backward kernel; the optimiser needs the sum), so
+      predicted_scale_W = W t_step / (t_step + max(exposed_measured_world1, t_collective))
+    at the batched step and at the reference's one frame per step."""
+    S = float(bytes_)
+    link = XGMI_LINK_GBS * 1e9
+    coll = {"rs_ag": 2.0 * S / (world * link) * 1e3, "all_reduce": 2.0 * (world - 1) / world * S / link * 1e3}
+    floor = exposed_ms or 0.0
+    pred = {}
+    for label, t in (("batched", t_step_ms), ("one_view_per_step", t_one_ms)):
+        pred[label] = {k: world * t / (t + max(floor, v)) for k, v in coll.items()}
+    return {"label": "MODEL of the 8-GPU step, not a measurement (SCALE runs are the driver's)", "world": world, "collective_bytes": int(S),
+            "xgmi_link_GBs": XGMI_LINK_GBS, "collective_ms": coll, "exposed_ms_measured_world1": exposed_ms,
+            "t_step_ms": {"batched": t_step_ms, "one_view_per_step": t_one_ms}, "predicted_scale_8": pred}
+PMC_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
+               "sings_amd/csrc/sg_project.h", "sings_amd/csrc/sg_preprocess.hip", "sings_amd/csrc/sg_skin.hip",
+               "sings_amd/csrc/sg_common.h", "sings_amd/csrc/sg_math.h")
+
+
+def git_blob_sha1(path):
+    """The hash `git hash-object` gives the file (no git needed on the GPU box)."""
+    import hashlib
+    data = open(path, "rb").read()
+    return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def source_hashes(root=ROOT):
+    return {rel: git_blob_sha1(os.path.join(root, rel)) for rel in PMC_SOURCES}
+
+
+def _meta_status(meta, cfg, root=ROOT):
+    """None if the PMC pass described by `meta` (sidecar written by tools/pmc_summary.py: configuration it ran + git blob
+    hashes of the kernel sources it profiled) is a pass of THIS configuration over THIS tree; otherwise the reason."""
+    if not isinstance(meta, dict) or "sources" not in meta or "config" not in meta:
+        return "no sidecar (configuration and kernel-source hashes of the PMC pass unknown)"
+    if any(meta["config"].get(k) != v for k, v in cfg.items()):
+        return f"PMC pass of another configuration ({meta['config']})"
+    cur = source_hashes(root)
+    changed = sorted(rel for rel, h in meta["sources"].items() if cur.get(rel) != h)
+    if changed:
+        return "kernel sources changed since the PMC pass: " + ", ".join(os.path.basename(c) for c in changed)
+    return None
+
+
+# kernels behind one event bracket of the library's profiler (sg_profile_collect): few-tile frames take the deep forward and
+# zero the records + run the sparse backward inside the "sg_render_bwd_kernel" bracket
+KERNEL_VARIANTS = {"sg_render_fwd_kernel": ("sg_render_fwd_kernel", "sg_render_fwd_deep_kernel"),
+                   "sg_render_bwd_kernel": ("sg_render_bwd_kernel", "sg_render_bwd_sparse_kernel", "sg_order_items_kernel")}
+
+
+def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
+    """VALU wave-instructions and HBM bytes per launch of `kernel` from the newest committed PMC passes of THIS configuration
+    (profiles/<tag>_pmc_SQ.csv + <tag>_pmc_SQ.meta.json, profiles/hbm_traffic.json with its "_meta"; tools/pmc_summary.py writes
+    them).  A pass whose sidecar names another configuration, or whose recorded source hashes differ from the tree, is NOT
+    used: the counts describe other kernels -- the caller then falls back to the HBM roofline and says why (`stale`)."""
+    import csv
+    res = {"stale": None}
+    pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
+    why = "no committed *_pmc_SQ.csv"
+    try:
+        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv")):
+            try:
+                meta = json.load(open(os.path.join(pdir, fn[:-4] + ".meta.json")))
+            except Exception:
+                meta = None
+            st = _meta_status(meta, cfg, root)
+            if st is not None:
+                why = f"profiles/{fn}: {st}"
+                continue
+            names = KERNEL_VARIANTS.get(kernel, (kernel,))
+            got = [float(r["mean"]) for r in csv.DictReader(open(os.path.join(pdir, fn)))
+                   if r["kernel"].split("<")[0] in names and r["Counter_Name"] == "SQ_INSTS_VALU"]
+            if got:
+                res["valu"], res["valu_source"] = sum(got), f"profiles/{fn}"
+            else:
+                why = f"profiles/{fn}: no SQ_INSTS_VALU row for {kernel}"
+    except Exception as e:
+        why = f"{type(e).__name__}: {e}"
+    if "valu" not in res:
+        res["stale"] = why
+    try:
+        for fn in sorted(f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")):
+            tj = json.load(open(os.path.join(pdir, fn)))
+            st = _meta_status(tj.get("_meta"), cfg, root)
+            if st is None:
+                got = [v for k, v in tj.items() if k.split("<")[0] in KERNEL_VARIANTS.get(kernel, (kernel,))]
+                res["traffic"] = sum(got) if got else None
+                res["traffic_source"] = f"profiles/{fn}"
+                res.pop("traffic_stale", None)
+                break
+            res["traffic_stale"] = f"{fn}: {st}"
+    except Exception:
+        pass
+    return res
+
+
+def pmc_view_traffic(cfg, pdir=None, root=ROOT, frames=1):
+    """Sum over ALL kernels of the committed HBM-traffic pass of this configuration and tree (bytes per VIEW), or None.  A pass
+    is taken with ONE view per launch or with K frames / cameras per launch (sidecar key `frames_per_launch`; the per-launch
+    counts are divided by K by tools/pmc_summary.py): the pass of the run's own K is preferred, the one-view pass is the fallback.
+    -> (bytes, source, frames per launch of the pass)."""
+    pdir = os.path.join(ROOT, "profiles") if pdir is None else pdir
+    best = None
+    try:
+        for fn in sorted((f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")), reverse=True):
+            tj = json.load(open(os.path.join(pdir, fn)))
+            meta = tj.get("_meta")
+            if _meta_status(meta, cfg, root) is None:
+                k = int(meta["config"].get("frames_per_launch", 1))
+                # (the raster line's one-view TRAIN step also runs the photometric-loss kernels: they are not part of a rendered
+                #  view -- neither of `value` nor of its algorithmic bytes -- and stay out of its traffic)
+                skip = ("sg_ssim", "sg_loss") if cfg.get("workload") == "raster" else ()
+                tot = sum(v for kk, v in tj.items() if not kk.startswith("_") and isinstance(v, (int, float)) and not kk.startswith(skip))
+                if k == frames:
+                    return tot, f"profiles/{fn}", k
+                if k == 1 and best is None:
+                    best = (tot, f"profiles/{fn}", 1)
+    except Exception:
+        pass
+    return best if best else (None, None, None)
+
+
+def build_roofline(kern, per, cfg, total_bytes, s_per_view, copy_gbs, frames=1):
+    """-> (roofline, roofline_valu).
+
+    roofline (SURVEY.md 8(d) "Which roofline" / "Algorithmic bytes per view"): bound "hbm", scope the WHOLE pass of one view --
+    `achieved` = algorithmic bytes per view / seconds per view of the timed region, `peak` = the float4-copy bandwidth measured in
+    this run (`peak_spec` = the 8 TB/s of the data sheet, `frac_of_spec` against it), `traffic` = HBM bytes per view summed over
+    the kernels of the committed PMC pass of this configuration and tree (null if none matches).  The dominant kernel rides
+    along: its own algorithmic bytes / its live HIP-event duration (`dominant_kernel_frac`, same peak).
+    roofline_valu: the secondary bound SURVEY.md 8(d) names -- VALU issue of the dominant composite kernel (instructions per
+    launch from the committed PMC pass x the guide's 2 cycles / (duration x 2.4 GHz x 1024 SIMDs)); null without a matching pass."""
+    dom = max((k for k in per if k in kern), key=lambda k: kern[k])
+    pmc = _committed_pmc(dom, cfg)
+    peak = copy_gbs if copy_gbs else HBM_COPY_GBS
+    ach = total_bytes / s_per_view / 1e9
+    dom_ach = per[dom] / (kern[dom] * 1e-3) / 1e9
+    view_traffic, tsrc, tframes = pmc_view_traffic(cfg, frames=frames)
+    roof = {"bound": "hbm", "scope": "whole_pass", "achieved": ach, "peak": peak, "unit": "GB/s", "frac": ach / peak,
+            "peak_source": "float4 copy measured in this run (sg_copy_probe, 1 GiB, best of 3, plain or non-temporal)" if copy_gbs else
+                           "MI355X_MICROARCH.md (6.29 TB/s float4 copy; not measured in this run)",
+            "peak_spec": HBM_PEAK_GBS, "frac_of_spec": ach / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_view": total_bytes, "ms_per_view": s_per_view * 1e3,
+            "traffic": view_traffic, "traffic_source": tsrc, "traffic_frames_per_launch": tframes,
+            "dominant_kernel": dom, "dominant_kernel_ms": kern[dom], "dominant_kernel_algorithmic_bytes": per[dom],
+            "dominant_kernel_achieved": dom_ach, "dominant_kernel_frac": dom_ach / peak,
+            "dominant_kernel_frac_of_spec": dom_ach / HBM_PEAK_GBS, "dominant_kernel_traffic": pmc.get("traffic")}
+    if pmc.get("traffic_stale"):
+        roof["traffic_note"] = "profiles/hbm_traffic.json not used: " + pmc["traffic_stale"]
+    if dom not in ("sg_render_bwd_kernel", "sg_render_fwd_kernel"):
+        return roof, None
+    if not pmc.get("valu"):
+        return roof, {"bound": "valu", "kernel": dom, "frac": None,
+                      "note": "the composite kernels are VALU-issue bound (DESIGN.md section 4); omitted because no PMC pass "
+                              "matches this run -- " + str(pmc["stale"])}
+    instr = pmc["valu"]
+    rate = instr / (kern[dom] * 1e-3) / 1e9                                     # G wave-instructions / s
+    vpeak = SIMDS * CLOCK_HZ / VALU_CYCLES_GUIDE / 1e9
+    cpi = kern[dom] * 1e-3 * CLOCK_HZ * SIMDS / instr
+    return roof, {"bound": "valu", "kernel": dom, "achieved": rate, "peak": vpeak, "unit": "G wave64-instr/s",
+                  "frac": rate / vpeak, "traffic": pmc.get("traffic"), "kernel_ms": kern[dom],
+                  "valu_wave_instructions_per_launch": instr, "source": pmc.get("valu_source"),
+                  "cycles_per_instruction": cpi, "peak_cycles_per_instruction": VALU_CYCLES_GUIDE,
+                  "frac_vs_measured_mix_cost": VALU_CYCLES_MIX / cpi,
+                  "note": "secondary bound (SURVEY.md 8(d)): peak = guide's 2 cycles per wave64 VALU instruction; "
+                          "frac_vs_measured_mix_cost uses the cycles per instruction that tools/valu_probe.hip's per-kind costs "
+                          "give for this kernel's instruction mix"}

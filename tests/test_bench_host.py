@@ -44,15 +44,16 @@ def test_tampered_sidecar_drops_the_valu_roofline(tmp_path):
     pdir = _profiles(tmp_path, meta)
     r = bench._committed_pmc("sg_render_bwd_kernel", CFG, pdir)
     assert "valu" not in r and "sg_render.hip" in r["stale"] and "traffic" not in r and "sg_render.hip" in r["traffic_stale"]
-    old = bench._committed_pmc
-    bench._committed_pmc = lambda k, c: old(k, c, pdir)
+    R = bench._roofline                                          # (build_roofline looks the helpers up in its own module)
+    old = R._committed_pmc
+    R._committed_pmc = lambda k, c: old(k, c, pdir)
     try:
         kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
                 "sg_preprocess_bwd_kernel": 0.03}
         per, total = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
         roof, valu = bench.build_roofline(kern, per, CFG, total, 0.25e-3, 6200.0)
     finally:
-        bench._committed_pmc = old
+        R._committed_pmc = old
     assert roof["bound"] == "hbm" and roof["dominant_kernel"] == "sg_render_bwd_kernel"
     assert valu["frac"] is None and "sg_render.hip" in valu["note"]
     assert roof["dominant_kernel_traffic"] is None and roof["peak"] == 6200.0
@@ -65,16 +66,17 @@ def test_roofline_is_the_whole_pass_hbm_quantity_and_valu_is_secondary(tmp_path)
     the VALU-issue figure of the dominant composite kernel is `roofline_valu`; `traffic` = the PMC bytes of ALL kernels."""
     meta = {"config": dict(CFG), "sources": bench.source_hashes()}
     pdir = _profiles(tmp_path, meta)
-    old, oldt = bench._committed_pmc, bench.pmc_view_traffic
-    bench._committed_pmc = lambda k, c: old(k, c, pdir)
-    bench.pmc_view_traffic = lambda c, frames=1: oldt(c, pdir, frames=frames)
+    R = bench._roofline
+    old, oldt = R._committed_pmc, R.pmc_view_traffic
+    R._committed_pmc = lambda k, c: old(k, c, pdir)
+    R.pmc_view_traffic = lambda c, frames=1: oldt(c, pdir, frames=frames)
     try:
         kern = {"sg_preprocess_fwd_kernel": 0.03, "sg_render_fwd_kernel": 0.07, "sg_render_bwd_kernel": 0.15,
                 "sg_preprocess_bwd_kernel": 0.03}
         per, total = bench.algorithmic_bytes(200000, 1080, 1920, 780000, 3)
         roof, valu = bench.build_roofline(kern, per, CFG, total, 0.25e-3, 6300.0)
     finally:
-        bench._committed_pmc, bench.pmc_view_traffic = old, oldt
+        R._committed_pmc, R.pmc_view_traffic = old, oldt
     assert roof["bound"] == "hbm" and roof["scope"] == "whole_pass" and roof["traffic"] == 123456 + 777
     assert roof["traffic_frames_per_launch"] == 1
     assert roof["algorithmic_bytes_per_view"] == total and roof["peak_spec"] == 8000.0
@@ -112,11 +114,11 @@ def test_timed_repeats_runs_whole_regions_until_the_minimum(monkeypatch):
     def fake_region(dist, dev, steps, step):
         calls.append(steps)
         return 0.1
-    monkeypatch.setattr(bench, "timed_region", fake_region)
+    monkeypatch.setattr(bench._distrib, "timed_region", fake_region)
     els = bench.timed_repeats(None, None, 7, None)
     assert calls == [7] * 5 and len(els) == 5                   # 5 x 0.1 s reaches MIN_TIMED_S = 0.5
     calls.clear()
-    monkeypatch.setattr(bench, "timed_region", lambda *a: calls.append(1) or 2.0)
+    monkeypatch.setattr(bench._distrib, "timed_region", lambda *a: calls.append(1) or 2.0)
     assert len(bench.timed_repeats(None, None, 3, None)) == 2   # never fewer than two regions
     assert bench._median([3.0, 1.0, 2.0]) == 2.0 and bench._median([1.0, 2.0]) == 1.5
 
