@@ -502,6 +502,12 @@ __device__ __forceinline__ int sg_red_idx(int lane)
         grec_a = sg_at(grec_a, fr); grec_b = sg_at(grec_b, fr);                                                          \
         dL_dpix += (size_t)blockIdx.y * bt.image;                                                                        \
     }
+// Round 5: the dependent gathers of an item (list id -> record slot -> records) are done in ONE round per chunk of SG_BCH entries, one
+// entry per thread, and the 64-entry batches then run out of LDS -- at cfg3 (lists of ~96 entries) one round per tile instead of one
+// per batch; the quadrant-sum slots are re-armed by the combine step itself (one barrier per batch less).  148.4 -> 145.8 us per
+// cfg3 view, +1.5 % views/s on one box (A / B / A / B).  Requesting the first chunk's ids and slot words in front of the prologue's
+// barrier on top of that: measured, no gain (146.7 us).
+#define SG_BCH 128
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
@@ -513,8 +519,8 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
                      const float4 *__restrict__ ckpt, uint32_t ck_cap, const uint8_t *__restrict__ pair_mask, uint32_t mask_plane,
                      int split_long)
 {
-    __shared__ float4 sR[SG_BB][3];            // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
-    __shared__ uint32_t sM[SG_BB];
+    __shared__ float4 sR[SG_BCH][3];           // staged entry: (mean x, mean y, A', B') (C', opacity, colour 0, 1) (colour 2, -, -, -)
+    __shared__ uint32_t sM[SG_BCH];
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
@@ -562,24 +568,24 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
     for (int o = 32; o > 0; o >>= 1) { uint32_t u = __shfl_xor(m, o, 64); m = u > m ? u : m; }
     const int maxq = (int)__builtin_amdgcn_readfirstlane(m);          // this quadrant's deepest contributor
     if (lane == 0) smax[wave] = m;
+    if (tid < SG_BB) {
+#pragma unroll
+        for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
+    }
     __syncthreads();
     const int max_contrib = (int)max(max(smax[0], smax[1]), max(smax[2], smax[3]));
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int cslot = lane == 63 ? 8 : sg_red_idx(lane);
-    for (int kb = (hi - 1) / SG_BB; kb >= lo / SG_BB; kb--) {
-        const int base = kb * SG_BB;
-        const int cnt = hi - base < SG_BB ? hi - base : SG_BB;
-        // ---- stage (threads 0..127): records, quadrant mask, gradient-record slot
+    for (int ch = (hi - 1) / SG_BCH; ch >= lo / SG_BCH; ch--) {
+        const int cbase = ch * SG_BCH;
+        const int ccnt = hi - cbase < SG_BCH ? hi - cbase : SG_BCH;
+        // ---- stage the chunk (threads 0..SG_BCH-1): records, quadrant mask, gradient-record slot
         uint32_t rslot = 0xffffffffu;
         float opac = 0.0f, cA = 0.0f, cB = 0.0f, cC = 0.0f;
-        if (tid < cnt) {
-            const int e = base + tid;
+        if (tid < ccnt) {
+            const int e = cbase + tid;
             const uint32_t gid = point_list[range.x + e];
-            const float4 c4 = recC[SG_REC_STRIDE * (size_t)gid];
-            const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
-            const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
-            rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
             // quadrants the forward composited this entry in: nothing else can carry a gradient, so neither the
             // rectangle tests nor the two record gathers are repeated for the rest
             // (a long tile of a few-tile frame was composited by four workgroups, one mask plane each: sg_render_fwd_body)
@@ -590,6 +596,7 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
                     mk = (mk & 1u) | (pair_mask[(size_t)mask_plane + range.x + e] & 2u) | (pair_mask[2 * (size_t)mask_plane + range.x + e] & 4u) |
                          (pair_mask[3 * (size_t)mask_plane + range.x + e] & 8u);
             }
+            const float4 c4 = recC[SG_REC_STRIDE * (size_t)gid];
             if (mk) {
                 const float4 a = recA[SG_REC_STRIDE * (size_t)gid], b = recB[SG_REC_STRIDE * (size_t)gid];
                 opac = b.y; cA = a.z; cB = a.w; cC = b.x;
@@ -597,43 +604,50 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
                 sR[tid][1] = make_float4(SG_KA * b.x, b.y, b.z, b.w);
                 sR[tid][2].x = c4.x;
             }
+            const uint32_t goff = __float_as_uint(c4.y), mn = __float_as_uint(c4.z), wh = __float_as_uint(c4.w);
+            const int x0 = mn & 0xffff, y0 = mn >> 16, rw = wh & 0xffff;
+            rslot = goff + (uint32_t)((ty - y0) * rw + (tx - x0));
             sM[tid] = mk;
         }
-        if (tid < SG_BB) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
-        }
         __syncthreads();
-        // ---- each wave: the entries that can reach its quadrant, back to front
-        if (base < maxq) {
-            uint16_t *list = sList[wave];
-            const int lim = maxq - base < cnt ? maxq - base : cnt;         // entries >= maxq touch no pixel here
-            const int nl = sg_compact_quadrant<1>(sM, lim, wave, lane, lt, list, SG_BB);
-            const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the batch
-            for (int i = nl - 1; i >= 0; i--) {
-                const uint32_t k = list[i];
-                const float4 ga = sR[k][0], gb = sR[k][1];
-                const float gc = sR[k][2].x;
-                SG_BWD_PASS(k, k);
-            }
-        }
-        __syncthreads();
-        // ---- combine the quadrants in a fixed order and store the record
-        if (tid < cnt && rslot < cap) {
-            float s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-            for (int w = 0; w < 4; w++)
-                if (__float_as_uint(sG[w][tid][8]) != SG_UNSET) {
-#pragma unroll
-                    for (int q = 0; q < 9; q++) s[q] += sG[w][tid][q];
+        for (int kb = (ccnt - 1) / SG_BB; kb >= 0; kb--) {
+            const int b0 = kb * SG_BB, base = cbase + b0;                  // the batch inside the chunk / inside the list
+            const int cnt = ccnt - b0 < SG_BB ? ccnt - b0 : SG_BB;
+            // ---- each wave: the entries that can reach its quadrant, back to front
+            if (base < maxq) {
+                uint16_t *list = sList[wave];
+                const int lim = maxq - base < cnt ? maxq - base : cnt;         // entries >= maxq touch no pixel here
+                const int nl = sg_compact_quadrant<1>(sM + b0, lim, wave, lane, lt, list, SG_BB);
+                const uint32_t ncq_b = ncq > (uint32_t)base ? ncq - (uint32_t)base : 0u;   // contributors of this pixel inside the batch
+                for (int i = nl - 1; i >= 0; i--) {
+                    const uint32_t k = list[i];
+                    const float4 ga = sR[b0 + k][0], gb = sR[b0 + k][1];
+                    const float gc = sR[b0 + k][2].x;
+                    SG_BWD_PASS(k, k);
                 }
-            const float no = -opac, nh = 0.5f * no;              // -opacity, -opacity / 2
-            const float m0 = fmaf(cA, s[0], cB * s[1]), m1 = fmaf(cB, s[0], cC * s[1]);   // conic . first moments
-            grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s[2], nh * s[3]);
-            grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
-            grec_b[rslot] = s[8];
+            }
+            __syncthreads();
+            // ---- combine the quadrants in a fixed order, store the record, re-arm the slots (the thread that staged the entry)
+            if (tid >= b0 && tid < b0 + cnt) {
+                const int q0 = tid - b0;
+                float s[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+                for (int w = 0; w < 4; w++)
+                    if (__float_as_uint(sG[w][q0][8]) != SG_UNSET) {
+#pragma unroll
+                        for (int q = 0; q < 9; q++) s[q] += sG[w][q0][q];
+                        sG[w][q0][8] = __uint_as_float(SG_UNSET);
+                    }
+                if (rslot < cap) {
+                    const float no = -opac, nh = 0.5f * no;              // -opacity, -opacity / 2
+                    const float m0 = fmaf(cA, s[0], cB * s[1]), m1 = fmaf(cB, s[0], cC * s[1]);   // conic . first moments
+                    grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s[2], nh * s[3]);
+                    grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s[4], s[5], s[6], s[7]);
+                    grec_b[rslot] = s[8];
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 }
 
@@ -789,16 +803,15 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
     const float ddelx_dx = 0.5f * (float)W, ddely_dy = 0.5f * (float)H;
     const unsigned long long lt = (1ull << lane) - 1ull;
     const int cslot = lane == 63 ? 8 : sg_red_idx(lane);
+    if (tid < SG_BB) {                                                  // armed once; the combine step re-arms what it consumed (round 5:
+#pragma unroll                                                          //  one barrier per sub-batch less)
+        for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
+    }
     __syncthreads();
     // ---- the sub-batches, back to front, out of LDS
     for (int sb = (cnt - 1) / SG_BB; sb >= 0; sb--) {
         const int b0 = sb * SG_BB, base = lo + b0;                      // staged index / list position of the sub-batch's first entry
         const int bc = cnt - b0 < SG_BB ? cnt - b0 : SG_BB;
-        if (tid < SG_BB) {
-#pragma unroll
-            for (int w = 0; w < 4; w++) sG[w][tid][8] = __uint_as_float(SG_UNSET);
-        }
-        __syncthreads();
         if (base < maxq) {
             uint16_t *list = sList[wave];
             const int lim = maxq - base < bc ? maxq - base : bc;          // entries >= maxq touch no pixel here
@@ -813,7 +826,7 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
         }
         __syncthreads();
         // ---- combine the quadrants in a fixed order and store the record (the thread that staged the entry)
-        if (tid >= b0 && tid < b0 + bc && rslot < cap) {
+        if (tid >= b0 && tid < b0 + bc) {
             const int q0 = tid - b0;
             float s9[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
@@ -821,13 +834,16 @@ sg_render_bwd_sparse_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks
                 if (__float_as_uint(sG[w][q0][8]) != SG_UNSET) {
 #pragma unroll
                     for (int q = 0; q < 9; q++) s9[q] += sG[w][q0][q];
+                    sG[w][q0][8] = __uint_as_float(SG_UNSET);
                 }
+            if (rslot < cap) {
             const float no = -opac, nh = 0.5f * no;
             const float m0 = fmaf(cA, s9[0], cB * s9[1]), m1 = fmaf(cB, s9[0], cC * s9[1]);
             grec_a[2 * (size_t)rslot] = make_float4(no * ddelx_dx * m0, no * ddely_dy * m1, nh * s9[2], nh * s9[3]);
             grec_a[2 * (size_t)rslot + 1] = make_float4(nh * s9[4], s9[5], s9[6], s9[7]);
             grec_b[rslot] = s9[8];
             rec_valid[rslot] = 1;                                  // (every other record of the frame is never read: sg_sum_records_coop)
+            }
         }
         __syncthreads();
     }
