@@ -130,8 +130,9 @@ def make_frame_parallel(ctx, nfloats):
     forced = os.environ.get("SINGS_DP_ALGO")
     if forced:
         return mk(forced), {"allreduce_algorithm_chosen_by": "SINGS_DP_ALGO"}
-    if world == 1:
+    if world == 1 and not FORCE_DIST:
         return mk("all_reduce"), {"allreduce_algorithm_chosen_by": "default (one rank)"}
+    # (a FORCED one-rank nccl group takes the measuring path too: it is the only way to execute it on a one-GPU box)
     scratch = torch.zeros(int(nfloats), dtype=torch.float32, device=dev)
     times = {}
     for algo in ("all_reduce", "rs_ag"):
