@@ -86,6 +86,31 @@ def _tp_early(dev):
     return True if _TP["mode"] else not torch.cuda.is_current_stream_capturing()
 
 
+# ---- capture order: the critical chain first ---------------------------------------------------------------------------------
+# ROCm 7.2's graph executor gives every kernel node a queue while it walks the captured graph (DEBUG_HIP_GRAPH_DOT_PRINT=1 prints
+# the assignment): the FIRST-captured dependent of a node stays on its queue, the k-th one goes to queue (q + k) mod 4 behind a
+# signal; lists that share a queue run in list order, not in time order.  A side stream forked BEFORE the next kernel of the main
+# chain is captured therefore KEEPS the main chain's queue and sends the main chain to another one: in the round-4 step each of the
+# ten input-gradient kernels of the decoders' backward sat on a different queue than its predecessor (a signal hop each) and two of
+# them behind a weight-gradient kernel of the side stream that happened to share their queue.  The weight-gradient launches are
+# therefore DEFERRED by one kernel of the main chain: kept as a closure whose wait is an event recorded at the fork point (nothing
+# starts later on the GPU) and issued right after the next input-gradient kernel (2.18 -> 2.06 ms per step, profiles/r05_graph_queues.log).
+_DEFER = []
+
+
+def _defer_side(fn):
+    _DEFER.append(fn)
+
+
+def _flush_deferred():
+    try:
+        while _DEFER:
+            _DEFER.pop(0)()
+    except BaseException:
+        del _DEFER[:]
+        raise
+
+
 # ---- gradient arena ----------------------------------------------------------------------------------------------------------
 # Frame-parallel training reduces the parameter gradients with ONE collective over ONE flat buffer.  Instead of
 # gathering the .grad tensors into that buffer and scattering them back every step (two extra passes over 35 MB), the kernels that
@@ -171,6 +196,9 @@ class _Triplane(torch.autograd.Function):
             if side is None:
                 side = _TP["streams"][dev.index] = torch.cuda.Stream(dev)
             cur = torch.cuda.current_stream(dev)
+            # (NOT deferred like the weight gradients below: issued first, this chain keeps the forward's queue and the decoders move
+            #  to the next one -- one hop; issued after the first decoder layer it shares a queue with the regularisers and the weight
+            #  gradients and was executed after them, 2.14 instead of 2.06 ms per step)
             side.wait_stream(cur)
             with torch.cuda.device(dev), torch.cuda.stream(side):
                 _lib.check(lib.sg_triplane_backward_prepare(C.byref(tp), N, _ptr(x), _ptr(bws), C.c_void_p(side.cuda_stream)),
@@ -209,6 +237,7 @@ class _Triplane(torch.autograd.Function):
             else:
                 fn = lib.sg_triplane_backward
             _lib.check(fn(C.byref(tp), N, _ptr(x), _ptr(ws), _ptr(df), C.byref(arr), _ptr(dxyz), _stream(dev)), "triplane backward")
+        _flush_deferred()                                        # (the first layers' weight gradients: behind this kernel)
         return (dxyz, None, None) + tuple(dplanes)
 
 
@@ -292,6 +321,7 @@ def overlap_weight_grads(flag=True):
 
 def _wg_join():
     _WG["armed"] = False
+    _flush_deferred()
     for dev_index, side in _WG["streams"].items():
         torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(side)
 
@@ -335,13 +365,23 @@ def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
             ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
             if _WG["on"]:
                 side, cur = _wg_stream(dev), torch.cuda.current_stream(dev)
-                side.wait_stream(cur)                                # dz (and x) are complete on the backward stream
-                with torch.cuda.stream(side):
-                    _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db),
-                                                  C.c_void_p(side.cuda_stream)), "weight gradient")
-                for t in (dz, x, ws2, dW, db):
-                    if t is not None:
+                fork = torch.cuda.Event()
+                fork.record(cur)                                     # dz (and x) are complete on the backward stream
+                _flush_deferred()                                    # the previous layer's: this layer's dx kernel has been issued
+
+                # (the closure must not hold dW / db: AccumulateGrad adopts a returned gradient without a copy only while nobody else
+                #  references it -- and a copy made BEFORE the deferred kernel has written it would be a copy of nothing.  p.grad
+                #  keeps them alive until the streams have joined: _wg_join)
+                p_dW, p_db = _ptr(dW), _ptr(db)
+
+                def launch(dz=dz, x=x, ws2=ws2):
+                    side.wait_event(fork)
+                    with torch.cuda.device(dev), torch.cuda.stream(side):
+                        _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), p_dW, p_db,
+                                                      C.c_void_p(side.cuda_stream)), "weight gradient")
+                    for t in (dz, x, ws2):
                         t.record_stream(side)
+                _defer_side(launch)
             else:
                 _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
                            "weight gradient")
@@ -522,11 +562,12 @@ def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_fac
     # both decoders' first layers read the tri-plane features: one fan, one feature gradient
     g1, a1 = linear_fan(tri_feats, [(geometry_dec.net[0], ACT_GELU, None), (appearance_dec.net[0], ACT_GELU, None)])
     g = geometry_dec(tri_feats, first=g1)
-    a = appearance_dec(tri_feats, first=a1)
     scales = g['scales']
     if thickness_factor != 1.0:
         scales = torch.cat([scales[:, :-1], scales[:, -1:] * thickness_factor], dim=1)
     if scaling_multiplier is not None:
         scales = scales * scaling_multiplier
-    return {"xyz_canon": xyz + g['xyz_offsets'], "xyz_offsets": g['xyz_offsets'], "rot6d_canon": g['rotations'],
+    xyz_canon = xyz + g['xyz_offsets']
+    a = appearance_dec(tri_feats, first=a1)
+    return {"xyz_canon": xyz_canon, "xyz_offsets": g['xyz_offsets'], "rot6d_canon": g['rotations'],
             "scales_aux": g['scales_aux'], "scales": scales, "opacity": a['opacity'], "shs": a['shs']}

@@ -13,12 +13,13 @@ attributes only, not on the render: with ``overlap_regularisers`` (default) they
 LBS + raster + photometric-loss chain, also inside a captured HIP graph.  WHERE they run decides what they cost
 (profiles/r03_train_step_trace.log): the k-NN query keeps 9 waves per SIMD resident on every CU for 0.23 ms, and beside it the
 raster forward's latency-bound chain took 2-7x as long per kernel (the long-list sort needs a nearly empty CU per workgroup:
-146 us instead of 21).  With ``defer_regulariser_join`` (round 3) the side stream builds the k-NN grids right after the decode
-(small kernels), holds the QUERY until the raster forward has finished, and is NOT joined before the loss: ``forward`` returns
-the photometric and the regulariser loss as two roots (``extras["loss_roots"]``), ``AvatarStep.backward`` hands both to one
-``torch.autograd.backward`` -- autograd runs every node on the stream its forward ran on and synchronises where the two
-gradient paths meet, at the decoders' heads -- and sums the reported loss afterwards.  The query then overlaps the photometric
-loss and the backward composite (0.23 ms of half-busy vector ALUs).
+146 us instead of 21).  With ``defer_regulariser_join`` the query is held until the raster forward has finished and is NOT
+joined before the loss: ``forward`` returns the photometric and the regulariser loss as two roots (``extras["loss_roots"]``) and
+``AvatarStep.backward`` STAGES the backward pass by hand (round 5): the render and the regularisers read detached views of the
+decoded attributes, so the photometric gradients (loss, composite, LBS: this stream) and the regularisers' (side stream) are two
+``torch.autograd.grad`` calls, one ``_foreach_add_`` joins them, and the decoders' backward starts from the sums -- the order of
+the launches is then the order the graph executor needs to keep the critical chain on ONE queue (sings_amd/decode.py "capture
+order"; 2.18 -> 2.00 ms per step with the deferred weight gradients, profiles/r05_graph_queues.log).
 """
 import torch
 
@@ -122,70 +123,60 @@ class AvatarStep(torch.nn.Module):
         the ONE side stream this module owns (``GaussiansEdgeLoss.finish`` refuses any other stream while capturing)."""
         attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
                                   self.scaling_multiplier)
-        # anisotropic: the decoder's 6-D rotations go to the fused kernels as they are (rotation_6d_to_matrix of
-        # sings_hybrid.py:356-357 runs inside them); isotropic: None
-        rot = attrs["rot6d_canon"]
-        reg = {}
-
-        def regularisers():
-            if self.l2_norm is not None:
-                reg["l2"] = self.l2_norm({"xyz_offsets": attrs["xyz_offsets"], "scales": attrs["scales"],
-                                          "opacity": attrs["opacity"]})
-            if self.gaussian_connect is not None and self.gaussian_connect_w > 0:
-                reg["gaussian_connect_loss"] = self.gaussian_connect_w * self.gaussian_connect(
-                    {"xyz_canon": attrs["xyz_canon"], "scales": attrs["scales"]})
-
         has_reg = self.l2_norm is not None or (self.gaussian_connect is not None and self.gaussian_connect_w > 0)
         has_knn = self.gaussian_connect is not None and self.gaussian_connect_w > 0
-        side = None
         overlap = has_reg and self.overlap_regularisers and attrs["xyz_canon"].is_cuda
-        defer = overlap and self.defer_regulariser_join and torch.is_grad_enabled()
+        defer = (overlap and self.defer_regulariser_join and torch.is_grad_enabled() and has_knn
+                 and hasattr(self.gaussian_connect, "prepare"))
+        # Two roots (defer): the render and the regularisers read DETACHED views of the decoded attributes (`use`), so that the
+        # backward pass can be staged by hand (AvatarStep.backward): photometric gradients on this stream, the regularisers' on the
+        # side stream, one addition, then the decoders' backward -- in an order the graph executor turns into ONE queue for the
+        # critical chain (sings_amd/decode.py "capture order").  One root: `use` IS `attrs`, plain autograd.
+        use = attrs
+        if defer:
+            use = {k: (v.detach().requires_grad_(v.requires_grad) if torch.is_tensor(v) else v) for k, v in attrs.items()}
+        # anisotropic: the decoder's 6-D rotations go to the fused kernels as they are (rotation_6d_to_matrix of
+        # sings_hybrid.py:356-357 runs inside them); isotropic: None
+        rot = use["rot6d_canon"]
+        reg = {}
+
+        def l2():
+            if self.l2_norm is not None:
+                reg["l2"] = self.l2_norm({"xyz_offsets": use["xyz_offsets"], "scales": use["scales"], "opacity": use["opacity"]})
+
+        def regularisers():
+            l2()
+            if has_knn:
+                reg["gaussian_connect_loss"] = self.gaussian_connect_w * self.gaussian_connect(
+                    {"xyz_canon": use["xyz_canon"], "scales": use["scales"]})
+
+        side = None
         if overlap:
             dev = attrs["xyz_canon"].device
             if self._side is None or self._side.device != dev:
                 self._side = torch.cuda.Stream(dev)
             side, cur = self._side, torch.cuda.current_stream(dev)
-            side.wait_stream(cur)                                # fork: the decoded attributes are complete
-            with torch.cuda.stream(side):
-                if defer and has_knn and hasattr(self.gaussian_connect, "prepare"):
-                    # the grids and the autograd node now, the query behind the raster forward
-                    if self.l2_norm is not None:
-                        reg["l2"] = self.l2_norm({"xyz_offsets": attrs["xyz_offsets"], "scales": attrs["scales"],
-                                                  "opacity": attrs["opacity"]})
-                    edge = self.gaussian_connect.prepare({"xyz_canon": attrs["xyz_canon"], "scales": attrs["scales"]})
-                else:
-                    defer = False
+            if defer:
+                decoded = torch.cuda.Event()
+                decoded.record(cur)                              # fork point; the side stream's work is ISSUED after the photometric loss
+            else:
+                side.wait_stream(cur)                            # fork: the decoded attributes are complete
+                with torch.cuda.stream(side):
                     regularisers()
         frames = A_cano2pose.dim() == 4                          # [K,J,4,4]: a CHUNK of K frames of this step's Gaussians (round 4)
-        try:
-            if frames:
-                # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
-                # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
-                color, radii = rasterize_skinned_frames(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
-                                                        self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                        transl=transl)
-            else:
-                color, radii = rasterize_skinned_gaussians(attrs["xyz_canon"], rot, attrs["scales"], attrs["opacity"], attrs["shs"],
-                                                           self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                           transl=transl)
-        except BaseException:
-            # a raster forward that raises (pair-capacity overflow with on_overflow='raise', out of memory, bad input) sits between
-            # the edge loss's prepare() and finish(): drop the prepared query, or every later step would fail with "prepare() called
-            # twice" (ADVICE r4) -- the step that raised is lost, the module is not
-            if defer:
-                self.gaussian_connect.abort()
-            raise
+        if frames:
+            # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
+            # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
+            color, radii = rasterize_skinned_frames(use["xyz_canon"], rot, use["scales"], use["opacity"], use["shs"],
+                                                    self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                    transl=transl)
+        else:
+            color, radii = rasterize_skinned_gaussians(use["xyz_canon"], rot, use["scales"], use["opacity"], use["shs"],
+                                                       self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
+                                                       transl=transl)
         if defer:
-            side.wait_stream(cur)                                # the raster forward has the GPU to itself; then the query
-            with torch.cuda.stream(side):
-                try:
-                    self.gaussian_connect.finish()
-                except BaseException:
-                    self.gaussian_connect.abort()
-                    raise
-                reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
-                vals = [v.reshape(()) for v in reg.values()]
-                reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
+            rendered = torch.cuda.Event()
+            rendered.record(cur)
         if frames:
             per_frame, extras = photometric_loss_frames(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
             loss_dict = {k: v.sum() for k, v in per_frame.items()}          # the step's photometric terms: summed over its frames
@@ -196,8 +187,27 @@ class AvatarStep(torch.nn.Module):
             # two roots, no join: the regularisers' gradients are waited for where they are consumed (AvatarStep.backward)
             vals = [v.reshape(()) for v in loss_dict.values()]
             photo_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
+            # the regularisers, ISSUED last (the main chain keeps its queue in the graph executor, sings_amd/decode.py "capture
+            # order") but waiting only for what they read: L2Norm and the k-NN grids for the decode, the k-NN QUERY -- 9 waves per
+            # SIMD on every CU for 0.23 ms -- for the raster forward.  (Measured, profiles/r05_graph_queues.log: the executor starts
+            # a second queue's chain 60-160 us after its dependency is met, so part of the query is still exposed behind the
+            # backward composite; issued FIRST, as in round 4, the chain starts at once and the raster forward is what waits.)
+            side.wait_event(decoded)
+            with torch.cuda.stream(side):
+                l2()
+                edge = self.gaussian_connect.prepare({"xyz_canon": use["xyz_canon"], "scales": use["scales"]})
+                side.wait_event(rendered)
+                try:
+                    self.gaussian_connect.finish()
+                except BaseException:
+                    self.gaussian_connect.abort()
+                    raise
+                reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
+                vals = [v.reshape(()) for v in reg.values()]
+                reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
             loss_dict.update(reg)
             extras["loss_roots"] = (photo_root, reg_root)
+            extras["staged"] = (attrs, use)
             return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
         if side is not None:
             cur.wait_stream(side)                                # join before the loss terms meet
@@ -224,13 +234,35 @@ class AvatarStep(torch.nn.Module):
         """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and
         ``loss_dict["loss"]`` = their sum.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
         photo_root, reg_root = extras["loss_roots"]
+        attrs, use = extras["staged"]
         one = getattr(self, "_one", None)
         if one is None or one.device != photo_root.device:
             one = self._one = torch.ones((), dtype=photo_root.dtype, device=photo_root.device)     # (not a fill launch per root and step)
-        torch.autograd.backward([photo_root, reg_root], [one, one])
         dev = photo_root.device
-        cur = torch.cuda.current_stream(dev)
-        cur.wait_stream(self._side)
+        cur, side = torch.cuda.current_stream(dev), self._side
+        names = [k for k, v in use.items() if torch.is_tensor(v) and v.requires_grad]
+        leaves = [use[k] for k in names]
+        # 1. the photometric gradients of the decoded attributes: loss, composite, LBS -- on this stream, issued first
+        g = list(torch.autograd.grad([photo_root], leaves, [one], allow_unused=True))
+        # 2. the regularisers' on theirs (every node of that graph ran there)
+        with torch.cuda.stream(side):
+            g_reg = torch.autograd.grad([reg_root], leaves, [one], allow_unused=True)
+        # 3. join, ONE addition for all attributes that have both
+        cur.wait_stream(side)
+        both_a, both_b = [], []
+        for i, gr in enumerate(g_reg):
+            if gr is None:
+                continue
+            gr.record_stream(cur)
+            if g[i] is None:
+                g[i] = gr
+            else:
+                both_a.append(g[i]); both_b.append(gr)
+        if both_a:
+            torch._foreach_add_(both_a, both_b)
+        # 4. the decoders' backward
+        roots = [(attrs[k], g[i]) for i, k in enumerate(names) if g[i] is not None]
+        torch.autograd.backward([r for r, _ in roots], [x for _, x in roots])
         for v in list(loss_dict.values()) + [reg_root]:
             v.record_stream(cur)
         loss_dict["loss"] = photo_root.detach() + reg_root.detach()
