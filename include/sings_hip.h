@@ -471,6 +471,21 @@ int sg_linear_backward(int N, int Cin, int Cout, int act, const float *aux, cons
 int sg_linear_backward_accumulate(int N, int Cin, int Cout, int act, const float *aux, const float *row_offset, const float *dh,
                                   const float *W, float *dz_out, float *dx_out, void *stream);
 
+/* A FAN backward: a wide layer and up to two NARROW heads that read the same input (decoders.py:75-94: scales[0] 128 beside
+ * xyz_offsets 3 and rotations 6; :41-49: shs 48 beside opacity 1).  dx_out [N,Cin] = dz W + dz_0 W_0 + dz_1 W_1 in ONE pass: the heads'
+ * columns are extra columns of the wide layer's reduction instead of one read-modify-write pass over dx per head.  Cin a multiple
+ * of 32, Cout a multiple of 4, side[0].cout + side[1].cout <= 16 (cout = 0: unused); a head's act is 0 or 2 (sigmoid: aux = its
+ * forward output h, dz_out receives dh h (1 - h) for its sg_weight_grad; act = 0: dz is dh, dz_out ignored). */
+typedef struct SgLinearSide {
+    int cout, act;
+    const float *aux;                /* [N,cout] | NULL */
+    const float *dh;                 /* [N,cout] */
+    const float *W;                  /* [cout,Cin] */
+    float *dz_out;                   /* [N,cout] | NULL */
+} SgLinearSide;
+int sg_linear_backward_fan(int N, int Cin, int Cout, int act, const float *aux, const float *dh, const float *W, float *dz_out,
+                           float *dx_out, const SgLinearSide side[2], void *stream);
+
 /* Weight / bias gradient of one decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz (db may be NULL);
  * dz [N,Cout], x [N,Cin]; Cin in {32, 64, 96, 128}, Cout <= 128.  fp32 on the matrix cores, deterministic.
  * `ws`: sg_weight_grad_ws_bytes(N, Cout, Cin). */

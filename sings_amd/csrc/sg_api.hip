@@ -646,6 +646,25 @@ extern "C" int sg_linear_backward(int N, int Cin, int Cout, int act, const float
 {
     return sg_linear_backward_impl("sg_linear_backward: bad argument", N, Cin, Cout, act, z, row_offset, dh, W, dz_out, dx_out, stream, 0);
 }
+// (declared here, not in sg_common.h: that header is one of the sources the committed PMC profiles are keyed on)
+int sg_launch_linear_bwd_fan(int N, int Cin, int Cout, int act, const float *z, const float *dh, const float *W, float *dz_out,
+                             float *dx_out, const SgLinearSide *side, hipStream_t st);
+extern "C" int sg_linear_backward_fan(int N, int Cin, int Cout, int act, const float *z, const float *dh, const float *W,
+                                      float *dz_out, float *dx_out, const SgLinearSide side[2], void *stream)
+{
+    if (N <= 0 || !dh || !W || !dx_out || !side || act < 0 || act > 3 || (act != 0 && !z))
+        return sg_fail("sg_linear_backward_fan: bad argument", hipSuccess);
+    for (int i = 0; i < 2; i++) {
+        const SgLinearSide &s = side[i];
+        if (s.cout < 0 || s.cout > 16 || (s.cout && (!s.dh || !s.W || (s.act != 0 && s.act != 2) || (s.act == 2 && !s.aux))))
+            return sg_fail("sg_linear_backward_fan: a head needs dh, W, act 0 | 2 (with aux)", hipSuccess);
+    }
+    if (side[0].cout + side[1].cout == 0) return sg_fail("sg_linear_backward_fan: no head (use sg_linear_backward)", hipSuccess);
+    if (sg_launch_linear_bwd_fan(N, Cin, Cout, act, z, dh, W, dz_out, dx_out, side, (hipStream_t)stream))
+        return sg_fail("sg_linear_backward_fan: Cin a multiple of 32 <= 128, Cout a multiple of 4 <= 128, heads <= 16 columns", hipSuccess);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_linear_backward_fan", e);
+}
 extern "C" int sg_linear_backward_accumulate(int N, int Cin, int Cout, int act, const float *z, const float *row_offset,
                                              const float *dh, const float *W, float *dz_out, float *dx_out, void *stream)
 {

@@ -260,15 +260,31 @@ template <int NQ> struct sgl_wide_cfg {
 };
 __host__ __device__ inline int sgl_wide_point_tiles(int TO, int ptcap) { const int pt = 4 / TO; return pt < ptcap ? pt : ptcap; }
 
-template <int NQ, bool BWD, bool GELU, bool VEC>
+// Backward of a FAN (several layers reading the same activation, decoders.py:41-49, 75-94): the narrow heads beside a wide layer
+// (xyz_offsets 3 + rotations 6 beside scales[0] 128; opacity 1 beside shs 48) used to ADD their dx in a pass of their own each --
+// read-modify-write of the whole [N,Cin] gradient for a K = 1..6 product, 17-50 us per head on the step's critical chain.  Here
+// their dz columns are 8 EXQ extra columns of the wide layer's reduction: X' = [dz_main | dz_side0 | dz_side1 | 0], M = [W_main; W_side0;
+// W_side1; 0]^T.  The extra columns of a tile (R rows x 8 EXQ) are fetched by element (two look-ahead sets like the rest, every load a
+// buffer load whose range check stands in for "not this source"), multiplied by sigmoid' where the head has one (opacity), stored
+// as that head's dz for its weight gradient, and written into the LDS tile behind the main columns.
+struct SgLinExtra {
+    const float *dh[2], *aux[2], *W[2];       // [N,c], [N,c] | NULL, [c,Cin]
+    float *dz[2];                             // [N,c] | NULL
+    int c[2], act[2];                         // columns (0: unused), 0 | 2 (sigmoid: aux = the forward's output)
+};
+
+template <int NQ, bool BWD, bool GELU, bool VEC, int EXQ = 0>
 __global__ void __launch_bounds__(256, (BWD || NQ == 12) ? 2 : 3)   // two register sets of look-ahead next to the weight registers: backward (x' and aux) and
                                                                     // the 96-input forward (64-point tiles) run two waves per SIMD, no spills
 sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ X, const float *__restrict__ Z,
                       const float *__restrict__ Mw, int m_co_stride, int m_ck_stride, const float *__restrict__ bias,
-                      float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out, int accum)
+                      float *__restrict__ out0, float *__restrict__ out1, float *__restrict__ dz_out, int accum, SgLinExtra ex)
 {
-    using cfg = sgl_wide_cfg<NQ>;
+    static_assert(EXQ == 0 || BWD, "extra reduction columns: backward only");
+    using cfg = sgl_wide_cfg<NQ + EXQ>;
     constexpr int CKP = cfg::CKP, HALF = CKP / 2, XS = cfg::XS, PER = cfg::PER;
+    constexpr int NQT = NQ + EXQ, CKM = NQ * 8, EXC = EXQ * 8;             // float4 steps of the whole reduction; main columns (padded), extra columns
+    constexpr int EPT = EXQ ? (32 * cfg::PTCAP * EXC + 255) / 256 : 1;     // extra elements per thread and tile
     extern __shared__ float sXd[];                                         // [2][R][XS]
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int TO = CO >> 5;                                                // 1..4
@@ -293,7 +309,13 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
 #pragma unroll
         for (int s = 0; s < HALF; s++) {
             const int k = h * HALF + s;
-            a[s] = (active && k < CK) ? Mw[(size_t)oc * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+            float w = (active && k < CK) ? Mw[(size_t)oc * m_co_stride + (size_t)k * m_ck_stride] : 0.0f;
+            if (EXQ && k >= CKM && active) {                               // a head's row of W [c, Cin]: reduction index k - CKM
+                const int e = k - CKM;
+                if (e < ex.c[0]) w = ex.W[0][(size_t)e * CO + oc];
+                else if (e < ex.c[0] + ex.c[1]) w = ex.W[1][(size_t)(e - ex.c[0]) * CO + oc];
+            }
+            a[s] = w;
         }
     }
     const float bv = (!BWD && bias && active) ? bias[oc] : 0.0f;
@@ -322,7 +344,23 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     for (int q = 0; q < PER; q++) {
         const int f = tid + 256 * q, row = f / f4_per_row, c = 4 * (f - row * f4_per_row);
         xoff[q] = (f < nf4 && c < CK) ? (row * CK + c) * 4 : 0x7ffffff0;
-        lofs[q] = f < nf4 ? row * XS + c : -1;
+        lofs[q] = (f < nf4 && (!EXQ || c < CKM)) ? row * XS + c : -1;      // (the extra columns are written by their own path)
+    }
+    // extra columns: element e of the tile's [R][EXC] block -> row e / EXC, column e % EXC -> source 0 | source 1 | nothing
+    const __amdgpu_buffer_rsrc_t re0 = __builtin_amdgcn_make_buffer_rsrc((void *)ex.dh[0], 0, EXQ && ex.c[0] ? (unsigned)N * ex.c[0] * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t re1 = __builtin_amdgcn_make_buffer_rsrc((void *)ex.dh[1], 0, EXQ && ex.c[1] ? (unsigned)N * ex.c[1] * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra0 = __builtin_amdgcn_make_buffer_rsrc((void *)ex.aux[0], 0, EXQ && ex.act[0] && ex.aux[0] ? (unsigned)N * ex.c[0] * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ra1 = __builtin_amdgcn_make_buffer_rsrc((void *)ex.aux[1], 0, EXQ && ex.act[1] && ex.aux[1] ? (unsigned)N * ex.c[1] * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd0 = __builtin_amdgcn_make_buffer_rsrc(ex.dz[0], 0, EXQ && ex.act[0] && ex.dz[0] ? (unsigned)N * ex.c[0] * 4u : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd1 = __builtin_amdgcn_make_buffer_rsrc(ex.dz[1], 0, EXQ && ex.act[1] && ex.dz[1] ? (unsigned)N * ex.c[1] * 4u : 0u, 0x00020000);
+    int eo0[EPT], eo1[EPT], elds[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; i++) {
+        const int e = tid + 256 * i, row = EXQ ? e / (EXC ? EXC : 1) : 0, col = EXQ ? e - row * EXC : 0;
+        const bool in = EXQ && row < R;
+        eo0[i] = (in && col < ex.c[0]) ? (row * ex.c[0] + col) * 4 : 0x7ffffff0;
+        eo1[i] = (in && col >= ex.c[0] && col < ex.c[0] + ex.c[1]) ? (row * ex.c[1] + col - ex.c[0]) * 4 : 0x7ffffff0;
+        elds[i] = in ? row * XS + CKM + col : -1;
     }
     constexpr bool vec = VEC;                                              // CK a multiple of 4 (compile time: no branch around a load)
     auto ld4 = [&](const __amdgpu_buffer_rsrc_t &rs, int off) {
@@ -341,6 +379,32 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
         return v;
     };
     float4 xrE[PER], xrO[PER], zrE[BWD ? PER : 1], zrO[BWD ? PER : 1];
+    struct ExRegs { float d0[EPT], d1[EPT], g0[EPT], g1[EPT]; } exE, exO;
+    auto ldx = [&](const __amdgpu_buffer_rsrc_t &rs, int o, int base) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o == 0x7ffffff0 ? 0x7ffffff0 : o + base, 0, 0));
+    };
+    auto fetch_ex = [&](ExRegs &er, int n0) {
+        if (!EXQ) return;
+        const int b0 = n0 * ex.c[0] * 4, b1 = n0 * ex.c[1] * 4;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            er.d0[i] = ldx(re0, eo0[i], b0); er.d1[i] = ldx(re1, eo1[i], b1);
+            er.g0[i] = ldx(ra0, eo0[i], b0); er.g1[i] = ldx(ra1, eo1[i], b1);      // (no activation: zero-sized buffer, the load returns 0)
+        }
+    };
+    auto stash_ex = [&](const ExRegs &er, int buf, int n0) {
+        if (!EXQ) return;
+        const int b0 = n0 * ex.c[0] * 4, b1 = n0 * ex.c[1] * 4;
+#pragma unroll
+        for (int i = 0; i < EPT; i++) {
+            // sigmoid' = h (1 - h) where the head has an activation; no branch around the stores (a head without one: zero-sized dz buffer)
+            const float v0 = er.d0[i] * (ex.act[0] ? er.g0[i] * (1.0f - er.g0[i]) : 1.0f);
+            const float v1 = er.d1[i] * (ex.act[1] ? er.g1[i] * (1.0f - er.g1[i]) : 1.0f);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v0), rd0, eo0[i] == 0x7ffffff0 ? 0x7ffffff0 : eo0[i] + b0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v1), rd1, eo1[i] == 0x7ffffff0 ? 0x7ffffff0 : eo1[i] + b1, 0, 0);
+            if (elds[i] >= 0) sXd[buf * TS + elds[i]] = v0 + v1;           // (one of them is the 0 of an out-of-range load; padding: both)
+        }
+    };
     auto fetch = [&](float4 (&xr)[PER], float4 (&zr)[BWD ? PER : 1], int n0) {
         const int t0 = n0 * CK4;                                           // (n0 <= N + 2 grid tiles: the launch keeps this below 2^31)
 #pragma unroll
@@ -394,13 +458,13 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
         const float *xrow = &sXd[buf * TS + (32 * pt + j) * XS + h * HALF];  // A operand: X'[point j][h HALF + s], inputs permuted
         float4 b = *(const float4 *)xrow;
 #pragma unroll
-        for (int q = 0; q < NQ; q++) {
+        for (int q = 0; q < NQT; q++) {
             float4 bn = b;
-            if (q + 1 < NQ) bn = *(const float4 *)(xrow + 4 * (q + 1));
+            if (q + 1 < NQT) bn = *(const float4 *)(xrow + 4 * (q + 1));
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.x, a[4 * q], acc, 0, 0, 0);
             if (decltype(EPI)::value) {
 #pragma unroll
-                for (int r = (q * 16) / NQ; r < ((q + 1) * 16) / NQ; r++) emit(accp, r, n0p);
+                for (int r = (q * 16) / NQT; r < ((q + 1) * 16) / NQT; r++) emit(accp, r, n0p);
             }
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.y, a[4 * q + 1], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b.z, a[4 * q + 2], acc, 0, 0, 0);
@@ -411,9 +475,9 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     };
     const int ntiles = (N + R - 1) / R, G = gridDim.x;
     int tile = blockIdx.x;                                                 // grid <= ntiles
-    fetch(xrE, zrE, tile * R);
-    fetch(xrO, zrO, (tile + G) * R);                                       // (beyond the last tile: out of range, zeros)
-    stash(xrE, zrE, 0, tile * R);
+    fetch(xrE, zrE, tile * R); fetch_ex(exE, tile * R);
+    fetch(xrO, zrO, (tile + G) * R); fetch_ex(exO, (tile + G) * R);        // (beyond the last tile: out of range, zeros)
+    stash(xrE, zrE, 0, tile * R); stash_ex(exE, 0, tile * R);
     __syncthreads();
     // Everything issued so far (the weights!) has landed: said HERE, once, or the compiler -- merging the loop entry with the back
     // edge -- keeps a conservative wait in front of the first MFMA of every tile.
@@ -423,9 +487,9 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     for (int r = 0; r < 16; r++) accp[r] = 0.0f;
     int n0p = N;                                                           // no finished tile yet
     // one tile: the loads of tile + 2 G go out, the tile in LDS buffer `buf` is multiplied, tile + G moves from registers to LDS
-    auto round = [&](float4 (&xa)[PER], float4 (&za)[BWD ? PER : 1], const float4 (&xb)[PER], const float4 (&zb)[BWD ? PER : 1],
-                     int t, int buf) {
-        fetch(xa, za, (t + 2 * G) * R);
+    auto round = [&](float4 (&xa)[PER], float4 (&za)[BWD ? PER : 1], ExRegs &ea, const float4 (&xb)[PER], const float4 (&zb)[BWD ? PER : 1],
+                     const ExRegs &eb, int t, int buf) {
+        fetch(xa, za, (t + 2 * G) * R); fetch_ex(ea, (t + 2 * G) * R);
         if (BWD) {
             // no element-wise work to hide: dx leaves as soon as the tile's MFMAs are done (the stores are asynchronous);
             // accumulate (a layer input with several consumers, dx += dz W): the old values are requested before the MFMAs
@@ -440,7 +504,7 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
 #pragma unroll
                 for (int r = 0; r < 16; r++) emit(acc, r, t * R);
             }
-            stash(xb, zb, buf ^ 1, (t + G) * R);
+            stash(xb, zb, buf ^ 1, (t + G) * R); stash_ex(eb, buf ^ 1, (t + G) * R);
             __syncthreads();
         } else {
             // (the first tile runs the same block with n0p = N: its "previous tile" stores fall outside the arrays and are dropped --
@@ -454,9 +518,9 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
         }
     };
     for (; tile < ntiles; tile += 2 * G) {
-        round(xrE, zrE, xrO, zrO, tile, 0);
+        round(xrE, zrE, exE, xrO, zrO, exO, tile, 0);
         if (tile + G >= ntiles) break;                                     // (a break, not an `if` around the second half: the back edge keeps its counts)
-        round(xrO, zrO, xrE, zrE, tile + G, 1);
+        round(xrO, zrO, exO, xrE, zrE, exE, tile + G, 1);
     }
     if (!BWD && active) {
 #pragma unroll
@@ -466,11 +530,37 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
 
 template <bool BWD>
 static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, const float *Z, const float *Mw, int s_co, int s_ck,
-                            const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st, int accum = 0)
+                            const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st, int accum = 0,
+                            const SgLinExtra *exp = nullptr)
 {
     if (N <= 0) return 0;
     if (CK < 1 || CK > SGL_MAXC || CO < 1 || CO > SGL_MAXC) return 1;
     const int nq = (CK + 7) / 8;
+    SgLinExtra ex = {};
+    if (exp) ex = *exp;
+    const int exc = ex.c[0] + ex.c[1];
+    if (exc) {
+        // the heads' columns ride in the wide backward kernel: (CK padded to 8) + 8 | 16 reduction columns
+        if (!BWD || (CO & 31) || exc > 16 || nq > 16 || (CK & 3) || ((long long)N + 2 * 512 * 128) * 144 * 4 >= 0x7fffffffLL) return 3;
+        const int exq = exc <= 8 ? 1 : 2;
+#define SGL_FAN_GO(NQv, EXQv)                                                                                                \
+        do {                                                                                                                \
+            using cfg = sgl_wide_cfg<NQv + EXQv>;                                                                           \
+            const int R = 32 * sgl_wide_point_tiles(CO >> 5, cfg::PTCAP), ntiles = (N + R - 1) / R;                         \
+            const int grid = ntiles < 512 ? ntiles : 512;                                                                   \
+            const size_t dyn = (size_t)2 * R * cfg::XS * sizeof(float);                                                     \
+            hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, true, false, true, EXQv>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
+                               Mw, s_co, s_ck, bias, out0, (float *)nullptr, out1, accum, ex);                              \
+        } while (0)
+#define SGL_FAN(NQv) do { if (exq == 1) SGL_FAN_GO(NQv, 1); else SGL_FAN_GO(NQv, 2); } while (0)
+        if (nq <= 6) SGL_FAN(6);
+        else if (nq <= 8) SGL_FAN(8);
+        else if (nq <= 12) SGL_FAN(12);
+        else SGL_FAN(16);
+#undef SGL_FAN
+#undef SGL_FAN_GO
+        return 0;
+    }
     // buffer descriptors and tile offsets are 32-bit byte quantities on BOTH sides: X / aux / dz rows are CK floats, outputs CO floats,
     // and the look-ahead fetches reach up to two rounds of tiles (2 x 512 workgroups x 128 rows) past N before the range check
     // drops them -- so the bound is on max(CK, CO); larger problems take the narrow kernel below (64-bit addressing)
@@ -481,10 +571,10 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
         do {                                                                                                                \
             if ((CK & 3) == 0)                                                                                              \
                 hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, B, G, true>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc);                                                  \
+                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc, ex);                                              \
             else                                                                                                            \
                 hipLaunchKernelGGL((sg_linear_wide_kernel<NQv, B, G, false>), dim3(grid), dim3(256), dyn, st, N, CK, CO, act, X, Z, \
-                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc);                                                  \
+                                   Mw, s_co, s_ck, bias, o0, o1, dz, acc, ex);                                              \
         } while (0)
 #define SGL_WIDE(NQv)                                                                                                      \
         do {                                                                                                                \
@@ -540,4 +630,15 @@ int sg_launch_linear_bwd(int N, int Cin, int Cout, int act, const float *z, cons
 {
     // Y = dx [N, CO = Cin], X' = dz [N, CK = Cout], M(co = input column, ck = output column) = W[ck][co]
     return sg_linear_launch<true>(N, Cout, Cin, act, dh, z, W, 1, Cin, nullptr, row_offset, dx_out, dz_out, st, accumulate);
+}
+// the same with up to two narrow heads' products added in the same pass (SgLinearSide of include/sings_hip.h)
+int sg_launch_linear_bwd_fan(int N, int Cin, int Cout, int act, const float *z, const float *dh, const float *W, float *dz_out,
+                             float *dx_out, const SgLinearSide *side, hipStream_t st)
+{
+    SgLinExtra ex = {};
+    for (int i = 0; i < 2; i++) {
+        ex.c[i] = side[i].cout; ex.act[i] = side[i].act; ex.dh[i] = side[i].dh; ex.aux[i] = side[i].aux; ex.W[i] = side[i].W;
+        ex.dz[i] = side[i].dz_out;
+    }
+    return sg_linear_launch<true>(N, Cout, Cin, act, dh, z, W, 1, Cin, nullptr, nullptr, dx_out, dz_out, st, 0, &ex);
 }

@@ -359,33 +359,44 @@ def _lin_bwd(x, W, aux, act, has_b, dh, need_dx, need_dw, dx_into=None):
             torch.mul(dh, torch.sigmoid(aux), out=dz)
         dW = db = None
         if need_dw:
-            # dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad)
-            dW = _arena_out(W)
-            db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
-            ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
-            if _WG["on"]:
-                side, cur = _wg_stream(dev), torch.cuda.current_stream(dev)
-                fork = torch.cuda.Event()
-                fork.record(cur)                                     # dz (and x) are complete on the backward stream
-                _flush_deferred()                                    # the previous layer's: this layer's dx kernel has been issued
-
-                # (the closure must not hold dW / db: AccumulateGrad adopts a returned gradient without a copy only while nobody else
-                #  references it -- and a copy made BEFORE the deferred kernel has written it would be a copy of nothing.  p.grad
-                #  keeps them alive until the streams have joined: _wg_join)
-                p_dW, p_db = _ptr(dW), _ptr(db)
-
-                def launch(dz=dz, x=x, ws2=ws2):
-                    side.wait_event(fork)
-                    with torch.cuda.device(dev), torch.cuda.stream(side):
-                        _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), p_dW, p_db,
-                                                      C.c_void_p(side.cuda_stream)), "weight gradient")
-                    for t in (dz, x, ws2):
-                        t.record_stream(side)
-                _defer_side(launch)
-            else:
-                _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
-                           "weight gradient")
+            dW, db = _weight_grad(x, W, dz, has_b)
     return dx, dW, db
+
+
+def _weight_grad(x, W, dz, has_b, flush=True):
+    """dW = dz^T x and db = column sums of dz in one pass on the matrix cores (sg_weight_grad); on the side stream, one kernel of the
+    main chain late, when ``overlap_weight_grads`` is on.  Call it right AFTER the kernel that produced dz has been issued
+    (``flush=False``: a further layer of the same kernel -- the launches deferred so far stay deferred)."""
+    lib = _lib.load()
+    dev, N, Cout, Cin = x.device, int(x.shape[0]), int(W.shape[0]), int(W.shape[1])
+    with torch.cuda.device(dev):
+        dW = _arena_out(W)
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
+        ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
+        if _WG["on"]:
+            side, cur = _wg_stream(dev), torch.cuda.current_stream(dev)
+            fork = torch.cuda.Event()
+            fork.record(cur)                                     # dz (and x) are complete on the backward stream
+            if flush:
+                _flush_deferred()                                # the previous layer's: this layer's dx kernel has been issued
+
+            # (the closure must not hold dW / db: AccumulateGrad adopts a returned gradient without a copy only while nobody else
+            #  references it -- and a copy made BEFORE the deferred kernel has written it would be a copy of nothing.  p.grad
+            #  keeps them alive until the streams have joined: _wg_join)
+            p_dW, p_db = _ptr(dW), _ptr(db)
+
+            def launch(dz=dz, x=x, ws2=ws2):
+                side.wait_event(fork)
+                with torch.cuda.device(dev), torch.cuda.stream(side):
+                    _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), p_dW, p_db,
+                                                  C.c_void_p(side.cuda_stream)), "weight gradient")
+                for t in (dz, x, ws2):
+                    t.record_stream(side)
+            _defer_side(launch)
+        else:
+            _lib.check(lib.sg_weight_grad(N, Cout, Cin, _ptr(dz), _ptr(x), _ptr(ws2), _ptr(dW), _ptr(db), _stream(dev)),
+                       "weight gradient")
+    return dW, db
 
 
 class _LinearAct(torch.autograd.Function):
@@ -432,10 +443,25 @@ class _LinearFan(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    def _fan_plan(ctx, dhs, x):
+        """Layer 0 wide and every other layer a narrow head (<= 16 columns together, at most two, act none | sigmoid): their input
+        gradients in ONE kernel (sg_linear_backward_fan).  None: the per-layer path."""
+        n = len(ctx.acts)
+        if not (2 <= n <= 3) or any(d is None for d in dhs) or (int(x.shape[1]) & 31):
+            return None
+        couts = [int(ctx.saved_tensors[1 + 2 * i].shape[0]) for i in range(n)]
+        if couts[0] & 3 or sum(couts[1:]) > 16 or any(a not in (ACT_NONE, ACT_SIGMOID) for a in ctx.acts[1:]):
+            return None
+        return couts
+
+    @staticmethod
     def backward(ctx, *dhs):
         x = ctx.saved_tensors[0]
         need_dx = ctx.needs_input_grad[0]
         can_acc = (int(x.shape[1]) & 31) == 0
+        couts = _LinearFan._fan_plan(ctx, dhs, x) if (need_dx and _FAN["on"]) else None
+        if couts is not None:
+            return _LinearFan._backward_fused(ctx, dhs, x, couts)
         dx, grads = None, []
         for i, act in enumerate(ctx.acts):
             W, aux = ctx.saved_tensors[1 + 2 * i], ctx.saved_tensors[2 + 2 * i]
@@ -449,6 +475,43 @@ class _LinearFan(torch.autograd.Function):
                 dx = dxi if (dx is None or can_acc) else dx + dxi
             grads += [dW, db]
         return (dx, None, None, *grads)
+
+
+    @staticmethod
+    def _backward_fused(ctx, dhs, x, couts):
+        lib = _lib.load()
+        dev, N, Cin = x.device, int(x.shape[0]), int(x.shape[1])
+        n = len(couts)
+        W = [ctx.saved_tensors[1 + 2 * i] for i in range(n)]
+        aux = [ctx.saved_tensors[2 + 2 * i] for i in range(n)]
+        dh = [d.contiguous().float() for d in dhs]
+        dz = [torch.empty_like(dh[i]) if ctx.acts[i] != ACT_NONE else dh[i] for i in range(n)]
+        dx = torch.empty((N, Cin), dtype=torch.float32, device=dev)
+        side = (_lib.SgLinearSide * 2)()
+        for j in range(1, n):
+            sd = side[j - 1]
+            sd.cout, sd.act = couts[j], ctx.acts[j]
+            sd.aux = aux[j].data_ptr() if ctx.acts[j] != ACT_NONE else None
+            sd.dh, sd.W = dh[j].data_ptr(), W[j].data_ptr()
+            sd.dz_out = dz[j].data_ptr() if ctx.acts[j] != ACT_NONE else None
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_linear_backward_fan(N, Cin, couts[0], ctx.acts[0], _ptr(aux[0]) if ctx.acts[0] != ACT_NONE else None,
+                                                  _ptr(dh[0]), _ptr(W[0]), _ptr(dz[0]) if ctx.acts[0] != ACT_NONE else None, _ptr(dx),
+                                                  side, _stream(dev)), "linear backward (fan)")
+        grads = []
+        for i in range(n):
+            need_dw = ctx.needs_input_grad[3 + 2 * i] or (ctx.has_b[i] and ctx.needs_input_grad[4 + 2 * i])
+            dW, db = _weight_grad(x, W[i], dz[i], ctx.has_b[i], flush=not grads) if need_dw else (None, None)
+            grads += [dW, db]
+        return (dx, None, None, *grads)
+
+
+_FAN = {"on": True}
+
+
+def fuse_fan_backward(flag=True):
+    """The narrow heads' input gradients inside the wide layer's kernel (default on; off: one accumulate pass per head)."""
+    _FAN["on"] = bool(flag)
 
 
 def linear_fan(x, layers):

@@ -275,6 +275,59 @@ def test_linear_fan_accumulates_input_gradient_like_separate_layers(N, Cin):
         _close(g.cpu().numpy(), r.numpy(), rtol=5e-5, atol_scale=5e-6, what="fan gradient")
 
 
+@pytest.mark.parametrize("N,Cin,couts,acts", [
+    (150000, 128, (128, 3, 6), ("gelu", "none", "none")),      # GeometryDecoder's heads (decoders.py:75-94)
+    (150000, 64, (48, 1), ("none", "sigmoid")),                # AppearanceDecoder's (decoders.py:41-49)
+    (4099, 128, (128, 3), ("gelu", "none")),                   # isotropic: no rotations head; ragged N
+    (777, 96, (64, 8, 8), ("gelu", "sigmoid", "none")),        # 16 extra columns, a sigmoid head first
+    (33, 32, (20, 1), ("none", "none")),                       # fewer rows than a tile, Cout not a multiple of 8
+])
+def test_fan_backward_heads_ride_in_the_wide_kernel(N, Cin, couts, acts):
+    """sg_linear_backward_fan: the narrow heads' dz columns as extra columns of the wide layer's reduction.  Against fp64 autograd
+    (values), and against the per-layer path (`fuse_fan_backward(False)`: one accumulate pass per head) at fp32 round-off."""
+    from sings_amd import decode
+    from sings_amd.decode import ACT_GELU, ACT_NONE, ACT_SIGMOID, linear_fan
+    code = {"gelu": ACT_GELU, "none": ACT_NONE, "sigmoid": ACT_SIGMOID}
+    dev = _dev()
+    torch.manual_seed(N + Cin + len(couts))
+    lins = [torch.nn.Linear(Cin, c) for c in couts]
+    A = [code[a] for a in acts]
+    off = torch.rand(N, 1) * 0.3                                 # (the opacity offset: a row offset exists for 1-column sigmoid heads)
+    with_off = [a == ACT_SIGMOID and c == 1 for a, c in zip(A, couts)]
+    x = torch.randn(N, Cin)
+    ups = [torch.randn(N, c) for c in couts]
+    xr = x.double().requires_grad_(True)
+    loss = 0.0
+    for l, a, u, wo in zip(lins, A, ups, with_off):
+        z = xr @ l.weight.double().T + l.bias.double()
+        h = torch.nn.functional.gelu(z) if a == ACT_GELU else (torch.sigmoid(z + (off.double() if wo else 0.0)) if a == ACT_SIGMOID else z)
+        loss = loss + (h * u.double()).sum()
+    params = [p for l in lins for p in (l.weight, l.bias)]
+    ref_g = torch.autograd.grad(loss, [xr] + params)
+    glins = [torch.nn.Linear(Cin, c).to(dev) for c in couts]
+    for gl, l in zip(glins, lins):
+        gl.load_state_dict(l.state_dict())
+
+    def run():
+        xg = x.to(dev).requires_grad_(True)
+        outs = linear_fan(xg, [(gl, a, off.to(dev) if wo else None) for gl, a, wo in zip(glins, A, with_off)])
+        lossg = sum((o * u.to(dev)).sum() for o, u in zip(outs, ups))
+        return torch.autograd.grad(lossg, [xg] + [p for gl in glins for p in (gl.weight, gl.bias)])
+
+    fused = run()
+    decode.fuse_fan_backward(False)
+    try:
+        plain = run()
+    finally:
+        decode.fuse_fan_backward(True)
+    for g, r in zip(fused, ref_g):
+        _close(g.cpu().numpy(), r.numpy(), rtol=5e-5, atol_scale=5e-6, what="fan gradient (fused)")
+    for g, q in zip(fused, plain):
+        _close(g.cpu().numpy(), q.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="fused vs per-layer")
+    for g, q in zip(fused[1:], plain[1:]):                      # weight / bias gradients: the same kernels on the same dz
+        assert torch.equal(g, q) or float((g - q).abs().max()) <= 1e-6 * float(q.abs().max())
+
+
 def test_weight_gradients_on_a_side_stream_match_the_inline_ones():
     """decode.overlap_weight_grads(True): sg_weight_grad runs beside the backward chain and joins when backward() returns --
     bit-identical parameter gradients (the kernels are deterministic), also when the pass runs twice in a row."""
