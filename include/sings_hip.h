@@ -391,6 +391,15 @@ size_t sg_reg_ws_bytes(int rows);
 int sg_region_laplacian(int V, int C, const float *x, const int *row_ptr, const int *col, const float *deg_inv,
                         const float *vscale, void *ws, float *g_ws, float *loss, const float *upstream,
                         float *dL_dx, void *stream);
+/* RegionLaplacianLoss_v2 with laplacian_type = "cotangent" (:150-165, :183-192): the regions overlap (every face that touches a
+ * vertex of the region), so the operator is a stack of R weighted rows -- one per (region, vertex of the region) -- over the global
+ * vertex array x [V,C]: CSR (row_ptr [R+1], col [nnz] = global vertex, val [nnz] = cot_laplacian's off-diagonal weight; no diagonal,
+ * as in the reference's product), rscale [R] = weight(region) / (rows of the region * C); the transposed CSR (t_row_ptr [V+1],
+ * t_row [nnz] = stacked row, t_val [nnz]) is needed for dL_dx only.  g_ws [R,C] scratch, ws: sg_reg_ws_bytes(R).
+ *   loss = sum_r rscale_r |sum_e val_e x[col_e]|^2 */
+int sg_rows_laplacian(int R, int V, int C, const float *x, const int *row_ptr, const int *col, const float *val,
+                      const float *rscale, const int *t_row_ptr, const int *t_row, const float *t_val, void *ws, float *g_ws,
+                      float *loss, const float *upstream, float *dL_dx, void *stream);
 /* pytorch3d.loss.mesh_edge_loss(mesh, target_length=0) (gs_trainer.py:366): (1/E) sum_e |v0 - v1|^2; CSR with both
  * directions of the E unique edges */
 int sg_mesh_edge_loss(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws, float *loss,

@@ -10,6 +10,12 @@
     mesh_edge_loss(mesh, target_length=0): mean over the mesh's unique edges of |v0 - v1|^2 (one mesh).
   The golden generator runs the REFERENCE classes on top of these restated primitives, so everything except the two
   primitives themselves is the reference's own arithmetic.
+* ``cot_laplacian`` (round 5) restates pytorch3d.ops.cot_laplacian (ops/laplacian_matrices.py of the 0.7 series; also absent
+  here: PARITY UNPINNED): per face, side lengths A, B, C opposite v0, v1, v2, Heron's area clamped at eps before the root,
+  cot(angle at v_k) = (sum of the other two squared sides - the opposite one) / (4 area); L[v1,v2] = cot a, L[v2,v0] = cot b,
+  L[v0,v1] = cot c, then L += L^T -- the off-diagonal weights only, NO diagonal; second result: 1 / (sum of the areas of the
+  faces around a vertex).  ``region_laplacian_cot_loss`` follows loss_items.py:150-165 (regions = faces with ANY vertex of the
+  label: the partitions overlap) and :183-192.  It is checked against hand-computed cotangents (tests/test_oracle_reg.py).
 Only tests/ may import this module.
 """
 import torch
@@ -88,3 +94,48 @@ def region_laplacian_hands(x, verts, edges, labels, hand_strength=1000):
 def mesh_edge_loss(verts, edges):
     v0, v1 = verts[edges[:, 0]], verts[edges[:, 1]]
     return ((v0 - v1).norm(dim=1, p=2) ** 2).sum() / edges.shape[0]
+
+
+def cot_laplacian(verts, faces, eps=1e-12):
+    """pytorch3d.ops.cot_laplacian as a DENSE [V,V] matrix (the reference multiplies its sparse result with x: the same numbers)."""
+    V = verts.shape[0]
+    fv = verts[faces]
+    v0, v1, v2 = fv[:, 0], fv[:, 1], fv[:, 2]
+    A = (v1 - v2).norm(dim=1); B = (v0 - v2).norm(dim=1); C = (v0 - v1).norm(dim=1)
+    s = 0.5 * (A + B + C)
+    area = (s * (s - A) * (s - B) * (s - C)).clamp(min=eps).sqrt()
+    A2, B2, C2 = A * A, B * B, C * C
+    cot = torch.stack([(B2 + C2 - A2) / area, (A2 + C2 - B2) / area, (A2 + B2 - C2) / area], dim=1) / 4.0
+    ii = faces[:, [1, 2, 0]].reshape(-1)
+    jj = faces[:, [2, 0, 1]].reshape(-1)
+    L = torch.zeros((V, V), dtype=verts.dtype)
+    L.index_put_((ii, jj), cot.reshape(-1), accumulate=True)
+    L = L + L.t()
+    inv_areas = torch.zeros(V, dtype=verts.dtype)
+    inv_areas.scatter_add_(0, faces.reshape(-1), torch.stack([area] * 3, dim=1).reshape(-1))
+    nz = inv_areas > 0
+    inv_areas[nz] = 1.0 / inv_areas[nz]
+    return L, inv_areas.view(-1, 1)
+
+
+def _region_parts_cot(verts, faces, labels):
+    parts = []
+    face_label = labels[faces]
+    for label in torch.unique(labels):
+        sel = faces[torch.any(face_label == label, dim=1)]
+        inc = torch.unique(sel)                                  # global ids of the region's vertices (sorted)
+        _, inv = torch.unique(sel, return_inverse=True)
+        L, _ = cot_laplacian(verts[inc], inv.reshape(sel.shape))
+        parts.append((int(label), inc, L))
+    return parts
+
+
+def region_laplacian_cot_loss(x, verts, faces, labels, weights, only=None, strength=None):
+    """forward (``only`` None: every label, weights[label]) / forward_hands (``only`` = (6, 7), ``strength``)."""
+    loss = 0.
+    for label, inc, L in _region_parts_cot(verts, faces, labels):
+        if only is not None and label not in only:
+            continue
+        w = strength if only is not None else weights[label]
+        loss = loss + w * torch.matmul(L, x[inc]).pow(2).mean()
+    return loss

@@ -58,7 +58,7 @@ EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_ras
            "sg_rasterize_backward_records", "sg_rasterize_backward_gaussians", "sg_skinned_backward_gaussians",
            "sg_mark_visible", "sg_read_num_rendered", "sg_signal_alloc", "sg_signal_free", "sg_profile_enable", "sg_profile_collect",
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
-           "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_mesh_edge_loss",
+           "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_rows_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare", "sg_gaussian_edge_finish", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
            "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_linear_backward_fan", "sg_copy_probe",
@@ -176,12 +176,13 @@ def load():
     lib.sg_reg_ws_bytes.argtypes = [i32]; lib.sg_reg_ws_bytes.restype = sz
     lib.sg_knn_ws_bytes.argtypes = [i32]; lib.sg_knn_ws_bytes.restype = sz
     lib.sg_region_laplacian.argtypes = [i32, i32] + [vp] * 11
+    lib.sg_rows_laplacian.argtypes = [i32, i32, i32] + [vp] * 14
     lib.sg_mesh_edge_loss.argtypes = [i32, i32] + [vp] * 8
     lib.sg_l2norm_reg.argtypes = [i32] + [vp] * 11
     lib.sg_gaussian_edge_loss.argtypes = [i32, i32] + [vp] * 8
     lib.sg_gaussian_edge_prepare.argtypes = [i32, vp, vp, vp]
     lib.sg_gaussian_edge_finish.argtypes = [i32, i32] + [vp] * 7
-    for f in ("sg_region_laplacian", "sg_mesh_edge_loss", "sg_l2norm_reg", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare",
+    for f in ("sg_region_laplacian", "sg_rows_laplacian", "sg_mesh_edge_loss", "sg_l2norm_reg", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare",
               "sg_gaussian_edge_finish"):
         getattr(lib, f).restype = C.c_int
     for f in ("sg_layout", "sg_rasterize_forward", "sg_rasterize_backward", "sg_mark_visible",

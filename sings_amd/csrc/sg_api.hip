@@ -798,6 +798,22 @@ extern "C" int sg_region_laplacian(int V, int C, const float *x, const int *row_
     SG_RET_LAST("sg_region_laplacian");
 }
 
+// (declared here, not in sg_common.h: that header is one of the sources the committed PMC profiles are keyed on)
+void sg_launch_rows_laplacian(int R, int V, int C, const float *x, const int *row_ptr, const int *col, const float *val,
+                              const float *rscale, const int *t_row_ptr, const int *t_row, const float *t_val, void *ws, float *g_ws,
+                              float *loss, const float *upstream, float *dL_dx, hipStream_t st);
+extern "C" int sg_rows_laplacian(int R, int V, int C, const float *x, const int *row_ptr, const int *col, const float *val,
+                                 const float *rscale, const int *t_row_ptr, const int *t_row, const float *t_val, void *ws,
+                                 float *g_ws, float *loss, const float *upstream, float *dL_dx, void *stream)
+{
+    if (R <= 0 || V <= 0 || C <= 0 || !x || !row_ptr || !col || !val || !rscale || !ws || !g_ws || (!loss && !dL_dx) ||
+        (dL_dx && (!t_row_ptr || !t_row || !t_val)))
+        return sg_fail("sg_rows_laplacian: bad argument", hipSuccess);
+    sg_launch_rows_laplacian(R, V, C, x, row_ptr, col, val, rscale, t_row_ptr, t_row, t_val, ws, g_ws, loss, upstream, dL_dx,
+                             (hipStream_t)stream);
+    SG_RET_LAST("sg_rows_laplacian");
+}
+
 extern "C" int sg_mesh_edge_loss(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws,
                                  float *loss, const float *upstream, float *dL_dx, void *stream)
 {

@@ -93,6 +93,44 @@ sg_lap_bwd_kernel(int V, int C, const float *__restrict__ g, const int *__restri
     }
 }
 
+// Cotangent variant (loss_items.py:150-165 with pytorch3d.ops.cot_laplacian): the regions OVERLAP (a region takes every face that
+// touches one of its vertices), so the operator is a STACK of weighted rows -- one row per (region, vertex of that region) -- over the
+// global vertex array: y_r = sum_e val_e x[col_e] (no diagonal term: cot_laplacian returns the off-diagonal weights only, and the
+// reference multiplies by exactly that), loss = sum_r rscale_r |y_r|^2 with rscale_r = weight(region) / (rows of the region * C).
+__global__ void __launch_bounds__(256)
+sg_rows_fwd_kernel(int R, int C, const float *__restrict__ x, const int *__restrict__ row_ptr, const int *__restrict__ col,
+                   const float *__restrict__ val, const float *__restrict__ rscale, float *__restrict__ g, float *__restrict__ partial)
+{
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    float acc[1] = { 0.0f };
+    if (r < R) {
+        const int e0 = row_ptr[r], e1 = row_ptr[r + 1];
+        const float sc = rscale[r];
+        for (int c = 0; c < C; c++) {
+            float y = 0.0f;
+            for (int e = e0; e < e1; e++) y += val[e] * x[(size_t)col[e] * C + c];
+            acc[0] += sc * y * y;
+            g[(size_t)r * C + c] = 2.0f * sc * y;
+        }
+    }
+    sg_block_partials<1>(acc, partial);
+}
+// dL/dx_j = sum over the entries of column j (the transposed CSR: t_row_ptr [V+1], t_row = stacked row, t_val) of val g_row
+__global__ void __launch_bounds__(256)
+sg_rows_bwd_kernel(int V, int C, const float *__restrict__ g, const int *__restrict__ t_row_ptr, const int *__restrict__ t_row,
+                   const float *__restrict__ t_val, const float *__restrict__ upstream, float *__restrict__ dx)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= V) return;
+    const float u = upstream ? upstream[0] : 1.0f;
+    const int e0 = t_row_ptr[j], e1 = t_row_ptr[j + 1];
+    for (int c = 0; c < C; c++) {
+        float s = 0.0f;
+        for (int e = e0; e < e1; e++) s += t_val[e] * g[(size_t)t_row[e] * C + c];
+        dx[(size_t)j * C + c] = u * s;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 sg_scalar_reduce_kernel(const float *__restrict__ partial, int nblocks, float scale, float *__restrict__ out)
 {
@@ -572,6 +610,17 @@ void sg_launch_region_laplacian(int V, int C, const float *x, const int *row_ptr
     hipLaunchKernelGGL(sg_lap_fwd_kernel, dim3(nb), dim3(256), 0, st, V, C, x, row_ptr, col, deg_inv, vscale, g_ws, partial);
     if (loss) hipLaunchKernelGGL(sg_scalar_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, loss);
     if (dL_dx) hipLaunchKernelGGL(sg_lap_bwd_kernel, dim3(nb), dim3(256), 0, st, V, C, g_ws, row_ptr, col, deg_inv, upstream, dL_dx);
+}
+
+void sg_launch_rows_laplacian(int R, int V, int C, const float *x, const int *row_ptr, const int *col, const float *val,
+                              const float *rscale, const int *t_row_ptr, const int *t_row, const float *t_val, void *ws, float *g_ws,
+                              float *loss, const float *upstream, float *dL_dx, hipStream_t st)
+{
+    float *partial = (float *)ws;
+    const int nb = sg_nb(R);
+    hipLaunchKernelGGL(sg_rows_fwd_kernel, dim3(nb), dim3(256), 0, st, R, C, x, row_ptr, col, val, rscale, g_ws, partial);
+    if (loss) hipLaunchKernelGGL(sg_scalar_reduce_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f, loss);
+    if (dL_dx) hipLaunchKernelGGL(sg_rows_bwd_kernel, dim3(sg_nb(V)), dim3(256), 0, st, V, C, g_ws, t_row_ptr, t_row, t_val, upstream, dL_dx);
 }
 
 void sg_launch_mesh_edge(int V, int E, const float *x, const int *row_ptr, const int *col, void *ws, float *loss,

@@ -184,8 +184,9 @@ class RegionLaplacianLoss_v2(torch.nn.Module):
         """only for unique edges.  ``region_weights``: sequence indexed by label (what the reference's ``parse_weights``
         returns) or a dict label -> weight."""
         super().__init__()
-        if laplacian_type != "standard":
-            raise NotImplementedError("only the standard (uniform) Laplacian of the reference's default is provided")
+        if laplacian_type not in ("standard", "cotangent"):
+            raise NotImplementedError("laplacian_type 'norm' raises in the reference too (loss_items.py:110-112)")
+        self.laplacian_type = laplacian_type
         self.dev = verts.device
         self.reset_laplacians(verts, edges, vertex_labels, faces)
         n_lab = int(self.unique_labels.max()) + 1
@@ -204,6 +205,11 @@ class RegionLaplacianLoss_v2(torch.nn.Module):
         lab = lab.astype(np.int64)
         if (lab < 0).any():
             raise ValueError("vertex labels must be >= 0")
+        if self.laplacian_type == "cotangent":
+            if faces is None:
+                raise ValueError("faces is supposed to be provided when using cotangent laplacian.")      # loss_items.py:130-131
+            self._reset_cot(verts, lab, faces)
+            return
         e = edges.detach().cpu().numpy() if torch.is_tensor(edges) else np.asarray(edges)
         e = e.astype(np.int64).reshape(-1, 2)
         V = int(lab.shape[0])
@@ -219,6 +225,78 @@ class RegionLaplacianLoss_v2(torch.nn.Module):
         self.deg_inv = t(np.where(deg > 0, 1.0 / np.maximum(deg, 1), 0.0), np.float32)
         self._vscale_cache = {}
 
+    def _reset_cot(self, verts, lab, faces, eps=1e-12):
+        """loss_items.py:150-165: per label, the faces with ANY vertex of that label, their vertices (the partitions overlap), the
+        cotangent weights of pytorch3d.ops.cot_laplacian on those faces (fp32, its formula order; duplicates of an edge summed).
+        Stored as ONE stack of weighted rows over the global vertex array + its transpose (sg_rows_laplacian)."""
+        v = (verts.detach().cpu().numpy() if torch.is_tensor(verts) else np.asarray(verts)).astype(np.float32)
+        f = (faces.detach().cpu().numpy() if torch.is_tensor(faces) else np.asarray(faces)).astype(np.int64).reshape(-1, 3)
+        V = int(lab.shape[0])
+        self.V, self.labels = V, lab
+        self.unique_labels = np.unique(lab)
+        n_lab = int(lab.max()) + 1
+        fl = lab[f]
+        rows_g, cols_g, vals, row_label, row_vertex = [], [], [], [], []
+        self.counts = np.zeros(n_lab, np.int64)                 # rows (= vertices of the partition) per label
+        base = 0
+        for label in self.unique_labels:
+            sel = f[(fl == label).any(axis=1)]
+            inc = np.unique(sel)
+            local = np.searchsorted(inc, sel)
+            p0, p1, p2 = v[sel[:, 0]], v[sel[:, 1]], v[sel[:, 2]]
+            A = np.linalg.norm(p1 - p2, axis=1); B = np.linalg.norm(p0 - p2, axis=1); Cc = np.linalg.norm(p0 - p1, axis=1)
+            s_ = np.float32(0.5) * (A + B + Cc)
+            area = np.sqrt(np.maximum(s_ * (s_ - A) * (s_ - B) * (s_ - Cc), np.float32(eps)))
+            A2, B2, C2 = A * A, B * B, Cc * Cc
+            cot = np.stack([(B2 + C2 - A2) / area, (A2 + C2 - B2) / area, (A2 + B2 - C2) / area], axis=1) / np.float32(4.0)
+            ii = local[:, [1, 2, 0]].reshape(-1); jj = local[:, [2, 0, 1]].reshape(-1); w = cot.reshape(-1)
+            r = np.concatenate([ii, jj]); c = np.concatenate([jj, ii]); w2 = np.concatenate([w, w])          # L += L^T
+            rows_g.append(base + r); cols_g.append(inc[c]); vals.append(w2)
+            row_label.append(np.full(len(inc), label)); row_vertex.append(inc)
+            self.counts[label] = len(inc)
+            base += len(inc)
+        R = base
+        r = np.concatenate(rows_g); c = np.concatenate(cols_g); w = np.concatenate(vals).astype(np.float64)
+        key = r * V + c                                          # coalesce duplicate (row, column) entries
+        uk, inv = np.unique(key, return_inverse=True)
+        ws = np.bincount(inv, weights=w, minlength=len(uk))
+        r, c = uk // V, uk % V                                   # sorted by row, then column: CSR order
+        row_ptr = np.zeros(R + 1, np.int64); np.add.at(row_ptr, r + 1, 1); row_ptr = np.cumsum(row_ptr)
+        order = np.lexsort((r, c))                               # transposed: by column, then row
+        t_row_ptr = np.zeros(V + 1, np.int64); np.add.at(t_row_ptr, c + 1, 1); t_row_ptr = np.cumsum(t_row_ptr)
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a.astype(dt))).to(self.dev)
+        self.R = R
+        self.row_label = np.concatenate(row_label)
+        self.row_ptr, self.col, self.val = t(row_ptr, np.int32), t(c, np.int32), t(ws, np.float32)
+        self.t_row_ptr, self.t_row, self.t_val = t(t_row_ptr, np.int32), t(r[order], np.int32), t(ws[order], np.float32)
+        self._vscale_cache = {}
+
+    def _rscale(self, C, per_label):
+        key = ("rows", C, tuple(np.round(per_label, 12)))
+        if key not in self._vscale_cache:
+            rs = per_label[self.row_label] / (self.counts[self.row_label] * float(C))
+            self._vscale_cache[key] = torch.from_numpy(rs.astype(np.float32)).to(self.dev)
+        return self._vscale_cache[key]
+
+    def _run_cot(self, x, per_label):
+        lib = _lib.load()
+        xin = x
+        x = x.contiguous().float()
+        _need_gpu(x, "RegionLaplacianLoss_v2")
+        if x.shape[0] != self.V:
+            raise ValueError(f"expected {self.V} rows, got {x.shape[0]}")
+        C_ = int(x.numel() // self.V)
+        rs = self._rscale(C_, per_label)
+        dev = x.device
+        ws = torch.empty(int(lib.sg_reg_ws_bytes(self.R)), dtype=torch.uint8, device=dev)
+        g = torch.empty((self.R, C_), dtype=torch.float32, device=dev); dx = torch.empty_like(x)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_rows_laplacian(self.R, self.V, C_, _ptr(x), _ptr(self.row_ptr), _ptr(self.col), _ptr(self.val),
+                                             _ptr(rs), _ptr(self.t_row_ptr), _ptr(self.t_row), _ptr(self.t_val), _ptr(ws), _ptr(g),
+                                             _ptr(loss), None, _ptr(dx), _stream(dev)), "region laplacian (cotangent)")
+        return _attach(loss[0], [xin], [dx.view_as(xin)])
+
     def _vscale(self, C, per_label):
         key = (C, tuple(np.round(per_label, 12)))
         if key not in self._vscale_cache:
@@ -227,6 +305,8 @@ class RegionLaplacianLoss_v2(torch.nn.Module):
         return self._vscale_cache[key]
 
     def _run(self, x, per_label):
+        if self.laplacian_type == "cotangent":
+            return self._run_cot(x, per_label)
         lib = _lib.load()
         xin = x
         x = x.contiguous().float()

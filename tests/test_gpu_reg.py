@@ -191,3 +191,40 @@ def test_edge_loss_without_gradients_returns_the_value_not_an_unwritten_buffer()
         mod.prepare({'xyz_canon': t("gs_xyz"), 'scales': t("gs_scales")})
     mod.finish()
     assert abs(out.item() - want) <= 2e-6 * abs(want)
+
+
+def test_region_laplacian_cotangent_vs_oracle():
+    """RegionLaplacianLoss_v2(laplacian_type='cotangent') (loss_items.py:150-165: overlapping regions, cot weights, no diagonal)
+    through sg_rows_laplacian against oracle.reg_oracle.region_laplacian_cot_loss + autograd, forward and forward_hands;
+    'norm' raises as in the reference (:110-112), 'cotangent' without faces raises as in :130-131."""
+    from sings_amd.regularizers import RegionLaplacianLoss_v2
+    from mesh_case import bumpy_sphere
+    dev = _dev()
+    vv, ff, lab = bumpy_sphere(nu=48, nv=40, seed=3)
+    rng = np.random.default_rng(5)
+    w = rng.uniform(0.5, 2.0, 8)
+    for C_ in (3, 1):
+        x = rng.standard_normal((len(vv), C_)).astype(np.float32)
+        xo = torch.from_numpy(x).requires_grad_(True)
+        lo = ro.region_laplacian_cot_loss(xo, torch.from_numpy(vv), torch.from_numpy(ff), torch.from_numpy(lab), w)
+        lo.backward()
+        mod = RegionLaplacianLoss_v2(verts=torch.from_numpy(vv).to(dev), edges=None, vertex_labels=torch.from_numpy(lab).to(dev),
+                                     faces=torch.from_numpy(ff).to(dev), region_weights=w, laplacian_type="cotangent")
+        xg = torch.from_numpy(x).to(dev).requires_grad_(True)
+        lg = mod(xg)
+        (2.0 * lg).backward()
+        assert abs(lg.item() - lo.item()) <= 1e-5 * abs(lo.item()), (lg.item(), lo.item())
+        _close(xg.grad.cpu().numpy() / 2.0, xo.grad.numpy(), rtol=2e-5, atol_scale=1e-5)
+        xo2 = torch.from_numpy(x).requires_grad_(True)
+        lh = ro.region_laplacian_cot_loss(xo2, torch.from_numpy(vv), torch.from_numpy(ff), torch.from_numpy(lab), w, only=(6, 7), strength=1000)
+        lh.backward()
+        xg2 = torch.from_numpy(x).to(dev).requires_grad_(True)
+        lhg = mod.forward_hands(xg2); lhg.backward()
+        assert abs(lhg.item() - lh.item()) <= 1e-5 * abs(lh.item())
+        _close(xg2.grad.cpu().numpy(), xo2.grad.numpy(), rtol=2e-5, atol_scale=1e-5)
+    with pytest.raises(NotImplementedError):
+        RegionLaplacianLoss_v2(verts=torch.from_numpy(vv).to(dev), edges=None, vertex_labels=torch.from_numpy(lab).to(dev),
+                               faces=torch.from_numpy(ff).to(dev), laplacian_type="norm")
+    with pytest.raises(ValueError):
+        RegionLaplacianLoss_v2(verts=torch.from_numpy(vv).to(dev), edges=None, vertex_labels=torch.from_numpy(lab).to(dev),
+                               laplacian_type="cotangent")

@@ -50,3 +50,32 @@ def test_host_csr_construction():
     row_ptr, col = _csr(5, np.array([[0, 1], [1, 2], [0, 2], [3, 4]]))
     assert row_ptr.tolist() == [0, 2, 4, 6, 7, 8]
     assert col.tolist() == [1, 2, 0, 2, 0, 1, 4, 3]
+
+
+def test_cot_laplacian_against_hand_computed_cotangents():
+    """oracle.reg_oracle.cot_laplacian (restating pytorch3d's: absent from this image) on triangles whose angles are known:
+    weight of an edge = sum over its (<= 2) faces of cot(opposite angle); no diagonal; inv_areas = 1 / sum of adjacent areas."""
+    # one right isosceles triangle: angles 90 (at v0), 45, 45
+    v = torch.tensor([[0., 0, 0], [1, 0, 0], [0, 1, 0]])
+    L, inv = ro.cot_laplacian(v, torch.tensor([[0, 1, 2]]))
+    assert torch.allclose(L, torch.tensor([[0., 1, 1], [1, 0, 0], [1, 0, 0]]), atol=1e-6)      # edge (1,2) faces the right angle: cot = 0
+    assert torch.allclose(inv, torch.full((3, 1), 2.0), atol=1e-6)                              # area 1/2
+    # unit square split along (0,2): the diagonal faces two right angles (0 + 0), every side one 45-degree angle (cot 1)
+    v = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+    L, inv = ro.cot_laplacian(v, torch.tensor([[0, 1, 2], [0, 2, 3]]))
+    exp = torch.zeros(4, 4)
+    for a, b in ((0, 1), (1, 2), (2, 3), (3, 0)):
+        exp[a, b] = exp[b, a] = 1.0
+    assert torch.allclose(L, exp, atol=1e-6) and torch.allclose(L, L.t())
+    assert torch.allclose(inv.view(-1), torch.tensor([1.0, 2.0, 1.0, 2.0]), atol=1e-6)
+    # equilateral triangle: cot 60 = 1 / sqrt 3 on every edge
+    v = torch.tensor([[0., 0, 0], [1, 0, 0], [0.5, 3 ** 0.5 / 2, 0]])
+    L, _ = ro.cot_laplacian(v, torch.tensor([[0, 1, 2]]))
+    assert torch.allclose(L[L > 0], torch.full((6,), 3 ** -0.5), atol=1e-6)
+    # on a closed mesh: symmetric, zero diagonal, and sum_j L_ij (x_j - x_i) of a LINEAR function is the area-weighted zero of the
+    # discrete Laplace-Beltrami operator only on flat patches -- here just the structural facts
+    from mesh_case import bumpy_sphere
+    vv, ff, _ = bumpy_sphere()
+    L, _ = ro.cot_laplacian(torch.from_numpy(vv), torch.from_numpy(ff))
+    assert torch.allclose(L, L.t(), atol=1e-5) and float(L.diagonal().abs().max()) == 0.0
+    assert int((L != 0).sum()) == 2 * (len(ff) * 3 // 2)          # every edge of a closed manifold mesh, both directions
