@@ -105,9 +105,10 @@ def test_full_step_matches_oracle_chain():
 def test_full_step_replays_from_a_hip_graph(defer_join):
     """The composed step incl. the regularisers on their side stream captured into ONE HIP graph (deferred pair-count check,
     no host round trip inside a step): replays separated by host synchronisations and by a change of the frame (joint
-    transforms updated IN PLACE) give the loss and gradients of the directly launched step.  `defer_join`: the round-3
-    schedule -- k-NN grids early, the query behind the raster forward, the regularisers joined inside the backward pass
-    (two autograd roots) -- against a reference computed with the early join."""
+    transforms updated IN PLACE) give the loss and gradients of the directly launched step.  `defer_join`: two roots -- the k-NN
+    query behind the raster forward, the backward pass staged by hand in `AvatarStep.backward` (photometric gradients, the
+    regularisers' gradients on their stream, one addition, the decoders' backward from the sums: round 5) -- against a reference
+    computed with the early join and one plain autograd pass."""
     from sings_amd import rasterizer as rz
     from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
     from sings_amd.rasterizer import GaussianRasterizationSettings
@@ -340,9 +341,11 @@ def test_a_step_over_a_chunk_of_frames_equals_the_sum_of_one_frame_steps():
 
 
 def test_a_step_that_raises_between_prepare_and_finish_leaves_the_module_usable():
-    """ADVICE r4: with `defer_regulariser_join` the edge loss's prepare() runs before the raster forward and its finish() after it;
-    a forward that RAISES in between (here: a camera tensor left on the host, refused by the op) used to leave the prepared query
-    pending, and every later step failed with "prepare() called twice".  Now the query is dropped with the step."""
+    """with `defer_regulariser_join` the edge loss's prepare() used to run before the raster forward and its finish() after
+    it; a forward that RAISED in between (here: a camera tensor left on the host, refused by the op) left the prepared query pending,
+    and every later step failed with "prepare() called twice".  Round 4 dropped the query with the step (`abort()`); since round 5 both
+    calls are issued after the raster forward and the photometric loss (a finish() that raises still aborts) -- either way a step that
+    raises leaves the module usable, and the module-level prepare / abort contract holds."""
     from sings_amd.body import joint_transforms
     from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
     from sings_amd.rasterizer import GaussianRasterizationSettings
