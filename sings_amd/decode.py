@@ -619,8 +619,12 @@ class _Act(torch.autograd.Function):
         return dz, None
 
 
-def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_factor=1.0, scaling_multiplier=None):
-    """SinGS.get_gs_attrs for one level (sings_hybrid.py:249-313): the dict the LBS/render path consumes."""
+def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_factor=1.0, scaling_multiplier=None,
+                      geometry_hook=None):
+    """SinGS.get_gs_attrs for one level (sings_hybrid.py:249-313): the dict the LBS/render path consumes.
+    ``geometry_hook(xyz_canon, scales) -> (xyz_canon, scales)``: applied to the geometry decoder's outputs BEFORE the appearance
+    decoder is issued -- autograd nodes the hook creates are visited after the appearance decoder's in the backward pass
+    (sings_amd.train_step uses it to add the k-NN regulariser's gradient as late as possible)."""
     tri_feats = triplane(xyz)
     # both decoders' first layers read the tri-plane features: one fan, one feature gradient
     g1, a1 = linear_fan(tri_feats, [(geometry_dec.net[0], ACT_GELU, None), (appearance_dec.net[0], ACT_GELU, None)])
@@ -631,6 +635,8 @@ def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_fac
     if scaling_multiplier is not None:
         scales = scales * scaling_multiplier
     xyz_canon = xyz + g['xyz_offsets']
+    if geometry_hook is not None:
+        xyz_canon, scales = geometry_hook(xyz_canon, scales)
     a = appearance_dec(tri_feats, first=a1)
     return {"xyz_canon": xyz_canon, "xyz_offsets": g['xyz_offsets'], "rot6d_canon": g['rotations'],
             "scales_aux": g['scales_aux'], "scales": scales, "opacity": a['opacity'], "shs": a['shs']}

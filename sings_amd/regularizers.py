@@ -97,6 +97,9 @@ class L2Norm(torch.nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.sg_l2norm_reg(N, _ptr(off), _ptr(sc), _ptr(op), _ptr(lam), _ptr(ws), _ptr(loss), None,
                                          _ptr(d_off), _ptr(d_sc), _ptr(d_op), _stream(dev)), "l2norm")
+        # (what the kernel computed besides the value: d loss / d input for an upstream gradient of 1 -- a caller that stages its
+        #  backward pass by hand, sings_amd.train_step.AvatarStep, reads them here instead of going through autograd)
+        self.last_grads = {"xyz_offsets": d_off, "scales": d_sc, "opacity": d_op}
         return _attach(loss[0], [human_gs_out['xyz_offsets'], human_gs_out['scales'], human_gs_out.get('opacity')],
                        [d_off, d_sc, d_op])
 
@@ -129,6 +132,7 @@ class GaussiansEdgeLoss(torch.nn.Module):
         with torch.cuda.device(dev):
             _lib.check(lib.sg_gaussian_edge_prepare(N, _ptr(verts), _ptr(ws), _stream(dev)), "gaussian edge loss (grids)")
         self._pending = (N, verts, sc, ws, loss, d_sc, torch.cuda.current_stream(dev))
+        self.last_grads = {"scales": d_sc}                       # (filled by finish(), like the loss; see L2Norm.last_grads)
         return _attach(loss[0], [human_gs_out['scales']], [d_sc], filled=False)
 
     def finish(self):

@@ -42,6 +42,27 @@ class _AddScalars(torch.autograd.Function):
         return g, g
 
 
+class _Inject(torch.autograd.Function):
+    """Identity in the forward; the backward ADDS a gradient that arrives late from another stream (``slot[key]``: a tensor or
+    None, ``slot["side"]``: the stream it is produced on).  Placed on the geometry decoder's outputs before the appearance decoder is
+    issued, so autograd reaches it -- and waits for that stream -- only after the appearance decoder's backward has been issued."""
+
+    @staticmethod
+    def forward(ctx, x, slot, key):
+        ctx.slot, ctx.key = slot, key
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        extra = ctx.slot.pop(ctx.key, None)
+        if extra is not None:
+            cur = torch.cuda.current_stream(g.device)
+            cur.wait_stream(ctx.slot["side"])
+            extra.record_stream(cur)
+            g = g + extra
+        return g, None, None
+
+
 def _tensors_of(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -121,13 +142,15 @@ class AvatarStep(torch.nn.Module):
         Inside a HIP-graph capture: use ``sings_amd.train_step.capture_step`` (it refuses, with an error instead of a dead
         process, a captured callable that returns tensors still carrying their autograd graph), and keep the regularisers on
         the ONE side stream this module owns (``GaussiansEdgeLoss.finish`` refuses any other stream while capturing)."""
-        attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
-                                  self.scaling_multiplier)
         has_reg = self.l2_norm is not None or (self.gaussian_connect is not None and self.gaussian_connect_w > 0)
         has_knn = self.gaussian_connect is not None and self.gaussian_connect_w > 0
-        overlap = has_reg and self.overlap_regularisers and attrs["xyz_canon"].is_cuda
+        overlap = has_reg and self.overlap_regularisers and self.xyz.is_cuda
         defer = (overlap and self.defer_regulariser_join and torch.is_grad_enabled() and has_knn
                  and hasattr(self.gaussian_connect, "prepare"))
+        inject = {} if defer else None                           # the k-NN regulariser's gradient (scales only: its edge lengths are
+        hook = (lambda x, sc: (x, _Inject.apply(sc, inject, "scales"))) if defer else None          # detached, loss_items.py:75)
+        attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
+                                  self.scaling_multiplier, geometry_hook=hook)
         # Two roots (defer): the render and the regularisers read DETACHED views of the decoded attributes (`use`), so that the
         # backward pass can be staged by hand (AvatarStep.backward): photometric gradients on this stream, the regularisers' on the
         # side stream, one addition, then the decoders' backward -- in an order the graph executor turns into ONE queue for the
@@ -192,22 +215,35 @@ class AvatarStep(torch.nn.Module):
             # SIMD on every CU for 0.23 ms -- for the raster forward.  (Measured, profiles/r05_graph_queues.log: the executor starts
             # a second queue's chain 60-160 us after its dependency is met, so part of the query is still exposed behind the
             # backward composite; issued FIRST, as in round 4, the chain starts at once and the raster forward is what waits.)
+            # No autograd on the side stream: both regularisers' kernels compute their gradients with the value (`last_grads`), and the
+            # engine's stream bookkeeping around an autograd call put a wait for THIS stream's newest kernel in front of them.
             side.wait_event(decoded)
+            l2_grads = None
+            det = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in use.items()}
             with torch.cuda.stream(side):
-                l2()
-                edge = self.gaussian_connect.prepare({"xyz_canon": use["xyz_canon"], "scales": use["scales"]})
+                if self.l2_norm is not None:
+                    # in front of the k-NN query on this stream: the appearance decoder's backward needs the opacity term
+                    reg["l2"] = self.l2_norm({"xyz_offsets": det["xyz_offsets"], "scales": det["scales"], "opacity": det["opacity"]})
+                    l2_grads = (dict(self.l2_norm.last_grads), torch.cuda.Event())
+                    l2_grads[1].record(side)
+                edge = self.gaussian_connect.prepare({"xyz_canon": det["xyz_canon"], "scales": det["scales"]})
                 side.wait_event(rendered)
                 try:
                     self.gaussian_connect.finish()
                 except BaseException:
                     self.gaussian_connect.abort()
                     raise
-                reg["gaussian_connect_loss"] = self.gaussian_connect_w * edge
-                vals = [v.reshape(()) for v in reg.values()]
-                reg_root = _AddScalars.apply(vals[0], vals[1]) if len(vals) == 2 else torch.stack(vals).sum()
+                g_edge = self.gaussian_connect.last_grads["scales"]
+                if self.gaussian_connect_w != 1.0:
+                    edge, g_edge = self.gaussian_connect_w * edge, self.gaussian_connect_w * g_edge
+                reg["gaussian_connect_loss"] = edge
+                if use["scales"].requires_grad:
+                    inject["scales"] = g_edge                    # reaches the decoders' backward through the _Inject node
+                reg_root = edge.reshape(())
             loss_dict.update(reg)
+            inject["side"] = side
             extras["loss_roots"] = (photo_root, reg_root)
-            extras["staged"] = (attrs, use)
+            extras["staged"] = (attrs, use, inject, l2_grads)
             return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
         if side is not None:
             cur.wait_stream(side)                                # join before the loss terms meet
@@ -234,7 +270,7 @@ class AvatarStep(torch.nn.Module):
         """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and
         ``loss_dict["loss"]`` = their sum.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
         photo_root, reg_root = extras["loss_roots"]
-        attrs, use = extras["staged"]
+        attrs, use, inject, l2_grads = extras["staged"]
         one = getattr(self, "_one", None)
         if one is None or one.device != photo_root.device:
             one = self._one = torch.ones((), dtype=photo_root.dtype, device=photo_root.device)     # (not a fill launch per root and step)
@@ -243,27 +279,31 @@ class AvatarStep(torch.nn.Module):
         names = [k for k, v in use.items() if torch.is_tensor(v) and v.requires_grad]
         leaves = [use[k] for k in names]
         # 1. the photometric gradients of the decoded attributes: loss, composite, LBS -- on this stream, issued first
-        g = list(torch.autograd.grad([photo_root], leaves, [one], allow_unused=True))
-        # 2. the regularisers' on theirs (every node of that graph ran there)
-        with torch.cuda.stream(side):
-            g_reg = torch.autograd.grad([reg_root], leaves, [one], allow_unused=True)
-        # 3. join, ONE addition for all attributes that have both
-        cur.wait_stream(side)
-        both_a, both_b = [], []
-        for i, gr in enumerate(g_reg):
-            if gr is None:
-                continue
-            gr.record_stream(cur)
-            if g[i] is None:
-                g[i] = gr
-            else:
-                both_a.append(g[i]); both_b.append(gr)
-        if both_a:
-            torch._foreach_add_(both_a, both_b)
-        # 4. the decoders' backward
-        roots = [(attrs[k], g[i]) for i, k in enumerate(names) if g[i] is not None]
+        g = dict(zip(names, torch.autograd.grad([photo_root], leaves, [one], allow_unused=True)))
+        # 2. L2Norm's gradients (computed with its value, in front of the k-NN query on the side stream): ONE addition for the
+        #    attributes that have both.  The k-NN regulariser's gradient (scales) is already in `inject`: it reaches the decoders'
+        #    backward through the _Inject node, i.e. AFTER the appearance decoder's backward has been issued
+        if l2_grads is not None:
+            cur.wait_event(l2_grads[1])
+            both_a, both_b = [], []
+            for k, gr in l2_grads[0].items():
+                if gr is None or k not in g:
+                    continue
+                gr.record_stream(cur)
+                if g[k] is None:
+                    g[k] = gr
+                else:
+                    both_a.append(g[k]); both_b.append(gr)
+            if both_a:
+                torch._foreach_add_(both_a, both_b)
+        # 3. the decoders' backward: appearance decoder first (its nodes are the youngest), then the _Inject node waits for the side stream
+        roots = [(attrs[k], g[k]) for k in names if g.get(k) is not None]
         torch.autograd.backward([r for r, _ in roots], [x for _, x in roots])
+        cur.wait_stream(side)
         for v in list(loss_dict.values()) + [reg_root]:
             v.record_stream(cur)
-        loss_dict["loss"] = photo_root.detach() + reg_root.detach()
+        total = photo_root.detach() + reg_root.detach()
+        if l2_grads is not None:
+            total = total + loss_dict["l2"].reshape(())
+        loss_dict["loss"] = total
         return loss_dict["loss"]
