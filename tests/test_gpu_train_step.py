@@ -393,3 +393,55 @@ def test_a_step_that_raises_between_prepare_and_finish_leaves_the_module_usable(
     edge.abort()
     torch.cuda.synchronize()
     assert abs(run(good) - ref) <= 1e-6 * abs(ref)
+
+
+@pytest.mark.parametrize("with_l2,edge_w,isotropic", [(False, 1.0, True), (True, 0.5, False), (True, 2.0, True)])
+def test_staged_backward_equals_one_autograd_pass(with_l2, edge_w, isotropic):
+    """`defer_regulariser_join` (round 5: backward staged by hand, the k-NN regulariser's gradient injected at the geometry decoder's
+    outputs, the regularisers' gradients taken from their kernels) against the early join + ONE plain autograd pass: same loss, same
+    parameter gradients -- without L2Norm, with a regulariser weight != 1 (the scaled hand-over), with the rotations head."""
+    from sings_amd.body import joint_transforms
+    from sings_amd.decode import AppearanceDecoder, GeometryDecoder, HexPlaneField
+    from sings_amd.rasterizer import GaussianRasterizationSettings
+    from sings_amd.regularizers import GaussiansEdgeLoss, L2Norm
+    from sings_amd.scene import avatar_scene
+    from sings_amd.train_step import AvatarStep
+    dev = torch.device("cuda:0")
+    torch.manual_seed(11)
+    s = avatar_scene(N=5000, J=24, W=96, H=160, seed=11)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [16, 16, 16], 'multires': [1, 2]}
+    tri = HexPlaneField(cfg, bounds=1.2, device=dev); geo = GeometryDecoder(64, isotropic=isotropic).to(dev); app = AppearanceDecoder(64).to(dev)
+    with torch.no_grad():
+        geo.scales[2].bias.fill_(-4.5); geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()
+    step = AvatarStep(t(s["xyz_canon"]), t(s["lbs_weights"]), tri, geo, app, l2_norm=L2Norm() if with_l2 else None,
+                      gaussian_connect=GaussiansEdgeLoss(), gaussian_connect_w=edge_w).to(dev)
+    params = [p for p in step.parameters() if p.requires_grad]
+    cam = s["cam"]
+    rset = GaussianRasterizationSettings(
+        image_height=s["H"], image_width=s["W"], tanfovx=math.tan(cam["fovx"] * 0.5), tanfovy=math.tan(cam["fovy"] * 0.5), bg=t(s["bg"]),
+        scale_modifier=1.0, viewmatrix=t(cam["world_view_transform"]), projmatrix=t(cam["full_proj_transform"]), sh_degree=0,
+        campos=t(cam["camera_center"]), prefiltered=False, debug=False)
+    A = joint_transforms(t(np.random.RandomState(2).normal(0, 0.15, 72).astype(np.float32)), t(s["joints_rest"]), tuple(s["parents"]))
+    gt = torch.rand(3, s["H"], s["W"], device=dev); ones = torch.ones(s["H"], s["W"], device=dev)
+
+    def run(defer):
+        step.defer_regulariser_join = defer
+        for p in params:
+            p.grad = None
+        loss, ld, ex = step(A, rset, gt, ones, t(s["bg"]), smpl_scale=t(s["smpl_scale"]), transl=t(s["transl"]))
+        if loss is None:
+            assert defer
+            loss = step.backward(ld, ex)
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: float(v) for k, v in ld.items()}, [p.grad.clone() for p in params]
+
+    l0, d0, g0 = run(False)
+    l1, d1, g1 = run(True)
+    assert abs(l1 - l0) <= 1e-6 * abs(l0), (l1, l0)
+    for k in d0:
+        assert abs(d1[k] - d0[k]) <= 1e-6 * abs(d0[k]) + 1e-12, (k, d1[k], d0[k])
+    for p, a, b in zip(params, g1, g0):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-12
