@@ -16,10 +16,13 @@ raster forward's latency-bound chain took 2-7x as long per kernel (the long-list
 146 us instead of 21).  With ``defer_regulariser_join`` the query is held until the raster forward has finished and is NOT
 joined before the loss: ``forward`` returns the photometric and the regulariser loss as two roots (``extras["loss_roots"]``) and
 ``AvatarStep.backward`` STAGES the backward pass by hand (round 5): the render and the regularisers read detached views of the
-decoded attributes, so the photometric gradients (loss, composite, LBS: this stream) and the regularisers' (side stream) are two
-``torch.autograd.grad`` calls, one ``_foreach_add_`` joins them, and the decoders' backward starts from the sums -- the order of
-the launches is then the order the graph executor needs to keep the critical chain on ONE queue (sings_amd/decode.py "capture
-order"; 2.18 -> 2.00 ms per step with the deferred weight gradients, profiles/r05_graph_queues.log).
+decoded attributes; the photometric gradients (loss, composite, LBS: this stream) are one ``torch.autograd.grad`` call, L2Norm's
+gradients -- computed by its kernel with the value, in front of the query on the side stream -- are added with one ``_foreach_add_``,
+and the decoders' backward starts from the sums.  The k-NN regulariser's gradient (scales only) enters at an identity node placed on
+the geometry decoder's outputs BEFORE the appearance decoder is issued: autograd visits the youngest nodes first, so the appearance
+decoder's backward is issued -- and runs beside the query -- before the main stream waits for the side stream at that node.  The
+order of the launches is then the order the graph executor needs to keep the critical chain on ONE queue (sings_amd/decode.py
+"capture order"; 2.18 -> 1.97-2.05 ms per step with the deferred weight gradients, profiles/r05_graph_queues.log).
 """
 import torch
 
@@ -267,8 +270,8 @@ class AvatarStep(torch.nn.Module):
                     v.record_stream(cur)
 
     def backward(self, loss_dict, extras):
-        """Backward pass of a ``defer_regulariser_join`` forward: both roots in one autograd pass, then the streams join and
-        ``loss_dict["loss"]`` = their sum.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
+        """Backward pass of a ``defer_regulariser_join`` forward, staged by hand (module docstring); then the streams join and
+        ``loss_dict["loss"]`` = the sum of the terms.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
         photo_root, reg_root = extras["loss_roots"]
         attrs, use, inject, l2_grads = extras["staged"]
         one = getattr(self, "_one", None)
