@@ -73,7 +73,22 @@ def _aabb_host(aabb):
 # a side stream, where the decoders' forward hides it, and the backward only waits for its event.  On by default outside HIP-graph
 # capture; inside a capture (where an unjoined side stream is an error if backward() never runs) only after
 # `prepare_triplane_backward_early(True)`; `False` turns it off everywhere.
-_TP = {"mode": None, "streams": {}}
+_TP = {"mode": None, "streams": {}, "late": False}
+_TP_PENDING = []
+
+
+def flush_triplane_prepare(stream=None):
+    """Issue a tri-plane backward preparation that `prepare_triplane_backward_late(True)` held back (``stream``: on that stream
+    instead of the module's own side stream)."""
+    while _TP_PENDING:
+        fn = _TP_PENDING.pop(0)
+        fn() if stream is None else fn(stream)
+
+
+def prepare_triplane_backward_late(flag=True):
+    """Hold the early preparation back until `flush_triplane_prepare()` (or the backward pass): beside the first decoder layers its
+    counting sorts cost the forward chain more than they save (sings_amd.train_step issues it at the end of the forward)."""
+    _TP["late"] = bool(flag)
 
 
 def prepare_triplane_backward_early(flag=True):
@@ -199,15 +214,23 @@ class _Triplane(torch.autograd.Function):
             # (NOT deferred like the weight gradients below: issued first, this chain keeps the forward's queue and the decoders move
             #  to the next one -- one hop; issued after the first decoder layer it shares a queue with the regularisers and the weight
             #  gradients and was executed after them, 2.14 instead of 2.06 ms per step)
-            side.wait_stream(cur)
-            with torch.cuda.device(dev), torch.cuda.stream(side):
-                _lib.check(lib.sg_triplane_backward_prepare(C.byref(tp), N, _ptr(x), _ptr(bws), C.c_void_p(side.cuda_stream)),
-                           "triplane backward (prepare)")
-                ev = torch.cuda.Event()
-                ev.record(side)
-            bws.record_stream(side); x.record_stream(side)
-            for p in planes:
-                p.record_stream(side)
+            ev = torch.cuda.Event()
+            fork = torch.cuda.Event()
+            fork.record(cur)
+
+            def launch(side=side):
+                side.wait_event(fork)
+                with torch.cuda.device(dev), torch.cuda.stream(side):
+                    _lib.check(lib.sg_triplane_backward_prepare(C.byref(tp), N, _ptr(x), _ptr(bws), C.c_void_p(side.cuda_stream)),
+                               "triplane backward (prepare)")
+                    ev.record(side)
+                bws.record_stream(side); x.record_stream(side)
+                for p in planes:
+                    p.record_stream(side)
+            if _TP.get("late"):
+                _TP_PENDING.append(launch)                       # issued by flush_triplane_prepare() / the backward
+            else:
+                launch()
             ctx.early = (bws, ev)
         return feats
 
@@ -220,6 +243,7 @@ class _Triplane(torch.autograd.Function):
         keep = []
         tp = _tp_struct(grids, aabb, keep)
         dev, N = x.device, int(x.shape[0])
+        flush_triplane_prepare()
         early = ctx.early
         ws = early[0] if early else torch.empty(int(lib.sg_triplane_bwd_ws_bytes(C.byref(tp), N)), dtype=torch.uint8, device=dev)
         dplanes = [_arena_out(p) for p in planes]                    # (straight into the caller's flat buffer, if registered)

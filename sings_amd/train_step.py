@@ -26,6 +26,7 @@ order of the launches is then the order the graph executor needs to keep the cri
 """
 import torch
 
+from . import decode as _dec
 from .decode import decode_attributes
 from .photo_loss import photometric_loss, photometric_loss_frames
 from .skinned import rasterize_skinned_frames, rasterize_skinned_gaussians
@@ -47,7 +48,7 @@ class _AddScalars(torch.autograd.Function):
 
 class _Inject(torch.autograd.Function):
     """Identity in the forward; the backward ADDS a gradient that arrives late from another stream (``slot[key]``: a tensor or
-    None, ``slot["side"]``: the stream it is produced on).  Placed on the geometry decoder's outputs before the appearance decoder is
+    None, ``slot["ready"]``: the event behind the kernel that produces it).  Placed on the geometry decoder's outputs before the appearance decoder is
     issued, so autograd reaches it -- and waits for that stream -- only after the appearance decoder's backward has been issued."""
 
     @staticmethod
@@ -60,7 +61,7 @@ class _Inject(torch.autograd.Function):
         extra = ctx.slot.pop(ctx.key, None)
         if extra is not None:
             cur = torch.cuda.current_stream(g.device)
-            cur.wait_stream(ctx.slot["side"])
+            cur.wait_event(ctx.slot["ready"])                    # (not the whole side stream: more may have been issued behind it)
             extra.record_stream(cur)
             g = g + extra
         return g, None, None
@@ -152,8 +153,17 @@ class AvatarStep(torch.nn.Module):
                  and hasattr(self.gaussian_connect, "prepare"))
         inject = {} if defer else None                           # the k-NN regulariser's gradient (scales only: its edge lengths are
         hook = (lambda x, sc: (x, _Inject.apply(sc, inject, "scales"))) if defer else None          # detached, loss_items.py:75)
-        attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
-                                  self.scaling_multiplier, geometry_hook=hook)
+        # the tri-plane backward's point sorts (decode.py: "the point-only half ... early") are held back: beside the first decoder
+        # layers they cost the forward chain ~70 us (the first layer: 121 instead of 53 us); here they are issued on the regularisers'
+        # stream behind the k-NN query, long before the tri-plane backward needs them
+        late_prev = _dec._TP["late"]
+        _dec._TP["late"] = bool(defer)
+        del _dec._TP_PENDING[:]                                  # (a preparation left behind by a forward that raised)
+        try:
+            attrs = decode_attributes(self.xyz, self.triplane, self.geometry_dec, self.appearance_dec, self.thickness_factor,
+                                      self.scaling_multiplier, geometry_hook=hook)
+        finally:
+            _dec._TP["late"] = late_prev
         # Two roots (defer): the render and the regularisers read DETACHED views of the decoded attributes (`use`), so that the
         # backward pass can be staged by hand (AvatarStep.backward): photometric gradients on this stream, the regularisers' on the
         # side stream, one addition, then the decoders' backward -- in an order the graph executor turns into ONE queue for the
@@ -243,8 +253,10 @@ class AvatarStep(torch.nn.Module):
                 if use["scales"].requires_grad:
                     inject["scales"] = g_edge                    # reaches the decoders' backward through the _Inject node
                 reg_root = edge.reshape(())
+                inject["ready"] = torch.cuda.Event()
+                inject["ready"].record(side)
+                _dec.flush_triplane_prepare(side)                # (same stream, behind the query: executed in this order)
             loss_dict.update(reg)
-            inject["side"] = side
             extras["loss_roots"] = (photo_root, reg_root)
             extras["staged"] = (attrs, use, inject, l2_grads)
             return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
