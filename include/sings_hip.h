@@ -463,6 +463,12 @@ int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias
 int sg_bias_act_backward(int N, int C, int act, const float *z, const float *row_offset, const float *dh, void *ws,
                          float *dz, float *dbias, void *stream);
 
+/* The isotropic scale head's tail (modules/decoders.py:88-94, the `.repeat(1, 3)` of :96-98): z [N,1] -> scales [N,3] = log(exp(z) + 1)
+ * and scales_aux [N,3] = z, every row three times; backward dz [N,1] = (sum_c dscales) e^z / (e^z + 1) + sum_c daux (either may be
+ * NULL).  One launch each way. */
+int sg_scales_head_forward(int N, const float *z, float *scales_out, float *aux_out, void *stream);
+int sg_scales_head_backward(int N, const float *z, const float *dscales, const float *daux, float *dz, void *stream);
+
 /* One decoder layer (nn.Linear + activation, modules/decoders.py:41-49, 75-94) as ONE kernel each way on the matrix cores
  * (v_mfma_f32_32x32x2_f32, fp32): bias and activation in the GEMM's epilogue, the activation derivative in the prologue of
  * the input-gradient GEMM.  x [N,Cin], W [Cout,Cin] (nn.Linear.weight), bias [Cout] | NULL, 1 <= Cin, Cout <= 128; `act`

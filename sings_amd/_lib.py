@@ -60,7 +60,7 @@ EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_ras
            "sg_kernel_name", "sg_skin_ws_floats", "sg_skinned_forward", "sg_skinned_backward",
            "sg_photo_loss_ws_bytes", "sg_photo_loss", "sg_photo_loss_backward", "sg_reg_ws_bytes", "sg_region_laplacian", "sg_rows_laplacian", "sg_mesh_edge_loss",
            "sg_l2norm_reg", "sg_knn_ws_bytes", "sg_gaussian_edge_loss", "sg_gaussian_edge_prepare", "sg_gaussian_edge_finish", "sg_joint_transforms", "sg_joint_transforms_backward", "sg_lbs_forward", "sg_lbs_backward", "sg_matrix_to_quaternion", "sg_matrix_to_quaternion_backward", "sg_rotation_convert", "sg_rotation_convert_backward", "sg_quaternion_multiply", "sg_quaternion_multiply_backward", "sg_triplane_ws_bytes", "sg_triplane_bwd_ws_bytes", "sg_triplane_forward",
-           "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward",
+           "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared", "sg_bias_act_ws_bytes", "sg_bias_act_forward", "sg_bias_act_backward", "sg_scales_head_forward", "sg_scales_head_backward",
            "sg_weight_grad_ws_bytes", "sg_weight_grad", "sg_linear_forward", "sg_linear_backward", "sg_linear_backward_accumulate", "sg_linear_backward_fan", "sg_copy_probe",
            "sg_frames_layout", "sg_rasterize_forward_frames", "sg_skinned_forward_frames", "sg_read_num_rendered_frames", "sg_photo_loss_backward_frames",
            "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
@@ -163,6 +163,8 @@ def load():
     lib.sg_bias_act_ws_bytes.argtypes = [i32, i32]; lib.sg_bias_act_ws_bytes.restype = sz
     lib.sg_bias_act_forward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp]
     lib.sg_bias_act_backward.argtypes = [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]
+    lib.sg_scales_head_forward.argtypes = [i32, vp, vp, vp, vp]; lib.sg_scales_head_forward.restype = C.c_int
+    lib.sg_scales_head_backward.argtypes = [i32, vp, vp, vp, vp, vp]; lib.sg_scales_head_backward.restype = C.c_int
     for f in ("sg_triplane_forward", "sg_triplane_backward", "sg_triplane_backward_prepare", "sg_triplane_backward_prepared",
               "sg_bias_act_forward", "sg_bias_act_backward"):
         getattr(lib, f).restype = C.c_int

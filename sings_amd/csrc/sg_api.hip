@@ -744,6 +744,23 @@ extern "C" int sg_triplane_backward_prepared(const SgTriplane *tp, int N, const 
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : sg_fail("sg_triplane_backward_prepared", e);
 }
+// (declared here, not in sg_common.h: that header is one of the sources the committed PMC profiles are keyed on)
+void sg_launch_scales_head(int N, const float *z, float *scales, float *aux, const float *dscales, const float *daux, float *dz,
+                           hipStream_t st);
+extern "C" int sg_scales_head_forward(int N, const float *z, float *scales_out, float *aux_out, void *stream)
+{
+    if (N <= 0 || !z || !scales_out || !aux_out) return sg_fail("sg_scales_head_forward: bad argument", hipSuccess);
+    sg_launch_scales_head(N, z, scales_out, aux_out, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_scales_head_forward", e);
+}
+extern "C" int sg_scales_head_backward(int N, const float *z, const float *dscales, const float *daux, float *dz, void *stream)
+{
+    if (N <= 0 || !z || !dz || (!dscales && !daux)) return sg_fail("sg_scales_head_backward: bad argument", hipSuccess);
+    sg_launch_scales_head(N, z, nullptr, nullptr, dscales, daux, dz, (hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : sg_fail("sg_scales_head_backward", e);
+}
 extern "C" size_t sg_bias_act_ws_bytes(int N, int C) { return sg_bias_act_ws_bytes_impl(N > 0 ? N : 1, C > 0 ? C : 1); }
 extern "C" int sg_bias_act_forward(int N, int C, int act, const float *y, const float *bias, const float *row_offset,
                                    float *z_out, float *h_out, void *stream)

@@ -619,6 +619,40 @@ void sg_launch_bias_act_bwd(int N, int C, int act, const float *z, const float *
     if (dbias) hipLaunchKernelGGL(sg_colsum_reduce_kernel, dim3((C + 127) / 128), dim3(128), 0, st, partial, nb, C, dbias);
 }
 
+// ---- the isotropic scale head's tail (decoders.py:88-94 + sings_hybrid.py:286-292): scales = log(exp(z) + 1) and scales_aux = z,
+// both repeated to three columns -- ONE launch each way instead of an activation kernel and two repeats forward, a row-sum reduction,
+// an activation-gradient kernel and two additions backward (each 5-9 us on the training step's serial chain).
+__global__ void __launch_bounds__(256)
+sg_scales_head_fwd_kernel(int N, const float *__restrict__ z, float *__restrict__ scales, float *__restrict__ aux)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const float zz = z[n], h = logf(expf(zz) + 1.0f);
+    scales[3 * (size_t)n] = h; scales[3 * (size_t)n + 1] = h; scales[3 * (size_t)n + 2] = h;
+    aux[3 * (size_t)n] = zz; aux[3 * (size_t)n + 1] = zz; aux[3 * (size_t)n + 2] = zz;
+}
+// dz = (sum_c dscales[n,c]) e^z / (e^z + 1) + sum_c daux[n,c]   (either gradient may be missing)
+__global__ void __launch_bounds__(256)
+sg_scales_head_bwd_kernel(int N, const float *__restrict__ z, const float *__restrict__ dscales, const float *__restrict__ daux,
+                          float *__restrict__ dz)
+{
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float d = 0.0f;
+    if (dscales) {
+        const float e = expf(z[n]);
+        d = ((dscales[3 * (size_t)n] + dscales[3 * (size_t)n + 1]) + dscales[3 * (size_t)n + 2]) * (e / (e + 1.0f));
+    }
+    if (daux) d += (daux[3 * (size_t)n] + daux[3 * (size_t)n + 1]) + daux[3 * (size_t)n + 2];
+    dz[n] = d;
+}
+void sg_launch_scales_head(int N, const float *z, float *scales, float *aux, const float *dscales, const float *daux, float *dz,
+                           hipStream_t st)
+{
+    if (dz) hipLaunchKernelGGL(sg_scales_head_bwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, z, dscales, daux, dz);
+    else hipLaunchKernelGGL(sg_scales_head_fwd_kernel, dim3((N + 255) / 256), dim3(256), 0, st, N, z, scales, aux);
+}
+
 // ---- weight / bias gradient of a decoder layer: dW [Cout,Cin] = dz^T x, db [Cout] = column sums of dz ---------------
 // A GEMM whose reduction dimension is the N ~ 10^5 points and whose output is at most 128 x 128: the library kernels
 // chosen for this shape ran at 330-430 us per layer (150 k points).  Here a workgroup owns a slice of rows and the whole

@@ -606,12 +606,47 @@ class GeometryDecoder(nn.Module):
         s1, xyz_offsets = outs[0], outs[1]
         rotations = outs[2] if not self.isotropic else None
         scales_aux = linear_act(s1, self.scales[2])
-        # scales = log(exp(scales_aux) + 1): the activation kernel on the bias-added value (identity GEMM avoided)
-        scales = _Act.apply(scales_aux, ACT_SOFTPLUS_REF)
-        if scales_aux.shape[-1] == 1:
-            scales_aux = scales_aux.repeat(1, 3)
-            scales = scales.repeat(1, 3)
+        if scales_aux.shape[-1] == 1 and scales_aux.is_cuda:
+            # isotropic: softplus and the two `.repeat(1, 3)` in one launch each way (sg_scales_head_*)
+            scales, scales_aux = _ScalesHead.apply(scales_aux)
+        else:
+            # scales = log(exp(scales_aux) + 1): the activation kernel on the bias-added value (identity GEMM avoided)
+            scales = _Act.apply(scales_aux, ACT_SOFTPLUS_REF)
+            if scales_aux.shape[-1] == 1:
+                scales_aux = scales_aux.repeat(1, 3)
+                scales = scales.repeat(1, 3)
         return {'xyz_offsets': xyz_offsets, 'rotations': rotations, 'scales': scales, 'scales_aux': scales_aux}
+
+
+class _ScalesHead(torch.autograd.Function):
+    """z [N,1] -> (scales [N,3] = softplus(z) three times, scales_aux [N,3] = z three times), decoders.py:88-98."""
+
+    @staticmethod
+    def forward(ctx, z):
+        lib = _lib.load()
+        z = z.contiguous().float()
+        dev, N = z.device, int(z.shape[0])
+        scales = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        aux = torch.empty_like(scales)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_scales_head_forward(N, _ptr(z), _ptr(scales), _ptr(aux), _stream(dev)), "scales head forward")
+        ctx.save_for_backward(z)
+        ctx.set_materialize_grads(False)                         # (an output nobody differentiates: None, not a zero-filled tensor)
+        return scales, aux
+
+    @staticmethod
+    def backward(ctx, dscales, daux):
+        lib = _lib.load()
+        (z,) = ctx.saved_tensors
+        dev, N = z.device, int(z.shape[0])
+        if dscales is None and daux is None:
+            return None
+        ds = dscales.contiguous().float() if dscales is not None else None
+        da = daux.contiguous().float() if daux is not None else None
+        dz = torch.empty_like(z)
+        with torch.cuda.device(dev):
+            _lib.check(lib.sg_scales_head_backward(N, _ptr(z), _ptr(ds), _ptr(da), _ptr(dz), _stream(dev)), "scales head backward")
+        return dz
 
 
 class _Act(torch.autograd.Function):
