@@ -528,6 +528,61 @@ sg_linear_wide_kernel(int N, int CK, int CO, int act, const float *__restrict__ 
     }
 }
 
+// ---- skinny heads, forward (xyz offsets 128 -> 3, rotations -> 6, the scale head's last layer 128 -> 1, opacity 64 -> 1) ---------
+// A 32-column MFMA tile of which 1-6 columns are used is a bad way to stream [N,Cin]: the narrow kernel above moved 2.6 TB/s on
+// these (25-30 us per head at 150 k points, all on the training step's serial chain).  Here the product is what it is -- CO dot
+// products per row: L = Cin / 8 lanes share a row (two 16-byte loads each: a row is two contiguous 16 L-byte segments per load
+// instruction), the CO partial dots are summed over the L lanes with log2 L shuffles, U rows groups are in flight per wave.
+template <int CO, int L>                      // L = 8 (Cin = 64) or 16 (Cin = 128)
+__global__ void __launch_bounds__(256)
+sg_linear_skinny_kernel(int N, int act, const float *__restrict__ X, const float *__restrict__ W, const float *__restrict__ bias,
+                        const float *__restrict__ row_offset, float *__restrict__ out)
+{
+    constexpr int CIN = 8 * L, RPW = 64 / L, U = 4;                        // rows per wave and load round; rounds in flight
+    const int lane = threadIdx.x & 63, sub = lane % L, rg = lane / L;
+    const int wave = (blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = (gridDim.x * 256) >> 6;
+    float w[CO][8];
+#pragma unroll
+    for (int c = 0; c < CO; c++) {
+        const float4 a = *(const float4 *)(W + (size_t)c * CIN + 4 * sub), b = *(const float4 *)(W + (size_t)c * CIN + 4 * (sub + L));
+        w[c][0] = a.x; w[c][1] = a.y; w[c][2] = a.z; w[c][3] = a.w; w[c][4] = b.x; w[c][5] = b.y; w[c][6] = b.z; w[c][7] = b.w;
+    }
+    float bv[CO];
+#pragma unroll
+    for (int c = 0; c < CO; c++) bv[c] = bias ? bias[c] : 0.0f;
+    const unsigned xbytes = (unsigned)N * CIN * 4u;
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void *)X, 0, xbytes, 0x00020000);     // rows beyond N read as zero
+    for (int r0 = wave * (RPW * U); r0 < N; r0 += nwaves * (RPW * U)) {
+        float4 xa[U], xb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int off = ((r0 + u * RPW + rg) * CIN + 4 * sub) * 4;
+            const auto va = __builtin_amdgcn_raw_buffer_load_b128(rsx, off, 0, 0), vb = __builtin_amdgcn_raw_buffer_load_b128(rsx, off + 16 * L, 0, 0);
+            xa[u] = make_float4(__uint_as_float(va[0]), __uint_as_float(va[1]), __uint_as_float(va[2]), __uint_as_float(va[3]));
+            xb[u] = make_float4(__uint_as_float(vb[0]), __uint_as_float(vb[1]), __uint_as_float(vb[2]), __uint_as_float(vb[3]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            float d[CO];
+#pragma unroll
+            for (int c = 0; c < CO; c++) {
+                float t = xa[u].x * w[c][0];
+                t = fmaf(xa[u].y, w[c][1], t); t = fmaf(xa[u].z, w[c][2], t); t = fmaf(xa[u].w, w[c][3], t);
+                t = fmaf(xb[u].x, w[c][4], t); t = fmaf(xb[u].y, w[c][5], t); t = fmaf(xb[u].z, w[c][6], t); t = fmaf(xb[u].w, w[c][7], t);
+#pragma unroll
+                for (int o = L / 2; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+                d[c] = t;
+            }
+            const int n = r0 + u * RPW + rg;
+            if (sub == 0 && n < N) {
+                const float ro = (act == 2 && row_offset) ? row_offset[n] : 0.0f;
+#pragma unroll
+                for (int c = 0; c < CO; c++) out[(size_t)n * CO + c] = sgl_act(act, d[c] + bv[c], ro);
+            }
+        }
+    }
+}
+
 template <bool BWD>
 static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, const float *Z, const float *Mw, int s_co, int s_ck,
                             const float *bias, const float *row_offset, float *out0, float *out1, hipStream_t st, int accum = 0,
@@ -621,6 +676,21 @@ static int sg_linear_launch(int N, int CK, int CO, int act, const float *X, cons
 int sg_launch_linear_fwd(int N, int Cin, int Cout, int act, const float *x, const float *W, const float *bias,
                          const float *row_offset, float *z_out, float *h_out, hipStream_t st)
 {
+    // skinny heads: a streaming dot-product kernel (no aux output: act 0 needs none, the sigmoid's aux is its output)
+    if (N > 0 && Cout <= 6 && (Cin == 64 || Cin == 128) && (act == 0 || act == 2) && !z_out && (long long)N * Cin * 4 < 0x7fffffffLL) {
+        const int rows_per_wg = 4 * (Cin == 128 ? 4 : 8) * 4;
+        int grid = (N + rows_per_wg - 1) / rows_per_wg;
+        if (grid > 2048) grid = 2048;
+#define SGL_SK(COv)                                                                                                        \
+        do {                                                                                                              \
+            if (Cin == 128) hipLaunchKernelGGL((sg_linear_skinny_kernel<COv, 16>), dim3(grid), dim3(256), 0, st, N, act, x, W, bias, row_offset, h_out); \
+            else hipLaunchKernelGGL((sg_linear_skinny_kernel<COv, 8>), dim3(grid), dim3(256), 0, st, N, act, x, W, bias, row_offset, h_out);            \
+        } while (0)
+        switch (Cout) { case 1: SGL_SK(1); break; case 2: SGL_SK(2); break; case 3: SGL_SK(3); break; case 4: SGL_SK(4); break;
+                        case 5: SGL_SK(5); break; default: SGL_SK(6); break; }
+#undef SGL_SK
+        return 0;
+    }
     return sg_linear_launch<false>(N, Cin, Cout, act, x, nullptr, W, Cin, 1, bias, row_offset, h_out, z_out, st);
 }
 // backward: dh, aux [N,Cout] (act 1: the forward's aux; act 2: h; act 3: z), W [Cout,Cin] -> dz_out [N,Cout] = dh * act'

@@ -206,7 +206,9 @@ def test_triplane_plane_configurations(res, multires):
 
 @pytest.mark.parametrize("N,Cin,Cout,act", [(1000, 96, 128, 1), (4097, 128, 128, 1), (333, 128, 3, 0), (2050, 128, 6, 0),
                                             (777, 128, 1, 0), (5000, 96, 64, 1), (1234, 64, 64, 1), (999, 64, 48, 0),
-                                            (640, 64, 1, 2), (31, 128, 128, 3), (50000, 128, 128, 1)])
+                                            (640, 64, 1, 2), (31, 128, 128, 3), (50000, 128, 128, 1),
+                                            # the skinny streaming kernel (Cout <= 6, Cin 64 | 128) at the training size, ragged
+                                            (150001, 128, 3, 0), (150000, 64, 1, 2), (70003, 128, 6, 0), (13, 64, 4, 0)])
 def test_fused_linear_layer_kernels_vs_torch(N, Cin, Cout, act):
     """sg_linear_forward / sg_linear_backward (one MFMA kernel per layer and direction, bias + activation fused) against the
     same layer in torch fp64 on the CPU: h, the saved pre-activation, dx, dW, db."""
