@@ -724,7 +724,9 @@ def leg_train(a, ctx):
     torch.manual_seed(0)
     cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [64, 64, 64],
            'multires': [1, 2, 4]}                                              # human_complex.yaml:38-43
-    tri = HexPlaneField(cfg, bounds=1.2, device=dev); geo = GeometryDecoder(96).to(dev); app = AppearanceDecoder(96).to(dev)
+    # (feature-minor planes: the reference's shapes and state_dict, channels_last in memory -- used in place by the sampling kernels)
+    tri = HexPlaneField(cfg, bounds=1.2, device=dev, feature_minor=not os.environ.get("SINGS_PLANES_NCHW"))
+    geo = GeometryDecoder(96).to(dev); app = AppearanceDecoder(96).to(dev)
     with torch.no_grad():                                                      # millimetre-sized splats, tiny offsets
         geo.scales[2].bias.fill_(-5.3); geo.scales[2].weight.mul_(0.1)
         geo.xyz_offsets.weight.mul_(0.01); geo.xyz_offsets.bias.zero_()

@@ -50,7 +50,7 @@ class SgLinearSide(C.Structure):
 
 class SgTriplane(C.Structure):
     _fields_ = [("n_scales", C.c_int), ("feat", C.c_int), ("res", (C.c_int * 3) * 4), ("planes", (C.c_void_p * 3) * 4),
-                ("aabb", (C.c_float * 3) * 2)]
+                ("aabb", (C.c_float * 3) * 2), ("feature_minor", C.c_int), ("reserved", C.c_int)]
 
 
 # every symbol include/sings_hip.h declares
@@ -66,7 +66,7 @@ EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_ras
            "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
            "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames")
 NUM_KERNELS = 8
-ABI_VERSION = 5                      # SG_ABI_VERSION
+ABI_VERSION = 6                      # SG_ABI_VERSION
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT

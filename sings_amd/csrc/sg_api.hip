@@ -28,7 +28,7 @@ static int sg_fail(const char *what, hipError_t e)
         }                                                                    \
     } while (0)
 
-extern "C" const char *sg_version(void) { return "sings_hip 0.5 (gfx950, abi 5)"; }
+extern "C" const char *sg_version(void) { return "sings_hip 0.6 (gfx950, abi 6)"; }
 extern "C" int sg_abi_version(void) { return SG_ABI_VERSION; }
 extern "C" const char *sg_last_error(void) { return g_err; }
 

@@ -24,7 +24,9 @@
 struct SgTpDev {                       // device-side view
     int n_scales;
     int res[SG_TP_MAXS][3];
-    size_t fm_off[SG_TP_MAXS][3];      // float offset of the texel-major copy of plane (s, c) in the workspace
+    long long fm_off[SG_TP_MAXS][3];   // float offset of the texel-major copy of plane (s, c) from the base pointer the kernel gets
+    long long gm_off[SG_TP_MAXS][3];   // the same for the gradient planes (backward).  Feature-minor planes (SgTriplane.feature_minor):
+                                       // the base is plane (0, 0) / its gradient, the offsets are address differences (any sign)
     float a0[3], ascale[3];            // normalised = (p - a0) * ascale - 1
 };
 __constant__ int sg_comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };   // itertools.combinations(range(3), 2)
@@ -309,7 +311,7 @@ sg_tp_sorted_scatter_kernel(SgTpDev d, int N, const float *__restrict__ G, const
     const int k1 = min(k0 + SG_TP_RUN, N);
     const float *Gp = G + (size_t)sc * N * 32;
     const float4 *rp = cellrec + (size_t)sc * N;
-    float *gp = gfm + d.fm_off[s][c];
+    float *gp = gfm + d.gm_off[s][c];
     const int W = d.res[s][sg_comb[c][0]];
     uint32_t c00 = 0xffffffffu, c11 = 0;
     float acc00 = 0.0f, acc01 = 0.0f, acc10 = 0.0f, acc11 = 0.0f;
@@ -448,7 +450,7 @@ static size_t sg_tp_layout(const SgTriplane *tp, SgTpDev *d)
     for (int s = 0; s < tp->n_scales; s++)
         for (int c = 0; c < 3; c++) {
             const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
-            d->fm_off[s][c] = o;
+            d->fm_off[s][c] = (long long)o; d->gm_off[s][c] = (long long)o;
             o += (size_t)tp->res[s][comb[c][0]] * tp->res[s][comb[c][1]] * SG_TP_FEAT;
             o = (o + 63) & ~(size_t)63;
         }
@@ -486,12 +488,21 @@ static void sg_tp_upload(const SgTriplane *tp, const SgTpDev &d, float *fm, hipS
         }
     hipLaunchKernelGGL(sg_plane_to_fm_kernel, dim3((maxHW + 31) / 32, tp->n_scales * 3), dim3(256), 0, st, P);
 }
+// feature-minor planes ([1, F, H, W] tensors in channels_last memory format = [H][W][F]): the kernels read them in place
+static const float *sg_tp_direct(const SgTriplane *tp, SgTpDev *d)
+{
+    const float *base = tp->planes[0][0];
+    for (int s = 0; s < tp->n_scales; s++)
+        for (int c = 0; c < 3; c++) d->fm_off[s][c] = (long long)(tp->planes[s][c] - base);
+    return base;
+}
 void sg_launch_triplane_fwd(const SgTriplane *tp, int N, const float *xyz, void *ws, float *feats, hipStream_t st)
 {
     SgTpDev d;
     sg_tp_layout(tp, &d);
-    float *fm = (float *)ws;
-    sg_tp_upload(tp, d, fm, st);
+    const float *fm = (const float *)ws;
+    if (tp->feature_minor) fm = sg_tp_direct(tp, &d);        // the planes ARE texel-major: no copy
+    else sg_tp_upload(tp, d, (float *)ws, st);
     hipLaunchKernelGGL(sg_triplane_fwd_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, feats);
 }
 static void sg_tp_sort_layout(const SgTriplane *tp, SgTpSort *g, size_t *cell_words, size_t *bsum_words)
@@ -554,12 +565,12 @@ int sg_launch_triplane_bwd_prepare(const SgTriplane *tp, int N, const float *xyz
 {
     SgTpDev d; SgTpSort g; SgTpBwdWs w; size_t cw;
     const size_t floats = sg_tp_bwd_carve(tp, N, ws, &d, &g, &w, &cw);
-    sg_tp_upload(tp, d, w.fm, st);                            // (parameters may have changed since the forward call)
+    if (!tp->feature_minor) sg_tp_upload(tp, d, w.fm, st);    // (parameters may have changed since the forward call)
     sg_zero_async(w.count, cw * 4, st);
     const int nb = (N + 255) / 256;
     int max_keys = 0;
     for (int c = 0; c < 3; c++) max_keys = g.nkeys[c] > max_keys ? g.nkeys[c] : max_keys;
-    sg_zero_async(w.gfm, floats * 4, st);
+    if (!tp->feature_minor) sg_zero_async(w.gfm, floats * 4, st);      // (feature-minor: the caller's gradient planes, zeroed by the caller)
     const int nkb = max_keys / 1024 + 1;
     hipLaunchKernelGGL(sg_tp_cell_count_kernel, dim3(nb, 3), dim3(256), 0, st, d, g, N, xyz, w.count, w.keys, w.rank);
     hipLaunchKernelGGL(sg_tp_cell_bsum_kernel, dim3(nkb, 3), dim3(256), 0, st, g, w.count, w.bsum);
@@ -573,10 +584,20 @@ int sg_launch_triplane_bwd_run(const SgTriplane *tp, int N, const float *xyz, vo
     SgTpDev d; SgTpSort g; SgTpBwdWs w; size_t cw;
     sg_tp_bwd_carve(tp, N, ws, &d, &g, &w, &cw);
     const int comb[3][2] = { { 0, 1 }, { 0, 2 }, { 1, 2 } };
-    hipLaunchKernelGGL(sg_tp_bwd_point_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, w.fm, dfeats, w.rank, w.G, w.cellrec,
+    const float *fm = w.fm;
+    float *gfm = w.gfm;
+    if (tp->feature_minor) {
+        // planes and gradient planes in place: no texel-major copies (the caller zero-filled dplanes)
+        fm = sg_tp_direct(tp, &d);
+        gfm = dplanes[0][0];
+        for (int s = 0; s < tp->n_scales; s++)
+            for (int c = 0; c < 3; c++) d.gm_off[s][c] = (long long)(dplanes[s][c] - gfm);
+    }
+    hipLaunchKernelGGL(sg_tp_bwd_point_kernel, dim3((N + 7) / 8), dim3(256), 0, st, d, N, xyz, fm, dfeats, w.rank, w.G, w.cellrec,
                        dxyz);
     hipLaunchKernelGGL(sg_tp_sorted_scatter_kernel, dim3((N + 8 * SG_TP_RUN - 1) / (8 * SG_TP_RUN), tp->n_scales * 3),
-                       dim3(256), 0, st, d, N, w.G, w.cellrec, w.gfm);
+                       dim3(256), 0, st, d, N, w.G, w.cellrec, gfm);
+    if (tp->feature_minor) return 0;
     SgTpPlanes P;
     int maxHW = 0;
     for (int s = 0; s < tp->n_scales; s++)

@@ -394,6 +394,61 @@ def test_triplane_backward_prepared_early_or_inline():
         _close(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="plane gradient")
 
 
+@pytest.mark.parametrize("early", [False, True])
+@pytest.mark.parametrize("arena", [False, True])
+def test_feature_minor_planes_are_used_in_place(early, arena):
+    """HexPlaneField(feature_minor=True): the planes keep the reference's shape [1, F, H, W] but live in channels_last memory
+    ([H][W][F]); the kernels read them and write their gradients in place (SgTriplane.feature_minor).  Same features bit for bit,
+    same point gradients bit for bit, plane gradients to rounding (float atomics) as the plain layout -- with the preparation early
+    or inline, with and without a gradient arena; state_dict round trip unchanged; p.grad has the parameter's layout."""
+    from sings_amd import decode
+    dev = _dev()
+    torch.manual_seed(21)
+    cfg = {'grid_dimensions': 2, 'input_coordinate_dim': 3, 'output_coordinate_dim': 32, 'resolution': [24, 20, 28], 'multires': [1, 2, 4]}
+    f0 = decode.HexPlaneField(cfg, bounds=1.2, device=dev)
+    f1 = decode.HexPlaneField(cfg, bounds=1.2, device=dev, feature_minor=True)
+    f1.load_state_dict(f0.state_dict())
+    for (k0, v0), (k1, v1) in zip(f0.state_dict().items(), f1.state_dict().items()):
+        assert k0 == k1 and v0.shape == v1.shape and torch.equal(v0, v1)
+    planes1 = [p for p in f1.parameters() if p.requires_grad]
+    assert all(p.is_contiguous(memory_format=torch.channels_last) and not p.is_contiguous() for p in planes1)
+    x0 = (torch.rand(40000, 3, device=dev) * 2.6 - 1.3)                       # some points beyond the box: border clamp
+    with torch.no_grad():
+        y0, y1 = f0(x0), f1(x0)
+    assert torch.equal(y0, y1)
+    g = torch.randn_like(y0)
+
+    def grads(f):
+        params = [p for p in f.parameters() if p.requires_grad]
+        for p in params:
+            p.grad = None
+        views = None
+        if arena:
+            flat = torch.full((sum(p.numel() for p in params),), float("nan"), device=dev)
+            views = decode.set_gradient_arena(params, flat)
+        try:
+            x = x0.clone().requires_grad_(True)
+            f(x).backward(g)
+            torch.cuda.synchronize()
+            if arena:
+                for p, v in zip(params, views):
+                    assert p.grad.data_ptr() == v.data_ptr() and p.grad.stride() == p.stride()
+            return x.grad.clone(), [p.grad.clone() for p in params]
+        finally:
+            decode.set_gradient_arena(None, None)
+
+    try:
+        decode.prepare_triplane_backward_early(early)
+        dx0, dp0 = grads(f0)
+        dx1, dp1 = grads(f1)
+    finally:
+        decode._TP["mode"] = None
+    assert torch.equal(dx0, dx1)
+    for a, b, p in zip(dp0, dp1, planes1):
+        assert b.shape == a.shape and b.stride() == p.stride()
+        _close(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-4, atol_scale=2e-6, what="plane gradient (feature-minor)")
+
+
 def test_gradient_arena_accumulates_like_plain_autograd():
     """with a gradient arena registered, a SECOND backward without a reset in between (micro-batch accumulation,
     zero_grad(set_to_none=False)) wrote the new gradient over p.grad's own memory and autograd then added the slot to itself:
