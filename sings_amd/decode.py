@@ -519,8 +519,8 @@ class _LinearFan(torch.autograd.Function):
         """Layer 0 wide and every other layer a narrow head (<= 16 columns together, at most two, act none | sigmoid): their input
         gradients in ONE kernel (sg_linear_backward_fan).  None: the per-layer path."""
         n = len(ctx.acts)
-        if not (2 <= n <= 3) or any(d is None for d in dhs) or (int(x.shape[1]) & 31):
-            return None
+        if not (2 <= n <= 3) or any(d is None for d in dhs) or (int(x.shape[1]) & 31) or int(x.shape[0]) > 3_000_000:
+            return None                                          # (the kernel's 32-bit byte offsets: N + look-ahead rows < 2^31 / 576)
         couts = [int(ctx.saved_tensors[1 + 2 * i].shape[0]) for i in range(n)]
         if couts[0] & 3 or sum(couts[1:]) > 16 or any(a not in (ACT_NONE, ACT_SIGMOID) for a in ctx.acts[1:]):
             return None
