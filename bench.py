@@ -1310,6 +1310,11 @@ def secondary_legs(a, ctx, head):
         sec["dropin_autograd_ms_per_view"] = sec["dropin_autograd"]["ms_per_view"]
     except Exception as e:
         sec["dropin_autograd"] = {"error": f"{type(e).__name__}: {e}"}
+    if isinstance(sec.get("train_step_K16"), dict) and sec["train_step_K16"].get("parity") is None:
+        # (same model, same kernels and frame 0 as train_step_K1, whose parity block stands for both; the chunk itself:)
+        sec["train_step_K16"]["parity"] = {"see": "train_step_K1.parity (same decode, frame 0 of the chunk)",
+                                           "chunk": "tests/test_gpu_train_step.py::test_a_step_over_a_chunk_of_frames_equals_the_"
+                                                    "sum_of_one_frame_steps (loss and every gradient of a K-frame step = the sum of K one-frame steps)"}
     if "train_step_ms_one_view" in sec.get("cfg4_avatar", {}):
         sec["cfg4_avatar"]["frames_per_s_one_frame_per_step"] = 1e3 / sec["cfg4_avatar"]["train_step_ms_one_view"]
     _release()
