@@ -691,7 +691,10 @@ typedef float sg_v16f __attribute__((ext_vector_type(16)));
 // Round 2: every load is a BUFFER load on a descriptor of the workgroup's own row range -- rows beyond it read as zero, so the
 // loop has no bounds branches at all and the compiler can count its s_waitcnt vmcnt(n) (with a branch per load it fell back to
 // vmcnt(0) right behind the look-ahead loads, which therefore never overlapped anything).
-template <int TI, int RR>
+// SPLIT (cout_pad <= 64: the 64- and 48-output layers): only two waves own output rows, so the four waves form two PAIRS that share a
+// round's RR rows -- pair g multiplies rows [g RR/2, (g + 1) RR/2) -- and leave TWO partial slabs per workgroup (the reduce kernel
+// sums 2 x as many): 43.5 -> ~25 us for dW [64 x 96] at 150 k points, where two of the four matrix cores of a CU used to idle.
+template <int TI, int RR, bool SPLIT>
 __global__ void __launch_bounds__(256)
 sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const float *__restrict__ x,
                 float *__restrict__ partial, float *__restrict__ bpartial, int cout_pad, int chunk)
@@ -700,8 +703,11 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     // round) instead of being read from L2/HBM by every wave (4x the traffic made the direct version bandwidth-bound)
     __shared__ float sX[2][RR][TI * 32 + 4];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const bool active = 32 * wave < cout_pad;
-    const int o = 32 * wave + (lane & 31), half = lane >> 5;
+    const int wv = SPLIT ? (wave & 1) : wave, grp = SPLIT ? (wave >> 1) : 0;           // output-row block, row group of the round
+    constexpr int NU = SPLIT ? RR / 4 : RR / 2;                                        // row pairs per wave and round
+    const int u0 = grp * NU;
+    const bool active = 32 * wv < cout_pad;
+    const int o = 32 * wv + (lane & 31), half = lane >> 5;
     constexpr int CIN = TI * 32;
     constexpr int F4 = RR * CIN / 4;          // float4 elements of one slab
     static_assert(F4 % 256 == 0, "a slab is a whole number of float4 per thread");
@@ -728,16 +734,16 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     // to the other LDS buffer at the end of the round) and the loads of round n + 2 are in flight into the other --
     // a round's MFMAs (0.85 us) are shorter than a memory round trip, one round of look-ahead left the waves waiting
     float4 xrE[PER], xrO[PER];
-    float anE[RR / 2], anO[RR / 2];
-    auto fetch = [&](float4 (&xr)[PER], float (&an)[RR / 2], int n) {
+    float anE[NU], anO[NU];
+    auto fetch = [&](float4 (&xr)[PER], float (&an)[NU], int n) {
 #pragma unroll
         for (int q = 0; q < PER; q++) {
             const auto v = __builtin_amdgcn_raw_buffer_load_b128(rsx, xoff[q] + n * (CIN * 4), 0, 0);
             xr[q] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
 #pragma unroll
-        for (int u = 0; u < RR / 2; u++)
-            an[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsz, zoff + (n + 2 * u) * (Cout * 4), 0, 0));
+        for (int u = 0; u < NU; u++)
+            an[u] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsz, zoff + (n + 2 * (u0 + u)) * (Cout * 4), 0, 0));
     };
     auto stash = [&](const float4 (&xr)[PER], int buf) {
 #pragma unroll
@@ -747,18 +753,18 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
         }
     };
     // round n: a-values from `cur` (its x rows are in sX[buf]); `oth` holds round n + 1
-    auto round = [&](float4 (&xc)[PER], float (&ac)[RR / 2], const float4 (&xo)[PER], int n, int buf) {
-        float a[RR / 2];
+    auto round = [&](float4 (&xc)[PER], float (&ac)[NU], const float4 (&xo)[PER], int n, int buf) {
+        float a[NU];
 #pragma unroll
-        for (int u = 0; u < RR / 2; u++) a[u] = ac[u];
+        for (int u = 0; u < NU; u++) a[u] = ac[u];
         fetch(xc, ac, n + 2 * RR);
         if (active) {
 #pragma unroll
-            for (int u = 0; u < RR / 2; u++) {
+            for (int u = 0; u < NU; u++) {
                 bsum += a[u];
 #pragma unroll
                 for (int t = 0; t < TI; t++)
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * u + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], sX[buf][2 * (u0 + u) + half][32 * t + (lane & 31)], acc[t], 0, 0, 0);
             }
         }
         stash(xo, buf ^ 1);
@@ -777,16 +783,17 @@ sg_wgrad_kernel(int N, int Cout, int Cin, const float *__restrict__ dz, const fl
     }
     if (!active) return;
     // D layout of the 32x32 tile: lane l, register r -> row 8 * (r / 4) + 4 * (l / 32) + r % 4, column l % 32
-    float *pw = partial + (size_t)blockIdx.x * cout_pad * Cin;
+    const size_t slab = SPLIT ? (size_t)blockIdx.x * 2 + grp : (size_t)blockIdx.x;      // (SPLIT: one slab per wave pair)
+    float *pw = partial + slab * cout_pad * Cin;
 #pragma unroll
     for (int t = 0; t < TI; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int i = 32 * wave + 8 * (r >> 2) + 4 * half + (r & 3);
+            const int i = 32 * wv + 8 * (r >> 2) + 4 * half + (r & 3);
             pw[(size_t)i * Cin + 32 * t + (lane & 31)] = acc[t][r];
         }
     bsum += __shfl_xor(bsum, 32, 64);
-    if (half == 0) bpartial[(size_t)blockIdx.x * cout_pad + o] = bsum;
+    if (half == 0) bpartial[slab * cout_pad + o] = bsum;
 }
 
 // Heads with <= 12 outputs (xyz offsets, rotations, scale, opacity): the product is a handful of dot products per input column --
@@ -911,7 +918,7 @@ static inline int sg_wg_chunk(int N, int rr)
     return c < 32 ? 32 : c;
 }
 static inline int sg_wg_count(int N) { const int n = (N + SG_WG_ROWS - 1) / SG_WG_ROWS; return n < 512 ? n : 512; }
-static inline int sg_wg_count_max(int N) { const int n = (N + 31) / 32; return n < 768 ? n : 768; }   // bound over both kernels
+static inline int sg_wg_count_max(int N) { const int n = 2 * ((N + 31) / 32); return n < 768 ? n : 768; }   // bound over the kernels' slab counts (SPLIT: two per workgroup)
 size_t sg_weight_grad_ws_bytes_impl(int N, int Cout, int Cin)
 {
     const size_t cp = (size_t)((Cout + 31) / 32) * 32;
@@ -938,9 +945,15 @@ int sg_launch_weight_grad(int N, int Cout, int Cin, const float *dz, const float
     } else {
         const int rr = ti == 4 ? 16 : 32, chunk = sg_wg_chunk(N, rr);
         nwg = (N + chunk - 1) / chunk;
-#define SG_WGK(T) hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32)>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp, chunk)
+        const bool split = cp <= 64;                          // two waves own output rows: the other pair shares the round's rows
+#define SG_WGK(T)                                                                                                                   \
+        do {                                                                                                                        \
+            if (split) hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32), true>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp, chunk); \
+            else hipLaunchKernelGGL((sg_wgrad_kernel<T, (T == 4 ? 16 : 32), false>), dim3(nwg), dim3(256), 0, st, N, Cout, Cin, dz, x, partial, bpartial, cp, chunk);    \
+        } while (0)
         switch (ti) { case 1: SG_WGK(1); break; case 2: SG_WGK(2); break; case 3: SG_WGK(3); break; default: SG_WGK(4); break; }
 #undef SG_WGK
+        if (split) nwg *= 2;                                  // (slabs for the reduce)
     }
     hipLaunchKernelGGL(sg_wgrad_reduce_kernel, dim3((Cout * Cin + Cout + 15) / 16), dim3(256), 0, st, partial, bpartial, nwg,
                        Cout, Cin, cp, dW, db);
