@@ -496,6 +496,43 @@ def linear_act(x, lin, act=ACT_NONE, row_offset=None):
     return _LinearAct.apply(x, lin.weight, lin.bias, act, row_offset)
 
 
+class _LinearActShared(torch.autograd.Function):
+    """A layer that shares its INPUT with other layers of the same `slot` (the tri-plane features read by both decoders' first
+    layers, sings_hybrid.py:259-262) without tying their backward passes together: whichever layer's backward runs first writes the
+    input gradient (and hands it to autograd), the others ADD theirs into that very tensor (sg_linear_backward_accumulate) and hand
+    autograd nothing -- one [N,Cin] gradient, no addition kernel, and each layer's backward runs as soon as ITS gradient is there.
+    (`linear_fan` needs all of them at once: in the training step the appearance decoder's first layer then waited for the geometry
+    decoder's, i.e. for the k-NN regulariser; here its 80 us run in that wait.)"""
+
+    @staticmethod
+    def forward(ctx, x, W, b, act, slot):
+        x = x.contiguous().float()
+        h, aux, Wc = _lin_fwd(x, W, b, act, None)
+        ctx.save_for_backward(x, Wc, aux if aux is not None else torch.empty(0, device=x.device))
+        ctx.act, ctx.has_b, ctx.slot = act, b is not None, slot
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, W, aux = ctx.saved_tensors
+        need_dw = ctx.needs_input_grad[1] or (ctx.has_b and ctx.needs_input_grad[2])
+        need_dx = ctx.needs_input_grad[0]
+        first = ctx.slot.get("dx") is None
+        can_acc = (int(x.shape[1]) & 31) == 0
+        if need_dx and not first and can_acc:
+            _, dW, db = _lin_bwd(x, W, aux, ctx.act, ctx.has_b, dh, True, need_dw, dx_into=ctx.slot["dx"])
+            dx = None                                            # (already inside the tensor the first layer handed over)
+        else:
+            dx, dW, db = _lin_bwd(x, W, aux, ctx.act, ctx.has_b, dh, need_dx, need_dw)
+            if need_dx and first and can_acc:
+                ctx.slot["dx"] = dx
+        return dx, dW, db, None, None
+
+
+def linear_act_shared(x, lin, act, slot):
+    return _LinearActShared.apply(x, lin.weight, lin.bias, act, slot)
+
+
 class _LinearFan(torch.autograd.Function):
     """Several layers reading the SAME activation (the decoder trunk and its heads, decoders.py:41-49, 75-94; the tri-plane
     features and the two decoders, sings_hybrid.py:259-262): forward = one sg_linear_forward per layer; backward: the first
@@ -733,8 +770,14 @@ def decode_attributes(xyz, triplane, geometry_dec, appearance_dec, thickness_fac
     decoder is issued -- autograd nodes the hook creates are visited after the appearance decoder's in the backward pass
     (sings_amd.train_step uses it to add the k-NN regulariser's gradient as late as possible)."""
     tri_feats = triplane(xyz)
-    # both decoders' first layers read the tri-plane features: one fan, one feature gradient
-    g1, a1 = linear_fan(tri_feats, [(geometry_dec.net[0], ACT_GELU, None), (appearance_dec.net[0], ACT_GELU, None)])
+    # both decoders' first layers read the tri-plane features: ONE feature gradient (the second layer to run its backward adds into
+    # the first one's), but two autograd nodes -- the appearance decoder's backward does not wait for the geometry decoder's
+    if tri_feats.is_cuda and torch.is_grad_enabled() and (int(tri_feats.shape[1]) & 31) == 0:
+        slot = {}
+        g1 = linear_act_shared(tri_feats, geometry_dec.net[0], ACT_GELU, slot)
+        a1 = linear_act_shared(tri_feats, appearance_dec.net[0], ACT_GELU, slot)
+    else:
+        g1, a1 = linear_fan(tri_feats, [(geometry_dec.net[0], ACT_GELU, None), (appearance_dec.net[0], ACT_GELU, None)])
     g = geometry_dec(tri_feats, first=g1)
     scales = g['scales']
     if thickness_factor != 1.0:

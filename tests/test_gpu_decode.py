@@ -330,6 +330,50 @@ def test_fan_backward_heads_ride_in_the_wide_kernel(N, Cin, couts, acts):
         assert torch.equal(g, q) or float((g - q).abs().max()) <= 1e-6 * float(q.abs().max())
 
 
+@pytest.mark.parametrize("order", ["first_then_second", "second_then_first", "only_second"])
+def test_layers_sharing_an_input_collect_one_gradient(order):
+    """decode.linear_act_shared: two layers on the same input as two autograd nodes with ONE input gradient -- whichever backward
+    runs first writes it, the other adds into that tensor and hands autograd nothing.  Same gradients as `linear_fan` (one node) in
+    either execution order, and with only one of the two layers under the loss."""
+    from sings_amd import decode
+    from sings_amd.decode import ACT_GELU
+    dev = _dev()
+    torch.manual_seed(31)
+    N, Cin = 20011, 96
+    l0, l1 = torch.nn.Linear(Cin, 128).to(dev), torch.nn.Linear(Cin, 64).to(dev)
+    x0 = torch.randn(N, Cin, device=dev)
+    u0, u1 = torch.randn(N, 128, device=dev), torch.randn(N, 64, device=dev)
+    params = list(l0.parameters()) + list(l1.parameters())
+
+    def run(shared):
+        for p in params:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if shared:
+            slot = {}
+            h0 = decode.linear_act_shared(x, l0, ACT_GELU, slot)
+            h1 = decode.linear_act_shared(x, l1, ACT_GELU, slot)
+        else:
+            h0, h1 = decode.linear_fan(x, [(l0, ACT_GELU, None), (l1, ACT_GELU, None)])
+        a, b = (h0 * u0).sum(), (h1 * u1).sum()
+        if order == "only_second":
+            b.backward()
+        elif order == "first_then_second" or not shared:
+            (a + b).backward()                                   # (autograd visits the younger node, h1's, first)
+        else:
+            # force the other execution order: h0's backward first, then h1's, in ONE pass
+            torch.autograd.backward([a, b.detach() * 0 + b], [torch.ones((), device=dev)] * 2)
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [None if p.grad is None else p.grad.clone() for p in params]
+
+    ref, got = run(False), run(True)
+    for r, g in zip(ref, got):
+        if r is None or g is None:                               # (a layer outside the loss: no gradient or a zero gradient)
+            assert all(t is None or float(t.abs().max()) == 0.0 for t in (r, g))
+            continue
+        _close(g.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="shared-input layers")
+
+
 def test_weight_gradients_on_a_side_stream_match_the_inline_ones():
     """decode.overlap_weight_grads(True): sg_weight_grad runs beside the backward chain and joins when backward() returns --
     bit-identical parameter gradients (the kernels are deterministic), also when the pass runs twice in a row."""
