@@ -81,7 +81,10 @@ typedef struct SgLayout {
  * a workspace size (round 4 inserted SgLayout.bin_rec_valid and enlarged the K-frame bwd_ws without a signal: ADVICE r4).  A C
  * caller checks `sg_abi_version() == SG_ABI_VERSION` once after dlopen; the Python host does (sings_amd/_lib.py).  New SgLayout
  * fields are appended from now on.  Workspaces are sized ONLY through sg_layout (one frame) / sg_frames_layout (K frames) -- never
- * as a multiple computed by the caller. */
+ * as a multiple computed by the caller.
+ * History: 5 = round 5's first tree; 6 = SgTriplane gained `feature_minor` (+ `reserved`) at its end, sg_weight_grad_ws_bytes grew
+ * (two partial slabs per workgroup for <= 64 outputs); entry points added since 5: sg_linear_backward_fan, sg_rows_laplacian,
+ * sg_scales_head_forward / _backward. */
 #define SG_ABI_VERSION 6
 int sg_abi_version(void);
 const char *sg_version(void);
