@@ -275,8 +275,7 @@ sg_bbox_partial_kernel(int N, const float *__restrict__ xyz, float *__restrict__
     }
 }
 // one workgroup: bounding box -> cell edge h with ~max_cells cells in the box, dims clamped
-__global__ void __launch_bounds__(256)
-sg_grid_setup_kernel(const float *__restrict__ partial, int nblocks, int N, int max_cells, SgGrid *__restrict__ grid)
+__device__ __forceinline__ void sg_grid_setup_body(const float *__restrict__ partial, int nblocks, int N, int max_cells, SgGrid *__restrict__ grid)
 {
     __shared__ float sMn[256][3], sMx[256][3];
     float mn[3] = { 3e38f, 3e38f, 3e38f }, mx[3] = { -3e38f, -3e38f, -3e38f };
@@ -316,8 +315,7 @@ __device__ __forceinline__ void sg_cell_of(const SgGrid &g, float x, float y, fl
     c[1] = min(max((int)((y - g.lo[1]) * g.inv_h), 0), g.dim[1] - 1);
     c[2] = min(max((int)((z - g.lo[2]) * g.inv_h), 0), g.dim[2] - 1);
 }
-__global__ void __launch_bounds__(256)
-sg_cell_count_kernel(int N, const float *__restrict__ xyz, const SgGrid *__restrict__ grid, uint32_t *__restrict__ cell_of,
+__device__ __forceinline__ void sg_cell_count_body(int N, const float *__restrict__ xyz, const SgGrid *__restrict__ grid, uint32_t *__restrict__ cell_of,
                      uint32_t *__restrict__ rank_in_cell, uint32_t *__restrict__ count)
 {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -330,8 +328,7 @@ sg_cell_count_kernel(int N, const float *__restrict__ xyz, const SgGrid *__restr
     rank_in_cell[i] = atomicAdd(&count[id], 1u);
 }
 // exclusive scan of count[0, ncells) in three steps (block sums, scan of block sums, add back); 1024 cells per block
-__global__ void __launch_bounds__(256)
-sg_cells_scan1_kernel(const SgGrid *__restrict__ grid, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
+__device__ __forceinline__ void sg_cells_scan1_body(const SgGrid *__restrict__ grid, const uint32_t *__restrict__ count, uint32_t *__restrict__ start,
                       uint32_t *__restrict__ block_sum)
 {
     __shared__ uint32_t sW[4];
@@ -354,8 +351,7 @@ sg_cells_scan1_kernel(const SgGrid *__restrict__ grid, const uint32_t *__restric
     for (int k = 0; k < 4; k++) { if (base + k < ncells) start[base + k] = ex; ex += v[k]; }
     if (threadIdx.x == 255) block_sum[blockIdx.x] = ex;
 }
-__global__ void __launch_bounds__(1024)
-sg_cells_scan2_kernel(const SgGrid *__restrict__ grid, uint32_t *__restrict__ block_sum)
+__device__ __forceinline__ void sg_cells_scan2_body(const SgGrid *__restrict__ grid, uint32_t *__restrict__ block_sum)
 {
     // single workgroup, serial over chunks of 1024 block sums
     __shared__ uint32_t sW[16];
@@ -380,8 +376,7 @@ sg_cells_scan2_kernel(const SgGrid *__restrict__ grid, uint32_t *__restrict__ bl
         __syncthreads();
     }
 }
-__global__ void __launch_bounds__(256)
-sg_cell_scatter_kernel(int N, const float *__restrict__ xyz, const uint32_t *__restrict__ cell_of,
+__device__ __forceinline__ void sg_cell_scatter_body(int N, const float *__restrict__ xyz, const uint32_t *__restrict__ cell_of,
                        const uint32_t *__restrict__ rank_in_cell, const uint32_t *__restrict__ start,
                        const uint32_t *__restrict__ block_sum, float4 *__restrict__ sorted /* xyz + original index */)
 {
@@ -393,12 +388,59 @@ sg_cell_scatter_kernel(int N, const float *__restrict__ xyz, const uint32_t *__r
 }
 
 // cells[id] = (first sorted slot, count): one 8-B load per visited cell in the query
-__global__ void __launch_bounds__(256)
-sg_cells_finalize_kernel(const SgGrid *__restrict__ grid, const uint32_t *__restrict__ count,
+__device__ __forceinline__ void sg_cells_finalize_body(const SgGrid *__restrict__ grid, const uint32_t *__restrict__ count,
                          const uint32_t *__restrict__ start, const uint32_t *__restrict__ block_sum, uint2 *__restrict__ cells)
 {
     const int id = blockIdx.x * 256 + threadIdx.x;
     if (id < grid->ncells) cells[id] = make_uint2(start[id] + block_sum[id >> 10], count[id]);
+}
+
+// The coarse and the fine grid are built by the SAME launches (blockIdx.y = level): seven launches instead of fourteen -- on a side
+// stream beside the raster kernels every small launch waits for dispatch slots (5-us kernels took 12-55 us each in the training
+// step's trace), so the number of launches is what the build costs.
+struct SgKnnLv { SgGrid *grid; float4 *sorted; uint2 *cells; uint32_t *cell_of, *rank_in, *count, *start, *bsum; int mc; };
+struct SgKnnLv2 { SgKnnLv l[2]; };
+__global__ void __launch_bounds__(256)
+sg_grid_setup2_kernel(const float *__restrict__ partial, int nblocks, int N, SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_grid_setup_body(partial, nblocks, N, g.mc, g.grid);
+}
+__global__ void __launch_bounds__(256)
+sg_zero2_kernel(SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < (size_t)g.mc; i += (size_t)gridDim.x * 256) g.count[i] = 0u;
+}
+__global__ void __launch_bounds__(256)
+sg_cell_count2_kernel(int N, const float *__restrict__ xyz, SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_cell_count_body(N, xyz, g.grid, g.cell_of, g.rank_in, g.count);
+}
+__global__ void __launch_bounds__(256)
+sg_cells_scan1_2_kernel(SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_cells_scan1_body(g.grid, g.count, g.start, g.bsum);
+}
+__global__ void __launch_bounds__(1024)
+sg_cells_scan2_2_kernel(SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_cells_scan2_body(g.grid, g.bsum);
+}
+__global__ void __launch_bounds__(256)
+sg_cell_scatter2_kernel(int N, const float *__restrict__ xyz, SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_cell_scatter_body(N, xyz, g.cell_of, g.rank_in, g.start, g.bsum, g.sorted);
+}
+__global__ void __launch_bounds__(256)
+sg_cells_finalize2_kernel(SgKnnLv2 L)
+{
+    const SgKnnLv &g = L.l[blockIdx.y];
+    sg_cells_finalize_body(g.grid, g.count, g.start, g.bsum, g.cells);
 }
 
 // One lane per (cell-sorted) point: grow a cube of cells around the point's cell ring by ring; the K best squared
@@ -692,27 +734,35 @@ static SgKnnWs sg_knn_ws_at(int N, void *ws)
     return w;
 }
 // bounding box partials -> grid -> counting sort of the points by cell
-static void sg_knn_build(int N, const float *xyz, const float *bpart, const SgKnnGrid &g, hipStream_t st)
+// bounding box partials -> both grids -> counting sort of the points by cell, both levels per launch
+static void sg_knn_build2(int N, const float *xyz, const float *bpart, const SgKnnGrid &gc, const SgKnnGrid &gf, hipStream_t st)
 {
-    const int nb = sg_nb(N), ncb = (int)((g.mc + 1023) / 1024);
-    hipLaunchKernelGGL(sg_grid_setup_kernel, dim3(1), dim3(256), 0, st, bpart, nb, N, (int)g.mc, g.grid);
-    sg_zero_async(g.count, g.mc * 4, st);
-    hipLaunchKernelGGL(sg_cell_count_kernel, dim3(nb), dim3(256), 0, st, N, xyz, g.grid, g.cell_of, g.rank_in, g.count);
-    hipLaunchKernelGGL(sg_cells_scan1_kernel, dim3(ncb), dim3(256), 0, st, g.grid, g.count, g.start, g.bsum);
-    hipLaunchKernelGGL(sg_cells_scan2_kernel, dim3(1), dim3(1024), 0, st, g.grid, g.bsum);
-    hipLaunchKernelGGL(sg_cell_scatter_kernel, dim3(nb), dim3(256), 0, st, N, xyz, g.cell_of, g.rank_in, g.start, g.bsum, g.sorted);
-    hipLaunchKernelGGL(sg_cells_finalize_kernel, dim3((unsigned)((g.mc + 255) / 256)), dim3(256), 0, st, g.grid, g.count, g.start, g.bsum, g.cells);
+    SgKnnLv2 L;
+    const SgKnnGrid *gs[2] = { &gc, &gf };
+    size_t mcmax = 0;
+    for (int k = 0; k < 2; k++) {
+        const SgKnnGrid &g = *gs[k];
+        L.l[k] = SgKnnLv{ g.grid, g.sorted, g.cells, g.cell_of, g.rank_in, g.count, g.start, g.bsum, (int)g.mc };
+        mcmax = g.mc > mcmax ? g.mc : mcmax;
+    }
+    const int nb = sg_nb(N), ncb = (int)((mcmax + 1023) / 1024);
+    hipLaunchKernelGGL(sg_grid_setup2_kernel, dim3(1, 2), dim3(256), 0, st, bpart, nb, N, L);
+    hipLaunchKernelGGL(sg_zero2_kernel, dim3(1024, 2), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(sg_cell_count2_kernel, dim3(nb, 2), dim3(256), 0, st, N, xyz, L);
+    hipLaunchKernelGGL(sg_cells_scan1_2_kernel, dim3(ncb, 2), dim3(256), 0, st, L);
+    hipLaunchKernelGGL(sg_cells_scan2_2_kernel, dim3(1, 2), dim3(1024), 0, st, L);
+    hipLaunchKernelGGL(sg_cell_scatter2_kernel, dim3(nb, 2), dim3(256), 0, st, N, xyz, L);
+    hipLaunchKernelGGL(sg_cells_finalize2_kernel, dim3((unsigned)((mcmax + 255) / 256), 2), dim3(256), 0, st, L);
 }
 
-// first half: the two grids over the cloud (fifteen small launches); second half: the query + the loss.  One call does both
+// first half: the two grids over the cloud (eight small launches: both levels per launch); second half: the query + the loss.  One call does both
 // (sg_gaussian_edge_loss); a caller that wants the latency-bound grid builds early and the GPU-filling query later -- beside
 // kernels with idle issue slots instead of beside a chain of small ones -- makes the two calls itself on the same workspace.
 void sg_launch_knn_prepare(int N, const float *xyz, void *ws, hipStream_t st)
 {
     const SgKnnWs w = sg_knn_ws_at(N, ws);
     hipLaunchKernelGGL(sg_bbox_partial_kernel, dim3(sg_nb(N)), dim3(256), 0, st, N, xyz, w.bpart);
-    sg_knn_build(N, xyz, w.bpart, w.gc, st);
-    sg_knn_build(N, xyz, w.bpart, w.gf, st);
+    sg_knn_build2(N, xyz, w.bpart, w.gc, w.gf, st);
 }
 int sg_launch_knn_finish(int N, int K, const float *scales, void *ws, float *mean_edge_out, float *loss, const float *upstream,
                          float *d_scales, hipStream_t st)
