@@ -398,11 +398,21 @@ def _wg_join():
         torch.cuda.current_stream(torch.device("cuda", dev_index)).wait_stream(side)
 
 
+def reset_deferred():
+    """Drop what a backward pass that RAISED left behind: deferred side-stream launches (their closures hold raw pointers to gradient
+    tensors that no parameter adopted), a held-back tri-plane preparation, the armed end-of-backward join.  The step that raised is
+    lost; the next one starts clean (sings_amd.train_step.AvatarStep.backward calls this on any exception)."""
+    del _DEFER[:]
+    del _TP_PENDING[:]
+    _WG["armed"] = False
+
+
 def _wg_stream(dev):
     side = _WG["streams"].get(dev.index)
     if side is None:
         side = _WG["streams"][dev.index] = torch.cuda.Stream(dev)
     if not _WG["armed"]:
+        del _DEFER[:]                                            # (nothing of an earlier pass may be pending when a new one arms the join)
         torch.autograd.Variable._execution_engine.queue_callback(_wg_join)     # joins when this backward pass ends
         _WG["armed"] = True
     return side

@@ -284,6 +284,13 @@ class AvatarStep(torch.nn.Module):
     def backward(self, loss_dict, extras):
         """Backward pass of a ``defer_regulariser_join`` forward, staged by hand (module docstring); then the streams join and
         ``loss_dict["loss"]`` = the sum of the terms.  (A forward that returned a loss: ``loss.backward()`` as usual.)"""
+        try:
+            return self._backward_staged(loss_dict, extras)
+        except BaseException:
+            _dec.reset_deferred()                                # (closures with raw gradient pointers must not outlive the pass)
+            raise
+
+    def _backward_staged(self, loss_dict, extras):
         photo_root, reg_root = extras["loss_roots"]
         attrs, use, inject, l2_grads = extras["staged"]
         one = getattr(self, "_one", None)
