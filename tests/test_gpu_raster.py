@@ -453,6 +453,21 @@ def test_cfg3_full_size_properties(N, W, H, seed):
     ref = 0.5 * ga.double() - 2.0 * g2.double()
     err = (g12.double() - ref).abs().max().item(); scale = ref.abs().max().item()
     assert err <= 2e-5 * scale, (err, scale)
+    # permutation invariance: the Gaussians in another order give the SAME image and, row for row, the same gradients -- bit for bit
+    # (no two Gaussians of a tile share their depth bits in these scenes: ties would be ordered by id)
+    assert bool((k0 < k1).all()), "these seeded scenes have no equal-depth neighbours inside a tile"
+    if True:
+        perm = torch.from_numpy(np.random.RandomState(7).permutation(N)).to(dev)
+        insp = [x[perm].contiguous() for x in ins]
+        eng.forward(*insp); eng.backward(*insp, d1)
+        torch.cuda.synchronize()
+        assert torch.equal(eng.color, ca)
+        o = 0
+        for x in (ins[0], ins[3], ins[4], ins[2], ins[1]):        # grad_flat: means3D, scales, rotations, opacities, shs (engine.py)
+            w = x[0].numel()
+            a = ga[o:o + N * w].view(N, w); b = eng.grad_flat[o:o + N * w].view(N, w)
+            assert torch.equal(b, a[perm]), "gradient rows follow the permutation"
+            o += N * w
 
 
 def test_capacity_overflow_is_reported_and_harmless():
