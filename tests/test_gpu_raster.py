@@ -454,10 +454,15 @@ def test_cfg3_full_size_properties(N, W, H, seed):
     err = (g12.double() - ref).abs().max().item(); scale = ref.abs().max().item()
     assert err <= 2e-5 * scale, (err, scale)
     # permutation invariance: the Gaussians in another order give the SAME image and, row for row, the same gradients -- bit for bit
-    # (no two Gaussians of a tile share their depth bits in these scenes: ties would be ordered by id)
-    assert bool((k0 < k1).all()), "these seeded scenes have no equal-depth neighbours inside a tile"
+    # (len(S) Gaussians share their depth bits with a tile neighbour)
     if True:
-        perm = torch.from_numpy(np.random.RandomState(7).permutation(N)).to(dev)
+        # (equal depth bits inside a tile are ordered by Gaussian id: the permutation keeps the relative order of the few Gaussians
+        #  that take part in such a tie, everything else moves freely)
+        tie = k0 == k1
+        S = np.unique(np.concatenate([g0[tie], g1[tie]]))
+        new_of_old = np.argsort(np.random.RandomState(7).permutation(N))
+        new_of_old[S] = np.sort(new_of_old[S])
+        perm = torch.from_numpy(np.argsort(new_of_old)).to(dev)                  # perm[new] = old
         insp = [x[perm].contiguous() for x in ins]
         eng.forward(*insp); eng.backward(*insp, d1)
         torch.cuda.synchronize()
