@@ -1,4 +1,4 @@
-// Photometric loss of one rendered view, forward + gradient in one pass over the image.
+// Photometric loss of one rendered view, forward + gradient in ONE pass over the image.
 //
 // Replaces, for the L1 and SSIM terms of HumanSceneLoss.forward (sings/rec/losses/loss.py:55-69), the chain
 //   torch.clamp(rendered, 0, 1)                                  gs_renderer_single.py:96
@@ -7,372 +7,627 @@
 //   ssim_w * (1 - ssim(pred, gt)) * mask.sum() / (H W)            losses/utils.py:28-70, loss.py:65-67
 // and their autograd backward down to dL/d(rasterizer output).  (The LPIPS term is a VGG network: out of scope.)
 //
-// The reference runs ~25 elementwise / conv2d kernels each way; here:
-//   pass 1  sg_ssim_stats_kernel : clamp + composite on load, 11x11 Gaussian window as two separable passes in LDS,
-//                                  SSIM map and its three partial-derivative maps, per-workgroup partial sums
-//   reduce  sg_loss_reduce_kernel: fixed-order sum of the partials -> the four loss scalars and the gradient scales
-//   pass 2  sg_ssim_grad_kernel  : the same separable window over the three derivative maps (a zero-padded
-//                                  symmetric window is its own adjoint), + the L1 sign term, x the clamp mask
-// HBM-bound streaming: algorithmic bytes per pixel = 3 ch x (raw 4 + gt 4 + grad 4) + mask 4 = 40; implementation
-// traffic adds the three fp32 derivative maps written and read once (72 B/pixel).  No float atomics: deterministic.
+// The reference runs ~25 elementwise / conv2d kernels each way.  Rounds 3-5 ran two tiled kernels with three fp32 derivative
+// maps per channel between them (36 B/pixel written, 62 B/pixel read back with the halo: 121 us per 1080p view, 5 x its HBM
+// bound, ten workgroup barriers per tile).  Round 6: the window statistics, their derivatives and the gradient window are ONE
+// marching kernel and nothing but the image planes touches memory:
+//   sg_mask_sum_kernel   : SG_NP fixed-order partial sums of the mask (the gradient scales need mask.sum() up front)
+//   sg_photo_kernel      : one WAVE per (channel, strip of 64 columns, chunk of R rows), marching down the rows.  Per step it loads
+//                          one row (coalesced, prefetched one step ahead), applies the 11-tap window ACROSS lanes through a
+//                          wave-private LDS row, and DOWN the rows in registers: the last 11 row results of the five window
+//                          quantities are a register ring (the row loop is unrolled by 11 so the ring index is static).  Five
+//                          rows later the SSIM value and its three partial derivatives exist for that row; they go through a
+//                          second register ring (vertical window) and one more LDS row (horizontal window) and leave as the
+//                          gradient ten rows behind the loads.  No workgroup barrier anywhere, no float atomics.
+//   sg_loss_reduce_kernel: fixed-order sum of the per-wave partials -> the four loss scalars
+// A strip holds statistics for 64 columns and emits gradients for the 54 inner ones (the gradient window needs +-5 columns of
+// derivatives); a chunk of R output rows reads R + 20 input rows.  Algorithmic bytes per pixel = 3 ch x (raw 4 + gt 4 + grad 4)
+// + mask 4 = 40; the halo re-reads (x 1.19 columns, x (R + 20) / R rows) and the second read of the centre row are L2 / Infinity
+// Cache hits.  Every pixel's sums run in the same order over its own 21 x 21 neighbourhood, so pixels with identical
+// neighbourhoods get identical bits wherever they lie in a strip (tests: flat background of an avatar frame).
 #include "sg_common.h"
+#include <stdlib.h>
 
-#define SG_LT 32                  // output tile edge
-#define SG_LH (SG_LT + 10)        // with the 5-pixel halo of the 11-tap window
-#define SG_LP (SG_LH + 1)         // LDS row pitch (bank-conflict padding)
-#define SG_LOADS ((SG_LH * SG_LH + 255) / 256)     // halo pixels per thread
+#define SG_LN 64                  // lanes of a strip = columns whose window statistics it holds
+#define SG_NP 256                 // mask partial sums per frame
+#define SG_LOSS_WAVES 2048        // waves a launch aims for: two per SIMD
+#define SG_LOSS_RUN 12
+#ifndef SG_LOSS_OCC
+#define SG_LOSS_OCC 2
+#endif
+// reciprocals of the two SSIM denominators: v_rcp_f32 (1 ulp) instead of the correctly rounded division (ten instructions each);
+// the difference is far inside the fp32 noise of the window sums in front of it
+#define SG_LOSS_RCP(v) __builtin_amdgcn_rcpf(v)            // consecutive units (3 channels x 4 strips) dealt to one XCD
 
 struct SgLossArgs {
     int W, H;
     float l1_w, ssim_w;
     float w[11];                  // the reference's fp32 window: exp(-(x-5)^2 / (2 * 1.5^2)), normalised
-    // K frames per launch (round 4): blockIdx.z = 3 frame + channel.  Frame f: raw / gradient / optional images at + 3 H W f,
-    // target at + gt_stride f, mask at + mask_stride f (floats; 0 = one target / mask for all frames), workspace at + ws_stride f
-    // bytes, losses at + 4 f
+    // K frames per launch: blockIdx.y = frame.  Frame f: raw / gradient / optional images at + 3 H W f, target at + gt_stride f,
+    // mask at + mask_stride f (floats; 0 = one target / mask for all frames), workspace at + ws_stride f bytes, losses at + 4 f
     size_t gt_stride, mask_stride, ws_stride;
     int up_stride;                // floats between the upstream weight pairs of consecutive frames: 0 (shared) | 2
+    int R, nstrips, nchunks, units;   // rows per chunk, strips per row of chunks, chunks, waves per frame (3 nstrips nchunks)
 };
+
+// workspace of one frame: [SG_NP floats: mask partials][cap float4: per-wave (sum |pred - gt|, sum ssim)][8 floats: scalars]
+__host__ __device__ inline size_t sg_loss_unit_cap(int W) { return (size_t)2 * SG_LOSS_WAVES + 3 * (size_t)((W + 53) / 54) + 8; }
+#define SG_LOSS_OFF_PART ((size_t)SG_NP * 4)
+__host__ __device__ inline size_t sg_loss_off_scalars(int W) { return SG_LOSS_OFF_PART + ((sg_loss_unit_cap(W) * 16 + 255) & ~(size_t)255); }
+
+typedef float sg_f2 __attribute__((ext_vector_type(2)));
+typedef float sg_f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float sg_clamp01(float v) { return fminf(fmaxf(v, 0.0f), 1.0f); }
 
-// true for all threads iff every thread's `same` holds and (v0, v1, v2) have the same bits in all 256 threads; contains the
-// workgroup barrier that also publishes the tile the caller has just stored to LDS.
-__device__ __forceinline__ bool sg_tile_is_flat(bool same, float v0, float v1, float v2, uint32_t (*sFlat)[4], int lane, int wave)
+// LDS hand-off inside ONE wave: the LDS executes a wave's instructions in order, only the compiler must not move the loads up
+__device__ __forceinline__ void sg_wave_lds_sync()
 {
-    const uint32_t b0 = __float_as_uint(v0), b1 = __float_as_uint(v1), b2 = __float_as_uint(v2);
-    const uint32_t f0 = __builtin_amdgcn_readfirstlane(b0), f1 = __builtin_amdgcn_readfirstlane(b1), f2 = __builtin_amdgcn_readfirstlane(b2);
-    const bool w = __all(same && b0 == f0 && b1 == f1 && b2 == f2);
-    if (lane == 0) { sFlat[wave][0] = w ? 1u : 0u; sFlat[wave][1] = f0; sFlat[wave][2] = f1; sFlat[wave][3] = f2; }
-    __syncthreads();
-    bool flat = true;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-        flat = flat && sFlat[k][0] != 0u && sFlat[k][1] == sFlat[0][1] && sFlat[k][2] == sFlat[0][2] && sFlat[k][3] == sFlat[0][3];
-    return flat;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// block partial layout: [block][4] = (sum |pred - gt|, sum ssim, sum mask, unused)
-__global__ void __launch_bounds__(256)
-sg_ssim_stats_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__restrict__ gt_rgb,
-                     const float *__restrict__ mask, const float *__restrict__ bg, float *__restrict__ maps,
-                     float *__restrict__ pred_out, float *__restrict__ gt_out, float4 *__restrict__ partial)
+__device__ __forceinline__ double sg_wave_sum_f64(double v)
 {
-    __shared__ float sX[SG_LH][SG_LP], sY[SG_LH][SG_LP];
-    __shared__ float sH[SG_LH][SG_LT + 1];
-    __shared__ float sRed[4][3];
-    __shared__ uint32_t sFlat[4][4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// mask.sum() of one frame from its SG_NP partials, the same operations in every wave that needs it (bitwise the same value)
+__device__ __forceinline__ double sg_mask_total(const float *__restrict__ mpart, int lane)
+{
+    const float4 p = ((const float4 *)mpart)[lane];
+    return sg_wave_sum_f64(((double)p.x + (double)p.y) + ((double)p.z + (double)p.w));
+}
+
+__global__ void __launch_bounds__(256)
+sg_mask_sum_kernel(SgLossArgs a, const float *__restrict__ mask, char *__restrict__ ws)
+{
+    __shared__ float sR[4];
     const size_t hw = (size_t)a.W * a.H;
-    float acc_l1 = 0.0f, acc_ssim = 0.0f, acc_mask = 0.0f;
-    const int frame = blockIdx.z / 3;
+    const int frame = blockIdx.y;
+    mask += (size_t)frame * a.mask_stride;
+    float *mpart = (float *)(ws + (size_t)frame * a.ws_stride);
+    const size_t per = (hw + SG_NP - 1) / SG_NP, i0 = (size_t)blockIdx.x * per, i1 = i0 + per < hw ? i0 + per : hw;
+    float acc = 0.0f;
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) acc += mask[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sR[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) mpart[blockIdx.x] = (sR[0] + sR[1]) + (sR[2] + sR[3]);
+}
+
+// image planes are addressed as raw buffers: descriptor in SGPRs, the row's byte offset in an SGPR, the lane's column offset in a
+// VGPR that never changes -- no vector instruction goes into addressing
+typedef __amdgpu_buffer_rsrc_t sg_rsrc;
+__device__ __forceinline__ sg_rsrc sg_make_rsrc(const void *p, size_t bytes)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(uint32_t)bytes, 0x00020000);
+}
+__device__ __forceinline__ float sg_buf_ld(sg_rsrc r, uint32_t voff, uint32_t soff)
+{
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void sg_buf_st(sg_rsrc r, uint32_t voff, uint32_t soff, float v)
+{
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, (int)voff, (int)soff, 0);
+}
+__device__ __forceinline__ int sg_clampi(int v, int hi) { return v < 0 ? 0 : (v < hi ? v : hi - 1); }
+
+// what a wave of a unit knows: its rows, its lane's columns, the planes of its channel
+struct SgLossCtx {
+    sg_rsrc raw, gt, mask;        // channel planes of this frame
+    sg_rsrc grad, pred_out, gt_out;
+    bool has_pred, has_gt;
+    sg_f2 *sIn;                   // [2][SG_LN + 16]   staged rows (x, y) of the statistics wave
+    sg_f4 *sD;                    // [2][SG_LN + 16]   derivative rows, statistics wave -> gradient wave (entry lane + 5)
+    int H, R0, R1, lane;
+    uint32_t pitch;               // bytes per image row
+    uint32_t o0, o1, oc;          // byte offsets in a row: the two columns a lane loads for the row window, its own column
+    bool in0, in1, incol, out_lane;   // those columns lie inside the image; this lane emits results (inner lane, column inside)
+    float bgc, c_l1, c_ss;
+};
+
+template <bool GRAD> struct SgLossGeo {
+    static constexpr int LAG = GRAD ? 10 : 5;     // rows between the loads and the centre (output) row
+    static constexpr int OUT0 = GRAD ? 5 : 0;     // first lane that emits results
+    static constexpr int NOUT = GRAD ? 54 : 64;   // lanes that emit results = strip pitch in columns
+};
+
+// register state of the statistics wave
+struct SgStatSt {
+    float hw[5][11];              // ring of the last 11 rows of the horizontally windowed x, y, x^2, y^2, x y
+    float pin[2][6];              // the next two input rows, in flight: raw, target, mask at the lane's column, and at the one 64 further (lanes 0-9)
+    float pc[3];                  // forward-only kernel: the next centre row in flight (raw, target, mask at the lane's own column)
+    float acc_l1, acc_ssim;
+};
+// register state of the gradient wave
+struct SgGradSt {
+    float dw[3][11];              // ring of the last 11 rows of the horizontally windowed dm/dmu1, dm/dE[x^2], dm/dE[xy]
+    float pc[2][3];               // the next two centre rows in flight: raw, target, mask at the lane's own column
+    float acc_l1;
+};
+
+// loads of row y (clamped into the image: rows outside count as zeros where they are USED), all lanes, no branches
+__device__ __forceinline__ void sg_loss_prefetch_row(const SgLossCtx &c, float (&pin)[6], int y)
+{
+    const uint32_t r = (uint32_t)sg_clampi(y, c.H) * c.pitch;
+    pin[0] = sg_buf_ld(c.raw, c.o0, r); pin[1] = sg_buf_ld(c.gt, c.o0, r); pin[2] = sg_buf_ld(c.mask, c.o0, r);
+    pin[3] = sg_buf_ld(c.raw, c.o1, r); pin[4] = sg_buf_ld(c.gt, c.o1, r); pin[5] = sg_buf_ld(c.mask, c.o1, r);
+}
+__device__ __forceinline__ void sg_loss_prefetch_centre(const SgLossCtx &c, float (&pc)[3], int y)
+{
+    const uint32_t r = (uint32_t)sg_clampi(y, c.H) * c.pitch;
+    pc[0] = sg_buf_ld(c.raw, c.oc, r); pc[1] = sg_buf_ld(c.gt, c.oc, r); pc[2] = sg_buf_ld(c.mask, c.oc, r);
+}
+
+// The window weights live in VECTOR registers.  A vector instruction with an SGPR source issues at half rate on gfx950 (tools/fmac_probe.hip:
+// v_fmac v,v,v 2.6 cycles per wave-instruction per SIMD, v_fmac v,s,v 4.2 -- as do v_max / v_min / v_cmp / v_cndmask and packed fp32), and nine
+// tenths of this file's instructions are w[k] * value.  The symmetric window has six distinct values; the asm keeps the compiler from
+// recognising them as uniform and putting them back into SGPRs.
+struct SgW { float w[11]; };
+__device__ __forceinline__ SgW sg_loss_weights(const SgLossArgs &a)
+{
+    SgW w;
+#pragma unroll
+    for (int k = 0; k < 6; k++) { float v; asm volatile("v_mov_b32 %0, %1" : "=v"(v) : "s"(a.w[k])); w.w[k] = v; w.w[10 - k] = v; }
+    return w;
+}
+
+// 11-tap sum in the fixed order k = 0..10 (the first tap is a product: fma(w, v, 0) without the zero)
+#define SG_WIN11(acc, expr) { acc = w.w[0] * (expr(0)); acc = fmaf(w.w[1], expr(1), acc); acc = fmaf(w.w[2], expr(2), acc);      \
+    acc = fmaf(w.w[3], expr(3), acc); acc = fmaf(w.w[4], expr(4), acc); acc = fmaf(w.w[5], expr(5), acc);                        \
+    acc = fmaf(w.w[6], expr(6), acc); acc = fmaf(w.w[7], expr(7), acc); acc = fmaf(w.w[8], expr(8), acc);                        \
+    acc = fmaf(w.w[9], expr(9), acc); acc = fmaf(w.w[10], expr(10), acc); }
+
+// One row step of the statistics wave.  PH = t mod 11 is the ring slot the new row goes to; slot (PH + 1 + k) mod 11 holds the row
+// k rows below the oldest.  GRAD: the derivative row of ys = yin - 5 goes to sD[t & 1] for the gradient wave (t >= 10);
+// otherwise (forward-only kernel) this wave also sums |x - y| over the centre row and writes the optional images.
+template <bool GRAD, bool LOSS, int PH>
+__device__ __forceinline__ void sg_stat_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgStatSt &s, int t)
+{
+    using G = SgLossGeo<GRAD>;
+    const int yin = c.R0 - G::LAG + t;
+    const int buf = t & 1;
+    sg_f2 *sIn = c.sIn + buf * (SG_LN + 16);
+    // (1) the row that arrived -> clamped render x, composited target y (zero outside the image: conv2d's zero padding)
     {
-        const size_t fi = (size_t)frame * 3 * hw;
-        raw += fi; gt_rgb += (size_t)frame * a.gt_stride; mask += (size_t)frame * a.mask_stride;
-        maps = sg_at(maps, (size_t)frame * a.ws_stride); partial = sg_at(partial, (size_t)frame * a.ws_stride);
-        if (pred_out) pred_out += fi;
-        if (gt_out) gt_out += fi;
+        const bool rowok = (unsigned)yin < (unsigned)c.H;
+        const bool k0 = rowok && c.in0, k1 = rowok && c.in1;
+        const float m0 = s.pin[0][2], m1 = s.pin[0][5];
+        const float xv0 = k0 ? sg_clamp01(s.pin[0][0]) : 0.0f, yv0 = k0 ? s.pin[0][1] * m0 + c.bgc * (1.0f - m0) : 0.0f;
+        const float xv1 = k1 ? sg_clamp01(s.pin[0][3]) : 0.0f, yv1 = k1 ? s.pin[0][4] * m1 + c.bgc * (1.0f - m1) : 0.0f;
+        sIn[c.lane] = sg_f2{ xv0, yv0 };
+        if (c.lane < 10) sIn[SG_LN + c.lane] = sg_f2{ xv1, yv1 };
     }
-    {   // one (tile, channel) per workgroup: a 512x896 frame is only 448 tiles, fewer than two per CU
-        const int ch = blockIdx.z - 3 * frame;
-        const float bgc = bg[ch];
-        // the halo tile: all 3 x SG_LOADS loads of a thread are in flight together (as a rolled loop hipcc emitted load, load, load,
-        // s_waitcnt vmcnt(0) per trip -- seven dependent memory round trips in front of the first barrier of a workgroup whose
-        // arithmetic is ~800 instructions per wave).  Addresses are clamped into the image instead of branched around.
-        bool same = true;
-        float x0 = 0.0f, y0 = 0.0f;
+    // two rows stay in flight: the memory latency under load is longer than the half step between these loads and the next step's head
+#pragma unroll
+    for (int q = 0; q < 6; q++) s.pin[0][q] = s.pin[1][q];
+    sg_loss_prefetch_row(c, s.pin[1], yin + 2);
+    sg_wave_lds_sync();
+    // (2) 11-tap window across the lanes
+    {
+        sg_f2 v[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) v[k] = sIn[c.lane + k];
+        float h0, h1, h2, h3, h4;
         {
-            float lx[SG_LOADS], ly[SG_LOADS], lm[SG_LOADS];
-#pragma unroll
-            for (int u = 0; u < SG_LOADS; u++) {
-                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
-                const int x = X0 - 5 + c, y = Y0 - 5 + r;
-                const int xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1), yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1);
-                const size_t p = (size_t)yc * a.W + xc;
-                lm[u] = mask[p]; lx[u] = raw[ch * hw + p]; ly[u] = gt_rgb[ch * hw + p];
-            }
-#pragma unroll
-            for (int u = 0; u < SG_LOADS; u++) {
-                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
-                const int x = X0 - 5 + c, y = Y0 - 5 + r;
-                const bool in = x >= 0 && x < a.W && y >= 0 && y < a.H;
-                const float m = lm[u];
-                const float xv = in ? sg_clamp01(lx[u]) : 0.0f, yv = in ? ly[u] * m + bgc * (1.0f - m) : 0.0f;
-                if (i < SG_LH * SG_LH) { sX[r][c] = xv; sY[r][c] = yv; }
-                if (u == 0) { x0 = xv; y0 = yv; }
-                else if (i < SG_LH * SG_LH) same = same && __float_as_uint(xv) == __float_as_uint(x0) && __float_as_uint(yv) == __float_as_uint(y0);
-            }
+            const float wx = w.w[0] * v[0].x, wy = w.w[0] * v[0].y;
+            h0 = wx; h1 = wy; h2 = wx * v[0].x; h3 = wy * v[0].y; h4 = wx * v[0].y;
         }
-        const bool flat = sg_tile_is_flat(same, x0, y0, 0.0f, sFlat, lane, wave);        // (holds the barrier behind the LDS stores)
-        // Separable window, one quantity at a time through ONE LDS plane (20 KB per workgroup instead of 42 KB: the
-        // kernel is latency-bound, resident workgroups are what hides it).  Horizontal pass: an item = 8 consecutive
-        // output columns of one halo row, its 18 samples of x and y stay in registers for all five quantities;
-        // vertical pass: 4 consecutive rows of one column per thread (14 LDS reads for 4 outputs).
-        const bool hthread = tid < SG_LH * 4;
-        const int hr = tid >> 2, hc0 = (tid & 3) * 8;
-        float xs[18], ys[18];
-        if (hthread && !flat) {
 #pragma unroll
-            for (int k = 0; k < 18; k++) { xs[k] = sX[hr][hc0 + k]; ys[k] = sY[hr][hc0 + k]; }
+        for (int k = 1; k < 11; k++) {
+            const float wx = w.w[k] * v[k].x, wy = w.w[k] * v[k].y;
+            h0 += wx; h1 += wy;
+            h2 = fmaf(wx, v[k].x, h2); h3 = fmaf(wy, v[k].y, h3); h4 = fmaf(wx, v[k].y, h4);
         }
-        const int c = tid & 31, r0 = (tid >> 5) * 4;
-        float vq[5][4];
-        if (flat) {
-            // every sample of the halo tile has the same bits (background behind the avatar: render = bg, target = bg; or the zero
-            // padding outside the image): each of the 8 x 11 and 4 x 11 FMA chains below would run on the same operands in the same
-            // order, so ONE chain per quantity IS the value of all of them -- no LDS traffic, no barriers, identical bits
-#pragma unroll
-            for (int q = 0; q < 5; q++) {
-                const float v = q == 0 ? x0 : q == 1 ? y0 : q == 2 ? x0 * x0 : q == 3 ? y0 * y0 : x0 * y0;
-                float h = 0.0f, t = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v, h);
-#pragma unroll
-                for (int k = 0; k < 11; k++) t = fmaf(a.w[k], h, t);
-#pragma unroll
-                for (int j = 0; j < 4; j++) vq[q][j] = t;
-            }
-        } else
+        s.hw[0][PH] = h0; s.hw[1][PH] = h1; s.hw[2][PH] = h2; s.hw[3][PH] = h3; s.hw[4][PH] = h4;
+    }
+    if (t < 10) return;
+    // (3) window down the rows: statistics of row ys, the SSIM value and its partial derivatives there
+    const int ys = yin - 5;
+    {
+        float st[5];
 #pragma unroll
         for (int q = 0; q < 5; q++) {
-            if (hthread) {
-                float v[18];
-#pragma unroll
-                for (int k = 0; k < 18; k++)
-                    v[k] = q == 0 ? xs[k] : q == 1 ? ys[k] : q == 2 ? xs[k] * xs[k] : q == 3 ? ys[k] * ys[k] : xs[k] * ys[k];
-#pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    float h = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v[o + k], h);
-                    sH[hr][hc0 + o] = h;
-                }
-            }
-            __syncthreads();
-            float col[14];
-#pragma unroll
-            for (int k = 0; k < 14; k++) col[k] = sH[r0 + k][c];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float h = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], col[j + k], h);
-                vq[q][j] = h;
-            }
-            __syncthreads();
+#define SG_RING(k) s.hw[q][(PH + 1 + (k)) % 11]
+            SG_WIN11(st[q], SG_RING)
+#undef SG_RING
         }
-        float mk[4] = { 0.0f, 0.0f, 0.0f, 0.0f };           // (channel 0 also sums the mask: its four loads go out together)
-        if (ch == 0) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int x = X0 + c, y = Y0 + r0 + j;
-                mk[j] = mask[(size_t)(y < a.H ? y : a.H - 1) * a.W + (x < a.W ? x : a.W - 1)];       // (clamped, not branched: used in-image only)
-            }
+        const float mu1 = st[0], mu2 = st[1], e11 = st[2], e22 = st[3], e12 = st[4];
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+        const float A = mu1s + mu2s + C1, B = s1 + s2 + C2, Cn = 2.0f * mu12 + C1, D = 2.0f * s12 + C2;
+        const float rA = SG_LOSS_RCP(A), rB = SG_LOSS_RCP(B);
+        const float m = (Cn * D) * (rA * rB);
+        const bool rowok = (unsigned)ys < (unsigned)c.H;
+        if (GRAD) {
+            // partials of m with respect to the window outputs mu1 = w*x, E[x^2] = w*x^2, E[xy] = w*xy; no pixel, no derivative
+            const float dm_ds1 = -m * rB;
+            const float dm_ds12 = 2.0f * Cn * (rA * rB);
+            const float dm_dmu1 = 2.0f * mu2 * D * (rA * rB) - 2.0f * mu1 * m * rA - 2.0f * mu1 * dm_ds1 - mu2 * dm_ds12;
+            const bool inimg = rowok && c.incol;
+            c.sD[buf * (SG_LN + 16) + c.lane + 5] = sg_f4{ inimg ? dm_dmu1 : 0.0f, inimg ? dm_ds1 : 0.0f, inimg ? dm_ds12 : 0.0f, 0.0f };
         }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = r0 + j;
-            const int x = X0 + c, y = Y0 + r;
-            const float mu1 = vq[0][j], mu2 = vq[1][j], e11 = vq[2][j], e22 = vq[3][j], e12 = vq[4][j];
-            if (x < a.W && y < a.H) {
-                const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-                const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
-                const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
-                const float A = mu1s + mu2s + C1, B = s1 + s2 + C2, Cn = 2.0f * mu12 + C1, D = 2.0f * s12 + C2;
-                const float rA = 1.0f / A, rB = 1.0f / B;
-                const float m = (Cn * D) * (rA * rB);
-                // partials of m with respect to the window outputs mu1 = w*x, E[x^2] = w*x^2, E[xy] = w*xy
-                const float dm_ds1 = -m * rB;                          // d/d sigma1^2
-                const float dm_ds12 = 2.0f * Cn * (rA * rB);            // d/d sigma12
-                const float dm_dmu1 = 2.0f * mu2 * D * (rA * rB) - 2.0f * mu1 * m * rA
-                                      - 2.0f * mu1 * dm_ds1 - mu2 * dm_ds12;
-                const size_t p = (size_t)y * a.W + x;
-                maps[(size_t)(ch * 3 + 0) * hw + p] = dm_dmu1;
-                maps[(size_t)(ch * 3 + 1) * hw + p] = dm_ds1;
-                maps[(size_t)(ch * 3 + 2) * hw + p] = dm_ds12;
-                const float xv = sX[r + 5][c + 5], yv = sY[r + 5][c + 5];
-                acc_ssim += m;
-                acc_l1 += fabsf(xv - yv);
-                if (ch == 0) acc_mask += mk[j];
-                if (pred_out) pred_out[ch * hw + p] = xv;
-                if (gt_out) gt_out[ch * hw + p] = yv;
-            }
-        }
+        if (LOSS) s.acc_ssim += (c.out_lane && rowok && ys >= c.R0 && ys < c.R1) ? m : 0.0f;
     }
-    // fixed-order block reduction
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        acc_l1 += __shfl_xor(acc_l1, o, 64); acc_ssim += __shfl_xor(acc_ssim, o, 64); acc_mask += __shfl_xor(acc_mask, o, 64);
-    }
-    if (lane == 0) { sRed[wave][0] = acc_l1; sRed[wave][1] = acc_ssim; sRed[wave][2] = acc_mask; }
-    __syncthreads();
-    if (tid == 0) {
-        float t0 = 0, t1 = 0, t2 = 0;
-        for (int w = 0; w < 4; w++) { t0 += sRed[w][0]; t1 += sRed[w][1]; t2 += sRed[w][2]; }
-        partial[((blockIdx.z - 3 * frame) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = make_float4(t0, t1, t2, 0.0f);
+    if (!GRAD) {
+        // forward only: the centre row is the statistics row
+        const float mk = s.pc[2];
+        const float xv = sg_clamp01(s.pc[0]), yv = s.pc[1] * mk + c.bgc * (1.0f - mk);
+        if (c.out_lane) {
+            if (LOSS) s.acc_l1 += fabsf(xv - yv);
+            const uint32_t r = (uint32_t)ys * c.pitch;
+            if (c.has_pred) sg_buf_st(c.pred_out, c.oc, r, xv);
+            if (c.has_gt) sg_buf_st(c.gt_out, c.oc, r, yv);
+        }
+        sg_loss_prefetch_centre(c, s.pc, ys + 1);
     }
 }
 
-// scalars[0..3] = (l1_w * Ll1, ssim_w * Lssim, Ll1, mean ssim); scalars[4..5] = gradient scales (c_l1, c_ssim)
-__global__ void __launch_bounds__(256)
-sg_loss_reduce_kernel(SgLossArgs a, const float4 *__restrict__ partial, int nblocks, float *__restrict__ scalars,
-                      float *__restrict__ losses)
+// One row step of the gradient wave: j = the step of the statistics wave whose derivative row (row R0 - 15 + j) lies in sD[j & 1].
+// The adjoint of the window (a zero-padded symmetric window is its own adjoint): across the lanes straight from that row, down the
+// rows in a register ring; the gradient row is yo = R0 - 20 + j.  PH = j mod 11.
+template <bool LOSS, int PH>
+__device__ __forceinline__ void sg_grad_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgGradSt &s, int j)
 {
-    __shared__ double sR[256][3];
-    partial = sg_at(partial, (size_t)blockIdx.x * a.ws_stride); scalars = sg_at(scalars, (size_t)blockIdx.x * a.ws_stride);   // frame blockIdx.x
+    const sg_f4 *sD = c.sD + (j & 1) * (SG_LN + 16);
+    {
+        // (all 16 bytes of an entry are asked for: ds_read_b128 runs at twice the rate of the b96 the compiler would narrow this to)
+#define SG_LDU(k) { u[k] = sD[c.lane + (k)]; asm volatile("" :: "v"(u[k].w)); }
+        sg_f4 u[11];
+        float g0, g1, g2;
+        SG_LDU(0) SG_LDU(1) SG_LDU(2) SG_LDU(3) SG_LDU(4) SG_LDU(5)
+        g0 = w.w[0] * u[0].x; g1 = w.w[0] * u[0].y; g2 = w.w[0] * u[0].z;
+#pragma unroll
+        for (int k = 1; k < 6; k++) { g0 = fmaf(w.w[k], u[k].x, g0); g1 = fmaf(w.w[k], u[k].y, g1); g2 = fmaf(w.w[k], u[k].z, g2); }
+        SG_LDU(6) SG_LDU(7) SG_LDU(8) SG_LDU(9) SG_LDU(10)
+#pragma unroll
+        for (int k = 6; k < 11; k++) { g0 = fmaf(w.w[k], u[k].x, g0); g1 = fmaf(w.w[k], u[k].y, g1); g2 = fmaf(w.w[k], u[k].z, g2); }
+#undef SG_LDU
+        s.dw[0][PH] = g0; s.dw[1][PH] = g1; s.dw[2][PH] = g2;
+    }
+    if (j < 20) return;
+    const int yo = c.R0 - 20 + j;
+    float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#define SG_RING(k) s.dw[q][(PH + 1 + (k)) % 11]
+        SG_WIN11(g[q], SG_RING)
+#undef SG_RING
+    }
+    {
+        const float rv = s.pc[0][0], mk = s.pc[0][2];
+        const float xv = sg_clamp01(rv), yv = s.pc[0][1] * mk + c.bgc * (1.0f - mk);
+        const float d = xv - yv;
+        if (c.out_lane) {
+            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+            const float gr = c.c_ss * (g[0] + 2.0f * xv * g[1] + yv * g[2]) + c.c_l1 * sgn;
+            const uint32_t r = (uint32_t)yo * c.pitch;
+            sg_buf_st(c.grad, c.oc, r, (rv >= 0.0f && rv <= 1.0f) ? gr : 0.0f);    // torch.clamp passes the gradient where min <= x <= max
+            if (c.has_pred) sg_buf_st(c.pred_out, c.oc, r, xv);
+            if (c.has_gt) sg_buf_st(c.gt_out, c.oc, r, yv);
+        }
+        if (LOSS) s.acc_l1 += c.out_lane ? fabsf(d) : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 3; q++) s.pc[0][q] = s.pc[1][q];
+    sg_loss_prefetch_centre(c, s.pc[1], yo + 2);
+}
+
+// unit of workgroup b: runs of SG_LOSS_RUN consecutive units (the three channels of neighbouring strips: shared mask, shared halo
+// columns) stay on one XCD's L2 (workgroup b runs on XCD b % 8), the runs are dealt round-robin to the XCDs
+__device__ __forceinline__ int sg_loss_unit_of_block(int b)
+{
+    const int xcd = b & 7, slot = b >> 3;
+    return ((slot / SG_LOSS_RUN) * 8 + xcd) * SG_LOSS_RUN + slot % SG_LOSS_RUN;
+}
+static inline int sg_loss_blocks(int units) { return ((units + 8 * SG_LOSS_RUN - 1) / (8 * SG_LOSS_RUN)) * (8 * SG_LOSS_RUN); }
+
+template <bool GRAD>
+__device__ __forceinline__ void sg_loss_ctx(SgLossCtx &c, const SgLossArgs &a, int u, int frame, int lane, const float *raw, const float *gt_rgb,
+                                            const float *mask, const float *bg, float *dL_draw, float *pred_out, float *gt_out)
+{
+    using G = SgLossGeo<GRAD>;
+    const int ch = u % 3, strip = (u / 3) % a.nstrips, chunk = u / (3 * a.nstrips);
+    const size_t hw = (size_t)a.W * a.H;
+    c.H = a.H; c.lane = lane; c.pitch = (uint32_t)a.W * 4u;
+    c.R0 = chunk * a.R; c.R1 = c.R0 + a.R < a.H ? c.R0 + a.R : a.H;
+    {
+        const int col = strip * G::NOUT - G::OUT0 + lane;        // the column whose window statistics this lane holds
+        const int l0 = col - 5, l1 = l0 + SG_LN;                 // the columns it loads for the row window (the second: lanes 0-9)
+        c.in0 = l0 >= 0 && l0 < a.W; c.in1 = l1 >= 0 && l1 < a.W; c.incol = col >= 0 && col < a.W;
+        c.o0 = 4u * (uint32_t)sg_clampi(l0, a.W); c.o1 = lane < 10 ? 4u * (uint32_t)sg_clampi(l1, a.W) : c.o0;
+        c.oc = 4u * (uint32_t)sg_clampi(col, a.W);
+        c.out_lane = lane >= G::OUT0 && lane < G::OUT0 + G::NOUT && c.incol;
+    }
+    {
+        const size_t plane = hw * 4, fo = (size_t)frame * 3 * hw + ch * hw;
+        c.raw = sg_make_rsrc(raw + fo, plane); c.gt = sg_make_rsrc(gt_rgb + (size_t)frame * a.gt_stride + ch * hw, plane);
+        c.mask = sg_make_rsrc(mask + (size_t)frame * a.mask_stride, plane);
+        c.grad = sg_make_rsrc(GRAD ? dL_draw + fo : nullptr, GRAD ? plane : 0);
+        c.has_pred = pred_out != nullptr; c.has_gt = gt_out != nullptr;
+        c.pred_out = sg_make_rsrc(pred_out ? pred_out + fo : nullptr, pred_out ? plane : 0);
+        c.gt_out = sg_make_rsrc(gt_out ? gt_out + fo : nullptr, gt_out ? plane : 0);
+    }
+    c.bgc = bg[ch];
+    c.c_l1 = 0.0f; c.c_ss = 0.0f;
+}
+
+__device__ __forceinline__ void sg_stat_init(SgStatSt &s)
+{
+#pragma unroll
+    for (int k = 0; k < 11; k++)
+#pragma unroll
+        for (int q = 0; q < 5; q++) s.hw[q][k] = 0.0f;
+    s.pc[0] = s.pc[1] = s.pc[2] = 0.0f;
+    s.acc_l1 = 0.0f; s.acc_ssim = 0.0f;
+}
+
+// forward only (the autograd forward): one wave per unit, 64 result columns per strip, chunks read R + 10 rows
+template <bool LOSS>
+__global__ void __launch_bounds__(64)
+sg_photo_fwd_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__restrict__ gt_rgb, const float *__restrict__ mask,
+                    const float *__restrict__ bg, char *__restrict__ ws, float *__restrict__ pred_out, float *__restrict__ gt_out)
+{
+    __shared__ sg_f2 sIn[2][SG_LN + 16];
+    const int u = sg_loss_unit_of_block(blockIdx.x);
+    if (u >= a.units) return;
+    const int lane = threadIdx.x, frame = blockIdx.y;
+    ws += (size_t)frame * a.ws_stride;
+    const SgW w = sg_loss_weights(a);
+    SgLossCtx c;
+    sg_loss_ctx<false>(c, a, u, frame, lane, raw, gt_rgb, mask, bg, nullptr, pred_out, gt_out);
+    c.sIn = &sIn[0][0]; c.sD = nullptr;
+    SgStatSt s;
+    sg_stat_init(s);
+    const int T = (c.R1 - c.R0) + 10;
+    sg_loss_prefetch_row(c, s.pin[0], c.R0 - 5);
+    sg_loss_prefetch_row(c, s.pin[1], c.R0 - 4);
+    sg_loss_prefetch_centre(c, s.pc, c.R0);                  // (first used at t = 10, refreshed at the end of every later step)
+    for (int t0 = 0; t0 < T; t0 += 11) {
+#define SG_STEP(PH) if (t0 + PH < T) sg_stat_step<false, LOSS, PH>(a, w, c, s, t0 + PH)
+        SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
+#undef SG_STEP
+    }
+    if (LOSS) {
+        float a1 = s.acc_l1, a2 = s.acc_ssim;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+        if (lane == 0) ((float4 *)(ws + SG_LOSS_OFF_PART))[u] = make_float4(a1, a2, 0.0f, 0.0f);
+    }
+}
+
+// ---- forward + gradient: three waves per unit, a pipeline over the rows ------------------------------------------------------------
+// As ONE wave the two rings cost 175 registers (two waves per SIMD), and a wave issues a vector instruction every four cycles at best:
+// the vector pipe idled 60 % of the time (105 us per 1080p view).  As a pipeline each wave runs a third of the instructions of a row
+// and the whole kernel fits 96 registers:
+//   wave H (row t)    : loads, clamp / composite, the five products -> LDS row -> 11-tap window across the lanes -> sH[t & 1]
+//   wave V (row t - 1): the 55-register ring, window down the rows, SSIM value and its three derivatives -> sD[(t - 1) & 1]
+//   wave G (row t - 2): adjoint window across the lanes straight from sD, the 33-register ring, window down the rows, gradient out
+// One workgroup barrier per row hands the two rows over (double-buffered: a slot is rewritten two barriers after it was read).
+struct SgHSt { float pin[2][6]; };
+struct SgVSt { float hw[5][11]; float acc_ssim; };
+
+__device__ __forceinline__ void sg_h_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgHSt &s, sg_f2 *sIn, sg_f4 *sH4, float *sH1, int t)
+{
+    const int yin = c.R0 - 10 + t;
+    const int buf = t & 1;
+    sIn += buf * (SG_LN + 16);
+    {
+        const bool rowok = (unsigned)yin < (unsigned)c.H;
+        const bool k0 = rowok && c.in0, k1 = rowok && c.in1;
+        const float m0 = s.pin[0][2], m1 = s.pin[0][5];
+        const float xv0 = k0 ? sg_clamp01(s.pin[0][0]) : 0.0f, yv0 = k0 ? s.pin[0][1] * m0 + c.bgc * (1.0f - m0) : 0.0f;
+        sIn[c.lane] = sg_f2{ xv0, yv0 };
+        if (c.lane < 10) {
+            const float xv1 = k1 ? sg_clamp01(s.pin[0][3]) : 0.0f, yv1 = k1 ? s.pin[0][4] * m1 + c.bgc * (1.0f - m1) : 0.0f;
+            sIn[SG_LN + c.lane] = sg_f2{ xv1, yv1 };
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 6; q++) s.pin[0][q] = s.pin[1][q];
+    sg_loss_prefetch_row(c, s.pin[1], yin + 2);
+    sg_wave_lds_sync();
+    float h0, h1, h2, h3, h4;
+    {
+        // (x, y) pairs only: the three products are made per tap -- two more vector instructions per tap than reading them, but the
+        // LDS, not the vector pipe, was the busiest unit of the CU with five values per entry (76 % against 53 %)
+        sg_f2 v[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) v[k] = sIn[c.lane + k];
+        {
+            const float wx = w.w[0] * v[0].x, wy = w.w[0] * v[0].y;
+            h0 = wx; h1 = wy; h2 = wx * v[0].x; h3 = wy * v[0].y; h4 = wx * v[0].y;
+        }
+#pragma unroll
+        for (int k = 1; k < 11; k++) {
+            const float wx = w.w[k] * v[k].x, wy = w.w[k] * v[k].y;
+            h0 += wx; h1 += wy;
+            h2 = fmaf(wx, v[k].x, h2); h3 = fmaf(wy, v[k].y, h3); h4 = fmaf(wx, v[k].y, h4);
+        }
+    }
+    sH4[buf * SG_LN + c.lane] = sg_f4{ h0, h1, h2, h3 }; sH1[buf * SG_LN + c.lane] = h4;
+}
+
+// row j of wave H (input row R0 - 10 + j) arrives in sH[j & 1]; statistics row ys = R0 - 15 + j from j = 10 on.  PH = j mod 11.
+template <bool LOSS, int PH>
+__device__ __forceinline__ void sg_v_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgVSt &s, const sg_f4 *sH4, const float *sH1, sg_f4 *sD, int j)
+{
+    {
+        const sg_f4 h = sH4[(j & 1) * SG_LN + c.lane];
+        const float h4 = sH1[(j & 1) * SG_LN + c.lane];
+        s.hw[0][PH] = h.x; s.hw[1][PH] = h.y; s.hw[2][PH] = h.z; s.hw[3][PH] = h.w; s.hw[4][PH] = h4;
+    }
+    if (j < 10) return;
+    const int ys = c.R0 - 15 + j;
+    float st[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+#define SG_RING(k) s.hw[q][(PH + 1 + (k)) % 11]
+        SG_WIN11(st[q], SG_RING)
+#undef SG_RING
+    }
+    const float mu1 = st[0], mu2 = st[1], e11 = st[2], e22 = st[3], e12 = st[4];
+    const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+    const float mu1s = mu1 * mu1, mu2s = mu2 * mu2, mu12 = mu1 * mu2;
+    const float s1 = e11 - mu1s, s2 = e22 - mu2s, s12 = e12 - mu12;
+    const float A = mu1s + mu2s + C1, B = s1 + s2 + C2, Cn = 2.0f * mu12 + C1, D = 2.0f * s12 + C2;
+    const float rA = SG_LOSS_RCP(A), rB = SG_LOSS_RCP(B);
+    const float m = (Cn * D) * (rA * rB);
+    const bool rowok = (unsigned)ys < (unsigned)c.H;
+    // partials of m with respect to the window outputs mu1 = w*x, E[x^2] = w*x^2, E[xy] = w*xy; no pixel, no derivative
+    const float dm_ds1 = -m * rB;
+    const float dm_ds12 = 2.0f * Cn * (rA * rB);
+    const float dm_dmu1 = 2.0f * mu2 * D * (rA * rB) - 2.0f * mu1 * m * rA - 2.0f * mu1 * dm_ds1 - mu2 * dm_ds12;
+    const bool inimg = rowok && c.incol;
+    sD[(j & 1) * (SG_LN + 16) + c.lane + 5] = sg_f4{ inimg ? dm_dmu1 : 0.0f, inimg ? dm_ds1 : 0.0f, inimg ? dm_ds12 : 0.0f, 0.0f };
+    if (LOSS) s.acc_ssim += (c.out_lane && rowok && ys >= c.R0 && ys < c.R1) ? m : 0.0f;
+}
+
+#ifdef SG_LOSS_STAMP
+// diagnostic build only (tools/loss_stamps.py): per-wave start / end stamps of the shader clock and of the 100 MHz real-time clock
+__device__ unsigned long long sg_loss_stamps[8192 * 3 * 4];
+extern "C" int sg_debug_loss_stamps(unsigned long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg_loss_stamps), (size_t)n * 8); }
+#define SG_STAMP_BEGIN const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#define SG_STAMP_END if (lane == 0 && blockIdx.y == 0) { unsigned long long *q = sg_loss_stamps + ((size_t)blockIdx.x * 3 + wave) * 4;      \
+    q[0] = st_c0; q[1] = st_r0; q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime(); }
+#else
+#define SG_STAMP_BEGIN
+#define SG_STAMP_END
+#endif
+#ifdef SG_LOSS_NOBAR
+#define SG_BAR()
+#else
+#define SG_BAR() __syncthreads()
+#endif
+
+template <bool LOSS>
+__global__ void __launch_bounds__(192)
+sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__restrict__ gt_rgb, const float *__restrict__ mask,
+                const float *__restrict__ bg, char *__restrict__ ws, const float *__restrict__ upstream,
+                float *__restrict__ dL_draw, float *__restrict__ pred_out, float *__restrict__ gt_out)
+{
+    __shared__ sg_f2 sIn[2][SG_LN + 16];
+    __shared__ sg_f4 sH4[2][SG_LN];
+    __shared__ float sH1[2][SG_LN];
+    __shared__ sg_f4 sD[2][SG_LN + 16];
+#ifdef SG_LOSS_PAD_LDS
+    __shared__ float sPad[SG_LOSS_PAD_LDS / 4];                // EXPERIMENT: caps the workgroups per CU
+    if (a.W < 0) sPad[threadIdx.x] = 1.0f;
+#endif
+    SG_STAMP_BEGIN
+    const int u = sg_loss_unit_of_block(blockIdx.x);
+    if (u >= a.units) return;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), frame = blockIdx.y;
+    ws += (size_t)frame * a.ws_stride;
+    const SgW w = sg_loss_weights(a);
+    SgLossCtx c;
+    sg_loss_ctx<true>(c, a, u, frame, lane, raw, gt_rgb, mask, bg, dL_draw, pred_out, gt_out);
+    c.sIn = nullptr; c.sD = &sD[0][0];
+    const int T = (c.R1 - c.R0) + 20;                        // rows wave H stages; V runs one row behind it, G two
+    float part = 0.0f;
+    if (wave == 0) {
+        SgHSt s;
+        sg_loss_prefetch_row(c, s.pin[0], c.R0 - 10);
+        sg_loss_prefetch_row(c, s.pin[1], c.R0 - 9);
+        for (int t = 0; t < T + 2; t++) {
+            if (t < T) sg_h_step(a, w, c, s, &sIn[0][0], &sH4[0][0], &sH1[0][0], t);
+            SG_BAR();
+        }
+    } else if (wave == 1) {
+        SgVSt s;
+#pragma unroll
+        for (int k = 0; k < 11; k++)
+#pragma unroll
+            for (int q = 0; q < 5; q++) s.hw[q][k] = 0.0f;
+        s.acc_ssim = 0.0f;
+        for (int t0 = 0; t0 < T + 2; t0 += 11) {
+#define SG_STEP(PH) if (t0 + PH < T + 2) { if (t0 + PH >= 1 && t0 + PH <= T) sg_v_step<LOSS, (PH + 10) % 11>(a, w, c, s, &sH4[0][0], &sH1[0][0], &sD[0][0], t0 + PH - 1); SG_BAR(); }
+            SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
+#undef SG_STEP
+        }
+        part = s.acc_ssim;
+    } else {
+        // gradient scales: d(l1_w |.|.sum() / mask.sum()) and d(ssim_w (1 - mean ssim) mask.sum() / (H W)), times the upstream weights
+        // (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL
+        {
+            const size_t hw = (size_t)a.W * a.H;
+            const double s_mask = sg_mask_total((const float *)ws, lane);
+            const float *up = upstream ? upstream + (size_t)frame * a.up_stride : nullptr;
+            const float u_l1 = up ? up[0] : 1.0f, u_ss = up ? up[1] : 1.0f;
+            c.c_l1 = (float)((double)a.l1_w / s_mask) * u_l1;
+            c.c_ss = (float)(-(double)a.ssim_w * (s_mask / (double)hw) / (3.0 * (double)hw)) * u_ss;
+        }
+        SgGradSt s;
+#pragma unroll
+        for (int k = 0; k < 11; k++)
+#pragma unroll
+            for (int q = 0; q < 3; q++) s.dw[q][k] = 0.0f;
+        s.acc_l1 = 0.0f;
+        sg_loss_prefetch_centre(c, s.pc[0], c.R0);
+        sg_loss_prefetch_centre(c, s.pc[1], c.R0 + 1);
+        for (int t0 = 0; t0 < T + 2; t0 += 11) {
+            // iteration t handles the derivative row of wave V's step j = t - 2 (rows exist from j = 10 on)
+#define SG_STEP(PH) if (t0 + PH < T + 2) { if (t0 + PH >= 12) sg_grad_step<LOSS, (PH + 9) % 11>(a, w, c, s, t0 + PH - 2); SG_BAR(); }
+            SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
+#undef SG_STEP
+        }
+        part = s.acc_l1;
+    }
+    if (LOSS && wave != 0) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        // float4 (sum |pred - gt|, sum ssim, -, -) of the unit: each wave writes its own component
+        if (lane == 0) ((float *)(ws + SG_LOSS_OFF_PART))[4 * u + (wave == 1 ? 1 : 0)] = part;
+    }
+    SG_STAMP_END
+}
+
+// scalars[0..3] = (l1_w * Ll1, ssim_w * Lssim, Ll1, mean ssim); scalars[4..5] = gradient scales (c_l1, c_ssim), for inspection
+__global__ void __launch_bounds__(256)
+sg_loss_reduce_kernel(SgLossArgs a, char *__restrict__ ws, float *__restrict__ losses)
+{
+    __shared__ double sR[256][2];
+    __shared__ double sMask;
+    ws += (size_t)blockIdx.x * a.ws_stride;                   // frame blockIdx.x
+    const float4 *partial = (const float4 *)(ws + SG_LOSS_OFF_PART);
+    float *scalars = (float *)(ws + sg_loss_off_scalars(a.W));
     if (losses) losses += 4 * blockIdx.x;
-    double t0 = 0, t1 = 0, t2 = 0;
-    for (int i = threadIdx.x; i < nblocks; i += 256) { const float4 p = partial[i]; t0 += p.x; t1 += p.y; t2 += p.z; }
-    sR[threadIdx.x][0] = t0; sR[threadIdx.x][1] = t1; sR[threadIdx.x][2] = t2;
+    double t0 = 0, t1 = 0;
+    for (int i = threadIdx.x; i < a.units; i += 256) { const float4 p = partial[i]; t0 += p.x; t1 += p.y; }
+    sR[threadIdx.x][0] = t0; sR[threadIdx.x][1] = t1;
+    if (threadIdx.x < 64) { const double m = sg_mask_total((const float *)ws, threadIdx.x); if (threadIdx.x == 0) sMask = m; }
     __syncthreads();
     for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s)
-            for (int q = 0; q < 3; q++) sR[threadIdx.x][q] += sR[threadIdx.x + s][q];
+        if ((int)threadIdx.x < s) { sR[threadIdx.x][0] += sR[threadIdx.x + s][0]; sR[threadIdx.x][1] += sR[threadIdx.x + s][1]; }
         __syncthreads();
     }
     if (threadIdx.x == 0) {
         const double hw = (double)a.W * a.H;
-        const double s_l1 = sR[0][0], s_ssim = sR[0][1], s_mask = sR[0][2];
+        const double s_l1 = sR[0][0], s_ssim = sR[0][1], s_mask = sMask;
         const double Ll1 = s_l1 / s_mask, ssim_mean = s_ssim / (3.0 * hw);
         const double Lssim = (1.0 - ssim_mean) * (s_mask / hw);
         scalars[0] = (float)(a.l1_w * Ll1); scalars[1] = (float)(a.ssim_w * Lssim);
         scalars[2] = (float)Ll1; scalars[3] = (float)ssim_mean;
-        scalars[4] = (float)(a.l1_w / s_mask);
+        scalars[4] = (float)((double)a.l1_w / s_mask);
         scalars[5] = (float)(-(double)a.ssim_w * (s_mask / hw) / (3.0 * hw));
         if (losses) { losses[0] = scalars[0]; losses[1] = scalars[1]; losses[2] = scalars[2]; losses[3] = scalars[3]; }
     }
 }
 
-__global__ void __launch_bounds__(256)
-sg_ssim_grad_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__restrict__ gt_rgb,
-                    const float *__restrict__ mask, const float *__restrict__ bg, const float *__restrict__ maps,
-                    const float *__restrict__ scalars, const float *__restrict__ upstream, float *__restrict__ dL_draw)
-{
-    __shared__ float sM[3][SG_LH][SG_LP];
-    __shared__ float sH[SG_LH][SG_LT + 1];
-    __shared__ uint32_t sFlat[4][4];
-    const int tid = threadIdx.x;
-    const int X0 = blockIdx.x * SG_LT, Y0 = blockIdx.y * SG_LT;
-    const size_t hw = (size_t)a.W * a.H;
-    const int frame = blockIdx.z / 3;
-    {
-        const size_t fi = (size_t)frame * 3 * hw;
-        raw += fi; gt_rgb += (size_t)frame * a.gt_stride; mask += (size_t)frame * a.mask_stride; dL_draw += fi;
-        maps = sg_at(maps, (size_t)frame * a.ws_stride); scalars = sg_at(scalars, (size_t)frame * a.ws_stride);
-    }
-    // upstream = (d loss / d weighted l1 term, d loss / d weighted ssim term); 1, 1 when NULL (the same for all frames)
-    const float *up = upstream ? upstream + (size_t)frame * a.up_stride : nullptr;     // (up_stride 2: a pair of weights per frame)
-    const float u_l1 = up ? up[0] : 1.0f, u_ss = up ? up[1] : 1.0f;
-    const float c_l1 = scalars[4] * u_l1, c_ss = scalars[5] * u_ss;
-    {
-        const int ch = blockIdx.z - 3 * frame;
-        bool same = true;
-        float f0 = 0.0f, f1 = 0.0f, f2 = 0.0f;
-        {   // (all loads of the halo tile in flight together: see sg_ssim_stats_kernel)
-            float l0[SG_LOADS], l1[SG_LOADS], l2[SG_LOADS];
-#pragma unroll
-            for (int u = 0; u < SG_LOADS; u++) {
-                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
-                const int x = X0 - 5 + c, y = Y0 - 5 + r;
-                const int xc = x < 0 ? 0 : (x < a.W ? x : a.W - 1), yc = y < 0 ? 0 : (y < a.H ? y : a.H - 1);
-                const size_t p = (size_t)yc * a.W + xc;
-                l0[u] = maps[(size_t)(ch * 3 + 0) * hw + p]; l1[u] = maps[(size_t)(ch * 3 + 1) * hw + p];
-                l2[u] = maps[(size_t)(ch * 3 + 2) * hw + p];
-            }
-#pragma unroll
-            for (int u = 0; u < SG_LOADS; u++) {
-                const int i = tid + 256 * u, r = i / SG_LH, c = i - r * SG_LH;
-                const int x = X0 - 5 + c, y = Y0 - 5 + r;
-                const bool in = x >= 0 && x < a.W && y >= 0 && y < a.H;
-                const float m0 = in ? l0[u] : 0.0f, m1 = in ? l1[u] : 0.0f, m2 = in ? l2[u] : 0.0f;
-                if (i < SG_LH * SG_LH) { sM[0][r][c] = m0; sM[1][r][c] = m1; sM[2][r][c] = m2; }
-                if (u == 0) { f0 = m0; f1 = m1; f2 = m2; }
-                else if (i < SG_LH * SG_LH)
-                    same = same && __float_as_uint(m0) == __float_as_uint(f0) && __float_as_uint(m1) == __float_as_uint(f1)
-                           && __float_as_uint(m2) == __float_as_uint(f2);
-            }
-        }
-        const bool flat = sg_tile_is_flat(same, f0, f1, f2, sFlat, tid & 63, tid >> 6);
-        const bool hthread = tid < SG_LH * 4;
-        const int hr = tid >> 2, hc0 = (tid & 3) * 8;
-        const int c = tid & 31, r0 = (tid >> 5) * 4;
-        const float bgc = bg[ch];
-        float gq[3][4];
-        if (flat) {                                         // (one chain per map: see sg_ssim_stats_kernel)
-#pragma unroll
-            for (int q = 0; q < 3; q++) {
-                const float v = q == 0 ? f0 : q == 1 ? f1 : f2;
-                float h = 0.0f, t = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v, h);
-#pragma unroll
-                for (int k = 0; k < 11; k++) t = fmaf(a.w[k], h, t);
-#pragma unroll
-                for (int j = 0; j < 4; j++) gq[q][j] = t;
-            }
-        } else
-#pragma unroll
-        for (int q = 0; q < 3; q++) {
-            if (hthread) {
-                float v[18];
-#pragma unroll
-                for (int k = 0; k < 18; k++) v[k] = sM[q][hr][hc0 + k];
-#pragma unroll
-                for (int o = 0; o < 8; o++) {
-                    float h = 0.0f;
-#pragma unroll
-                    for (int k = 0; k < 11; k++) h = fmaf(a.w[k], v[o + k], h);
-                    sH[hr][hc0 + o] = h;
-                }
-            }
-            __syncthreads();
-            float col[14];
-#pragma unroll
-            for (int k = 0; k < 14; k++) col[k] = sH[r0 + k][c];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                float h = 0.0f;
-#pragma unroll
-                for (int k = 0; k < 11; k++) h = fmaf(a.w[k], col[j + k], h);
-                gq[q][j] = h;
-            }
-            __syncthreads();
-        }
-        float trv[4], tm[4], tgt[4];                        // the rendered / mask / target pixels of the four rows: twelve loads, one round trip
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int x = X0 + c, y = Y0 + r0 + j;
-            const int xc = x < a.W ? x : a.W - 1, yc = y < a.H ? y : a.H - 1;
-            const size_t p = (size_t)yc * a.W + xc;
-            trv[j] = raw[ch * hw + p]; tm[j] = mask[p]; tgt[j] = gt_rgb[ch * hw + p];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const int r = r0 + j;
-            const int x = X0 + c, y = Y0 + r;
-            const float g0 = gq[0][j], g1 = gq[1][j], g2 = gq[2][j];
-            if (x < a.W && y < a.H) {
-                const size_t p = (size_t)y * a.W + x;
-                const float rv = trv[j], m = tm[j];
-                const float xv = sg_clamp01(rv), yv = tgt[j] * m + bgc * (1.0f - m);
-                const float d = xv - yv;
-                const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-                float g = c_ss * (g0 + 2.0f * xv * g1 + yv * g2) + c_l1 * sgn;
-                // torch.clamp passes the gradient where min <= x <= max
-                dL_draw[ch * hw + p] = (rv >= 0.0f && rv <= 1.0f) ? g : 0.0f;
-            }
-        }
-    }
-}
-
 size_t sg_photo_loss_ws_bytes_impl(int W, int H)
 {
-    const size_t hw = (size_t)W * H;
-    const size_t nb = (size_t)((W + SG_LT - 1) / SG_LT) * ((H + SG_LT - 1) / SG_LT) * 3;
-    return sg_align(9 * hw * 4) + sg_align(nb * 16) + 256;
+    (void)H;
+    return sg_loss_off_scalars(W) + 256;
 }
 
-static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt_stride = 0, size_t mask_stride = 0, int up_stride = 0)
+static SgLossArgs sg_loss_args(int K, bool grad, int W, int H, float l1_w, float ssim_w, size_t gt_stride = 0, size_t mask_stride = 0,
+                               int up_stride = 0)
 {
     SgLossArgs a;
     a.W = W; a.H = H; a.l1_w = l1_w; a.ssim_w = ssim_w; a.up_stride = up_stride;
@@ -383,43 +638,46 @@ static SgLossArgs sg_loss_args(int W, int H, float l1_w, float ssim_w, size_t gt
         for (int x = 0; x < 11; x++) s += g[x];
         for (int x = 0; x < 11; x++) a.w[x] = g[x] / s;
     }
+    {   // strips x chunks: about SG_LOSS_WAVES waves in the launch, chunks of at least 16 rows
+        const int nout = grad ? SgLossGeo<true>::NOUT : SgLossGeo<false>::NOUT;
+        a.nstrips = (W + nout - 1) / nout;
+        const int cols = a.nstrips * 3 * K, most = (H + 15) / 16;
+        static const int waves = getenv("SG_LOSS_WAVES_EXP") ? atoi(getenv("SG_LOSS_WAVES_EXP")) : SG_LOSS_WAVES;   // EXPERIMENT
+        int nch = waves / cols;
+        nch = nch < 1 ? 1 : (nch > most ? most : nch);
+        a.R = (H + nch - 1) / nch;
+        a.nchunks = (H + a.R - 1) / a.R;
+        a.units = a.nstrips * a.nchunks * 3;
+    }
     return a;
 }
 
-// gradient pass alone over the workspace of an earlier forward-only call (window statistics + scalars)
+// gradient pass alone, after an earlier forward-only call on the same inputs (which left the mask partials in the workspace)
 void sg_launch_photo_loss_bwd(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                               const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,
                               size_t gt_stride, size_t mask_stride, hipStream_t st, int up_stride)
 {
-    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride, up_stride);
-    const size_t hw = (size_t)W * H;
-    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3 * K), block(256);
-    const int nb = (int)(grid.x * grid.y * 3);
-    const char *b = (const char *)ws;
-    const float *maps = (const float *)b;
-    const float *scalars = (const float *)(b + sg_align(9 * hw * 4) + sg_align((size_t)nb * 16));
+    const SgLossArgs a = sg_loss_args(K, true, W, H, l1_w, ssim_w, gt_stride, mask_stride, up_stride);
     sg_prof_begin(SG_K_PHOTO_LOSS, st);
-    hipLaunchKernelGGL(sg_ssim_grad_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, scalars, upstream, dL_draw);
+    hipLaunchKernelGGL((sg_photo_kernel<false>), dim3(sg_loss_blocks(a.units), K), dim3(192), 0, st, a, raw, gt_rgb, mask, bg,
+                       (char *)ws, upstream, dL_draw, (float *)nullptr, (float *)nullptr);
     sg_prof_end(SG_K_PHOTO_LOSS, st);
 }
 
-// K frames per launch: three launches for the K losses and gradients (frame = blockIdx.z / 3), K = 1: the single-frame call
+// K frames per launch: three launches for the K losses and gradients (frame = blockIdx.y), K = 1: the single-frame call
 void sg_launch_photo_loss(int K, int W, int H, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                           const float *mask, const float *bg, void *ws, float *pred_out, float *gt_out,
                           float *losses, const float *upstream, float *dL_draw, size_t gt_stride, size_t mask_stride, hipStream_t st)
 {
-    const SgLossArgs a = sg_loss_args(W, H, l1_w, ssim_w, gt_stride, mask_stride);
-    const size_t hw = (size_t)W * H;
-    dim3 grid((W + SG_LT - 1) / SG_LT, (H + SG_LT - 1) / SG_LT, 3 * K), block(256);
-    const int nb = (int)(grid.x * grid.y * 3);
-    char *b = (char *)ws;
-    float *maps = (float *)b;
-    float4 *partial = (float4 *)(b + sg_align(9 * hw * 4));
-    float *scalars = (float *)(b + sg_align(9 * hw * 4) + sg_align((size_t)nb * 16));
+    const SgLossArgs a = sg_loss_args(K, dL_draw != nullptr, W, H, l1_w, ssim_w, gt_stride, mask_stride);
+    const dim3 grid(sg_loss_blocks(a.units), K);
     sg_prof_begin(SG_K_PHOTO_LOSS, st);
-    hipLaunchKernelGGL(sg_ssim_stats_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, pred_out, gt_out, partial);
-    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(K), dim3(256), 0, st, a, partial, nb, scalars, losses);
+    hipLaunchKernelGGL(sg_mask_sum_kernel, dim3(SG_NP, K), dim3(256), 0, st, a, mask, (char *)ws);
     if (dL_draw)
-        hipLaunchKernelGGL(sg_ssim_grad_kernel, grid, block, 0, st, a, raw, gt_rgb, mask, bg, maps, scalars, upstream, dL_draw);
+        hipLaunchKernelGGL((sg_photo_kernel<true>), grid, dim3(192), 0, st, a, raw, gt_rgb, mask, bg, (char *)ws, upstream, dL_draw,
+                           pred_out, gt_out);
+    else
+        hipLaunchKernelGGL((sg_photo_fwd_kernel<true>), grid, dim3(64), 0, st, a, raw, gt_rgb, mask, bg, (char *)ws, pred_out, gt_out);
+    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(K), dim3(256), 0, st, a, (char *)ws, losses);
     sg_prof_end(SG_K_PHOTO_LOSS, st);
 }
