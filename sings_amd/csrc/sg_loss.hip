@@ -82,22 +82,32 @@ __device__ __forceinline__ double sg_mask_total(const float *__restrict__ mpart,
     return sg_wave_sum_f64(((double)p.x + (double)p.y) + ((double)p.z + (double)p.w));
 }
 
-__global__ void __launch_bounds__(256)
+// 1024 threads x 8 independent loads: the 8 MB of a 1080p mask are a latency problem (256 threads x 32 dependent trips took 7.2 us)
+__global__ void __launch_bounds__(1024)
 sg_mask_sum_kernel(SgLossArgs a, const float *__restrict__ mask, char *__restrict__ ws)
 {
-    __shared__ float sR[4];
+    __shared__ float sR[16];
     const size_t hw = (size_t)a.W * a.H;
     const int frame = blockIdx.y;
     mask += (size_t)frame * a.mask_stride;
     float *mpart = (float *)(ws + (size_t)frame * a.ws_stride);
     const size_t per = (hw + SG_NP - 1) / SG_NP, i0 = (size_t)blockIdx.x * per, i1 = i0 + per < hw ? i0 + per : hw;
     float acc = 0.0f;
-    for (size_t i = i0 + threadIdx.x; i < i1; i += 256) acc += mask[i];
+    for (size_t i = i0 + threadIdx.x; i < i1; i += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const size_t j = i + (size_t)k * 1024; v[k] = j < i1 ? mask[j] : 0.0f; }
+        acc += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sR[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) mpart[blockIdx.x] = (sR[0] + sR[1]) + (sR[2] + sR[3]);
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int k = 0; k < 16; k++) t += sR[k];
+        mpart[blockIdx.x] = t;
+    }
 }
 
 // image planes are addressed as raw buffers: descriptor in SGPRs, the row's byte offset in an SGPR, the lane's column offset in a
@@ -144,13 +154,6 @@ struct SgStatSt {
     float pc[3];                  // forward-only kernel: the next centre row in flight (raw, target, mask at the lane's own column)
     float acc_l1, acc_ssim;
 };
-// register state of the gradient wave
-struct SgGradSt {
-    float dw[3][11];              // ring of the last 11 rows of the horizontally windowed dm/dmu1, dm/dE[x^2], dm/dE[xy]
-    float pc[2][3];               // the next two centre rows in flight: raw, target, mask at the lane's own column
-    float acc_l1;
-};
-
 // loads of row y (clamped into the image: rows outside count as zeros where they are USED), all lanes, no branches
 __device__ __forceinline__ void sg_loss_prefetch_row(const SgLossCtx &c, float (&pin)[6], int y)
 {
@@ -269,56 +272,6 @@ __device__ __forceinline__ void sg_stat_step(const SgLossArgs &a, const SgW &w, 
     }
 }
 
-// One row step of the gradient wave: j = the step of the statistics wave whose derivative row (row R0 - 15 + j) lies in sD[j & 1].
-// The adjoint of the window (a zero-padded symmetric window is its own adjoint): across the lanes straight from that row, down the
-// rows in a register ring; the gradient row is yo = R0 - 20 + j.  PH = j mod 11.
-template <bool LOSS, int PH>
-__device__ __forceinline__ void sg_grad_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgGradSt &s, int j)
-{
-    const sg_f4 *sD = c.sD + (j & 1) * (SG_LN + 16);
-    {
-        // (all 16 bytes of an entry are asked for: ds_read_b128 runs at twice the rate of the b96 the compiler would narrow this to)
-#define SG_LDU(k) { u[k] = sD[c.lane + (k)]; asm volatile("" :: "v"(u[k].w)); }
-        sg_f4 u[11];
-        float g0, g1, g2;
-        SG_LDU(0) SG_LDU(1) SG_LDU(2) SG_LDU(3) SG_LDU(4) SG_LDU(5)
-        g0 = w.w[0] * u[0].x; g1 = w.w[0] * u[0].y; g2 = w.w[0] * u[0].z;
-#pragma unroll
-        for (int k = 1; k < 6; k++) { g0 = fmaf(w.w[k], u[k].x, g0); g1 = fmaf(w.w[k], u[k].y, g1); g2 = fmaf(w.w[k], u[k].z, g2); }
-        SG_LDU(6) SG_LDU(7) SG_LDU(8) SG_LDU(9) SG_LDU(10)
-#pragma unroll
-        for (int k = 6; k < 11; k++) { g0 = fmaf(w.w[k], u[k].x, g0); g1 = fmaf(w.w[k], u[k].y, g1); g2 = fmaf(w.w[k], u[k].z, g2); }
-#undef SG_LDU
-        s.dw[0][PH] = g0; s.dw[1][PH] = g1; s.dw[2][PH] = g2;
-    }
-    if (j < 20) return;
-    const int yo = c.R0 - 20 + j;
-    float g[3];
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-#define SG_RING(k) s.dw[q][(PH + 1 + (k)) % 11]
-        SG_WIN11(g[q], SG_RING)
-#undef SG_RING
-    }
-    {
-        const float rv = s.pc[0][0], mk = s.pc[0][2];
-        const float xv = sg_clamp01(rv), yv = s.pc[0][1] * mk + c.bgc * (1.0f - mk);
-        const float d = xv - yv;
-        if (c.out_lane) {
-            const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
-            const float gr = c.c_ss * (g[0] + 2.0f * xv * g[1] + yv * g[2]) + c.c_l1 * sgn;
-            const uint32_t r = (uint32_t)yo * c.pitch;
-            sg_buf_st(c.grad, c.oc, r, (rv >= 0.0f && rv <= 1.0f) ? gr : 0.0f);    // torch.clamp passes the gradient where min <= x <= max
-            if (c.has_pred) sg_buf_st(c.pred_out, c.oc, r, xv);
-            if (c.has_gt) sg_buf_st(c.gt_out, c.oc, r, yv);
-        }
-        if (LOSS) s.acc_l1 += c.out_lane ? fabsf(d) : 0.0f;
-    }
-#pragma unroll
-    for (int q = 0; q < 3; q++) s.pc[0][q] = s.pc[1][q];
-    sg_loss_prefetch_centre(c, s.pc[1], yo + 2);
-}
-
 // unit of workgroup b: runs of SG_LOSS_RUN consecutive units (the three channels of neighbouring strips: shared mask, shared halo
 // columns) stay on one XCD's L2 (workgroup b runs on XCD b % 8), the runs are dealt round-robin to the XCDs
 __device__ __forceinline__ int sg_loss_unit_of_block(int b)
@@ -403,67 +356,75 @@ sg_photo_fwd_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
 }
 
 // ---- forward + gradient: three waves per unit, a pipeline over the rows ------------------------------------------------------------
-// As ONE wave the two rings cost 175 registers (two waves per SIMD), and a wave issues a vector instruction every four cycles at best:
-// the vector pipe idled 60 % of the time (105 us per 1080p view).  As a pipeline each wave runs a third of the instructions of a row
-// and the whole kernel fits 96 registers:
-//   wave H (row t)    : loads, clamp / composite, the five products -> LDS row -> 11-tap window across the lanes -> sH[t & 1]
-//   wave V (row t - 1): the 55-register ring, window down the rows, SSIM value and its three derivatives -> sD[(t - 1) & 1]
-//   wave G (row t - 2): adjoint window across the lanes straight from sD, the 33-register ring, window down the rows, gradient out
-// One workgroup barrier per row hands the two rows over (double-buffered: a slot is rewritten two barriers after it was read).
-struct SgHSt { float pin[2][6]; };
+// As ONE wave the two rings cost 175 registers (two waves per SIMD) and every LDS round trip of a row sat on that wave's critical path:
+// 105 us per 1080p view.  As a pipeline each wave runs a third of the instructions of a row and the kernel fits 96 registers:
+//   wave H (rows 2i, 2i+1)    : loads, clamp / composite -> LDS rows -> 11-tap window across the lanes (x, y, x^2, y^2, x y) -> sH[i & 1]
+//   wave V (rows of step i-1) : the 55-register ring, window down the rows, SSIM value and its three derivatives -> sD[(i - 1) & 1]
+//   wave G (rows of step i-2) : adjoint window across the lanes straight from sD, the 33-register ring, window down the rows, gradient out
+// One workgroup barrier per step hands the rows over (double-buffered: a slot is rewritten two barriers after it was read).  A step is TWO
+// rows: a lone workgroup needs 1 200 cycles for a one-row step of ~100 vector instructions per wave (LDS round trips, the barrier, the
+// loop) and 82 such steps in sequence bound the kernel from below; with two independent rows per step those latencies overlap.
+#define SG_SIN_PITCH (SG_LN + 16)
+struct SgHSt { float pin[2][6]; };                           // the two rows of the NEXT step, in flight: raw, target, mask at the two columns of a lane
 struct SgVSt { float hw[5][11]; float acc_ssim; };
+struct SgGSt { float dw[3][11]; float pc[2][3]; float acc_l1; };    // pc: the two centre rows of the next step, in flight
 
-__device__ __forceinline__ void sg_h_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgHSt &s, sg_f2 *sIn, sg_f4 *sH4, float *sH1, int t)
+__device__ __forceinline__ void sg_h_stage(const SgLossCtx &c, const float (&pin)[6], int yin, float bgc, sg_f2 *row)
 {
-    const int yin = c.R0 - 10 + t;
-    const int buf = t & 1;
-    sIn += buf * (SG_LN + 16);
-    {
-        const bool rowok = (unsigned)yin < (unsigned)c.H;
-        const bool k0 = rowok && c.in0, k1 = rowok && c.in1;
-        const float m0 = s.pin[0][2], m1 = s.pin[0][5];
-        const float xv0 = k0 ? sg_clamp01(s.pin[0][0]) : 0.0f, yv0 = k0 ? s.pin[0][1] * m0 + c.bgc * (1.0f - m0) : 0.0f;
-        sIn[c.lane] = sg_f2{ xv0, yv0 };
-        if (c.lane < 10) {
-            const float xv1 = k1 ? sg_clamp01(s.pin[0][3]) : 0.0f, yv1 = k1 ? s.pin[0][4] * m1 + c.bgc * (1.0f - m1) : 0.0f;
-            sIn[SG_LN + c.lane] = sg_f2{ xv1, yv1 };
-        }
+    const bool rowok = (unsigned)yin < (unsigned)c.H;
+    const bool k0 = rowok && c.in0, k1 = rowok && c.in1;
+    const float m0 = pin[2], m1 = pin[5];
+    const float xv0 = k0 ? sg_clamp01(pin[0]) : 0.0f, yv0 = k0 ? pin[1] * m0 + bgc * (1.0f - m0) : 0.0f;
+    row[c.lane] = sg_f2{ xv0, yv0 };
+    if (c.lane < 10) {
+        const float xv1 = k1 ? sg_clamp01(pin[3]) : 0.0f, yv1 = k1 ? pin[4] * m1 + bgc * (1.0f - m1) : 0.0f;
+        row[SG_LN + c.lane] = sg_f2{ xv1, yv1 };
     }
-#pragma unroll
-    for (int q = 0; q < 6; q++) s.pin[0][q] = s.pin[1][q];
-    sg_loss_prefetch_row(c, s.pin[1], yin + 2);
+}
+
+// step i of wave H: input rows R0 - 10 + 2i and the next one
+__device__ __forceinline__ void sg_h_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgHSt &s, sg_f2 *sIn, sg_f4 *sH4, float *sH1, int i)
+{
+    const int yin = c.R0 - 10 + 2 * i;
+    const int buf = i & 1;
+    sg_f2 *row0 = sIn + (buf * 2) * SG_SIN_PITCH, *row1 = row0 + SG_SIN_PITCH;
+    sg_h_stage(c, s.pin[0], yin, c.bgc, row0);
+    sg_h_stage(c, s.pin[1], yin + 1, c.bgc, row1);
+    sg_loss_prefetch_row(c, s.pin[0], yin + 2);              // (a whole step ahead: ~2 us under load)
+    sg_loss_prefetch_row(c, s.pin[1], yin + 3);
     sg_wave_lds_sync();
-    float h0, h1, h2, h3, h4;
-    {
-        // (x, y) pairs only: the three products are made per tap -- two more vector instructions per tap than reading them, but the
-        // LDS, not the vector pipe, was the busiest unit of the CU with five values per entry (76 % against 53 %)
-        sg_f2 v[11];
+    // (x, y) pairs only: the three products are made per tap -- two more vector instructions per tap than reading them, but with five
+    // values per entry the LDS was the busiest unit of the CU
+    sg_f2 v0[11], v1[11];
 #pragma unroll
-        for (int k = 0; k < 11; k++) v[k] = sIn[c.lane + k];
+    for (int k = 0; k < 11; k++) v0[k] = row0[c.lane + k];
+#pragma unroll
+    for (int k = 0; k < 11; k++) v1[k] = row1[c.lane + k];
+    float h[2][5];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const sg_f2 *v = r ? v1 : v0;
         {
             const float wx = w.w[0] * v[0].x, wy = w.w[0] * v[0].y;
-            h0 = wx; h1 = wy; h2 = wx * v[0].x; h3 = wy * v[0].y; h4 = wx * v[0].y;
+            h[r][0] = wx; h[r][1] = wy; h[r][2] = wx * v[0].x; h[r][3] = wy * v[0].y; h[r][4] = wx * v[0].y;
         }
 #pragma unroll
         for (int k = 1; k < 11; k++) {
             const float wx = w.w[k] * v[k].x, wy = w.w[k] * v[k].y;
-            h0 += wx; h1 += wy;
-            h2 = fmaf(wx, v[k].x, h2); h3 = fmaf(wy, v[k].y, h3); h4 = fmaf(wx, v[k].y, h4);
+            h[r][0] += wx; h[r][1] += wy;
+            h[r][2] = fmaf(wx, v[k].x, h[r][2]); h[r][3] = fmaf(wy, v[k].y, h[r][3]); h[r][4] = fmaf(wx, v[k].y, h[r][4]);
         }
     }
-    sH4[buf * SG_LN + c.lane] = sg_f4{ h0, h1, h2, h3 }; sH1[buf * SG_LN + c.lane] = h4;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        sH4[(buf * 2 + r) * SG_LN + c.lane] = sg_f4{ h[r][0], h[r][1], h[r][2], h[r][3] }; sH1[(buf * 2 + r) * SG_LN + c.lane] = h[r][4];
+    }
 }
 
-// row j of wave H (input row R0 - 10 + j) arrives in sH[j & 1]; statistics row ys = R0 - 15 + j from j = 10 on.  PH = j mod 11.
+// statistics row ys = R0 - 15 + j from the ring whose newest entry (row j of wave H) sits in slot PH: SSIM value, its three derivatives -> sD row
 template <bool LOSS, int PH>
-__device__ __forceinline__ void sg_v_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgVSt &s, const sg_f4 *sH4, const float *sH1, sg_f4 *sD, int j)
+__device__ __forceinline__ void sg_v_row(const SgW &w, const SgLossCtx &c, SgVSt &s, sg_f4 *drow, int j)
 {
-    {
-        const sg_f4 h = sH4[(j & 1) * SG_LN + c.lane];
-        const float h4 = sH1[(j & 1) * SG_LN + c.lane];
-        s.hw[0][PH] = h.x; s.hw[1][PH] = h.y; s.hw[2][PH] = h.z; s.hw[3][PH] = h.w; s.hw[4][PH] = h4;
-    }
-    if (j < 10) return;
     const int ys = c.R0 - 15 + j;
     float st[5];
 #pragma unroll
@@ -485,8 +446,79 @@ __device__ __forceinline__ void sg_v_step(const SgLossArgs &a, const SgW &w, con
     const float dm_ds12 = 2.0f * Cn * (rA * rB);
     const float dm_dmu1 = 2.0f * mu2 * D * (rA * rB) - 2.0f * mu1 * m * rA - 2.0f * mu1 * dm_ds1 - mu2 * dm_ds12;
     const bool inimg = rowok && c.incol;
-    sD[(j & 1) * (SG_LN + 16) + c.lane + 5] = sg_f4{ inimg ? dm_dmu1 : 0.0f, inimg ? dm_ds1 : 0.0f, inimg ? dm_ds12 : 0.0f, 0.0f };
+    drow[c.lane + 5] = sg_f4{ inimg ? dm_dmu1 : 0.0f, inimg ? dm_ds1 : 0.0f, inimg ? dm_ds12 : 0.0f, 0.0f };
     if (LOSS) s.acc_ssim += (c.out_lane && rowok && ys >= c.R0 && ys < c.R1) ? m : 0.0f;
+}
+
+// step iv of wave V (P = iv mod 11): the two rows wave H left in sH[iv & 1] are rows j = 2 iv and 2 iv + 1 of the march
+template <bool LOSS, int P>
+__device__ __forceinline__ void sg_v_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgVSt &s, const sg_f4 *sH4, const float *sH1, sg_f4 *sD, int iv)
+{
+    constexpr int PH0 = (2 * P) % 11, PH1 = (2 * P + 1) % 11;
+    const int buf = iv & 1, j = 2 * iv;
+    const sg_f4 ha = sH4[(buf * 2) * SG_LN + c.lane], hb = sH4[(buf * 2 + 1) * SG_LN + c.lane];
+    const float ha4 = sH1[(buf * 2) * SG_LN + c.lane], hb4 = sH1[(buf * 2 + 1) * SG_LN + c.lane];
+    s.hw[0][PH0] = ha.x; s.hw[1][PH0] = ha.y; s.hw[2][PH0] = ha.z; s.hw[3][PH0] = ha.w; s.hw[4][PH0] = ha4;
+    if (j >= 10) sg_v_row<LOSS, PH0>(w, c, s, sD + (buf * 2) * SG_SIN_PITCH, j);
+    s.hw[0][PH1] = hb.x; s.hw[1][PH1] = hb.y; s.hw[2][PH1] = hb.z; s.hw[3][PH1] = hb.w; s.hw[4][PH1] = hb4;
+    if (j >= 10) sg_v_row<LOSS, PH1>(w, c, s, sD + (buf * 2 + 1) * SG_SIN_PITCH, j + 1);
+}
+
+// one derivative row of wave V (row j of the march) through the adjoint window: across the lanes straight from sD, into ring slot PH,
+// and from j = 20 on down the rows -> gradient row yo = R0 - 20 + j
+template <bool LOSS, int PH>
+__device__ __forceinline__ void sg_g_row(const SgW &w, const SgLossCtx &c, SgGSt &s, const sg_f4 *drow, const float (&pc)[3], int j)
+{
+    {
+        // (all 16 bytes of an entry are asked for: ds_read_b128 runs at twice the rate of the b96 the compiler would narrow this to)
+#define SG_LDU(k) { u[k] = drow[c.lane + (k)]; asm volatile("" :: "v"(u[k].w)); }
+        sg_f4 u[11];
+        float g0, g1, g2;
+        SG_LDU(0) SG_LDU(1) SG_LDU(2) SG_LDU(3) SG_LDU(4) SG_LDU(5) SG_LDU(6) SG_LDU(7) SG_LDU(8) SG_LDU(9) SG_LDU(10)
+#undef SG_LDU
+        g0 = w.w[0] * u[0].x; g1 = w.w[0] * u[0].y; g2 = w.w[0] * u[0].z;
+#pragma unroll
+        for (int k = 1; k < 11; k++) { g0 = fmaf(w.w[k], u[k].x, g0); g1 = fmaf(w.w[k], u[k].y, g1); g2 = fmaf(w.w[k], u[k].z, g2); }
+        s.dw[0][PH] = g0; s.dw[1][PH] = g1; s.dw[2][PH] = g2;
+    }
+    if (j < 20) return;
+    const int yo = c.R0 - 20 + j;
+    float g[3];
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+#define SG_RING(k) s.dw[q][(PH + 1 + (k)) % 11]
+        SG_WIN11(g[q], SG_RING)
+#undef SG_RING
+    }
+    const float rv = pc[0], mk = pc[2];
+    const float xv = sg_clamp01(rv), yv = pc[1] * mk + c.bgc * (1.0f - mk);
+    const float d = xv - yv;
+    const bool out = c.out_lane && yo < c.R1;                // (an odd number of rows: the second row of the last step belongs to the next chunk)
+    if (out) {
+        const float sgn = d > 0.0f ? 1.0f : (d < 0.0f ? -1.0f : 0.0f);
+        const float gr = c.c_ss * (g[0] + 2.0f * xv * g[1] + yv * g[2]) + c.c_l1 * sgn;
+        const uint32_t r = (uint32_t)yo * c.pitch;
+        sg_buf_st(c.grad, c.oc, r, (rv >= 0.0f && rv <= 1.0f) ? gr : 0.0f);        // torch.clamp passes the gradient where min <= x <= max
+        if (c.has_pred) sg_buf_st(c.pred_out, c.oc, r, xv);
+        if (c.has_gt) sg_buf_st(c.gt_out, c.oc, r, yv);
+    }
+    if (LOSS) s.acc_l1 += out ? fabsf(d) : 0.0f;
+}
+
+// step ig of wave G (P = ig mod 11): the two derivative rows in sD[ig & 1] are rows j = 2 ig and 2 ig + 1 of the march (called from j = 10 on)
+template <bool LOSS, int P>
+__device__ __forceinline__ void sg_g_step(const SgLossArgs &a, const SgW &w, const SgLossCtx &c, SgGSt &s, const sg_f4 *sD, int ig)
+{
+    constexpr int PH0 = (2 * P) % 11, PH1 = (2 * P + 1) % 11;
+    const int buf = ig & 1, j = 2 * ig;
+    sg_g_row<LOSS, PH0>(w, c, s, sD + (buf * 2) * SG_SIN_PITCH, s.pc[0], j);
+    sg_g_row<LOSS, PH1>(w, c, s, sD + (buf * 2 + 1) * SG_SIN_PITCH, s.pc[1], j + 1);
+    if (j >= 20) {
+        // the centre rows (raw, target, mask at the lane's own column) of the next step
+        const int yo = c.R0 - 20 + j;
+        sg_loss_prefetch_centre(c, s.pc[0], yo + 2);
+        sg_loss_prefetch_centre(c, s.pc[1], yo + 3);
+    }
 }
 
 #ifdef SG_LOSS_STAMP
@@ -495,10 +527,23 @@ __device__ unsigned long long sg_loss_stamps[8192 * 3 * 4];
 extern "C" int sg_debug_loss_stamps(unsigned long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg_loss_stamps), (size_t)n * 8); }
 #define SG_STAMP_BEGIN const unsigned long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
 #define SG_STAMP_END if (lane == 0 && blockIdx.y == 0) { unsigned long long *q = sg_loss_stamps + ((size_t)blockIdx.x * 3 + wave) * 4;      \
-    q[0] = st_c0; q[1] = st_r0; q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime(); }
+    q[0] = st_c0; q[1] = st_r0 | ((unsigned long long)(__builtin_amdgcn_s_getreg((4) | (0 << 6) | (31 << 11)) & 0xffffu) << 48) | ((unsigned long long)(__builtin_amdgcn_s_getreg((20) | (0 << 6) | (3 << 11)) & 0xfu) << 44); q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime(); }
 #else
 #define SG_STAMP_BEGIN
 #define SG_STAMP_END
+#endif
+// Time-sliced wave priority.  The arbiter serves the OLDEST wave first: of the eight workgroups of a CU (all start within 2 us) the first
+// dispatched finished at 55 us and the last at 78, the CU half empty in between (tools/loss_stamps.py).  A priority that rotates every step
+// gives every workgroup the same share: lifetimes 56-70 us, the launch 4.5 % shorter in cycles.
+__device__ __forceinline__ void sg_rot_prio(int x)
+{
+    switch (x & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
+                     case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
+}
+#ifndef SG_LOSS_NOPRIO
+#define SG_PRIO(i) sg_rot_prio((i) + (int)blockIdx.x)
+#else
+#define SG_PRIO(i)
 #endif
 #ifdef SG_LOSS_NOBAR
 #define SG_BAR()
@@ -512,10 +557,10 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
                 const float *__restrict__ bg, char *__restrict__ ws, const float *__restrict__ upstream,
                 float *__restrict__ dL_draw, float *__restrict__ pred_out, float *__restrict__ gt_out)
 {
-    __shared__ sg_f2 sIn[2][SG_LN + 16];
-    __shared__ sg_f4 sH4[2][SG_LN];
-    __shared__ float sH1[2][SG_LN];
-    __shared__ sg_f4 sD[2][SG_LN + 16];
+    __shared__ sg_f2 sIn[2 * 2][SG_SIN_PITCH];               // [step parity x row of the step]
+    __shared__ sg_f4 sH4[2 * 2][SG_LN];
+    __shared__ float sH1[2 * 2][SG_LN];
+    __shared__ sg_f4 sD[2 * 2][SG_SIN_PITCH];
 #ifdef SG_LOSS_PAD_LDS
     __shared__ float sPad[SG_LOSS_PAD_LDS / 4];                // EXPERIMENT: caps the workgroups per CU
     if (a.W < 0) sPad[threadIdx.x] = 1.0f;
@@ -528,15 +573,16 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
     const SgW w = sg_loss_weights(a);
     SgLossCtx c;
     sg_loss_ctx<true>(c, a, u, frame, lane, raw, gt_rgb, mask, bg, dL_draw, pred_out, gt_out);
-    c.sIn = nullptr; c.sD = &sD[0][0];
-    const int T = (c.R1 - c.R0) + 20;                        // rows wave H stages; V runs one row behind it, G two
+    c.sIn = nullptr; c.sD = nullptr;
+    // rows wave H stages: R + 20, in steps of two (an odd last row is computed and dropped); V runs one step behind H, G two
+    const int S = ((c.R1 - c.R0) + 20 + 1) / 2, I = S + 2;
     float part = 0.0f;
     if (wave == 0) {
         SgHSt s;
-        sg_loss_prefetch_row(c, s.pin[0], c.R0 - 10);
-        sg_loss_prefetch_row(c, s.pin[1], c.R0 - 9);
-        for (int t = 0; t < T + 2; t++) {
-            if (t < T) sg_h_step(a, w, c, s, &sIn[0][0], &sH4[0][0], &sH1[0][0], t);
+        sg_loss_prefetch_row(c, s.pin[0], c.R0 - 10); sg_loss_prefetch_row(c, s.pin[1], c.R0 - 9);
+        for (int i = 0; i < I; i++) {
+            SG_PRIO(i);
+            if (i < S) sg_h_step(a, w, c, s, &sIn[0][0], &sH4[0][0], &sH1[0][0], i);
             SG_BAR();
         }
     } else if (wave == 1) {
@@ -546,8 +592,9 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
 #pragma unroll
             for (int q = 0; q < 5; q++) s.hw[q][k] = 0.0f;
         s.acc_ssim = 0.0f;
-        for (int t0 = 0; t0 < T + 2; t0 += 11) {
-#define SG_STEP(PH) if (t0 + PH < T + 2) { if (t0 + PH >= 1 && t0 + PH <= T) sg_v_step<LOSS, (PH + 10) % 11>(a, w, c, s, &sH4[0][0], &sH1[0][0], &sD[0][0], t0 + PH - 1); SG_BAR(); }
+        for (int i0 = 0; i0 < I; i0 += 11) {
+            // step i handles the rows of wave H's step i - 1
+#define SG_STEP(P) if (i0 + P < I) { SG_PRIO(i0 + P); if (i0 + P >= 1 && i0 + P <= S) sg_v_step<LOSS, (P + 10) % 11>(a, w, c, s, &sH4[0][0], &sH1[0][0], &sD[0][0], i0 + P - 1); SG_BAR(); }
             SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
 #undef SG_STEP
         }
@@ -563,17 +610,16 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
             c.c_l1 = (float)((double)a.l1_w / s_mask) * u_l1;
             c.c_ss = (float)(-(double)a.ssim_w * (s_mask / (double)hw) / (3.0 * (double)hw)) * u_ss;
         }
-        SgGradSt s;
+        SgGSt s;
 #pragma unroll
         for (int k = 0; k < 11; k++)
 #pragma unroll
             for (int q = 0; q < 3; q++) s.dw[q][k] = 0.0f;
         s.acc_l1 = 0.0f;
-        sg_loss_prefetch_centre(c, s.pc[0], c.R0);
-        sg_loss_prefetch_centre(c, s.pc[1], c.R0 + 1);
-        for (int t0 = 0; t0 < T + 2; t0 += 11) {
-            // iteration t handles the derivative row of wave V's step j = t - 2 (rows exist from j = 10 on)
-#define SG_STEP(PH) if (t0 + PH < T + 2) { if (t0 + PH >= 12) sg_grad_step<LOSS, (PH + 9) % 11>(a, w, c, s, t0 + PH - 2); SG_BAR(); }
+        sg_loss_prefetch_centre(c, s.pc[0], c.R0); sg_loss_prefetch_centre(c, s.pc[1], c.R0 + 1);
+        for (int i0 = 0; i0 < I; i0 += 11) {
+            // step i handles the derivative rows of wave V's step i - 1 = wave H's step i - 2 (derivative rows exist from march row 10 on)
+#define SG_STEP(P) if (i0 + P < I) { SG_PRIO(i0 + P); if (i0 + P >= 7) sg_g_step<LOSS, (P + 9) % 11>(a, w, c, s, &sD[0][0], i0 + P - 2); SG_BAR(); }
             SG_STEP(0); SG_STEP(1); SG_STEP(2); SG_STEP(3); SG_STEP(4); SG_STEP(5); SG_STEP(6); SG_STEP(7); SG_STEP(8); SG_STEP(9); SG_STEP(10);
 #undef SG_STEP
         }
@@ -589,27 +635,26 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
 }
 
 // scalars[0..3] = (l1_w * Ll1, ssim_w * Lssim, Ll1, mean ssim); scalars[4..5] = gradient scales (c_l1, c_ssim), for inspection
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 sg_loss_reduce_kernel(SgLossArgs a, char *__restrict__ ws, float *__restrict__ losses)
 {
-    __shared__ double sR[256][2];
+    __shared__ double sR[16][2];
     __shared__ double sMask;
     ws += (size_t)blockIdx.x * a.ws_stride;                   // frame blockIdx.x
     const float4 *partial = (const float4 *)(ws + SG_LOSS_OFF_PART);
     float *scalars = (float *)(ws + sg_loss_off_scalars(a.W));
     if (losses) losses += 4 * blockIdx.x;
     double t0 = 0, t1 = 0;
-    for (int i = threadIdx.x; i < a.units; i += 256) { const float4 p = partial[i]; t0 += p.x; t1 += p.y; }
-    sR[threadIdx.x][0] = t0; sR[threadIdx.x][1] = t1;
+    for (int i = threadIdx.x; i < a.units; i += 1024) { const float4 p = partial[i]; t0 += p.x; t1 += p.y; }
+    t0 = sg_wave_sum_f64(t0); t1 = sg_wave_sum_f64(t1);
+    if ((threadIdx.x & 63) == 0) { sR[threadIdx.x >> 6][0] = t0; sR[threadIdx.x >> 6][1] = t1; }
     if (threadIdx.x < 64) { const double m = sg_mask_total((const float *)ws, threadIdx.x); if (threadIdx.x == 0) sMask = m; }
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) { sR[threadIdx.x][0] += sR[threadIdx.x + s][0]; sR[threadIdx.x][1] += sR[threadIdx.x + s][1]; }
-        __syncthreads();
-    }
     if (threadIdx.x == 0) {
+        double s_l1 = 0, s_ssim = 0;
+        for (int k = 0; k < 16; k++) { s_l1 += sR[k][0]; s_ssim += sR[k][1]; }
         const double hw = (double)a.W * a.H;
-        const double s_l1 = sR[0][0], s_ssim = sR[0][1], s_mask = sMask;
+        const double s_mask = sMask;
         const double Ll1 = s_l1 / s_mask, ssim_mean = s_ssim / (3.0 * hw);
         const double Lssim = (1.0 - ssim_mean) * (s_mask / hw);
         scalars[0] = (float)(a.l1_w * Ll1); scalars[1] = (float)(a.ssim_w * Lssim);
@@ -672,12 +717,12 @@ void sg_launch_photo_loss(int K, int W, int H, float l1_w, float ssim_w, const f
     const SgLossArgs a = sg_loss_args(K, dL_draw != nullptr, W, H, l1_w, ssim_w, gt_stride, mask_stride);
     const dim3 grid(sg_loss_blocks(a.units), K);
     sg_prof_begin(SG_K_PHOTO_LOSS, st);
-    hipLaunchKernelGGL(sg_mask_sum_kernel, dim3(SG_NP, K), dim3(256), 0, st, a, mask, (char *)ws);
+    hipLaunchKernelGGL(sg_mask_sum_kernel, dim3(SG_NP, K), dim3(1024), 0, st, a, mask, (char *)ws);
     if (dL_draw)
         hipLaunchKernelGGL((sg_photo_kernel<true>), grid, dim3(192), 0, st, a, raw, gt_rgb, mask, bg, (char *)ws, upstream, dL_draw,
                            pred_out, gt_out);
     else
         hipLaunchKernelGGL((sg_photo_fwd_kernel<true>), grid, dim3(64), 0, st, a, raw, gt_rgb, mask, bg, (char *)ws, pred_out, gt_out);
-    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(K), dim3(256), 0, st, a, (char *)ws, losses);
+    hipLaunchKernelGGL(sg_loss_reduce_kernel, dim3(K), dim3(1024), 0, st, a, (char *)ws, losses);
     sg_prof_end(SG_K_PHOTO_LOSS, st);
 }

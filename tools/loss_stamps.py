@@ -16,9 +16,12 @@ n = 8192 * 3 * 4
 buf = (C.c_ulonglong * n)()
 lib.sg_debug_loss_stamps.argtypes = [C.c_void_p, C.c_int]
 assert lib.sg_debug_loss_stamps(buf, n) == 0
-s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 3, 4).astype(np.int64)
+raw_s = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 3, 4).copy()
+hwid = (raw_s[..., 1] >> np.uint64(48)).astype(np.int64); xcc = ((raw_s[..., 1] >> np.uint64(44)) & np.uint64(0xf)).astype(np.int64)
+raw_s[..., 1] &= np.uint64((1 << 44) - 1)
+s = raw_s.astype(np.int64)
 live = s[:, :, 3] > 0
-s = s[live.all(1)]
+sel = live.all(1); s = s[sel]; hwid = hwid[sel]; xcc = xcc[sel]
 print("workgroups", len(s))
 c0, r0, c1, r1 = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
 t0 = r0.min()
@@ -30,3 +33,26 @@ clk = (c1 - c0) / np.maximum(r1 - r0, 1) * 100.0
 print("shader clock MHz: median %.0f min %.0f max %.0f" % (np.median(clk), clk.min(), clk.max()))
 for w, nme in enumerate("HVG"):
     print(nme, "life median %.1f us" % np.median(life[:, w]), "end offset median %.1f" % np.median((r1[:, w] - t0) / 100.0))
+
+# placement: workgroups per CU (XCC, SE, CU) and lifetime against the load of the CU
+cu = xcc[:, 0] * 1000 + ((hwid[:, 0] >> 13) & 7) * 100 + ((hwid[:, 0] >> 8) & 15)
+ids, cnt = np.unique(cu, return_counts=True)
+print("CUs used", len(ids), "workgroups per CU histogram", dict(zip(*np.unique(cnt, return_counts=True))))
+wl = life[:, 0]
+for n in np.unique(cnt):
+    m = np.isin(cu, ids[cnt == n])
+    print("  CUs with %d workgroups: wave life median %.1f max %.1f us" % (n, np.median(wl[m]), wl[m].max()))
+simd = (hwid >> 4) & 3
+print("waves per SIMD of the busiest CU:", np.bincount(simd[cu == ids[np.argmax(cnt)]].ravel(), minlength=4))
+print("life by XCC:", " ".join("%d:%.1f" % (x, np.median(wl[xcc[:, 0] == x])) for x in np.unique(xcc[:, 0])))
+se = (hwid[:, 0] >> 13) & 7
+print("life by SE :", " ".join("%d:%.1f" % (x, np.median(wl[se == x])) for x in np.unique(se)))
+percu = np.array([np.median(wl[cu == i]) for i in ids])
+print("per-CU median life: min %.1f median %.1f max %.1f ; within-CU spread (max-min) median %.1f" % (percu.min(), np.median(percu), percu.max(), np.median([wl[cu == i].max() - wl[cu == i].min() for i in ids])))
+order = np.argsort(wl)
+blk = np.nonzero(sel)[0]
+print("slowest 12 workgroups: block ids", blk[order[-12:]], "life", np.round(wl[order[-12:]], 1))
+print("fastest 12 workgroups: block ids", blk[order[:12]], "life", np.round(wl[order[:12]], 1))
+clkw = clk[:, 0]
+print("clock by XCC:", " ".join("%d:%.0f" % (x, np.median(clkw[xcc[:, 0] == x])) for x in np.unique(xcc[:, 0])))
+print("corr(life, clock) %.2f" % np.corrcoef(wl, clkw)[0, 1])
