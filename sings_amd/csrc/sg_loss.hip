@@ -26,18 +26,14 @@
 // Cache hits.  Every pixel's sums run in the same order over its own 21 x 21 neighbourhood, so pixels with identical
 // neighbourhoods get identical bits wherever they lie in a strip (tests: flat background of an avatar frame).
 #include "sg_common.h"
-#include <stdlib.h>
 
 #define SG_LN 64                  // lanes of a strip = columns whose window statistics it holds
 #define SG_NP 256                 // mask partial sums per frame
-#define SG_LOSS_WAVES 2048        // waves a launch aims for: two per SIMD
-#define SG_LOSS_RUN 12
-#ifndef SG_LOSS_OCC
-#define SG_LOSS_OCC 2
-#endif
+#define SG_LOSS_UNITS 2048        // units (workgroups) a launch aims for: eight per CU, all resident
+#define SG_LOSS_RUN 12            // consecutive units (3 channels x 4 strips) dealt to one XCD
 // reciprocals of the two SSIM denominators: v_rcp_f32 (1 ulp) instead of the correctly rounded division (ten instructions each);
 // the difference is far inside the fp32 noise of the window sums in front of it
-#define SG_LOSS_RCP(v) __builtin_amdgcn_rcpf(v)            // consecutive units (3 channels x 4 strips) dealt to one XCD
+#define SG_LOSS_RCP(v) __builtin_amdgcn_rcpf(v)
 
 struct SgLossArgs {
     int W, H;
@@ -51,7 +47,7 @@ struct SgLossArgs {
 };
 
 // workspace of one frame: [SG_NP floats: mask partials][cap float4: per-wave (sum |pred - gt|, sum ssim)][8 floats: scalars]
-__host__ __device__ inline size_t sg_loss_unit_cap(int W) { return (size_t)2 * SG_LOSS_WAVES + 3 * (size_t)((W + 53) / 54) + 8; }
+__host__ __device__ inline size_t sg_loss_unit_cap(int W) { return (size_t)SG_LOSS_UNITS + 3 * (size_t)((W + 53) / 54) + 8; }
 #define SG_LOSS_OFF_PART ((size_t)SG_NP * 4)
 __host__ __device__ inline size_t sg_loss_off_scalars(int W) { return SG_LOSS_OFF_PART + ((sg_loss_unit_cap(W) * 16 + 255) & ~(size_t)255); }
 
@@ -540,16 +536,8 @@ __device__ __forceinline__ void sg_rot_prio(int x)
     switch (x & 3) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break;
                      case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
 }
-#ifndef SG_LOSS_NOPRIO
 #define SG_PRIO(i) sg_rot_prio((i) + (int)blockIdx.x)
-#else
-#define SG_PRIO(i)
-#endif
-#ifdef SG_LOSS_NOBAR
-#define SG_BAR()
-#else
 #define SG_BAR() __syncthreads()
-#endif
 
 template <bool LOSS>
 __global__ void __launch_bounds__(192)
@@ -561,10 +549,6 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
     __shared__ sg_f4 sH4[2 * 2][SG_LN];
     __shared__ float sH1[2 * 2][SG_LN];
     __shared__ sg_f4 sD[2 * 2][SG_SIN_PITCH];
-#ifdef SG_LOSS_PAD_LDS
-    __shared__ float sPad[SG_LOSS_PAD_LDS / 4];                // EXPERIMENT: caps the workgroups per CU
-    if (a.W < 0) sPad[threadIdx.x] = 1.0f;
-#endif
     SG_STAMP_BEGIN
     const int u = sg_loss_unit_of_block(blockIdx.x);
     if (u >= a.units) return;
@@ -683,12 +667,11 @@ static SgLossArgs sg_loss_args(int K, bool grad, int W, int H, float l1_w, float
         for (int x = 0; x < 11; x++) s += g[x];
         for (int x = 0; x < 11; x++) a.w[x] = g[x] / s;
     }
-    {   // strips x chunks: about SG_LOSS_WAVES waves in the launch, chunks of at least 16 rows
+    {   // strips x chunks: at most SG_LOSS_UNITS units per launch (one round of workgroups), chunks of at least 16 rows
         const int nout = grad ? SgLossGeo<true>::NOUT : SgLossGeo<false>::NOUT;
         a.nstrips = (W + nout - 1) / nout;
         const int cols = a.nstrips * 3 * K, most = (H + 15) / 16;
-        static const int waves = getenv("SG_LOSS_WAVES_EXP") ? atoi(getenv("SG_LOSS_WAVES_EXP")) : SG_LOSS_WAVES;   // EXPERIMENT
-        int nch = waves / cols;
+        int nch = SG_LOSS_UNITS / cols;
         nch = nch < 1 ? 1 : (nch > most ? most : nch);
         a.R = (H + nch - 1) / nch;
         a.nchunks = (H + a.R - 1) / a.R;
