@@ -55,10 +55,10 @@ from benchkit import roofline as _roofline                                   # n
 from benchkit.distrib import (COMM_KEYS, FORCE_DIST, LIGHT_TIMED_S, MAX_REPEATS, MIN_TIMED_S, _grad_sha256, _log, _median,   # noqa: E402,F401
                               _ranks_agree, allreduce_probe, densification_stats_check, dist_setup, dp_self_check,
                               exposed_by_algorithm, make_frame_parallel, spawn_ranks, timed_region, timed_repeats, usable_cores)
-from benchkit.roofline import (CLOCK_HZ, HBM_COPY_GBS, HBM_PEAK_GBS, KERNEL_VARIANTS, PMC_SOURCES, SIMDS, VALU_CYCLES_GUIDE,   # noqa: E402,F401
+from benchkit.roofline import (CLOCK_HZ, HBM_COPY_GBS, HBM_PEAK_GBS, KERNEL_VARIANTS, PMC_SOURCES, RASTER_SOURCES, SIMDS, VALU_CYCLES_GUIDE,   # noqa: E402,F401
                                VALU_CYCLES_MIX, XGMI_LINK_GBS, _committed_pmc, _meta_status, algorithmic_bytes,
                                algorithmic_bytes_skinned, build_roofline, git_blob_sha1, measure_copy_peak, pmc_view_traffic,
-                               scaling_model, source_hashes)
+                               scaling_model, source_hashes, sources_of)
 
 
 def parse_args():
@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--scene-seed", type=int, default=3,
+                    help="seed of the synthetic scene S(N,W,H,deg,seed) (SURVEY.md 8(d): cfg2 = 2, cfg3 = 3, cfg5 = 5; what tests/test_gpu_raster.py checks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true",
                     help="default single-GPU run only: skip the `secondary` block (the other BASELINE configurations, each a timed "
@@ -188,7 +190,8 @@ def leg_raster(a, ctx):
     from sings_amd.scene import synthetic_scene
 
     N, W, H, deg = a.gaussians, a.width, a.height, a.sh_degree
-    s = synthetic_scene(N, W, H, deg, 3)
+    seed = int(getattr(a, "scene_seed", 3))
+    s = synthetic_scene(N, W, H, deg, seed)
     # frame-parallel: every (rank, view-of-the-step) pair looks at the same Gaussians from its own camera, shifted along x
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     P_T = np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"]
@@ -417,7 +420,7 @@ def leg_raster(a, ctx):
         "timed_region_s": sum(els), "repeats": len(els), "ms_per_step_min": min(els) / a.steps * 1e3,
         "ms_per_step_max": max(els) / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"S({N},{W},{H},deg={deg},seed=3): {N} Gaussians, {W}x{H}, SH deg {deg}, "
+        "config": {"workload": f"S({N},{W},{H},deg={deg},seed={seed}): {N} Gaussians, {W}x{H}, SH deg {deg}, "
                                f"{'forward only' if a.forward_only else 'fwd+bwd'}, "
                                f"R={R} (tile,Gaussian) pairs, every view of a step within 0.1 % of that (cameras a few cm apart), "
                                f"frame-parallel dp{world}",
@@ -1289,9 +1292,9 @@ def secondary_legs(a, ctx, head):
             setattr(v, k, val)
         return v
     plan = [
-        ("cfg2_forward", "raster", variant(gaussians=50000, width=512, height=512, sh_degree=0, forward_only=True, steps=max(a.steps, 50))),
+        ("cfg2_forward", "raster", variant(gaussians=50000, width=512, height=512, sh_degree=0, scene_seed=2, forward_only=True, steps=max(a.steps, 50))),
         ("cfg4_avatar", "avatar", variant(workload="avatar", views_per_step=24, streams=3, frames_per_launch=None, steps=max(a.steps // 2, 10))),
-        ("cfg5_regularisers", "raster", variant(gaussians=500000, width=2048, height=2048, regularisers=True, steps=max(a.steps // 4, 5))),
+        ("cfg5_regularisers", "raster", variant(gaussians=500000, width=2048, height=2048, scene_seed=5, regularisers=True, steps=max(a.steps // 4, 5))),
         ("train_step_K1", "train", variant(workload="train", views_per_step=1, steps=max(a.steps, 20), warmup=5)),
         ("train_step_K16", "train", variant(workload="train", views_per_step=16, steps=max(a.steps // 2, 10), warmup=3, no_cpu_baseline=True)),
     ]

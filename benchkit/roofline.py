@@ -88,9 +88,33 @@ def scaling_model(bytes_, t_step_ms, t_one_ms, exposed_ms=None, world=8):
     return {"label": "MODEL of the 8-GPU step, not a measurement (SCALE runs are the driver's)", "world": world, "collective_bytes": int(S),
             "xgmi_link_GBs": XGMI_LINK_GBS, "collective_ms": coll, "exposed_ms_measured_world1": exposed_ms,
             "t_step_ms": {"batched": t_step_ms, "one_view_per_step": t_one_ms}, "predicted_scale_8": pred}
-PMC_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
-               "sings_amd/csrc/sg_project.h", "sings_amd/csrc/sg_preprocess.hip", "sings_amd/csrc/sg_skin.hip",
-               "sings_amd/csrc/sg_common.h", "sings_amd/csrc/sg_math.h")
+# kernel sources a PMC pass is keyed to (git blob hashes in the sidecar): the rasterisation path ...
+RASTER_SOURCES = ("sings_amd/csrc/sg_render.hip", "sings_amd/csrc/sg_sort.h", "sings_amd/csrc/sg_binning.hip",
+                  "sings_amd/csrc/sg_project.h", "sings_amd/csrc/sg_preprocess.hip", "sings_amd/csrc/sg_skin.hip",
+                  "sings_amd/csrc/sg_common.h", "sings_amd/csrc/sg_math.h")
+# ... and (round 6) the loss / decode / linear / regulariser / rotation kernels of the training step
+PMC_SOURCES = RASTER_SOURCES + ("sings_amd/csrc/sg_loss.hip", "sings_amd/csrc/sg_decode.hip", "sings_amd/csrc/sg_linear.hip",
+                                "sings_amd/csrc/sg_reg.hip", "sings_amd/csrc/sg_rot.hip", "sings_amd/csrc/sg_rot.h")
+# which of them a kernel is compiled from (by name prefix; everything else: the rasterisation path)
+KERNEL_SOURCES = (
+    (("sg_photo", "sg_mask_sum", "sg_loss_reduce", "sg_ssim"), ("sings_amd/csrc/sg_loss.hip", "sings_amd/csrc/sg_common.h")),
+    (("sg_triplane", "sg_tp_", "sg_bias_act"), ("sings_amd/csrc/sg_decode.hip", "sings_amd/csrc/sg_common.h")),
+    (("sg_linear", "sg_weight_grad", "sg_wgrad"), ("sings_amd/csrc/sg_linear.hip", "sings_amd/csrc/sg_common.h")),
+    (("sg_region", "sg_rows_lap", "sg_mesh_edge", "sg_l2norm", "sg_knn", "sg_reg"), ("sings_amd/csrc/sg_reg.hip", "sings_amd/csrc/sg_common.h")),
+    (("sg_m2q", "sg_rot", "sg_qmul", "sg_joint"), ("sings_amd/csrc/sg_rot.hip", "sings_amd/csrc/sg_rot.h", "sings_amd/csrc/sg_common.h")),
+)
+
+
+def sources_of(kernel=None, workload="raster"):
+    """The source files whose hashes decide whether a committed PMC pass still describes `kernel` (None: every kernel the
+    workload launches -- the rasterisation path for 'raster', all of PMC_SOURCES for 'avatar' / 'train')."""
+    if kernel is not None:
+        base = kernel.split("<")[0]
+        for prefixes, files in KERNEL_SOURCES:
+            if base.startswith(prefixes):
+                return files
+        return RASTER_SOURCES
+    return RASTER_SOURCES if workload == "raster" else PMC_SOURCES
 
 
 def git_blob_sha1(path):
@@ -104,15 +128,21 @@ def source_hashes(root=ROOT):
     return {rel: git_blob_sha1(os.path.join(root, rel)) for rel in PMC_SOURCES}
 
 
-def _meta_status(meta, cfg, root=ROOT):
+def _meta_status(meta, cfg, root=ROOT, kernel=None):
     """None if the PMC pass described by `meta` (sidecar written by tools/pmc_summary.py: configuration it ran + git blob
-    hashes of the kernel sources it profiled) is a pass of THIS configuration over THIS tree; otherwise the reason."""
+    hashes of the kernel sources it profiled) is a pass of THIS configuration over THIS tree; otherwise the reason.  The sources
+    that count are those `kernel` is compiled from (sources_of; None: all the workload's kernels): a sidecar that does not key one
+    of them (passes older than round 6 key the rasterisation path only) says nothing about that kernel."""
     if not isinstance(meta, dict) or "sources" not in meta or "config" not in meta:
         return "no sidecar (configuration and kernel-source hashes of the PMC pass unknown)"
     if any(meta["config"].get(k) != v for k, v in cfg.items()):
         return f"PMC pass of another configuration ({meta['config']})"
     cur = source_hashes(root)
-    changed = sorted(rel for rel, h in meta["sources"].items() if cur.get(rel) != h)
+    need = sources_of(kernel, cfg.get("workload", "raster"))
+    missing = sorted(rel for rel in need if rel not in meta["sources"])
+    if missing:
+        return "the PMC pass is not keyed to " + ", ".join(os.path.basename(c) for c in missing)
+    changed = sorted(rel for rel in need if cur.get(rel) != meta["sources"][rel])
     if changed:
         return "kernel sources changed since the PMC pass: " + ", ".join(os.path.basename(c) for c in changed)
     return None
@@ -139,7 +169,7 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
                 meta = json.load(open(os.path.join(pdir, fn[:-4] + ".meta.json")))
             except Exception:
                 meta = None
-            st = _meta_status(meta, cfg, root)
+            st = _meta_status(meta, cfg, root, kernel)
             if st is not None:
                 why = f"profiles/{fn}: {st}"
                 continue
@@ -157,7 +187,7 @@ def _committed_pmc(kernel, cfg, pdir=None, root=ROOT):
     try:
         for fn in sorted(f for f in os.listdir(pdir) if f.endswith("hbm_traffic.json")):
             tj = json.load(open(os.path.join(pdir, fn)))
-            st = _meta_status(tj.get("_meta"), cfg, root)
+            st = _meta_status(tj.get("_meta"), cfg, root, kernel)
             if st is None:
                 got = [v for k, v in tj.items() if k.split("<")[0] in KERNEL_VARIANTS.get(kernel, (kernel,))]
                 res["traffic"] = sum(got) if got else None

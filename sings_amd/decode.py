@@ -455,7 +455,9 @@ def _weight_grad(x, W, dz, has_b, flush=True):
         dW = _arena_out(W)
         db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_b else None
         ws2 = torch.empty(int(lib.sg_weight_grad_ws_bytes(N, Cout, Cin)), dtype=torch.uint8, device=dev)
-        if _WG["on"]:
+        # (a parameter that already carries a .grad -- gradient accumulation, zero_grad(set_to_none=False) -- makes AccumulateGrad READ dW
+        #  on the main stream at once: the deferred launch would write memory autograd has read and may have freed.  Inline there.)
+        if _WG["on"] and getattr(W, "grad", None) is None:
             side, cur = _wg_stream(dev), torch.cuda.current_stream(dev)
             fork = torch.cuda.Event()
             fork.record(cur)                                     # dz (and x) are complete on the backward stream
@@ -535,7 +537,12 @@ class _LinearActShared(torch.autograd.Function):
         else:
             dx, dW, db = _lin_bwd(x, W, aux, ctx.act, ctx.has_b, dh, need_dx, need_dw)
             if need_dx and first and can_acc:
-                ctx.slot["dx"] = dx
+                slot = ctx.slot
+                slot["dx"] = dx
+                # The shared gradient belongs to THIS backward pass only.  A later pass over the same graph (retain_graph=True, one
+                # autograd.grad call per loss term, a pass that reaches only one of the decoders) must start with an empty slot: it
+                # would otherwise add into the earlier pass's tensor, hand autograd nothing, and lose its input gradient.
+                torch.autograd.Variable._execution_engine.queue_callback(lambda: slot.pop("dx", None))
         return dx, dW, db, None, None
 
 

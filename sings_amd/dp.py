@@ -190,8 +190,8 @@ class GradientPipeline:
         active = self.n_full if active is None else int(active)
         if not 0 < active <= self.n_full:
             raise ValueError("active must be in (0, floats_per_view]")
-        if active < self.n and self.k > 1:
-            self.acc[active:self.n].zero_()                      # (what the wider fold left there)
+        if active < self.n:
+            self.acc[active:self.n].zero_()                      # (what the wider fold -- k == 1: the row itself -- left there)
         self.n = active
         self._set_bounds()
 

@@ -302,6 +302,27 @@ def _backward_buffers(dev, P, M, bwd_bytes, has_sh, has_col, has_scale, has_cov)
             torch.empty(int(bwd_bytes), dtype=torch.uint8, device=dev))
 
 
+_PREALLOC_SETS = 2                   # backward-buffer sets a forward may allocate ahead of their backward (two views in flight)
+_PREALLOC = {"out": 0}
+
+
+class _PreallocSet:
+    """A forward's pre-allocated backward buffers; counted while they wait (a graph dropped without a backward frees the count too)."""
+
+    def __init__(self, bufs):
+        self.bufs = bufs
+        _PREALLOC["out"] += 1
+
+    def take(self):
+        bufs, self.bufs = self.bufs, None
+        if bufs is not None:
+            _PREALLOC["out"] -= 1
+        return bufs
+
+    def __del__(self):
+        self.take()
+
+
 def _empty_to_none(t):
     return None if t is None or t.numel() == 0 else t
 
@@ -348,8 +369,12 @@ class _RasterizeGaussians(torch.autograd.Function):
                 # (drop-in surface 0.358 ms against 0.293 for the pre-allocated engine; now the allocations hide under the previous
                 # view's backward).  Only when a gradient is wanted; handed out once (a second backward through a retained graph
                 # allocates afresh: autograd may have adopted the first set as .grad).
-                bufs = _backward_buffers(dev, P, M, L.bwd_bytes, sh is not None, colors_precomp is not None, scales is not None,
-                                         cov3Ds_precomp is not None) if need_bwd else None
+                # (At most _PREALLOC_SETS such sets are outstanding: a caller that renders many views before ONE backward would hold a
+                #  set -- ~80 MB at cfg3 -- per view; its later forwards leave the allocation to the backward, as before round 5.)
+                bufs = None
+                if need_bwd and _PREALLOC["out"] < _PREALLOC_SETS:
+                    bufs = _backward_buffers(dev, P, M, L.bwd_bytes, sh is not None, colors_precomp is not None, scales is not None,
+                                             cov3Ds_precomp is not None)
                 nr = C.c_int64(0)
                 _lib.check(lib.sg_rasterize_forward(
                     C.byref(s), P, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
@@ -367,7 +392,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.num_rendered = R
         ctx.capacity = cap
         ctx.sh_coeffs = M
-        ctx.bwd_bufs = bufs
+        ctx.bwd_bufs = None if bufs is None else _PreallocSet(bufs)
         ctx.bwd_bytes = int(L.bwd_bytes)
         ctx.settings_struct = (s, keep)                     # the backward passes the same struct (same camera, same flags)
         ctx.flags = (sh is not None, colors_precomp is not None, scales is not None, cov3Ds_precomp is not None)
@@ -394,7 +419,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         s, keep = ctx.settings_struct
         s.count_signal = None; s.count_signal_host = None
         g = _f32(grad_out_color, "grad_out_color", dev)
-        bufs, ctx.bwd_bufs = ctx.bwd_bufs, None
+        held, ctx.bwd_bufs = ctx.bwd_bufs, None
+        bufs = None if held is None else held.take()
         if bufs is None:
             bufs = _backward_buffers(dev, P, ctx.sh_coeffs, ctx.bwd_bytes, has_sh, has_col, has_scale, has_cov)
         dmeans3D, dmeans2D, dopac, dsh, dcol, dscales, drots, dcov, bwd_ws = bufs

@@ -98,8 +98,27 @@ def test_committed_passes_have_sidecars():
     pdir = os.path.join(ROOT, "profiles")
     newest = sorted(f for f in os.listdir(pdir) if f.endswith("_pmc_SQ.csv"))[-1]
     meta = json.load(open(os.path.join(pdir, newest[:-4] + ".meta.json")))
-    assert set(meta["sources"]) == set(bench.PMC_SOURCES) and "gaussians" in meta["config"]
+    assert set(meta["sources"]) >= set(bench.RASTER_SOURCES) and "gaussians" in meta["config"]
     assert "_meta" in json.load(open(os.path.join(pdir, "hbm_traffic.json")))
+
+
+def test_a_pass_counts_for_a_kernel_only_if_it_is_keyed_to_that_kernels_sources(tmp_path):
+    """Round 6: the loss / decode / linear / regulariser / rotation kernels are keyed to their own files.  A sidecar of the
+    rasterisation sources alone (rounds 1-5) still serves sg_render_bwd_kernel and says nothing about sg_photo_kernel; a full
+    sidecar serves both; a changed sg_loss.hip drops the loss kernel's counts and keeps the composite's."""
+    assert set(bench.sources_of("sg_photo_kernel<true>")) == {"sings_amd/csrc/sg_loss.hip", "sings_amd/csrc/sg_common.h"}
+    assert bench.sources_of("sg_render_bwd_kernel") == bench.RASTER_SOURCES and bench.sources_of(None, "train") == bench.PMC_SOURCES
+    full = bench.source_hashes()
+    assert set(full) == set(bench.PMC_SOURCES)
+    old = {"config": dict(CFG), "sources": {k: v for k, v in full.items() if k in bench.RASTER_SOURCES}}
+    assert bench._meta_status(old, CFG, kernel="sg_render_bwd_kernel") is None
+    assert "not keyed to sg_loss.hip" in bench._meta_status(old, CFG, kernel="sg_photo_kernel<true>")
+    new = {"config": dict(CFG), "sources": dict(full)}
+    assert bench._meta_status(new, CFG, kernel="sg_photo_kernel<true>") is None
+    new["sources"]["sings_amd/csrc/sg_loss.hip"] = "0" * 40
+    assert "sg_loss.hip" in bench._meta_status(new, CFG, kernel="sg_photo_kernel<true>")
+    assert bench._meta_status(new, CFG, kernel="sg_render_bwd_kernel") is None
+    assert bench._meta_status(new, dict(CFG, workload="train")) is not None      # (a whole train step: every source counts)
 
 
 def test_git_blob_hash_is_gits(tmp_path):

@@ -174,6 +174,9 @@ def test_default_line_carries_every_baseline_configuration():
         assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["algorithmic_bytes_per_view"] > 0
         assert e["parity"]["ok"], (k, e["parity"])
     assert sec["cfg2_forward"]["config"]["forward_only"] and sec["cfg2_forward"]["config"]["gaussians"] == 50000
+    # the SURVEY 8(d) scenes, the ones tests/test_gpu_raster.py checks: cfg2 = S(..., seed 2), cfg3 = seed 3, cfg5 = seed 5
+    assert "seed=3)" in j["config"]["workload"] and "seed=2)" in sec["cfg2_forward"]["config"]["workload"]
+    assert "seed=5)" in sec["cfg5_regularisers"]["config"]["workload"]
     assert sec["cfg5_regularisers"]["config"]["regularisers"] and sec["cfg5_regularisers"]["config"]["gaussians"] == 500000
     av = sec["cfg4_avatar"]
     assert av["config"]["gaussians"] == 150000 and av["train_step_ms_one_view"] > 0 and av["frames_per_s_one_frame_per_step"] > 0

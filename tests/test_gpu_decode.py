@@ -374,6 +374,46 @@ def test_layers_sharing_an_input_collect_one_gradient(order):
         _close(g.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="shared-input layers")
 
 
+def test_layers_sharing_an_input_over_two_backward_passes():
+    """The shared input gradient of decode.linear_act_shared lives for ONE backward pass: a.backward(retain_graph=True) followed by
+    b.backward() (each pass reaches one of the two layers) accumulates the same x.grad and parameter gradients as `linear_fan`, and a
+    second full pass over the retained graph doubles them instead of losing the input gradient."""
+    from sings_amd import decode
+    from sings_amd.decode import ACT_GELU
+    dev = _dev()
+    torch.manual_seed(32)
+    N, Cin = 10007, 96
+    l0, l1 = torch.nn.Linear(Cin, 128).to(dev), torch.nn.Linear(Cin, 64).to(dev)
+    x0 = torch.randn(N, Cin, device=dev)
+    u0, u1 = torch.randn(N, 128, device=dev), torch.randn(N, 64, device=dev)
+    params = list(l0.parameters()) + list(l1.parameters())
+
+    def run(shared, passes):
+        for p in params:
+            p.grad = None
+        x = x0.clone().requires_grad_(True)
+        if shared:
+            slot = {}
+            h0 = decode.linear_act_shared(x, l0, ACT_GELU, slot)
+            h1 = decode.linear_act_shared(x, l1, ACT_GELU, slot)
+        else:
+            h0, h1 = decode.linear_fan(x, [(l0, ACT_GELU, None), (l1, ACT_GELU, None)])
+        a, b = (h0 * u0).sum(), (h1 * u1).sum()
+        if passes == "a_then_b":
+            a.backward(retain_graph=True)
+            b.backward()
+        else:                                                    # two full passes over the retained graph
+            (a + b).backward(retain_graph=True)
+            (a + b).backward()
+        torch.cuda.synchronize()
+        return [x.grad.clone()] + [p.grad.clone() for p in params]
+
+    for passes in ("a_then_b", "twice"):
+        ref, got = run(False, passes), run(True, passes)
+        for r, g in zip(ref, got):
+            _close(g.cpu().numpy(), r.cpu().numpy(), rtol=2e-5, atol_scale=2e-6, what="shared-input layers, " + passes)
+
+
 def test_weight_gradients_on_a_side_stream_match_the_inline_ones():
     """decode.overlap_weight_grads(True): sg_weight_grad runs beside the backward chain and joins when backward() returns --
     bit-identical parameter gradients (the kernels are deterministic), also when the pass runs twice in a row."""

@@ -2,7 +2,7 @@
 (GPU box): python tools/wrapper_time.py  -- per view: wall time and the host's submission time."""
 import os, sys, time
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 from sings_amd import rasterizer as rz
 from sings_amd.scene import synthetic_scene
