@@ -53,7 +53,7 @@ sys.path.insert(0, ROOT)
 from benchkit import distrib as _distrib                                     # noqa: E402
 from benchkit import roofline as _roofline                                   # noqa: E402
 from benchkit.distrib import (COMM_KEYS, FORCE_DIST, LIGHT_TIMED_S, MAX_REPEATS, MIN_TIMED_S, _grad_sha256, _log, _median,   # noqa: E402,F401
-                              _ranks_agree, allreduce_probe, densification_stats_check, dist_setup, dp_self_check,
+                              _ranks_agree, allreduce_probe, densification_stats_check, dist_setup, dp_self_check, one_view_step_by_algorithm,
                               exposed_by_algorithm, make_frame_parallel, spawn_ranks, timed_region, timed_repeats, usable_cores)
 from benchkit.roofline import (CLOCK_HZ, HBM_COPY_GBS, HBM_PEAK_GBS, KERNEL_VARIANTS, PMC_SOURCES, RASTER_SOURCES, SIMDS, VALU_CYCLES_GUIDE,   # noqa: E402,F401
                                VALU_CYCLES_MIX, XGMI_LINK_GBS, _committed_pmc, _meta_status, algorithmic_bytes,
@@ -148,6 +148,7 @@ def main():
         raise SystemExit("--gpus must be >= 1")
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return spawn_ranks(a, os.path.abspath(__file__))
+    t_wall = time.perf_counter()
     ctx = dist_setup(a)
     out = LEGS[a.workload](a, ctx)                               # rank 0: the line (a dict); other ranks: None
     if out is not None and wants_secondary(a, ctx):
@@ -156,7 +157,14 @@ def main():
         ctx[3].destroy_process_group()
     if out is not None:
         _log("done")
+        out["wall_s"] = time.perf_counter() - t_wall
         _emit(out)
+        # a multi-GPU run is short and decisive or it is an error: one rank per device over RCCL (dist_setup refuses anything else on a
+        # box with enough GPUs), the reduced bytes equal on all ranks and equal to the re-rendered sum, the whole run inside MULTI_GPU_WALL_S
+        if ctx[1] > 1 and not ctx[4].get("ranks_per_device", 1) > 1:
+            if ctx[4].get("rccl_world") != ctx[1] or out.get("ranks_agree") is False or out["wall_s"] > MULTI_GPU_WALL_S:
+                raise SystemExit(f"bench.py: the {ctx[1]}-GPU run is not decisive: rccl_world={ctx[4].get('rccl_world')}, "
+                                 f"ranks_agree={out.get('ranks_agree')}, wall {out['wall_s']:.0f} s (limit {MULTI_GPU_WALL_S} s)")
 
 
 def _release():
@@ -169,6 +177,9 @@ def _release():
     torch.cuda.empty_cache()
     _rz.set_overflow_check("sync")
     _rz.reset_overflow_state()
+
+
+MULTI_GPU_WALL_S = 120               # --gpus N > 1: the whole run (all ranks up, warm-up, timed regions, checks) must end inside this
 
 
 def wants_secondary(a, ctx):
@@ -341,6 +352,10 @@ def leg_raster(a, ctx):
     for _ in range(10):
         step_one_view()
     el_one = _median(timed_repeats(dist, dev, n_one, step_one_view, min_s=0.25))
+    one_by_algo = None
+    if fp is not None and world > 1:
+        _log("one view per step with each collective")
+        one_by_algo = one_view_step_by_algorithm(ctx, fp, eng.grad_flat, lambda: one_view(0, eng), max(20, n_one // 4), timed_repeats, _median)
     # SURVEY.md 8(d) "Timing": train-step ms = forward + L1(-SSIM)-to-random-target loss + backward (+ the all-reduce): the same
     # one-view step with the photometric loss of the reference (clamp, 0.8 L1 + 0.2 SSIM: loss.py:55-69) computed from the rendered
     # image and ITS gradient fed to the backward, instead of a fixed dL/dimage
@@ -450,6 +465,8 @@ def leg_raster(a, ctx):
         out["grad_sha256"] = grad_hash
     if dp_check is not None:
         out.update(dp_check)
+    if one_by_algo is not None:
+        out["one_view_per_step_by_algorithm"] = one_by_algo
     if world == 1 and not a.no_cpu_baseline:
         _log("CPU baseline (child process, bounded) + parity of the full-size views against the oracle")
         ins = (means3D, shs, opac, scales, rots)

@@ -145,9 +145,22 @@ def _flush_deferred():
 _ARENA = {}                            # parameter storage address -> [flat, offset, shape, weakref(parameter), weakref(last view handed out)]
 
 
+_ARENA_REG = {"params": None, "stale": False}       # the registered parameter objects (weak) / dropped by a topology change
+
+
+def invalidate_gradient_arena():
+    """The set of parameters changed (AvatarStep.set_topology): the registration describes parameters that no longer exist.  Nothing is
+    written into the old buffer any more, and ``arena_sync`` raises until ``set_gradient_arena`` has registered the new set."""
+    if _ARENA or _ARENA_REG["params"] is not None:
+        _ARENA.clear()
+        _ARENA_REG["stale"] = True
+
+
 def set_gradient_arena(params, flat):
     """Register (or, with ``params=None``, drop) the flat gradient buffer.  Returns the per-parameter views of ``flat``."""
     _ARENA.clear()
+    _ARENA_REG["stale"] = False
+    _ARENA_REG["params"] = None if params is None else [weakref.ref(p) for p in params]
     if params is None:
         return []
     views, o = [], 0
@@ -195,6 +208,12 @@ def _arena_out(param_like):
 def arena_sync(params, views, to_arena=True):
     """Gradients that did not land in their slot (produced by torch's own backward functions): copy them in (before the
     collective) / back out (after it) with one multi-tensor launch."""
+    reg = _ARENA_REG["params"]
+    if _ARENA_REG["stale"] or reg is None or len(reg) != len(params) or any(r() is not p for r, p in zip(reg, params)):
+        raise RuntimeError("gradient arena: the registration is stale (a densify / prune replaced parameters, or another parameter list "
+                           "is passed than the one registered): call set_gradient_arena(params, flat) for the CURRENT parameters first")
+    if any(tuple(v.shape) != tuple(p.shape) for p, v in zip(params, views)):
+        raise RuntimeError("gradient arena: the views do not match the parameters' shapes (views of an earlier registration)")
     pairs = [(p.grad, v) for p, v in zip(params, views) if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
     if pairs:
         if to_arena:

@@ -133,6 +133,50 @@ class AvatarStep(torch.nn.Module):
         self.l1_w, self.ssim_w, self.thickness_factor = l1_w, ssim_w, thickness_factor
         self.scaling_multiplier = scaling_multiplier
         self.l2_norm, self.gaussian_connect, self.gaussian_connect_w = l2_norm, gaussian_connect, gaussian_connect_w
+        # what was captured / sized for this set of Gaussians (sings_amd.train_loop): moves on with every densify / prune / SH-degree change
+        self.topology_version = 0
+        self.xyz_gradient_accum = self.denom = self.max_radii2D = None
+
+    # ---- densification statistics and topology (sings_hybrid.py:1013-1015, 930-932; gs_trainer.py:486-492)
+    def enable_densification_stats(self):
+        """(Re)allocate the statistics for the current set: from now on ``forward`` hands the rasterizer a ``means2D`` holder and
+        ``add_densification_stats(extras)`` after the backward accumulates |screen-space gradient|, the visibility count and the
+        largest radius per Gaussian."""
+        n, dev = int(self.xyz.shape[0]), self.xyz.device
+        self.xyz_gradient_accum = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        self.denom = torch.zeros((n, 1), dtype=torch.float32, device=dev)
+        self.max_radii2D = torch.zeros(n, dtype=torch.float32, device=dev)
+
+    def add_densification_stats(self, extras):
+        """``xyz_gradient_accum[vis] += |viewspace_points.grad[vis, :2]|``, ``denom[vis] += 1``, ``max_radii2D[vis] = max(., radii[vis])``
+        for every frame of the step.  Masked arithmetic instead of boolean indexing: the same sums without a host round trip, so the
+        call may sit inside a captured step."""
+        if self.xyz_gradient_accum is None:
+            return
+        g, radii = extras["viewspace_points"].grad, extras["radii"]
+        if g is None:
+            raise RuntimeError("add_densification_stats: call it after the backward pass of the step (viewspace_points.grad is empty)")
+        g, radii = g.reshape(-1, g.shape[-2], 3), radii.reshape(-1, radii.shape[-1])
+        vis = (radii > 0).to(torch.float32)                                       # [K, N]
+        self.xyz_gradient_accum.add_((torch.norm(g[..., :2], dim=-1) * vis).sum(0).unsqueeze(1))
+        self.denom.add_(vis.sum(0).unsqueeze(1))
+        torch.maximum(self.max_radii2D, radii.to(torch.float32).max(0).values, out=self.max_radii2D)
+
+    def set_topology(self, xyz_anchor, lbs_weights, scaling_multiplier=None):
+        """A new set of Gaussians (densify / prune): new anchor PARAMETER (the old object is dead: an optimiser, a gradient arena or a
+        captured graph that still holds it must be rebuilt -- ``topology_version`` says so), new skinning weights, statistics reset."""
+        if xyz_anchor.shape[0] != lbs_weights.shape[0] or xyz_anchor.dim() != 2 or xyz_anchor.shape[1] != 3:
+            raise ValueError("set_topology: xyz_anchor [N,3] and lbs_weights [N,J] must describe the same N Gaussians")
+        self.xyz = torch.nn.Parameter(xyz_anchor.detach().clone().contiguous())
+        self.lbs_weights = lbs_weights.detach().clone().contiguous()
+        if scaling_multiplier is not None:
+            self.scaling_multiplier = scaling_multiplier
+        elif torch.is_tensor(self.scaling_multiplier) and self.scaling_multiplier.dim() > 0 and self.scaling_multiplier.shape[0] != xyz_anchor.shape[0]:
+            raise ValueError("set_topology: the per-Gaussian scaling_multiplier must be passed for the new set")
+        self.topology_version += 1
+        _dec.invalidate_gradient_arena()
+        if self.xyz_gradient_accum is not None:
+            self.enable_densification_stats()
 
     def forward(self, A_cano2pose, raster_settings, gt_rgb, mask, bg_color, smpl_scale=None, transl=None):
         """-> (loss, loss_dict, extras).  ``A_cano2pose`` [J,4,4]: one frame per step (the reference's step); [K,J,4,4]: a chunk
@@ -200,16 +244,21 @@ class AvatarStep(torch.nn.Module):
                 with torch.cuda.stream(side):
                     regularisers()
         frames = A_cano2pose.dim() == 4                          # [K,J,4,4]: a CHUNK of K frames of this step's Gaussians (round 4)
+        # the screen-space gradient the densifier reads (gs_renderer_single.py:50-56): a holder per step, only when statistics are kept
+        m2d = None
+        if self.xyz_gradient_accum is not None and torch.is_grad_enabled():
+            shape = (int(A_cano2pose.shape[0]), int(self.xyz.shape[0]), 3) if frames else (int(self.xyz.shape[0]), 3)
+            m2d = torch.zeros(shape, dtype=torch.float32, device=self.xyz.device, requires_grad=True)
         if frames:
             # one decode, K frames rendered and differentiated in one call per direction: the attribute decode -- 3/4 of a
             # one-frame step -- is paid once per step, not once per frame (gt_rgb / mask: [K,...] or one for all frames)
             color, radii = rasterize_skinned_frames(use["xyz_canon"], rot, use["scales"], use["opacity"], use["shs"],
                                                     self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                    transl=transl)
+                                                    transl=transl, means2D=m2d)
         else:
             color, radii = rasterize_skinned_gaussians(use["xyz_canon"], rot, use["scales"], use["opacity"], use["shs"],
                                                        self.lbs_weights, A_cano2pose, raster_settings, smpl_scale=smpl_scale,
-                                                       transl=transl)
+                                                       transl=transl, means2D=m2d)
         if defer:
             rendered = torch.cuda.Event()
             rendered.record(cur)
@@ -259,7 +308,7 @@ class AvatarStep(torch.nn.Module):
             loss_dict.update(reg)
             extras["loss_roots"] = (photo_root, reg_root)
             extras["staged"] = (attrs, use, inject, l2_grads)
-            return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
+            return None, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, "viewspace_points": m2d, **extras}
         if side is not None:
             cur.wait_stream(side)                                # join before the loss terms meet
             for v in reg.values():
@@ -269,7 +318,7 @@ class AvatarStep(torch.nn.Module):
         loss_dict.update(reg)
         loss = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()      # two launches, not one addition per term
         loss_dict["loss"] = loss
-        return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, **extras}
+        return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, "viewspace_points": m2d, **extras}
 
     def join_regularisers(self, loss_dict=None):
         """Make the current stream wait for the regularisers' side stream (a ``defer_regulariser_join`` forward leaves it
@@ -300,8 +349,12 @@ class AvatarStep(torch.nn.Module):
         cur, side = torch.cuda.current_stream(dev), self._side
         names = [k for k, v in use.items() if torch.is_tensor(v) and v.requires_grad]
         leaves = [use[k] for k in names]
+        m2d = extras.get("viewspace_points")
         # 1. the photometric gradients of the decoded attributes: loss, composite, LBS -- on this stream, issued first
-        g = dict(zip(names, torch.autograd.grad([photo_root], leaves, [one], allow_unused=True)))
+        got = torch.autograd.grad([photo_root], leaves + ([m2d] if m2d is not None else []), [one], allow_unused=True)
+        if m2d is not None:
+            m2d.grad = got[-1]                                   # (what add_densification_stats reads: the densifier's statistic)
+        g = dict(zip(names, got))
         # 2. L2Norm's gradients (computed with its value, in front of the k-NN query on the side stream): ONE addition for the
         #    attributes that have both.  The k-NN regulariser's gradient (scales) is already in `inject`: it reaches the decoders'
         #    backward through the _Inject node, i.e. AFTER the appearance decoder's backward has been issued

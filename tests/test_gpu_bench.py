@@ -138,6 +138,11 @@ def test_gpus_2_starts_two_ranks_and_the_collective_layer_sees_them():
     assert j["allreduce_algorithm"] == min(by, key=by.get) and "measured" in j["allreduce_algorithm_chosen_by"]
     assert set(j["allreduce_exposed_ms_by_algorithm"]) == {"all_reduce", "rs_ag"}
     #  (c) one device per rank, or the line says that the box is oversubscribed
+    #  (d) round 6: the reference's one view per step with EACH collective next to the batched step, and the whole run short
+    #      (a real multi-GPU run that takes longer than bench.MULTI_GPU_WALL_S exits non-zero)
+    ov = j["one_view_per_step_by_algorithm"]
+    assert set(ov) == {"all_reduce", "rs_ag"} and all(v["ms_per_step"] > 0 and v["views_per_s"] > 0 for v in ov.values())
+    assert 0 < j["wall_s"] < 120
     assert len(j["rank_devices"]) == 2
     assert (len(set(j["rank_devices"])) == 2) == (torch.cuda.device_count() >= 2)
 
