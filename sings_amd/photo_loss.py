@@ -37,13 +37,18 @@ class _PhotoLoss(torch.autograd.Function):
         losses = torch.empty(4, dtype=torch.float32, device=dev)
         pred = torch.empty_like(raw) if want_images else None
         gt = torch.empty_like(raw) if want_images else None
+        # Round 6: forward and gradient are ONE kernel (sg_loss.hip), so a forward that will be differentiated computes the gradient
+        # for unit upstream weights right away; the usual backward -- both terms under one sum, i.e. the SAME upstream tensor for
+        # both -- is then one multiplication by that scalar instead of a second march over the image.
+        unit = torch.empty_like(raw) if ctx.needs_input_grad[0] else None
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.sg_photo_loss(W, H, float(l1_w), float(ssim_w), _ptr(raw), _ptr(gt_rgb), _ptr(mask), _ptr(bg),
-                                         _ptr(ws), _ptr(pred), _ptr(gt), _ptr(losses), None, None, stream),
+                                         _ptr(ws), _ptr(pred), _ptr(gt), _ptr(losses), None, _ptr(unit), stream),
                        "photo loss")
-        # the window statistics stay in `ws`; backward runs the gradient pass over them with the two upstream weights as
-        # DEVICE scalars -- nothing is read back to find out whether they are equal (a host synchronisation per step)
+        # the mask partial sums stay in `ws`; a backward with DIFFERENT upstream weights for the two terms runs the gradient kernel
+        # again with them as device scalars -- nothing is read back to compare them (a host synchronisation per step)
+        ctx.unit_grad = unit
         ctx.save_for_backward(raw, gt_rgb, mask, bg, ws)
         ctx.args = (float(l1_w), float(ssim_w), W, H)
         ctx.set_materialize_grads(False)       # the two report-only outputs get None, not a zero tensor each (two fill launches)
@@ -59,6 +64,9 @@ class _PhotoLoss(torch.autograd.Function):
         l1_w, ssim_w, W, H = ctx.args
         lib = _lib.load()
         dev = raw.device
+        unit, ctx.unit_grad = ctx.unit_grad, None
+        if unit is not None and g_l1 is not None and g_l1 is g_ssim:
+            return unit * g_l1.reshape(()).float(), None, None, None, None, None, None
         if g_l1 is None or g_ssim is None:
             zero = torch.zeros((), dtype=torch.float32, device=dev)
             g_l1 = zero if g_l1 is None else g_l1
@@ -110,11 +118,13 @@ class _PhotoLossFrames(torch.autograd.Function):
         dev = raw.device
         ws = torch.empty(K * int(lib.sg_photo_loss_ws_bytes(W, H)), dtype=torch.uint8, device=dev)
         losses = torch.empty((K, 4), dtype=torch.float32, device=dev)
+        unit = torch.empty_like(raw) if ctx.needs_input_grad[0] else None       # (gradient for unit upstream weights: see _PhotoLoss)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.sg_photo_loss_frames(K, W, H, float(l1_w), float(ssim_w), _ptr(raw), _ptr(gt_rgb), gt_stride, _ptr(mask),
-                                                mask_stride, _ptr(bg), _ptr(ws), None, None, _ptr(losses), None, None, stream),
+                                                mask_stride, _ptr(bg), _ptr(ws), None, None, _ptr(losses), None, _ptr(unit), stream),
                        "photo loss (frames)")
+        ctx.unit_grad = unit
         ctx.save_for_backward(raw, gt_rgb, mask, bg, ws)
         ctx.args = (float(l1_w), float(ssim_w), K, W, H, gt_stride, mask_stride)
         ctx.set_materialize_grads(False)
@@ -126,6 +136,9 @@ class _PhotoLossFrames(torch.autograd.Function):
         l1_w, ssim_w, K, W, H, gt_stride, mask_stride = ctx.args
         lib = _lib.load()
         dev = raw.device
+        unit, ctx.unit_grad = ctx.unit_grad, None
+        if unit is not None and g_l1 is not None and g_l1 is g_ssim:
+            return unit * g_l1.reshape(K, 1, 1, 1).float(), None, None, None, None, None
         zero = torch.zeros(K, dtype=torch.float32, device=dev)
         up = torch.stack([zero if g_l1 is None else g_l1.reshape(K).float(), zero if g_ssim is None else g_ssim.reshape(K).float()], 1)
         up = up.contiguous()                                                   # [K,2]: a pair of weights per frame, device memory

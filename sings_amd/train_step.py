@@ -46,6 +46,22 @@ class _AddScalars(torch.autograd.Function):
         return g, g
 
 
+class _SumFrames(torch.autograd.Function):
+    """(l1[K].sum(), ssim[K].sum()) in one node whose backward hands BOTH per-frame terms the SAME upstream tensor when the two sums got
+    the same one (they do under ``_AddScalars``): the photometric loss then returns the gradient it computed in the forward, times
+    that tensor, instead of marching over the K images again (sings_amd.photo_loss._PhotoLossFrames.backward)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.k = int(a.shape[0])
+        return a.sum(), b.sum()
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        ea = ga.expand(ctx.k)
+        return ea, (ea if gb is ga else gb.expand(ctx.k))
+
+
 class _Inject(torch.autograd.Function):
     """Identity in the forward; the backward ADDS a gradient that arrives late from another stream (``slot[key]``: a tensor or
     None, ``slot["ready"]``: the event behind the kernel that produces it).  Placed on the geometry decoder's outputs before the appearance decoder is
@@ -264,7 +280,10 @@ class AvatarStep(torch.nn.Module):
             rendered.record(cur)
         if frames:
             per_frame, extras = photometric_loss_frames(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
-            loss_dict = {k: v.sum() for k, v in per_frame.items()}          # the step's photometric terms: summed over its frames
+            if len(per_frame) == 2:                                         # the step's photometric terms: summed over its frames
+                loss_dict = dict(zip(per_frame.keys(), _SumFrames.apply(*per_frame.values())))
+            else:
+                loss_dict = {k: v.sum() for k, v in per_frame.items()}
             extras = dict(extras, per_frame=per_frame)
         else:
             loss_dict, extras = photometric_loss(color, gt_rgb, mask, bg_color, self.l1_w, self.ssim_w)
@@ -315,8 +334,15 @@ class AvatarStep(torch.nn.Module):
                 v.record_stream(cur)
         elif has_reg:
             regularisers()
+        # l1 + ssim first, under ONE node that hands both the same upstream tensor (the loss kernel's backward is then a multiplication:
+        # sings_amd.photo_loss), the regularisers added behind
+        vals = [v.reshape(()) for v in loss_dict.values()]
+        loss = _AddScalars.apply(vals[0], vals[1]) if len(vals) >= 2 else vals[0]
+        for v in vals[2:]:
+            loss = loss + v
+        for v in reg.values():
+            loss = loss + v.reshape(())
         loss_dict.update(reg)
-        loss = torch.stack([v.reshape(()) for v in loss_dict.values()]).sum()      # two launches, not one addition per term
         loss_dict["loss"] = loss
         return loss, loss_dict, {"render_raw": color, "radii": radii, "attrs": attrs, "viewspace_points": m2d, **extras}
 
