@@ -21,6 +21,14 @@ from . import _lib
 from .rasterizer import _ptr
 
 
+def _same_upstream(a, b):
+    """Both loss terms received the SAME upstream gradient -- the same memory, not merely equal values (nothing is read back): the two
+    outputs sit under one sum (autograd hands each consumer its own tensor OBJECT for the one buffer ``_AddScalars`` / ``_SumFrames``
+    returned twice)."""
+    return (a is not None and b is not None and a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
+            and a.dtype == b.dtype)
+
+
 class _PhotoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, gt_rgb, mask, bg, l1_w, ssim_w, want_images):
@@ -65,7 +73,7 @@ class _PhotoLoss(torch.autograd.Function):
         lib = _lib.load()
         dev = raw.device
         unit, ctx.unit_grad = ctx.unit_grad, None
-        if unit is not None and g_l1 is not None and g_l1 is g_ssim:
+        if unit is not None and _same_upstream(g_l1, g_ssim):
             return unit * g_l1.reshape(()).float(), None, None, None, None, None, None
         if g_l1 is None or g_ssim is None:
             zero = torch.zeros((), dtype=torch.float32, device=dev)
@@ -137,7 +145,7 @@ class _PhotoLossFrames(torch.autograd.Function):
         lib = _lib.load()
         dev = raw.device
         unit, ctx.unit_grad = ctx.unit_grad, None
-        if unit is not None and g_l1 is not None and g_l1 is g_ssim:
+        if unit is not None and _same_upstream(g_l1, g_ssim):
             return unit * g_l1.reshape(K, 1, 1, 1).float(), None, None, None, None, None
         zero = torch.zeros(K, dtype=torch.float32, device=dev)
         up = torch.stack([zero if g_l1 is None else g_l1.reshape(K).float(), zero if g_ssim is None else g_ssim.reshape(K).float()], 1)
