@@ -508,6 +508,21 @@ __device__ __forceinline__ int sg_red_idx(int lane)
 // cfg3 view, +1.5 % views/s on one box (A / B / A / B).  Requesting the first chunk's ids and slot words in front of the prologue's
 // barrier on top of that: measured, no gain (146.7 us).
 #define SG_BCH 128
+#ifdef SG_RENDER_STAMP
+// diagnostic build only (tools/render_stamps.py): per-workgroup start / end stamps of the shader clock and of the 100 MHz real-time clock
+__device__ unsigned long long sg_render_stamps[65536 * 4];
+extern "C" int sg_debug_render_stamps(unsigned long long *host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(sg_render_stamps), (size_t)n * 8); }
+struct SgStampScope {
+    unsigned long long c0, r0; unsigned slot;
+    __device__ SgStampScope() : c0(__builtin_amdgcn_s_memtime()), r0(__builtin_amdgcn_s_memrealtime()), slot(blockIdx.y * gridDim.x + blockIdx.x) { }
+    __device__ ~SgStampScope() {
+        if (threadIdx.x == 0 && slot < 65536u) { unsigned long long *q = sg_render_stamps + (size_t)slot * 4; q[0] = c0; q[1] = r0; q[2] = __builtin_amdgcn_s_memtime(); q[3] = __builtin_amdgcn_s_memrealtime(); }
+    }
+};
+#define SG_STAMP_SCOPE SgStampScope sg_stamp_scope_;
+#else
+#define SG_STAMP_SCOPE
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const uint2 *__restrict__ ranges,
                      const uint32_t *__restrict__ point_list, const float4 *__restrict__ recA,
@@ -524,6 +539,7 @@ sg_render_bwd_kernel(SgBatch bt, int W, int H, int gx, int T, int nblocks, const
     __shared__ uint16_t sList[4][SG_BB];
     __shared__ float sG[4][SG_BB][9];          // per-quadrant reduced partials of the batch; [8] = SG_UNSET: quadrant w wrote nothing
     __shared__ uint32_t smax[4];
+    SG_STAMP_SCOPE
     SG_BWD_FRAME_OFFSETS;
     // one workgroup per work item (tile, depth segment); the item list is in tile order, so the XCD-aware map
     // over the ACTUAL item count keeps neighbouring tiles on one L2.  The grid is an upper bound.
