@@ -11,7 +11,7 @@
 # (the default bench overlaps the views of a step on three streams: kernels of different views share the GPU and every
 # one of them takes longer while the step gets shorter).
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT $OUT/avatar $OUT/k8 $OUT/avatar_k8
@@ -83,6 +83,11 @@ for ctr in FETCH_SIZE WRITE_SIZE SQ; do
   $TO rocprofv3 --pmc $set --output-format csv -d $OUT/cfg2/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG2 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg2/pmc_$ctr.log 2>&1
   $TO rocprofv3 --pmc $set --output-format csv -d $OUT/cfg5/pmc_$ctr -o c3 -- python3 $ROOT/bench.py $CFG5 --steps 5 --warmup 2 $K1 --no-cpu-baseline > $OUT/cfg5/pmc_$ctr.log 2>&1
 done
+# the photometric-loss kernels on their own (1080p noise image, and the avatar frame size with 8 frames per launch): kernel stats + counters
+( cd $ROOT && bash tools/prof_loss.sh ${TAG}_loss 1920x1080 > $OUT/loss_prof.log 2>&1; bash tools/pmc_loss.sh ${TAG}_loss 1920x1080 > $OUT/loss_pmc.log 2>&1;
+  cp gpurun_out/prof_${TAG}_loss/kernel_stats.csv $OUT/loss_kernel_stats.csv; cp gpurun_out/pmc_${TAG}_loss/summary.csv $OUT/loss_pmc_summary.csv;
+  python3 tools/loss_time.py 1920x1080 > $OUT/loss_time.log 2>&1; python3 tools/loss_time.py 512x896 K=8 >> $OUT/loss_time.log 2>&1; python3 tools/loss_time.py 512x896 K=8 avatar >> $OUT/loss_time.log 2>&1 )
+cd /tmp
 # keep the merge under the 64 MiB limit: drop per-dispatch traces, keep stats + counter files (the three columns of the library's
 # own kernels, averaged over the dispatches: what tools/pmc_summary.py reads)
 python3 - $OUT <<'PY'
