@@ -57,7 +57,7 @@ from benchkit.distrib import (COMM_KEYS, FORCE_DIST, LIGHT_TIMED_S, MAX_REPEATS,
                               exposed_by_algorithm, make_frame_parallel, spawn_ranks, timed_region, timed_repeats, usable_cores)
 from benchkit.roofline import (CLOCK_HZ, HBM_COPY_GBS, HBM_PEAK_GBS, KERNEL_VARIANTS, PMC_SOURCES, RASTER_SOURCES, SIMDS, VALU_CYCLES_GUIDE,   # noqa: E402,F401
                                VALU_CYCLES_MIX, XGMI_LINK_GBS, _committed_pmc, _meta_status, algorithmic_bytes,
-                               algorithmic_bytes_skinned, build_roofline, git_blob_sha1, measure_copy_peak, pmc_view_traffic,
+                               algorithmic_bytes_skinned, build_roofline, git_blob_sha1, measure_copy_peak, pmc_view_traffic, train_step_roofline,
                                scaling_model, source_hashes, sources_of)
 
 
@@ -885,6 +885,9 @@ def leg_train(a, ctx):
                                 "(config.py:27, gs_trainer.py:209-254); at K > 1 ONE optimiser step consumes a chunk of K frames -- "
                                 "K times fewer parameter updates per frame, a different optimisation trajectory, quoted per frame "
                                 "for throughput only")
+        copy_gbs = a.copy_gbs if getattr(a, "copy_gbs", None) else measure_copy_peak(dev)
+        out["hbm_copy_GBs_measured"] = copy_gbs
+        out["roofline"] = train_step_roofline(N, Kt, (tri, geo, app), W, H, int(R_last), J, el / a.steps * 1e3, copy_gbs)
         if world == 1 and not a.no_cpu_baseline:
             _log("train: parity of one step's decode / image / loss against the oracle chain")
             out["parity"] = train_parity(s, step_mod, (tri, geo, app), rs, A_all[0], gt_rgb, mask, bg_t, smpl_scale, transl)
@@ -1284,8 +1287,11 @@ def _compact(j):
                                           "regularisers", "forward_only", "hip_graph") if k in cfg}
     r = j.get("roofline")
     if r:
-        keep["roofline"] = {k: r.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "frac_of_spec", "algorithmic_bytes_per_view",
-                                                  "traffic", "dominant_kernel", "dominant_kernel_ms", "dominant_kernel_frac")}
+        keep["roofline"] = {k: r.get(k) for k in ("bound", "scope", "achieved", "peak", "unit", "frac", "frac_of_spec", "algorithmic_bytes_per_view",
+                                                  "traffic", "dominant_kernel", "dominant_kernel_ms", "dominant_kernel_frac") if k in r}
+        for sub in ("mfma", "hbm"):                                 # (the train step's two roofs)
+            if isinstance(r.get(sub), dict):
+                keep["roofline"][sub] = {k: v for k, v in r[sub].items() if k != "note"}
     if "raster_oracle_1core" in (j.get("cpu_baseline") or {}):
         keep["cpu_oracle_views_per_s_1core"] = j["cpu_baseline"]["raster_oracle_1core"]["value"]
     elif (j.get("cpu_baseline") or {}).get("unit") == "views/s":

@@ -44,6 +44,50 @@ def algorithmic_bytes_skinned(N, H, W, R, deg, J, has_rot=False):
     return per, total + 2 * extra_in + extra_out
 
 
+MFMA_F32_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32-input MFMA (v_mfma_f32_32x32x2_f32), dense = the fp32 vector peak
+
+
+def train_step_roofline(N, K, modules, W, H, R, J, ms_per_step, copy_gbs):
+    """The complete training step (decode -> LBS-fused raster -> loss -> backward) against its two roofs: the decoders' linear layers on the
+    fp32 matrix cores and the bytes every stage has to move once.  `modules` = (tri-plane, geometry decoder, appearance decoder).
+      FLOPs  every nn.Linear of the two decoders: 2 N Cin Cout forward, the same again for the input gradient and for the weight gradient
+             (the first layers' input gradient included: the tri-plane features carry gradient to the planes)
+      bytes  per linear layer N 4 (3 Cin + 2 Cout + 2 Cout [activation]): x read forward and again for the weight gradient, h written,
+             dh read, dx written, the activation's saved value written and read;  tri-plane: the planes read forward, their gradient
+             written (2 x plane bytes; the 12 x 4 texel gathers per point hit L2 / MALL), xyz in, features out, their gradient in;
+             raster + LBS: algorithmic_bytes_skinned per frame; loss: 40 B per pixel and frame;  k-NN and L2 regularisers: N (12 + 4 + 4)
+             read, N 4 written (their neighbour search is compute, not traffic).
+    -> the roofline block: bound = whichever roof takes longer at its peak; frac = that time / the measured step."""
+    import torch
+    tri, geo, app = modules
+    lin = [m for mod in (geo, app) for m in mod.modules() if isinstance(m, torch.nn.Linear)]
+    acts = {id(m) for mod in (geo, app) for seq in mod.modules() if isinstance(seq, torch.nn.Sequential)
+            for a_, b_ in zip(list(seq), list(seq)[1:]) if isinstance(a_, torch.nn.Linear) and not isinstance(b_, torch.nn.Linear) for m in (a_,)}
+    flops = sum(3 * 2 * N * m.in_features * m.out_features for m in lin)
+    b_lin = sum(N * 4 * (3 * m.in_features + 2 * m.out_features + (2 * m.out_features if id(m) in acts else 0)) for m in lin)
+    plane_bytes = sum(p.numel() * 4 for p in tri.parameters())
+    feat = lin[0].in_features
+    b_tri = 2 * plane_bytes + N * (12 + 2 * 4 * feat + 12)
+    _, b_raster = algorithmic_bytes_skinned(N, H, W, R, 0, J, has_rot=False)
+    b_loss = 40 * W * H
+    b_reg = N * (12 + 4 + 4 + 4)
+    total = b_lin + b_tri + K * (b_raster + b_loss) + b_reg
+    t_mfma = flops / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e3
+    t_hbm = total / (copy_gbs * 1e9) * 1e3
+    bound = "mfma" if t_mfma >= t_hbm else "hbm"
+    return {"bound": bound, "scope": "whole_step", "frac": max(t_mfma, t_hbm) / ms_per_step,
+            "achieved": flops / (ms_per_step * 1e-3) / 1e12 if bound == "mfma" else total / (ms_per_step * 1e-3) / 1e9,
+            "peak": MFMA_F32_PEAK_TFLOPS if bound == "mfma" else copy_gbs, "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+            "mfma": {"flops_per_step": flops, "ms_at_peak": t_mfma, "frac": t_mfma / ms_per_step, "peak_TFLOPs": MFMA_F32_PEAK_TFLOPS,
+                     "achieved_TFLOPs": flops / (ms_per_step * 1e-3) / 1e12, "note": "fp32-input MFMA, dense; the decoders' nn.Linear layers only"},
+            "hbm": {"algorithmic_bytes_per_step": total, "ms_at_copy_rate": t_hbm, "frac": t_hbm / ms_per_step, "peak_GBs": copy_gbs,
+                    "achieved_GBs": total / (ms_per_step * 1e-3) / 1e9,
+                    "split": {"linear_layers": b_lin, "triplane": b_tri, "raster_lbs": K * b_raster, "loss": K * b_loss, "regularisers": b_reg}},
+            "traffic": None,
+            "note": "both roofs are lower bounds that overlap at best: the step cannot be shorter than the larger one; roofs in sequence "
+                    "(ms_at_peak + ms_at_copy_rate) are the bound of a step that overlaps nothing"}
+
+
 def measure_copy_peak(dev, gib=1.0):
     """float4-copy bandwidth of THIS box in GB/s: sg_copy_probe (a plain 16-byte-per-lane copy kernel) over `gib` GiB, HIP events
     on the launch stream, best of 3 after one warm-up; bytes = read + written.  SURVEY.md 8(d) / BASELINE.md section 2: the

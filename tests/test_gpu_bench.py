@@ -190,6 +190,10 @@ def test_default_line_carries_every_baseline_configuration():
         e = sec[k]
         assert e["config"]["frames_per_step"] == K and e["value"] > 0 and e["timed_region_s"] >= 0.3 and "trajectory" in e["schedule_note"]
     assert sec["train_step_K1"]["parity"]["ok"], sec["train_step_K1"]["parity"]
+    for k in ("train_step_K1", "train_step_K16"):                   # round 6: the step has a stated bound (decoder FLOPs on the fp32 matrix cores, bytes)
+        r = sec[k]["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] < 1 and r["mfma"]["flops_per_step"] > 5e10 and r["hbm"]["algorithmic_bytes_per_step"] > 3e9
+        assert abs(r["frac"] - max(r["mfma"]["frac"], r["hbm"]["frac"])) < 1e-9
     assert sec["dropin_autograd_ms_per_view"] == sec["dropin_autograd"]["ms_per_view"] > 0
     assert sec["wall_s"] < 240
 
