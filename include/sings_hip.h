@@ -376,7 +376,9 @@ int sg_photo_loss(int width, int height, float l1_w, float ssim_w, const float *
                   const float *upstream, float *dL_draw, void *stream);
 /* The gradient alone, for an autograd backward whose upstream weights are only known later (loss.backward() of
  * sum(loss_dict.values()), gs_trainer.py:240-262): `ws` is the workspace a forward-only sg_photo_loss call on the SAME
- * inputs left behind (window statistics + loss scalars; not modified), `upstream` [2] device memory (NULL = (1, 1)).
+ * inputs left behind (the mask's partial sums + loss scalars; not modified), `upstream` [2] device memory (NULL = (1, 1)).  Since round 6 a call
+ * WITH `dL_draw` costs one march over the image (forward and gradient are one kernel): a host that will differentiate should ask for
+ * the unit-upstream gradient in the forward call and scale it (sings_amd/photo_loss.py does).
  * Forward + this call cost what the fused call costs, and nothing has to be read back to compare the two weights. */
 int sg_photo_loss_backward(int width, int height, float l1_w, float ssim_w, const float *raw, const float *gt_rgb,
                            const float *mask, const float *bg, const void *ws, const float *upstream, float *dL_draw,

@@ -8,9 +8,11 @@ renderer's final clamp (gs_renderer_single.py:96):
     loss_dict['ssim'] = ssim_w * (1 - ssim(pred, gt)) * mask.sum() / (H * W)
 
 ``photometric_loss`` takes the UNCLAMPED rasterizer output (the clamp is fused) and returns the reference's
-``loss_dict`` / ``extras_dict`` entries; both loss tensors carry autograd back to ``raw``.  The forward leaves its
-window statistics in a workspace and backward runs the gradient pass over them (sg_photo_loss_backward), with the
-upstream weights as device scalars: no host synchronisation anywhere.  LPIPS (a VGG network) is not provided.
+``loss_dict`` / ``extras_dict`` entries; both loss tensors carry autograd back to ``raw``.  Forward and gradient are ONE kernel
+(csrc/sg_loss.hip): a forward whose input requires grad computes the gradient for unit upstream weights in the same march and the
+backward multiplies it by the upstream scalar when both terms share it (the usual ``l1 + ssim`` under one sum); with different
+weights for the two terms the gradient kernel runs again with them as device scalars (sg_photo_loss_backward).  No host
+synchronisation anywhere.  LPIPS (a VGG network) is not provided.
 No CPU fallback: the HIP library must be present.
 """
 import ctypes as C
