@@ -259,7 +259,7 @@ def pmc_view_traffic(cfg, pdir=None, root=ROOT, frames=1):
                 k = int(meta["config"].get("frames_per_launch", 1))
                 # (the raster line's one-view TRAIN step also runs the photometric-loss kernels: they are not part of a rendered
                 #  view -- neither of `value` nor of its algorithmic bytes -- and stay out of its traffic)
-                skip = ("sg_ssim", "sg_loss") if cfg.get("workload") == "raster" else ()
+                skip = ("sg_ssim", "sg_loss", "sg_photo", "sg_mask_sum") if cfg.get("workload") == "raster" else ()
                 tot = sum(v for kk, v in tj.items() if not kk.startswith("_") and isinstance(v, (int, float)) and not kk.startswith(skip))
                 if k == frames:
                     return tot, f"profiles/{fn}", k
