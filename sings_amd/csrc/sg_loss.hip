@@ -361,21 +361,31 @@ sg_photo_fwd_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__
 // rows: a lone workgroup needs 1 200 cycles for a one-row step of ~100 vector instructions per wave (LDS round trips, the barrier, the
 // loop) and 82 such steps in sequence bound the kernel from below; with two independent rows per step those latencies overlap.
 #define SG_SIN_PITCH (SG_LN + 16)
-struct SgHSt { float pin[2][6]; };                           // the two rows of the NEXT step, in flight: raw, target, mask at the two columns of a lane
+// REPEATED ROWS.  Behind an avatar most of a frame is background on both sides (render = target = bg, bit for bit).  A row whose 74 staged
+// (x, y) pairs are all equal, and equal to the row above, has the window sums of the row above: wave H hands those on and skips the LDS
+// round trip and its 77 instructions per row.  The reused sums ARE what the skipped instructions would have produced (same operands, same
+// order), so every pixel keeps the bits of the long way (tests: test_flat_tiles_take_the_short_path_with_the_same_bits).  (Carrying the
+// flag on through waves V and G -- eleven repeated rows repeat the SSIM row -- was built too: it costs the kernel its 80 registers and a
+// fast step is then as long as its row's memory round trip: LAB.md 6.1.)
+struct SgHSt {
+    float pin[2][6];              // the two rows of the NEXT step, in flight: raw, target, mask at the two columns of a lane
+    uint32_t lasth[5];            // (uniform: SGPRs) window sums of the newest row, meaningful when that row held ONE (x, y) pair ...
+    uint32_t lx, ly; bool lastflat;   // (uniform) ... these bits
+};
 struct SgVSt { float hw[5][11]; float acc_ssim; };
 struct SgGSt { float dw[3][11]; float pc[2][3]; float acc_l1; };    // pc: the two centre rows of the next step, in flight
 
-__device__ __forceinline__ void sg_h_stage(const SgLossCtx &c, const float (&pin)[6], int yin, float bgc, sg_f2 *row)
+// clamp / composite of one prefetched row; returns (uniform) whether all 74 pairs of the row hold the bits (fx, fy)
+__device__ __forceinline__ bool sg_h_stage(const SgLossCtx &c, const float (&pin)[6], int yin, float bgc, sg_f2 &own, sg_f2 &halo, uint32_t &fx, uint32_t &fy)
 {
     const bool rowok = (unsigned)yin < (unsigned)c.H;
     const bool k0 = rowok && c.in0, k1 = rowok && c.in1;
     const float m0 = pin[2], m1 = pin[5];
     const float xv0 = k0 ? sg_clamp01(pin[0]) : 0.0f, yv0 = k0 ? pin[1] * m0 + bgc * (1.0f - m0) : 0.0f;
-    row[c.lane] = sg_f2{ xv0, yv0 };
-    if (c.lane < 10) {
-        const float xv1 = k1 ? sg_clamp01(pin[3]) : 0.0f, yv1 = k1 ? pin[4] * m1 + bgc * (1.0f - m1) : 0.0f;
-        row[SG_LN + c.lane] = sg_f2{ xv1, yv1 };
-    }
+    const float xv1 = k1 ? sg_clamp01(pin[3]) : 0.0f, yv1 = k1 ? pin[4] * m1 + bgc * (1.0f - m1) : 0.0f;    // (lanes >= 10: their own column again)
+    own = sg_f2{ xv0, yv0 }; halo = sg_f2{ xv1, yv1 };
+    fx = __builtin_amdgcn_readfirstlane(__float_as_uint(xv0)); fy = __builtin_amdgcn_readfirstlane(__float_as_uint(yv0));
+    return __all(__float_as_uint(xv0) == fx && __float_as_uint(yv0) == fy && __float_as_uint(xv1) == fx && __float_as_uint(yv1) == fy);
 }
 
 // step i of wave H: input rows R0 - 10 + 2i and the next one
@@ -384,10 +394,26 @@ __device__ __forceinline__ void sg_h_step(const SgLossArgs &a, const SgW &w, con
     const int yin = c.R0 - 10 + 2 * i;
     const int buf = i & 1;
     sg_f2 *row0 = sIn + (buf * 2) * SG_SIN_PITCH, *row1 = row0 + SG_SIN_PITCH;
-    sg_h_stage(c, s.pin[0], yin, c.bgc, row0);
-    sg_h_stage(c, s.pin[1], yin + 1, c.bgc, row1);
+    sg_f2 own0, halo0, own1, halo1;
+    uint32_t fx0, fy0, fx1, fy1;
+    const bool flat0 = sg_h_stage(c, s.pin[0], yin, c.bgc, own0, halo0, fx0, fy0);
+    const bool flat1 = sg_h_stage(c, s.pin[1], yin + 1, c.bgc, own1, halo1, fx1, fy1);
     sg_loss_prefetch_row(c, s.pin[0], yin + 2);              // (a whole step ahead: ~2 us under load)
     sg_loss_prefetch_row(c, s.pin[1], yin + 3);
+    // a row repeats the one above: one pair in both, the same bits.  Both rows of the step repeat: nothing to do but hand the sums on
+    const bool rep0 = flat0 && s.lastflat && fx0 == s.lx && fy0 == s.ly, rep1 = flat1 && flat0 && fx1 == fx0 && fy1 == fy0;
+    s.lastflat = flat1; s.lx = fx1; s.ly = fy1;
+    if (rep0 && rep1) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            sH4[(buf * 2 + r) * SG_LN + c.lane] = sg_f4{ __uint_as_float(s.lasth[0]), __uint_as_float(s.lasth[1]), __uint_as_float(s.lasth[2]),
+                                                         __uint_as_float(s.lasth[3]) };
+            sH1[(buf * 2 + r) * SG_LN + c.lane] = __uint_as_float(s.lasth[4]);
+        }
+        return;
+    }
+    row0[c.lane] = own0; row1[c.lane] = own1;
+    if (c.lane < 10) { row0[SG_LN + c.lane] = halo0; row1[SG_LN + c.lane] = halo1; }
     sg_wave_lds_sync();
     // (x, y) pairs only: the three products are made per tap -- two more vector instructions per tap than reading them, but with five
     // values per entry the LDS was the busiest unit of the CU
@@ -415,6 +441,8 @@ __device__ __forceinline__ void sg_h_step(const SgLossArgs &a, const SgW &w, con
     for (int r = 0; r < 2; r++) {
         sH4[(buf * 2 + r) * SG_LN + c.lane] = sg_f4{ h[r][0], h[r][1], h[r][2], h[r][3] }; sH1[(buf * 2 + r) * SG_LN + c.lane] = h[r][4];
     }
+#pragma unroll
+    for (int q = 0; q < 5; q++) s.lasth[q] = __builtin_amdgcn_readfirstlane(__float_as_uint(h[1][q]));    // (one value across the lanes if the row was flat)
 }
 
 // statistics row ys = R0 - 15 + j from the ring whose newest entry (row j of wave H) sits in slot PH: SSIM value, its three derivatives -> sD row
@@ -563,6 +591,9 @@ sg_photo_kernel(SgLossArgs a, const float *__restrict__ raw, const float *__rest
     float part = 0.0f;
     if (wave == 0) {
         SgHSt s;
+        s.lastflat = false; s.lx = s.ly = 0u;
+#pragma unroll
+        for (int q = 0; q < 5; q++) s.lasth[q] = 0u;
         sg_loss_prefetch_row(c, s.pin[0], c.R0 - 10); sg_loss_prefetch_row(c, s.pin[1], c.R0 - 9);
         for (int i = 0; i < I; i++) {
             SG_PRIO(i);
