@@ -70,6 +70,7 @@ typedef struct SgLayout {
         bin_sort_items, bin_rank_items, bin_items,      /* work lists: long-list sort chunks, chunk merges, backward segments */
         bin_ck_start, bin_plan, bin_pair_mask, bin_item_w, bin_item_perm,
         bin_rec_valid,          /* [cap] one byte per gradient record (Gaussian-major pair slot): written by the sparse backward */
+        bin_tile_keys,          /* [T][1024] SG_FLAG_SHORT_LISTS on images of many tiles: the preprocess leaves every pair's key in its tile's row */
         bin_bytes;
     /* image workspace */
     size_t img_final_T, img_n_contrib, img_ckpt, img_bytes;
@@ -85,7 +86,7 @@ typedef struct SgLayout {
  * History: 5 = round 5's first tree; 6 = SgTriplane gained `feature_minor` (+ `reserved`) at its end, sg_weight_grad_ws_bytes grew
  * (two partial slabs per workgroup for <= 64 outputs); entry points added since 5: sg_linear_backward_fan, sg_rows_laplacian,
  * sg_scales_head_forward / _backward. */
-#define SG_ABI_VERSION 6
+#define SG_ABI_VERSION 7
 int sg_abi_version(void);
 const char *sg_version(void);
 const char *sg_last_error(void);
@@ -94,7 +95,11 @@ const char *sg_last_error(void);
  * itself -- (known from an earlier forward of the same scene: a pre-sized engine).  The two kernels that sort longer lists are then not launched at all -- such lists are
  * sorted by the compositing workgroups themselves -- which saves their launch latency (3.6 us of a 350-us cfg3 view).  If a
  * longer list does turn up the forward does NOT follow it: it renders the background, writes no gradients, and
- * sg_read_num_rendered / num_rendered_host report SG_NUM_RENDERED_LONG_LIST (re-run without the flag). */
+ * sg_read_num_rendered / num_rendered_host report SG_NUM_RENDERED_LONG_LIST (re-run without the flag).
+ * On images of many tiles (no per-workgroup tile histogram: more than 4096 tile counters) the flag also selects DIRECT binning: the
+ * preprocess writes a pair's key (depth bits << 32 | id) straight into row `tile` of a [T][1024] array at the rank its counting
+ * atomic returned -- no (Gaussian, tile, rank) records, no scatter pass over the pairs; the compositing workgroup sorts its row.
+ * Lists, ranges, images and gradients are the same bits either way. */
 #define SG_FLAG_SHORT_LISTS 1
 /* SG_FLAG_WS_CLEAN: the caller vouches that the counters at the head of `binning_ws` (the first sg_layout().bin_ranges
  * bytes) are zero: the workspace was zero-filled there after allocation, or its last use was a forward of this library that

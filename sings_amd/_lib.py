@@ -28,7 +28,7 @@ class SgLayout(C.Structure):
     _fields_ = [(n, C.c_size_t) for n in (
         "geom_recA", "geom_recB", "geom_recC", "geom_depth", "geom_flags", "geom_slot", "geom_bytes",
         "bin_header", "bin_tile_count", "bin_ranges", "bin_cursor", "bin_pair_keys", "bin_point_list",
-        "bin_point_keys", "bin_pair_gid", "bin_pair_tile", "bin_pair_local", "bin_sort_items", "bin_rank_items", "bin_items", "bin_ck_start", "bin_plan", "bin_pair_mask", "bin_item_w", "bin_item_perm", "bin_rec_valid", "bin_bytes", "img_final_T", "img_n_contrib", "img_ckpt", "img_bytes", "bwd_bytes")]
+        "bin_point_keys", "bin_pair_gid", "bin_pair_tile", "bin_pair_local", "bin_sort_items", "bin_rank_items", "bin_items", "bin_ck_start", "bin_plan", "bin_pair_mask", "bin_item_w", "bin_item_perm", "bin_rec_valid", "bin_tile_keys", "bin_bytes", "img_final_T", "img_n_contrib", "img_ckpt", "img_bytes", "bwd_bytes")]
 
 
 class SgSkinInputs(C.Structure):
@@ -66,7 +66,7 @@ EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_ras
            "sg_rasterize_backward_records_frames", "sg_rasterize_backward_gaussians_frames", "sg_skin_ws_floats_frames",
            "sg_skinned_backward_gaussians_frames", "sg_photo_loss_frames")
 NUM_KERNELS = 8
-ABI_VERSION = 6                      # SG_ABI_VERSION
+ABI_VERSION = 7                      # SG_ABI_VERSION
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT

@@ -28,7 +28,7 @@ static int sg_fail(const char *what, hipError_t e)
         }                                                                    \
     } while (0)
 
-extern "C" const char *sg_version(void) { return "sings_hip 0.6 (gfx950, abi 6)"; }
+extern "C" const char *sg_version(void) { return "sings_hip 0.7 (gfx950, abi 7)"; }
 extern "C" int sg_abi_version(void) { return SG_ABI_VERSION; }
 extern "C" const char *sg_last_error(void) { return g_err; }
 
@@ -67,6 +67,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_item_w = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);       // backward work-item weights
     L->bin_item_perm = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
     L->bin_rec_valid = o; o = sg_align(o + cap + 16);                                // one byte per gradient record (few-tile frames)
+    L->bin_tile_keys = o; o = sg_align(o + (sg_lds_hist((int)gx, (int)gy) ? 0 : T * SG_TILE_KEY_PITCH * 8));     // direct binning (sg_direct_keys)
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);

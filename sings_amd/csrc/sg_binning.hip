@@ -166,7 +166,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
                        uint64_t *__restrict__ pair_keys, uint32_t cap, int T, const uint4 *__restrict__ plan,
                        uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items, uint32_t sort_cap,
                        uint32_t rank_cap, uint32_t *__restrict__ items, uint32_t items_cap, uint32_t *__restrict__ item_w,
-                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid)
+                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid, int direct)
 {
     rec_valid = sg_at(rec_valid, (size_t)blockIdx.y * bin_stride);
     {   // frame blockIdx.y
@@ -187,7 +187,7 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
             sort_items[pl.y] = make_uint4(tile, pl.z, s0, e0 - s0);
         }
     }
-    const uint32_t R = header[0] < cap ? header[0] : cap;
+    const uint32_t R = direct ? 0u : (header[0] < cap ? header[0] : cap);     // (direct binning: the preprocess placed the keys itself)
     for (uint32_t i = gtid; i < R; i += nthreads) {
         uint32_t gid = pair_gid[i];
         uint32_t slot = start[pair_tile[i]] + pair_local[i];
@@ -204,6 +204,9 @@ sg_pair_scatter_kernel(const uint32_t *__restrict__ header, const uint32_t *__re
 // between them; (4) the workgroup scatters its share of the pairs with the cursors in LDS.  No workgroup waits for
 // another one.  LDS: 4 T bytes (T <= SG_SS_MAX_TILES; larger images take the two-kernel path below).
 #define SG_SS_THREADS 1024
+#ifndef SG_DIRECT_SCAN_WGS
+#define SG_DIRECT_SCAN_WGS 8          // direct binning: workgroups per frame that scan (each all T counts) and write a share of the outputs
+#endif
 #define SG_SS_MAX_TILES 32768
 __global__ void __launch_bounds__(SG_SS_THREADS)
 sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, uint2 *__restrict__ ranges,
@@ -213,7 +216,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
                        const uint32_t *__restrict__ pair_local, const float *__restrict__ depth,
                        uint64_t *__restrict__ pair_keys, uint4 *__restrict__ sort_items, uint2 *__restrict__ rank_items,
                        uint32_t *__restrict__ items, uint32_t *__restrict__ item_w, int short_lists, unsigned long long *signal,
-                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid)
+                       size_t bin_stride, size_t geom_stride, uint8_t *__restrict__ rec_valid, int direct)
 {
     rec_valid = sg_at(rec_valid, (size_t)blockIdx.y * bin_stride);
     constexpr int NQ = SG_SCAN_NQ;
@@ -279,11 +282,13 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
             run[a] = woff + incl[a] - own[a];
         }
     }
-    const bool writer = (uint32_t)tid % gridDim.x == blockIdx.x;
+    // (direct binning: the tiles are dealt out one by one -- a thread then writes 8 / gridDim of its 8 tiles at cfg3, not all or none)
+    const bool wthread = (uint32_t)tid % gridDim.x == blockIdx.x;
     for (int t = t0; t < t1; t++) {
         const uint32_t v = sStart[t];
         uint32_t q[NQ];
         sg_scan_derive(v, q);
+        const bool writer = direct ? (uint32_t)t % gridDim.x == blockIdx.x : wthread;
         if (writer) {
             const uint32_t s = run[0] < cap ? run[0] : cap, e = run[0] + v < cap ? run[0] + v : cap;
             ranges[t] = v ? make_uint2(s, e) : make_uint2(0u, 0u);
@@ -311,6 +316,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
         header[6] = tot[4] < rank_cap ? tot[4] : rank_cap;
         header[7] = 0u;                                   // groups the partition kernel hands to the group kernel
     }
+    if (direct) return;                                   // direct binning: the preprocess placed the keys itself (sg_store_proj)
     __syncthreads();
     const uint32_t R = tot[0] < cap ? tot[0] : cap;
     for (uint32_t i = blockIdx.x * SG_SS_THREADS + tid; i < R; i += gridDim.x * SG_SS_THREADS) {
@@ -713,18 +719,20 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
     // counts in front of its share of the scatter -- the price of saving a launch when ONE frame's 211 workgroups are all the GPU
     // has; with K x 211 workgroups queued a 10-us scan kernel (one workgroup row per frame) + a plain scatter are faster (cfg3, 8
     // cameras: 10.4 + 78.0 against 110.9 us; few-tile frames: 75.6 against 77.0, left fused)
-    bool fused = T <= SG_SS_MAX_TILES && (K == 1 || sg_lds_hist(c.gx, c.gy));
+    // DIRECT binning (sg_direct_keys): nothing to scatter -- the fused kernel's scan part alone, a few workgroups per frame
+    const int direct = sg_direct_keys(c.gx, c.gy, c.flags) ? 1 : 0;
+    bool fused = T <= SG_SS_MAX_TILES && (K == 1 || sg_lds_hist(c.gx, c.gy) || direct);
     if (fused && (size_t)T * 4 + 1024 > 64 * 1024)
         fused = sg_dyn_lds_limit(0, (const void *)sg_scan_scatter_kernel, SG_SS_MAX_TILES * 4);
     if (fused) {
         sg_prof_begin(SG_K_TILE_SCAN, st);
         size_t want = (cap + 4 * SG_SS_THREADS - 1) / (4 * SG_SS_THREADS);     // ~4 pairs per thread
-        const int grid = (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
+        const int grid = direct ? SG_DIRECT_SCAN_WGS : (int)(want < 8 ? 8 : (want > 256 ? 256 : want));
         hipLaunchKernelGGL(sg_scan_scatter_kernel, dim3(grid, K), dim3(SG_SS_THREADS), (size_t)T * 4, st, T, c.gx, b.tile_count, b.ranges,
                            b.cursor, b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
                            sg_items_cap(T, cap), b.pair_gid, b.pair_tile, b.pair_local, g.depth, b.pair_keys, b.sort_items,
                            b.rank_items, b.items, b.item_w, short_lists, c.count_signal, bt.bin, bt.geom,
-                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr);
+                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr, direct);
         sg_prof_end(SG_K_TILE_SCAN, st);
     } else {
         sg_prof_begin(SG_K_TILE_SCAN, st);
@@ -735,12 +743,12 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
                            sg_items_cap(T, cap), short_lists, c.count_signal, bt.bin);
         sg_prof_end(SG_K_TILE_SCAN, st);
         sg_prof_begin(SG_K_TILE_SCATTER, st);
-        size_t want = ((cap > (size_t)T ? cap : (size_t)T) + 255) / 256;
+        size_t want = (((direct || cap < (size_t)T) ? (size_t)T : cap) + 255) / 256;
         int grid = (int)(want < 1 ? 1 : (want > 8192 ? 8192 : want));
         hipLaunchKernelGGL(sg_pair_scatter_kernel, dim3(grid, K), dim3(256), 0, st, b.header, b.pair_gid, b.pair_tile,
                            b.pair_local, g.depth, b.cursor, b.pair_keys, cap32, T, b.plan, b.sort_items, b.rank_items,
                            sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.items, sg_items_cap(T, cap), b.item_w, bt.bin, bt.geom,
-                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr);
+                           sg_lds_hist(c.gx, c.gy) ? b.rec_valid : (uint8_t *)nullptr, direct);
         sg_prof_end(SG_K_TILE_SCATTER, st);
     }
     // lists longer than 1024 entries (the composite kernel sorts the others): both kernels exit at once when there are none

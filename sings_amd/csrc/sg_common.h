@@ -54,6 +54,20 @@ static inline bool sg_lds_hist(int gx, int gy) { return sg_ctr_count((uint32_t)g
 // The same regime (few tiles, a handful of them with lists of thousands of entries) is where the forward composite ends in a few
 // deep tiles running alone: there a tile of more than 1024 entries is composited by four workgroups, one per quadrant
 // (sg_render.hip), and the per-entry quadrant masks live in four planes of mask_plane bytes.
+// DIRECT binning: the caller vouches for lists of <= SG_WSORT_MAX entries (SG_FLAG_SHORT_LISTS, checked on the device) and the image has
+// too many tiles for the per-workgroup histogram -- then a pair's key goes straight into its tile's row of SgBin::tile_keys at the rank
+// its counting atomic returned: no pair records, no scatter pass (round 6; sg_project.h::sg_store_proj, sg_binning.hip)
+#ifdef SG_NO_DIRECT
+__host__ __device__ static inline bool sg_direct_flag(int) { return false; }
+#else
+__host__ __device__ static inline bool sg_direct_flag(int flags) { return (flags & SG_FLAG_SHORT_LISTS) != 0; }     // (device side: && no histogram)
+#endif
+#define SG_TILE_KEY_PITCH 1024      // = SG_WSORT_MAX (sg_sort.h)
+#ifdef SG_NO_DIRECT      /* A/B builds only (tools/ab_direct.sh) */
+static inline bool sg_direct_keys(int, int, int) { return false; }
+#else
+static inline bool sg_direct_keys(int gx, int gy, int flags) { return (flags & SG_FLAG_SHORT_LISTS) && !sg_lds_hist(gx, gy); }
+#endif
 static inline bool sg_split_long(int gx, int gy, int flags) { return sg_lds_hist(gx, gy) && !(flags & SG_FLAG_THROUGHPUT); }
 static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 
@@ -88,6 +102,7 @@ struct SgBin {
     uint32_t *item_w;      // [items_cap] weight of a backward work item: the scatter zeroes it, the few-tile forward sets it to the entries
                            //             of the segment it composited somewhere (split tiles: the largest of the four quadrants)
     uint32_t *item_perm;   // [items_cap]    ... and the work items by descending weight (sg_order_items_kernel)
+    uint64_t *tile_keys;   // [T][SG_TILE_KEY_PITCH] direct binning (sg_direct_keys): the unsorted keys of tile t in row t, written by the preprocess
     uint8_t *rec_valid;    // [cap] few-tile frames: 1 = the sparse backward composite wrote the gradient record of this Gaussian-major
                            //       pair slot; zeroed by the forward's scatter (one lane per pair anyway).  Readers skip the others:
                            //       the 36-B records themselves are never zeroed (round 3 streamed 27 MB of zeros per avatar frame)
@@ -136,7 +151,7 @@ static inline SgBin sg_bin_view(void *ws, const SgLayout &L)
     g.items = (uint32_t *)(b + L.bin_items); g.ck_start = (uint32_t *)(b + L.bin_ck_start);
     g.plan = (uint4 *)(b + L.bin_plan); g.pair_mask = (uint8_t *)(b + L.bin_pair_mask);
     g.item_w = (uint32_t *)(b + L.bin_item_w); g.item_perm = (uint32_t *)(b + L.bin_item_perm);
-    g.rec_valid = (uint8_t *)(b + L.bin_rec_valid);
+    g.rec_valid = (uint8_t *)(b + L.bin_rec_valid); g.tile_keys = (uint64_t *)(b + L.bin_tile_keys);
     return g;
 }
 static inline SgImg sg_img_view(void *ws, const SgLayout &L)
@@ -195,7 +210,7 @@ __host__ __device__ __forceinline__ SgBin sg_frame(SgBin b, size_t off)
     b.pair_local = sg_at(b.pair_local, off); b.sort_items = sg_at(b.sort_items, off); b.rank_items = sg_at(b.rank_items, off);
     b.items = sg_at(b.items, off); b.ck_start = sg_at(b.ck_start, off); b.plan = sg_at(b.plan, off);
     b.pair_mask = sg_at(b.pair_mask, off); b.item_w = sg_at(b.item_w, off); b.item_perm = sg_at(b.item_perm, off);
-    b.rec_valid = sg_at(b.rec_valid, off);
+    b.rec_valid = sg_at(b.rec_valid, off); b.tile_keys = sg_at(b.tile_keys, off);
     return b;
 }
 __host__ __device__ __forceinline__ SgImg sg_frame(SgImg i, size_t off)

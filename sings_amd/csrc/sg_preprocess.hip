@@ -16,7 +16,7 @@ sg_preprocess_fwd_kernel(SgCam c, SgBatch bt, int P, const float *__restrict__ m
                          SgGeom g, SgBin bn, uint32_t cap, int32_t *__restrict__ radii, int hist_tiles, int nblocks)
 {
     extern __shared__ uint32_t sg_hist_lds[];               // hist_tiles words (0: per-pair global atomics)
-    __shared__ uint32_t scratch_all[4][192];
+    __shared__ uint32_t scratch_all[4][256];
     // (Gaussian block, camera) of this workgroup: the K cameras of one block run back to back on ONE XCD (sg_block_frame)
     int gblock, frame;
     if (!sg_block_frame((int)blockIdx.x, bt.K, nblocks, gblock, frame)) return;
@@ -58,7 +58,8 @@ sg_preprocess_fwd_kernel(SgCam c, SgBatch bt, int P, const float *__restrict__ m
                           colors_precomp ? colors_precomp + 3 * (size_t)idx : nullptr, sh, o);
         opac = opacities[idx];
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave], hist_tiles ? sg_hist_lds : nullptr, hist_tiles);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave], hist_tiles ? sg_hist_lds : nullptr, hist_tiles,
+                  sg_direct_flag(c.flags) && !hist_tiles);
 }
 
 void sg_launch_preprocess_fwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,

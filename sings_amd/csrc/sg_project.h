@@ -101,12 +101,17 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
 //    follows the tile scan then needs no atomics at all.  With `hist` (T words of workgroup LDS, images of few
 //    tiles) the ranks are first taken from an LDS histogram of the workgroup and rebased with one global atomic per
 //    touched tile.
-// `scratch`: >= 192 words of LDS private to this wave.
+//  * DIRECT (sg_direct_keys: short lists vouched for, no histogram): the pair's key goes straight into row `tile` of bn.tile_keys
+//    at that rank -- the (Gaussian, tile, rank) records, and the scatter pass that read them back, are gone; a rank beyond the row
+//    is dropped (the scan flags the long list and nothing is composited).
+// `scratch`: >= 256 words of LDS private to this wave.
+// (the key store of direct binning as a non-temporal store: the preprocess 36 -> 48-57 us at cfg3.  Plain stores.)
+#define SG_KEY_STORE(p, v) (*(p) = (v))
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
                                               int gx, uint32_t cap, int32_t *__restrict__ radii,
-                                              uint32_t *__restrict__ scratch, uint32_t *__restrict__ hist, int T)
+                                              uint32_t *__restrict__ scratch, uint32_t *__restrict__ hist, int T, bool direct)
 {
-    uint32_t *sIncl = scratch, *sMin = scratch + 64, *sWid = scratch + 128;
+    uint32_t *sIncl = scratch, *sMin = scratch + 64, *sWid = scratch + 128, *sDep = scratch + 192;
     const int lane = threadIdx.x & 63;
     uint32_t incl = o.tt;
 #pragma unroll
@@ -137,17 +142,17 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         g.flags[idx] = o.clampbits;
     }
     const bool expand = total != 0 || hist;     // wave-uniform
-    sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu;
+    sIncl[lane] = incl; sMin[lane] = rmin; sWid[lane] = rwh & 0xffffu; sDep[lane] = __float_as_uint(o.depth);
     __builtin_amdgcn_s_waitcnt(0xC07F);
     __builtin_amdgcn_wave_barrier();
     const int g0 = idx - lane;
     // four pairs per lane per round: the four returning atomics are in flight together
-    uint32_t tile[4], local[4], gj[4], ctr[4];
+    uint32_t tile[4], local[4], gj[4], ctr[4], dep[4];
     auto take = [&](uint32_t p0) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
             const uint32_t p = p0 + 64 * u + lane;
-            tile[u] = 0; local[u] = 0; gj[u] = 0; ctr[u] = 0;
+            tile[u] = 0; local[u] = 0; gj[u] = 0; ctr[u] = 0; dep[u] = 0;
             if (p < total) {
                 int lo = 0, hi = 63;                  // smallest j with incl[j] > p
 #pragma unroll
@@ -166,6 +171,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 // are indexed alike, in 4x4 blocks of tiles (sg_ctr_index)
                 ctr[u] = sg_ctr_index((mn & 0xffffu) + tx, (mn >> 16) + ty, (uint32_t)gx);
                 local[u] = hist ? atomicAdd(&hist[ctr[u]], 1u) : atomicAdd(&bn.tile_count[ctr[u]], 1u);
+                dep[u] = sDep[j];
             }
         }
     };
@@ -187,9 +193,9 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
     }
     // round 0 (all of the wave's pairs at cfg3 / most of them on an avatar) stays in registers until its ranks are final: with the
     // LDS histogram they are rebased here instead of being written, re-read and rewritten
-    uint32_t tile0[4], local0[4], gj0[4], ctr0[4];
+    uint32_t tile0[4], local0[4], gj0[4], ctr0[4], dep0[4];
 #pragma unroll
-    for (int u = 0; u < 4; u++) { tile0[u] = tile[u]; local0[u] = local[u]; gj0[u] = gj[u]; ctr0[u] = ctr[u]; }
+    for (int u = 0; u < 4; u++) { tile0[u] = tile[u]; local0[u] = local[u]; gj0[u] = gj[u]; ctr0[u] = ctr[u]; dep0[u] = dep[u]; }
     if (expand) {
         for (uint32_t p0 = 256; p0 < total; p0 += 256) {
             take(p0);
@@ -197,7 +203,9 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             for (int u = 0; u < 4; u++) {
                 const uint32_t p = p0 + 64 * u + lane;
                 const uint32_t slot = base + p;
-                if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
+                if (direct) {
+                    if (p < total && local[u] < SG_TILE_KEY_PITCH) SG_KEY_STORE(&bn.tile_keys[(size_t)tile[u] * SG_TILE_KEY_PITCH + local[u]], ((uint64_t)dep[u] << 32) | gj[u]);
+                } else if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
             }
         }
     }
@@ -231,7 +239,10 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         for (int u = 0; u < 4; u++) {
             const uint32_t p = 64 * u + lane;
             const uint32_t slot = base + p;
-            if (p < total && slot < cap) {
+            if (direct) {
+                if (p < total && local0[u] < SG_TILE_KEY_PITCH)
+                    SG_KEY_STORE(&bn.tile_keys[(size_t)tile0[u] * SG_TILE_KEY_PITCH + local0[u]], ((uint64_t)dep0[u] << 32) | gj0[u]);
+            } else if (p < total && slot < cap) {
                 bn.pair_gid[slot] = gj0[u]; bn.pair_tile[slot] = tile0[u];
                 bn.pair_local[slot] = local0[u] + (hist ? hist[ctr0[u]] : 0u);
             }

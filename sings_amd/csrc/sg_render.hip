@@ -165,9 +165,9 @@ __device__ __forceinline__ int sg_compact_quadrant(const uint32_t *__restrict__ 
                       const uint32_t *__restrict__ ck_start, float4 *__restrict__ ckpt, uint32_t ck_cap,                 \
                       uint32_t *__restrict__ header, uint8_t *__restrict__ pair_mask, uint32_t *__restrict__ tile_count,            \
                       const uint4 *__restrict__ long_items, uint32_t mask_plane, const uint4 *__restrict__ plan,                  \
-                      uint32_t *__restrict__ item_w, uint32_t w_plane
+                      uint32_t *__restrict__ item_w, uint32_t w_plane, uint32_t key_pitch
 #define SG_FWD_ARGS W, H, gx, T, nblocks, ranges, pair_keys, point_list, point_keys, recA, recB, recC, bg, out_color, final_T, \
-                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane, plan, item_w, w_plane
+                    n_contrib, ck_start, ckpt, ck_cap, header, pair_mask, tile_count, long_items, mask_plane, plan, item_w, w_plane, key_pitch
 // WEIGHTS: leave the backward's work-item weights (few-tile frames: item_w, first_item); always with PIPE
 template <bool PIPE, bool WEIGHTS>
 __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
@@ -232,7 +232,8 @@ __device__ __forceinline__ void sg_render_fwd_body(SG_FWD_PARAMS)
         // the backward pass through point_list -- the separate sort pass of round 1 (18 us, all latency) is gone and the
         // sort of one tile overlaps the compositing of the other tiles resident on the CU.
         uint64_t *sKey = (uint64_t *)sR;                    // aliases the staging buffer: consumed before the first batch
-        sg_sort_short_list(pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
+        // (direct binning, key_pitch != 0: `pair_keys` is SgBin::tile_keys, the tile's unsorted keys are its row)
+        sg_sort_short_list(key_pitch ? pair_keys + (size_t)tile * key_pitch : pair_keys + range.x, n, sKey, sKey + SG_WSORT_MAX, tid);
         for (int i = tid; i < n; i += SG_FB) {              // (later batches read their ids back from point_list: the barrier at
             const uint64_t key = sKey[i];                   //  the top of the batch loop orders these stores in front of those loads)
             const uint32_t gid = (uint32_t)key;
@@ -393,9 +394,10 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
     const unsigned K = (unsigned)bt.K;
     const bool few = sg_lds_hist(c.gx, c.gy);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
-#define SG_RF_ARGS(NB) c.W, c.H, c.gx, T, NB, b.ranges, b.pair_keys, b.point_list, pk, g.recA, g.recB, g.recC, c.bg, out_color,     \
+    const bool direct = sg_direct_keys(c.gx, c.gy, c.flags);       // the tile's unsorted keys: its row of tile_keys
+#define SG_RF_ARGS(NB) c.W, c.H, c.gx, T, NB, b.ranges, direct ? b.tile_keys : b.pair_keys, b.point_list, pk, g.recA, g.recB, g.recC, c.bg, out_color,     \
                        im.final_T, im.n_contrib, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,       \
-                       (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap)
+                       (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap), direct ? (uint32_t)SG_TILE_KEY_PITCH : 0u
     sg_prof_begin(SG_K_RENDER_FWD, st);
     if (K > 1 || (few && (c.flags & SG_FLAG_THROUGHPUT))) {
         // K frames per launch, or a few-tile frame that shares the chip with other views: the plain loop (see the kernel)

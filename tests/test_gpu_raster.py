@@ -576,6 +576,74 @@ def test_short_lists_hint_skips_the_long_sort_and_is_checked_on_the_device():
     assert float(eng.d_means3D.abs().max()) == 0.0 and float(eng.d_sh.abs().max()) == 0.0
 
 
+def test_direct_binning_leaves_the_bits_of_the_scatter_path():
+    """Images of many tiles with SG_FLAG_SHORT_LISTS take DIRECT binning (include/sings_hip.h): the preprocess writes every pair's key into
+    its tile's row of `tile_keys` at the rank its counting atomic returned -- no pair records, no scatter pass.  Ranges, sorted lists,
+    image and every gradient carry the bits of the plain path, with one frame and with K frames per launch; a list longer than a row
+    is refused exactly as the hint promises (background, no gradients, NUM_RENDERED_LONG_LIST)."""
+    from sings_amd import _lib
+    from sings_amd.engine import RasterEngine, RasterFramesEngine
+    dev = _dev()
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    N, W, H = 30000, 1280, 1040                                  # 80 x 65 = 5200 tiles: no per-workgroup histogram
+    s = synthetic_scene(N, W, H, 3, 41)
+    ins = [t(s[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    dL = t(s["dL_dimage"])
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    eng = RasterEngine(N, W, H, 16, dev, capacity_pairs=16 * N + 65536)
+    assert eng.L.bin_bytes - eng.L.bin_tile_keys >= T * 1024 * 8
+
+    def lists(e):
+        rg = e.binning[e.L.bin_ranges:e.L.bin_ranges + 8 * T].view(torch.int32).view(-1, 2).clone()
+        R = int(rg[:, 1].max())
+        return rg, e.binning[e.L.bin_point_list:e.L.bin_point_list + 4 * R].view(torch.int32).clone()
+
+    eng.set_camera(_settings(s, dev))
+    eng.forward(*ins); eng.backward(*ins, dL)
+    R = eng.num_rendered()
+    color0, grad0 = eng.color.clone(), eng.grad_flat.clone()
+    rg0, pl0 = lists(eng)
+    assert R > 3 * N and int((rg0[:, 1] - rg0[:, 0]).max()) <= 1024
+    for rep in range(2):                                         # (twice: the counters the forward leaves zeroed serve the next call)
+        eng.set_camera(_settings(s, dev), short_lists=True)
+        eng.color.zero_(); eng.grad_flat.zero_()
+        eng.forward(*ins); eng.backward(*ins, dL)
+        rg1, pl1 = lists(eng)
+        assert eng.num_rendered() == R and torch.equal(rg1, rg0) and torch.equal(pl1, pl0)
+        assert torch.equal(eng.color, color0) and torch.equal(eng.grad_flat, grad0)
+    # K = 2 frames per launch (two cameras), against two single-frame calls of the plain path
+    sv = dict(s)
+    view = s["viewmatrix"].copy(); view[3, 0] = 0.03
+    sv["viewmatrix"] = view
+    sv["projmatrix"] = (view @ (np.linalg.inv(s["viewmatrix"]) @ s["projmatrix"])).astype(np.float32)
+    sv["campos"] = np.linalg.inv(view)[3, :3].astype(np.float32)
+    st0, st1 = _settings(s, dev), _settings(sv, dev)
+    eng.set_camera(st1)
+    eng.forward(*ins)
+    color1 = eng.color.clone()
+    fe = RasterFramesEngine(N, W, H, 16, 2, dev, capacity_pairs=16 * N + 65536)
+    fe.set_camera(st0._replace(viewmatrix=torch.stack([st0.viewmatrix, st1.viewmatrix]), projmatrix=torch.stack([st0.projmatrix, st1.projmatrix]),
+                               campos=torch.stack([st0.campos, st1.campos])), short_lists=True)
+    fe.forward(*ins)
+    assert torch.equal(fe.color[0], color0) and torch.equal(fe.color[1], color1)
+    # a list longer than a row of tile_keys
+    s2 = synthetic_scene(N, W, H, 3, 41)
+    s2["means3D"][:, :2] *= 0.02
+    ins2 = [t(s2[k]) for k in ("means3D", "shs", "opacities", "scales", "rotations")]
+    eng.set_camera(_settings(s2, dev))
+    eng.forward(*ins2)
+    rg2, _ = lists(eng)
+    assert int((rg2[:, 1] - rg2[:, 0]).max()) > 1024 and eng.num_rendered() > 0
+    color2 = eng.color.clone()
+    eng.set_camera(_settings(s2, dev), short_lists=True)
+    eng.forward(*ins2); eng.backward(*ins2, dL)
+    assert eng.num_rendered() == _lib.NUM_RENDERED_LONG_LIST
+    assert torch.equal(eng.color, t(s2["bg"])[:, None, None].expand_as(eng.color)) and float(eng.d_means3D.abs().max()) == 0.0
+    eng.set_camera(_settings(s2, dev))                           # ... and the plain path still renders it (nothing stale left behind)
+    eng.forward(*ins2)
+    assert torch.equal(eng.color, color2)
+
+
 def test_views_in_flight_on_two_streams_match_sequential_runs():
     """bench.py renders the views of a step through one engine per view (own workspaces, own row of a shared gradient
     buffer) spread over two HIP streams.  The library keeps no state between calls, so views in flight at the same time
