@@ -53,7 +53,10 @@ typedef struct SgRasterSettings {
      * the per-Gaussian kernel and the tile scan, a third of the way into a cfg3 forward -- so the call returns R WITHOUT
      * synchronising the stream: the composite kernel is still running while the caller already queues its next work.  This is
      * what lets the drop-in autograd wrapper keep upstream's guarantee (upstream blocks the host mid-forward for R: never a
-     * frame rendered with a too small workspace) at nearly the speed of never looking. */
+     * frame rendered with a too small workspace) at nearly the speed of never looking.
+     * flags: bit 0 more pairs than the workspace holds, bit 1 a long list under SG_FLAG_SHORT_LISTS (both: nothing was composited),
+     * bit 2 (SG_COUNT_FLAG_HALF_ROWS, in this word only) no tile list is longer than 512 entries -- a caller that reads the word
+     * itself after the call may pass SG_FLAG_SHORT_LISTS for the next frame of the scene (the Python wrapper does). */
     unsigned long long *count_signal;
     volatile unsigned long long *count_signal_host;
 } SgRasterSettings;
@@ -101,6 +104,7 @@ const char *sg_last_error(void);
  * atomic returned -- no (Gaussian, tile, rank) records, no scatter pass over the pairs; the compositing workgroup sorts its row.
  * Lists, ranges, images and gradients are the same bits either way. */
 #define SG_FLAG_SHORT_LISTS 1
+#define SG_COUNT_FLAG_HALF_ROWS 4u   /* in the count_signal word: see SgRasterSettings */
 /* SG_FLAG_WS_CLEAN: the caller vouches that the counters at the head of `binning_ws` (the first sg_layout().bin_ranges
  * bytes) are zero: the workspace was zero-filled there after allocation, or its last use was a forward of this library that
  * returned 0 -- every forward leaves them zeroed (its last kernel clears what the next forward's first kernel counts into).

@@ -68,6 +68,7 @@ EXPORTS = ("sg_abi_version", "sg_version", "sg_last_error", "sg_layout", "sg_ras
 NUM_KERNELS = 8
 ABI_VERSION = 7                      # SG_ABI_VERSION
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
+COUNT_FLAG_HALF_ROWS = 4             # SG_COUNT_FLAG_HALF_ROWS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT
 FLAG_FORWARD_BINNING = 8             # SG_FLAG_FORWARD_BINNING

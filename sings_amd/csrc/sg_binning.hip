@@ -26,7 +26,7 @@
 #include <atomic>
 
 // Exclusive scans over the T tile counts of
-//   q0 pairs (-> ranges, cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items.
+//   q0 pairs (-> ranges, cursors), q1 backward work items, q2 checkpoint slots, q3 sort items, q4 rank items, q5 lists > 512 (total only).
 // Workgroup b owns tiles [b * SG_SCAN_BS * tpt, (b + 1) * SG_SCAN_BS * tpt), one tile per thread and round.  Instead of a second
 // kernel (or a look-back chain) every workgroup first REDUCES the counts of all tiles in front of its range itself:
 // at most T words per workgroup, coalesced and L2-resident.  The kernel is a handful of waves that start with a cold
@@ -34,14 +34,15 @@
 // straight-line code) took 22 us at 8160 tiles, this one 12 us.
 // The work lists themselves are written by the (chip-wide) scatter kernel from the per-tile
 // `plan` = (first backward item, first sort item, first rank item, pair count).
-#define SG_SCAN_NQ 5
+#define SG_SCAN_NQ 6
 // BS = threads (= tiles per round) of a scan workgroup: 256 for images of few tiles (several CUs even at 1000 tiles),
 // 1024 for many tiles (fewer workgroups re-reducing the counts in front of them)
 __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ])
 {
     const uint32_t seg = sg_nseg(v);
     // q3: partition work items (one per list the compositing workgroup does not sort itself); q4: group slots reserved for it
-    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = v > SG_WSORT_MAX ? 1u : 0u; q[4] = sg_group_slots(v);
+    // q5: lists of more than half a row of SgBin::tile_keys -- none of them: the published count says so (SG_COUNT_FLAG_HALF_ROWS)
+    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = v > SG_WSORT_MAX ? 1u : 0u; q[4] = sg_group_slots(v); q[5] = v > SG_WSORT_MAX / 2 ? 1u : 0u;
 }
 
 // Early pair count: one 64-bit system-scope store to a mapped, coherent host word (valid bit | flags << 32 | R) -- visible to a
@@ -70,7 +71,7 @@ sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_co
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int first = blockIdx.x * SG_SCAN_BS * tpt;
     // ---- 1. totals of everything in front of this workgroup's range
-    uint32_t acc[NQ] = { 0, 0, 0, 0, 0 };
+    uint32_t acc[NQ] = { 0, 0, 0, 0, 0, 0 };
     for (int t = tid; t < first; t += SG_SCAN_BS) {
         uint32_t q[NQ];
         const uint32_t v = tile_count[sg_ctr_of_tile((uint32_t)t, (uint32_t)gx)];
@@ -99,7 +100,7 @@ sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_co
     for (int r = 0; r < tpt; r++) {
         const int tile = first + r * SG_SCAN_BS + tid;
         const bool ok = tile < T;
-        uint32_t q[NQ] = { 0, 0, 0, 0, 0 };
+        uint32_t q[NQ] = { 0, 0, 0, 0, 0, 0 };
         const uint32_t v = ok ? tile_count[sg_ctr_of_tile((uint32_t)tile, (uint32_t)gx)] : 0u;
         if (ok) sg_scan_derive(v, q);
         uint32_t incl[NQ];
@@ -148,7 +149,7 @@ sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_co
         header[0] = carry[0];
         const uint32_t hflags = (carry[0] > cap ? 1u : 0u) | (short_lists && carry[3] ? 2u : 0u);
         header[1] = hflags;
-        sg_publish_count(signal, carry[0], hflags);
+        sg_publish_count(signal, carry[0], hflags | (carry[5] ? 0u : SG_COUNT_FLAG_HALF_ROWS));
         header[3] = (uint32_t)T;
         header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
         header[5] = carry[1] < items_cap ? carry[1] : items_cap;
@@ -236,7 +237,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
     __syncthreads();
     const int tpt = (T + SG_SS_THREADS - 1) / SG_SS_THREADS;
     const int t0 = tid * tpt < T ? tid * tpt : T, t1 = t0 + tpt < T ? t0 + tpt : T;
-    uint32_t own[NQ] = { 0, 0, 0, 0, 0 };
+    uint32_t own[NQ] = { 0, 0, 0, 0, 0, 0 };
 #pragma unroll 8
     for (int t = t0; t < t1; t++) {
         uint32_t q[NQ];
@@ -309,7 +310,7 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
         // Either way the lists are incomplete / unsorted and the composite kernels touch nothing.
         const uint32_t hflags = (tot[0] > cap ? 1u : 0u) | (short_lists && tot[3] ? 2u : 0u);
         header[1] = hflags;
-        sg_publish_count(signal, tot[0], hflags);         // the host may be waiting for exactly this (SgRasterSettings.count_signal)
+        sg_publish_count(signal, tot[0], hflags | (tot[5] ? 0u : SG_COUNT_FLAG_HALF_ROWS));     // the host may be waiting for exactly this (SgRasterSettings.count_signal)
         header[3] = (uint32_t)T;
         header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
         header[5] = tot[1] < items_cap ? tot[1] : items_cap;

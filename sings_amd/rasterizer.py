@@ -58,6 +58,12 @@ _seen = {}                             # device index -> set of (P, W, H) signat
 _pending = {}                          # device index -> list of [pinned (R, flag), event, cap] of async forwards
 _accum = {}                            # device index -> int32[2] device tensor: max R, OR of flags (deferred mode)
 _HEADROOM = 2.0
+# "sync" forwards learn, scene by scene, whether SG_FLAG_SHORT_LISTS may be passed: the count word of a frame says whether any tile
+# list was longer than 512 entries (SG_COUNT_FLAG_HALF_ROWS); if none was, the next frame of that (device, P, W, H) runs with the
+# flag -- no long-list sort launches and, on images of many tiles, direct binning (no scatter pass: include/sings_hip.h).  A frame
+# that does meet a list of more than 1024 entries under the flag reports NUM_RENDERED_LONG_LIST and is rendered again without it
+# before the call returns: the drop-in guarantee (never a wrong frame) stands.
+_short_ok = {}                         # (device index, P, W, H) -> the last frame's lists were all <= 512 entries
 _ring = {}                             # device index -> [pinned int32[_RING, 2], next slot]
 _RING = 16
 _signal = {}                           # device index -> [host address, device address, next slot] of the early-count words
@@ -218,6 +224,8 @@ def _forward_done_sync(dev, R, sig):
 
 def reset_overflow_state(device=None):
     """Forget capacities, checked signatures and pending results (tests; after a change of scene scale)."""
+    for k in [k for k in _short_ok if device is None or k[0] == torch.device(device).index]:
+        del _short_ok[k]
     for d in (_capacity_hint, _seen, _pending, _accum):
         if device is None:
             d.clear()
@@ -354,6 +362,8 @@ class _RasterizeGaussians(torch.autograd.Function):
         radii = torch.empty((P,), dtype=torch.int32, device=dev)
         cap, sync, sig = _forward_plan(dev, P, W, H)
         need_bwd = any(ctx.needs_input_grad[:8])
+        hint_key = (dev.index,) + sig
+        hint = sync and not rs.debug and _short_ok.get(hint_key, False)
         with torch.cuda.device(dev):
             if sync and not rs.debug:
                 _arm_early_count(s, dev)
@@ -376,16 +386,24 @@ class _RasterizeGaussians(torch.autograd.Function):
                     bufs = _backward_buffers(dev, P, M, L.bwd_bytes, sh is not None, colors_precomp is not None, scales is not None,
                                              cov3Ds_precomp is not None)
                 nr = C.c_int64(0)
+                s.flags = _lib.FLAG_SHORT_LISTS if hint else 0
                 _lib.check(lib.sg_rasterize_forward(
                     C.byref(s), P, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
                     _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(geom), _ptr(binning), cap, _ptr(img),
                     _ptr(color), _ptr(radii), int(bool(write_point_keys)), C.byref(nr) if sync else None, stream), "forward")
                 R = int(nr.value) if sync else None
+                if hint and R == _lib.NUM_RENDERED_LONG_LIST:       # the scene changed under the hint: this frame again, without it
+                    _short_ok[hint_key] = hint = False
+                    continue
                 if not sync or R <= cap:
                     break
                 cap = int(R * _HEADROOM) + 1024     # workspace too small: grow and re-run
             if sync:
                 _forward_done_sync(dev, R, sig)
+                if s.count_signal_host:
+                    word = C.c_uint64.from_address(s.count_signal_host).value
+                    if word >> 63:                                   # (not after a timed-out wait: that read the header instead)
+                        _short_ok[hint_key] = bool((word >> 32) & _lib.COUNT_FLAG_HALF_ROWS)
             else:
                 _after_forward(dev, binning, cap)
         ctx.raster_settings = rs

@@ -644,6 +644,41 @@ def test_direct_binning_leaves_the_bits_of_the_scatter_path():
     assert torch.equal(eng.color, color2)
 
 
+def test_drop_in_surface_learns_the_short_list_hint_and_never_returns_a_wrong_frame():
+    """GaussianRasterizer in its default ("sync") mode: the count word of a frame says whether every list had <= 512 entries; if so the
+    NEXT frame of that (device, P, W, H) runs with SG_FLAG_SHORT_LISTS (direct binning at this image size) and gives the same bits.  When
+    the scene then grows a long list under the hint, the frame is rendered again without it before the call returns."""
+    from diff_gaussian_rasterization import GaussianRasterizer
+    from sings_amd import rasterizer as rz
+    dev = _dev()
+    N, W, H = 30000, 1280, 1040
+    rz.reset_overflow_state(dev)
+    key = (dev.index, N, W, H)
+
+    def frame(sc):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev).requires_grad_(True)
+        ins = dict(means3D=t(sc["means3D"]), opacities=t(sc["opacities"]), shs=t(sc["shs"]), scales=t(sc["scales"]), rotations=t(sc["rotations"]))
+        m2d = torch.zeros_like(ins["means3D"], requires_grad=True)
+        color, _ = GaussianRasterizer(_settings(sc, dev))(means2D=m2d, **ins)
+        color.backward(torch.from_numpy(sc["dL_dimage"]).to(dev))
+        return color.detach().clone(), [ins[k].grad.clone() for k in ("means3D", "opacities", "shs", "scales", "rotations")] + [m2d.grad.clone()]
+
+    s = synthetic_scene(N, W, H, 3, 41)
+    c0, g0 = frame(s)                                            # plain path; learns the hint
+    assert rz._short_ok.get(key) is True
+    c1, g1 = frame(s)                                            # with the hint
+    assert torch.equal(c1, c0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+    s2 = synthetic_scene(N, W, H, 3, 41)
+    s2["means3D"][:, :2] *= 0.02                                 # lists of more than 1024 entries
+    c2, g2 = frame(s2)                                           # under the hint: refused on the device, rendered again without it
+    assert rz._short_ok.get(key) is False
+    rz.reset_overflow_state(dev)
+    c3, g3 = frame(s2)                                           # never hinted
+    assert torch.equal(c2, c3) and all(torch.equal(a, b) for a, b in zip(g2, g3))
+    assert float((c2 - torch.from_numpy(s2["bg"]).to(dev)[:, None, None]).abs().max()) > 0.1
+    rz.reset_overflow_state(dev)
+
+
 def test_views_in_flight_on_two_streams_match_sequential_runs():
     """bench.py renders the views of a step through one engine per view (own workspaces, own row of a shared gradient
     buffer) spread over two HIP streams.  The library keeps no state between calls, so views in flight at the same time
