@@ -62,7 +62,10 @@ __host__ __device__ static inline bool sg_direct_flag(int) { return false; }
 #else
 __host__ __device__ static inline bool sg_direct_flag(int flags) { return (flags & SG_FLAG_SHORT_LISTS) != 0; }     // (device side: && no histogram)
 #endif
-#define SG_TILE_KEY_PITCH 1024      // = SG_WSORT_MAX (sg_sort.h)
+#define SG_TILE_KEY_CAP 1024        // keys a row holds = SG_WSORT_MAX (sg_sort.h)
+#ifndef SG_TILE_KEY_PITCH
+#define SG_TILE_KEY_PITCH 1024      // entries between rows
+#endif
 #ifdef SG_NO_DIRECT      /* A/B builds only (tools/ab_direct.sh) */
 static inline bool sg_direct_keys(int, int, int) { return false; }
 #else

@@ -105,7 +105,8 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
 //    at that rank -- the (Gaussian, tile, rank) records, and the scatter pass that read them back, are gone; a rank beyond the row
 //    is dropped (the scan flags the long list and nothing is composited).
 // `scratch`: >= 256 words of LDS private to this wave.
-// (the key store of direct binning as a non-temporal store: the preprocess 36 -> 48-57 us at cfg3.  Plain stores.)
+// (the key store of direct binning as a non-temporal store: the preprocess 36 -> 48-57 us at cfg3; as an agent-scope write-through
+// store (sc1): 37, and 1.5 % fewer views/s.  Plain stores.)
 #define SG_KEY_STORE(p, v) (*(p) = (v))
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
                                               int gx, uint32_t cap, int32_t *__restrict__ radii,
@@ -204,7 +205,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
                 const uint32_t p = p0 + 64 * u + lane;
                 const uint32_t slot = base + p;
                 if (direct) {
-                    if (p < total && local[u] < SG_TILE_KEY_PITCH) SG_KEY_STORE(&bn.tile_keys[(size_t)tile[u] * SG_TILE_KEY_PITCH + local[u]], ((uint64_t)dep[u] << 32) | gj[u]);
+                    if (p < total && local[u] < SG_TILE_KEY_CAP) SG_KEY_STORE(&bn.tile_keys[(size_t)tile[u] * SG_TILE_KEY_PITCH + local[u]], ((uint64_t)dep[u] << 32) | gj[u]);
                 } else if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
             }
         }
@@ -240,7 +241,7 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             const uint32_t p = 64 * u + lane;
             const uint32_t slot = base + p;
             if (direct) {
-                if (p < total && local0[u] < SG_TILE_KEY_PITCH)
+                if (p < total && local0[u] < SG_TILE_KEY_CAP)
                     SG_KEY_STORE(&bn.tile_keys[(size_t)tile0[u] * SG_TILE_KEY_PITCH + local0[u]], ((uint64_t)dep0[u] << 32) | gj0[u]);
             } else if (p < total && slot < cap) {
                 bn.pair_gid[slot] = gj0[u]; bn.pair_tile[slot] = tile0[u];

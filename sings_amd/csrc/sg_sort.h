@@ -5,7 +5,7 @@
 #include "sg_common.h"
 
 #define SG_WSORT_MAX 1024      // longest list a composite workgroup sorts itself (8 KiB of keys in the staging buffer)
-static_assert(SG_WSORT_MAX == SG_TILE_KEY_PITCH, "a row of SgBin::tile_keys holds what a compositing workgroup sorts");
+static_assert(SG_WSORT_MAX == SG_TILE_KEY_CAP, "a row of SgBin::tile_keys holds what a compositing workgroup sorts");
 #define SG_RANKSORT_MAX 128    // up to here: rank sort (every thread counts the smaller keys); beyond: one-wave bitonic
 
 // One WAVE sorts s[0, n2) (n2 a power of two <= SG_WSORT_MAX, padded with ~0) -- no workgroup barriers.
