@@ -51,13 +51,18 @@ def leg_avatar(a, ctx):
     smpl_scale, transl, dL = t(s["smpl_scale"]), t(s["transl"]), t(s["dL_dimage"])
     eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=16 * N + 65536)
     eng.set_camera(rs)
-    Rmax, tile_mean, tile_max = 0, 0.0, 0
+    Rmax, tile_mean, tile_max, longest = 0, 0.0, 0, 0
     for f in range(0, F, 8):
         eng.set_frame(xyz, None, w, A_all[f], smpl_scale, transl)
         Rf = eng.forward(sh, op, sc, sync_num_rendered=True)
+        tm_, tx_ = _tile_list_stats(eng, W, H)
+        longest = max(longest, tx_)
         if Rf > Rmax:
             Rmax = Rf
-            tile_mean, tile_max = _tile_list_stats(eng, W, H)
+            tile_mean, tile_max = tm_, tx_
+    # the sizing pass knows the longest tile list of the sequence (~1e4): with 1.3x margin it fits a 16384-key row, so the frames are
+    # binned directly (SG_FLAG_LONG_ROWS; checked on the device, a violation surfaces as NUM_RENDERED_LONG_LIST in num_rendered())
+    long_rows = longest * 1.3 <= 16384
     del eng
     torch.cuda.empty_cache()
     # one engine (workspaces) + loss engine per view of the batch, each writing its own row of `grads`; the views are dealt
@@ -85,13 +90,13 @@ def leg_avatar(a, ctx):
         else:
             e = SkinnedFramesEngine(N, J, W, H, sh.shape[1], Kf, dev, capacity_pairs=int(Rmax * 1.3) + 4096, grad_flat=grads[v % rows],
                                     sh_planar=True)
-        e.set_camera(rs)
+        e.set_camera(rs, long_rows=long_rows)
         engs.append(e)
         losses.append(PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2, K=Kf))    # human.loss.l1_w / ssim_w
     eng = SkinnedEngine(N, J, W, H, sh.shape[1], dev, capacity_pairs=int(Rmax * 1.3) + 4096, sh_planar=True) if Kf > 1 else engs[0]
     active = eng.active_floats(0)                                    # N * 10 of the N * 55 floats
     if Kf > 1:
-        eng.set_camera(rs)
+        eng.set_camera(rs, long_rows=long_rows)
     loss1 = PhotoLossEngine(W, H, dev, l1_w=0.8, ssim_w=0.2) if Kf > 1 else losses[0]
     transl_k = transl[None].repeat(Kf, 1).contiguous()                            # (per-frame translations: here all equal)
     shard = FrameSharder(F, world, rank, seed=0)
@@ -159,7 +164,8 @@ def leg_avatar(a, ctx):
     els = timed_repeats(dist, dev, a.steps, lambda i: step(a.warmup + i), min_s=LIGHT_TIMED_S if a.light else None)
     el = _median(els)
     comm = allreduce_probe(fp, batch.acc[:active])
-    assert all(max(e.num_rendered()) <= e.cap if Kf > 1 else e.num_rendered() <= e.cap for e in engs)
+    assert all((0 <= min(e.num_rendered()) and max(e.num_rendered()) <= e.cap) if Kf > 1 else 0 <= e.num_rendered() <= e.cap for e in engs), \
+        "pair capacity / long-rows hint violated"
     grad_hash = None
     if a.grad_hash:
         step(0)
@@ -254,7 +260,7 @@ def avatar_parity(s, eng, rs, A, ins, t):
     N, J, W, H, dev = eng.P, eng.J, eng.W, eng.H, eng.dev
     e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
     posed = (e(N, 3), e(N, 4), e(N, 3))
-    eng.set_camera(rs)
+    eng.set_camera(rs, long_rows=bool(getattr(eng, "_rows", 0)))
     eng.set_frame(xyz, None, w, A, smpl_scale, transl)
     eng._chain = None
     Rv = eng.forward(sh, op, sc, sync_num_rendered=True, posed_out=posed)

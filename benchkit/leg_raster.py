@@ -87,22 +87,23 @@ def leg_raster(a, ctx):
     for v in range(n_batches):
         # the sizing pass knows the longest tile list (135 at cfg3): with 1.5x margin for the other cameras of the batch no
         # list can need the long-list sort kernels (lists <= 1024 are sorted by the compositing workgroups; checked on the device, a
-        # violation surfaces in num_rendered() below)
+        # violation surfaces in num_rendered() below).  Either flag selects direct binning (many tiles: SG_FLAG_SHORT_LISTS, few tiles, e.g.
+        # cfg2's 1 024: SG_FLAG_LONG_ROWS; each is ignored in the other regime)
         if Kf == 1:
             e = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
-            e.set_camera(camera(rank * k_views + v)[3], short_lists=short)
+            e.set_camera(camera(rank * k_views + v)[3], short_lists=short, long_rows=short)
         else:
             from sings_amd.engine import RasterFramesEngine
             e = RasterFramesEngine(N, W, H, shs.shape[1], Kf, dev, capacity_pairs=int(R * 1.1) + 4096, grad_flat=grads[v % rows])
             cams = [camera(rank * k_views + v * Kf + f) for f in range(Kf)]
             e.set_camera(cams[0][3]._replace(viewmatrix=t(np.stack([c_[0] for c_ in cams])), projmatrix=t(np.stack([c_[1] for c_ in cams])),
-                                             campos=t(np.stack([c_[2] for c_ in cams]))), short_lists=short)
+                                             campos=t(np.stack([c_[2] for c_ in cams]))), short_lists=short, long_rows=short)
         engs.append(e)
     if Kf == 1:
         eng = engs[0]
     else:                                                        # the one-view-per-step leg and the parity views: a plain engine
         eng = RasterEngine(N, W, H, shs.shape[1], dev, capacity_pairs=int(R * 1.1) + 4096)
-        eng.set_camera(camera(rank * k_views)[3], short_lists=short)
+        eng.set_camera(camera(rank * k_views)[3], short_lists=short, long_rows=short)
     dL_k = dL if Kf == 1 else dL[None].expand(Kf, -1, -1, -1).contiguous()
     batch = ViewBatch(engs, grads, n_streams, frame_parallel=fp, chunks=a.reduce_chunks)
 

@@ -56,7 +56,8 @@ typedef struct SgRasterSettings {
      * frame rendered with a too small workspace) at nearly the speed of never looking.
      * flags: bit 0 more pairs than the workspace holds, bit 1 a long list under SG_FLAG_SHORT_LISTS (both: nothing was composited),
      * bit 2 (SG_COUNT_FLAG_HALF_ROWS, in this word only) no tile list is longer than 512 entries -- a caller that reads the word
-     * itself after the call may pass SG_FLAG_SHORT_LISTS for the next frame of the scene (the Python wrapper does). */
+     * itself after the call may pass SG_FLAG_SHORT_LISTS for the next frame of the scene (the Python wrapper does); bit 3
+     * (SG_COUNT_FLAG_HALF_LONG_ROWS) none longer than 8192 -- the same for SG_FLAG_LONG_ROWS. */
     unsigned long long *count_signal;
     volatile unsigned long long *count_signal_host;
 } SgRasterSettings;
@@ -73,7 +74,8 @@ typedef struct SgLayout {
         bin_sort_items, bin_rank_items, bin_items,      /* work lists: long-list sort chunks, chunk merges, backward segments */
         bin_ck_start, bin_plan, bin_pair_mask, bin_item_w, bin_item_perm,
         bin_rec_valid,          /* [cap] one byte per gradient record (Gaussian-major pair slot): written by the sparse backward */
-        bin_tile_keys,          /* [T][1024] SG_FLAG_SHORT_LISTS on images of many tiles: the preprocess leaves every pair's key in its tile's row */
+        bin_tile_keys,          /* direct binning: the preprocess leaves every pair's key in its tile's row -- [T][1024] on images of many tiles
+                                 * (SG_FLAG_SHORT_LISTS), [T][16384] on images of few tiles (SG_FLAG_LONG_ROWS) */
         bin_bytes;
     /* image workspace */
     size_t img_final_T, img_n_contrib, img_ckpt, img_bytes;
@@ -105,6 +107,7 @@ const char *sg_last_error(void);
  * Lists, ranges, images and gradients are the same bits either way. */
 #define SG_FLAG_SHORT_LISTS 1
 #define SG_COUNT_FLAG_HALF_ROWS 4u   /* in the count_signal word: see SgRasterSettings */
+#define SG_COUNT_FLAG_HALF_LONG_ROWS 8u   /* ... no tile list longer than 8192 entries: SG_FLAG_LONG_ROWS is safe for a similar frame */
 /* SG_FLAG_WS_CLEAN: the caller vouches that the counters at the head of `binning_ws` (the first sg_layout().bin_ranges
  * bytes) are zero: the workspace was zero-filled there after allocation, or its last use was a forward of this library that
  * returned 0 -- every forward leaves them zeroed (its last kernel clears what the next forward's first kernel counts into).
@@ -132,6 +135,12 @@ const char *sg_last_error(void);
  * canonical-Gaussian gradient of a step is ONE contiguous prefix of the flat buffer (sings_amd.engine: 10 floats per Gaussian on
  * the avatar) and the frame-parallel collective moves 6 MB instead of 33. */
 #define SG_FLAG_SH_PLANAR 32
+/* SG_FLAG_LONG_ROWS: images of FEW tiles (at most 4096 tile counters: the per-workgroup tile histogram regime, an avatar frame): the caller
+ * asserts that no tile's list exceeds 16384 entries -- a row of `bin_tile_keys` there -- and gets direct binning as under
+ * SG_FLAG_SHORT_LISTS (the preprocess writes every pair's key into its tile's row at its final rank; no pair scatter pass).  Lists of more
+ * than 1024 entries are still sorted by the long-list kernels, from their rows.  A longer list: nothing is composited,
+ * SG_NUM_RENDERED_LONG_LIST, as for SG_FLAG_SHORT_LISTS.  Ignored on images of many tiles.  Same bits either way. */
+#define SG_FLAG_LONG_ROWS 64
 #define SG_NUM_RENDERED_LONG_LIST (-2)
 /* Workspace sizing.  capacity_pairs = upper bound on R = sum of tiles touched. */
 int sg_layout(int P, int width, int height, size_t capacity_pairs, SgLayout *out);

@@ -69,11 +69,13 @@ NUM_KERNELS = 8
 ABI_VERSION = 7                      # SG_ABI_VERSION
 FLAG_SHORT_LISTS = 1                 # SG_FLAG_SHORT_LISTS
 COUNT_FLAG_HALF_ROWS = 4             # SG_COUNT_FLAG_HALF_ROWS
+COUNT_FLAG_HALF_LONG_ROWS = 8        # SG_COUNT_FLAG_HALF_LONG_ROWS
 FLAG_WS_CLEAN = 2                    # SG_FLAG_WS_CLEAN
 FLAG_THROUGHPUT = 4                  # SG_FLAG_THROUGHPUT
 FLAG_FORWARD_BINNING = 8             # SG_FLAG_FORWARD_BINNING
 FLAG_FORWARD_COMPOSITE = 16          # SG_FLAG_FORWARD_COMPOSITE
 FLAG_SH_PLANAR = 32                  # SG_FLAG_SH_PLANAR
+FLAG_LONG_ROWS = 64                  # SG_FLAG_LONG_ROWS
 NUM_RENDERED_LONG_LIST = -2          # SG_NUM_RENDERED_LONG_LIST
 
 

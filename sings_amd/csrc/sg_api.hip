@@ -67,7 +67,7 @@ extern "C" int sg_layout(int P, int width, int height, size_t cap, SgLayout *L)
     L->bin_item_w = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);       // backward work-item weights
     L->bin_item_perm = o; o = sg_align(o + (size_t)sg_items_cap(T, cap) * 4);
     L->bin_rec_valid = o; o = sg_align(o + cap + 16);                                // one byte per gradient record (few-tile frames)
-    L->bin_tile_keys = o; o = sg_align(o + (sg_lds_hist((int)gx, (int)gy) ? 0 : T * SG_TILE_KEY_PITCH * 8));     // direct binning (sg_direct_keys)
+    L->bin_tile_keys = o; o = sg_align(o + T * (sg_lds_hist((int)gx, (int)gy) ? (size_t)SG_TILE_ROW_LONG : (size_t)SG_TILE_KEY_PITCH) * 8);     // direct binning (sg_key_pitch)
     L->bin_bytes = o;
     o = 0;
     L->img_final_T = o; o = sg_align(o + hw * 4);

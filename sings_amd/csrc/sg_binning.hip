@@ -41,8 +41,10 @@ __device__ __forceinline__ void sg_scan_derive(uint32_t v, uint32_t q[SG_SCAN_NQ
 {
     const uint32_t seg = sg_nseg(v);
     // q3: partition work items (one per list the compositing workgroup does not sort itself); q4: group slots reserved for it
-    // q5: lists of more than half a row of SgBin::tile_keys -- none of them: the published count says so (SG_COUNT_FLAG_HALF_ROWS)
-    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = v > SG_WSORT_MAX ? 1u : 0u; q[4] = sg_group_slots(v); q[5] = v > SG_WSORT_MAX / 2 ? 1u : 0u;
+    // q5: lists of more than half a row of SgBin::tile_keys (512; bits 20+: 8192, half a long row; T < 2^20) -- none of them: the
+    // published count says so (SG_COUNT_FLAG_HALF_ROWS, SG_COUNT_FLAG_HALF_LONG_ROWS)
+    q[0] = v; q[1] = seg ? seg : 1u; q[2] = seg; q[3] = v > SG_WSORT_MAX ? 1u : 0u; q[4] = sg_group_slots(v);
+    q[5] = (v > SG_WSORT_MAX / 2 ? 1u : 0u) | (v > SG_TILE_ROW_LONG / 2 ? 1u << 20 : 0u);
 }
 
 // Early pair count: one 64-bit system-scope store to a mapped, coherent host word (valid bit | flags << 32 | R) -- visible to a
@@ -57,7 +59,8 @@ __global__ void __launch_bounds__(SG_SCAN_BS)
 sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_count,
                     uint2 *__restrict__ ranges, uint32_t *__restrict__ cursor, uint32_t *__restrict__ header,
                     uint32_t cap, uint32_t sort_cap, uint32_t rank_cap, uint4 *__restrict__ plan,
-                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal, size_t bin_stride)
+                    uint32_t *__restrict__ ck_start, uint32_t items_cap, int short_lists, unsigned long long *signal, size_t bin_stride,
+                    int direct)
 {
     constexpr int NQ = SG_SCAN_NQ;
     __shared__ uint32_t wsum[NQ][SG_SCAN_BS / 64];
@@ -147,9 +150,10 @@ sg_tile_scan_kernel(int T, int gx, int tpt, const uint32_t *__restrict__ tile_co
     }
     if (blockIdx.x == gridDim.x - 1 && tid == 0) {
         header[0] = carry[0];
-        const uint32_t hflags = (carry[0] > cap ? 1u : 0u) | (short_lists && carry[3] ? 2u : 0u);
+        const uint32_t hflags = (carry[0] > cap ? 1u : 0u) | ((short_lists && carry[3]) || (direct && header[8]) ? 2u : 0u);
+        header[8] = 0u;
         header[1] = hflags;
-        sg_publish_count(signal, carry[0], hflags | (carry[5] ? 0u : SG_COUNT_FLAG_HALF_ROWS));
+        sg_publish_count(signal, carry[0], hflags | ((carry[5] & 0xfffffu) ? 0u : SG_COUNT_FLAG_HALF_ROWS) | ((carry[5] >> 20) ? 0u : SG_COUNT_FLAG_HALF_LONG_ROWS));
         header[3] = (uint32_t)T;
         header[4] = carry[3] < sort_cap ? carry[3] : sort_cap;
         header[5] = carry[1] < items_cap ? carry[1] : items_cap;
@@ -308,9 +312,11 @@ sg_scan_scatter_kernel(int T, int gx, const uint32_t *__restrict__ tile_count, u
         header[0] = tot[0];
         // bit 0: more pairs than the workspace holds; bit 1: a list needs the long-list kernels the caller told us to skip.
         // Either way the lists are incomplete / unsorted and the composite kernels touch nothing.
-        const uint32_t hflags = (tot[0] > cap ? 1u : 0u) | (short_lists && tot[3] ? 2u : 0u);
+        // (header[8]: a lane of the direct preprocess met a rank beyond its tile's row)
+        const uint32_t hflags = (tot[0] > cap ? 1u : 0u) | ((short_lists && tot[3]) || (direct && header[8]) ? 2u : 0u);
+        header[8] = 0u;
         header[1] = hflags;
-        sg_publish_count(signal, tot[0], hflags | (tot[5] ? 0u : SG_COUNT_FLAG_HALF_ROWS));     // the host may be waiting for exactly this (SgRasterSettings.count_signal)
+        sg_publish_count(signal, tot[0], hflags | ((tot[5] & 0xfffffu) ? 0u : SG_COUNT_FLAG_HALF_ROWS) | ((tot[5] >> 20) ? 0u : SG_COUNT_FLAG_HALF_LONG_ROWS));     // the host may be waiting for exactly this (SgRasterSettings.count_signal)
         header[3] = (uint32_t)T;
         header[4] = tot[3] < sort_cap ? tot[3] : sort_cap;
         header[5] = tot[1] < items_cap ? tot[1] : items_cap;
@@ -584,13 +590,14 @@ __global__ void __launch_bounds__(SG_PT_THREADS)
 sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
                          uint64_t *__restrict__ pair_keys, uint64_t *__restrict__ scratch, uint2 *__restrict__ groups,
                          uint32_t group_cap, uint32_t *__restrict__ point_list, uint64_t *__restrict__ point_keys,
-                         uint32_t resident_max, size_t bin_stride)
+                         uint32_t resident_max, size_t bin_stride, const uint64_t *__restrict__ row_keys, uint32_t key_pitch)
 {
     __shared__ SgPartLds L;
     {   // frame blockIdx.y
         const size_t off = (size_t)blockIdx.y * bin_stride;
         header = sg_at(header, off); part_items = sg_at(part_items, off); pair_keys = sg_at(pair_keys, off); scratch = sg_at(scratch, off);
         groups = sg_at(groups, off); point_list = sg_at(point_list, off); point_keys = sg_at(point_keys, off);
+        row_keys = sg_at(row_keys, off);
     }
     extern __shared__ __attribute__((aligned(16))) uint64_t sKeys[];                               // resident_max keys (>= 1024: the counting fallback's slab)
     const int tid = threadIdx.x;
@@ -609,12 +616,14 @@ sg_tile_partition_kernel(uint32_t *header, const uint4 *__restrict__ part_items,
         __syncthreads();
         // Lists that fit the workgroup's LDS (every list of an avatar frame): sorted right here -- partition into LDS, then every
         // key counts the smaller keys of ITS bucket (ten on average): no second kernel, no trip through memory.
-        if (n <= resident_max && sg_sort_resident(pair_keys + r.x, n, r.x, tile, L, sKeys, point_list, point_keys, tid)) {
+        // (direct binning: the list's unsorted keys are row `tile` of tile_keys)
+        const uint64_t *in0 = key_pitch ? row_keys + (size_t)tile * key_pitch : pair_keys + r.x;
+        if (n <= resident_max && sg_sort_resident(in0, n, r.x, tile, L, sKeys, point_list, point_keys, tid)) {
             for (uint32_t g = g0 + tid; g < gend; g += SG_PT_THREADS) groups[g] = make_uint2(0u, 0u);
             continue;
         }
         // level 0: pair_keys -> scratch
-        sg_partition_pass(pair_keys + r.x, scratch + r.x, n, r.x, 0u, tile, L, groups, gend, tid);
+        sg_partition_pass(in0, scratch + r.x, n, r.x, 0u, tile, L, groups, gend, tid);
         const uint32_t nb0 = L.nbig;
         if (nb0) {
             // level 1 for every bucket of more than 1024 keys: scratch -> pair_keys over the bucket's own key range.  (The level-1
@@ -721,7 +730,8 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
     // has; with K x 211 workgroups queued a 10-us scan kernel (one workgroup row per frame) + a plain scatter are faster (cfg3, 8
     // cameras: 10.4 + 78.0 against 110.9 us; few-tile frames: 75.6 against 77.0, left fused)
     // DIRECT binning (sg_direct_keys): nothing to scatter -- the fused kernel's scan part alone, a few workgroups per frame
-    const int direct = sg_direct_keys(c.gx, c.gy, c.flags) ? 1 : 0;
+    const uint32_t key_pitch = sg_key_pitch(c.gx, c.gy, c.flags);
+    const int direct = key_pitch ? 1 : 0;
     bool fused = T <= SG_SS_MAX_TILES && (K == 1 || sg_lds_hist(c.gx, c.gy) || direct);
     if (fused && (size_t)T * 4 + 1024 > 64 * 1024)
         fused = sg_dyn_lds_limit(0, (const void *)sg_scan_scatter_kernel, SG_SS_MAX_TILES * 4);
@@ -741,7 +751,7 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
         const int sgrid = (T + 1024 * tpt - 1) / (1024 * tpt) > 0 ? (T + 1024 * tpt - 1) / (1024 * tpt) : 1;
         hipLaunchKernelGGL((sg_tile_scan_kernel<1024>), dim3(sgrid, K), dim3(1024), 0, st, T, c.gx, tpt, b.tile_count, b.ranges, b.cursor,
                            b.header, cap32, sg_sort_items_cap(T, cap), sg_rank_items_cap(cap), b.plan, b.ck_start,
-                           sg_items_cap(T, cap), short_lists, c.count_signal, bt.bin);
+                           sg_items_cap(T, cap), short_lists, c.count_signal, bt.bin, direct);
         sg_prof_end(SG_K_TILE_SCAN, st);
         sg_prof_begin(SG_K_TILE_SCATTER, st);
         size_t want = (((direct || cap < (size_t)T) ? (size_t)T : cap) + 255) / 256;
@@ -764,7 +774,7 @@ void sg_launch_binning(const SgCam &c, const SgBatch &bt, int P, const int32_t *
     if (!sg_dyn_lds_limit(1, (const void *)sg_tile_partition_kernel, (int)dyn)) { resident = SG_PT_NB; dyn = (size_t)SG_PT_NB * 8; }
     hipLaunchKernelGGL(sg_tile_partition_kernel, dim3(pgrid, K), dim3(SG_PT_THREADS), dyn, st, b.header, b.sort_items,
                        b.pair_keys, b.point_keys, b.rank_items, sg_rank_items_cap(cap), b.point_list, pk,
-                       resident > SG_PT_NB ? resident : 0u, bt.bin);
+                       resident > SG_PT_NB ? resident : 0u, bt.bin, b.tile_keys, key_pitch);
     const uint32_t ggrid = sg_rank_items_cap(cap) < 256 ? sg_rank_items_cap(cap) : 256;       // (usually nothing to do: header[7])
     hipLaunchKernelGGL(sg_group_sort_kernel, dim3(ggrid, K), dim3(256), 0, st, b.header, b.rank_items, b.pair_keys, b.point_keys,
                        b.point_list, pk, bt.bin);

@@ -57,20 +57,21 @@ static inline bool sg_lds_hist(int gx, int gy) { return sg_ctr_count((uint32_t)g
 // DIRECT binning: the caller vouches for lists of <= SG_WSORT_MAX entries (SG_FLAG_SHORT_LISTS, checked on the device) and the image has
 // too many tiles for the per-workgroup histogram -- then a pair's key goes straight into its tile's row of SgBin::tile_keys at the rank
 // its counting atomic returned: no pair records, no scatter pass (round 6; sg_project.h::sg_store_proj, sg_binning.hip)
-#ifdef SG_NO_DIRECT
-__host__ __device__ static inline bool sg_direct_flag(int) { return false; }
-#else
-__host__ __device__ static inline bool sg_direct_flag(int flags) { return (flags & SG_FLAG_SHORT_LISTS) != 0; }     // (device side: && no histogram)
-#endif
-#define SG_TILE_KEY_CAP 1024        // keys a row holds = SG_WSORT_MAX (sg_sort.h)
-#ifndef SG_TILE_KEY_PITCH
-#define SG_TILE_KEY_PITCH 1024      // entries between rows
-#endif
+#define SG_TILE_KEY_CAP 1024        // many tiles: keys a row holds = SG_WSORT_MAX (sg_sort.h) = entries between rows
+#define SG_TILE_KEY_PITCH 1024
+#define SG_TILE_ROW_LONG 16384      // few tiles (SG_FLAG_LONG_ROWS): keys a row holds = entries between rows
+// entries between the rows of SgBin::tile_keys for this frame; 0: plain binning (pair records + scatter pass)
+__host__ __device__ inline uint32_t sg_key_pitch_of(bool hist, int flags)
+{
 #ifdef SG_NO_DIRECT      /* A/B builds only (tools/ab_direct.sh) */
-static inline bool sg_direct_keys(int, int, int) { return false; }
+    (void)hist; (void)flags;
+    return 0u;
 #else
-static inline bool sg_direct_keys(int gx, int gy, int flags) { return (flags & SG_FLAG_SHORT_LISTS) && !sg_lds_hist(gx, gy); }
+    if (hist) return (flags & SG_FLAG_LONG_ROWS) ? (uint32_t)SG_TILE_ROW_LONG : 0u;
+    return (flags & SG_FLAG_SHORT_LISTS) ? (uint32_t)SG_TILE_KEY_PITCH : 0u;
 #endif
+}
+static inline uint32_t sg_key_pitch(int gx, int gy, int flags) { return sg_key_pitch_of(sg_lds_hist(gx, gy), flags); }
 static inline bool sg_split_long(int gx, int gy, int flags) { return sg_lds_hist(gx, gy) && !(flags & SG_FLAG_THROUGHPUT); }
 static inline uint32_t sg_mask_plane(size_t cap) { const size_t v = (cap + 256) & ~(size_t)255; return v > 0xffffffffull ? 0xffffffffu : (uint32_t)v; }
 

@@ -59,7 +59,7 @@ sg_preprocess_fwd_kernel(SgCam c, SgBatch bt, int P, const float *__restrict__ m
         opac = opacities[idx];
     }
     sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, scratch_all[wave], hist_tiles ? sg_hist_lds : nullptr, hist_tiles,
-                  sg_direct_flag(c.flags) && !hist_tiles);
+                  sg_key_pitch_of(hist_tiles != 0, c.flags));
 }
 
 void sg_launch_preprocess_fwd(const SgCam &c, const SgBatch &bt, int P, const float *means3D, const float *shs,

@@ -103,15 +103,17 @@ __device__ __forceinline__ void sg_project_fwd(const SgCam &c, const float p[3],
 //    touched tile.
 //  * DIRECT (sg_direct_keys: short lists vouched for, no histogram): the pair's key goes straight into row `tile` of bn.tile_keys
 //    at that rank -- the (Gaussian, tile, rank) records, and the scatter pass that read them back, are gone; a rank beyond the row
-//    is dropped (the scan flags the long list and nothing is composited).
+//    is dropped (header[8] tells the scan, nothing is composited).  With `hist` (SG_FLAG_LONG_ROWS, rows of 16384) the key is stored
+//    once the rank is final, and the lane clears the pair's rec_valid byte as the scatter pass used to.
 // `scratch`: >= 256 words of LDS private to this wave.
 // (the key store of direct binning as a non-temporal store: the preprocess 36 -> 48-57 us at cfg3; as an agent-scope write-through
 // store (sc1): 37, and 1.5 % fewer views/s.  Plain stores.)
 #define SG_KEY_STORE(p, v) (*(p) = (v))
 __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &o, float opac, SgGeom g, SgBin bn,
                                               int gx, uint32_t cap, int32_t *__restrict__ radii,
-                                              uint32_t *__restrict__ scratch, uint32_t *__restrict__ hist, int T, bool direct)
+                                              uint32_t *__restrict__ scratch, uint32_t *__restrict__ hist, int T, uint32_t key_pitch)
 {
+    const bool direct = key_pitch != 0u;                  // (kernel-uniform) rows of key_pitch keys; with `hist`: SG_FLAG_LONG_ROWS
     uint32_t *sIncl = scratch, *sMin = scratch + 64, *sWid = scratch + 128, *sDep = scratch + 192;
     const int lane = threadIdx.x & 63;
     uint32_t incl = o.tt;
@@ -204,8 +206,11 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             for (int u = 0; u < 4; u++) {
                 const uint32_t p = p0 + 64 * u + lane;
                 const uint32_t slot = base + p;
-                if (direct) {
-                    if (p < total && local[u] < SG_TILE_KEY_CAP) SG_KEY_STORE(&bn.tile_keys[(size_t)tile[u] * SG_TILE_KEY_PITCH + local[u]], ((uint64_t)dep[u] << 32) | gj[u]);
+                if (direct && !hist) {
+                    if (p < total) {
+                        if (local[u] < key_pitch) SG_KEY_STORE(&bn.tile_keys[(size_t)tile[u] * key_pitch + local[u]], ((uint64_t)dep[u] << 32) | gj[u]);
+                        else bn.header[8] = 1u;                 // a list longer than its row: sticky until the scan has seen it
+                    }
                 } else if (p < total && slot < cap) { bn.pair_gid[slot] = gj[u]; bn.pair_tile[slot] = tile[u]; bn.pair_local[slot] = local[u]; }
             }
         }
@@ -232,7 +237,16 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
         __syncthreads();
         for (uint32_t p = 256 + lane; p < total; p += 64) {      // later rounds: a lane re-reads exactly the slots it wrote above
             const uint32_t slot = base + p;
-            if (slot < cap) bn.pair_local[slot] += hist[sg_ctr_of_tile(bn.pair_tile[slot], (uint32_t)gx)];
+            if (slot >= cap) continue;
+            if (direct) {
+                // (its records were the lane's notes: the key goes to the tile's row at the final rank; the depth of a Gaussian of this
+                // workgroup was stored in front of the barriers above)
+                const uint32_t gid = bn.pair_gid[slot], tl = bn.pair_tile[slot];
+                const uint32_t rank = bn.pair_local[slot] + hist[sg_ctr_of_tile(tl, (uint32_t)gx)];
+                if (rank < key_pitch) SG_KEY_STORE(&bn.tile_keys[(size_t)tl * key_pitch + rank], ((uint64_t)__float_as_uint(g.depth[gid]) << 32) | gid);
+                else bn.header[8] = 1u;
+                bn.rec_valid[slot] = 0;                          // (what the scatter pass did, one lane per pair: see SgBin::rec_valid)
+            } else bn.pair_local[slot] += hist[sg_ctr_of_tile(bn.pair_tile[slot], (uint32_t)gx)];
         }
     }
     if (expand) {
@@ -241,8 +255,12 @@ __device__ __forceinline__ void sg_store_proj(bool live, int idx, const SgProj &
             const uint32_t p = 64 * u + lane;
             const uint32_t slot = base + p;
             if (direct) {
-                if (p < total && local0[u] < SG_TILE_KEY_CAP)
-                    SG_KEY_STORE(&bn.tile_keys[(size_t)tile0[u] * SG_TILE_KEY_PITCH + local0[u]], ((uint64_t)dep0[u] << 32) | gj0[u]);
+                if (p < total) {
+                    const uint32_t rank = local0[u] + (hist ? hist[ctr0[u]] : 0u);
+                    if (rank < key_pitch) SG_KEY_STORE(&bn.tile_keys[(size_t)tile0[u] * key_pitch + rank], ((uint64_t)dep0[u] << 32) | gj0[u]);
+                    else bn.header[8] = 1u;
+                    if (hist && slot < cap) bn.rec_valid[slot] = 0;
+                }
             } else if (p < total && slot < cap) {
                 bn.pair_gid[slot] = gj0[u]; bn.pair_tile[slot] = tile0[u];
                 bn.pair_local[slot] = local0[u] + (hist ? hist[ctr0[u]] : 0u);

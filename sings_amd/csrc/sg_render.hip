@@ -394,10 +394,11 @@ void sg_launch_render_fwd(const SgCam &c, const SgBatch &bt, SgGeom g, SgBin b, 
     const unsigned K = (unsigned)bt.K;
     const bool few = sg_lds_hist(c.gx, c.gy);
     uint64_t *pk = write_keys ? b.point_keys : (uint64_t *)nullptr;
-    const bool direct = sg_direct_keys(c.gx, c.gy, c.flags);       // the tile's unsorted keys: its row of tile_keys
+    const uint32_t key_pitch = sg_key_pitch(c.gx, c.gy, c.flags);   // direct binning: the tile's unsorted keys are its row of tile_keys
+    const bool direct = key_pitch != 0u;
 #define SG_RF_ARGS(NB) c.W, c.H, c.gx, T, NB, b.ranges, direct ? b.tile_keys : b.pair_keys, b.point_list, pk, g.recA, g.recB, g.recC, c.bg, out_color,     \
                        im.final_T, im.n_contrib, b.ck_start, im.ckpt, sg_ckpt_cap(cap), b.header, b.pair_mask, b.tile_count,       \
-                       (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap), direct ? (uint32_t)SG_TILE_KEY_PITCH : 0u
+                       (const uint4 *)b.sort_items, sg_mask_plane(cap), b.plan, b.item_w, sg_items_cap((size_t)T, cap), key_pitch
     sg_prof_begin(SG_K_RENDER_FWD, st);
     if (K > 1 || (few && (c.flags & SG_FLAG_THROUGHPUT))) {
         // K frames per launch, or a few-tile frame that shares the chip with other views: the plain loop (see the kernel)

@@ -298,7 +298,7 @@ sg_skin_fwd_kernel(SgCam c, SgBatch bt, int P, SgSkin k, const float *__restrict
         __syncthreads();
         hist = (uint32_t *)&sW[0][0];
     }
-    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, (uint32_t *)sT[wave], hist, hist_tiles, sg_direct_flag(c.flags) && !hist_tiles);
+    sg_store_proj(live, idx, o, opac, g, bn, c.gx, cap, radii, (uint32_t *)sT[wave], hist, hist_tiles, sg_key_pitch_of(hist_tiles != 0, c.flags));
 }
 
 // Backward: LBS^T.  Per Gaussian: dL/dxyz_canon, dL/dR_canon, dL/dscales, dL/dopacity, dL/dsh;

@@ -56,13 +56,15 @@ class RasterEngine:
         self._chain = None                                    # inside ViewBatch.run: callable -> (accumulate, wait-for event, done event)
         self.throughput = False                               # SG_FLAG_THROUGHPUT: set by a ViewBatch that keeps several views in flight
 
-    def set_camera(self, raster_settings, short_lists=False):
+    def set_camera(self, raster_settings, short_lists=False, long_rows=False):
         """``short_lists``: the caller knows (from a sizing pass over this scene) that no tile list exceeds 1024 entries (what the
-        compositing workgroups sort themselves); the two long-list sort launches are then skipped (SG_FLAG_SHORT_LISTS).  A longer list makes ``num_rendered()`` return
-        ``_lib.NUM_RENDERED_LONG_LIST`` (the frame rendered the background): call set_camera again without the hint."""
+        compositing workgroups sort themselves); the two long-list sort launches are then skipped and, on images of many tiles, the
+        frame is binned directly (SG_FLAG_SHORT_LISTS).  ``long_rows``: images of few tiles -- no list exceeds 16384 entries: direct
+        binning there (SG_FLAG_LONG_ROWS).  A longer list makes ``num_rendered()`` return ``_lib.NUM_RENDERED_LONG_LIST`` (the frame
+        rendered the background): call set_camera again without the hint."""
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
-        self._hint = _lib.FLAG_SHORT_LISTS if short_lists else 0
+        self._hint = (_lib.FLAG_SHORT_LISTS if short_lists else 0) | (_lib.FLAG_LONG_ROWS if long_rows else 0)
 
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
@@ -189,9 +191,12 @@ class SkinnedEngine:
         self._chain = None
         self.throughput = False
 
-    def set_camera(self, raster_settings):
+    def set_camera(self, raster_settings, long_rows=False):
+        """``long_rows``: the caller knows (from a sizing pass) that no tile list of this avatar exceeds 16384 entries: direct binning
+        (SG_FLAG_LONG_ROWS, include/sings_hip.h; a longer list: ``num_rendered()`` = NUM_RENDERED_LONG_LIST, background frame)."""
         self._keep = []
         self._s = _settings_struct(raster_settings, self.dev, self.M, self._keep)
+        self._rows = _lib.FLAG_LONG_ROWS if long_rows else 0
 
     active_floats = _active_floats
 
@@ -208,7 +213,7 @@ class SkinnedEngine:
         (what SinGS.forward returns: sings_hybrid.py:400-419); the render itself never reads them back."""
         nr = C.c_int64(-1)
         self._s.flags = ((_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0) |
-                         (_lib.FLAG_SH_PLANAR if self.sh_planar else 0))
+                         (_lib.FLAG_SH_PLANAR if self.sh_planar else 0) | getattr(self, "_rows", 0))
         self._clean = False
         pxyz, pq, psc = posed_out if posed_out is not None else (None, None, None)
         _lib.check(self.lib.sg_skinned_forward(
@@ -421,9 +426,10 @@ class _FramesBase:
     def _stream(self):
         return C.c_void_p(torch.cuda.current_stream(self.dev).cuda_stream)
 
-    def set_camera(self, raster_settings):
+    def set_camera(self, raster_settings, long_rows=False):
         """One camera for all K frames ([4,4] matrices) or one per frame (``viewmatrix`` / ``projmatrix`` [K,4,4], ``campos``
-        [K,3]: the other fields are shared)."""
+        [K,3]: the other fields are shared).  ``long_rows``: SG_FLAG_LONG_ROWS (see SkinnedEngine.set_camera)."""
+        self._rows = _lib.FLAG_LONG_ROWS if long_rows else 0
         self._keep = []
         vm = raster_settings.viewmatrix
         per_frame = vm.dim() == 3
@@ -440,7 +446,7 @@ class _FramesBase:
 
     def _flags(self):
         f = ((_lib.FLAG_WS_CLEAN if self._clean else 0) | (_lib.FLAG_THROUGHPUT if self.throughput else 0) |
-             (_lib.FLAG_SH_PLANAR if getattr(self, "sh_planar", False) else 0))
+             (_lib.FLAG_SH_PLANAR if getattr(self, "sh_planar", False) else 0) | getattr(self, "_rows", 0))
         return f
 
     active_floats = _active_floats
@@ -594,8 +600,8 @@ class RasterFramesEngine(_FramesBase):
             self.d_sh = carve(self.P * 3 * self.M, self.P, self.M, 3)
         self._hint = 0
 
-    def set_camera(self, raster_settings, short_lists=False):
-        super().set_camera(raster_settings)
+    def set_camera(self, raster_settings, short_lists=False, long_rows=False):
+        super().set_camera(raster_settings, long_rows=long_rows)
         self._hint = _lib.FLAG_SHORT_LISTS if short_lists else 0
         self._fb = _frame_batch(self.K, self._cam_stride, 0)
 

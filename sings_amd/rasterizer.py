@@ -63,7 +63,21 @@ _HEADROOM = 2.0
 # flag -- no long-list sort launches and, on images of many tiles, direct binning (no scatter pass: include/sings_hip.h).  A frame
 # that does meet a list of more than 1024 entries under the flag reports NUM_RENDERED_LONG_LIST and is rendered again without it
 # before the call returns: the drop-in guarantee (never a wrong frame) stands.
+# Images of few tiles (an avatar frame): the same with SG_COUNT_FLAG_HALF_LONG_ROWS (no list over 8192) and SG_FLAG_LONG_ROWS (rows of
+# 16384 keys); the fused LBS ops (sings_amd/skinned.py) pass a learned hint in "deferred" mode / under graph capture too, where a
+# violated hint is what a capacity overflow is there: a background frame that check_deferred_overflow() reports.
 _short_ok = {}                         # (device index, P, W, H) -> the last frame's lists were all <= 512 entries
+_rows_ok = {}                          # (device index, P, W, H) -> ... all <= 8192 entries
+
+
+def _learn_hints(s, key):
+    """After a "sync" forward: read the flags of its count word (if it arrived) into the two hint tables."""
+    if not s.count_signal_host:
+        return
+    word = C.c_uint64.from_address(s.count_signal_host).value
+    if word >> 63:                                                   # (not after a timed-out wait: that read the header instead)
+        _short_ok[key] = bool((word >> 32) & _lib.COUNT_FLAG_HALF_ROWS)
+        _rows_ok[key] = bool((word >> 32) & _lib.COUNT_FLAG_HALF_LONG_ROWS)
 _ring = {}                             # device index -> [pinned int32[_RING, 2], next slot]
 _RING = 16
 _signal = {}                           # device index -> [host address, device address, next slot] of the early-count words
@@ -224,8 +238,9 @@ def _forward_done_sync(dev, R, sig):
 
 def reset_overflow_state(device=None):
     """Forget capacities, checked signatures and pending results (tests; after a change of scene scale)."""
-    for k in [k for k in _short_ok if device is None or k[0] == torch.device(device).index]:
-        del _short_ok[k]
+    for tbl in (_short_ok, _rows_ok):
+        for k in [k for k in tbl if device is None or k[0] == torch.device(device).index]:
+            del tbl[k]
     for d in (_capacity_hint, _seen, _pending, _accum):
         if device is None:
             d.clear()
@@ -259,8 +274,13 @@ def check_deferred_overflow(device=None):
     if R == 0 and flag == 0:
         return None
     _grow(dev.index, R)
+    if flag & 2:                                       # a learned list-length hint was violated: forget the hints of this device
+        for tbl in (_short_ok, _rows_ok):
+            for k in [k for k in tbl if k[0] == dev.index]:
+                del tbl[k]
     if flag:
-        raise RuntimeError(f"sings_amd: a deferred forward produced up to {R} (tile, Gaussian) pairs, more than its capacity: "
+        raise RuntimeError(f"sings_amd: a deferred forward produced up to {R} (tile, Gaussian) pairs, more than its capacity"
+                           f"{' (or met a tile list longer than the row its learned hint promised: the hints are dropped)' if flag & 2 else ''}: "
                            f"it rendered the background and no gradients; the capacity is now {_capacity_hint[dev.index]}")
     return R
 
@@ -364,6 +384,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad[:8])
         hint_key = (dev.index,) + sig
         hint = sync and not rs.debug and _short_ok.get(hint_key, False)
+        rows = sync and not rs.debug and _rows_ok.get(hint_key, False)       # (images of few tiles; the other flag is ignored there)
         with torch.cuda.device(dev):
             if sync and not rs.debug:
                 _arm_early_count(s, dev)
@@ -386,24 +407,22 @@ class _RasterizeGaussians(torch.autograd.Function):
                     bufs = _backward_buffers(dev, P, M, L.bwd_bytes, sh is not None, colors_precomp is not None, scales is not None,
                                              cov3Ds_precomp is not None)
                 nr = C.c_int64(0)
-                s.flags = _lib.FLAG_SHORT_LISTS if hint else 0
+                s.flags = (_lib.FLAG_SHORT_LISTS if hint else 0) | (_lib.FLAG_LONG_ROWS if rows else 0)
                 _lib.check(lib.sg_rasterize_forward(
                     C.byref(s), P, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
                     _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(geom), _ptr(binning), cap, _ptr(img),
                     _ptr(color), _ptr(radii), int(bool(write_point_keys)), C.byref(nr) if sync else None, stream), "forward")
                 R = int(nr.value) if sync else None
-                if hint and R == _lib.NUM_RENDERED_LONG_LIST:       # the scene changed under the hint: this frame again, without it
+                if (hint or rows) and R == _lib.NUM_RENDERED_LONG_LIST:       # the scene changed under the hint: this frame again, without it
                     _short_ok[hint_key] = hint = False
+                    _rows_ok[hint_key] = rows = False
                     continue
                 if not sync or R <= cap:
                     break
                 cap = int(R * _HEADROOM) + 1024     # workspace too small: grow and re-run
             if sync:
                 _forward_done_sync(dev, R, sig)
-                if s.count_signal_host:
-                    word = C.c_uint64.from_address(s.count_signal_host).value
-                    if word >> 63:                                   # (not after a timed-out wait: that read the header instead)
-                        _short_ok[hint_key] = bool((word >> 32) & _lib.COUNT_FLAG_HALF_ROWS)
+                _learn_hints(s, hint_key)
             else:
                 _after_forward(dev, binning, cap)
         ctx.raster_settings = rs

@@ -69,11 +69,14 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
         e = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
         pxyz, pq, psc = (e(P, 3), e(P, 4), e(P, 3)) if return_posed else (None, None, None)
         cap, sync, sig = _rz._forward_plan(dev, P, W, H)     # see rasterizer.set_overflow_check
+        hint_key = (dev.index,) + sig
+        rows = not rs.debug and _rz._rows_ok.get(hint_key, False)    # learned by a "sync" forward of this shape (rasterizer.py)
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             if sync and not rs.debug:
                 _rz._arm_early_count(s, dev)
             while True:
+                s.flags = _lib.FLAG_LONG_ROWS if rows else 0
                 L = _lib.layout(P, W, H, cap)
                 geom = torch.empty(L.geom_bytes, dtype=torch.uint8, device=dev)
                 binning = torch.empty(L.bin_bytes, dtype=torch.uint8, device=dev)
@@ -84,11 +87,15 @@ class _RasterizeSkinnedGaussians(torch.autograd.Function):
                                                   _ptr(pxyz), _ptr(pq), _ptr(psc), C.byref(nr) if sync else None, stream),
                            "skinned forward")
                 R = int(nr.value) if sync else None
+                if sync and rows and R == _lib.NUM_RENDERED_LONG_LIST:       # a list outgrew its row: this frame again, without the hint
+                    _rz._rows_ok[hint_key] = rows = False
+                    continue
                 if not sync or R <= cap:
                     break
                 cap = int(R * _rz._HEADROOM) + 1024
             if sync:
                 _rz._forward_done_sync(dev, R, sig)
+                _rz._learn_hints(s, hint_key)
             else:
                 _rz._after_forward(dev, binning, cap)
         ctx.rs, ctx.cap, ctx.M, ctx.num_rendered = rs, cap, M, R
@@ -220,9 +227,12 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
         # "async" does so for the first call of a shape only and afterwards copies the K headers' (worst R, OR of the flags) to the
         # pinned ring without waiting, "deferred" / a graph capture folds them into the device-side accumulator
         cap, sync, sig = _rz._forward_plan(dev, P, W, H)
+        hint_key = (dev.index,) + sig
+        rows = not rs.debug and _rz._rows_ok.get(hint_key, False)    # learned by a "sync" single-frame forward of this shape
         with torch.cuda.device(dev):
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             while True:
+                s.flags = _lib.FLAG_THROUGHPUT | (_lib.FLAG_LONG_ROWS if rows else 0)
                 L = _lib.SgLayout(); sizes = [C.c_size_t() for _ in range(4)]
                 _lib.check(lib.sg_frames_layout(P, W, H, cap, K, C.byref(L), *[C.byref(x) for x in sizes]), "sg_frames_layout")
                 geom = torch.empty(sizes[0].value, dtype=torch.uint8, device=dev)
@@ -234,6 +244,9 @@ class _RasterizeSkinnedFrames(torch.autograd.Function):
                                                          None, nr if sync else None, stream), "skinned forward (frames)")
                 if not sync:
                     break
+                if rows and min(int(v) for v in nr) == _lib.NUM_RENDERED_LONG_LIST:
+                    _rz._rows_ok[hint_key] = rows = False
+                    continue
                 R = max(int(v) for v in nr)
                 if R <= cap:
                     break

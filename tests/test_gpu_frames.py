@@ -96,6 +96,48 @@ def test_skinned_frames_equal_single_frame_calls_bit_for_bit(K, per_frame_camera
         assert float((per_frame[0][0] - per_frame[-1][0]).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("K", [1, 4])
+def test_direct_binning_of_few_tile_frames_leaves_the_bits_of_the_scatter_path(K):
+    """SG_FLAG_LONG_ROWS (``set_camera(long_rows=True)``): on images of few tiles the preprocess writes every pair's key into its
+    tile's row (16384 keys) once the workgroup histogram has given the rank; no pair scatter pass, lists of more than 1024 entries
+    sorted by the long-list kernels from their rows.  Same images, lists and gradients as the plain path, bit for bit -- on a scene
+    with long lists (small splats piled on the image centre), twice (workspaces reused)."""
+    from sings_amd.engine import SkinnedEngine, SkinnedFramesEngine
+    dev = _dev()
+    N, J, W, H = 100000, 52, 160, 288
+    s, ins, A, transl, one, stacked, dL = _avatar(N, J, W, H, 5, K, False, True)
+    cap = 32 * N
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+
+    def run(long_rows):
+        if K == 1:
+            e = SkinnedEngine(N, J, W, H, 16, dev, cap, with_rot=True, rot_width=6)
+            e.set_camera(one[0], long_rows=long_rows)
+            e.set_frame(ins["xyz"], ins["rot"], ins["w"], A[0], ins["smpl_scale"], transl[0])
+        else:
+            e = SkinnedFramesEngine(N, J, W, H, 16, K, dev, cap, with_rot=True, rot_width=6)
+            e.set_camera(stacked, long_rows=long_rows)
+            e.set_frames(ins["xyz"], ins["rot"], ins["w"], A, ins["smpl_scale"], transl)
+        outs = []
+        for rep in range(2):
+            R = e.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+            e.backward(ins["sh"], ins["op"], ins["sc"], dL[0] if K == 1 else dL)
+            torch.cuda.synchronize()
+            L = e.L
+            b0 = e.binning if K == 1 else e.binning.view(K, L.bin_bytes)[0]
+            rg = b0[L.bin_ranges:L.bin_ranges + 8 * T].view(torch.int32).view(-1, 2).clone()
+            pl = b0[L.bin_point_list:L.bin_point_list + 4 * int(rg[:, 1].max())].view(torch.int32).clone()
+            outs.append((R, e.color.clone(), e.grad_flat.clone(), e.d_A.clone(), e.d_transl.clone(), rg, pl))
+        return outs
+    plain, direct = run(False), run(True)
+    assert int((plain[0][5][:, 1] - plain[0][5][:, 0]).max()) > 1024, "the scene should hold a long list"
+    for a, b in zip(plain, direct):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:], b[1:]):
+            assert torch.equal(x, y)
+    assert float(plain[0][2].abs().max()) > 0
+
+
 def test_a_frame_that_overflows_its_workspace_is_background_with_zero_gradient_and_harms_no_other_frame():
     """The pair capacity lies between the smallest and the largest R of the batch: frames that fit render and differentiate as
     ever, frames that do not render the background, report their (too large) R, and contribute ZERO to the summed gradient --

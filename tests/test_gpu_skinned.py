@@ -163,6 +163,39 @@ def test_fused_backward(J, iso, seed):
     assert not hasattr(_RasterizeSkinnedGaussians, "last_viewspace_grad")      # the round-1 class attribute (last call wins) is gone
 
 
+def test_fused_op_learns_the_long_rows_hint_and_reports_a_violation():
+    """rasterize_skinned_gaussians in "sync" mode reads the count word's SG_COUNT_FLAG_HALF_LONG_ROWS bit; the next call of that
+    (device, P, W, H) -- in any overflow mode -- passes SG_FLAG_LONG_ROWS (direct binning of the few-tile frame) and returns the same
+    bits.  A violated hint: "sync" renders the frame again without it; "deferred" reports it from check_deferred_overflow()."""
+    from sings_amd import rasterizer as rz
+    from sings_amd.skinned import rasterize_skinned_gaussians
+    dev = torch.device("cuda:0")
+    s = _scene(5000, 24, 11, isotropic=False)
+    rs = _settings(s, dev)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    key = (dev.index, s["N"], 256, 224)
+    rz.reset_overflow_state(dev)
+
+    def frame(scale=1.0):
+        req = lambda a: torch.from_numpy(a).to(dev).requires_grad_(True)
+        xyz, Rc, sc, op, sh = req(s["xyz"] * np.float32(scale)), req(s["Rc"]), req(s["scales"]), req(s["opac"]), req(s["shs"])
+        color, radii = rasterize_skinned_gaussians(xyz, Rc, sc, op, sh, t(s["w"]), t(s["A"]), rs, smpl_scale=t(s["smpl_scale"]), transl=t(s["transl"]))
+        color.backward(t(s["dL"]))
+        return color.detach().clone(), [x.grad.clone() for x in (xyz, Rc, sc, op, sh)]
+    c0, g0 = frame()
+    assert rz._rows_ok.get(key) is True
+    c1, g1 = frame()                                            # hinted
+    assert torch.equal(c0, c1) and all(torch.equal(a, b) for a, b in zip(g0, g1))
+    rz.set_deferred_overflow_check(True, device=dev)
+    try:
+        c2, g2 = frame()                                        # hinted, no host read
+        assert rz.check_deferred_overflow(dev) is not None
+        assert torch.equal(c0, c2) and all(torch.equal(a, b) for a, b in zip(g0, g2))
+    finally:
+        rz.set_overflow_check("sync")
+    rz.reset_overflow_state(dev)
+
+
 def test_avatar_shaped_scene_with_long_lists_against_the_oracle():
     """The geometry of the reference's workload, scaled down so that the oracle finishes in seconds: one narrow body far from
     a long-focal-length camera (fx = 5000 at 512 x 896 -> 937.5 at 96 x 128, z ~ 10 m), J = 52, anisotropic Gaussians a few
