@@ -31,6 +31,27 @@ def _same_upstream(a, b):
             and a.dtype == b.dtype)
 
 
+_UNIT = {}                             # data_ptr -> weak reference to a 0-dim tensor its owner vouches holds 1.0 and never writes
+
+
+def register_unit_scalar(t):
+    """``t``: a 0-dim float tensor that holds 1.0 for as long as it lives (the seed a caller hands ``torch.autograd.grad`` for its
+    loss root: sings_amd.train_step).  A backward pass whose two upstream gradients ARE that tensor returns the gradient the forward
+    computed as it is -- no ``unit * 1.0`` launch (a broadcast multiplication of a 1080p image: 12 us on the step's main chain)."""
+    import weakref
+    _UNIT[t.data_ptr()] = weakref.ref(t)
+    return t
+
+
+def _is_unit(g):
+    r = _UNIT.get(g.data_ptr())
+    t = r() if r is not None else None
+    if t is None:
+        _UNIT.pop(g.data_ptr(), None)
+        return False
+    return t.data_ptr() == g.data_ptr() and g.dtype == t.dtype and g.storage_offset() == t.storage_offset()
+
+
 class _PhotoLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, raw, gt_rgb, mask, bg, l1_w, ssim_w, want_images):
@@ -76,7 +97,7 @@ class _PhotoLoss(torch.autograd.Function):
         dev = raw.device
         unit, ctx.unit_grad = ctx.unit_grad, None
         if unit is not None and _same_upstream(g_l1, g_ssim):
-            return unit * g_l1.reshape(()).float(), None, None, None, None, None, None
+            return (unit if _is_unit(g_l1) else unit * g_l1.reshape(()).float()), None, None, None, None, None, None
         if g_l1 is None or g_ssim is None:
             zero = torch.zeros((), dtype=torch.float32, device=dev)
             g_l1 = zero if g_l1 is None else g_l1
@@ -148,7 +169,7 @@ class _PhotoLossFrames(torch.autograd.Function):
         dev = raw.device
         unit, ctx.unit_grad = ctx.unit_grad, None
         if unit is not None and _same_upstream(g_l1, g_ssim):
-            return unit * g_l1.reshape(K, 1, 1, 1).float(), None, None, None, None, None
+            return (unit if _is_unit(g_l1) else unit * g_l1.reshape(K, 1, 1, 1).float()), None, None, None, None, None
         zero = torch.zeros(K, dtype=torch.float32, device=dev)
         up = torch.stack([zero if g_l1 is None else g_l1.reshape(K).float(), zero if g_ssim is None else g_ssim.reshape(K).float()], 1)
         up = up.contiguous()                                                   # [K,2]: a pair of weights per frame, device memory

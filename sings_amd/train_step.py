@@ -370,7 +370,8 @@ class AvatarStep(torch.nn.Module):
         attrs, use, inject, l2_grads = extras["staged"]
         one = getattr(self, "_one", None)
         if one is None or one.device != photo_root.device:
-            one = self._one = torch.ones((), dtype=photo_root.dtype, device=photo_root.device)     # (not a fill launch per root and step)
+            from .photo_loss import register_unit_scalar
+            one = self._one = register_unit_scalar(torch.ones((), dtype=photo_root.dtype, device=photo_root.device))     # (not a fill launch per root and step)
         dev = photo_root.device
         cur, side = torch.cuda.current_stream(dev), self._side
         names = [k for k, v in use.items() if torch.is_tensor(v) and v.requires_grad]
@@ -395,8 +396,11 @@ class AvatarStep(torch.nn.Module):
                     g[k] = gr
                 else:
                     both_a.append(g[k]); both_b.append(gr)
-            if both_a:
-                torch._foreach_add_(both_a, both_b)
+            # (not torch._foreach_add_: its 64 k-element chunks make ten workgroups of the two 150 k-row attributes -- 19 us alone on the
+            #  chip, 92 beside the k-NN query of the side stream; an add per tensor is 5 us.  The step itself did not get shorter
+            #  for it -- 1.867-1.875 ms either way, same box: its length is the work of BOTH queues, LAB 6.8)
+            for x, y in zip(both_a, both_b):
+                x.add_(y)
         # 3. the decoders' backward: appearance decoder first (its nodes are the youngest), then the _Inject node waits for the side stream
         roots = [(attrs[k], g[k]) for k in names if g.get(k) is not None]
         torch.autograd.backward([r for r, _ in roots], [x for _, x in roots])

@@ -20,4 +20,5 @@ print(f"# nothing running: {sum(g for g, _ in gaps):.1f} us in {len(gaps)} gaps;
 print("# start_us duration_us queue kernel")
 for r in seg:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    print(f"{(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f}  q{r.get('Queue_Id', '?')} {r['Kernel_Name'].split('(')[0][:70]}")
+    name = r['Kernel_Name'] if len(sys.argv) > 2 and sys.argv[2] == "--full" else r['Kernel_Name'].split('(')[0][:70]
+    print(f"{(s - t0) / 1e3:8.1f} {(e - s) / 1e3:7.1f}  q{r.get('Queue_Id', '?')} {name[:400]}")
