@@ -16,6 +16,7 @@
 import numpy as np
 import torch
 
+from . import _lib
 from .body import SMPL_PARENTS, rodrigues
 from .renderer import _settings, get_render_pkg_fused
 
@@ -117,6 +118,10 @@ class FrameAnimator:
         self.n = max(1, int(streams))
         self.streams = [torch.cuda.Stream(self.dev) for _ in range(self.n)]
         self.engs, self.shape, self.cap = [], None, 0
+        # SG_FLAG_LONG_ROWS (direct binning of few-tile frames: no tile list beyond 16384 entries), passed optimistically: every path
+        # below reads the frames' counts before it hands an image out, and a frame that reports NUM_RENDERED_LONG_LIST is rendered
+        # again without the hint -- which then stays off
+        self.long_rows = True
 
     def _engines(self, J, W, H, cap):
         from .engine import SkinnedEngine
@@ -146,14 +151,18 @@ class FrameAnimator:
             for (cam, A, transl, smpl_scale, ext), e, st in zip(jobs, engs, self.streams):
                 with torch.cuda.stream(st):
                     e.color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)    # handed to the caller
-                    e.set_camera(_settings(cam, bg_color, scaling_modifier, c['active_sh_degree']))
+                    e.set_camera(_settings(cam, bg_color, scaling_modifier, c['active_sh_degree']), long_rows=self.long_rows)
                     e.set_frame(c['xyz_canon'], c.get('rotmat_canon'), c['lbs_weights'], A, smpl_scale, transl, ext)
                     e.forward(c['shs'], c['opacity'], c['scales'])
                     outs.append(torch.clamp(e.color, 0.0, 1.0))
                     outs[-1].record_stream(cur)
             for st in self.streams[:len(jobs)]:
                 cur.wait_stream(st)
-            need = max(e.num_rendered() for e in engs[:len(jobs)])
+            counts = [e.num_rendered() for e in engs[:len(jobs)]]
+            if self.long_rows and min(counts) == _lib.NUM_RENDERED_LONG_LIST:
+                self.long_rows = False                           # a list outgrew its row: these frames again, on the plain path
+                continue
+            need = max(counts)
             if need <= self.cap:
                 return outs
             cap = need + need // 4 + 1024
@@ -169,7 +178,7 @@ class FrameAnimator:
         depth = 2 * self.n if depth is None else max(1, int(depth))
         cur = torch.cuda.current_stream(self.dev)
         P = int(c['xyz_canon'].shape[0])
-        slots = [torch.empty(1, dtype=torch.int32).pin_memory() for _ in range(depth + self.n + 1)]
+        slots = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(depth + self.n + 1)]
         q = deque()
 
         def submit(i, job):
@@ -183,12 +192,12 @@ class FrameAnimator:
             st.wait_stream(cur)                                  # the job's tensors were produced on the caller's stream
             with torch.cuda.stream(st):
                 e.color = torch.empty((3, H, W), dtype=torch.float32, device=self.dev)
-                e.set_camera(_settings(cam, bg_color, scaling_modifier, c['active_sh_degree']))
+                e.set_camera(_settings(cam, bg_color, scaling_modifier, c['active_sh_degree']), long_rows=self.long_rows)
                 e.set_frame(c['xyz_canon'], c.get('rotmat_canon'), c['lbs_weights'], A, smpl_scale, transl, ext)
                 e.forward(c['shs'], c['opacity'], c['scales'])
                 img = torch.clamp(e.color, 0.0, 1.0)
                 slot = slots[i % len(slots)]
-                slot.copy_(e.binning[:4].view(torch.int32), non_blocking=True)      # header word 0 = pair count R
+                slot.copy_(e.binning[:8].view(torch.int32), non_blocking=True)      # header words 0, 1 = pair count R, flags
                 ev = torch.cuda.Event()
                 ev.record(st)
             img.record_stream(cur)
@@ -199,10 +208,13 @@ class FrameAnimator:
             ev.synchronize()
             # compared with the capacity of the engine that rendered it: an earlier pop may have grown self.cap while this
             # frame was still queued, and a count between the two capacities means a background-only image
-            if int(slot[0]) > cap_used:                          # rare: grow the workspaces, render this frame again
+            if int(slot[0]) > cap_used or (int(slot[1]) & 2):    # rare: grow the workspaces / drop the hint, render this frame again
                 torch.cuda.synchronize(self.dev)
-                need = int(slot[0])
-                self._engines(self.shape[1], self.shape[2], self.shape[3], need + need // 4 + 1024)
+                if int(slot[1]) & 2:
+                    self.long_rows = False
+                if int(slot[0]) > cap_used:
+                    need = int(slot[0])
+                    self._engines(self.shape[1], self.shape[2], self.shape[3], need + need // 4 + 1024)
                 img = self.render_round([job], bg_color, scaling_modifier)[0]
                 torch.cuda.synchronize(self.dev)
             return i, img
@@ -259,7 +271,7 @@ class FrameAnimator:
                     rs = rs._replace(viewmatrix=torch.stack([cm['world_view_transform'] for cm in pad]).contiguous(),
                                      projmatrix=torch.stack([cm['full_proj_transform'] for cm in pad]).contiguous(),
                                      campos=torch.stack([cm['camera_center'] for cm in pad]).contiguous())
-                e.set_camera(rs)
+                e.set_camera(rs, long_rows=self.long_rows)
                 e.set_frames(c['xyz_canon'], c.get('rotmat_canon'), c['lbs_weights'], A, batch[0][3], tr)
                 e.forward(c['shs'], c['opacity'], c['scales'])
                 img = torch.clamp(e.color, 0.0, 1.0)             # [K,3,H,W]: a new tensor, the engine's image buffer is reused
@@ -288,13 +300,23 @@ class FrameAnimator:
             ev.synchronize()
             with torch.cuda.stream(st):
                 Rs = e.num_rendered()                            # (this engine has nothing else queued: one launch per engine)
-            if max(Rs[:len(batch)]) > e.cap:                     # rare: grow the workspaces, render this batch again
+            long_list = self.long_rows and min(Rs[:len(batch)]) == _lib.NUM_RENDERED_LONG_LIST
+            if max(Rs[:len(batch)]) > e.cap or long_list:        # rare: grow the workspaces / drop the hint, render this batch again
                 torch.cuda.synchronize(self.dev)
-                need = max(Rs[:len(batch)])
+                if long_list:
+                    self.long_rows = False
+                # (a NEW set of engines either way: the queued batches keep theirs, whose counts are still to be read)
+                need = max(max(Rs[:len(batch)]), self._fcap - self._fcap // 5)
                 J, W, H = self._fshape[1], self._fshape[2], self._fshape[3]
                 e2 = self._frame_engines(J, W, H, K, need + need // 4 + 1024)[0]
                 img, ev = launch(i0, batch, e2, self.streams[0])
                 torch.cuda.synchronize(self.dev)
+                Rs2 = e2.num_rendered()
+                if max(Rs2[:len(batch)]) > e2.cap:               # (both at once: the plain path has now counted the batch)
+                    need = max(Rs2[:len(batch)])
+                    e2 = self._frame_engines(J, W, H, K, need + need // 4 + 1024)[0]
+                    img, ev = launch(i0, batch, e2, self.streams[0])
+                    torch.cuda.synchronize(self.dev)
             for k in range(len(batch)):
                 yield i0 + k, img[k]
 

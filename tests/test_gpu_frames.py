@@ -136,6 +136,30 @@ def test_direct_binning_of_few_tile_frames_leaves_the_bits_of_the_scatter_path(K
         for x, y in zip(a[1:], b[1:]):
             assert torch.equal(x, y)
     assert float(plain[0][2].abs().max()) > 0
+    if K == 1:
+        # a list that outgrows its row (every splat on the image centre): refused on the device, as the hint promises
+        from sings_amd import _lib
+        e = SkinnedEngine(N, J, W, H, 16, dev, cap)
+        tiny = ins["xyz"] * 0.02
+        e.set_camera(one[0]); e.set_frame(tiny, None, ins["w"], A[0], ins["smpl_scale"], transl[0])
+        R = e.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True)
+        rg = e.binning[e.L.bin_ranges:e.L.bin_ranges + 8 * T].view(torch.int32).view(-1, 2)
+        assert R > 0 and int((rg[:, 1] - rg[:, 0]).max()) > 16384
+        c_plain = e.color.clone()
+        e.set_camera(one[0], long_rows=True)
+        assert e.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True) == _lib.NUM_RENDERED_LONG_LIST
+        assert torch.equal(e.color, torch.from_numpy(s["bg"]).to(dev)[:, None, None].expand_as(e.color))
+        e.set_camera(one[0])
+        assert e.forward(ins["sh"], ins["op"], ins["sc"], sync_num_rendered=True) == R and torch.equal(e.color, c_plain)
+        # ... and the frame animator, which passes the hint optimistically, falls back to the plain path for good
+        from sings_amd.posed import FrameAnimator
+        canon = dict(xyz_canon=tiny, rotmat_canon=None, scales=ins["sc"], opacity=ins["op"], shs=ins["sh"], lbs_weights=ins["w"],
+                     active_sh_degree=0)
+        fa = FrameAnimator(canon, streams=2)
+        cam = s["cam"]
+        camd = {k_: (torch.from_numpy(np.ascontiguousarray(v)).to(dev) if isinstance(v, np.ndarray) else v) for k_, v in cam.items()}
+        img = fa.render_round([(camd, A[0].reshape(J, 4, 4), transl[0], ins["smpl_scale"], None)], torch.from_numpy(s["bg"]).to(dev))[0]
+        assert fa.long_rows is False and torch.equal(img, torch.clamp(c_plain, 0.0, 1.0))
 
 
 def test_a_frame_that_overflows_its_workspace_is_background_with_zero_gradient_and_harms_no_other_frame():
