@@ -13,13 +13,14 @@ from .rasterizer import _settings_struct, _ptr
 
 
 def forward_with_state(rs, means3D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
-                       cov3D_precomp=None, capacity=None):
+                       cov3D_precomp=None, capacity=None, flags=0):
     lib = _lib.load()
     dev = means3D.device
     P = int(means3D.shape[0]); H, W = int(rs.image_height), int(rs.image_width)
     M = int(shs.shape[1]) if shs is not None else 0
     keep = []
     s = _settings_struct(rs, dev, M, keep)
+    s.flags = int(flags)                                          # SG_FLAG_* promises of the caller (tests: direct binning)
     gx, gy = (W + 15) // 16, (H + 15) // 16
     T = gx * gy
     cap = capacity or max(8 * P + T, 1 << 16)
@@ -41,6 +42,8 @@ def forward_with_state(rs, means3D, opacities, shs=None, colors_precomp=None, sc
                 _ptr(rotations), _ptr(cov3D_precomp), _ptr(geom), _ptr(binning), cap, _ptr(img), _ptr(color),
                 _ptr(radii), 1, C.byref(nr), stream), "forward")
             R = int(nr.value)
+            if R < 0:                                            # NUM_RENDERED_LONG_LIST: a promise of `flags` did not hold
+                return dict(color=color, radii=radii, R=R, capacity=cap, layout=L)
             if R <= cap:
                 break
             cap = R + 1024

@@ -2,7 +2,9 @@
 round 3 ran the sweeps by hand and committed their logs -- the driver never saw them.  The crafted tile lists sit exactly on the
 internal boundaries of the path (128 = rank sort, 256 = depth segment / forward batch, 1024 = in-kernel sort, 4096, 12 288 = keys
 the bucket sort keeps resident in LDS, beyond: group slots + sg_group_sort_kernel); the random cases draw image size, Gaussian
-count, SH degree, opacity and splat scale; every case checks bit-exact binning, RGB off borderline pixels and EVERY gradient element."""
+count, SH degree, opacity and splat scale; every case checks bit-exact binning, RGB off borderline pixels and EVERY gradient element --
+and then renders once more with the direct-binning promise of its regime (SG_FLAG_SHORT_LISTS / SG_FLAG_LONG_ROWS): the same lists,
+keys and image bit for bit where the promise holds, a refusal where it does not (crafted 20 000 > a 16 384-key row)."""
 import numpy as np
 import pytest
 

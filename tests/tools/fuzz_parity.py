@@ -51,6 +51,21 @@ def check(s, tag):
         bad = np.abs(a - b) > 1e-3 * np.abs(b) + 6e-6 * scale
         assert not bad.any(), (tag, name, int(bad.sum()), np.abs(a - b).max(), scale)
     tl = o["ranges"][:, 1].astype(int) - o["ranges"][:, 0]
+    # direct binning (include/sings_hip.h: SG_FLAG_SHORT_LISTS on images of many tiles, SG_FLAG_LONG_ROWS on few): the same lists, ranges,
+    # keys and image bit for bit whenever the promise holds, a refusal (background, NUM_RENDERED_LONG_LIST) when it does not
+    from sings_amd import _lib
+    gx, gy = (s["W"] + 15) // 16, (s["H"] + 15) // 16
+    few = ((gx + 3) // 4) * ((gy + 3) // 4) * 16 <= 4096
+    flags = (_lib.FLAG_LONG_ROWS if few else _lib.FLAG_SHORT_LISTS)
+    holds = int(tl.max()) <= (16384 if few else 1024)
+    sd = forward_with_state(rs, t(s["means3D"]), t(s["opacities"]), shs=t(s["shs"]), scales=t(s["scales"]), rotations=t(s["rotations"]), flags=flags)
+    if holds:
+        assert sd["R"] == st["R"], (tag, "direct R", sd["R"], st["R"])
+        for name in ("ranges", "point_list", "point_keys", "color", "final_T", "n_contrib"):
+            assert torch.equal(sd[name], st[name]), (tag, "direct binning", name)
+    else:
+        assert sd["R"] == _lib.NUM_RENDERED_LONG_LIST, (tag, "direct binning should have refused", sd["R"])
+        assert torch.equal(sd["color"], t(s["bg"])[:, None, None].expand_as(sd["color"])), (tag, "refused frame is not the background")
     return int(o["R"]), int(tl.max())
 
 
