@@ -165,6 +165,7 @@ def _drain_async(dev, wait_all=False):
         return None
     worst, worst_cap, Rmax = None, None, None
     keep = []
+    long_list = False
     for k, (host, ev, cap) in enumerate(lst):
         if not wait_all and k == len(lst) - 1 and not ev.query():
             keep.append(lst[k])                        # the newest one may still be in flight: leave it for the next call
@@ -172,11 +173,18 @@ def _drain_async(dev, wait_all=False):
         ev.synchronize()
         R = int(host[0]) & 0xffffffff
         Rmax = R if Rmax is None else max(Rmax, R)
+        long_list = long_list or bool(int(host[1]) & 2)
         if R > cap and (worst is None or R > worst):
             worst, worst_cap = R, cap
     _pending[dev.index] = keep
     if Rmax is not None:
         _grow(dev.index, Rmax)
+    if long_list:                                      # a learned list-length hint did not hold for an earlier (fused LBS) forward
+        for tbl in (_short_ok, _rows_ok):
+            for k in [k for k in tbl if k[0] == dev.index]:
+                del tbl[k]
+        _report(f"sings_amd: an earlier forward on {dev} met a tile list longer than the row its learned hint promised: that frame "
+                f"rendered the background and received zero gradients; the hints of the device are dropped")
     if worst is not None:
         _report(f"sings_amd: an earlier forward on {dev} produced {worst} (tile, Gaussian) pairs for a capacity of {worst_cap}: "
                 f"that frame rendered the background and received zero gradients; the capacity is now "
